@@ -1,0 +1,79 @@
+// Wave64 cross-lane primitives for gfx950 (CDNA4).  DPP-only reductions: no LDS traffic,
+// no ds_bpermute.  A CDNA wavefront is 64 lanes = 4 DPP rows of 16.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace hgmm {
+
+// DPP control words (GFX9/CDNA encoding)
+constexpr int DPP_QUAD_XOR1 = 0xB1;       // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;       // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_MIRROR = 0x140;
+constexpr int DPP_ROW_BCAST15 = 0x142;    // lane 15 of each row -> next row
+constexpr int DPP_ROW_BCAST31 = 0x143;    // lane 31 -> rows 2,3
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL,
+                                                      ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+}
+
+struct OpMax { __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); } };
+struct OpSum { __device__ __forceinline__ float operator()(float a, float b) const { return a + b; } };
+struct OpMinI { __device__ __forceinline__ int operator()(int a, int b) const { return a < b ? a : b; } };
+
+// Reduce over the 64 lanes; result is wave-uniform (returned through an SGPR read of lane 63).
+template <class Op>
+__device__ __forceinline__ float wave_reduce(float v, Op op) {
+    v = op(v, dpp_f32<DPP_QUAD_XOR1>(v));
+    v = op(v, dpp_f32<DPP_QUAD_XOR2>(v));
+    v = op(v, dpp_f32<DPP_ROW_HALF_MIRROR>(v));
+    v = op(v, dpp_f32<DPP_ROW_MIRROR>(v));              // every lane: its row's (16) result
+    v = op(v, dpp_f32<DPP_ROW_BCAST15, 0xA>(v));        // rows 1,3 += rows 0,2
+    v = op(v, dpp_f32<DPP_ROW_BCAST31, 0xC>(v));        // rows 2,3 += row 1 (which holds 0+1)
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+template <class Op>
+__device__ __forceinline__ int wave_reduce_i(int v, Op op) {
+    v = op(v, dpp_i32<DPP_QUAD_XOR1>(v));
+    v = op(v, dpp_i32<DPP_QUAD_XOR2>(v));
+    v = op(v, dpp_i32<DPP_ROW_HALF_MIRROR>(v));
+    v = op(v, dpp_i32<DPP_ROW_MIRROR>(v));
+    v = op(v, dpp_i32<DPP_ROW_BCAST15, 0xA>(v));
+    v = op(v, dpp_i32<DPP_ROW_BCAST31, 0xC>(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// double-precision sum over the wave (two 32-bit DPP moves per step)
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double dpp_f64(double v) {
+    long long b = __double_as_longlong(v);
+    int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_f64<DPP_QUAD_XOR1>(v);
+    v += dpp_f64<DPP_QUAD_XOR2>(v);
+    v += dpp_f64<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_f64<DPP_ROW_MIRROR>(v);
+    v += dpp_f64<DPP_ROW_BCAST15, 0xA>(v);
+    v += dpp_f64<DPP_ROW_BCAST31, 0xC>(v);
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), 63);
+    int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int wave_in_block() {
+    return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+}
+
+}  // namespace hgmm
