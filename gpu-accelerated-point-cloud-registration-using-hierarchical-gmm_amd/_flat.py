@@ -1,0 +1,84 @@
+"""Host side of the flat GMM EM path, shared by the two reference flavours.
+
+``gmm_waymo/gmm_impl.py`` (variant "W": diag + spherical) and ``gmmreg_gpu/gmm_impl.py``
+(variant "G": diag only) are thin, signature-compatible shells over these functions.
+All arithmetic on points happens in the HIP kernels (csrc/flat_kernels.hip) through the
+C ABI; this module only marshals small parameter arrays.
+"""
+from __future__ import annotations
+
+import contextlib
+import time
+
+import numpy as np
+
+from ._native import Context, DeviceArray, default_context
+
+
+class DevicePoints:
+    """A point cloud resident in HBM on one context (what ``cupy.asarray(X)`` was to the
+    reference, gmm_waymo/src/gmm.py:73).  Pass it wherever the API takes ``X``."""
+
+    def __init__(self, X, ctx: Context | None = None):
+        self.ctx = ctx or default_context()
+        X = np.asarray(X)
+        self.shape = X.shape
+        self.dtype = np.dtype(np.float32)
+        self.ctx.set_points(X)
+        self.ctx._points_owner = self
+
+    def __len__(self):
+        return self.shape[0]
+
+
+def asarray(X, ctx: Context | None = None):
+    return X if isinstance(X, DevicePoints) else DevicePoints(X, ctx)
+
+
+def _ctx_for(X) -> Context:
+    """Returns the context holding X, uploading host arrays first."""
+    if isinstance(X, DevicePoints):
+        if getattr(X.ctx, "_points_owner", None) is not X:
+            raise RuntimeError("this DevicePoints was superseded by a later upload on its context")
+        return X.ctx
+    return DevicePoints(X).ctx
+
+
+def _host(a):
+    return np.asarray(a.get() if isinstance(a, DeviceArray) else a)
+
+
+@contextlib.contextmanager
+def timer(message):
+    """gmm_impl.timer: synchronise, time, print (gmm_waymo/src/gmm_impl.py:43-50)."""
+    ctx = default_context()
+    ctx.synchronize()
+    start = time.time()
+    yield
+    ctx.synchronize()
+    print('%s:  %f sec' % (message, time.time() - start))
+
+
+def e_step(X, inv_cov, means, weights, cov_type, variant):
+    ctx = _ctx_for(X)
+    mean_lpn, log_resp, _, _ = ctx.flat_estep(_host(inv_cov), _host(means), _host(weights), cov_type, variant)
+    return np.float32(mean_lpn), log_resp
+
+
+def m_step(X, resp, cov_type, variant, centre_hint=None):
+    ctx = _ctx_for(X)
+    return ctx.flat_mstep(resp, cov_type, variant, centre_hint)
+
+
+def train_gmm(X, max_iter, tol, means, covariances, weights, cov_type, variant):
+    ctx = _ctx_for(X)
+    inv, mu, w, cov, lls, converged = ctx.flat_train(max_iter, tol, _host(means), _host(covariances),
+                                                     _host(weights), cov_type, variant)
+    if not converged:
+        print('Failed to converge. Increase max-iter or tol.')
+    return inv, mu, w, cov, [np.float32(v) for v in lls]
+
+
+def predict(X, inv_cov, means, weights, cov_type, variant):
+    ctx = _ctx_for(X)
+    return ctx.flat_predict(_host(inv_cov), _host(means), _host(weights), cov_type, variant).get().astype(np.int64)

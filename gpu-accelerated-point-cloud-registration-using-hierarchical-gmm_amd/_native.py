@@ -1,0 +1,442 @@
+"""ctypes binding of libhgmm_hip.so (the C ABI declared in include/hgmm.h).
+
+There is NO CPU fallback anywhere in this package: if the HIP library is missing or no
+gfx950 device is visible, loading / context creation raises ``HgmmError`` loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhgmm_hip.so")
+
+COV_TYPES = {"diag": 0, "spherical": 1}
+VARIANTS = {"W": 0, "G": 1}
+KERNEL_IDS = {"flat_estep": 0, "flat_fused": 1, "flat_mstep": 2, "tree_estep": 3,
+              "tree_loglik": 4, "tree_reg": 5}
+
+
+class HgmmError(RuntimeError):
+    pass
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+
+
+def _sig(lib, name, argtypes, restype=C.c_int):
+    fn = getattr(lib, name)
+    fn.argtypes = argtypes
+    fn.restype = restype
+    return fn
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen the HIP library and declare every entry point of include/hgmm.h."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(path):
+            raise HgmmError(
+                "HIP extension %s is missing; build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or python <package>/build.py). There is no CPU fallback." % path)
+        lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        ctx = _vp
+        _sig(lib, "hgmm_version", [])
+        _sig(lib, "hgmm_device_count", [C.POINTER(C.c_int)])
+        _sig(lib, "hgmm_create", [C.c_int, C.POINTER(_vp)])
+        _sig(lib, "hgmm_destroy", [ctx])
+        _sig(lib, "hgmm_last_error", [ctx], C.c_char_p)
+        _sig(lib, "hgmm_device_info", [ctx, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)])
+        _sig(lib, "hgmm_synchronize", [ctx])
+        _sig(lib, "hgmm_alloc", [ctx, C.c_size_t, C.POINTER(_vp)])
+        _sig(lib, "hgmm_free", [ctx, _vp])
+        _sig(lib, "hgmm_h2d", [ctx, _vp, _vp, C.c_size_t])
+        _sig(lib, "hgmm_d2h", [ctx, _vp, _vp, C.c_size_t])
+        _sig(lib, "hgmm_set_points_f32", [ctx, _vp, C.c_int64])
+        _sig(lib, "hgmm_set_points_f64", [ctx, _vp, C.c_int64])
+        _sig(lib, "hgmm_num_points", [ctx], C.c_int64)
+        _sig(lib, "hgmm_flat_estep", [ctx, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _f64p])
+        _sig(lib, "hgmm_flat_predict", [ctx, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp])
+        _sig(lib, "hgmm_flat_mstep", [ctx, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp])
+        _sig(lib, "hgmm_flat_train", [ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp,
+                                      _vp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)])
+        _sig(lib, "hgmm_flat_train_begin", [ctx, C.c_int, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp, C.c_int])
+        _sig(lib, "hgmm_flat_train_step", [ctx, C.c_int])
+        _sig(lib, "hgmm_flat_train_end", [ctx, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)])
+        _sig(lib, "hgmm_flat_stats", [ctx, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _f64p, _f64p])
+        _sig(lib, "hgmm_tree_build", [ctx, C.c_int, C.c_double, C.c_double, _vp, C.c_double, C.c_int,
+                                      _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.POINTER(C.c_int)])
+        _sig(lib, "hgmm_tree_set_nodes", [ctx, C.c_int, _vp, _vp, _vp])
+        _sig(lib, "hgmm_tree_set_target", [ctx, _vp, C.c_int64])
+        _sig(lib, "hgmm_tree_reg_estep", [ctx, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp])
+        _sig(lib, "hgmm_tree_node_complexity", [ctx, _vp])
+        _sig(lib, "hgmm_comm_unique_id", [_vp])
+        _sig(lib, "hgmm_comm_init_rank", [ctx, C.c_int, C.c_int, _vp])
+        _sig(lib, "hgmm_comm_destroy", [ctx])
+        _sig(lib, "hgmm_comm_allreduce_f64", [ctx, _vp, C.c_int, C.c_int])
+        _sig(lib, "hgmm_profile_enable", [ctx, C.c_int])
+        _sig(lib, "hgmm_profile_reset", [ctx])
+        _sig(lib, "hgmm_profile_get", [ctx, C.c_int, _f64p, C.POINTER(C.c_int64)])
+        _lib = lib
+        return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError("expected shape %s, got %s" % (shape, a.shape))
+    return a
+
+
+class DeviceArray:
+    """A dense array living in HBM (what a CuPy ndarray was to the reference).
+
+    ``np.asarray(d)`` / ``d.get()`` copy it to the host.  ``d.exp()`` is a lazy view used by
+    ``m_step(X, log_resp.exp())`` so the exponential is fused into the moment kernel."""
+
+    def __init__(self, ctx, shape, dtype, is_log=False, _base=None):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.is_log = is_log
+        self._base = _base
+        if _base is None:
+            self.ptr = ctx._alloc(self.nbytes)
+            self._owner = True
+        else:
+            self.ptr = _base.ptr
+            self._owner = False
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape)) if self.shape else 1
+
+    @property
+    def nbytes(self):
+        return self.size * self.dtype.itemsize
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def get(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        self.ctx._d2h(out, self.ptr)
+        if self._base is not None and self.is_log and not self._base.is_log:
+            np.exp(out, out=out)
+        return out
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.get()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def exp(self):
+        """Lazy exp view (keeps log values in HBM; consumers fuse the exponential)."""
+        return DeviceArray(self.ctx, self.shape, self.dtype, is_log=True, _base=self)
+
+    def argmax(self, axis=None):
+        return self.get().argmax(axis=axis)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def free(self):
+        if self._owner and self.ptr:
+            self.ctx._free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One engine context = one GPU (one rank).  Thin, explicit wrapper over the C ABI."""
+
+    def __init__(self, device_id: int = 0):
+        self.lib = load_library()
+        h = _vp()
+        rc = self.lib.hgmm_create(int(device_id), C.byref(h))
+        if rc != 0:
+            msg = self.lib.hgmm_last_error(None)
+            raise HgmmError("hgmm_create(device=%d) failed (%d): %s -- this package has no CPU fallback"
+                            % (device_id, rc, msg.decode() if msg else "?"))
+        self.h = h
+        self.device_id = device_id
+        self._points_key = None
+        self.nranks, self.rank = 1, 0
+
+    # -- plumbing ---------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.lib.hgmm_last_error(self.h)
+            raise HgmmError("hgmm call failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hgmm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _alloc(self, nbytes):
+        p = _vp()
+        self._check(self.lib.hgmm_alloc(self.h, int(max(nbytes, 4)), C.byref(p)))
+        return p
+
+    def _free(self, p):
+        if getattr(self, "h", None):
+            self.lib.hgmm_free(self.h, p)
+
+    def _d2h(self, host, dev_ptr):
+        self._check(self.lib.hgmm_d2h(self.h, _ptr(host), dev_ptr, host.nbytes))
+
+    def synchronize(self):
+        self._check(self.lib.hgmm_synchronize(self.h))
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus = C.c_int()
+        mem = C.c_int64()
+        self._check(self.lib.hgmm_device_info(self.h, name, 256, C.byref(cus), C.byref(mem)))
+        return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": mem.value}
+
+    def empty(self, shape, dtype=np.float32):
+        return DeviceArray(self, shape, dtype)
+
+    def to_device(self, a):
+        a = np.ascontiguousarray(a)
+        d = DeviceArray(self, a.shape, a.dtype)
+        self._check(self.lib.hgmm_h2d(self.h, d.ptr, _ptr(a), a.nbytes))
+        return d
+
+    # -- points -----------------------------------------------------------------------
+    def set_points(self, X):
+        """Upload the point cloud [N,3]; float64 input keeps full precision for the HGMM path
+        (the reference's CPU twin works on Open3D float64 points), the flat EM path uses the
+        float32 cast the reference applies (gmm_waymo/src/gmm.py:73)."""
+        X = np.asarray(X)
+        if X.ndim != 2 or X.shape[1] != 3:
+            raise ValueError("points must have shape [N,3], got %s" % (X.shape,))
+        if X.dtype == np.float64:
+            Xc = np.ascontiguousarray(X)
+            self._check(self.lib.hgmm_set_points_f64(self.h, _ptr(Xc), Xc.shape[0]))
+        else:
+            Xc = np.ascontiguousarray(X, dtype=np.float32)
+            self._check(self.lib.hgmm_set_points_f32(self.h, _ptr(Xc), Xc.shape[0]))
+        self.n = Xc.shape[0]
+        return self
+
+    @property
+    def num_points(self):
+        return int(self.lib.hgmm_num_points(self.h))
+
+    # -- flat EM ----------------------------------------------------------------------
+    @staticmethod
+    def _flat_args(mu, inv_or_cov, w, cov_type):
+        mu = _f32(mu)
+        J = mu.shape[0]
+        if mu.shape != (J, 3):
+            raise ValueError("means must be [J,3]")
+        ic = _f32(inv_or_cov, (J, 3) if cov_type == "diag" else (J,))
+        w = _f32(w, (J,))
+        return J, mu, ic, w
+
+    def flat_estep(self, inv_std, mu, w, cov_type="diag", variant="W", want_log_resp=True,
+                   want_lpn=False, want_argmax=False, out=None):
+        """``out``: optional pre-allocated DeviceArray [N,J] float32 to write log_resp into."""
+        J, mu, inv_std, w = self._flat_args(mu, inv_std, w, cov_type)
+        n = self.num_points
+        if out is not None and (out.shape != (n, J) or out.dtype != np.float32):
+            raise ValueError("out must be a float32 DeviceArray of shape %s" % ((n, J),))
+        lr = out if out is not None else (self.empty((n, J), np.float32) if want_log_resp else None)
+        lpn = self.empty((n,), np.float32) if want_lpn else None
+        am = self.empty((n,), np.int32) if want_argmax else None
+        mean = C.c_double()
+        self._check(self.lib.hgmm_flat_estep(
+            self.h, COV_TYPES[cov_type], VARIANTS[variant], J, _ptr(mu), _ptr(inv_std), _ptr(w),
+            None if lr is None else lr.ptr, None if lpn is None else lpn.ptr, None if am is None else am.ptr, C.byref(mean)))
+        return mean.value, lr, lpn, am
+
+    def flat_predict(self, inv_std, mu, w, cov_type="diag", variant="W"):
+        J, mu, inv_std, w = self._flat_args(mu, inv_std, w, cov_type)
+        lab = self.empty((self.num_points,), np.int32)
+        self._check(self.lib.hgmm_flat_predict(self.h, COV_TYPES[cov_type], VARIANTS[variant], J,
+                                               _ptr(mu), _ptr(inv_std), _ptr(w), lab.ptr))
+        return lab
+
+    def flat_mstep(self, resp, cov_type="diag", variant="W", centre_hint=None):
+        if not isinstance(resp, DeviceArray):
+            resp = self.to_device(np.ascontiguousarray(resp, dtype=np.float32))
+        n, J = resp.shape
+        if n != self.num_points:
+            raise ValueError("resp has %d rows, context holds %d points" % (n, self.num_points))
+        hint = None if centre_hint is None else _f32(centre_hint, (J, 3))
+        w = np.empty(J, np.float32)
+        mu = np.empty((J, 3), np.float32)
+        cov = np.empty((J, 3) if cov_type == "diag" else (J,), np.float32)
+        self._check(self.lib.hgmm_flat_mstep(self.h, COV_TYPES[cov_type], VARIANTS[variant], J, resp.ptr,
+                                             1 if resp.is_log else 0, _ptr(hint), _ptr(w), _ptr(mu), _ptr(cov)))
+        return w, mu, cov
+
+    def flat_train(self, max_iter, tol, mu, cov, w, cov_type="diag", variant="W"):
+        J, mu, cov, w = self._flat_args(mu, cov, w, cov_type)
+        mu, cov, w = mu.copy(), cov.copy(), w.copy()
+        inv = np.empty_like(cov)
+        lls = np.zeros(max(int(max_iter), 1), np.float32)
+        n_it, conv = C.c_int(), C.c_int()
+        self._check(self.lib.hgmm_flat_train(self.h, COV_TYPES[cov_type], VARIANTS[variant], J, int(max_iter),
+                                             float(tol), _ptr(mu), _ptr(cov), _ptr(w), _ptr(inv), _ptr(lls),
+                                             C.byref(n_it), C.byref(conv)))
+        return inv, mu, w, cov, lls[:n_it.value].copy(), bool(conv.value)
+
+    def flat_train_begin(self, tol, mu, cov, w, cov_type="diag", variant="W", lls_capacity=1024):
+        J, mu, cov, w = self._flat_args(mu, cov, w, cov_type)
+        self._train_shape = (J, cov_type, lls_capacity)
+        self._check(self.lib.hgmm_flat_train_begin(self.h, COV_TYPES[cov_type], VARIANTS[variant], J,
+                                                   float(tol), _ptr(mu), _ptr(cov), _ptr(w), int(lls_capacity)))
+
+    def flat_train_step(self, iters=1):
+        self._check(self.lib.hgmm_flat_train_step(self.h, int(iters)))
+
+    def flat_train_end(self):
+        J, cov_type, cap = self._train_shape
+        mu = np.empty((J, 3), np.float32)
+        cov = np.empty((J, 3) if cov_type == "diag" else (J,), np.float32)
+        inv = np.empty_like(cov)
+        w = np.empty(J, np.float32)
+        lls = np.zeros(cap, np.float32)
+        n_it, conv = C.c_int(), C.c_int()
+        self._check(self.lib.hgmm_flat_train_end(self.h, _ptr(mu), _ptr(cov), _ptr(w), _ptr(inv), _ptr(lls),
+                                                 C.byref(n_it), C.byref(conv)))
+        return inv, mu, w, cov, lls[:min(n_it.value, cap)].copy(), bool(conv.value), n_it.value
+
+    def flat_stats(self, inv_std, mu, w, cov_type="diag", variant="W"):
+        J, mu, inv_std, w = self._flat_args(mu, inv_std, w, cov_type)
+        stats = np.empty((J, 7), np.float64)
+        s, n = C.c_double(), C.c_double()
+        self._check(self.lib.hgmm_flat_stats(self.h, COV_TYPES[cov_type], VARIANTS[variant], J, _ptr(mu),
+                                             _ptr(inv_std), _ptr(w), _ptr(stats), C.byref(s), C.byref(n)))
+        return stats, s.value, n.value
+
+    # -- HGMM ---------------------------------------------------------------------------
+    def tree_build(self, L, ls, ld, init_mu, sig2, max_iters_per_level=1000, q_capacity=None):
+        T = 8 * (8 ** L - 1) // 7
+        init_mu = np.ascontiguousarray(init_mu, dtype=np.float64)
+        if init_mu.shape != (T, 3):
+            raise ValueError("init_mu must be [%d,3]" % T)
+        n = self.num_points
+        pi = np.empty(T)
+        mu = np.empty((T, 3))
+        cov = np.empty((T, 3, 3))
+        leaf = np.empty(n, np.int32)
+        iters = np.zeros(L, np.int32)
+        qcap = int(q_capacity or L * max_iters_per_level)
+        q = np.zeros(qcap)
+        qlen = C.c_int()
+        self._check(self.lib.hgmm_tree_build(self.h, int(L), float(ls), float(ld), _ptr(init_mu), float(sig2),
+                                             int(max_iters_per_level), _ptr(pi), _ptr(mu), _ptr(cov), _ptr(leaf),
+                                             _ptr(iters), _ptr(q), qcap, C.byref(qlen)))
+        return pi, mu, cov, leaf, iters, q[:qlen.value].copy()
+
+    def tree_set_nodes(self, L, pi, mu, cov):
+        T = 8 * (8 ** L - 1) // 7
+        pi = np.ascontiguousarray(pi, dtype=np.float64).reshape(T)
+        mu = np.ascontiguousarray(mu, dtype=np.float64).reshape(T, 3)
+        cov = np.ascontiguousarray(cov, dtype=np.float64).reshape(T, 3, 3)
+        self._tree_T = T
+        self._check(self.lib.hgmm_tree_set_nodes(self.h, int(L), _ptr(pi), _ptr(mu), _ptr(cov)))
+
+    def tree_set_target(self, target):
+        t = np.ascontiguousarray(target, dtype=np.float64)
+        if t.ndim != 2 or t.shape[1] != 3:
+            raise ValueError("target must be [M,3]")
+        self._check(self.lib.hgmm_tree_set_target(self.h, _ptr(t), t.shape[0]))
+
+    def tree_reg_estep(self, T, rot=None, t=None, scale=1.0, lambda_c=0.01):
+        rot = None if rot is None else np.ascontiguousarray(rot, dtype=np.float64).reshape(3, 3)
+        t = None if t is None else np.ascontiguousarray(t, dtype=np.float64).reshape(3)
+        m0 = np.empty(T)
+        m1 = np.empty((T, 3))
+        m2 = np.empty((T, 3, 3))
+        self._check(self.lib.hgmm_tree_reg_estep(self.h, _ptr(rot), _ptr(t), float(scale), float(lambda_c),
+                                                 _ptr(m0), _ptr(m1), _ptr(m2)))
+        return m0, m1, m2
+
+    def tree_node_complexity(self, T):
+        out = np.empty(T)
+        self._check(self.lib.hgmm_tree_node_complexity(self.h, _ptr(out)))
+        return out
+
+    # -- multi-GPU ------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        lib = load_library()
+        buf = C.create_string_buffer(128)
+        rc = lib.hgmm_comm_unique_id(buf)
+        if rc != 0:
+            raise HgmmError("ncclGetUniqueId failed (%d)" % rc)
+        return buf.raw
+
+    def comm_init(self, nranks, rank, unique_id: bytes):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check(self.lib.hgmm_comm_init_rank(self.h, int(nranks), int(rank), buf))
+        self.nranks, self.rank = int(nranks), int(rank)
+
+    def comm_destroy(self):
+        self._check(self.lib.hgmm_comm_destroy(self.h))
+        self.nranks, self.rank = 1, 0
+
+    def allreduce(self, values, op="sum"):
+        a = np.ascontiguousarray(values, dtype=np.float64).copy()
+        self._check(self.lib.hgmm_comm_allreduce_f64(self.h, _ptr(a), a.size, 1 if op == "max" else 0))
+        return a
+
+    # -- profiling ----------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._check(self.lib.hgmm_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self.lib.hgmm_profile_reset(self.h))
+
+    def profile_get(self, kernel):
+        ms, n = C.c_double(), C.c_int64()
+        self._check(self.lib.hgmm_profile_get(self.h, KERNEL_IDS[kernel], C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+_default_ctx = None
+
+
+def default_context() -> Context:
+    """Process-wide context on the rank's GPU (LOCAL_RANK, else device 0)."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default_ctx
+
+
+def set_default_context(ctx):
+    global _default_ctx
+    _default_ctx = ctx

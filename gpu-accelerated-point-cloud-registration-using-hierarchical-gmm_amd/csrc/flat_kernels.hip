@@ -1,0 +1,892 @@
+// Flat (non-hierarchical) GMM EM for gfx950: diag / spherical covariance, float32 arithmetic.
+//
+// Replaces the reference's array-library EM (src/python/gmm_waymo/src/gmm_impl.py:53-155 and
+// src/python/gmmreg_gpu/gmm_impl.py:36-91): per EM iteration the reference runs 5 SGEMMs with
+// K = 3 / K = N and ~10 elementwise passes over N x J temporaries.  Here:
+//
+//   flat_estep_kernel   one wavefront per point row, lanes across components.  The row's
+//                       x is wave-uniform (scalar loads); each lane keeps the packed
+//                       parameters (mu, 0.5/sigma^2, const) of its components in VGPRs for the
+//                       whole kernel, evaluates the *centred* quadratic form, does the
+//                       log-sum-exp with DPP wave reductions and streams log_resp[N,J] out
+//                       with coalesced stores.  HBM-write-bound: 4 N J bytes.
+//   flat_fused_kernel   same mapping, but instead of writing N x J it accumulates the
+//                       7 sufficient statistics per component in registers (centred about
+//                       the current mean, so no raw-moment cancellation), combines the waves
+//                       of a workgroup through LDS in a fixed order and writes one partial per
+//                       workgroup.  No atomics, run-to-run deterministic.
+//   flat_mstep_kernel   moments from a materialised resp / log_resp matrix (HBM-read-bound).
+//   flat_reduce_kernel  fp64 second-stage reduction of the per-workgroup partials; its output
+//                       is the buffer the RCCL all-reduce works on.
+//   flat_finalize_kernel  fp64 M-step (both reference flavours), next E-step's packed
+//                       parameters, log-likelihood trace and the device-side stop rule.
+#include "hgmm_ctx.h"
+#include "wave_ops.h"
+
+#include <cmath>
+
+namespace hgmm {
+
+constexpr float NEG_INF = -__builtin_huge_valf();
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int PK_MU = 0, PK_H = 3, PK_C = 6;   // rows of the packed parameter table
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int BLOCK = WAVES_PER_BLOCK * 64;
+
+// ------------------------------------------------------------------------------------------
+// parameter packing:  wlp_ij = c_j - sum_d h_jd (x_id - mu_jd)^2
+//   h_jd = 0.5 * inv_std_jd^2
+//   c_j  = -0.5 * 3 * log(2 pi) + sum_d log(inv_std_jd + eps) + log(w_j [+ eps])
+// (estimate_log_prob / estimate_log_prob_spherical / e_step, gmm_waymo gmm_impl.py:53-116)
+// ------------------------------------------------------------------------------------------
+__device__ inline void pack_component(int j, int J, int Jpad, int cov_type, int variant,
+                                      const float* mu, const float* inv, const float* w,
+                                      float* pack) {
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, h0 = 0.f, h1 = 0.f, h2 = 0.f, c = NEG_INF;
+    if (j < J) {
+        const double eps = (double)FLAT_EPS;
+        double i0, i1, i2;
+        if (cov_type == HGMM_COV_DIAG) {
+            i0 = inv[3 * j + 0]; i1 = inv[3 * j + 1]; i2 = inv[3 * j + 2];
+        } else {
+            i0 = i1 = i2 = inv[j];
+        }
+        const double log2pi = (double)1.8378770351409912f;   // reference casts log(2 pi) to float32
+        double half_log_det = log(i0 + eps) + log(i1 + eps) + log(i2 + eps);
+        double lw = (variant == HGMM_VARIANT_W) ? log((double)w[j] + eps) : log((double)w[j]);
+        double cc = -0.5 * 3.0 * log2pi + half_log_det + lw;
+        m0 = mu[3 * j + 0]; m1 = mu[3 * j + 1]; m2 = mu[3 * j + 2];
+        h0 = (float)(0.5 * i0 * i0); h1 = (float)(0.5 * i1 * i1); h2 = (float)(0.5 * i2 * i2);
+        c = (cc != cc) ? NEG_INF : (float)cc;
+    }
+    pack[(PK_MU + 0) * Jpad + j] = m0;
+    pack[(PK_MU + 1) * Jpad + j] = m1;
+    pack[(PK_MU + 2) * Jpad + j] = m2;
+    pack[(PK_H + 0) * Jpad + j] = h0;
+    pack[(PK_H + 1) * Jpad + j] = h1;
+    pack[(PK_H + 2) * Jpad + j] = h2;
+    pack[PK_C * Jpad + j] = c;
+}
+
+__global__ void flat_pack_kernel(int J, int Jpad, int cov_type, int variant, const float* mu,
+                                 const float* inv, const float* w, float* pack) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < Jpad) pack_component(j, J, Jpad, cov_type, variant, mu, inv, w, pack);
+}
+
+// ------------------------------------------------------------------------------------------
+// register-resident component parameters of one lane: K = NSLOT * VEC components,
+// component k = s*VEC + e  <->  j = (s*64 + lane)*VEC + e
+// ------------------------------------------------------------------------------------------
+template <int VEC, int NSLOT>
+struct LaneParams {
+    static constexpr int K = VEC * NSLOT;
+    float mu0[K], mu1[K], mu2[K], h0[K], h1[K], h2[K], c[K];
+
+    __device__ __forceinline__ void load(const float* __restrict__ pack, int Jpad, int lane) {
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            const int jb = (s * 64 + lane) * VEC;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int k = s * VEC + e;
+                mu0[k] = pack[(PK_MU + 0) * Jpad + jb + e];
+                mu1[k] = pack[(PK_MU + 1) * Jpad + jb + e];
+                mu2[k] = pack[(PK_MU + 2) * Jpad + jb + e];
+                h0[k] = pack[(PK_H + 0) * Jpad + jb + e];
+                h1[k] = pack[(PK_H + 1) * Jpad + jb + e];
+                h2[k] = pack[(PK_H + 2) * Jpad + jb + e];
+                c[k] = pack[PK_C * Jpad + jb + e];
+            }
+        }
+    }
+};
+
+// weighted log-probabilities of one row for this lane's components + the wave-wide
+// log-sum-exp pieces.  Returns the row maximum m and S = sum_j exp(wlp_j - m); e[] holds
+// exp(wlp - m) on return when WANT_E.
+template <int VEC, int NSLOT, bool WANT_E>
+__device__ __forceinline__ void row_lse(const LaneParams<VEC, NSLOT>& P, float x0, float x1,
+                                        float x2, float (&wl)[VEC * NSLOT],
+                                        float (&e)[VEC * NSLOT], float& m_out, float& s_out) {
+    constexpr int K = VEC * NSLOT;
+    float m = NEG_INF;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float d0 = x0 - P.mu0[k], d1 = x1 - P.mu1[k], d2 = x2 - P.mu2[k];
+        float q = P.h0[k] * (d0 * d0);
+        q = fmaf(P.h1[k], d1 * d1, q);
+        q = fmaf(P.h2[k], d2 * d2, q);
+        wl[k] = P.c[k] - q;
+        m = fmaxf(m, wl[k]);
+    }
+    m = wave_reduce(m, OpMax());
+    if (m == NEG_INF) m = 0.f;            // every component has zero weight: avoid inf - inf
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float ek = __builtin_amdgcn_exp2f((wl[k] - m) * LOG2E);
+        if (WANT_E) e[k] = ek;
+        s += ek;
+    }
+    s = wave_reduce(s, OpSum());
+    m_out = m;
+    s_out = s;
+}
+
+// log( sum_j exp(wlp_j) + eps )  from (m, S), exactly the reference's normaliser
+// (gmm_waymo gmm_impl.py:113 -- no max-shift there; this is the overflow-safe equivalent).
+// Also returns inv_den with  r_j = exp(wlp_j - m) * inv_den.
+__device__ __forceinline__ float lpn_from(float m, float s, float& inv_den) {
+    float lpn;
+    if (m < 0.f) {
+        const float em = expf(m);
+        const float tot = fmaf(s, em, FLAT_EPS);
+        lpn = logf(tot);
+        inv_den = em / tot;
+    } else {
+        const float den = fmaf(FLAT_EPS, expf(-m), s);
+        lpn = m + logf(den);
+        inv_den = 1.0f / den;
+    }
+    return lpn;
+}
+
+__device__ __forceinline__ void wave_row_range(int64_t n, int64_t& r0, int64_t& r1) {
+    const int64_t nw = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    const int64_t gw = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
+    const int64_t per = (n + nw - 1) / nw;
+    r0 = gw * per;
+    r1 = r0 + per < n ? r0 + per : n;
+    if (r0 > n) r0 = n;
+}
+
+// ------------------------------------------------------------------------------------------
+// materialising E-step / predict
+// ------------------------------------------------------------------------------------------
+template <int VEC, int NSLOT, bool NORMALISE>
+__global__ __launch_bounds__(BLOCK) void flat_estep_kernel(
+    const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int J, int Jpad,
+    float* __restrict__ log_resp, float* __restrict__ lpn_out, int32_t* __restrict__ argmax_out,
+    double* __restrict__ lpn_partials) {
+    constexpr int K = VEC * NSLOT;
+    const int lane = lane_id();
+    LaneParams<VEC, NSLOT> P;
+    P.load(pack, Jpad, lane);
+
+    int64_t r0, r1;
+    wave_row_range(n, r0, r1);
+    double lsum = 0.0;
+    float keep_lpn = 0.f;
+    int keep_arg = 0;
+    for (int64_t row = r0; row < r1; ++row) {
+        const float* xp = X + 3 * row;
+        const float x0 = xp[0], x1 = xp[1], x2 = xp[2];
+        float wl[K], e[K];
+        float m, s;
+        if (NORMALISE) {
+            row_lse<VEC, NSLOT, false>(P, x0, x1, x2, wl, e, m, s);
+        } else {
+            m = NEG_INF;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float d0 = x0 - P.mu0[k], d1 = x1 - P.mu1[k], d2 = x2 - P.mu2[k];
+                float q = P.h0[k] * (d0 * d0);
+                q = fmaf(P.h1[k], d1 * d1, q);
+                q = fmaf(P.h2[k], d2 * d2, q);
+                wl[k] = P.c[k] - q;
+                m = fmaxf(m, wl[k]);
+            }
+            m = wave_reduce(m, OpMax());
+            s = 0.f;
+        }
+        const int slot = (int)((row - r0) & 63);
+        if (NORMALISE) {
+            float inv_den;
+            const float lpn = lpn_from(m, s, inv_den);
+            lsum += (double)lpn;
+            if (log_resp) {
+                float* out = log_resp + row * (int64_t)J;
+#pragma unroll
+                for (int sidx = 0; sidx < NSLOT; ++sidx) {
+                    const int jb = (sidx * 64 + lane) * VEC;
+                    if (VEC == 4) {
+                        if (jb < J) {
+                            float4 v = make_float4(wl[sidx * 4 + 0] - lpn, wl[sidx * 4 + 1] - lpn,
+                                                   wl[sidx * 4 + 2] - lpn, wl[sidx * 4 + 3] - lpn);
+                            *reinterpret_cast<float4*>(out + jb) = v;
+                        }
+                    } else {
+                        if (jb < J) out[jb] = wl[sidx] - lpn;
+                    }
+                }
+            }
+            if (lane == slot) keep_lpn = lpn;
+        }
+        if (argmax_out) {
+            // first index attaining the row maximum (numpy argmax tie rule)
+            int best = 0x7fffffff;
+#pragma unroll
+            for (int k = K - 1; k >= 0; --k) {
+                const int j = ((k / VEC) * 64 + lane) * VEC + (k % VEC);
+                if (wl[k] == m && j < J) best = j;
+            }
+            best = wave_reduce_i(best, OpMinI());
+            if (best == 0x7fffffff) best = 0;
+            if (lane == slot) keep_arg = best;
+        }
+        if (slot == 63 || row + 1 == r1) {
+            const int64_t base = row - slot;
+            if (lane <= slot) {
+                if (NORMALISE && lpn_out) lpn_out[base + lane] = keep_lpn;
+                if (argmax_out) argmax_out[base + lane] = keep_arg;
+            }
+        }
+    }
+    if (NORMALISE && lpn_partials) {
+        __shared__ double sh[WAVES_PER_BLOCK];
+        if (lane == 0) sh[wave_in_block()] = lsum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int i = 0; i < WAVES_PER_BLOCK; ++i) t += sh[i];
+            lpn_partials[blockIdx.x] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fused E+M: sufficient statistics without the N x J round trip
+//   s0_j = sum_i r_ij,  a_jd = sum_i r_ij (x_id - mu_jd),  b_jd = sum_i r_ij (x_id - mu_jd)^2
+// ------------------------------------------------------------------------------------------
+template <int NSLOT>
+__global__ __launch_bounds__(BLOCK) void flat_fused_kernel(
+    const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int J, int Jpad,
+    float* __restrict__ partials, double* __restrict__ lpn_partials,
+    const int* __restrict__ done_flag) {
+    if (done_flag && *done_flag) return;
+    constexpr int K = NSLOT;
+    const int lane = lane_id();
+    LaneParams<1, NSLOT> P;
+    P.load(pack, Jpad, lane);
+    float a_s0[K], a_a0[K], a_a1[K], a_a2[K], a_b0[K], a_b1[K], a_b2[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) a_s0[k] = a_a0[k] = a_a1[k] = a_a2[k] = a_b0[k] = a_b1[k] = a_b2[k] = 0.f;
+
+    int64_t r0, r1;
+    wave_row_range(n, r0, r1);
+    double lsum = 0.0;
+    for (int64_t row = r0; row < r1; ++row) {
+        const float* xp = X + 3 * row;
+        const float x0 = xp[0], x1 = xp[1], x2 = xp[2];
+        float wl[K], e[K];
+        float m, s, inv_den;
+        row_lse<1, NSLOT, true>(P, x0, x1, x2, wl, e, m, s);
+        const float lpn = lpn_from(m, s, inv_den);
+        lsum += (double)lpn;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float r = e[k] * inv_den;
+            const float d0 = x0 - P.mu0[k], d1 = x1 - P.mu1[k], d2 = x2 - P.mu2[k];
+            const float rd0 = r * d0, rd1 = r * d1, rd2 = r * d2;
+            a_s0[k] += r;
+            a_a0[k] += rd0; a_a1[k] += rd1; a_a2[k] += rd2;
+            a_b0[k] = fmaf(rd0, d0, a_b0[k]);
+            a_b1[k] = fmaf(rd1, d1, a_b1[k]);
+            a_b2[k] = fmaf(rd2, d2, a_b2[k]);
+        }
+    }
+
+    // combine the workgroup's waves through LDS in a fixed order (deterministic), one HBM write
+    __shared__ float sh[FLAT_NSTAT * NSLOT * 64];
+    __shared__ double shl[WAVES_PER_BLOCK];
+    const int w = wave_in_block();
+    if (lane == 0) shl[w] = lsum;
+    for (int turn = 0; turn < WAVES_PER_BLOCK; ++turn) {
+        if (w == turn) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int j = k * 64 + lane;
+                float* p = sh + j;
+                constexpr int ST = NSLOT * 64;
+                if (turn == 0) {
+                    p[0 * ST] = a_s0[k]; p[1 * ST] = a_a0[k]; p[2 * ST] = a_a1[k]; p[3 * ST] = a_a2[k];
+                    p[4 * ST] = a_b0[k]; p[5 * ST] = a_b1[k]; p[6 * ST] = a_b2[k];
+                } else {
+                    p[0 * ST] += a_s0[k]; p[1 * ST] += a_a0[k]; p[2 * ST] += a_a1[k]; p[3 * ST] += a_a2[k];
+                    p[4 * ST] += a_b0[k]; p[5 * ST] += a_b1[k]; p[6 * ST] += a_b2[k];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* outp = partials + (size_t)blockIdx.x * FLAT_NSTAT * Jpad;
+    for (int idx = threadIdx.x; idx < FLAT_NSTAT * NSLOT * 64; idx += BLOCK) {
+        const int st = idx / (NSLOT * 64), j = idx % (NSLOT * 64);
+        outp[st * Jpad + j] = sh[idx];
+    }
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < WAVES_PER_BLOCK; ++i) t += shl[i];
+        lpn_partials[blockIdx.x] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// M-step moments from a materialised responsibility matrix (m_step(X, resp))
+// ------------------------------------------------------------------------------------------
+template <int VEC, int NSLOT>
+__global__ __launch_bounds__(BLOCK) void flat_mstep_kernel(
+    const float* __restrict__ X, const float* __restrict__ resp, int is_log,
+    const float* __restrict__ hint /*[3][Jpad]*/, int64_t n, int J, int Jpad,
+    float* __restrict__ partials) {
+    constexpr int K = VEC * NSLOT;
+    const int lane = lane_id();
+    float c0[K], c1[K], c2[K];
+    float a_s0[K], a_a0[K], a_a1[K], a_a2[K], a_b0[K], a_b1[K], a_b2[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int j = ((k / VEC) * 64 + lane) * VEC + (k % VEC);
+        c0[k] = hint[0 * Jpad + j]; c1[k] = hint[1 * Jpad + j]; c2[k] = hint[2 * Jpad + j];
+        a_s0[k] = a_a0[k] = a_a1[k] = a_a2[k] = a_b0[k] = a_b1[k] = a_b2[k] = 0.f;
+    }
+    int64_t r0, r1;
+    wave_row_range(n, r0, r1);
+
+    float cur[K], nxt[K];
+    auto load_row = [&](int64_t row, float (&v)[K]) {
+        const float* in = resp + row * (int64_t)J;
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            const int jb = (s * 64 + lane) * VEC;
+            if (VEC == 4) {
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (jb < J) t = *reinterpret_cast<const float4*>(in + jb);
+                else if (is_log) t = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+                v[s * 4 + 0] = t.x; v[s * 4 + 1] = t.y; v[s * 4 + 2] = t.z; v[s * 4 + 3] = t.w;
+            } else {
+                v[s] = (jb < J) ? in[jb] : (is_log ? NEG_INF : 0.f);
+            }
+        }
+    };
+    if (r0 < r1) load_row(r0, cur);
+    for (int64_t row = r0; row < r1; ++row) {
+        if (row + 1 < r1) load_row(row + 1, nxt);
+        const float* xp = X + 3 * row;
+        const float x0 = xp[0], x1 = xp[1], x2 = xp[2];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float r = is_log ? __builtin_amdgcn_exp2f(cur[k] * LOG2E) : cur[k];
+            const float d0 = x0 - c0[k], d1 = x1 - c1[k], d2 = x2 - c2[k];
+            const float rd0 = r * d0, rd1 = r * d1, rd2 = r * d2;
+            a_s0[k] += r;
+            a_a0[k] += rd0; a_a1[k] += rd1; a_a2[k] += rd2;
+            a_b0[k] = fmaf(rd0, d0, a_b0[k]);
+            a_b1[k] = fmaf(rd1, d1, a_b1[k]);
+            a_b2[k] = fmaf(rd2, d2, a_b2[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) cur[k] = nxt[k];
+    }
+    __shared__ float sh[FLAT_NSTAT * K * 64];
+    const int w = wave_in_block();
+    constexpr int ST = K * 64;
+    for (int turn = 0; turn < WAVES_PER_BLOCK; ++turn) {
+        if (w == turn) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int j = ((k / VEC) * 64 + lane) * VEC + (k % VEC);
+                float* p = sh + j;
+                if (turn == 0) {
+                    p[0 * ST] = a_s0[k]; p[1 * ST] = a_a0[k]; p[2 * ST] = a_a1[k]; p[3 * ST] = a_a2[k];
+                    p[4 * ST] = a_b0[k]; p[5 * ST] = a_b1[k]; p[6 * ST] = a_b2[k];
+                } else {
+                    p[0 * ST] += a_s0[k]; p[1 * ST] += a_a0[k]; p[2 * ST] += a_a1[k]; p[3 * ST] += a_a2[k];
+                    p[4 * ST] += a_b0[k]; p[5 * ST] += a_b1[k]; p[6 * ST] += a_b2[k];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* outp = partials + (size_t)blockIdx.x * FLAT_NSTAT * Jpad;
+    for (int idx = threadIdx.x; idx < FLAT_NSTAT * ST; idx += BLOCK) {
+        const int st = idx / ST, j = idx % ST;
+        outp[st * Jpad + j] = sh[idx];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// second stage: fp64 sum of the per-workgroup partials -> stats[7][Jpad], sum lpn, n
+// ------------------------------------------------------------------------------------------
+__global__ void flat_reduce_kernel(const float* __restrict__ partials,
+                                   const double* __restrict__ lpn_partials, int nblocks,
+                                   int valid_j, int Jpad, double n_local,
+                                   double* __restrict__ stats, const int* __restrict__ done_flag) {
+    if (done_flag && *done_flag) return;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = FLAT_NSTAT * Jpad;
+    if (idx < total) {
+        const int j = idx % Jpad;
+        double acc = 0.0;
+        if (j < valid_j) {
+            for (int b = 0; b < nblocks; ++b) acc += (double)partials[(size_t)b * total + idx];
+        }
+        stats[idx] = acc;
+    }
+    if (idx == 0) {
+        double t = 0.0;
+        if (lpn_partials)
+            for (int b = 0; b < nblocks; ++b) t += lpn_partials[b];
+        stats[total] = t;
+        stats[total + 1] = n_local;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// M-step in fp64 from centred statistics (single workgroup, Jpad <= 1024 threads).
+//   Sx = a + c s0,  Sxx = b + 2 c a + c^2 s0   (c = centre the statistics were taken about)
+//   W (gmm_waymo gmm_impl.py:81-103,134): nk = s0 + eps; mu = Sx/nk; cov = Sxx/nk - mu^2 + 1e-6;
+//        spherical: mean over axes; w = nk / N; inv_std = 1/(sqrt(cov + 1e-6) + eps)
+//   G (gmmreg_gpu gmm_impl.py:46-52,74): nk = s0; mu = Sx/(nk+eps); cov = max(Sxx/(nk+eps) - mu^2, 0);
+//        w = nk / N; inv_std = 1/(sqrt(cov) + eps)
+// ctl: [0] done, [1] n_iter, [2] converged; prev_ll lives in ctl_f[0].
+// ------------------------------------------------------------------------------------------
+__global__ void flat_finalize_kernel(const double* __restrict__ stats,
+                                     const float* __restrict__ centre /*[3][Jpad] or pack mu rows*/,
+                                     int J, int Jpad, int cov_type, int variant,
+                                     float* mu, float* cov, float* w, float* inv, float* pack,
+                                     float* lls, int lls_cap, float tol, int* ctl, float* ctl_f) {
+    const int j = threadIdx.x;
+    const int done = ctl ? ctl[0] : 0;
+    __syncthreads();
+    if (done) return;
+    const double eps = (double)FLAT_EPS;
+    const double n_total = stats[FLAT_NSTAT * Jpad + 1];
+    if (j < J) {
+        const double s0 = stats[0 * Jpad + j];
+        double nmu[3], ncov[3];
+        const double nk = (variant == HGMM_VARIANT_W) ? s0 + eps : s0;
+        const double den = (variant == HGMM_VARIANT_W) ? nk : nk + eps;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const double c = (double)centre[d * Jpad + j];
+            const double a = stats[(1 + d) * Jpad + j];
+            const double b = stats[(4 + d) * Jpad + j];
+            const double sx = a + c * s0;
+            const double sxx = b + 2.0 * c * a + c * c * s0;
+            const double m = sx / den;
+            double v = sxx / den - m * m;
+            if (variant == HGMM_VARIANT_W) v += 1e-6; else v = v < 0.0 ? 0.0 : v;
+            nmu[d] = m;
+            ncov[d] = v;
+        }
+        // round to the reference's storage type (float32) before deriving inv_std
+        float fc[3];
+        if (cov_type == HGMM_COV_SPHERICAL) {
+            const float sph = (float)((ncov[0] + ncov[1] + ncov[2]) / 3.0);
+            fc[0] = fc[1] = fc[2] = sph;
+            cov[j] = sph;
+        } else {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { fc[d] = (float)ncov[d]; cov[3 * j + d] = fc[d]; }
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) mu[3 * j + d] = (float)nmu[d];
+        w[j] = (float)(nk / n_total);
+        if (inv) {
+            float fi[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const double cv = (double)fc[d];
+                fi[d] = (float)((variant == HGMM_VARIANT_W) ? 1.0 / (sqrt(cv + 1e-6) + eps)
+                                                             : 1.0 / (sqrt(cv) + eps));
+            }
+            if (cov_type == HGMM_COV_SPHERICAL) inv[j] = fi[0];
+            else { inv[3 * j + 0] = fi[0]; inv[3 * j + 1] = fi[1]; inv[3 * j + 2] = fi[2]; }
+        }
+    }
+    __syncthreads();
+    if (pack && j < Jpad) pack_component(j, J, Jpad, cov_type, variant, mu, inv, w, pack);
+    if (j == 0 && ctl) {
+        const float ll = (float)(stats[FLAT_NSTAT * Jpad] / n_total);
+        const int it = ctl[1];
+        if (it < lls_cap) lls[it] = ll;
+        const float change = ll - ctl_f[0];          // prev starts at -inf (gmm_impl.py:120)
+        ctl_f[0] = ll;
+        ctl[1] = it + 1;
+        if (fabsf(change) < tol) { ctl[0] = 1; ctl[2] = 1; }
+    }
+}
+
+__global__ void flat_ctl_init_kernel(int* ctl, float* ctl_f) {
+    ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; ctl[3] = 0;
+    ctl_f[0] = -__builtin_huge_valf();
+}
+
+// hint table [3][Jpad] from host-layout mu [J,3]
+__global__ void flat_hint_kernel(const float* mu, int J, int Jpad, float* hint) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Jpad) return;
+    for (int d = 0; d < 3; ++d) hint[d * Jpad + j] = (j < J) ? mu[3 * j + d] : 0.f;
+}
+__global__ void flat_hint_const_kernel(float c0, float c1, float c2, int Jpad, float* hint) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Jpad) return;
+    hint[0 * Jpad + j] = c0; hint[1 * Jpad + j] = c1; hint[2 * Jpad + j] = c2;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side launch logic
+// ------------------------------------------------------------------------------------------
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+static int grid_for(hgmm_ctx* c, int64_t n, int blocks_per_cu) {
+    int64_t want = (n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;     // one row per wave at least
+    int64_t cap = (int64_t)c->cus * blocks_per_cu;
+    if (cap > FLAT_MAX_BLOCKS) cap = FLAT_MAX_BLOCKS;
+    int64_t g = want < cap ? want : cap;
+    return (int)(g < 1 ? 1 : g);
+}
+
+static int flat_check(hgmm_ctx* c, int cov_type, int variant, int J) {
+    if (!c->have_f32 || c->n <= 0) return fail(c, HGMM_ERR_STATE, "flat EM: call hgmm_set_points_f32 first");
+    if (cov_type != HGMM_COV_DIAG && cov_type != HGMM_COV_SPHERICAL)
+        return fail(c, HGMM_ERR_ARG, "cov_type must be 0 (diag) or 1 (spherical)");
+    if (variant != HGMM_VARIANT_W && variant != HGMM_VARIANT_G)
+        return fail(c, HGMM_ERR_ARG, "variant must be 0 (W) or 1 (G)");
+    if (variant == HGMM_VARIANT_G && cov_type != HGMM_COV_DIAG)
+        return fail(c, HGMM_ERR_ARG, "variant G (gmmreg_gpu) is diag-only");
+    if (J < 1 || J > FLAT_MAX_J)
+        return fail(c, HGMM_ERR_ARG, "J = %d outside the supported range 1..%d", J, FLAT_MAX_J);
+    return HGMM_OK;
+}
+
+static int flat_setup(hgmm_ctx* c, int cov_type, int variant, int J) {
+    const int Jpad = round_up(J, 256);
+    c->flat.cov_type = cov_type; c->flat.variant = variant; c->flat.J = J; c->flat.Jpad = Jpad;
+    HGMM_TRY(ensure(c, c->f_mu, sizeof(float) * 3 * Jpad));
+    HGMM_TRY(ensure(c, c->f_cov, sizeof(float) * 3 * Jpad));
+    HGMM_TRY(ensure(c, c->f_inv, sizeof(float) * 3 * Jpad));
+    HGMM_TRY(ensure(c, c->f_w, sizeof(float) * Jpad));
+    HGMM_TRY(ensure(c, c->f_pack, sizeof(float) * FLAT_NSTAT * Jpad));
+    HGMM_TRY(ensure(c, c->f_hint, sizeof(float) * 3 * Jpad));
+    HGMM_TRY(ensure(c, c->f_partials, sizeof(float) * (size_t)FLAT_MAX_BLOCKS * FLAT_NSTAT * Jpad));
+    HGMM_TRY(ensure(c, c->f_lpn_partials, sizeof(double) * FLAT_MAX_BLOCKS));
+    HGMM_TRY(ensure(c, c->f_stats, sizeof(double) * (FLAT_NSTAT * Jpad + 2)));
+    HGMM_TRY(ensure(c, c->f_ctl, 64));
+    return HGMM_OK;
+}
+
+static size_t cov_elems(int cov_type, int J) { return cov_type == HGMM_COV_DIAG ? (size_t)3 * J : (size_t)J; }
+
+static int flat_upload(hgmm_ctx* c, const float* mu, const float* inv_or_cov, bool is_cov, const float* w) {
+    const int J = c->flat.J;
+    HGMM_HIP(c, hipMemcpyAsync(c->f_mu.p, mu, sizeof(float) * 3 * J, hipMemcpyHostToDevice, c->stream));
+    HGMM_HIP(c, hipMemcpyAsync(is_cov ? c->f_cov.p : c->f_inv.p, inv_or_cov,
+                               sizeof(float) * cov_elems(c->flat.cov_type, J), hipMemcpyHostToDevice, c->stream));
+    HGMM_HIP(c, hipMemcpyAsync(c->f_w.p, w, sizeof(float) * J, hipMemcpyHostToDevice, c->stream));
+    return HGMM_OK;
+}
+
+static void launch_pack(hgmm_ctx* c) {
+    const FlatState& f = c->flat;
+    flat_pack_kernel<<<(f.Jpad + 255) / 256, 256, 0, c->stream>>>(
+        f.J, f.Jpad, f.cov_type, f.variant, c->f_mu.as<float>(), c->f_inv.as<float>(), c->f_w.as<float>(),
+        c->f_pack.as<float>());
+}
+
+template <bool NORMALISE>
+static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argmax, int* grid_out) {
+    const FlatState& f = c->flat;
+    const int grid = grid_for(c, c->n, 3);
+    *grid_out = grid;
+    const float* X = c->x_aos.as<float>();
+    const float* pk = c->f_pack.as<float>();
+    double* lp = c->f_lpn_partials.as<double>();
+    const bool vec4 = (f.J % 4 == 0);
+#define ESTEP_CASE(V, S)                                                                      \
+    flat_estep_kernel<V, S, NORMALISE><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, \
+                                                                     log_resp, lpn, argmax, lp)
+    ProfScope prof(c, HGMM_K_FLAT_ESTEP);
+    if (vec4) {
+        const int ns = (f.J + 255) / 256;
+        switch (ns) {
+            case 1: ESTEP_CASE(4, 1); break;
+            case 2: ESTEP_CASE(4, 2); break;
+            case 3: ESTEP_CASE(4, 3); break;
+            default: ESTEP_CASE(4, 4); break;
+        }
+    } else {
+        const int ns = (f.J + 63) / 64;
+        if (ns <= 1) ESTEP_CASE(1, 1);
+        else if (ns <= 2) ESTEP_CASE(1, 2);
+        else if (ns <= 4) ESTEP_CASE(1, 4);
+        else if (ns <= 8) ESTEP_CASE(1, 8);
+        else if (ns <= 12) ESTEP_CASE(1, 12);
+        else ESTEP_CASE(1, 16);
+    }
+#undef ESTEP_CASE
+    HGMM_HIP(c, hipGetLastError());
+    return HGMM_OK;
+}
+
+static int launch_fused(hgmm_ctx* c, const int* done_flag, int* grid_out, int* valid_j) {
+    const FlatState& f = c->flat;
+    const int grid = grid_for(c, c->n, 2);
+    *grid_out = grid;
+    const float* X = c->x_aos.as<float>();
+    const float* pk = c->f_pack.as<float>();
+    float* part = c->f_partials.as<float>();
+    double* lp = c->f_lpn_partials.as<double>();
+    const int ns = (f.J + 63) / 64;
+#define FUSED_CASE(S)                                                                           \
+    do {                                                                                        \
+        flat_fused_kernel<S><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, part, lp,   \
+                                                           done_flag);                         \
+        *valid_j = S * 64;                                                                      \
+    } while (0)
+    ProfScope prof(c, HGMM_K_FLAT_FUSED);
+    switch (ns) {
+        case 1: FUSED_CASE(1); break;
+        case 2: FUSED_CASE(2); break;
+        case 3: FUSED_CASE(3); break;
+        case 4: FUSED_CASE(4); break;
+        case 5: FUSED_CASE(5); break;
+        case 6: FUSED_CASE(6); break;
+        case 7: FUSED_CASE(7); break;
+        case 8: FUSED_CASE(8); break;
+        case 9: FUSED_CASE(9); break;
+        case 10: FUSED_CASE(10); break;
+        case 11: FUSED_CASE(11); break;
+        case 12: FUSED_CASE(12); break;
+        case 13: FUSED_CASE(13); break;
+        case 14: FUSED_CASE(14); break;
+        case 15: FUSED_CASE(15); break;
+        default: FUSED_CASE(16); break;
+    }
+#undef FUSED_CASE
+    HGMM_HIP(c, hipGetLastError());
+    return HGMM_OK;
+}
+
+static int launch_reduce(hgmm_ctx* c, int nblocks, int valid_j, bool with_lpn, const int* done_flag) {
+    const FlatState& f = c->flat;
+    const int total = FLAT_NSTAT * f.Jpad;
+    flat_reduce_kernel<<<(total + 255) / 256, 256, 0, c->stream>>>(
+        c->f_partials.as<float>(), with_lpn ? c->f_lpn_partials.as<double>() : nullptr, nblocks,
+        valid_j, f.Jpad, (double)c->n, c->f_stats.as<double>(), done_flag);
+    HGMM_HIP(c, hipGetLastError());
+    if (c->comm) HGMM_TRY(allreduce_f64_dev(c, c->f_stats.as<double>(), (size_t)total + 2));
+    return HGMM_OK;
+}
+
+// one EM iteration, everything asynchronous on the context's stream
+static int enqueue_em_iteration(hgmm_ctx* c) {
+    FlatState& f = c->flat;
+    int* ctl = c->f_ctl.as<int>();
+    float* ctl_f = reinterpret_cast<float*>(ctl + 8);
+    int grid = 0, valid_j = 0;
+    HGMM_TRY(launch_fused(c, ctl, &grid, &valid_j));
+    HGMM_TRY(launch_reduce(c, grid, valid_j, true, ctl));
+    // the statistics were centred about the means the E-step used = rows PK_MU.. of pack
+    flat_finalize_kernel<<<1, f.Jpad, 0, c->stream>>>(
+        c->f_stats.as<double>(), c->f_pack.as<float>() + PK_MU * f.Jpad, f.J, f.Jpad, f.cov_type,
+        f.variant, c->f_mu.as<float>(), c->f_cov.as<float>(), c->f_w.as<float>(), c->f_inv.as<float>(),
+        c->f_pack.as<float>(), c->f_lls.as<float>(), f.lls_cap, f.tol, ctl, ctl_f);
+    HGMM_HIP(c, hipGetLastError());
+    f.launched++;
+    return HGMM_OK;
+}
+
+}  // namespace hgmm
+
+using namespace hgmm;
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" int hgmm_flat_estep(hgmm_ctx* c, int cov_type, int variant, int J, const float* mu,
+                               const float* inv_std, const float* w, float* dev_log_resp,
+                               float* dev_lpn, int32_t* dev_argmax, double* mean_lpn_out) {
+    if (!c) return HGMM_ERR_ARG;
+    HGMM_TRY(flat_check(c, cov_type, variant, J));
+    HGMM_TRY(flat_setup(c, cov_type, variant, J));
+    HGMM_TRY(flat_upload(c, mu, inv_std, false, w));
+    launch_pack(c);
+    int grid = 0;
+    HGMM_TRY(launch_estep<true>(c, dev_log_resp, dev_lpn, dev_argmax, &grid));
+    if (mean_lpn_out) {
+        std::vector<double> h(grid);
+        HGMM_HIP(c, hipMemcpyAsync(h.data(), c->f_lpn_partials.p, sizeof(double) * grid,
+                                   hipMemcpyDeviceToHost, c->stream));
+        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+        double t = 0.0;
+        for (double v : h) t += v;
+        *mean_lpn_out = t / (double)c->n;
+    }
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_flat_predict(hgmm_ctx* c, int cov_type, int variant, int J, const float* mu,
+                                 const float* inv_std, const float* w, int32_t* dev_labels) {
+    if (!c || !dev_labels) return c ? fail(c, HGMM_ERR_ARG, "dev_labels is NULL") : HGMM_ERR_ARG;
+    HGMM_TRY(flat_check(c, cov_type, variant, J));
+    HGMM_TRY(flat_setup(c, cov_type, variant, J));
+    HGMM_TRY(flat_upload(c, mu, inv_std, false, w));
+    launch_pack(c);
+    int grid = 0;
+    HGMM_TRY(launch_estep<false>(c, nullptr, nullptr, dev_labels, &grid));
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_flat_mstep(hgmm_ctx* c, int cov_type, int variant, int J, const float* dev_resp,
+                               int is_log, const float* centre_hint, float* w_out, float* mu_out,
+                               float* cov_out) {
+    if (!c || !dev_resp) return c ? fail(c, HGMM_ERR_ARG, "dev_resp is NULL") : HGMM_ERR_ARG;
+    HGMM_TRY(flat_check(c, cov_type, variant, J));
+    HGMM_TRY(flat_setup(c, cov_type, variant, J));
+    FlatState& f = c->flat;
+    if (centre_hint) {
+        HGMM_HIP(c, hipMemcpyAsync(c->f_mu.p, centre_hint, sizeof(float) * 3 * J, hipMemcpyHostToDevice, c->stream));
+        flat_hint_kernel<<<(f.Jpad + 255) / 256, 256, 0, c->stream>>>(c->f_mu.as<float>(), J, f.Jpad,
+                                                                    c->f_hint.as<float>());
+    } else {
+        flat_hint_const_kernel<<<(f.Jpad + 255) / 256, 256, 0, c->stream>>>(0.f, 0.f, 0.f, f.Jpad,
+                                                                          c->f_hint.as<float>());
+    }
+    const int grid = grid_for(c, c->n, 2);
+    const float* X = c->x_aos.as<float>();
+    float* part = c->f_partials.as<float>();
+    const float* hint = c->f_hint.as<float>();
+    int valid_j = 0;
+    {
+        ProfScope prof(c, HGMM_K_FLAT_MSTEP);
+#define MSTEP_CASE(V, S)                                                                        \
+    do {                                                                                        \
+        flat_mstep_kernel<V, S><<<grid, BLOCK, 0, c->stream>>>(X, dev_resp, is_log, hint, c->n, J, \
+                                                              f.Jpad, part);                   \
+        valid_j = V * S * 64;                                                                   \
+    } while (0)
+        if (J % 4 == 0) {
+            const int ns = (J + 255) / 256;
+            switch (ns) {
+                case 1: MSTEP_CASE(4, 1); break;
+                case 2: MSTEP_CASE(4, 2); break;
+                case 3: MSTEP_CASE(4, 3); break;
+                default: MSTEP_CASE(4, 4); break;
+            }
+        } else {
+            const int ns = (J + 63) / 64;
+            if (ns <= 1) MSTEP_CASE(1, 1);
+            else if (ns <= 2) MSTEP_CASE(1, 2);
+            else if (ns <= 4) MSTEP_CASE(1, 4);
+            else if (ns <= 8) MSTEP_CASE(1, 8);
+            else if (ns <= 12) MSTEP_CASE(1, 12);
+            else MSTEP_CASE(1, 16);
+        }
+#undef MSTEP_CASE
+    }
+    HGMM_HIP(c, hipGetLastError());
+    HGMM_TRY(launch_reduce(c, grid, valid_j, false, nullptr));
+    flat_finalize_kernel<<<1, f.Jpad, 0, c->stream>>>(
+        c->f_stats.as<double>(), hint, J, f.Jpad, cov_type, variant, c->f_mu.as<float>(),
+        c->f_cov.as<float>(), c->f_w.as<float>(), nullptr, nullptr, nullptr, 0, 0.f, nullptr, nullptr);
+    HGMM_HIP(c, hipGetLastError());
+    HGMM_HIP(c, hipMemcpyAsync(mu_out, c->f_mu.p, sizeof(float) * 3 * J, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipMemcpyAsync(cov_out, c->f_cov.p, sizeof(float) * cov_elems(cov_type, J),
+                               hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipMemcpyAsync(w_out, c->f_w.p, sizeof(float) * J, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    return HGMM_OK;
+}
+
+__global__ void flat_inv_from_cov_kernel(const float* cov, float* inv, int n) {
+    // initial inv_std = 1/sqrt(cov)  (gmm_waymo gmm_impl.py:122, gmmreg_gpu gmm_impl.py:67)
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) inv[i] = 1.0f / sqrtf(cov[i]);
+}
+
+extern "C" int hgmm_flat_train_begin(hgmm_ctx* c, int cov_type, int variant, int J, float tol,
+                                     const float* mu, const float* cov, const float* w,
+                                     int lls_capacity) {
+    if (!c) return HGMM_ERR_ARG;
+    HGMM_TRY(flat_check(c, cov_type, variant, J));
+    HGMM_TRY(flat_setup(c, cov_type, variant, J));
+    if (lls_capacity < 1) lls_capacity = 1;
+    HGMM_TRY(ensure(c, c->f_lls, sizeof(float) * lls_capacity));
+    FlatState& f = c->flat;
+    f.tol = tol; f.lls_cap = lls_capacity; f.launched = 0; f.active = true;
+    HGMM_TRY(flat_upload(c, mu, cov, true, w));
+    const int ne = (int)cov_elems(cov_type, J);
+    flat_inv_from_cov_kernel<<<(ne + 255) / 256, 256, 0, c->stream>>>(c->f_cov.as<float>(),
+                                                                     c->f_inv.as<float>(), ne);
+    launch_pack(c);
+    int* ctl = c->f_ctl.as<int>();
+    flat_ctl_init_kernel<<<1, 1, 0, c->stream>>>(ctl, reinterpret_cast<float*>(ctl + 8));
+    HGMM_HIP(c, hipGetLastError());
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_flat_train_step(hgmm_ctx* c, int iters) {
+    if (!c) return HGMM_ERR_ARG;
+    if (!c->flat.active) return fail(c, HGMM_ERR_STATE, "hgmm_flat_train_step before hgmm_flat_train_begin");
+    for (int i = 0; i < iters; ++i) HGMM_TRY(enqueue_em_iteration(c));
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_flat_train_end(hgmm_ctx* c, float* mu, float* cov, float* w, float* inv_std_out,
+                                   float* lls_out, int* n_iter_out, int* converged_out) {
+    if (!c) return HGMM_ERR_ARG;
+    FlatState& f = c->flat;
+    if (!f.active) return fail(c, HGMM_ERR_STATE, "hgmm_flat_train_end before hgmm_flat_train_begin");
+    int ctl[4] = {0, 0, 0, 0};
+    HGMM_HIP(c, hipMemcpyAsync(ctl, c->f_ctl.p, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
+    const int J = f.J;
+    if (mu) HGMM_HIP(c, hipMemcpyAsync(mu, c->f_mu.p, sizeof(float) * 3 * J, hipMemcpyDeviceToHost, c->stream));
+    if (cov) HGMM_HIP(c, hipMemcpyAsync(cov, c->f_cov.p, sizeof(float) * cov_elems(f.cov_type, J), hipMemcpyDeviceToHost, c->stream));
+    if (w) HGMM_HIP(c, hipMemcpyAsync(w, c->f_w.p, sizeof(float) * J, hipMemcpyDeviceToHost, c->stream));
+    if (inv_std_out) HGMM_HIP(c, hipMemcpyAsync(inv_std_out, c->f_inv.p, sizeof(float) * cov_elems(f.cov_type, J), hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    const int n_it = ctl[1];
+    if (lls_out && n_it > 0) {
+        const int cnt = n_it < f.lls_cap ? n_it : f.lls_cap;
+        HGMM_HIP(c, hipMemcpy(lls_out, c->f_lls.p, sizeof(float) * cnt, hipMemcpyDeviceToHost));
+    }
+    if (n_iter_out) *n_iter_out = n_it;
+    if (converged_out) *converged_out = ctl[2];
+    f.active = false;
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_flat_train(hgmm_ctx* c, int cov_type, int variant, int J, int max_iter, float tol,
+                               float* mu, float* cov, float* w, float* inv_std_out, float* lls_out,
+                               int* n_iter_out, int* converged_out) {
+    if (!c) return HGMM_ERR_ARG;
+    if (max_iter < 0) return fail(c, HGMM_ERR_ARG, "max_iter < 0");
+    HGMM_TRY(hgmm_flat_train_begin(c, cov_type, variant, J, tol, mu, cov, w, max_iter));
+    HGMM_TRY(hgmm_flat_train_step(c, max_iter));
+    return hgmm_flat_train_end(c, mu, cov, w, inv_std_out, lls_out, n_iter_out, converged_out);
+}
+
+extern "C" int hgmm_flat_stats(hgmm_ctx* c, int cov_type, int variant, int J, const float* mu,
+                               const float* inv_std, const float* w, double* stats_out,
+                               double* sum_lpn_out, double* n_points_out) {
+    if (!c) return HGMM_ERR_ARG;
+    HGMM_TRY(flat_check(c, cov_type, variant, J));
+    HGMM_TRY(flat_setup(c, cov_type, variant, J));
+    HGMM_TRY(flat_upload(c, mu, inv_std, false, w));
+    launch_pack(c);
+    int grid = 0, valid_j = 0;
+    HGMM_TRY(launch_fused(c, nullptr, &grid, &valid_j));
+    HGMM_TRY(launch_reduce(c, grid, valid_j, true, nullptr));
+    const FlatState& f = c->flat;
+    std::vector<double> h((size_t)FLAT_NSTAT * f.Jpad + 2);
+    HGMM_HIP(c, hipMemcpyAsync(h.data(), c->f_stats.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    if (stats_out)
+        for (int j = 0; j < J; ++j)
+            for (int s = 0; s < FLAT_NSTAT; ++s) stats_out[(size_t)j * FLAT_NSTAT + s] = h[(size_t)s * f.Jpad + j];
+    if (sum_lpn_out) *sum_lpn_out = h[(size_t)FLAT_NSTAT * f.Jpad];
+    if (n_points_out) *n_points_out = h[(size_t)FLAT_NSTAT * f.Jpad + 1];
+    return HGMM_OK;
+}

@@ -1,0 +1,313 @@
+// Context lifecycle, device memory, point upload, RCCL attachment and the hipEvent profiler
+// behind the C ABI of include/hgmm.h.
+#include "hgmm_ctx.h"
+
+#include <cstring>
+#include <mutex>
+
+namespace hgmm {
+
+static std::string g_create_error;
+static std::mutex g_mu;
+
+int ensure(hgmm_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return HGMM_OK;
+    if (b.p) {
+        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+        HGMM_HIP(c, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes < 256 ? 256 : bytes;
+    HGMM_HIP(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return HGMM_OK;
+}
+
+ProfScope::ProfScope(hgmm_ctx* ctx, int kernel) : c(ctx) {
+    if (!c->profiling) return;
+    if (c->events_used == c->events.size()) {
+        EventPair p;
+        p.kernel = kernel;
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+        c->events.push_back(p);
+    }
+    ev = &c->events[c->events_used++];
+    ev->kernel = kernel;
+    (void)hipEventRecord(ev->a, c->stream);
+}
+ProfScope::~ProfScope() {
+    if (ev) (void)hipEventRecord(ev->b, c->stream);
+}
+
+int profile_collect(hgmm_ctx* c) {
+    if (c->events_used == 0) return HGMM_OK;
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < c->events_used; ++i) {
+        float ms = 0.f;
+        EventPair& p = c->events[i];
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            c->prof_ms[p.kernel] += (double)ms;
+            c->prof_n[p.kernel] += 1;
+        }
+    }
+    c->events_used = 0;
+    return HGMM_OK;
+}
+
+int allreduce_f64_dev(hgmm_ctx* c, double* dev, size_t n) {
+    if (!c->comm) return HGMM_OK;
+    HGMM_NCCL(c, ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, c->comm, c->stream));
+    return HGMM_OK;
+}
+
+__global__ void aos_to_soa64_f32(const float* __restrict__ in, int64_t n, int64_t n_pad,
+                                 double* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    for (int d = 0; d < 3; ++d) out[d * n_pad + i] = (i < n) ? (double)in[3 * i + d] : 0.0;
+}
+__global__ void aos_to_soa64_f64(const double* __restrict__ in, int64_t n, int64_t n_pad,
+                                 double* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    for (int d = 0; d < 3; ++d) out[d * n_pad + i] = (i < n) ? in[3 * i + d] : 0.0;
+}
+__global__ void f64_to_f32(const double* __restrict__ in, int64_t n, float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+
+}  // namespace hgmm
+
+using namespace hgmm;
+
+extern "C" int hgmm_version(void) { return 100; }
+
+extern "C" int hgmm_device_count(int* count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (count) *count = (e == hipSuccess) ? n : 0;
+    return e == hipSuccess ? HGMM_OK : HGMM_ERR_NODEVICE;
+}
+
+extern "C" const char* hgmm_last_error(const hgmm_ctx* c) {
+    if (c) return c->err.c_str();
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_create_error.c_str();
+}
+
+extern "C" int hgmm_create(int device_id, hgmm_ctx** out) {
+    if (!out) return HGMM_ERR_ARG;
+    *out = nullptr;
+    auto set_err = [](const std::string& s) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_create_error = s;
+    };
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_err(std::string("no HIP device available: ") + hipGetErrorString(e));
+        return HGMM_ERR_NODEVICE;
+    }
+    if (device_id < 0 || device_id >= n) {
+        set_err("device_id out of range");
+        return HGMM_ERR_ARG;
+    }
+    e = hipSetDevice(device_id);
+    if (e != hipSuccess) {
+        set_err(std::string("hipSetDevice failed: ") + hipGetErrorString(e));
+        return HGMM_ERR_HIP;
+    }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) {
+        set_err(std::string("hipGetDeviceProperties failed: ") + hipGetErrorString(e));
+        return HGMM_ERR_HIP;
+    }
+    hgmm_ctx* c = new hgmm_ctx();
+    c->device = device_id;
+    c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        set_err(std::string("hipStreamCreate failed: ") + hipGetErrorString(e));
+        delete c;
+        return HGMM_ERR_HIP;
+    }
+    *out = c;
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_destroy(hgmm_ctx* c) {
+    if (!c) return HGMM_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
+    DevBuf* bufs[] = {&c->x_aos, &c->x_soa64, &c->f_mu, &c->f_cov, &c->f_w, &c->f_inv, &c->f_pack,
+                      &c->f_partials, &c->f_lpn_partials, &c->f_stats, &c->f_lls, &c->f_ctl, &c->f_hint,
+                      &c->scratch, &c->t_pi, &c->t_mu, &c->t_cov, &c->t_prep, &c->t_cplx, &c->t_mom,
+                      &c->t_parent, &c->t_current, &c->t_perm, &c->t_seg, &c->t_chunks, &c->t_partials,
+                      &c->t_q, &c->tgt_soa64, &c->comm_buf};
+    for (DevBuf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (auto& p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_device_info(hgmm_ctx* c, char* name, int name_len, int* compute_units,
+                                int64_t* hbm_bytes) {
+    if (!c) return HGMM_ERR_ARG;
+    hipDeviceProp_t prop;
+    HGMM_HIP(c, hipGetDeviceProperties(&prop, c->device));
+    if (name && name_len > 0) {
+        std::string s = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+        strncpy(name, s.c_str(), (size_t)name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_synchronize(hgmm_ctx* c) {
+    if (!c) return HGMM_ERR_ARG;
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_alloc(hgmm_ctx* c, size_t bytes, void** dev_out) {
+    if (!c || !dev_out) return HGMM_ERR_ARG;
+    HGMM_HIP(c, hipSetDevice(c->device));
+    HGMM_HIP(c, hipMalloc(dev_out, bytes ? bytes : 4));
+    return HGMM_OK;
+}
+extern "C" int hgmm_free(hgmm_ctx* c, void* dev) {
+    if (!c) return HGMM_ERR_ARG;
+    if (!dev) return HGMM_OK;
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, hipFree(dev));
+    return HGMM_OK;
+}
+extern "C" int hgmm_h2d(hgmm_ctx* c, void* dev_dst, const void* host_src, size_t bytes) {
+    if (!c) return HGMM_ERR_ARG;
+    HGMM_HIP(c, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, c->stream));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    return HGMM_OK;
+}
+extern "C" int hgmm_d2h(hgmm_ctx* c, void* host_dst, const void* dev_src, size_t bytes) {
+    if (!c) return HGMM_ERR_ARG;
+    HGMM_HIP(c, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    return HGMM_OK;
+}
+
+extern "C" int64_t hgmm_num_points(const hgmm_ctx* c) { return c ? c->n : 0; }
+
+static int upload_common(hgmm_ctx* c, int64_t n) {
+    if (n <= 0) return fail(c, HGMM_ERR_ARG, "number of points must be positive");
+    HGMM_HIP(c, hipSetDevice(c->device));
+    c->n = n;
+    c->n_pad = (n + 255) / 256 * 256;
+    c->flat.active = false;
+    c->tree.nodes_ready = false;
+    HGMM_TRY(ensure(c, c->x_aos, sizeof(float) * 3 * (size_t)n));
+    HGMM_TRY(ensure(c, c->x_soa64, sizeof(double) * 3 * (size_t)c->n_pad));
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_set_points_f32(hgmm_ctx* c, const float* xyz, int64_t n) {
+    if (!c || !xyz) return c ? fail(c, HGMM_ERR_ARG, "xyz is NULL") : HGMM_ERR_ARG;
+    HGMM_TRY(upload_common(c, n));
+    HGMM_HIP(c, hipMemcpyAsync(c->x_aos.p, xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    aos_to_soa64_f32<<<(unsigned)((c->n_pad + 255) / 256), 256, 0, c->stream>>>(
+        c->x_aos.as<float>(), n, c->n_pad, c->x_soa64.as<double>());
+    HGMM_HIP(c, hipGetLastError());
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    c->have_f32 = c->have_f64 = true;
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_set_points_f64(hgmm_ctx* c, const double* xyz, int64_t n) {
+    if (!c || !xyz) return c ? fail(c, HGMM_ERR_ARG, "xyz is NULL") : HGMM_ERR_ARG;
+    HGMM_TRY(upload_common(c, n));
+    HGMM_TRY(ensure(c, c->scratch, sizeof(double) * 3 * (size_t)n));
+    HGMM_HIP(c, hipMemcpyAsync(c->scratch.p, xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    aos_to_soa64_f64<<<(unsigned)((c->n_pad + 255) / 256), 256, 0, c->stream>>>(
+        c->scratch.as<double>(), n, c->n_pad, c->x_soa64.as<double>());
+    f64_to_f32<<<(unsigned)((3 * n + 255) / 256), 256, 0, c->stream>>>(c->scratch.as<double>(), 3 * n,
+                                                                      c->x_aos.as<float>());
+    HGMM_HIP(c, hipGetLastError());
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    c->have_f32 = c->have_f64 = true;
+    return HGMM_OK;
+}
+
+// ---- RCCL -----------------------------------------------------------------------------------
+extern "C" int hgmm_comm_unique_id(void* id128_out) {
+    if (!id128_out) return HGMM_ERR_ARG;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return HGMM_ERR_RCCL;
+    memcpy(id128_out, &id, sizeof id);
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_comm_init_rank(hgmm_ctx* c, int nranks, int rank, const void* id128) {
+    if (!c || !id128) return HGMM_ERR_ARG;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(c, HGMM_ERR_ARG, "bad rank %d / %d", rank, nranks);
+    if (c->comm) return fail(c, HGMM_ERR_STATE, "communicator already attached");
+    HGMM_HIP(c, hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    HGMM_NCCL(c, ncclCommInitRank(&c->comm, nranks, id, rank));
+    c->nranks = nranks;
+    c->rank = rank;
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_comm_destroy(hgmm_ctx* c) {
+    if (!c) return HGMM_ERR_ARG;
+    if (c->comm) {
+        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+        HGMM_NCCL(c, ncclCommDestroy(c->comm));
+        c->comm = nullptr;
+        c->nranks = 1;
+        c->rank = 0;
+    }
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_comm_allreduce_f64(hgmm_ctx* c, double* host_inout, int n, int op) {
+    if (!c || !host_inout || n < 1) return HGMM_ERR_ARG;
+    if (!c->comm) return HGMM_OK;   // single rank: identity
+    HGMM_TRY(ensure(c, c->comm_buf, sizeof(double) * (size_t)n));
+    HGMM_HIP(c, hipMemcpyAsync(c->comm_buf.p, host_inout, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HGMM_NCCL(c, ncclAllReduce(c->comm_buf.p, c->comm_buf.p, (size_t)n, ncclDouble,
+                               op == 1 ? ncclMax : ncclSum, c->comm, c->stream));
+    HGMM_HIP(c, hipMemcpyAsync(host_inout, c->comm_buf.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    return HGMM_OK;
+}
+
+// ---- profiling --------------------------------------------------------------------------------
+extern "C" int hgmm_profile_enable(hgmm_ctx* c, int on) {
+    if (!c) return HGMM_ERR_ARG;
+    if (!on) HGMM_TRY(profile_collect(c));
+    c->profiling = on != 0;
+    return HGMM_OK;
+}
+extern "C" int hgmm_profile_reset(hgmm_ctx* c) {
+    if (!c) return HGMM_ERR_ARG;
+    HGMM_TRY(profile_collect(c));
+    for (int i = 0; i < HGMM_K_COUNT; ++i) { c->prof_ms[i] = 0.0; c->prof_n[i] = 0; }
+    return HGMM_OK;
+}
+extern "C" int hgmm_profile_get(hgmm_ctx* c, int kernel_id, double* total_ms_out, int64_t* launches_out) {
+    if (!c || kernel_id < 0 || kernel_id >= HGMM_K_COUNT) return HGMM_ERR_ARG;
+    HGMM_TRY(profile_collect(c));
+    if (total_ms_out) *total_ms_out = c->prof_ms[kernel_id];
+    if (launches_out) *launches_out = c->prof_n[kernel_id];
+    return HGMM_OK;
+}

@@ -1,0 +1,147 @@
+// Internal context of libhgmm_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/hgmm.h"
+
+namespace hgmm {
+
+constexpr float FLAT_EPS = 1e-8f;     // gmm_waymo gmm_impl.py:15 / gmmreg_gpu gmm_impl.py:16
+constexpr int FLAT_NSTAT = 7;         // s0, a[3], b[3]
+constexpr int FLAT_MAX_J = 1024;      // register-resident parameter kernels
+constexpr int FLAT_MAX_BLOCKS = 1024; // persistent grid upper bound (partials buffer)
+
+// A growable device buffer owned by the context.
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct EventPair { hipEvent_t a, b; int kernel; };
+
+struct FlatState {
+    int cov_type = 0, variant = 0, J = 0, Jpad = 0;
+    float tol = 0.f;
+    int lls_cap = 0;
+    int launched = 0;                 // EM iterations enqueued since train_begin
+    bool active = false;
+};
+
+struct TreeState {
+    int L = 0;
+    int T = 0;
+    bool nodes_ready = false;
+};
+
+}  // namespace hgmm
+
+struct hgmm_ctx {
+    int device = 0;
+    int cus = 256;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // ---- points -----------------------------------------------------------------
+    int64_t n = 0;                    // local points
+    hgmm::DevBuf x_aos;               // float [n,3]  (flat EM; wave-uniform scalar loads)
+    hgmm::DevBuf x_soa64;             // double [3][n_pad] (HGMM; lanes across points)
+    bool have_f32 = false, have_f64 = false;
+    int64_t n_pad = 0;
+
+    // ---- flat EM ----------------------------------------------------------------
+    hgmm::FlatState flat;
+    hgmm::DevBuf f_mu, f_cov, f_w, f_inv;     // float model parameters (reference layout)
+    hgmm::DevBuf f_pack;                      // float [7][Jpad] packed E-step params
+    hgmm::DevBuf f_partials;                  // float [blocks][7][Jpad]
+    hgmm::DevBuf f_lpn_partials;              // double [blocks]
+    hgmm::DevBuf f_stats;                     // double [7*Jpad + 2]  (+ sum lpn, + n)
+    hgmm::DevBuf f_lls;                       // float [cap]
+    hgmm::DevBuf f_ctl;                       // int  [4]: done, n_iter, converged, pad ; float prev
+    hgmm::DevBuf f_hint;                      // float [3][Jpad] centre hint for m-step
+    hgmm::DevBuf scratch;
+
+    // ---- tree -------------------------------------------------------------------
+    hgmm::TreeState tree;
+    hgmm::DevBuf t_pi, t_mu, t_cov;           // double node tables [T], [T,3], [T,9]
+    hgmm::DevBuf t_prep;                      // double [T][12] : inv(6) coef logc pi mu(3) -> see tree_kernels
+    hgmm::DevBuf t_cplx;                      // double [T]
+    hgmm::DevBuf t_mom;                       // double [T][10]
+    hgmm::DevBuf t_parent, t_current;         // int32 [n]
+    hgmm::DevBuf t_perm;                      // int32 [n]  points sorted by parent
+    hgmm::DevBuf t_seg;                       // int32 segment tables
+    hgmm::DevBuf t_chunks;                    // int32 chunk descriptors
+    hgmm::DevBuf t_partials;                  // double per-chunk partial moments
+    hgmm::DevBuf t_q;                         // double per-block q partials + result
+    hgmm::DevBuf tgt_soa64;                   // double [3][m_pad] registration target
+    int64_t tgt_n = 0, tgt_pad = 0;
+
+    // ---- multi-GPU --------------------------------------------------------------
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+    hgmm::DevBuf comm_buf;
+
+    // ---- profiling --------------------------------------------------------------
+    bool profiling = false;
+    std::vector<hgmm::EventPair> events;
+    size_t events_used = 0;
+    double prof_ms[HGMM_K_COUNT] = {0};
+    int64_t prof_n[HGMM_K_COUNT] = {0};
+};
+
+namespace hgmm {
+
+inline int fail(hgmm_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HGMM_HIP(ctx, call)                                                              \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return hgmm::fail((ctx), HGMM_ERR_HIP, "%s failed: %s (%s:%d)", #call,       \
+                              hipGetErrorString(e_), __FILE__, __LINE__);                \
+    } while (0)
+
+#define HGMM_NCCL(ctx, call)                                                             \
+    do {                                                                                 \
+        ncclResult_t r_ = (call);                                                        \
+        if (r_ != ncclSuccess)                                                           \
+            return hgmm::fail((ctx), HGMM_ERR_RCCL, "%s failed: %s (%s:%d)", #call,      \
+                              ncclGetErrorString(r_), __FILE__, __LINE__);               \
+    } while (0)
+
+#define HGMM_TRY(expr)                   \
+    do {                                 \
+        int rc_ = (expr);                \
+        if (rc_ != HGMM_OK) return rc_;  \
+    } while (0)
+
+int ensure(hgmm_ctx* c, DevBuf& b, size_t bytes);
+
+// profiling brackets: record an event pair around one kernel launch when enabled
+struct ProfScope {
+    hgmm_ctx* c;
+    EventPair* ev = nullptr;
+    ProfScope(hgmm_ctx* ctx, int kernel);
+    ~ProfScope();
+};
+int profile_collect(hgmm_ctx* c);
+
+// sub-system entry points implemented in flat_kernels.hip / tree_kernels.hip
+int allreduce_f64_dev(hgmm_ctx* c, double* dev, size_t n);
+
+}  // namespace hgmm

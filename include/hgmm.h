@@ -1,0 +1,171 @@
+/*
+ * hgmm.h -- C ABI of the MI355X-native (gfx950) GMM / hierarchical-GMM EM engine.
+ *
+ * This is the drop-in boundary for the EM hot path of
+ * somanshu25/GPU-Accelerated-Point-Cloud-Registration-Using-Hierarchical-GMM.
+ * The reference has no FFI seam of its own: its seam is Python duck typing
+ * (`cupy.get_array_module(X)` in src/python/gmm_waymo/src/gmm_impl.py:19,31,54,68 and the
+ * single host->device hop in src/python/gmm_waymo/src/gmm.py:72-80).  Each entry point
+ * below names the reference function(s) it replaces (paths relative to the upstream
+ * repository root).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success or a negative hgmm_status.
+ *     hgmm_last_error(ctx) returns a human-readable description of the last failure.
+ *   - "host" pointers are borrowed for the duration of the call; "dev" pointers are device
+ *     addresses obtained from hgmm_alloc() (or any hipMalloc'd buffer on ctx's device).
+ *   - one context per device / per rank, no global state; a context is not re-entrant,
+ *     distinct contexts may be driven from distinct threads.
+ *   - all kernels run on the context's own HIP stream; calls that return host data
+ *     synchronise that stream, all others are asynchronous.
+ *   - cov_type: 0 = diag ([J,3] per-axis), 1 = spherical ([J]);
+ *     variant : 0 = "W" (gmm_waymo/src/gmm_impl.py), 1 = "G" (gmmreg_gpu/gmm_impl.py)
+ *     -- the two flavours differ in eps / regularisation, see SURVEY.md 8(a).
+ *   - `inv_std` is what the reference calls `inv_cov` (it is 1/sigma, not 1/sigma^2).
+ */
+#ifndef HGMM_H
+#define HGMM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hgmm_ctx hgmm_ctx;
+
+enum hgmm_status {
+    HGMM_OK = 0,
+    HGMM_ERR_HIP = -1,        /* a HIP runtime call failed */
+    HGMM_ERR_ARG = -2,        /* invalid argument / unsupported size */
+    HGMM_ERR_STATE = -3,      /* call sequence error (e.g. no points set) */
+    HGMM_ERR_RCCL = -4,       /* an RCCL call failed */
+    HGMM_ERR_NODEVICE = -5    /* no usable gfx950 device */
+};
+
+enum { HGMM_COV_DIAG = 0, HGMM_COV_SPHERICAL = 1 };
+enum { HGMM_VARIANT_W = 0, HGMM_VARIANT_G = 1 };
+
+/* kernels that the in-library profiler times with hipEvents (hgmm_profile_*) */
+enum hgmm_kernel_id {
+    HGMM_K_FLAT_ESTEP = 0,    /* materialising E-step (writes log_resp[N,J]) */
+    HGMM_K_FLAT_FUSED = 1,    /* fused E+M sufficient-statistics kernel      */
+    HGMM_K_FLAT_MSTEP = 2,    /* M-step moments from materialised resp       */
+    HGMM_K_TREE_ESTEP = 3,    /* HGMM level E-step (8 children / point)      */
+    HGMM_K_TREE_LOGLIK = 4,   /* HGMM level log-likelihood (all level nodes) */
+    HGMM_K_TREE_REG = 5,      /* HGMM registration E-step (tree descent)     */
+    HGMM_K_COUNT = 6
+};
+
+/* ---- lifecycle ------------------------------------------------------------------ */
+int hgmm_version(void);
+int hgmm_device_count(int* count);
+int hgmm_create(int device_id, hgmm_ctx** out);
+int hgmm_destroy(hgmm_ctx* ctx);
+const char* hgmm_last_error(const hgmm_ctx* ctx);  /* ctx may be NULL: last create() error */
+int hgmm_device_info(hgmm_ctx* ctx, char* name, int name_len, int* compute_units,
+                     int64_t* hbm_bytes);
+int hgmm_synchronize(hgmm_ctx* ctx);
+
+/* ---- device memory (what cupy.asarray / cupy.asnumpy did: gmm.py:73-80, 95) ------ */
+int hgmm_alloc(hgmm_ctx* ctx, size_t bytes, void** dev_out);
+int hgmm_free(hgmm_ctx* ctx, void* dev);
+int hgmm_h2d(hgmm_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);
+int hgmm_d2h(hgmm_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
+
+/* ---- point cloud ------------------------------------------------------------------
+ * Replaces `dev_X = cupy.asarray(X.astype(np.float32))` (gmm_waymo/src/gmm.py:73) and
+ * `cuda.to_device(points)` (hgmm/hgmm_gpu.py:513).  xyz is host row-major [n,3]. */
+int hgmm_set_points_f32(hgmm_ctx* ctx, const float* xyz, int64_t n);
+int hgmm_set_points_f64(hgmm_ctx* ctx, const double* xyz, int64_t n);
+int64_t hgmm_num_points(const hgmm_ctx* ctx);
+
+/* ---- flat GMM EM (diag / spherical) ------------------------------------------------
+ * hgmm_flat_estep   <- e_step()            gmm_waymo gmm_impl.py:105-116, gmmreg_gpu gmm_impl.py:55-61
+ *                      (+ estimate_log_prob[_spherical] 53-78)
+ * hgmm_flat_predict <- predict()           gmm_waymo gmm_impl.py:147-155, gmmreg_gpu gmm_impl.py:88-91
+ * hgmm_flat_mstep   <- m_step()            gmm_waymo gmm_impl.py:90-103 (+81-88), gmmreg_gpu gmm_impl.py:46-52
+ * hgmm_flat_train   <- train_gmm()         gmm_waymo gmm_impl.py:118-145, gmmreg_gpu gmm_impl.py:63-85
+ *
+ * mu [J,3], inv_std / cov [J,3] (diag) or [J] (spherical), w [J]: host float32.
+ * dev_log_resp [N,J] row-major, dev_lpn [N], dev_argmax [N]: device buffers or NULL.    */
+int hgmm_flat_estep(hgmm_ctx* ctx, int cov_type, int variant, int J,
+                    const float* mu, const float* inv_std, const float* w,
+                    float* dev_log_resp, float* dev_lpn, int32_t* dev_argmax,
+                    double* mean_lpn_out);
+int hgmm_flat_predict(hgmm_ctx* ctx, int cov_type, int variant, int J,
+                      const float* mu, const float* inv_std, const float* w,
+                      int32_t* dev_labels);
+/* dev_resp: [N,J] responsibilities (is_log = 0) or log-responsibilities (is_log = 1, the
+ * exp() of train_gmm's `m_step(X, xp.exp(log_resp))` is then fused into the read).
+ * centre_hint [J,3] (host, may be NULL): moments are accumulated about it to avoid the
+ * raw-second-moment cancellation; results are mathematically independent of it.        */
+int hgmm_flat_mstep(hgmm_ctx* ctx, int cov_type, int variant, int J,
+                    const float* dev_resp, int is_log, const float* centre_hint,
+                    float* w_out, float* mu_out, float* cov_out);
+/* Whole loop device-resident (fused E+M, no N x J traffic).  mu/cov/w: in = initial,
+ * out = final.  lls has room for max_iter floats.                                      */
+int hgmm_flat_train(hgmm_ctx* ctx, int cov_type, int variant, int J, int max_iter, float tol,
+                    float* mu, float* cov, float* w, float* inv_std_out,
+                    float* lls_out, int* n_iter_out, int* converged_out);
+/* The same loop split so a caller (bench, streaming refit) can time / interleave steps:
+ * begin uploads the initial parameters, step enqueues `iters` EM iterations without
+ * synchronising, end synchronises and downloads.                                       */
+int hgmm_flat_train_begin(hgmm_ctx* ctx, int cov_type, int variant, int J, float tol,
+                          const float* mu, const float* cov, const float* w, int lls_capacity);
+int hgmm_flat_train_step(hgmm_ctx* ctx, int iters);
+int hgmm_flat_train_end(hgmm_ctx* ctx, float* mu, float* cov, float* w, float* inv_std_out,
+                        float* lls_out, int* n_iter_out, int* converged_out);
+/* Sufficient statistics of ONE fused E+M pass on this context's points (after the
+ * all-reduce when a communicator is attached): stats [J,7] doubles laid out
+ * (s0, a_x, a_y, a_z, b_x, b_y, b_z) with a = sum r (x - mu_old), b = sum r (x - mu_old)^2,
+ * plus sum_i lpn_i and the (global) point count.                                        */
+int hgmm_flat_stats(hgmm_ctx* ctx, int cov_type, int variant, int J,
+                    const float* mu, const float* inv_std, const float* w,
+                    double* stats_out, double* sum_lpn_out, double* n_points_out);
+
+/* ---- hierarchical GMM (8-ary tree, full 3x3 covariance, float64) -------------------
+ * hgmm_tree_build     <- buildGMMTree()     hgmm/hgmm_cupy_cpu_working.py:122-160 (CPU twin,
+ *                        canonical) == hgmm/hgmm_gpu.py:466-548 (kernels 107-115, 387-426)
+ * hgmm_tree_set_nodes <- GMMTree._nodes     hgmm_cupy_cpu_working.py:334,341
+ * hgmm_tree_reg_estep <- gmmTreeRegESTep()  hgmm_cupy_cpu_working.py:202-228 == hgmm_gpu.py:550-577
+ *
+ * T = 8 (8^L - 1) / 7 nodes.  init_mu [T,3] host float64 (RNG stays with the caller).
+ * Outputs pi [T], mu [T,3], cov [T,3,3] host float64; leaf_idx [N] = currentIdx after the
+ * last level (may be NULL); iters_per_level [L]; q_trace[q_capacity] (may be NULL).     */
+int hgmm_tree_build(hgmm_ctx* ctx, int L, double ls, double ld, const double* init_mu,
+                    double sig2, int max_iters_per_level,
+                    double* pi_out, double* mu_out, double* cov_out, int32_t* leaf_idx_out,
+                    int32_t* iters_per_level_out, double* q_trace_out, int q_capacity,
+                    int* q_len_out);
+int hgmm_tree_set_nodes(hgmm_ctx* ctx, int L, const double* pi, const double* mu,
+                        const double* cov);
+/* Registration target cloud (host [n,3] float64), kept resident across iterations. */
+int hgmm_tree_set_target(hgmm_ctx* ctx, const double* xyz, int64_t n);
+/* E-step of the registration loop on the resident target transformed on the fly by
+ * x' = scale * R x + t (R row-major [3,3]; pass NULL for identity).  Outputs host
+ * float64 m0 [T], m1 [T,3], m2 [T,3,3].                                                 */
+int hgmm_tree_reg_estep(hgmm_ctx* ctx, const double* rot, const double* t, double scale,
+                        double lambda_c, double* m0_out, double* m1_out, double* m2_out);
+/* smallest eigenvalue / trace per node (complexity(), hgmm_cupy_cpu_working.py:87-91) */
+int hgmm_tree_node_complexity(hgmm_ctx* ctx, double* cplx_out);
+
+/* ---- multi-GPU: one context per rank, RCCL over xGMI --------------------------------
+ * New functionality (the reference is single-GPU).  With a communicator attached,
+ * hgmm_flat_train*, hgmm_flat_stats and hgmm_tree_build all-reduce their per-cluster
+ * sufficient statistics (and the point count) across ranks before every M-step.        */
+int hgmm_comm_unique_id(void* id128_out);                       /* 128 bytes */
+int hgmm_comm_init_rank(hgmm_ctx* ctx, int nranks, int rank, const void* id128);
+int hgmm_comm_destroy(hgmm_ctx* ctx);
+int hgmm_comm_allreduce_f64(hgmm_ctx* ctx, double* host_inout, int n, int op /*0 sum,1 max*/);
+
+/* ---- profiling (hipEvent pairs around the hot kernels, on the context's stream) ---- */
+int hgmm_profile_enable(hgmm_ctx* ctx, int on);
+int hgmm_profile_reset(hgmm_ctx* ctx);
+int hgmm_profile_get(hgmm_ctx* ctx, int kernel_id, double* total_ms_out, int64_t* launches_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HGMM_H */
