@@ -418,27 +418,55 @@ __global__ __launch_bounds__(BLOCK) void flat_mstep_kernel(
 // ------------------------------------------------------------------------------------------
 // second stage: fp64 sum of the per-workgroup partials -> stats[7][Jpad], sum lpn, n
 // ------------------------------------------------------------------------------------------
-__global__ void flat_reduce_kernel(const float* __restrict__ partials,
-                                   const double* __restrict__ lpn_partials, int nblocks,
-                                   int valid_j, int Jpad, double n_local,
-                                   double* __restrict__ stats, const int* __restrict__ done_flag) {
+constexpr int RED_IDX = 32;      // consecutive statistics per workgroup (one 128-byte line)
+constexpr int RED_SLICES = 8;    // partial-block slices summed in parallel, combined in fixed order
+__global__ __launch_bounds__(RED_IDX * RED_SLICES) void flat_reduce_kernel(
+    const float* __restrict__ partials, const double* __restrict__ lpn_partials, int nblocks,
+    int valid_j, int Jpad, double n_local, double* __restrict__ stats,
+    const int* __restrict__ done_flag) {
     if (done_flag && *done_flag) return;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = FLAT_NSTAT * Jpad;
-    if (idx < total) {
-        const int j = idx % Jpad;
+    const int stat_blocks = (total + RED_IDX - 1) / RED_IDX;
+    __shared__ double sh[RED_SLICES][RED_IDX];
+    if ((int)blockIdx.x < stat_blocks) {
+        const int li = threadIdx.x % RED_IDX, slice = threadIdx.x / RED_IDX;
+        const int idx = blockIdx.x * RED_IDX + li;
         double acc = 0.0;
-        if (j < valid_j) {
-            for (int b = 0; b < nblocks; ++b) acc += (double)partials[(size_t)b * total + idx];
+        if (idx < total && (idx % Jpad) < valid_j) {
+            const float* src = partials + idx;
+            int b = slice;
+            for (; b + 3 * RED_SLICES < nblocks; b += 4 * RED_SLICES) {
+                const float v0 = src[(size_t)b * total];
+                const float v1 = src[(size_t)(b + RED_SLICES) * total];
+                const float v2 = src[(size_t)(b + 2 * RED_SLICES) * total];
+                const float v3 = src[(size_t)(b + 3 * RED_SLICES) * total];
+                acc += (double)v0; acc += (double)v1; acc += (double)v2; acc += (double)v3;
+            }
+            for (; b < nblocks; b += RED_SLICES) acc += (double)src[(size_t)b * total];
         }
-        stats[idx] = acc;
-    }
-    if (idx == 0) {
-        double t = 0.0;
+        sh[slice][li] = acc;
+        __syncthreads();
+        if (slice == 0 && idx < total) {
+            double t = 0.0;
+#pragma unroll
+            for (int s = 0; s < RED_SLICES; ++s) t += sh[s][li];
+            stats[idx] = t;
+        }
+    } else {
+        // last workgroup: sum of the per-workgroup log-normaliser partials + the point count
+        double acc = 0.0;
         if (lpn_partials)
-            for (int b = 0; b < nblocks; ++b) t += lpn_partials[b];
-        stats[total] = t;
-        stats[total + 1] = n_local;
+            for (int b = threadIdx.x; b < nblocks; b += RED_IDX * RED_SLICES) acc += lpn_partials[b];
+        acc = wave_sum_f64(acc);
+        double* shw = &sh[0][0];
+        if (lane_id() == 0) shw[wave_in_block()] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < RED_IDX * RED_SLICES / 64; ++w) t += shw[w];
+            stats[total] = t;
+            stats[total + 1] = n_local;
+        }
     }
 }
 
@@ -672,7 +700,7 @@ static int launch_fused(hgmm_ctx* c, const int* done_flag, int* grid_out, int* v
 static int launch_reduce(hgmm_ctx* c, int nblocks, int valid_j, bool with_lpn, const int* done_flag) {
     const FlatState& f = c->flat;
     const int total = FLAT_NSTAT * f.Jpad;
-    flat_reduce_kernel<<<(total + 255) / 256, 256, 0, c->stream>>>(
+    flat_reduce_kernel<<<(total + RED_IDX - 1) / RED_IDX + 1, RED_IDX * RED_SLICES, 0, c->stream>>>(
         c->f_partials.as<float>(), with_lpn ? c->f_lpn_partials.as<double>() : nullptr, nblocks,
         valid_j, f.Jpad, (double)c->n, c->f_stats.as<double>(), done_flag);
     HGMM_HIP(c, hipGetLastError());

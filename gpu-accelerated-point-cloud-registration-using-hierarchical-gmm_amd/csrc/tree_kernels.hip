@@ -1,8 +1,796 @@
-// placeholder, replaced below
+// Hierarchical GMM (8-ary GMM tree, full 3x3 covariances) for gfx950, float64 arithmetic.
+//
+// Replaces the reference's Numba-CUDA kernels (src/python/hgmm/hgmm_gpu.py:107-115, 284-426:
+// one thread per point, 3x3 inverse + determinant recomputed for every (point,node) pair,
+// 104 global float atomics per point per iteration) and follows the semantics of its CPU twin
+// (src/python/hgmm/hgmm_cupy_cpu_working.py:62-228), which is the canonical one.
+//
+//   tree_prep_kernel      once per M-step, per node: Sigma^-1 (6 unique), pi*coef, the
+//                         log-likelihood weight (0 when pi < eps or det < eps) and the
+//                         'complexity' ratio  -- instead of per pair.
+//   partition (hist / offsets / scatter)
+//                         the per-level recursion: after a level converges the points are
+//                         regrouped (stable counting sort) by the child they were assigned to, so
+//                         that at the next level every 256-point chunk shares ONE parent.
+//   tree_estep_kernel     one workgroup per chunk, lanes across points; the 8 children's
+//                         parameters are workgroup-uniform (scalar loads); responsibilities,
+//                         arg-max and the 8 x 10 moment contributions are reduced with DPP wave
+//                         reductions + LDS to one partial per chunk.  No atomics, deterministic.
+//   tree_moments_kernel   fixed-order fp64 reduction of the chunk partials per node -> the
+//                         buffer an RCCL all-reduce works on.
+//   tree_mstep_kernel     ML estimate with the CPU twin's empty-node rule (m0 < ld).
+//   tree_loglik_kernel    q = sum_i log max(sum_j pi_j N(x_i; j), eps) over ALL nodes of the
+//                         level, node table tiled through LDS, wave-uniform skip of far nodes.
+//   tree_reg_estep_kernel registration E-step: per target point descend the tree.
 #include "hgmm_ctx.h"
+#include "wave_ops.h"
+
+#include <cmath>
+#include <vector>
+
+namespace hgmm {
+
+constexpr double TREE_EPS = 1.0e-15;                 // hgmm_cupy_cpu_working.py:29
+constexpr double TWO_PI_POW_1_5 = 15.749609945722419; // (2 pi)^(3/2)
+constexpr int PREP_N = 12;   // i00 i01 i02 i11 i12 i22 | mu0 mu1 mu2 | wE | wL | complexity
+constexpr int CH = 256;      // points per chunk = threads per workgroup
+constexpr int NMOM = 10;     // m0, m1[3], m2 unique[6] (xx xy xz yy yz zz)
+
+__host__ __device__ inline int64_t level_first(int l) {  // 8 (8^l - 1) / 7
+    int64_t p = 1;
+    for (int i = 0; i < l; ++i) p *= 8;
+    return 8 * (p - 1) / 7;
+}
+
+// ------------------------------------------------------------------------------------------
+// per-node preparation
+// ------------------------------------------------------------------------------------------
+__device__ inline double sym3_min_eig_over_trace(double a00, double a01, double a02, double a11,
+                                                 double a12, double a22) {
+    // closed-form eigenvalues of a symmetric 3x3 (trigonometric solution)
+    const double tr = a00 + a11 + a22;
+    const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
+    double e_min;
+    if (p1 == 0.0) {
+        e_min = fmin(a00, fmin(a11, a22));
+    } else {
+        const double q = tr / 3.0;
+        const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
+        const double p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * p1;
+        const double p = sqrt(p2 / 6.0);
+        const double ip = 1.0 / p;
+        const double c00 = b00 * ip, c01 = a01 * ip, c02 = a02 * ip, c11 = b11 * ip, c12 = a12 * ip,
+                     c22 = b22 * ip;
+        double r = 0.5 * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) +
+                          c02 * (c01 * c12 - c11 * c02));
+        r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
+        const double phi = acos(r) / 3.0;
+        e_min = q + 2.0 * p * cos(phi + 2.0943951023931953);   // + 2 pi / 3
+    }
+    return e_min / tr;
+}
+
+__global__ void tree_prep_kernel(const double* __restrict__ pi, const double* __restrict__ mu,
+                                 const double* __restrict__ cov, int64_t j_begin, int64_t j_end,
+                                 double* __restrict__ prep) {
+    const int64_t j = j_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= j_end) return;
+    const double* c = cov + 9 * j;
+    const double c00 = c[0], c01 = c[1], c02 = c[2], c10 = c[3], c11 = c[4], c12 = c[5], c20 = c[6],
+                 c21 = c[7], c22 = c[8];
+    const double det = c00 * (c11 * c22 - c12 * c21) - c01 * (c10 * c22 - c12 * c20) +
+                       c02 * (c10 * c21 - c11 * c20);
+    double* o = prep + PREP_N * j;
+    const double p = pi[j];
+    if (det < TREE_EPS) {           // gaussianPdf returns 0 (hgmm_cupy_cpu_working.py:65-67)
+        o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = 0.0;
+        o[9] = 0.0;
+        o[10] = 0.0;
+    } else {
+        const double id = 1.0 / det;
+        // symmetric part of the adjugate (covariances are symmetric by construction)
+        o[0] = (c11 * c22 - c12 * c21) * id;
+        o[1] = (c02 * c21 - c01 * c22) * id;
+        o[2] = (c01 * c12 - c02 * c11) * id;
+        o[3] = (c00 * c22 - c02 * c20) * id;
+        o[4] = (c02 * c10 - c00 * c12) * id;
+        o[5] = (c00 * c11 - c01 * c10) * id;
+        const double coef = 1.0 / (sqrt(det) * TWO_PI_POW_1_5);
+        o[9] = p * coef;
+        o[10] = (p < TREE_EPS) ? 0.0 : p * coef;   // logLikelihoodValue skips pi < eps (C:80)
+    }
+    o[6] = mu[3 * j + 0]; o[7] = mu[3 * j + 1]; o[8] = mu[3 * j + 2];
+    o[11] = sym3_min_eig_over_trace(c00, c01, c02, c11, c12, c22);
+}
+
+__global__ void tree_init_nodes_kernel(const double* __restrict__ init_mu, double sig2, int64_t T,
+                                       double* pi, double* mu, double* cov) {
+    // pi = 1/8, mu = given, cov = sig2 * I   (hgmm_cupy_cpu_working.py:132-136)
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= T) return;
+    pi[j] = 1.0 / 8.0;
+    for (int d = 0; d < 3; ++d) mu[3 * j + d] = init_mu[3 * j + d];
+    for (int e = 0; e < 9; ++e) cov[9 * j + e] = (e % 4 == 0) ? sig2 : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// chunk table: segment p (points of one parent, contiguous in sorted order) -> ceil(n_p/CH) chunks
+// seg_start[P+1]; chunk_first[P+1] (first chunk id of each parent); chunk_desc[c] = {parent, begin, end}
+// single workgroup (P <= 32768)
+// ------------------------------------------------------------------------------------------
+__global__ void tree_chunks_kernel(const int* __restrict__ seg_start, int P, int* __restrict__ chunk_first,
+                                   int* __restrict__ chunk_desc, int* __restrict__ n_chunks_out) {
+    __shared__ int carry;
+    __shared__ int sh[1024];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < P; base += 1024) {
+        const int p = base + threadIdx.x;
+        int cnt = 0;
+        if (p < P) cnt = (seg_start[p + 1] - seg_start[p] + CH - 1) / CH;
+        sh[threadIdx.x] = cnt;
+        __syncthreads();
+        // inclusive scan (Hillis-Steele)
+        for (int off = 1; off < 1024; off <<= 1) {
+            int v = (threadIdx.x >= (unsigned)off) ? sh[threadIdx.x - off] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const int first = carry + sh[threadIdx.x] - cnt;
+        if (p < P) {
+            chunk_first[p] = first;
+            const int s0 = seg_start[p], s1 = seg_start[p + 1];
+            for (int k = 0; k < cnt; ++k) {
+                int* d = chunk_desc + 3 * (first + k);
+                d[0] = p;
+                d[1] = s0 + k * CH;
+                d[2] = (s0 + (k + 1) * CH < s1) ? s0 + (k + 1) * CH : s1;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += sh[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        chunk_first[P] = carry;
+        *n_chunks_out = carry;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// E-step of one tree level
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CH) void tree_estep_kernel(
+    const double* __restrict__ xs, int64_t n_pad, const double* __restrict__ prep,
+    const int* __restrict__ chunk_desc, const int* __restrict__ n_chunks, int64_t parent_level_first,
+    int level, double* __restrict__ partials, int* __restrict__ cur_sorted) {
+    const int c = blockIdx.x;
+    if (c >= *n_chunks) return;
+    const int p = chunk_desc[3 * c + 0], begin = chunk_desc[3 * c + 1], end = chunk_desc[3 * c + 2];
+    // node id of the parent: level 0 -> pseudo-parent -1; child(j) = 8 (j + 1)
+    const int64_t parent_node = (level == 0) ? -1 : parent_level_first + p;
+    const int64_t j0 = 8 * (parent_node + 1);
+    const int i = begin + (int)threadIdx.x;
+    const bool active = i < end;
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+    if (active) { x0 = xs[i]; x1 = xs[n_pad + i]; x2 = xs[2 * n_pad + i]; }
+
+    double g[8];
+    double den = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const double* pr = prep + PREP_N * (j0 + k);
+        const double d0 = x0 - pr[6], d1 = x1 - pr[7], d2 = x2 - pr[8];
+        const double q = pr[0] * d0 * d0 + pr[3] * d1 * d1 + pr[5] * d2 * d2 +
+                         2.0 * (pr[1] * d0 * d1 + pr[2] * d0 * d2 + pr[4] * d1 * d2);
+        const double wE = pr[9];
+        g[k] = (wE == 0.0) ? 0.0 : wE * exp(-0.5 * q);
+        den += g[k];
+    }
+    // gamma = g / den if den > eps else 0; arg-max = first maximum  (C:174-187)
+    const bool good = den > TREE_EPS;
+    const double inv = good ? 1.0 / den : 0.0;
+    int am = 0;
+    double best = -1.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        g[k] = good ? g[k] / den : 0.0;
+        if (g[k] > best) { best = g[k]; am = k; }
+        if (g[k] < TREE_EPS || !active) g[k] = 0.0;      // accumulate() ignores gamma < eps (C:100)
+    }
+    (void)inv;
+    if (active) cur_sorted[i] = (int)(j0 + am);
+
+    __shared__ double sh[CH / 64][8 * NMOM];
+    const int w = wave_in_block();
+    const int lane = lane_id();
+    const double f[NMOM] = {1.0, x0, x1, x2, x0 * x0, x0 * x1, x0 * x2, x1 * x1, x1 * x2, x2 * x2};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int m = 0; m < NMOM; ++m) {
+            const double v = wave_sum_f64(g[k] * f[m]);
+            if (lane == 0) sh[w][k * NMOM + m] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 * NMOM) {
+        double t = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < CH / 64; ++ww) t += sh[ww][threadIdx.x];
+        partials[(size_t)c * (8 * NMOM) + threadIdx.x] = t;
+    }
+}
+
+// one wave per child node of the level: fixed-order sum of its parent's chunk partials
+__global__ __launch_bounds__(64) void tree_moments_kernel(const double* __restrict__ partials,
+                                                          const int* __restrict__ chunk_first,
+                                                          int n_level_nodes, double* __restrict__ mom) {
+    const int cl = blockIdx.x;            // level-local child index
+    if (cl >= n_level_nodes) return;
+    const int p = cl >> 3, k = cl & 7;
+    const int c0 = chunk_first[p], c1 = chunk_first[p + 1];
+    double acc[NMOM];
+#pragma unroll
+    for (int m = 0; m < NMOM; ++m) acc[m] = 0.0;
+    for (int c = c0 + (int)threadIdx.x; c < c1; c += 64) {
+        const double* src = partials + (size_t)c * (8 * NMOM) + k * NMOM;
+#pragma unroll
+        for (int m = 0; m < NMOM; ++m) acc[m] += src[m];
+    }
+#pragma unroll
+    for (int m = 0; m < NMOM; ++m) {
+        const double v = wave_sum_f64(acc[m]);
+        if (threadIdx.x == 0) mom[(size_t)cl * NMOM + m] = v;
+    }
+}
+
+// ML estimate of the level's nodes (mlEstimator, hgmm_cupy_cpu_working.py:109-119)
+__global__ void tree_mstep_kernel(const double* __restrict__ mom, int64_t lb, int n_level_nodes,
+                                  double n_points_total, double ld, double* pi, double* mu, double* cov) {
+    const int cl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cl >= n_level_nodes) return;
+    const int64_t j = lb + cl;
+    const double* m = mom + (size_t)cl * NMOM;
+    const double m0 = m[0];
+    if (m0 < ld) {
+        pi[j] = 0.0;
+        mu[3 * j] = mu[3 * j + 1] = mu[3 * j + 2] = 0.0;
+        for (int e = 0; e < 9; ++e) cov[9 * j + e] = (e % 4 == 0) ? 1.0 : 0.0;
+        return;
+    }
+    pi[j] = m0 / n_points_total;
+    const double u0 = m[1] / m0, u1 = m[2] / m0, u2 = m[3] / m0;
+    mu[3 * j] = u0; mu[3 * j + 1] = u1; mu[3 * j + 2] = u2;
+    const double s00 = m[4] / m0 - u0 * u0, s01 = m[5] / m0 - u0 * u1, s02 = m[6] / m0 - u0 * u2,
+                 s11 = m[7] / m0 - u1 * u1, s12 = m[8] / m0 - u1 * u2, s22 = m[9] / m0 - u2 * u2;
+    double* c = cov + 9 * j;
+    c[0] = s00; c[1] = s01; c[2] = s02; c[3] = s01; c[4] = s11; c[5] = s12; c[6] = s02; c[7] = s12; c[8] = s22;
+}
+
+// ------------------------------------------------------------------------------------------
+// level log-likelihood over ALL nodes of the level (logLikelihoodValue, C:72-85)
+// ------------------------------------------------------------------------------------------
+constexpr int LL_TILE = 256;
+__global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restrict__ xs, int64_t n,
+                                                         int64_t n_pad, const double* __restrict__ prep,
+                                                         int64_t lb, int n_level_nodes,
+                                                         double* __restrict__ block_q) {
+    __shared__ double tile[LL_TILE][10];
+    __shared__ double shq[CH / 64];
+    const int64_t i = (int64_t)blockIdx.x * CH + threadIdx.x;
+    const bool active = i < n;
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+    if (active) { x0 = xs[i]; x1 = xs[n_pad + i]; x2 = xs[2 * n_pad + i]; }
+    double tot = 0.0;
+    for (int base = 0; base < n_level_nodes; base += LL_TILE) {
+        const int cnt = (n_level_nodes - base < LL_TILE) ? n_level_nodes - base : LL_TILE;
+        __syncthreads();
+        for (int t = threadIdx.x; t < cnt * 10; t += CH) {
+            const int node = t / 10, fidx = t % 10;
+            const double* pr = prep + PREP_N * (lb + base + node);
+            tile[node][fidx] = (fidx < 9) ? pr[fidx] : pr[10];
+        }
+        __syncthreads();
+        for (int node = 0; node < cnt; ++node) {
+            const double wL = tile[node][9];
+            if (wL == 0.0) continue;                                    // workgroup-uniform
+            const double d0 = x0 - tile[node][6], d1 = x1 - tile[node][7], d2 = x2 - tile[node][8];
+            const double q = tile[node][0] * d0 * d0 + tile[node][3] * d1 * d1 + tile[node][5] * d2 * d2 +
+                             2.0 * (tile[node][1] * d0 * d1 + tile[node][2] * d0 * d2 + tile[node][4] * d1 * d2);
+            // exp(-0.5 q) underflows to exactly 0 in float64 beyond q ~ 1490: skip the
+            // transcendental when no lane of the wave needs it (points are sorted spatially)
+            if (__any(q < 1500.0)) tot += wL * exp(-0.5 * q);
+        }
+    }
+    double lq = active ? log(fmax(tot, TREE_EPS)) : 0.0;
+    lq = wave_sum_f64(lq);
+    if (lane_id() == 0) shq[wave_in_block()] = lq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < CH / 64; ++w) t += shq[w];
+        block_q[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void tree_sum_kernel(const double* __restrict__ v, int n, double* out) {
+    // single workgroup, fixed order
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += v[i];
+    acc = wave_sum_f64(acc);
+    if (lane_id() == 0) sh[wave_in_block()] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ------------------------------------------------------------------------------------------
+// partition: regroup the (already parent-grouped) points by the child they were assigned to
+// ------------------------------------------------------------------------------------------
+// per chunk: 8-bin histogram of the child index
+__global__ __launch_bounds__(CH) void tree_hist_kernel(const int* __restrict__ cur_sorted,
+                                                       const int* __restrict__ chunk_desc,
+                                                       const int* __restrict__ n_chunks,
+                                                       int* __restrict__ hist /*[chunks][8]*/) {
+    const int c = blockIdx.x;
+    if (c >= *n_chunks) return;
+    const int begin = chunk_desc[3 * c + 1], end = chunk_desc[3 * c + 2];
+    const int i = begin + (int)threadIdx.x;
+    const int key = (i < end) ? (cur_sorted[i] & 7) : -1;
+    __shared__ int sh[CH / 64][8];
+    const int w = wave_in_block();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned long long m = __ballot(key == k);
+        if (lane_id() == 0) sh[w][k] = __popcll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        int t = 0;
+        for (int ww = 0; ww < CH / 64; ++ww) t += sh[ww][threadIdx.x];
+        hist[c * 8 + threadIdx.x] = t;
+    }
+}
+
+// one thread per parent: new segment sizes + per-chunk write offsets (relative to the parent's
+// segment start, children laid out k = 0..7 inside it)
+__global__ void tree_offsets_kernel(const int* __restrict__ hist, const int* __restrict__ chunk_first,
+                                    const int* __restrict__ seg_start, int P,
+                                    int* __restrict__ chunk_off /*[chunks][8]*/,
+                                    int* __restrict__ new_seg_start /*[8P+1]*/) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int c0 = chunk_first[p], c1 = chunk_first[p + 1];
+    int tot[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot[k] = 0;
+    for (int c = c0; c < c1; ++c)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tot[k] += hist[c * 8 + k];
+    int start[8];
+    int run = seg_start[p];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { start[k] = run; new_seg_start[8 * p + k] = run; run += tot[k]; }
+    if (p == P - 1) new_seg_start[8 * P] = run;
+    int acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = start[k];
+    for (int c = c0; c < c1; ++c)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { chunk_off[c * 8 + k] = acc[k]; acc[k] += hist[c * 8 + k]; }
+}
+
+// stable scatter of coordinates / permutation / (as the new parent) child index
+__global__ __launch_bounds__(CH) void tree_scatter_kernel(
+    const double* __restrict__ xs, int64_t n_pad, const int* __restrict__ perm,
+    const int* __restrict__ cur_sorted, const int* __restrict__ chunk_desc,
+    const int* __restrict__ n_chunks, const int* __restrict__ chunk_off, double* __restrict__ xs_new,
+    int* __restrict__ perm_new) {
+    const int c = blockIdx.x;
+    if (c >= *n_chunks) return;
+    const int begin = chunk_desc[3 * c + 1], end = chunk_desc[3 * c + 2];
+    const int i = begin + (int)threadIdx.x;
+    const bool active = i < end;
+    const int key = active ? (cur_sorted[i] & 7) : -1;
+    __shared__ int sh[CH / 64][8];
+    const int w = wave_in_block(), lane = lane_id();
+    int rank_in_wave = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned long long m = __ballot(key == k);
+        if (key == k) rank_in_wave = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) sh[w][k] = __popcll(m);
+    }
+    __syncthreads();
+    if (!active) return;
+    int before = 0;
+    for (int ww = 0; ww < w; ++ww) before += sh[ww][key];
+    const int dst = chunk_off[c * 8 + key] + before + rank_in_wave;
+    xs_new[dst] = xs[i];
+    xs_new[n_pad + dst] = xs[n_pad + i];
+    xs_new[2 * n_pad + dst] = xs[2 * n_pad + i];
+    perm_new[dst] = perm[i];
+}
+
+__global__ void tree_iota_kernel(int* perm, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) perm[i] = (int)i;
+}
+__global__ void tree_unsort_kernel(const int* __restrict__ perm, const int* __restrict__ cur_sorted,
+                                   int64_t n, int* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[perm[i]] = cur_sorted[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// registration E-step (gmmTreeRegESTep, hgmm_cupy_cpu_working.py:202-228)
+// ------------------------------------------------------------------------------------------
+struct Rigid { double r[9]; double t[3]; double s; };
+
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+__global__ __launch_bounds__(CH) void tree_reg_estep_kernel(const double* __restrict__ tg, int64_t n,
+                                                            int64_t n_pad, Rigid tf,
+                                                            const double* __restrict__ prep, int L,
+                                                            double lambda_c, double* __restrict__ mom) {
+    const int64_t i = (int64_t)blockIdx.x * CH + threadIdx.x;
+    bool alive = i < n;
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+    if (alive) {
+        const double a = tg[i], b = tg[n_pad + i], c = tg[2 * n_pad + i];
+        x0 = tf.s * (tf.r[0] * a + tf.r[1] * b + tf.r[2] * c) + tf.t[0];
+        x1 = tf.s * (tf.r[3] * a + tf.r[4] * b + tf.r[5] * c) + tf.t[1];
+        x2 = tf.s * (tf.r[6] * a + tf.r[7] * b + tf.r[8] * c) + tf.t[2];
+    }
+    int64_t search = -1;
+    for (int l = 0; l < L; ++l) {
+        if (!__any(alive)) break;
+        const int64_t j0 = 8 * (search + 1);
+        double g[8];
+        double den = 0.0;
+        if (alive) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const double* pr = prep + PREP_N * (j0 + k);
+                const double d0 = x0 - pr[6], d1 = x1 - pr[7], d2 = x2 - pr[8];
+                const double q = pr[0] * d0 * d0 + pr[3] * d1 * d1 + pr[5] * d2 * d2 +
+                                 2.0 * (pr[1] * d0 * d1 + pr[2] * d0 * d2 + pr[4] * d1 * d2);
+                const double wE = pr[9];
+                g[k] = (wE == 0.0) ? 0.0 : wE * exp(-0.5 * q);
+                den += g[k];
+            }
+        }
+        double gs = 0.0;
+        int64_t s = 0;
+        bool contribute = false;
+        if (alive) {
+            const bool good = den > TREE_EPS;
+            int am = 0;
+            double best = -1.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const double gk = good ? g[k] / den : 0.0;
+                if (gk > best) { best = gk; am = k; }
+            }
+            s = j0 + am;
+            search = s;
+            if (prep[PREP_N * s + 11] <= lambda_c) {       // complexity(cov_s) <= lambda_c: stop
+                alive = false;
+            } else {
+                gs = best;
+                contribute = !(gs < TREE_EPS);
+            }
+        }
+        // combine lanes that hit the same node before touching HBM: up to 8 leader rounds of
+        // wave reductions, whatever is left goes out as per-lane atomics
+        const double f[NMOM] = {1.0, x0, x1, x2, x0 * x0, x0 * x1, x0 * x2, x1 * x1, x1 * x2, x2 * x2};
+        bool pending = contribute;
+        for (int round = 0; round < 8; ++round) {
+            const unsigned long long pm = __ballot(pending);
+            if (pm == 0ull) break;
+            const int leader = __ffsll((long long)pm) - 1;
+            const int64_t node = __shfl(s, leader);
+            const bool mine = pending && (s == node);
+#pragma unroll
+            for (int m = 0; m < NMOM; ++m) {
+                const double v = wave_sum_f64(mine ? gs * f[m] : 0.0);
+                if (lane_id() == leader) atomic_add_f64(mom + NMOM * node + m, v);
+            }
+            if (mine) pending = false;
+        }
+        if (pending) {
+#pragma unroll
+            for (int m = 0; m < NMOM; ++m) atomic_add_f64(mom + NMOM * s + m, gs * f[m]);
+        }
+    }
+}
+
+// expand the 10 unique moments into the reference layout m0[T], m1[T,3], m2[T,3,3]
+__global__ void tree_expand_moments_kernel(const double* __restrict__ mom, int64_t T, double* m0,
+                                           double* m1, double* m2) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= T) return;
+    const double* m = mom + NMOM * j;
+    m0[j] = m[0];
+    m1[3 * j] = m[1]; m1[3 * j + 1] = m[2]; m1[3 * j + 2] = m[3];
+    double* o = m2 + 9 * j;
+    o[0] = m[4]; o[1] = m[5]; o[2] = m[6]; o[3] = m[5]; o[4] = m[7]; o[5] = m[8]; o[6] = m[6]; o[7] = m[8]; o[8] = m[9];
+}
+
+__global__ void tree_copy_cplx_kernel(const double* __restrict__ prep, int64_t T, double* out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < T) out[j] = prep[PREP_N * j + 11];
+}
+
+// ------------------------------------------------------------------------------------------
+// host driver
+// ------------------------------------------------------------------------------------------
+static unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
+
+static int tree_alloc_nodes(hgmm_ctx* c, int L) {
+    const int64_t T = level_first(L);
+    c->tree.L = L;
+    c->tree.T = (int)T;
+    HGMM_TRY(ensure(c, c->t_pi, sizeof(double) * T));
+    HGMM_TRY(ensure(c, c->t_mu, sizeof(double) * 3 * T));
+    HGMM_TRY(ensure(c, c->t_cov, sizeof(double) * 9 * T));
+    HGMM_TRY(ensure(c, c->t_prep, sizeof(double) * PREP_N * T));
+    HGMM_TRY(ensure(c, c->t_mom, sizeof(double) * NMOM * T));
+    return HGMM_OK;
+}
+
+static int tree_prep(hgmm_ctx* c, int64_t jb, int64_t je) {
+    tree_prep_kernel<<<nblk(je - jb, 256), 256, 0, c->stream>>>(c->t_pi.as<double>(), c->t_mu.as<double>(),
+                                                               c->t_cov.as<double>(), jb, je,
+                                                               c->t_prep.as<double>());
+    HGMM_HIP(c, hipGetLastError());
+    return HGMM_OK;
+}
+
+}  // namespace hgmm
+
 using namespace hgmm;
-extern "C" int hgmm_tree_build(hgmm_ctx* c, int, double, double, const double*, double, int, double*, double*, double*, int32_t*, int32_t*, double*, int, int*) { return fail(c, HGMM_ERR_STATE, "tree not built yet"); }
-extern "C" int hgmm_tree_set_nodes(hgmm_ctx* c, int, const double*, const double*, const double*) { return fail(c, HGMM_ERR_STATE, "tree not built yet"); }
-extern "C" int hgmm_tree_set_target(hgmm_ctx* c, const double*, int64_t) { return fail(c, HGMM_ERR_STATE, "tree not built yet"); }
-extern "C" int hgmm_tree_reg_estep(hgmm_ctx* c, const double*, const double*, double, double, double*, double*, double*) { return fail(c, HGMM_ERR_STATE, "tree not built yet"); }
-extern "C" int hgmm_tree_node_complexity(hgmm_ctx* c, double*) { return fail(c, HGMM_ERR_STATE, "tree not built yet"); }
+
+extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const double* init_mu,
+                               double sig2, int max_iters_per_level, double* pi_out, double* mu_out,
+                               double* cov_out, int32_t* leaf_idx_out, int32_t* iters_per_level_out,
+                               double* q_trace_out, int q_capacity, int* q_len_out) {
+    if (!c) return HGMM_ERR_ARG;
+    if (!c->have_f64 || c->n <= 0) return fail(c, HGMM_ERR_STATE, "tree build: set points first");
+    if (L < 1 || L > 6) return fail(c, HGMM_ERR_ARG, "tree levels L = %d outside 1..6", L);
+    if (!init_mu) return fail(c, HGMM_ERR_ARG, "init_mu is NULL");
+    if (c->n > 0x7fffffff - 1024) return fail(c, HGMM_ERR_ARG, "too many points for 32-bit indices");
+    if (max_iters_per_level < 1) max_iters_per_level = 1;
+    HGMM_HIP(c, hipSetDevice(c->device));
+    HGMM_TRY(tree_alloc_nodes(c, L));
+    const int64_t T = c->tree.T;
+    const int64_t n = c->n, n_pad = c->n_pad;
+    int64_t maxP = 1;
+    for (int i = 0; i < L - 1; ++i) maxP *= 8;                 // parents at the last level
+    const int64_t max_chunks = n / CH + maxP + 8;
+    // buffers
+    HGMM_TRY(ensure(c, c->scratch, sizeof(double) * 3 * T));
+    HGMM_TRY(ensure(c, c->t_current, sizeof(int) * n_pad));
+    HGMM_TRY(ensure(c, c->t_perm, sizeof(int) * 2 * n_pad));                 // ping-pong
+    HGMM_TRY(ensure(c, c->t_parent, sizeof(double) * 3 * n_pad));            // second coordinate buffer
+    HGMM_TRY(ensure(c, c->t_seg, sizeof(int) * (2 * (8 * maxP + 2) + 2 * (maxP + 2) + 8)));
+    HGMM_TRY(ensure(c, c->t_chunks, sizeof(int) * (size_t)(3 + 8 + 8) * max_chunks));
+    HGMM_TRY(ensure(c, c->t_partials, sizeof(double) * (size_t)8 * NMOM * max_chunks));
+    HGMM_TRY(ensure(c, c->t_q, sizeof(double) * (nblk(n, CH) + 8)));
+
+    double* d_pi = c->t_pi.as<double>();
+    double* d_mu = c->t_mu.as<double>();
+    double* d_cov = c->t_cov.as<double>();
+    double* d_prep = c->t_prep.as<double>();
+    double* d_mom = c->t_mom.as<double>();
+    // coordinate ping-pong: A = x_soa64 (original order == sorted order at level 0), B = t_parent
+    double* xs_a = c->x_soa64.as<double>();
+    double* xs_b = c->t_parent.as<double>();
+    int* perm_a = c->t_perm.as<int>();
+    int* perm_b = perm_a + n_pad;
+    int* cur = c->t_current.as<int>();
+    int* seg_a = c->t_seg.as<int>();
+    int* seg_b = seg_a + (8 * maxP + 2);
+    int* chunk_first = seg_b + (8 * maxP + 2);
+    int* n_chunks_dev = chunk_first + (maxP + 2) * 2;
+    int* chunk_desc = c->t_chunks.as<int>();
+    int* hist = chunk_desc + 3 * max_chunks;
+    int* chunk_off = hist + 8 * max_chunks;
+    double* partials = c->t_partials.as<double>();
+    double* block_q = c->t_q.as<double>();
+    double* q_dev = block_q + nblk(n, CH);
+
+    // the level-0 "sorted" coordinates must not alias the resident cloud once we start
+    // scattering, so keep x_soa64 read-only: first scatter goes A -> B, later ones B <-> scratch2
+    hgmm::DevBuf& xs_c_buf = c->tgt_soa64;   // reuse lazily? no: dedicated third buffer below
+    (void)xs_c_buf;
+
+    HGMM_HIP(c, hipMemcpyAsync(c->scratch.p, init_mu, sizeof(double) * 3 * T, hipMemcpyHostToDevice, c->stream));
+    tree_init_nodes_kernel<<<nblk(T, 256), 256, 0, c->stream>>>(c->scratch.as<double>(), sig2, T, d_pi, d_mu, d_cov);
+    HGMM_TRY(tree_prep(c, 0, T));
+    tree_iota_kernel<<<nblk(n, 256), 256, 0, c->stream>>>(perm_a, n);
+    const int seg0[2] = {0, (int)n};
+    HGMM_HIP(c, hipMemcpyAsync(seg_a, seg0, sizeof seg0, hipMemcpyHostToDevice, c->stream));
+    HGMM_HIP(c, hipGetLastError());
+
+    // global point count (pi = m0 / N_total)
+    double n_total = (double)n;
+    if (c->comm) {
+        HGMM_TRY(hgmm_comm_allreduce_f64(c, &n_total, 1, 0));
+    }
+
+    // third coordinate buffer so that x_soa64 is never overwritten
+    hgmm::DevBuf xs_c_owner;
+    double* xs_c = nullptr;
+    if (L > 2) {
+        HGMM_HIP(c, hipMalloc(&xs_c_owner.p, sizeof(double) * 3 * n_pad));
+        xs_c = xs_c_owner.as<double>();
+    }
+    auto cleanup = [&]() { if (xs_c_owner.p) (void)hipFree(xs_c_owner.p); };
+
+    const double* xs_cur = xs_a;
+    int* perm_cur = perm_a;
+    int* seg_cur = seg_a;
+    int P = 1;
+    int q_len = 0;
+    int rc = HGMM_OK;
+    for (int l = 0; l < L && rc == HGMM_OK; ++l) {
+        const int64_t lb = level_first(l), le = level_first(l + 1);
+        const int n_level = (int)(le - lb);
+        const int64_t parent_first = (l == 0) ? 0 : level_first(l - 1);
+        tree_chunks_kernel<<<1, 1024, 0, c->stream>>>(seg_cur, P, chunk_first, chunk_desc, n_chunks_dev);
+        const unsigned grid_chunks = (unsigned)(n / CH + P + 1);
+        double prev_q = 0.0;
+        int it = 0;
+        while (true) {
+            {
+                ProfScope prof(c, HGMM_K_TREE_ESTEP);
+                tree_estep_kernel<<<grid_chunks, CH, 0, c->stream>>>(xs_cur, n_pad, d_prep, chunk_desc, n_chunks_dev,
+                                                                    parent_first, l, partials, cur);
+            }
+            tree_moments_kernel<<<n_level, 64, 0, c->stream>>>(partials, chunk_first, n_level, d_mom + NMOM * lb);
+            if (c->comm) {
+                rc = allreduce_f64_dev(c, d_mom + NMOM * lb, (size_t)NMOM * n_level);
+                if (rc != HGMM_OK) break;
+            }
+            tree_mstep_kernel<<<nblk(n_level, 256), 256, 0, c->stream>>>(d_mom + NMOM * lb, lb, n_level, n_total, ld,
+                                                                         d_pi, d_mu, d_cov);
+            tree_prep_kernel<<<nblk(n_level, 256), 256, 0, c->stream>>>(d_pi, d_mu, d_cov, lb, le, d_prep);
+            {
+                ProfScope prof(c, HGMM_K_TREE_LOGLIK);
+                tree_loglik_kernel<<<nblk(n, CH), CH, 0, c->stream>>>(xs_cur, n, n_pad, d_prep, lb, n_level, block_q);
+            }
+            tree_sum_kernel<<<1, 256, 0, c->stream>>>(block_q, (int)nblk(n, CH), q_dev);
+            if (c->comm) {
+                rc = allreduce_f64_dev(c, q_dev, 1);
+                if (rc != HGMM_OK) break;
+            }
+            double q = 0.0;
+            if (hipMemcpyAsync(&q, q_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess) {
+                rc = fail(c, HGMM_ERR_HIP, "tree build: device error: %s", hipGetErrorString(hipGetLastError()));
+                break;
+            }
+            ++it;
+            if (q_trace_out && q_len < q_capacity) q_trace_out[q_len] = q;
+            ++q_len;
+            if (fabs(q - prev_q) < ls || it >= max_iters_per_level) break;   // C:155-157
+            prev_q = q;
+        }
+        if (rc != HGMM_OK) break;
+        if (iters_per_level_out) iters_per_level_out[l] = it;
+        if (l + 1 < L) {
+            // partition for the next level
+            tree_hist_kernel<<<grid_chunks, CH, 0, c->stream>>>(cur, chunk_desc, n_chunks_dev, hist);
+            int* seg_next = (seg_cur == seg_a) ? seg_b : seg_a;
+            tree_offsets_kernel<<<nblk(P, 128), 128, 0, c->stream>>>(hist, chunk_first, seg_cur, P, chunk_off, seg_next);
+            double* xs_next = (xs_cur == xs_a) ? xs_b : ((xs_cur == xs_b) ? (xs_c ? xs_c : xs_b) : xs_b);
+            int* perm_next = (perm_cur == perm_a) ? perm_b : perm_a;
+            tree_scatter_kernel<<<grid_chunks, CH, 0, c->stream>>>(xs_cur, n_pad, perm_cur, cur, chunk_desc, n_chunks_dev,
+                                                                  chunk_off, xs_next, perm_next);
+            HGMM_HIP(c, hipGetLastError());
+            xs_cur = xs_next;
+            perm_cur = perm_next;
+            seg_cur = seg_next;
+            P *= 8;
+        } else if (leaf_idx_out) {
+            int* out_dev = (perm_cur == perm_a) ? perm_b : perm_a;
+            tree_unsort_kernel<<<nblk(n, 256), 256, 0, c->stream>>>(perm_cur, cur, n, out_dev);
+            if (hipMemcpyAsync(leaf_idx_out, out_dev, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+                rc = fail(c, HGMM_ERR_HIP, "tree build: leaf index download failed");
+        }
+    }
+    if (rc == HGMM_OK) {
+        hipError_t e = hipSuccess;
+        if (pi_out) e = hipMemcpyAsync(pi_out, d_pi, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && mu_out) e = hipMemcpyAsync(mu_out, d_mu, sizeof(double) * 3 * T, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && cov_out) e = hipMemcpyAsync(cov_out, d_cov, sizeof(double) * 9 * T, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(c, HGMM_ERR_HIP, "tree build: download failed: %s", hipGetErrorString(e));
+    } else {
+        (void)hipStreamSynchronize(c->stream);
+    }
+    cleanup();
+    if (q_len_out) *q_len_out = q_len < q_capacity ? q_len : q_capacity;
+    if (rc == HGMM_OK) c->tree.nodes_ready = true;
+    return rc;
+}
+
+extern "C" int hgmm_tree_set_nodes(hgmm_ctx* c, int L, const double* pi, const double* mu, const double* cov) {
+    if (!c || !pi || !mu || !cov) return c ? fail(c, HGMM_ERR_ARG, "NULL node table") : HGMM_ERR_ARG;
+    if (L < 1 || L > 6) return fail(c, HGMM_ERR_ARG, "tree levels L = %d outside 1..6", L);
+    HGMM_HIP(c, hipSetDevice(c->device));
+    HGMM_TRY(tree_alloc_nodes(c, L));
+    const int64_t T = c->tree.T;
+    HGMM_HIP(c, hipMemcpyAsync(c->t_pi.p, pi, sizeof(double) * T, hipMemcpyHostToDevice, c->stream));
+    HGMM_HIP(c, hipMemcpyAsync(c->t_mu.p, mu, sizeof(double) * 3 * T, hipMemcpyHostToDevice, c->stream));
+    HGMM_HIP(c, hipMemcpyAsync(c->t_cov.p, cov, sizeof(double) * 9 * T, hipMemcpyHostToDevice, c->stream));
+    HGMM_TRY(tree_prep(c, 0, T));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    c->tree.nodes_ready = true;
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_tree_set_target(hgmm_ctx* c, const double* xyz, int64_t n) {
+    if (!c || !xyz) return c ? fail(c, HGMM_ERR_ARG, "xyz is NULL") : HGMM_ERR_ARG;
+    if (n <= 0) return fail(c, HGMM_ERR_ARG, "target must have at least one point");
+    HGMM_HIP(c, hipSetDevice(c->device));
+    const int64_t n_pad = (n + 255) / 256 * 256;
+    HGMM_TRY(ensure(c, c->tgt_soa64, sizeof(double) * 3 * n_pad));
+    std::vector<double> soa((size_t)3 * n_pad, 0.0);
+    for (int64_t i = 0; i < n; ++i)
+        for (int d = 0; d < 3; ++d) soa[(size_t)d * n_pad + i] = xyz[3 * i + d];
+    HGMM_HIP(c, hipMemcpyAsync(c->tgt_soa64.p, soa.data(), sizeof(double) * soa.size(), hipMemcpyHostToDevice, c->stream));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    c->tgt_n = n;
+    c->tgt_pad = n_pad;
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_tree_reg_estep(hgmm_ctx* c, const double* rot, const double* t, double scale,
+                                   double lambda_c, double* m0_out, double* m1_out, double* m2_out) {
+    if (!c) return HGMM_ERR_ARG;
+    if (!c->tree.nodes_ready) return fail(c, HGMM_ERR_STATE, "registration E-step: no tree (build or set_nodes first)");
+    if (c->tgt_n <= 0) return fail(c, HGMM_ERR_STATE, "registration E-step: call hgmm_tree_set_target first");
+    HGMM_HIP(c, hipSetDevice(c->device));
+    const int64_t T = c->tree.T;
+    Rigid tf;
+    for (int i = 0; i < 9; ++i) tf.r[i] = rot ? rot[i] : ((i % 4 == 0) ? 1.0 : 0.0);
+    for (int i = 0; i < 3; ++i) tf.t[i] = t ? t[i] : 0.0;
+    tf.s = scale;
+    double* mom = c->t_mom.as<double>();
+    HGMM_HIP(c, hipMemsetAsync(mom, 0, sizeof(double) * NMOM * T, c->stream));
+    {
+        ProfScope prof(c, HGMM_K_TREE_REG);
+        tree_reg_estep_kernel<<<nblk(c->tgt_n, CH), CH, 0, c->stream>>>(c->tgt_soa64.as<double>(), c->tgt_n, c->tgt_pad,
+                                                                        tf, c->t_prep.as<double>(), c->tree.L,
+                                                                        lambda_c, mom);
+    }
+    HGMM_HIP(c, hipGetLastError());
+    if (c->comm) HGMM_TRY(allreduce_f64_dev(c, mom, (size_t)NMOM * T));
+    HGMM_TRY(ensure(c, c->scratch, sizeof(double) * 13 * T));
+    double* e0 = c->scratch.as<double>();
+    double* e1 = e0 + T;
+    double* e2 = e1 + 3 * T;
+    tree_expand_moments_kernel<<<nblk(T, 256), 256, 0, c->stream>>>(mom, T, e0, e1, e2);
+    HGMM_HIP(c, hipGetLastError());
+    if (m0_out) HGMM_HIP(c, hipMemcpyAsync(m0_out, e0, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
+    if (m1_out) HGMM_HIP(c, hipMemcpyAsync(m1_out, e1, sizeof(double) * 3 * T, hipMemcpyDeviceToHost, c->stream));
+    if (m2_out) HGMM_HIP(c, hipMemcpyAsync(m2_out, e2, sizeof(double) * 9 * T, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_tree_node_complexity(hgmm_ctx* c, double* cplx_out) {
+    if (!c || !cplx_out) return c ? fail(c, HGMM_ERR_ARG, "cplx_out is NULL") : HGMM_ERR_ARG;
+    if (!c->tree.nodes_ready) return fail(c, HGMM_ERR_STATE, "no tree");
+    const int64_t T = c->tree.T;
+    HGMM_TRY(ensure(c, c->t_cplx, sizeof(double) * T));
+    tree_copy_cplx_kernel<<<nblk(T, 256), 256, 0, c->stream>>>(c->t_prep.as<double>(), T, c->t_cplx.as<double>());
+    HGMM_HIP(c, hipGetLastError());
+    HGMM_HIP(c, hipMemcpyAsync(cplx_out, c->t_cplx.p, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    return HGMM_OK;
+}

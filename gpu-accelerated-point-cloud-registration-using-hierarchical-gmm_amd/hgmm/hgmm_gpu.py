@@ -1,0 +1,234 @@
+"""Drop-in for the reference's ``src/python/hgmm/hgmm_gpu.py`` (and its CPU twin
+``hgmm_cupy_cpu_working.py``): ``buildGMMTree``, ``GMMTree``, ``registration_gmmtree``,
+``RigidTransformation`` with the same signatures and return values.
+
+What runs where
+  * tree construction (E-step, M-step, level log-likelihood, the per-level partition) and the
+    registration E-step (tree descent + moment accumulation): HIP kernels, float64
+    (csrc/tree_kernels.hip) -- the reference ran the latter as a pure-Python triple loop
+    (hgmm_gpu.py:550-577);
+  * the rigid update (per-node eigh + 6-dof twist least squares, hgmm_gpu.py:729-752) stays on
+    the host in NumPy, as in the reference.
+
+Semantics follow the CPU twin where the two reference files differ (empty-node rule m0 < ld;
+the Numba file has it commented out, hgmm_gpu.py:250-256).  Initialisation constants default
+to the Numba file's (seed 72, sig2 = 0.004, hgmm_gpu.py:469-477) and can be overridden.
+"""
+from __future__ import annotations
+
+import abc
+import time
+from collections import namedtuple
+
+import numpy as np
+
+from .._native import Context, default_context
+
+eps = np.float32(1.0e-15)     # hgmm_gpu.py:29
+n_node = 8                    # hgmm_gpu.py:30
+
+
+def child2(j):
+    return (j + 1) * n_node
+
+
+def level(l):
+    """First node index of level l (hgmm_gpu.py:91-92)."""
+    return n_node * (np.power(n_node, l) - 1) / (n_node - 1)
+
+
+def n_total_nodes(maxTreeLevel):
+    return int(n_node * (np.power(n_node, maxTreeLevel) - 1) / (n_node - 1))
+
+
+def complexity(cov):
+    """smallest eigenvalue / trace (hgmm_gpu.py:78-82)."""
+    lam = np.linalg.eigvalsh(np.asarray(cov, dtype=np.float64))
+    return lam[0] / np.sum(lam)
+
+
+def _points(x):
+    return np.asarray(x.points if hasattr(x, "points") else x)
+
+
+def buildGMMTree(points, maxTreeLevel, ls, ld, sig2=0.004, seed=72, init_idx=None,
+                 max_iters_per_level=1000, ctx: Context | None = None, return_trace=False):
+    """-> (mixingCoeff[T], mean[T,3], covar[T,3,3])   (hgmm_gpu.py:466-548).
+
+    ``init_idx`` (T indices into ``points``) overrides the reference's
+    ``np.random.seed(72); randint(nTotal, size=nTotal)`` draw."""
+    ctx = ctx or default_context()
+    P = np.ascontiguousarray(_points(points), dtype=np.float64)
+    T = n_total_nodes(maxTreeLevel)
+    if init_idx is None:
+        rs = np.random.RandomState(seed)
+        init_idx = rs.randint(T, size=T)
+    ctx.set_points(P)
+    pi, mu, cov, leaf, iters, q = ctx.tree_build(maxTreeLevel, ls, ld, P[np.asarray(init_idx)], sig2,
+                                                 max_iters_per_level)
+    if return_trace:
+        return pi, mu, cov, {"leaf_idx": leaf, "iters_per_level": iters, "q_trace": q}
+    return pi, mu, cov
+
+
+def gmmTreeRegESTep(points, mixingCoeff, mean, covar, maxTreeLevel, lc, ctx: Context | None = None):
+    """-> (momentsZero[T], momentsOne[T,3], momentsTwo[T,3,3])   (hgmm_gpu.py:550-577)."""
+    ctx = ctx or default_context()
+    ctx.tree_set_nodes(maxTreeLevel, mixingCoeff, mean, covar)
+    ctx.tree_set_target(_points(points))
+    return ctx.tree_reg_estep(n_total_nodes(maxTreeLevel), lambda_c=lc)
+
+
+class Transformation(abc.ABC):
+    def transform(self, points, array_type=None):
+        if array_type is not None and isinstance(points, array_type):
+            return array_type(self._transform(np.asarray(points)))
+        return self._transform(points)
+
+    @abc.abstractmethod
+    def _transform(self, points):
+        return points
+
+
+class RigidTransformation(Transformation):
+    """scale * X R^T + t   (hgmm_gpu.py:599-618)."""
+
+    def __init__(self, rot=np.identity(3), t=np.zeros(3), scale=1.0):
+        self.rot = rot
+        self.t = t
+        self.scale = scale
+
+    def _transform(self, points):
+        return self.scale * np.dot(points, self.rot.T) + self.t
+
+    def inverse(self):
+        return RigidTransformation(self.rot.T, -np.dot(self.rot.T, self.t), 1.0 / self.scale)
+
+
+def skew(x):
+    return np.array([[0.0, -x[2], x[1]], [x[2], 0.0, -x[0]], [-x[1], x[0], 0.0]])
+
+
+def twist_trans(tw, linear=False):
+    """twist -> (R, t), Rodrigues (hgmm_gpu.py:646-664)."""
+    if linear:
+        return np.identity(3) + skew(tw[:3]), tw[3:]
+    twd = np.linalg.norm(tw[:3])
+    if twd == 0.0:
+        return np.identity(3), tw[3:]
+    ntw = tw[:3] / twd
+    c, s = np.cos(twd), np.sin(twd)
+    return c * np.identity(3) + (1.0 - c) * np.outer(ntw, ntw) + s * skew(ntw), tw[3:]
+
+
+def twist_mul(tw, rot, t, linear=False):
+    tr, tt = twist_trans(tw, linear=linear)
+    return np.dot(tr, rot), np.dot(t, tr.T) + tt
+
+
+EstepResult = namedtuple('EstepResult', ['momentZero', 'momentOne', 'momentTwo'])
+MstepResult = namedtuple('MstepResult', ['transformation', 'q'])
+
+
+class GMMTree():
+    """GMM tree registration (hgmm_gpu.py:669-768).
+
+    Args mirror the reference; ``ls`` / ``ld`` / ``sig2`` / ``init_idx`` expose the constants it
+    hard-codes (20, 1e-4, 0.004, seed 72)."""
+
+    def __init__(self, source=None, tree_level=5, lambda_c=0.01, ls=20, ld=1.0e-4, sig2=0.004,
+                 init_idx=None, ctx: Context | None = None, verbose=False):
+        self._source = None
+        self._tree_level = tree_level
+        self._lambda_c = lambda_c
+        self._ls, self._ld, self._sig2, self._init_idx = ls, ld, sig2, init_idx
+        self._tf_type = RigidTransformation
+        self._tf_result = self._tf_type()
+        self._callbacks = []
+        self._ctx_arg = ctx
+        self._verbose = verbose
+        self._target_id = None
+        if source is not None:
+            self.set_source(source)
+
+    @property
+    def _ctx(self):
+        if self._ctx_arg is None:
+            self._ctx_arg = default_context()
+        return self._ctx_arg
+
+    def set_source(self, source):
+        self._source = _points(source)
+        t1 = time.time()
+        self._mixingCoeff, self._mean, self._covar = buildGMMTree(
+            self._source, self._tree_level, self._ls, self._ld, sig2=self._sig2,
+            init_idx=self._init_idx, ctx=self._ctx)
+        if self._verbose:
+            print("Build tree Time: ", time.time() - t1)
+
+    def set_nodes(self, mixingCoeff, mean, covar):
+        """Use an existing tree (e.g. a saved one) instead of building from a source cloud."""
+        self._mixingCoeff = np.asarray(mixingCoeff, dtype=np.float64)
+        self._mean = np.asarray(mean, dtype=np.float64)
+        self._covar = np.asarray(covar, dtype=np.float64)
+
+    def set_callbacks(self, callbacks):
+        self._callbacks = callbacks
+
+    def expectation_step(self, target=None):
+        """With ``target`` given: E-step on that (already transformed) cloud, like the reference.
+        Inside :meth:`registration` the resident target is transformed on the device instead."""
+        T = len(self._mixingCoeff)
+        if target is not None:
+            self._ctx.tree_set_target(_points(target))
+            self._target_id = None
+            m = self._ctx.tree_reg_estep(T, lambda_c=self._lambda_c)
+        else:
+            tf = self._tf_result
+            m = self._ctx.tree_reg_estep(T, tf.rot, tf.t, tf.scale, self._lambda_c)
+        return EstepResult(*m)
+
+    def maximization_step(self, estep_res, trans_p):
+        """Twist least squares over the nodes that received mass (hgmm_gpu.py:729-752)."""
+        m0, m1 = estep_res.momentZero, estep_res.momentOne
+        n = len(self._mixingCoeff)
+        amat = np.zeros((n * 3, 6))
+        bmat = np.zeros(n * 3)
+        live = np.nonzero(~(m0 < np.finfo(np.float32).eps))[0]
+        if len(live):
+            lmd, nn = np.linalg.eigh(self._covar[live])              # batched
+            s = m1[live] / m0[live][:, None]
+            nn = nn * np.sqrt(m0[live][:, None] / lmd)[:, None, :]
+            nnT = np.transpose(nn, (0, 2, 1))
+            b = np.einsum('nij,nj->ni', nnT, self._mean[live]) - np.einsum('nij,nj->ni', nnT, s)
+            rows = (3 * live[:, None] + np.arange(3)[None, :]).ravel()
+            bmat[rows] = b.ravel()
+            amat[rows, :3] = np.cross(s[:, None, :], nnT).reshape(-1, 3)
+            amat[rows, 3:] = nnT.reshape(-1, 3)
+        x, q, _, _ = np.linalg.lstsq(amat, bmat, rcond=-1)
+        rot, t = twist_mul(x, trans_p.rot, trans_p.t)
+        return MstepResult(RigidTransformation(rot, t), q)
+
+    def registration(self, target, maxiter=20, tol=1.0e-4):
+        """-> MstepResult(tf.inverse(), q)   (hgmm_gpu.py:754-768)."""
+        self._ctx.tree_set_nodes(self._tree_level, self._mixingCoeff, self._mean, self._covar)
+        self._ctx.tree_set_target(_points(target))
+        q = None
+        res = None
+        for _ in range(maxiter):
+            estep_res = self.expectation_step()          # target transformed on the device
+            res = self.maximization_step(estep_res, self._tf_result)
+            self._tf_result = res.transformation
+            for c in self._callbacks:
+                c(self._tf_result.inverse())
+            if q is not None and np.size(q) and np.size(res.q) and abs(res.q - q) < tol:
+                break
+            q = res.q
+        return MstepResult(self._tf_result.inverse(), res.q)
+
+
+def registration_gmmtree(source, target, maxiter=20, tol=1.0e-4, callbacks=[], **kargs):
+    """hgmm_gpu.py:802-807."""
+    gt = GMMTree(_points(source), **kargs)
+    gt.set_callbacks(callbacks)
+    return gt.registration(_points(target), maxiter, tol)

@@ -1,0 +1,183 @@
+"""GPU parity tests of the hierarchical-GMM path (HIP kernels via the C ABI) against the CPU
+oracle and the golden vectors produced by the reference's CPU twin.
+
+Arithmetic is float64 on both sides; differences come only from summation order, so the
+tolerances are tight (1e-9 relative on q, 1e-10 on parameters) and hard assignments / iteration
+counts must be identical."""
+import time
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import hgmm_tree
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import hgmm_amd
+    c = hgmm_amd.Context(0)
+    yield c
+    c.close()
+
+
+def build(ctx, P, L, ls, ld, init_idx, sig2, max_iters=1000):
+    ctx.set_points(np.asarray(P, dtype=np.float64))
+    return ctx.tree_build(L, ls, ld, np.asarray(P, dtype=np.float64)[init_idx], sig2, max_iters)
+
+
+@pytest.mark.parametrize("name", ["hgmm_build_L2.npz", "hgmm_build_L3.npz"])
+def test_build_matches_reference_golden(ctx, name):
+    g = load_golden(name)
+    P, L = g["points"], int(g["L"])
+    pi, mu, cov, leaf, iters, q = build(ctx, P, L, float(g["ls"]), float(g["ld"]), g["init_idx"], float(g["sig2"]))
+    assert list(iters) == list(g["iters_per_level"])
+    np.testing.assert_allclose(q, g["q_trace"], rtol=1e-9, atol=1e-6)
+    assert np.array_equal(leaf, g["current_idx_L%d" % (L - 1)])
+    np.testing.assert_allclose(pi, g["pi"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(mu, g["mu"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(cov, g["cov"], rtol=1e-7, atol=1e-14)
+    dead = int((pi == 0).sum())
+    print(name, "iters", iters, "dead nodes", dead)
+    assert dead == int((g["pi"] == 0).sum())
+
+
+def test_build_bunny_subsample_L4_vs_oracle(ctx, bunny):
+    """4-level tree (4680 nodes, BASELINE config 4 shape) on bun000[::8] against the oracle."""
+    P = bunny[::8].astype(np.float64)
+    L = 4
+    T = hgmm_tree.n_total(L)
+    idx = np.random.RandomState(72).randint(T, size=T)
+    pi, mu, cov, leaf, iters, q = build(ctx, P, L, 80.0, 1e-4, idx, 0.00034)
+    o_pi, o_mu, o_cov, tr = hgmm_tree.build_tree(P, L, 80.0, 1e-4, idx, 0.00034)
+    assert list(iters) == list(tr.iters_per_level)
+    np.testing.assert_allclose(q, tr.q, rtol=1e-9, atol=1e-6)
+    assert np.array_equal(leaf, tr.current_idx_per_level[-1])
+    np.testing.assert_allclose(pi, o_pi, rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(mu, o_mu, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(cov, o_cov, rtol=1e-6, atol=1e-14)
+
+
+def test_build_full_bunny_L4_properties(ctx, bunny):
+    """BASELINE config 4 at full size (bun000.ply, 40256 pts, L = 4, 4680 nodes): properties that
+    do not need the O(N 8^(l+1)) oracle, plus one oracle log-likelihood evaluation of level 1."""
+    P = bunny.astype(np.float64)
+    L = 4
+    T = hgmm_tree.n_total(L)
+    idx = np.random.RandomState(72).randint(T, size=T)
+    t0 = time.perf_counter()
+    pi, mu, cov, leaf, iters, q = build(ctx, P, L, 80.0, 1e-4, idx, 0.00034)
+    dt = time.perf_counter() - t0
+    print("bun000 L=4 build: %.3f s, level-iterations %s (%.1f it/s)" % (dt, list(iters), iters.sum() / dt))
+    assert len(q) == iters.sum()
+    # leaves are level-3 nodes
+    assert leaf.min() >= hgmm_tree.level(3) and leaf.max() < T
+    # mixing coefficients of every level sum to <= 1 and to the mass of the points assigned
+    for l in range(L):
+        s = pi[hgmm_tree.level(l):hgmm_tree.level(l + 1)].sum()
+        assert 0.5 < s <= 1.0 + 1e-9
+    # children of a dead node are dead
+    for j in np.nonzero(pi[:hgmm_tree.level(L - 1)] == 0)[0]:
+        kids = slice(8 * (j + 1), 8 * (j + 1) + 8)
+        assert (pi[kids] == 0).all()
+    # live covariances are symmetric PSD-ish
+    live = pi > 0
+    assert np.allclose(cov[live], np.transpose(cov[live], (0, 2, 1)))
+    # the recorded q of the last level-1 iteration == oracle log-likelihood of the final level-1 nodes
+    k = iters[0] + iters[1] - 1
+    o_q = hgmm_tree.log_likelihood(P, pi, mu, cov, 1)
+    assert abs(o_q - q[k]) <= 1e-9 * abs(o_q)
+    # moments consistency: pi_j * N == number-weighted mass; mean of a leaf lies inside the cloud box
+    lo, hi = P.min(0) - 1e-9, P.max(0) + 1e-9
+    leaves = np.arange(hgmm_tree.level(L - 1), T)
+    lv = leaves[pi[leaves] > 0]
+    assert ((mu[lv] >= lo) & (mu[lv] <= hi)).all()
+    # rebuild: run-to-run bitwise reproducible (no atomics on this path)
+    pi2, mu2, cov2, leaf2, iters2, q2 = build(ctx, P, L, 80.0, 1e-4, idx, 0.00034)
+    assert np.array_equal(q, q2) and np.array_equal(leaf, leaf2) and np.array_equal(cov, cov2)
+
+
+def test_max_iters_and_single_level(ctx):
+    rs = np.random.RandomState(3)
+    P = rs.rand(700, 3)
+    T = hgmm_tree.n_total(1)
+    idx = rs.randint(T, size=T)
+    pi, mu, cov, leaf, iters, q = build(ctx, P, 1, 1e-30, 1e-4, idx, 0.02, max_iters=3)
+    o_pi, o_mu, o_cov, tr = hgmm_tree.build_tree(P, 1, 1e-30, 1e-4, idx, 0.02, max_iters_per_level=3)
+    assert list(iters) == [3] == list(tr.iters_per_level)
+    np.testing.assert_allclose(q, tr.q, rtol=1e-10)
+    np.testing.assert_allclose(cov, o_cov, rtol=1e-8, atol=1e-15)
+    assert np.array_equal(leaf, tr.current_idx_per_level[0])
+
+
+def test_ragged_point_counts(ctx):
+    """N not a multiple of the 256-point chunk, tiny N, and a cloud where most nodes die."""
+    for n in (1, 9, 255, 257, 1000):
+        rs = np.random.RandomState(n)
+        P = rs.rand(n, 3) * 0.1
+        L = 2
+        T = hgmm_tree.n_total(L)
+        idx = rs.randint(min(T, n), size=T)
+        pi, mu, cov, leaf, iters, q = build(ctx, P, L, 5.0, 1e-4, idx, 0.001, max_iters=50)
+        o_pi, o_mu, o_cov, tr = hgmm_tree.build_tree(P, L, 5.0, 1e-4, idx, 0.001, max_iters_per_level=50)
+        assert list(iters) == list(tr.iters_per_level), n
+        np.testing.assert_allclose(q, tr.q, rtol=1e-9, atol=1e-9)
+        assert np.array_equal(leaf, tr.current_idx_per_level[-1])
+        np.testing.assert_allclose(pi, o_pi, rtol=1e-9, atol=1e-13)
+
+
+def test_registration_estep_and_loop_match_reference(ctx):
+    from hgmm_amd.hgmm.hgmm_gpu import GMMTree, gmmTreeRegESTep
+    g = load_golden("hgmm_reg_L2.npz")
+    L, lc = int(g["L"]), float(g["lambda_c"])
+    T = hgmm_tree.n_total(L)
+    ctx.tree_set_nodes(L, g["pi"], g["mu"], g["cov"])
+    np.testing.assert_allclose(ctx.tree_node_complexity(T), hgmm_tree.complexity(g["cov"]), rtol=1e-9, atol=1e-12)
+    for deg in (10, 30):
+        tag = "rot%d_" % deg
+        target = g[tag + "target"]
+        m0, m1, m2 = gmmTreeRegESTep(target, g["pi"], g["mu"], g["cov"], L, lc, ctx=ctx)
+        np.testing.assert_allclose(m0, g[tag + "m0"], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(m1, g[tag + "m1"], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(m2, g[tag + "m2"], rtol=1e-10, atol=1e-12)
+        # the on-device transform: E-step of (R, t)-transformed target == E-step of pre-transformed one
+        th = 0.05
+        R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+        t = np.array([0.01, -0.02, 0.005])
+        ctx.tree_set_target(target)
+        a = ctx.tree_reg_estep(T, R, t, 1.0, lc)
+        o = hgmm_tree.reg_e_step(target @ R.T + t, g["pi"], g["mu"], g["cov"], L, lc)
+        for x, y in zip(a, o):
+            np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-12)
+        # full loop, 5 iterations, against the reference's recorded per-iteration transforms
+        gt = GMMTree(None, tree_level=L, lambda_c=lc, ctx=ctx)
+        gt.set_nodes(g["pi"], g["mu"], g["cov"])
+        trace = []
+        gt.set_callbacks([lambda tf: trace.append((tf.rot.copy(), tf.t.copy()))])
+        res = gt.registration(target, 5, 1.0e-4)
+        assert len(trace) == len(g[tag + "iter_rot"])
+        for k, (r_k, t_k) in enumerate(trace):
+            np.testing.assert_allclose(r_k, g[tag + "iter_rot"][k], rtol=0, atol=1e-8)
+            np.testing.assert_allclose(t_k, g[tag + "iter_t"][k], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(res.transformation.rot, g[tag + "final_rot"], atol=1e-8)
+        np.testing.assert_allclose(res.transformation.t, g[tag + "final_t"], atol=1e-8)
+        np.testing.assert_allclose(res.q, g[tag + "final_q"], rtol=1e-6)
+
+
+def test_registration_recovers_known_rotation(ctx, bunny):
+    """End to end through the drop-in API: build a 3-level tree on a bunny subsample, register a
+    rotated copy; the recovered transform maps the target back onto the source."""
+    from hgmm_amd.hgmm.hgmm_gpu import registration_gmmtree
+    P = bunny[::10].astype(np.float64)
+    th = np.deg2rad(10.0)
+    Rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    target = P @ Rz.T + np.array([0.005, -0.003, 0.002])
+    res = registration_gmmtree(P, target, maxiter=20, tol=1e-4, tree_level=2, lambda_c=0.01, ls=80,
+                               sig2=0.00034, ctx=ctx)
+    # reference convention: the returned transform is tf.inverse(), mapping source -> target
+    moved = res.transformation.transform(P)
+    err = np.linalg.norm(moved - target, axis=1).mean()
+    print("mean residual after registration: %.3g m" % err)
+    assert err < 2e-3
