@@ -49,18 +49,6 @@ def init_params(frame0, J=J_COMP, seed=100):
     return mu, w, cov
 
 
-def bcast_unique_id(rank, world):
-    """Bootstrap only: ship the 128-byte RCCL unique id from rank 0 to the other ranks through
-    torch.distributed (gloo, CPU) -- the launcher's rendezvous.  No tensors, no CUDA."""
-    import torch.distributed as dist
-    from hgmm_amd import Context
-    if not dist.is_initialized():
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    obj = [Context.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(obj, src=0)
-    return obj[0]
-
-
 def cpu_baseline_main(sample_n=100_000, iters=2):
     """NumPy oracle (fp32, reference op sequence) on a bounded sample of the workload."""
     from oracle import flat_em
@@ -129,7 +117,9 @@ def main():
     ctx = hgmm_amd.Context(local_rank)
     info = ctx.device_info()
     if world > 1:
-        ctx.comm_init(world, rank, bcast_unique_id(rank, world))
+        # RCCL communicator; the 128-byte unique id travels through the launcher's rendezvous
+        from hgmm_amd import parallel
+        parallel.attach_communicator(ctx, rank, world, transport="torch")
 
     frame = synth_frame(rank)
     mu0, w0, cov0 = init_params(synth_frame(0) if rank else frame)

@@ -266,3 +266,33 @@ def test_profiler_reports_kernel_time(ctx):
     ctx.profile_enable(False)
     ms, n = ctx.profile_get("flat_fused")
     assert n == 4 and ms > 0
+
+
+def test_rccl_single_rank_communicator(ctx, bunny):
+    """The N>1 data path with world_size = 1 (the GPU box has one GPU): attaching an RCCL
+    communicator routes every statistics buffer through ncclAllReduce on the context's stream;
+    results must be identical to the communicator-less run."""
+    import hgmm_amd
+    from oracle import hgmm_tree
+    X = bunny[::4]
+    mu0, w0, cov0 = flat_em.seeded_init(X, 48, 2)
+    ctx.set_points(X)
+    ref = ctx.flat_train(6, 0.0, mu0, cov0, w0, "diag", "W")
+    c2 = hgmm_amd.Context(0)
+    try:
+        c2.comm_init(1, 0, hgmm_amd.Context.comm_unique_id())
+        c2.set_points(X)
+        got = c2.flat_train(6, 0.0, mu0, cov0, w0, "diag", "W")
+        for a, b in zip(ref[:5], got[:5]):
+            assert np.array_equal(a, b)
+        assert float(c2.allreduce([3.5], op="max")[0]) == 3.5
+        P = X[:3000].astype(np.float64)
+        T = hgmm_tree.n_total(2)
+        idx = np.random.RandomState(1).randint(T, size=T)
+        t1 = ctx.set_points(P).tree_build(2, 20.0, 1e-4, P[idx], 0.001, 100)
+        t2 = c2.set_points(P).tree_build(2, 20.0, 1e-4, P[idx], 0.001, 100)
+        for a, b in zip(t1, t2):
+            assert np.array_equal(a, b)
+        c2.comm_destroy()
+    finally:
+        c2.close()

@@ -1,0 +1,98 @@
+"""world_size-2 CPU tests of the N>1 host path (no GPU): the unique-id bootstrap over gloo and
+over plain TCP, the shard partition, and the algebra the library relies on -- centred sufficient
+statistics of shards add up to the statistics of the whole cloud and give the oracle's M-step."""
+import multiprocessing as mp
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import flat_em
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, transport, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from hgmm_amd import parallel
+    payload = bytes(range(128)) if rank == 0 else None
+    got = parallel.broadcast_from_rank0(rank, world, payload, transport=transport)
+    extra = None
+    if transport == "torch":
+        # the barrier / max-over-ranks reduction pattern bench.py uses, on gloo
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        extra = float(t[0])
+        dist.barrier()
+        dist.destroy_process_group()
+    q.put((rank, got, extra))
+
+
+@pytest.mark.parametrize("transport", ["tcp", "torch"])
+def test_unique_id_bootstrap_world2(transport):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, transport, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == bytes(range(128))
+    if transport == "torch":
+        assert res[0][2] == res[1][2] == 2.0
+
+
+def test_shard_bounds_cover_exactly_once():
+    from hgmm_amd.parallel import shard_bounds
+    for n in (1, 7, 1000, 1_000_003):
+        for world in (1, 2, 3, 8):
+            cuts = [shard_bounds(n, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in cuts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def centred_stats(X, inv, mu, w):
+    """What flat_fused_kernel accumulates (s0, a, b about mu), in float64 via the oracle."""
+    _, lr = flat_em.e_step(X, inv, mu, w, "diag", "W")
+    r = np.exp(lr)
+    d = X[:, None, :] - mu[None]
+    return np.concatenate([r.sum(0)[:, None], (r[:, :, None] * d).sum(0), (r[:, :, None] * d * d).sum(0)], axis=1)
+
+
+def test_sharded_statistics_allreduce_equals_single_rank():
+    rs = np.random.RandomState(0)
+    X = rs.rand(3000, 3)
+    mu = X[rs.choice(3000, 20, replace=False)]
+    inv = 1 / np.sqrt(0.02 + 0.05 * rs.rand(20, 3))
+    w = np.ones(20) / 20
+    from hgmm_amd.parallel import shard_bounds
+    whole = centred_stats(X, inv, mu, w)
+    parts = sum(centred_stats(X[a:b], inv, mu, w) for a, b in (shard_bounds(3000, r, 2) for r in range(2)))
+    np.testing.assert_allclose(parts, whole, rtol=1e-12, atol=1e-14)
+    # M-step from the (all-reduced) centred statistics == the reference M-step (flavour W)
+    s0, a, b = whole[:, 0], whole[:, 1:4], whole[:, 4:7]
+    nk = s0 + 1e-8
+    sx = a + mu * s0[:, None]
+    sxx = b + 2 * mu * a + mu * mu * s0[:, None]
+    m = sx / nk[:, None]
+    cov = sxx / nk[:, None] - m * m + 1e-6
+    _, lr = flat_em.e_step(X, inv, mu, w, "diag", "W")
+    o_w, o_mu, o_cov = flat_em.m_step(X, np.exp(lr), "diag", "W")
+    np.testing.assert_allclose(m, o_mu, rtol=1e-10)
+    np.testing.assert_allclose(cov, o_cov, rtol=1e-8)
+    np.testing.assert_allclose(nk / 3000, o_w, rtol=1e-12)
