@@ -5,11 +5,12 @@
 // K = 3 / K = N and ~10 elementwise passes over N x J temporaries.  Here:
 //
 //   flat_estep_kernel   one wavefront per point row, lanes across components.  The row's
-//                       x is wave-uniform (scalar loads); each lane keeps the packed
-//                       parameters (mu, 0.5/sigma^2, const) of its components in VGPRs for the
-//                       whole kernel, evaluates the *centred* quadratic form, does the
-//                       log-sum-exp with DPP wave reductions and streams log_resp[N,J] out
-//                       with coalesced stores.  HBM-write-bound: 4 N J bytes.
+//                       x is wave-uniform (scalar loads, prefetched one row ahead); each lane
+//                       keeps the packed parameters (mu, 0.5 log2(e)/sigma^2, const) of its
+//                       components in VGPRs for the whole kernel, evaluates the *centred*
+//                       quadratic form in the log2 domain (v_exp_f32 / v_log_f32 are base 2),
+//                       does the log-sum-exp with DPP wave reductions and streams log_resp[N,J]
+//                       out with coalesced 16-byte stores.  HBM-write-bound: 4 N J bytes.
 //   flat_fused_kernel   same mapping, but instead of writing N x J it accumulates the
 //                       7 sufficient statistics per component in registers (centred about
 //                       the current mean, so no raw-moment cancellation), combines the waves
@@ -24,27 +25,30 @@
 #include "wave_ops.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace hgmm {
 
 constexpr float NEG_INF = -__builtin_huge_valf();
 constexpr float LOG2E = 1.4426950408889634f;
-constexpr int PK_MU = 0, PK_H = 3, PK_C = 6;   // rows of the packed parameter table
+constexpr float LN2 = 0.6931471805599453f;
+constexpr int PK_MU = 0, PK_G = 3, PK_C = 6;   // rows of the packed parameter table
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int BLOCK = WAVES_PER_BLOCK * 64;
 
 // ------------------------------------------------------------------------------------------
-// parameter packing:  wlp_ij = c_j - sum_d h_jd (x_id - mu_jd)^2
-//   h_jd = 0.5 * inv_std_jd^2
-//   c_j  = -0.5 * 3 * log(2 pi) + sum_d log(inv_std_jd + eps) + log(w_j [+ eps])
+// parameter packing (log2 domain):  wl2_ij = c2_j - sum_d g_jd (x_id - mu_jd)^2 = log2e * wlp_ij
+//   g_jd = 0.5 * log2(e) * inv_std_jd^2
+//   c2_j = log2(e) * ( -0.5 * 3 * log(2 pi) + sum_d log(inv_std_jd + eps) + log(w_j [+ eps]) )
 // (estimate_log_prob / estimate_log_prob_spherical / e_step, gmm_waymo gmm_impl.py:53-116)
 // ------------------------------------------------------------------------------------------
 __device__ inline void pack_component(int j, int J, int Jpad, int cov_type, int variant,
                                       const float* mu, const float* inv, const float* w,
                                       float* pack) {
-    float m0 = 0.f, m1 = 0.f, m2 = 0.f, h0 = 0.f, h1 = 0.f, h2 = 0.f, c = NEG_INF;
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, c = NEG_INF;
     if (j < J) {
         const double eps = (double)FLAT_EPS;
+        const double l2e = 1.4426950408889634074;
         double i0, i1, i2;
         if (cov_type == HGMM_COV_DIAG) {
             i0 = inv[3 * j + 0]; i1 = inv[3 * j + 1]; i2 = inv[3 * j + 2];
@@ -54,17 +58,17 @@ __device__ inline void pack_component(int j, int J, int Jpad, int cov_type, int 
         const double log2pi = (double)1.8378770351409912f;   // reference casts log(2 pi) to float32
         double half_log_det = log(i0 + eps) + log(i1 + eps) + log(i2 + eps);
         double lw = (variant == HGMM_VARIANT_W) ? log((double)w[j] + eps) : log((double)w[j]);
-        double cc = -0.5 * 3.0 * log2pi + half_log_det + lw;
+        double cc = (-0.5 * 3.0 * log2pi + half_log_det + lw) * l2e;
         m0 = mu[3 * j + 0]; m1 = mu[3 * j + 1]; m2 = mu[3 * j + 2];
-        h0 = (float)(0.5 * i0 * i0); h1 = (float)(0.5 * i1 * i1); h2 = (float)(0.5 * i2 * i2);
+        g0 = (float)(0.5 * l2e * i0 * i0); g1 = (float)(0.5 * l2e * i1 * i1); g2 = (float)(0.5 * l2e * i2 * i2);
         c = (cc != cc) ? NEG_INF : (float)cc;
     }
     pack[(PK_MU + 0) * Jpad + j] = m0;
     pack[(PK_MU + 1) * Jpad + j] = m1;
     pack[(PK_MU + 2) * Jpad + j] = m2;
-    pack[(PK_H + 0) * Jpad + j] = h0;
-    pack[(PK_H + 1) * Jpad + j] = h1;
-    pack[(PK_H + 2) * Jpad + j] = h2;
+    pack[(PK_G + 0) * Jpad + j] = g0;
+    pack[(PK_G + 1) * Jpad + j] = g1;
+    pack[(PK_G + 2) * Jpad + j] = g2;
     pack[PK_C * Jpad + j] = c;
 }
 
@@ -75,81 +79,70 @@ __global__ void flat_pack_kernel(int J, int Jpad, int cov_type, int variant, con
 }
 
 // ------------------------------------------------------------------------------------------
-// register-resident component parameters of one lane: K = NSLOT * VEC components,
-// component k = s*VEC + e  <->  j = (s*64 + lane)*VEC + e
+// lane <-> component layout.  A lane owns K = 4*NV4 + NV1 components:
+//   k <  4*NV4 : "vector" slots, j = ((k/4)*64 + lane)*4 + k%4      (16-byte loads/stores)
+//   k >= 4*NV4 : "scalar" slots, j = 256*NV4 + (k-4*NV4)*64 + lane  (4-byte loads/stores)
+// J = 800 -> NV4 = 3, NV1 = 1: 13 components per lane, 3 x 1 KiB + 1 x 128 B stores per row.
 // ------------------------------------------------------------------------------------------
-template <int VEC, int NSLOT>
+template <int NV4, int NV1>
+struct Layout {
+    static constexpr int K = 4 * NV4 + NV1;
+    static constexpr int CAP = 256 * NV4 + 64 * NV1;
+    __device__ static __forceinline__ int j_of(int k, int lane) {
+        return (k < 4 * NV4) ? ((k >> 2) * 64 + lane) * 4 + (k & 3) : 256 * NV4 + (k - 4 * NV4) * 64 + lane;
+    }
+};
+
+template <int NV4, int NV1>
 struct LaneParams {
-    static constexpr int K = VEC * NSLOT;
-    float mu0[K], mu1[K], mu2[K], h0[K], h1[K], h2[K], c[K];
+    using L = Layout<NV4, NV1>;
+    static constexpr int K = L::K;
+    float mu0[K], mu1[K], mu2[K], g0[K], g1[K], g2[K], c[K];
 
     __device__ __forceinline__ void load(const float* __restrict__ pack, int Jpad, int lane) {
 #pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-            const int jb = (s * 64 + lane) * VEC;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const int k = s * VEC + e;
-                mu0[k] = pack[(PK_MU + 0) * Jpad + jb + e];
-                mu1[k] = pack[(PK_MU + 1) * Jpad + jb + e];
-                mu2[k] = pack[(PK_MU + 2) * Jpad + jb + e];
-                h0[k] = pack[(PK_H + 0) * Jpad + jb + e];
-                h1[k] = pack[(PK_H + 1) * Jpad + jb + e];
-                h2[k] = pack[(PK_H + 2) * Jpad + jb + e];
-                c[k] = pack[PK_C * Jpad + jb + e];
-            }
+        for (int k = 0; k < K; ++k) {
+            const int j = L::j_of(k, lane);
+            mu0[k] = pack[(PK_MU + 0) * Jpad + j];
+            mu1[k] = pack[(PK_MU + 1) * Jpad + j];
+            mu2[k] = pack[(PK_MU + 2) * Jpad + j];
+            g0[k] = pack[(PK_G + 0) * Jpad + j];
+            g1[k] = pack[(PK_G + 1) * Jpad + j];
+            g2[k] = pack[(PK_G + 2) * Jpad + j];
+            c[k] = pack[PK_C * Jpad + j];
         }
     }
 };
 
-// weighted log-probabilities of one row for this lane's components + the wave-wide
-// log-sum-exp pieces.  Returns the row maximum m and S = sum_j exp(wlp_j - m); e[] holds
-// exp(wlp - m) on return when WANT_E.
-template <int VEC, int NSLOT, bool WANT_E>
-__device__ __forceinline__ void row_lse(const LaneParams<VEC, NSLOT>& P, float x0, float x1,
-                                        float x2, float (&wl)[VEC * NSLOT],
-                                        float (&e)[VEC * NSLOT], float& m_out, float& s_out) {
-    constexpr int K = VEC * NSLOT;
+// weighted log2-probabilities of one row for this lane's components; returns the lane-local max
+template <int NV4, int NV1>
+__device__ __forceinline__ float row_wl2(const LaneParams<NV4, NV1>& P, float x0, float x1, float x2,
+                                         float (&wl)[4 * NV4 + NV1]) {
+    constexpr int K = 4 * NV4 + NV1;
     float m = NEG_INF;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const float d0 = x0 - P.mu0[k], d1 = x1 - P.mu1[k], d2 = x2 - P.mu2[k];
-        float q = P.h0[k] * (d0 * d0);
-        q = fmaf(P.h1[k], d1 * d1, q);
-        q = fmaf(P.h2[k], d2 * d2, q);
-        wl[k] = P.c[k] - q;
-        m = fmaxf(m, wl[k]);
+        float a = fmaf(-(d0 * P.g0[k]), d0, P.c[k]);
+        a = fmaf(-(d1 * P.g1[k]), d1, a);
+        a = fmaf(-(d2 * P.g2[k]), d2, a);
+        wl[k] = a;
+        m = fmaxf(m, a);
     }
-    m = wave_reduce(m, OpMax());
-    if (m == NEG_INF) m = 0.f;            // every component has zero weight: avoid inf - inf
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const float ek = __builtin_amdgcn_exp2f((wl[k] - m) * LOG2E);
-        if (WANT_E) e[k] = ek;
-        s += ek;
-    }
-    s = wave_reduce(s, OpSum());
-    m_out = m;
-    s_out = s;
+    return m;
 }
 
-// log( sum_j exp(wlp_j) + eps )  from (m, S), exactly the reference's normaliser
-// (gmm_waymo gmm_impl.py:113 -- no max-shift there; this is the overflow-safe equivalent).
-// Also returns inv_den with  r_j = exp(wlp_j - m) * inv_den.
-__device__ __forceinline__ float lpn_from(float m, float s, float& inv_den) {
-    float lpn;
-    if (m < 0.f) {
-        const float em = expf(m);
-        const float tot = fmaf(s, em, FLAT_EPS);
-        lpn = logf(tot);
-        inv_den = em / tot;
-    } else {
-        const float den = fmaf(FLAT_EPS, expf(-m), s);
-        lpn = m + logf(den);
-        inv_den = 1.0f / den;
-    }
-    return lpn;
+// The reference's normaliser  log( sum_j exp(wlp_j) + eps )  (gmm_waymo gmm_impl.py:113, no
+// max-shift there) from the wave maximum m2 and S = sum_j 2^(wl2_j - m2), all in log2 units:
+//   lpn2 = mc + log2( S' + eps 2^-mc ),  mc = max(m2, -64),  S' = S (or 0 when m2 < -64: then
+//   sum_j exp(wlp_j) < 1e-19 J is below float32 resolution of eps = 1e-8).
+// inv_den satisfies  r_j = 2^(wl2_j - m2) * inv_den.
+__device__ __forceinline__ float lpn2_from(float m2, float s, float& inv_den) {
+    const bool tiny = m2 < -64.0f;
+    const float mc = tiny ? -64.0f : m2;
+    const float den = fmaf(FLAT_EPS, __builtin_amdgcn_exp2f(-mc), tiny ? 0.0f : s);
+    inv_den = tiny ? 0.0f : __builtin_amdgcn_rcpf(den);
+    return mc + __builtin_amdgcn_logf(den);
 }
 
 __device__ __forceinline__ void wave_row_range(int64_t n, int64_t& r0, int64_t& r1) {
@@ -161,17 +154,31 @@ __device__ __forceinline__ void wave_row_range(int64_t n, int64_t& r0, int64_t& 
     if (r0 > n) r0 = n;
 }
 
+template <bool NT>
+__device__ __forceinline__ void store_f4(float* p, float a, float b, float c, float d) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 v = {a, b, c, d};
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<f4*>(p));
+    else *reinterpret_cast<f4*>(p) = v;
+}
+template <bool NT>
+__device__ __forceinline__ void store_f1(float* p, float a) {
+    if (NT) __builtin_nontemporal_store(a, p);
+    else *p = a;
+}
+
 // ------------------------------------------------------------------------------------------
-// materialising E-step / predict
+// materialising E-step (NORMALISE) / predict (!NORMALISE: arg-max of wlp only)
 // ------------------------------------------------------------------------------------------
-template <int VEC, int NSLOT, bool NORMALISE>
+template <int NV4, int NV1, bool NORMALISE, bool NT>
 __global__ __launch_bounds__(BLOCK) void flat_estep_kernel(
     const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int J, int Jpad,
     float* __restrict__ log_resp, float* __restrict__ lpn_out, int32_t* __restrict__ argmax_out,
     double* __restrict__ lpn_partials) {
-    constexpr int K = VEC * NSLOT;
+    using L = Layout<NV4, NV1>;
+    constexpr int K = L::K;
     const int lane = lane_id();
-    LaneParams<VEC, NSLOT> P;
+    LaneParams<NV4, NV1> P;
     P.load(pack, Jpad, lane);
 
     int64_t r0, r1;
@@ -179,57 +186,60 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_kernel(
     double lsum = 0.0;
     float keep_lpn = 0.f;
     int keep_arg = 0;
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+    if (r0 < r1) { const float* xp = X + 3 * r0; x0 = xp[0]; x1 = xp[1]; x2 = xp[2]; }
     for (int64_t row = r0; row < r1; ++row) {
-        const float* xp = X + 3 * row;
-        const float x0 = xp[0], x1 = xp[1], x2 = xp[2];
-        float wl[K], e[K];
-        float m, s;
-        if (NORMALISE) {
-            row_lse<VEC, NSLOT, false>(P, x0, x1, x2, wl, e, m, s);
-        } else {
-            m = NEG_INF;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const float d0 = x0 - P.mu0[k], d1 = x1 - P.mu1[k], d2 = x2 - P.mu2[k];
-                float q = P.h0[k] * (d0 * d0);
-                q = fmaf(P.h1[k], d1 * d1, q);
-                q = fmaf(P.h2[k], d2 * d2, q);
-                wl[k] = P.c[k] - q;
-                m = fmaxf(m, wl[k]);
-            }
-            m = wave_reduce(m, OpMax());
-            s = 0.f;
-        }
+        // prefetch the next row's coordinates (wave-uniform scalar loads) behind this row's math
+        const int64_t nrow = (row + 1 < r1) ? row + 1 : row;
+        const float* xn = X + 3 * nrow;
+        const float nx0 = xn[0], nx1 = xn[1], nx2 = xn[2];
+
+        float wl[K];
+        float m = row_wl2<NV4, NV1>(P, x0, x1, x2, wl);
+        m = wave_reduce(m, OpMax());
         const int slot = (int)((row - r0) & 63);
         if (NORMALISE) {
+            if (m == NEG_INF) m = 0.f;            // every component has zero weight: avoid inf - inf
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) s += __builtin_amdgcn_exp2f(wl[k] - m);
+            s = wave_reduce(s, OpSum());
             float inv_den;
-            const float lpn = lpn_from(m, s, inv_den);
+            const float lpn2 = lpn2_from(m, s, inv_den);
+            const float lpn = lpn2 * LN2;
             lsum += (double)lpn;
             if (log_resp) {
                 float* out = log_resp + row * (int64_t)J;
 #pragma unroll
-                for (int sidx = 0; sidx < NSLOT; ++sidx) {
-                    const int jb = (sidx * 64 + lane) * VEC;
-                    if (VEC == 4) {
-                        if (jb < J) {
-                            float4 v = make_float4(wl[sidx * 4 + 0] - lpn, wl[sidx * 4 + 1] - lpn,
-                                                   wl[sidx * 4 + 2] - lpn, wl[sidx * 4 + 3] - lpn);
-                            *reinterpret_cast<float4*>(out + jb) = v;
-                        }
-                    } else {
-                        if (jb < J) out[jb] = wl[sidx] - lpn;
-                    }
+                for (int v = 0; v < NV4; ++v) {
+                    const int jb = (v * 64 + lane) * 4;
+                    if (jb < J)
+                        store_f4<NT>(out + jb, fmaf(wl[4 * v + 0], LN2, -lpn), fmaf(wl[4 * v + 1], LN2, -lpn),
+                                     fmaf(wl[4 * v + 2], LN2, -lpn), fmaf(wl[4 * v + 3], LN2, -lpn));
+                }
+#pragma unroll
+                for (int v = 0; v < NV1; ++v) {
+                    const int j = 256 * NV4 + v * 64 + lane;
+                    if (j < J) store_f1<NT>(out + j, fmaf(wl[4 * NV4 + v], LN2, -lpn));
                 }
             }
             if (lane == slot) keep_lpn = lpn;
+        } else if (log_resp) {
+            // raw weighted log-probabilities (estimate_log_prob + log weights), natural log
+            float* out = log_resp + row * (int64_t)J;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int j = L::j_of(k, lane);
+                if (j < J) out[j] = wl[k] * LN2;
+            }
         }
         if (argmax_out) {
             // first index attaining the row maximum (numpy argmax tie rule)
             int best = 0x7fffffff;
 #pragma unroll
-            for (int k = K - 1; k >= 0; --k) {
-                const int j = ((k / VEC) * 64 + lane) * VEC + (k % VEC);
-                if (wl[k] == m && j < J) best = j;
+            for (int k = 0; k < K; ++k) {
+                const int j = L::j_of(k, lane);
+                if (wl[k] == m && j < J && j < best) best = j;
             }
             best = wave_reduce_i(best, OpMinI());
             if (best == 0x7fffffff) best = 0;
@@ -242,6 +252,7 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_kernel(
                 if (argmax_out) argmax_out[base + lane] = keep_arg;
             }
         }
+        x0 = nx0; x1 = nx1; x2 = nx2;
     }
     if (NORMALISE && lpn_partials) {
         __shared__ double sh[WAVES_PER_BLOCK];
@@ -267,7 +278,7 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_kernel(
     if (done_flag && *done_flag) return;
     constexpr int K = NSLOT;
     const int lane = lane_id();
-    LaneParams<1, NSLOT> P;
+    LaneParams<0, NSLOT> P;
     P.load(pack, Jpad, lane);
     float a_s0[K], a_a0[K], a_a1[K], a_a2[K], a_b0[K], a_b1[K], a_b2[K];
 #pragma unroll
@@ -276,17 +287,30 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_kernel(
     int64_t r0, r1;
     wave_row_range(n, r0, r1);
     double lsum = 0.0;
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+    if (r0 < r1) { const float* xp = X + 3 * r0; x0 = xp[0]; x1 = xp[1]; x2 = xp[2]; }
     for (int64_t row = r0; row < r1; ++row) {
-        const float* xp = X + 3 * row;
-        const float x0 = xp[0], x1 = xp[1], x2 = xp[2];
-        float wl[K], e[K];
-        float m, s, inv_den;
-        row_lse<1, NSLOT, true>(P, x0, x1, x2, wl, e, m, s);
-        const float lpn = lpn_from(m, s, inv_den);
-        lsum += (double)lpn;
+        const int64_t nrow = (row + 1 < r1) ? row + 1 : row;
+        const float* xn = X + 3 * nrow;
+        const float nx0 = xn[0], nx1 = xn[1], nx2 = xn[2];
+
+        float wl[K];
+        float m = row_wl2<0, NSLOT>(P, x0, x1, x2, wl);
+        m = wave_reduce(m, OpMax());
+        if (m == NEG_INF) m = 0.f;
+        float s = 0.f;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const float r = e[k] * inv_den;
+            wl[k] = __builtin_amdgcn_exp2f(wl[k] - m);
+            s += wl[k];
+        }
+        s = wave_reduce(s, OpSum());
+        float inv_den;
+        const float lpn2 = lpn2_from(m, s, inv_den);
+        lsum += (double)(lpn2 * LN2);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float r = wl[k] * inv_den;
             const float d0 = x0 - P.mu0[k], d1 = x1 - P.mu1[k], d2 = x2 - P.mu2[k];
             const float rd0 = r * d0, rd1 = r * d1, rd2 = r * d2;
             a_s0[k] += r;
@@ -295,6 +319,7 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_kernel(
             a_b1[k] = fmaf(rd1, d1, a_b1[k]);
             a_b2[k] = fmaf(rd2, d2, a_b2[k]);
         }
+        x0 = nx0; x1 = nx1; x2 = nx2;
     }
 
     // combine the workgroup's waves through LDS in a fixed order (deterministic), one HBM write
@@ -335,40 +360,42 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_kernel(
 // ------------------------------------------------------------------------------------------
 // M-step moments from a materialised responsibility matrix (m_step(X, resp))
 // ------------------------------------------------------------------------------------------
-template <int VEC, int NSLOT>
+template <int NV4, int NV1>
 __global__ __launch_bounds__(BLOCK) void flat_mstep_kernel(
     const float* __restrict__ X, const float* __restrict__ resp, int is_log,
     const float* __restrict__ hint /*[3][Jpad]*/, int64_t n, int J, int Jpad,
     float* __restrict__ partials) {
-    constexpr int K = VEC * NSLOT;
+    using L = Layout<NV4, NV1>;
+    constexpr int K = L::K;
     const int lane = lane_id();
     float c0[K], c1[K], c2[K];
     float a_s0[K], a_a0[K], a_a1[K], a_a2[K], a_b0[K], a_b1[K], a_b2[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const int j = ((k / VEC) * 64 + lane) * VEC + (k % VEC);
+        const int j = L::j_of(k, lane);
         c0[k] = hint[0 * Jpad + j]; c1[k] = hint[1 * Jpad + j]; c2[k] = hint[2 * Jpad + j];
         a_s0[k] = a_a0[k] = a_a1[k] = a_a2[k] = a_b0[k] = a_b1[k] = a_b2[k] = 0.f;
     }
     int64_t r0, r1;
     wave_row_range(n, r0, r1);
 
-    float cur[K], nxt[K];
+    const float fill = is_log ? NEG_INF : 0.f;
     auto load_row = [&](int64_t row, float (&v)[K]) {
         const float* in = resp + row * (int64_t)J;
 #pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-            const int jb = (s * 64 + lane) * VEC;
-            if (VEC == 4) {
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (jb < J) t = *reinterpret_cast<const float4*>(in + jb);
-                else if (is_log) t = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
-                v[s * 4 + 0] = t.x; v[s * 4 + 1] = t.y; v[s * 4 + 2] = t.z; v[s * 4 + 3] = t.w;
-            } else {
-                v[s] = (jb < J) ? in[jb] : (is_log ? NEG_INF : 0.f);
-            }
+        for (int s = 0; s < NV4; ++s) {
+            const int jb = (s * 64 + lane) * 4;
+            float4 t = make_float4(fill, fill, fill, fill);
+            if (jb < J) t = *reinterpret_cast<const float4*>(in + jb);
+            v[s * 4 + 0] = t.x; v[s * 4 + 1] = t.y; v[s * 4 + 2] = t.z; v[s * 4 + 3] = t.w;
+        }
+#pragma unroll
+        for (int s = 0; s < NV1; ++s) {
+            const int j = 256 * NV4 + s * 64 + lane;
+            v[4 * NV4 + s] = (j < J) ? in[j] : fill;
         }
     };
+    float cur[K], nxt[K];
     if (r0 < r1) load_row(r0, cur);
     for (int64_t row = r0; row < r1; ++row) {
         if (row + 1 < r1) load_row(row + 1, nxt);
@@ -388,14 +415,14 @@ __global__ __launch_bounds__(BLOCK) void flat_mstep_kernel(
 #pragma unroll
         for (int k = 0; k < K; ++k) cur[k] = nxt[k];
     }
-    __shared__ float sh[FLAT_NSTAT * K * 64];
+    __shared__ float sh[FLAT_NSTAT * L::CAP];
     const int w = wave_in_block();
-    constexpr int ST = K * 64;
+    constexpr int ST = L::CAP;
     for (int turn = 0; turn < WAVES_PER_BLOCK; ++turn) {
         if (w == turn) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const int j = ((k / VEC) * 64 + lane) * VEC + (k % VEC);
+                const int j = L::j_of(k, lane);
                 float* p = sh + j;
                 if (turn == 0) {
                     p[0 * ST] = a_s0[k]; p[1 * ST] = a_a0[k]; p[2 * ST] = a_a1[k]; p[3 * ST] = a_a2[k];
@@ -623,37 +650,64 @@ static void launch_pack(hgmm_ctx* c) {
         c->f_pack.as<float>());
 }
 
+// layout choice: vector slots for full 256-component groups, scalar slots for a short remainder
+static void pick_layout(int J, int* nv4, int* nv1) {
+    if (J % 4 == 0) {
+        int a = J / 256, rem = J - 256 * (J / 256), b = 0;
+        if (rem > 128) { a += 1; } else if (rem > 0) { b = (rem + 63) / 64; }
+        *nv4 = a; *nv1 = b;
+    } else {
+        const int ns = (J + 63) / 64;
+        const int steps[] = {1, 2, 3, 4, 6, 8, 12, 16};
+        int b = 16;
+        for (int s : steps) if (s >= ns) { b = s; break; }
+        *nv4 = 0; *nv1 = b;
+    }
+}
+
+static bool env_flag(const char* name, bool dflt) {
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    return v[0] != '0';
+}
+
+// LAYOUT_DISPATCH(nv4, nv1, M): expands M(NV4, NV1) for the supported (NV4, NV1) pairs
+#define LAYOUT_DISPATCH(nv4, nv1, M)                                                           \
+    do {                                                                                       \
+        const int key_ = (nv4) * 100 + (nv1);                                                  \
+        switch (key_) {                                                                        \
+            case 1: M(0, 1); break;   case 2: M(0, 2); break;   case 3: M(0, 3); break;        \
+            case 4: M(0, 4); break;   case 6: M(0, 6); break;   case 8: M(0, 8); break;        \
+            case 12: M(0, 12); break; case 16: M(0, 16); break;                                \
+            case 100: M(1, 0); break; case 101: M(1, 1); break; case 102: M(1, 2); break;      \
+            case 200: M(2, 0); break; case 201: M(2, 1); break; case 202: M(2, 2); break;      \
+            case 300: M(3, 0); break; case 301: M(3, 1); break; case 302: M(3, 2); break;      \
+            case 400: M(4, 0); break;                                                          \
+            default: return fail(c, HGMM_ERR_ARG, "unsupported layout %d/%d", (nv4), (nv1));   \
+        }                                                                                      \
+    } while (0)
+
 template <bool NORMALISE>
 static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argmax, int* grid_out) {
     const FlatState& f = c->flat;
-    const int grid = grid_for(c, c->n, 3);
+    const int grid = grid_for(c, c->n, env_flag("HGMM_ESTEP_BPC3", true) ? 3 : 2);
     *grid_out = grid;
     const float* X = c->x_aos.as<float>();
     const float* pk = c->f_pack.as<float>();
     double* lp = c->f_lpn_partials.as<double>();
-    const bool vec4 = (f.J % 4 == 0);
-#define ESTEP_CASE(V, S)                                                                      \
-    flat_estep_kernel<V, S, NORMALISE><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, \
-                                                                     log_resp, lpn, argmax, lp)
+    int nv4, nv1;
+    pick_layout(f.J, &nv4, &nv1);
+    const bool nt = NORMALISE && env_flag("HGMM_ESTEP_NT", false);
     ProfScope prof(c, HGMM_K_FLAT_ESTEP);
-    if (vec4) {
-        const int ns = (f.J + 255) / 256;
-        switch (ns) {
-            case 1: ESTEP_CASE(4, 1); break;
-            case 2: ESTEP_CASE(4, 2); break;
-            case 3: ESTEP_CASE(4, 3); break;
-            default: ESTEP_CASE(4, 4); break;
-        }
-    } else {
-        const int ns = (f.J + 63) / 64;
-        if (ns <= 1) ESTEP_CASE(1, 1);
-        else if (ns <= 2) ESTEP_CASE(1, 2);
-        else if (ns <= 4) ESTEP_CASE(1, 4);
-        else if (ns <= 8) ESTEP_CASE(1, 8);
-        else if (ns <= 12) ESTEP_CASE(1, 12);
-        else ESTEP_CASE(1, 16);
-    }
-#undef ESTEP_CASE
+#define ESTEP_M(A, B)                                                                              \
+    do {                                                                                           \
+        if (nt) flat_estep_kernel<A, B, NORMALISE, NORMALISE><<<grid, BLOCK, 0, c->stream>>>(       \
+                    X, pk, c->n, f.J, f.Jpad, log_resp, lpn, argmax, lp);                           \
+        else flat_estep_kernel<A, B, NORMALISE, false><<<grid, BLOCK, 0, c->stream>>>(              \
+                    X, pk, c->n, f.J, f.Jpad, log_resp, lpn, argmax, lp);                           \
+    } while (0)
+    LAYOUT_DISPATCH(nv4, nv1, ESTEP_M);
+#undef ESTEP_M
     HGMM_HIP(c, hipGetLastError());
     return HGMM_OK;
 }
@@ -789,30 +843,16 @@ extern "C" int hgmm_flat_mstep(hgmm_ctx* c, int cov_type, int variant, int J, co
     int valid_j = 0;
     {
         ProfScope prof(c, HGMM_K_FLAT_MSTEP);
-#define MSTEP_CASE(V, S)                                                                        \
-    do {                                                                                        \
-        flat_mstep_kernel<V, S><<<grid, BLOCK, 0, c->stream>>>(X, dev_resp, is_log, hint, c->n, J, \
-                                                              f.Jpad, part);                   \
-        valid_j = V * S * 64;                                                                   \
+        int nv4, nv1;
+        pick_layout(J, &nv4, &nv1);
+#define MSTEP_M(A, B)                                                                              \
+    do {                                                                                           \
+        flat_mstep_kernel<A, B><<<grid, BLOCK, 0, c->stream>>>(X, dev_resp, is_log, hint, c->n, J,  \
+                                                              f.Jpad, part);                      \
+        valid_j = 256 * A + 64 * B;                                                                \
     } while (0)
-        if (J % 4 == 0) {
-            const int ns = (J + 255) / 256;
-            switch (ns) {
-                case 1: MSTEP_CASE(4, 1); break;
-                case 2: MSTEP_CASE(4, 2); break;
-                case 3: MSTEP_CASE(4, 3); break;
-                default: MSTEP_CASE(4, 4); break;
-            }
-        } else {
-            const int ns = (J + 63) / 64;
-            if (ns <= 1) MSTEP_CASE(1, 1);
-            else if (ns <= 2) MSTEP_CASE(1, 2);
-            else if (ns <= 4) MSTEP_CASE(1, 4);
-            else if (ns <= 8) MSTEP_CASE(1, 8);
-            else if (ns <= 12) MSTEP_CASE(1, 12);
-            else MSTEP_CASE(1, 16);
-        }
-#undef MSTEP_CASE
+        LAYOUT_DISPATCH(nv4, nv1, MSTEP_M);
+#undef MSTEP_M
     }
     HGMM_HIP(c, hipGetLastError());
     HGMM_TRY(launch_reduce(c, grid, valid_j, false, nullptr));
