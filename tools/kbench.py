@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks on the GPU box (hipEvent timing through hgmm_profile_*).
+
+    python tools/kbench.py [--n 1000000] [--j 800] [--reps 20]
+Environment switches read by the library at launch time are swept here."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--j", type=int, default=800)
+    ap.add_argument("--reps", type=int, default=20)
+    args = ap.parse_args()
+    import hgmm_amd
+    ctx = hgmm_amd.Context(0)
+    N, J = args.n, args.j
+    X = np.random.RandomState(0).rand(N, 3).astype(np.float32)
+    idx = np.random.RandomState(100).choice(N, J, replace=False)
+    mu0 = X[idx].copy()
+    w0 = (np.ones(J) / J).astype(np.float32)
+    cov0 = (0.1 * np.ones((J, 3))).astype(np.float32)
+    ctx.set_points(X)
+    inv, mu, w, cov, lls, _ = ctx.flat_train(3, 0.0, mu0, cov0, w0, "diag", "W")
+    lr = ctx.empty((N, J), np.float32)
+    alg = 12 * N + 4 * N * J + 4 * N + 28 * J
+    res = {}
+
+    def time_estep(label):
+        ctx.flat_estep(inv, mu, w, "diag", "W", out=lr)
+        ctx.profile_reset(); ctx.profile_enable(True)
+        for _ in range(args.reps):
+            ctx.flat_estep(inv, mu, w, "diag", "W", out=lr)
+        ctx.profile_enable(False)
+        ms, n = ctx.profile_get("flat_estep")
+        res[label] = {"ms": ms / n, "GBs": alg / (ms / n * 1e-3) / 1e9}
+        print("%-28s %.4f ms  %.0f GB/s (%.1f%% of 8 TB/s)" % (label, ms / n, res[label]["GBs"], res[label]["GBs"] / 80))
+
+    for nt in ("0", "1"):
+        for bpc in ("1", "0"):
+            os.environ["HGMM_ESTEP_NT"] = nt
+            os.environ["HGMM_ESTEP_BPC3"] = bpc
+            time_estep("estep nt=%s blocks/CU=%s" % (nt, "3" if bpc == "1" else "2"))
+    os.environ["HGMM_ESTEP_NT"] = "0"; os.environ["HGMM_ESTEP_BPC3"] = "1"
+
+    ctx.profile_reset(); ctx.profile_enable(True)
+    ctx.flat_train(args.reps, 0.0, mu0, cov0, w0, "diag", "W")
+    ctx.profile_enable(False)
+    ms, n = ctx.profile_get("flat_fused")
+    print("%-28s %.4f ms  %.3g pairs/s" % ("fused", ms / n, N * J / (ms / n * 1e-3)))
+    res["fused"] = {"ms": ms / n}
+
+    ctx.flat_mstep(lr.exp(), "diag", "W", centre_hint=mu)
+    ctx.profile_reset(); ctx.profile_enable(True)
+    for _ in range(5):
+        ctx.flat_mstep(lr.exp(), "diag", "W", centre_hint=mu)
+    ctx.profile_enable(False)
+    ms, n = ctx.profile_get("flat_mstep")
+    print("%-28s %.4f ms  %.0f GB/s" % ("mstep(log_resp.exp())", ms / n, (4 * N * J + 12 * N) / (ms / n * 1e-3) / 1e9))
+    res["mstep"] = {"ms": ms / n}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
