@@ -96,6 +96,28 @@ def bunny_leg(ctx):
             "gpu_it_per_s": g, "cpu_it_per_s": c, "cpu_cores": os.cpu_count(), "speedup": g / c}
 
 
+def hgmm_leg(ctx):
+    """BASELINE configs[3]: 4-level GMM tree (8 + 64 + 512 + 4096 = 4680 nodes) on bun000.ply,
+    CPU-twin constants (ls = 80, ld = 1e-4, sig2 = 0.00034, seed-72 initial means)."""
+    path = os.path.join(ROOT, "tests", "golden", "bun000_xyz.npy")
+    if not os.path.exists(path):
+        return None
+    P = np.load(path).astype(np.float64)
+    L, T = 4, 4680
+    idx = np.random.RandomState(72).randint(T, size=T)
+    ctx.set_points(P)
+    ctx.tree_build(L, 80.0, 1e-4, P[idx], 0.00034, 1000)               # warm-up
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        pi, mu, cov, leaf, iters, q = ctx.tree_build(L, 80.0, 1e-4, P[idx], 0.00034, 1000)
+        ts.append(time.perf_counter() - t0)
+    dt = float(np.median(ts))
+    return {"workload": "bun000.ply N=40256, HGMM L=4 (4680 nodes), float64, ls=80 ld=1e-4 sig2=0.00034",
+            "build_ms": dt * 1e3, "level_iterations": [int(v) for v in iters],
+            "level_iterations_per_s": float(iters.sum() / dt), "q_final": float(q[-1])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,8 +232,18 @@ def main():
         out["materialised_iteration"] = {"it_per_s": 1.0 / api_dt,
                                          "mstep_avg_ms": m_ms / max(m_n, 1),
                                          "mstep_GBs": (4 * N_POINTS * J_COMP + 12 * N_POINTS) / (m_ms / max(m_n, 1) * 1e-3) / 1e9}
+        # what a pure 16-byte store stream of the same size reaches on this chip (write ceiling)
+        ctx.util_fill(lr, 0.0, True)
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        for _ in range(10):
+            ctx.util_fill(lr, 0.0, True)
+        ctx.profile_enable(False)
+        f_ms, f_n = ctx.profile_get("util_fill")
+        out["roofline"]["store_stream_ceiling_GBs"] = 4 * N_POINTS * J_COMP / (f_ms / f_n * 1e-3) / 1e9
         lr.free()
         out["bunny"] = bunny_leg(ctx)
+        out["hgmm"] = hgmm_leg(ctx)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_main()
     elif rank == 0:

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libhgmm_hip.so")
 COV_TYPES = {"diag": 0, "spherical": 1}
 VARIANTS = {"W": 0, "G": 1}
 KERNEL_IDS = {"flat_estep": 0, "flat_fused": 1, "flat_mstep": 2, "tree_estep": 3,
-              "tree_loglik": 4, "tree_reg": 5}
+              "tree_loglik": 4, "tree_reg": 5, "util_fill": 6}
 
 
 class HgmmError(RuntimeError):
@@ -88,6 +88,7 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_profile_enable", [ctx, C.c_int])
         _sig(lib, "hgmm_profile_reset", [ctx])
         _sig(lib, "hgmm_profile_get", [ctx, C.c_int, _f64p, C.POINTER(C.c_int64)])
+        _sig(lib, "hgmm_util_fill_f32", [ctx, _vp, C.c_int64, C.c_float, C.c_int])
         _lib = lib
         return lib
 
@@ -419,6 +420,9 @@ class Context:
 
     def profile_reset(self):
         self._check(self.lib.hgmm_profile_reset(self.h))
+
+    def util_fill(self, arr, value=0.0, nontemporal=True):
+        self._check(self.lib.hgmm_util_fill_f32(self.h, arr.ptr, arr.size, float(value), 1 if nontemporal else 0))
 
     def profile_get(self, kernel):
         ms, n = C.c_double(), C.c_int64()

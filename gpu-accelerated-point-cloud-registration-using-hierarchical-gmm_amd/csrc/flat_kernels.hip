@@ -665,6 +665,11 @@ static void pick_layout(int J, int* nv4, int* nv1) {
     }
 }
 
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    return atoi(v);
+}
 static bool env_flag(const char* name, bool dflt) {
     const char* v = getenv(name);
     if (!v || !*v) return dflt;
@@ -690,14 +695,14 @@ static bool env_flag(const char* name, bool dflt) {
 template <bool NORMALISE>
 static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argmax, int* grid_out) {
     const FlatState& f = c->flat;
-    const int grid = grid_for(c, c->n, env_flag("HGMM_ESTEP_BPC3", true) ? 3 : 2);
+    const int grid = grid_for(c, c->n, env_int("HGMM_ESTEP_BPC", 2));
     *grid_out = grid;
     const float* X = c->x_aos.as<float>();
     const float* pk = c->f_pack.as<float>();
     double* lp = c->f_lpn_partials.as<double>();
     int nv4, nv1;
     pick_layout(f.J, &nv4, &nv1);
-    const bool nt = NORMALISE && env_flag("HGMM_ESTEP_NT", false);
+    const bool nt = NORMALISE && env_flag("HGMM_ESTEP_NT", true);
     ProfScope prof(c, HGMM_K_FLAT_ESTEP);
 #define ESTEP_M(A, B)                                                                              \
     do {                                                                                           \
@@ -714,7 +719,7 @@ static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argma
 
 static int launch_fused(hgmm_ctx* c, const int* done_flag, int* grid_out, int* valid_j) {
     const FlatState& f = c->flat;
-    const int grid = grid_for(c, c->n, 2);
+    const int grid = grid_for(c, c->n, env_int("HGMM_FUSED_BPC", 2));
     *grid_out = grid;
     const float* X = c->x_aos.as<float>();
     const float* pk = c->f_pack.as<float>();
@@ -836,7 +841,7 @@ extern "C" int hgmm_flat_mstep(hgmm_ctx* c, int cov_type, int variant, int J, co
         flat_hint_const_kernel<<<(f.Jpad + 255) / 256, 256, 0, c->stream>>>(0.f, 0.f, 0.f, f.Jpad,
                                                                           c->f_hint.as<float>());
     }
-    const int grid = grid_for(c, c->n, 2);
+    const int grid = grid_for(c, c->n, env_int("HGMM_MSTEP_BPC", 2));
     const float* X = c->x_aos.as<float>();
     float* part = c->f_partials.as<float>();
     const float* hint = c->f_hint.as<float>();

@@ -78,9 +78,33 @@ __global__ void f64_to_f32(const double* __restrict__ in, int64_t n, float* __re
     if (i < n) out[i] = (float)in[i];
 }
 
+template <bool NT>
+__global__ __launch_bounds__(256) void util_fill_kernel(float* __restrict__ p, int64_t n4, float v) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 val = {v, v, v, v};
+    f4* q = reinterpret_cast<f4*>(p);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        if (NT) __builtin_nontemporal_store(val, q + i);
+        else q[i] = val;
+    }
+}
+
 }  // namespace hgmm
 
 using namespace hgmm;
+
+extern "C" int hgmm_util_fill_f32(hgmm_ctx* c, float* dev, int64_t n, float value, int nontemporal) {
+    if (!c || !dev || n < 4) return HGMM_ERR_ARG;
+    const int64_t n4 = n / 4;
+    const int grid = c->cus * 8;
+    {
+        ProfScope prof(c, HGMM_K_UTIL_FILL);
+        if (nontemporal) util_fill_kernel<true><<<grid, 256, 0, c->stream>>>(dev, n4, value);
+        else util_fill_kernel<false><<<grid, 256, 0, c->stream>>>(dev, n4, value);
+    }
+    HGMM_HIP(c, hipGetLastError());
+    return HGMM_OK;
+}
 
 extern "C" int hgmm_version(void) { return 100; }
 

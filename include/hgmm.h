@@ -55,7 +55,8 @@ enum hgmm_kernel_id {
     HGMM_K_TREE_ESTEP = 3,    /* HGMM level E-step (8 children / point)      */
     HGMM_K_TREE_LOGLIK = 4,   /* HGMM level log-likelihood (all level nodes) */
     HGMM_K_TREE_REG = 5,      /* HGMM registration E-step (tree descent)     */
-    HGMM_K_COUNT = 6
+    HGMM_K_UTIL_FILL = 6,     /* hgmm_util_fill_f32 (HBM write-ceiling probe) */
+    HGMM_K_COUNT = 7
 };
 
 /* ---- lifecycle ------------------------------------------------------------------ */
@@ -164,6 +165,9 @@ int hgmm_comm_allreduce_f64(hgmm_ctx* ctx, double* host_inout, int n, int op /*0
 int hgmm_profile_enable(hgmm_ctx* ctx, int on);
 int hgmm_profile_reset(hgmm_ctx* ctx);
 int hgmm_profile_get(hgmm_ctx* ctx, int kernel_id, double* total_ms_out, int64_t* launches_out);
+/* Streams `value` into n float32 of a device buffer with 16-byte (optionally non-temporal)
+ * stores: the pure-write HBM ceiling the E-step's log_resp stream is compared with. */
+int hgmm_util_fill_f32(hgmm_ctx* ctx, float* dev, int64_t n, float value, int nontemporal);
 
 #ifdef __cplusplus
 }

@@ -44,12 +44,40 @@ def main():
         res[label] = {"ms": ms / n, "GBs": alg / (ms / n * 1e-3) / 1e9}
         print("%-28s %.4f ms  %.0f GB/s (%.1f%% of 8 TB/s)" % (label, ms / n, res[label]["GBs"], res[label]["GBs"] / 80))
 
-    for nt in ("0", "1"):
-        for bpc in ("1", "0"):
+    for nt in (True, False):
+        ctx.util_fill(lr, 1.0, nt)
+        ctx.profile_reset(); ctx.profile_enable(True)
+        for _ in range(args.reps):
+            ctx.util_fill(lr, 1.0, nt)
+        ctx.profile_enable(False)
+        ms, n = ctx.profile_get("util_fill")
+        print("%-28s %.4f ms  %.0f GB/s  (pure 16-byte store stream, %d MB)" % ("fill nt=%d" % nt, ms / n, 4 * N * J / (ms / n * 1e-3) / 1e9, 4 * N * J >> 20))
+        res["fill_nt%d" % nt] = {"ms": ms / n, "GBs": 4 * N * J / (ms / n * 1e-3) / 1e9}
+    for nt in ("1", "0"):
+        for bpc in ("2", "3"):
             os.environ["HGMM_ESTEP_NT"] = nt
-            os.environ["HGMM_ESTEP_BPC3"] = bpc
-            time_estep("estep nt=%s blocks/CU=%s" % (nt, "3" if bpc == "1" else "2"))
-    os.environ["HGMM_ESTEP_NT"] = "0"; os.environ["HGMM_ESTEP_BPC3"] = "1"
+            os.environ["HGMM_ESTEP_BPC"] = bpc
+            time_estep("estep nt=%s blocks/CU=%s" % (nt, bpc))
+    os.environ.pop("HGMM_ESTEP_NT"); os.environ.pop("HGMM_ESTEP_BPC")
+
+    for bpc in ("1", "2", "3"):
+        os.environ["HGMM_FUSED_BPC"] = bpc
+        ctx.profile_reset(); ctx.profile_enable(True)
+        ctx.flat_train(args.reps, 0.0, mu0, cov0, w0, "diag", "W")
+        ctx.profile_enable(False)
+        ms, n = ctx.profile_get("flat_fused")
+        print("%-28s %.4f ms  %.3g pairs/s" % ("fused blocks/CU=%s" % bpc, ms / n, N * J / (ms / n * 1e-3)))
+    os.environ.pop("HGMM_FUSED_BPC")
+    for bpc in ("1", "2", "3", "4"):
+        os.environ["HGMM_MSTEP_BPC"] = bpc
+        ctx.flat_mstep(lr.exp(), "diag", "W", centre_hint=mu)
+        ctx.profile_reset(); ctx.profile_enable(True)
+        for _ in range(5):
+            ctx.flat_mstep(lr.exp(), "diag", "W", centre_hint=mu)
+        ctx.profile_enable(False)
+        ms, n = ctx.profile_get("flat_mstep")
+        print("%-28s %.4f ms  %.0f GB/s" % ("mstep blocks/CU=%s" % bpc, ms / n, (4 * N * J + 12 * N) / (ms / n * 1e-3) / 1e9))
+    os.environ.pop("HGMM_MSTEP_BPC")
 
     ctx.profile_reset(); ctx.profile_enable(True)
     ctx.flat_train(args.reps, 0.0, mu0, cov0, w0, "diag", "W")
