@@ -59,6 +59,11 @@ def timer(message):
     print('%s:  %f sec' % (message, time.time() - start))
 
 
+def estimate_log_prob(X, inv_cov, means, cov_type):
+    ctx = _ctx_for(X)
+    return ctx.flat_log_prob(_host(inv_cov), _host(means), cov_type)
+
+
 def e_step(X, inv_cov, means, weights, cov_type, variant):
     ctx = _ctx_for(X)
     mean_lpn, log_resp, _, _ = ctx.flat_estep(_host(inv_cov), _host(means), _host(weights), cov_type, variant)

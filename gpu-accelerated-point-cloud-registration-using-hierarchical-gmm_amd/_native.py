@@ -68,6 +68,7 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_num_points", [ctx], C.c_int64)
         _sig(lib, "hgmm_flat_estep", [ctx, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _f64p])
         _sig(lib, "hgmm_flat_predict", [ctx, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp])
+        _sig(lib, "hgmm_flat_log_prob", [ctx, C.c_int, C.c_int, _vp, _vp, _vp])
         _sig(lib, "hgmm_flat_mstep", [ctx, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp])
         _sig(lib, "hgmm_flat_train", [ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp,
                                       _vp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)])
@@ -279,6 +280,12 @@ class Context:
             self.h, COV_TYPES[cov_type], VARIANTS[variant], J, _ptr(mu), _ptr(inv_std), _ptr(w),
             None if lr is None else lr.ptr, None if lpn is None else lpn.ptr, None if am is None else am.ptr, C.byref(mean)))
         return mean.value, lr, lpn, am
+
+    def flat_log_prob(self, inv_std, mu, cov_type="diag"):
+        J, mu, inv_std, _ = self._flat_args(mu, inv_std, np.ones(len(mu), np.float32), cov_type)
+        out = self.empty((self.num_points, J), np.float32)
+        self._check(self.lib.hgmm_flat_log_prob(self.h, COV_TYPES[cov_type], J, _ptr(mu), _ptr(inv_std), out.ptr))
+        return out
 
     def flat_predict(self, inv_std, mu, w, cov_type="diag", variant="W"):
         J, mu, inv_std, w = self._flat_args(mu, inv_std, w, cov_type)

@@ -826,6 +826,21 @@ extern "C" int hgmm_flat_predict(hgmm_ctx* c, int cov_type, int variant, int J, 
     return HGMM_OK;
 }
 
+extern "C" int hgmm_flat_log_prob(hgmm_ctx* c, int cov_type, int J, const float* mu, const float* inv_std,
+                                  float* dev_log_prob) {
+    if (!c || !dev_log_prob) return c ? fail(c, HGMM_ERR_ARG, "dev_log_prob is NULL") : HGMM_ERR_ARG;
+    // weights = 1 under flavour G (log 1 = 0, no eps) gives the bare log-density
+    HGMM_TRY(flat_check(c, cov_type, cov_type == HGMM_COV_DIAG ? HGMM_VARIANT_G : HGMM_VARIANT_W, J));
+    HGMM_TRY(flat_setup(c, cov_type, HGMM_VARIANT_G, J));
+    std::vector<float> ones((size_t)J, 1.0f);
+    HGMM_TRY(flat_upload(c, mu, inv_std, false, ones.data()));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));   // `ones` is pageable host memory
+    launch_pack(c);
+    int grid = 0;
+    HGMM_TRY(launch_estep<false>(c, dev_log_prob, nullptr, nullptr, &grid));
+    return HGMM_OK;
+}
+
 extern "C" int hgmm_flat_mstep(hgmm_ctx* c, int cov_type, int variant, int J, const float* dev_resp,
                                int is_log, const float* centre_hint, float* w_out, float* mu_out,
                                float* cov_out) {

@@ -34,6 +34,22 @@ def init_gmm_params(X, k, cov_type='diag'):
     return means.astype(np.float32), weights, covs
 
 
+def estimate_log_prob(X, inv_cov, means):
+    """-> log N(x_i; mu_j, diag) [N,J] DeviceArray.  Reference gmm_impl.py:67-78."""
+    return _flat.estimate_log_prob(X, inv_cov, means, 'diag')
+
+
+def estimate_log_prob_spherical(X, inv_cov, means):
+    """Reference gmm_impl.py:53-65."""
+    return _flat.estimate_log_prob(X, inv_cov, means, 'spherical')
+
+
+def row_norms(X, squared=False):
+    """Host helper kept for API parity (reference gmm_impl.py:18-24)."""
+    n = np.einsum('ij,ij->i', np.asarray(X), np.asarray(X))
+    return n if squared else np.sqrt(n)
+
+
 def e_step(X, inv_cov, means, weights, cov_type='diag'):
     """-> (mean log-normaliser, log_resp[N,J] DeviceArray).  Reference gmm_impl.py:105-116."""
     return _flat.e_step(X, inv_cov, means, weights, cov_type, VARIANT)

@@ -17,6 +17,11 @@ def init_gmm_params(X, k):
     return kmeans.cluster_centers_, np.ones((k)) / k
 
 
+def estimate_log_prob(X, inv_cov, means):
+    """Reference gmmreg_gpu/gmm_impl.py:36-43."""
+    return _flat.estimate_log_prob(X, inv_cov, means, 'diag')
+
+
 def e_step(X, inv_cov, means, weights):
     return _flat.e_step(X, inv_cov, means, weights, 'diag', VARIANT)
 

@@ -95,6 +95,10 @@ int hgmm_flat_estep(hgmm_ctx* ctx, int cov_type, int variant, int J,
                     const float* mu, const float* inv_std, const float* w,
                     float* dev_log_resp, float* dev_lpn, int32_t* dev_argmax,
                     double* mean_lpn_out);
+/* Un-normalised per-pair log-densities log N(x_i; mu_j, diag) -> dev_log_prob [N,J]
+ * (estimate_log_prob / estimate_log_prob_spherical, gmm_waymo gmm_impl.py:53-78). */
+int hgmm_flat_log_prob(hgmm_ctx* ctx, int cov_type, int J, const float* mu, const float* inv_std,
+                       float* dev_log_prob);
 int hgmm_flat_predict(hgmm_ctx* ctx, int cov_type, int variant, int J,
                       const float* mu, const float* inv_std, const float* w,
                       int32_t* dev_labels);

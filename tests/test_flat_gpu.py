@@ -296,3 +296,61 @@ def test_rccl_single_rank_communicator(ctx, bunny):
         c2.comm_destroy()
     finally:
         c2.close()
+
+
+@pytest.mark.parametrize("cov_type", ["diag", "spherical"])
+def test_estimate_log_prob(ctx, cov_type):
+    """estimate_log_prob[_spherical] through the drop-in module API."""
+    import hgmm_amd
+    from hgmm_amd.gmm_waymo import gmm_impl
+    hgmm_amd.set_default_context(ctx)
+    g = load_golden("flat_small_W_%s.npz" % cov_type)
+    X = g["X"]
+    fn = gmm_impl.estimate_log_prob if cov_type == "diag" else gmm_impl.estimate_log_prob_spherical
+    lp = fn(X, g["it5_inv"], g["it5_mu"]).get()
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    ofn = flat_em.log_gauss_diag if cov_type == "diag" else flat_em.log_gauss_spherical
+    o = ofn(f64(X), f64(g["it5_inv"]), f64(g["it5_mu"]))
+    np.testing.assert_allclose(lp, o, rtol=2e-5, atol=2e-5)
+
+
+def test_dropin_module_api(ctx, bunny):
+    """The reference-shaped entry points end to end: GMM_GPU.init/compute/predict,
+    train_gmm/e_step/m_step/predict with host arrays and with a resident DevicePoints."""
+    import hgmm_amd
+    from hgmm_amd.gmm_waymo import gmm as Wg, gmm_impl as W
+    from hgmm_amd.gmmreg_gpu import gmm as Gg
+    hgmm_amd.set_default_context(ctx)
+    X = bunny[::4]
+    np.random.seed(0)
+    f = Wg.GMM_GPU(n_gmm_components=20, max_iter=5, tol=1e-9, cov_type='spherical')
+    f.init()
+    means, weights, covs, inv = f.compute(X)
+    assert means.shape == (20, 3) and covs.shape == (20,) and inv.shape == (20,)
+    labels = f.predict(X)
+    assert labels.dtype == np.int64 and labels.shape == (len(X),)
+    o = flat_em.predict(X.astype(np.float64), inv.astype(np.float64), means.astype(np.float64),
+                        weights.astype(np.float64), 'spherical', 'W')
+    assert (labels != o).mean() < 1e-3
+    assert len(Wg.GMM_CPU(5, max_iter=2).__class__.__mro__) > 1
+    c = Wg.GMM_CPU(n_gmm_components=5, max_iter=2)
+    c.init()
+    assert len(c.compute(X)) == 3
+    gq = Gg.GMM_GPU(n_gmm_components=6, max_iter=3)
+    gq.init()
+    m2, w2 = gq.compute(X)
+    assert m2.shape == (6, 3) and abs(w2.sum() - 1) < 1e-3
+    # function level, resident points
+    dX = W.asarray(X)
+    mu0, w0, cov0 = flat_em.seeded_init(X, 16, 4)
+    inv0 = 1 / np.sqrt(cov0)
+    ll, lr = W.e_step(dX, inv0, mu0, w0)
+    wts, mus, cvs = W.m_step(dX, lr.exp(), centre_hint=mu0)
+    o_ll, o_lr = flat_em.e_step(X.astype(np.float64), inv0.astype(np.float64), mu0.astype(np.float64), w0.astype(np.float64))
+    o_w, o_mu, o_cov = flat_em.m_step(X.astype(np.float64), np.exp(o_lr))
+    assert abs(ll - o_ll) < 1e-5
+    np.testing.assert_allclose(mus, o_mu, atol=5e-6)
+    np.testing.assert_allclose(cvs, o_cov, rtol=1e-4)
+    # m_step with a host responsibilities array (the reference's calling convention)
+    wts2, mus2, cvs2 = W.m_step(X, np.exp(lr.get()))
+    np.testing.assert_allclose(mus2, o_mu, atol=5e-6)
