@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libhgmm_hip.so")
 COV_TYPES = {"diag": 0, "spherical": 1}
 VARIANTS = {"W": 0, "G": 1}
 KERNEL_IDS = {"flat_estep": 0, "flat_fused": 1, "flat_mstep": 2, "tree_estep": 3,
-              "tree_loglik": 4, "tree_reg": 5, "util_fill": 6}
+              "tree_loglik": 4, "tree_reg": 5, "util_fill": 6, "full_pass": 7, "full_moments": 8}
 
 
 class HgmmError(RuntimeError):
@@ -82,6 +82,9 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_tree_set_target", [ctx, _vp, C.c_int64])
         _sig(lib, "hgmm_tree_reg_estep", [ctx, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp])
         _sig(lib, "hgmm_tree_node_complexity", [ctx, _vp])
+        _sig(lib, "hgmm_fullcov_fit", [ctx, C.c_int, C.c_double, C.c_double, _vp, C.c_double, C.c_int, _vp, _vp, _vp,
+                                       _vp, _vp, C.c_int, C.POINTER(C.c_int)])
+        _sig(lib, "hgmm_fullcov_estep", [ctx, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64p])
         _sig(lib, "hgmm_comm_unique_id", [_vp])
         _sig(lib, "hgmm_comm_init_rank", [ctx, C.c_int, C.c_int, _vp])
         _sig(lib, "hgmm_comm_destroy", [ctx])
@@ -396,6 +399,32 @@ class Context:
         out = np.empty(T)
         self._check(self.lib.hgmm_tree_node_complexity(self.h, _ptr(out)))
         return out
+
+    # -- flat full-covariance EM -----------------------------------------------------------
+    def fullcov_fit(self, J, ls, ld, init_mu, sig2, max_iters=1000):
+        init_mu = np.ascontiguousarray(init_mu, dtype=np.float64)
+        if init_mu.shape != (J, 3):
+            raise ValueError("init_mu must be [%d,3]" % J)
+        pi, mu, cov = np.empty(J), np.empty((J, 3)), np.empty((J, 3, 3))
+        labels = np.empty(self.num_points, np.int32)
+        q = np.zeros(int(max_iters))
+        qlen = C.c_int()
+        self._check(self.lib.hgmm_fullcov_fit(self.h, int(J), float(ls), float(ld), _ptr(init_mu), float(sig2),
+                                              int(max_iters), _ptr(pi), _ptr(mu), _ptr(cov), _ptr(labels), _ptr(q),
+                                              int(max_iters), C.byref(qlen)))
+        return pi, mu, cov, labels, q[:qlen.value].copy()
+
+    def fullcov_estep(self, pi, mu, cov):
+        pi = np.ascontiguousarray(pi, dtype=np.float64)
+        J = len(pi)
+        mu = np.ascontiguousarray(mu, dtype=np.float64).reshape(J, 3)
+        cov = np.ascontiguousarray(cov, dtype=np.float64).reshape(J, 3, 3)
+        m0, m1, m2 = np.empty(J), np.empty((J, 3)), np.empty((J, 3, 3))
+        labels = np.empty(self.num_points, np.int32)
+        q = C.c_double()
+        self._check(self.lib.hgmm_fullcov_estep(self.h, J, _ptr(pi), _ptr(mu), _ptr(cov), _ptr(m0), _ptr(m1), _ptr(m2),
+                                                _ptr(labels), C.byref(q)))
+        return m0, m1, m2, labels, q.value
 
     # -- multi-GPU ------------------------------------------------------------------------
     @staticmethod

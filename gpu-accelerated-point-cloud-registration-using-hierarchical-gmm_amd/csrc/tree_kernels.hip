@@ -794,3 +794,319 @@ extern "C" int hgmm_tree_node_complexity(hgmm_ctx* c, double* cplx_out) {
     HGMM_HIP(c, hipStreamSynchronize(c->stream));
     return HGMM_OK;
 }
+
+// ==========================================================================================
+// Flat FULL-covariance EM  ==  ONE tree level with branching J  (the CPU twin run
+// with its module global n_node = J and maxTreeLevel = 1, hgmm_cupy_cpu_working.py:30,122-198).
+// float64.  Per iteration:
+//   full_pass_kernel     lanes across points, the J components tiled through LDS: for every
+//                        point  den_i = sum_j pi_j N(x_i; j),  arg-max_j,  and the level
+//                        log-likelihood term  log max(sum_{pi_j >= eps} pi_j N, eps).
+//   full_moments_kernel  the 10 sufficient statistics per component as a dense contraction
+//                        M[J,10] = Gamma^T [N,J] . F[N,10],  F_i = (1, x, y, z, xx, xy, xz, yy, yz, zz),
+//                        on the fp64 matrix cores (v_mfma_f64_16x16x4_f64): per wave a 16-component
+//                        x 16-feature accumulator tile stays in registers across all of the
+//                        workgroup's points; gamma and F are transposed through LDS.
+//   full_reduce_kernel   fixed-order sum of the per-workgroup partials -> mom[J][10] (the
+//                        buffer the RCCL all-reduce works on), then tree_mstep/tree_prep.
+// ==========================================================================================
+namespace hgmm {
+
+constexpr int FULL_LD = 66;          // LDS row stride (doubles): conflict-free 16x4 fragment reads
+constexpr int FULL_WAVES = 2;        // waves per workgroup of the moments kernel (LDS: 2 x 2 x 8.4 KB)
+constexpr int FULL_BLOCK = FULL_WAVES * 64;
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(CH) void full_pass_kernel(const double* __restrict__ xs, int64_t n, int64_t n_pad,
+                                                       const double* __restrict__ prep, int J,
+                                                       double* __restrict__ den_out, int* __restrict__ label_out,
+                                                       double* __restrict__ block_q) {
+    __shared__ double tile[LL_TILE][11];
+    __shared__ double shq[CH / 64];
+    const int64_t i = (int64_t)blockIdx.x * CH + threadIdx.x;
+    const bool active = i < n;
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+    if (active) { x0 = xs[i]; x1 = xs[n_pad + i]; x2 = xs[2 * n_pad + i]; }
+    double den = 0.0, tot = 0.0, best = -1.0;
+    int am = 0;
+    for (int base = 0; base < J; base += LL_TILE) {
+        const int cnt = (J - base < LL_TILE) ? J - base : LL_TILE;
+        __syncthreads();
+        for (int t = threadIdx.x; t < cnt * 11; t += CH) {
+            const int node = t / 11, fidx = t % 11;
+            tile[node][fidx] = prep[PREP_N * (base + node) + fidx];
+        }
+        __syncthreads();
+        for (int node = 0; node < cnt; ++node) {
+            const double wE = tile[node][9];
+            if (wE == 0.0) continue;                                    // workgroup-uniform
+            const double d0 = x0 - tile[node][6], d1 = x1 - tile[node][7], d2 = x2 - tile[node][8];
+            const double q = tile[node][0] * d0 * d0 + tile[node][3] * d1 * d1 + tile[node][5] * d2 * d2 +
+                             2.0 * (tile[node][1] * d0 * d1 + tile[node][2] * d0 * d2 + tile[node][4] * d1 * d2);
+            double g = 0.0;
+            if (__any(q < 1500.0)) g = wE * exp(-0.5 * q);
+            den += g;
+            if (tile[node][10] != 0.0) tot += g;      // pi >= eps: counts towards the log-likelihood
+            if (g > best) { best = g; am = base + node; }
+        }
+    }
+    if (active) {
+        den_out[i] = den;
+        label_out[i] = (den > TREE_EPS) ? am : 0;   // all gammas zero -> argmax = 0 (C:178,184)
+    }
+    double lq = active ? log(fmax(tot, TREE_EPS)) : 0.0;
+    lq = wave_sum_f64(lq);
+    if (lane_id() == 0) shq[wave_in_block()] = lq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < CH / 64; ++w) t += shq[w];
+        block_q[blockIdx.x] = t;
+    }
+}
+
+// grid = persistent workgroups, each owning a contiguous range of 64-point groups
+__global__ __launch_bounds__(FULL_BLOCK) void full_moments_kernel(const double* __restrict__ xs, int64_t n, int64_t n_pad,
+                                                          const double* __restrict__ prep, int J16,
+                                                          const double* __restrict__ den_in,
+                                                          double* __restrict__ partials /*[grid][J16][NMOM]*/) {
+    __shared__ double G[FULL_WAVES][16][FULL_LD];    // gamma, component-major, per wave
+    __shared__ double F[FULL_WAVES][16][FULL_LD];    // features, feature-major, per wave
+    __shared__ double red[FULL_WAVES][16][16];
+    const int w = wave_in_block(), lane = lane_id();
+    const int64_t groups = (n + 63) / 64;
+    const int64_t nw = (int64_t)gridDim.x * FULL_WAVES;
+    const int64_t per = (groups + nw - 1) / nw;
+    const int64_t gw = (int64_t)blockIdx.x * FULL_WAVES + w;
+    const int64_t g0 = gw * per, g1 = (g0 + per < groups) ? g0 + per : groups;
+    const int a_idx = lane & 15, b_idx = lane >> 4;
+
+    for (int tile = 0; tile < J16; tile += 16) {
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+        for (int64_t grp = g0; grp < g1; ++grp) {
+            const int64_t i = grp * 64 + lane;
+            const bool active = i < n;
+            double x0 = 0.0, x1 = 0.0, x2 = 0.0, inv_den = 0.0;
+            if (active) {
+                x0 = xs[i]; x1 = xs[n_pad + i]; x2 = xs[2 * n_pad + i];
+                const double den = den_in[i];
+                inv_den = (den > TREE_EPS) ? 1.0 / den : 0.0;
+            }
+            // features of this lane's point, feature-major
+            F[w][0][lane] = 1.0; F[w][1][lane] = x0; F[w][2][lane] = x1; F[w][3][lane] = x2;
+            F[w][4][lane] = x0 * x0; F[w][5][lane] = x0 * x1; F[w][6][lane] = x0 * x2;
+            F[w][7][lane] = x1 * x1; F[w][8][lane] = x1 * x2; F[w][9][lane] = x2 * x2;
+#pragma unroll
+            for (int f = 10; f < 16; ++f) F[w][f][lane] = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) {
+                const double* pr = prep + PREP_N * (tile + cc);     // wave-uniform
+                const double wE = pr[9];
+                double gam = 0.0;
+                if (wE != 0.0) {
+                    const double d0 = x0 - pr[6], d1 = x1 - pr[7], d2 = x2 - pr[8];
+                    const double q = pr[0] * d0 * d0 + pr[3] * d1 * d1 + pr[5] * d2 * d2 +
+                                     2.0 * (pr[1] * d0 * d1 + pr[2] * d0 * d2 + pr[4] * d1 * d2);
+                    if (__any(q < 1500.0)) gam = wE * exp(-0.5 * q) * inv_den;
+                    // reference: gamma = g / den (C:176); accumulate() drops gamma < eps (C:100)
+                    if (gam < TREE_EPS || !active) gam = 0.0;
+                }
+                G[w][cc][lane] = gam;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): this wave's LDS writes landed
+            __builtin_amdgcn_wave_barrier();
+            // 16 MFMAs: D[comp][feat] += sum over the 4 points of sub-group s
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const double a = G[w][a_idx][4 * s + b_idx];
+                const double b = F[w][a_idx][4 * s + b_idx];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // D layout (f64 16x16x4): row (component) = (lane >> 4) + 4 r, col (feature) = lane & 15
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[w][b_idx + 4 * r][a_idx] = acc[r];
+        __syncthreads();
+        // fixed-order combination of the workgroup's waves, one partial per workgroup
+        for (int e = threadIdx.x; e < 16 * NMOM; e += FULL_BLOCK) {
+            const int comp = e / NMOM, feat = e % NMOM;
+            double t = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < FULL_WAVES; ++ww) t += red[ww][comp][feat];
+            partials[((size_t)blockIdx.x * J16 + tile + comp) * NMOM + feat] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// one wave per component: fixed-order sum over the workgroups' partials
+__global__ __launch_bounds__(64) void full_reduce_kernel(const double* __restrict__ partials, int nblocks,
+                                                         int J, int J16, double* __restrict__ mom) {
+    const int j = blockIdx.x;
+    if (j >= J) return;
+    double acc[NMOM];
+#pragma unroll
+    for (int m = 0; m < NMOM; ++m) acc[m] = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 64) {
+        const double* src = partials + ((size_t)b * J16 + j) * NMOM;
+#pragma unroll
+        for (int m = 0; m < NMOM; ++m) acc[m] += src[m];
+    }
+#pragma unroll
+    for (int m = 0; m < NMOM; ++m) {
+        const double v = wave_sum_f64(acc[m]);
+        if (threadIdx.x == 0) mom[(size_t)j * NMOM + m] = v;
+    }
+}
+
+__global__ void full_init_nodes_kernel(const double* __restrict__ init_mu, double sig2, int J, int J16,
+                                       double* pi, double* mu, double* cov) {
+    // pi = 1/J (n_node = J), mu = given, cov = sig2 I; padding components get pi = 0
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= J16) return;
+    pi[j] = (j < J) ? 1.0 / (double)J : 0.0;
+    for (int d = 0; d < 3; ++d) mu[3 * j + d] = (j < J) ? init_mu[3 * j + d] : 0.0;
+    for (int e = 0; e < 9; ++e) cov[9 * j + e] = (e % 4 == 0) ? ((j < J) ? sig2 : 1.0) : 0.0;
+}
+
+}  // namespace hgmm
+
+static int fullcov_alloc(hgmm_ctx* c, int J, int* J16_out, int* grid_out) {
+    const int J16 = (J + 15) / 16 * 16;
+    *J16_out = J16;
+    const int64_t groups = (c->n + 63) / 64;
+    int64_t grid = (groups + FULL_WAVES - 1) / FULL_WAVES;
+    if (grid > 4 * c->cus) grid = 4 * c->cus;
+    if (grid < 1) grid = 1;
+    *grid_out = (int)grid;
+    HGMM_TRY(ensure(c, c->t_pi, sizeof(double) * J16));
+    HGMM_TRY(ensure(c, c->t_mu, sizeof(double) * 3 * J16));
+    HGMM_TRY(ensure(c, c->t_cov, sizeof(double) * 9 * J16));
+    HGMM_TRY(ensure(c, c->t_prep, sizeof(double) * PREP_N * J16));
+    HGMM_TRY(ensure(c, c->t_mom, sizeof(double) * NMOM * J16));
+    HGMM_TRY(ensure(c, c->t_partials, sizeof(double) * (size_t)grid * J16 * NMOM));
+    HGMM_TRY(ensure(c, c->t_q, sizeof(double) * (nblk(c->n, CH) + 8)));
+    HGMM_TRY(ensure(c, c->t_current, sizeof(int) * 2 * c->n_pad));
+    HGMM_TRY(ensure(c, c->t_parent, sizeof(double) * c->n_pad));     // den
+    c->tree.nodes_ready = false;
+    return HGMM_OK;
+}
+
+static int fullcov_moments(hgmm_ctx* c, int J, int J16, int grid) {
+    {
+        ProfScope prof(c, HGMM_K_FULL_MOMENTS);
+        full_moments_kernel<<<grid, FULL_BLOCK, 0, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad, c->t_prep.as<double>(),
+                                                       J16, c->t_parent.as<double>(), c->t_partials.as<double>());
+    }
+    full_reduce_kernel<<<J, 64, 0, c->stream>>>(c->t_partials.as<double>(), grid, J, J16, c->t_mom.as<double>());
+    HGMM_HIP(c, hipGetLastError());
+    if (c->comm) HGMM_TRY(allreduce_f64_dev(c, c->t_mom.as<double>(), (size_t)NMOM * J));
+    return HGMM_OK;
+}
+
+static int fullcov_pass(hgmm_ctx* c, int J, int* labels, double* q_host) {
+    double* block_q = c->t_q.as<double>();
+    double* q_dev = block_q + nblk(c->n, CH);
+    {
+        ProfScope prof(c, HGMM_K_FULL_PASS);
+        full_pass_kernel<<<nblk(c->n, CH), CH, 0, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
+                                                             c->t_prep.as<double>(), J, c->t_parent.as<double>(),
+                                                             labels, block_q);
+    }
+    tree_sum_kernel<<<1, 256, 0, c->stream>>>(block_q, (int)nblk(c->n, CH), q_dev);
+    HGMM_HIP(c, hipGetLastError());
+    if (c->comm) HGMM_TRY(allreduce_f64_dev(c, q_dev, 1));
+    if (q_host) {
+        HGMM_HIP(c, hipMemcpyAsync(q_host, q_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_fullcov_fit(hgmm_ctx* c, int J, double ls, double ld, const double* init_mu, double sig2,
+                                int max_iters, double* pi_out, double* mu_out, double* cov_out,
+                                int32_t* labels_out, double* q_trace_out, int q_capacity, int* q_len_out) {
+    if (!c) return HGMM_ERR_ARG;
+    if (!c->have_f64 || c->n <= 0) return fail(c, HGMM_ERR_STATE, "full-covariance fit: set points first");
+    if (J < 1 || J > 4096) return fail(c, HGMM_ERR_ARG, "J = %d outside 1..4096", J);
+    if (!init_mu) return fail(c, HGMM_ERR_ARG, "init_mu is NULL");
+    if (max_iters < 1) max_iters = 1;
+    HGMM_HIP(c, hipSetDevice(c->device));
+    int J16 = 0, grid = 0;
+    HGMM_TRY(fullcov_alloc(c, J, &J16, &grid));
+    HGMM_TRY(ensure(c, c->scratch, sizeof(double) * 3 * J16));
+    double* d_pi = c->t_pi.as<double>();
+    double* d_mu = c->t_mu.as<double>();
+    double* d_cov = c->t_cov.as<double>();
+    double* d_prep = c->t_prep.as<double>();
+    int* lab_a = c->t_current.as<int>();
+    int* lab_b = lab_a + c->n_pad;
+    HGMM_HIP(c, hipMemcpyAsync(c->scratch.p, init_mu, sizeof(double) * 3 * J, hipMemcpyHostToDevice, c->stream));
+    full_init_nodes_kernel<<<nblk(J16, 256), 256, 0, c->stream>>>(c->scratch.as<double>(), sig2, J, J16, d_pi, d_mu, d_cov);
+    tree_prep_kernel<<<nblk(J16, 256), 256, 0, c->stream>>>(d_pi, d_mu, d_cov, 0, J16, d_prep);
+    double n_total = (double)c->n;
+    if (c->comm) HGMM_TRY(hgmm_comm_allreduce_f64(c, &n_total, 1, 0));
+    // E-step quantities of the initial parameters
+    HGMM_TRY(fullcov_pass(c, J, lab_a, nullptr));
+    int* lab_cur = lab_a;      // arg-max of the most recent E-step
+    int* lab_nxt = lab_b;
+    double prev_q = 0.0;
+    int it = 0, q_len = 0;
+    while (true) {
+        HGMM_TRY(fullcov_moments(c, J, J16, grid));                                   // E (moments)
+        tree_mstep_kernel<<<nblk(J, 256), 256, 0, c->stream>>>(c->t_mom.as<double>(), 0, J, n_total, ld, d_pi, d_mu, d_cov);
+        tree_prep_kernel<<<nblk(J, 256), 256, 0, c->stream>>>(d_pi, d_mu, d_cov, 0, J, d_prep);   // M
+        double q = 0.0;
+        HGMM_TRY(fullcov_pass(c, J, lab_nxt, &q));                                    // q (+ next E-step's den)
+        ++it;
+        if (q_trace_out && q_len < q_capacity) q_trace_out[q_len] = q;
+        ++q_len;
+        if (fabs(q - prev_q) < ls || it >= max_iters) break;
+        prev_q = q;
+        int* t = lab_cur; lab_cur = lab_nxt; lab_nxt = t;
+    }
+    if (labels_out) HGMM_HIP(c, hipMemcpyAsync(labels_out, lab_cur, sizeof(int) * c->n, hipMemcpyDeviceToHost, c->stream));
+    if (pi_out) HGMM_HIP(c, hipMemcpyAsync(pi_out, d_pi, sizeof(double) * J, hipMemcpyDeviceToHost, c->stream));
+    if (mu_out) HGMM_HIP(c, hipMemcpyAsync(mu_out, d_mu, sizeof(double) * 3 * J, hipMemcpyDeviceToHost, c->stream));
+    if (cov_out) HGMM_HIP(c, hipMemcpyAsync(cov_out, d_cov, sizeof(double) * 9 * J, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    if (q_len_out) *q_len_out = q_len < q_capacity ? q_len : q_capacity;
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_fullcov_estep(hgmm_ctx* c, int J, const double* pi, const double* mu, const double* cov,
+                                  double* m0_out, double* m1_out, double* m2_out, int32_t* labels_out,
+                                  double* q_out) {
+    if (!c || !pi || !mu || !cov) return c ? fail(c, HGMM_ERR_ARG, "NULL parameter table") : HGMM_ERR_ARG;
+    if (!c->have_f64 || c->n <= 0) return fail(c, HGMM_ERR_STATE, "full-covariance E-step: set points first");
+    if (J < 1 || J > 4096) return fail(c, HGMM_ERR_ARG, "J = %d outside 1..4096", J);
+    HGMM_HIP(c, hipSetDevice(c->device));
+    int J16 = 0, grid = 0;
+    HGMM_TRY(fullcov_alloc(c, J, &J16, &grid));
+    HGMM_HIP(c, hipMemsetAsync(c->t_pi.p, 0, sizeof(double) * J16, c->stream));
+    HGMM_HIP(c, hipMemsetAsync(c->t_mu.p, 0, sizeof(double) * 3 * J16, c->stream));
+    HGMM_HIP(c, hipMemsetAsync(c->t_cov.p, 0, sizeof(double) * 9 * J16, c->stream));
+    HGMM_HIP(c, hipMemcpyAsync(c->t_pi.p, pi, sizeof(double) * J, hipMemcpyHostToDevice, c->stream));
+    HGMM_HIP(c, hipMemcpyAsync(c->t_mu.p, mu, sizeof(double) * 3 * J, hipMemcpyHostToDevice, c->stream));
+    HGMM_HIP(c, hipMemcpyAsync(c->t_cov.p, cov, sizeof(double) * 9 * J, hipMemcpyHostToDevice, c->stream));
+    tree_prep_kernel<<<nblk(J16, 256), 256, 0, c->stream>>>(c->t_pi.as<double>(), c->t_mu.as<double>(),
+                                                           c->t_cov.as<double>(), 0, J16, c->t_prep.as<double>());
+    int* lab = c->t_current.as<int>();
+    double q = 0.0;
+    HGMM_TRY(fullcov_pass(c, J, lab, &q));
+    HGMM_TRY(fullcov_moments(c, J, J16, grid));
+    HGMM_TRY(ensure(c, c->scratch, sizeof(double) * 13 * J16));
+    double* e0 = c->scratch.as<double>();
+    double* e1 = e0 + J16;
+    double* e2 = e1 + 3 * J16;
+    tree_expand_moments_kernel<<<nblk(J, 256), 256, 0, c->stream>>>(c->t_mom.as<double>(), J, e0, e1, e2);
+    HGMM_HIP(c, hipGetLastError());
+    if (m0_out) HGMM_HIP(c, hipMemcpyAsync(m0_out, e0, sizeof(double) * J, hipMemcpyDeviceToHost, c->stream));
+    if (m1_out) HGMM_HIP(c, hipMemcpyAsync(m1_out, e1, sizeof(double) * 3 * J, hipMemcpyDeviceToHost, c->stream));
+    if (m2_out) HGMM_HIP(c, hipMemcpyAsync(m2_out, e2, sizeof(double) * 9 * J, hipMemcpyDeviceToHost, c->stream));
+    if (labels_out) HGMM_HIP(c, hipMemcpyAsync(labels_out, lab, sizeof(int) * c->n, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    if (q_out) *q_out = q;
+    return HGMM_OK;
+}

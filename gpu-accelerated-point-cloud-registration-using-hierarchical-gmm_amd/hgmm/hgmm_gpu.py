@@ -71,6 +71,26 @@ def buildGMMTree(points, maxTreeLevel, ls, ld, sig2=0.004, seed=72, init_idx=Non
     return pi, mu, cov
 
 
+def fitFullCovGMM(points, n_components, ls=80.0, ld=1.0e-4, sig2=0.00034, init_idx=None, seed=None,
+                  max_iters=1000, ctx: Context | None = None, return_trace=False):
+    """Flat full-covariance GMM = ONE tree level with branching ``n_components`` (the reference's
+    CPU twin run with its module global ``n_node = J`` and ``buildGMMTree(P, 1, ls, ld)``,
+    hgmm_cupy_cpu_working.py:30,122-160).  -> (mixingCoeff[J], mean[J,3], covar[J,3,3]).
+
+    ``init_idx``: J indices of the initial means (default: the twin's draw
+    ``RandomState(J).randint(J, size=J)`` -- note it only ever picks among the first J points)."""
+    ctx = ctx or default_context()
+    P = np.ascontiguousarray(_points(points), dtype=np.float64)
+    J = int(n_components)
+    if init_idx is None:
+        init_idx = np.random.RandomState(J if seed is None else seed).randint(J, size=J)
+    ctx.set_points(P)
+    pi, mu, cov, labels, q = ctx.fullcov_fit(J, ls, ld, P[np.asarray(init_idx)], sig2, max_iters)
+    if return_trace:
+        return pi, mu, cov, {"labels": labels, "q_trace": q}
+    return pi, mu, cov
+
+
 def gmmTreeRegESTep(points, mixingCoeff, mean, covar, maxTreeLevel, lc, ctx: Context | None = None):
     """-> (momentsZero[T], momentsOne[T,3], momentsTwo[T,3,3])   (hgmm_gpu.py:550-577)."""
     ctx = ctx or default_context()

@@ -56,7 +56,9 @@ enum hgmm_kernel_id {
     HGMM_K_TREE_LOGLIK = 4,   /* HGMM level log-likelihood (all level nodes) */
     HGMM_K_TREE_REG = 5,      /* HGMM registration E-step (tree descent)     */
     HGMM_K_UTIL_FILL = 6,     /* hgmm_util_fill_f32 (HBM write-ceiling probe) */
-    HGMM_K_COUNT = 7
+    HGMM_K_FULL_PASS = 7,     /* full-cov flat EM: denominators + arg-max + log-likelihood */
+    HGMM_K_FULL_MOMENTS = 8,  /* full-cov flat EM: fp64-MFMA sufficient statistics */
+    HGMM_K_COUNT = 9
 };
 
 /* ---- lifecycle ------------------------------------------------------------------ */
@@ -155,6 +157,22 @@ int hgmm_tree_reg_estep(hgmm_ctx* ctx, const double* rot, const double* t, doubl
                         double lambda_c, double* m0_out, double* m1_out, double* m2_out);
 /* smallest eigenvalue / trace per node (complexity(), hgmm_cupy_cpu_working.py:87-91) */
 int hgmm_tree_node_complexity(hgmm_ctx* ctx, double* cplx_out);
+
+/* ---- flat GMM EM, FULL 3x3 covariance (float64) --------------------------------------
+ * The reference's Python has no flat full-covariance EM; its in-scope definition
+ * is ONE tree level with branching J: the CPU twin run with its module global n_node = J and
+ * maxTreeLevel = 1 (hgmm_cupy_cpu_working.py:30, 62-198): pi0 = 1/J, cov0 = sig2 I,
+ * gamma = pi N / sum, gammas < 1e-15 dropped, m0 < ld -> (pi = 0, mu = 0, cov = I), stop when
+ * |q - q_prev| < ls.  Statistics are the 10 floats per cluster (m0, m1[3], unique m2[6]) that
+ * the multi-GPU all-reduce exchanges; they are contracted on the fp64 matrix cores.
+ * hgmm_fullcov_estep returns one E-step's moments in the reference layout m0[J], m1[J,3],
+ * m2[J,3,3] + hard labels + the level log-likelihood q of the given parameters.            */
+int hgmm_fullcov_fit(hgmm_ctx* ctx, int J, double ls, double ld, const double* init_mu, double sig2,
+                     int max_iters, double* pi_out, double* mu_out, double* cov_out,
+                     int32_t* labels_out, double* q_trace_out, int q_capacity, int* q_len_out);
+int hgmm_fullcov_estep(hgmm_ctx* ctx, int J, const double* pi, const double* mu, const double* cov,
+                       double* m0_out, double* m1_out, double* m2_out, int32_t* labels_out,
+                       double* q_out);
 
 /* ---- multi-GPU: one context per rank, RCCL over xGMI --------------------------------
  * New functionality (the reference is single-GPU).  With a communicator attached,

@@ -1,0 +1,81 @@
+"""GPU parity tests of the flat FULL-covariance EM (fp64, MFMA sufficient statistics) against the
+reference's CPU twin run with n_node = J (golden) and the oracle restatement."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import hgmm_tree
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import hgmm_amd
+    c = hgmm_amd.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("J", [8, 32])
+def test_fullcov_matches_reference_golden(ctx, J):
+    g = load_golden("fullcov_flat.npz")
+    P = g["points"]
+    tag = "J%d_" % J
+    ctx.set_points(P)
+    pi, mu, cov, labels, q = ctx.fullcov_fit(J, 80.0, 1e-4, P[g[tag + "init_idx"]], 0.00034)
+    np.testing.assert_allclose(q, g[tag + "q_trace"], rtol=1e-9, atol=1e-6)
+    assert np.array_equal(labels, g[tag + "current_idx"])
+    np.testing.assert_allclose(pi, g[tag + "pi"], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(mu, g[tag + "mu"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(cov, g[tag + "cov"], rtol=1e-7, atol=1e-14)
+
+
+@pytest.mark.parametrize("N,J", [(5032, 100), (777, 17), (64, 16), (1, 3), (3000, 800)])
+def test_fullcov_vs_oracle(ctx, bunny, N, J):
+    P = bunny[:: max(1, len(bunny) // N)][:N].astype(np.float64)
+    rs = np.random.RandomState(J)
+    idx = rs.choice(len(P), J, replace=len(P) < J)
+    iters = 6 if J >= 800 else 40
+    ctx.set_points(P)
+    pi, mu, cov, labels, q = ctx.fullcov_fit(J, 1.0, 1e-4, P[idx], 0.0005, iters)
+    o_pi, o_mu, o_cov, o_q, o_cur = hgmm_tree.build_flat_fullcov(P, J, 1.0, 1e-4, idx, 0.0005, max_iters=iters)
+    assert len(q) == len(o_q)
+    np.testing.assert_allclose(q, o_q, rtol=1e-9, atol=1e-6)
+    assert np.array_equal(labels, o_cur)
+    np.testing.assert_allclose(pi, o_pi, rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(mu, o_mu, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(cov, o_cov, rtol=1e-6, atol=1e-14)
+
+
+def test_fullcov_estep_moments_layout(ctx, bunny):
+    """hgmm_fullcov_estep: the 10-float statistics expanded to the reference's m0/m1/m2 layout."""
+    P = bunny[::16].astype(np.float64)
+    J = 24
+    rs = np.random.RandomState(1)
+    idx = rs.choice(len(P), J, replace=False)
+    pi = np.full(J, 1.0 / J)
+    mu = P[idx].copy()
+    cov = np.tile(np.identity(3) * 0.0004, (J, 1, 1))
+    cov[:, 0, 1] = cov[:, 1, 0] = 0.0001            # asymmetric-looking features catch transposes
+    ctx.set_points(P)
+    m0, m1, m2, labels, q = ctx.fullcov_estep(pi, mu, cov)
+    ok, inv, coef = hgmm_tree.node_prep(cov)
+    g = pi[None, :] * hgmm_tree.pdf_pairs(P[:, None, :], mu[None], inv[None], coef[None])
+    den = g.sum(1)
+    gam = np.where((den > 1e-15)[:, None], g / np.where(den > 1e-15, den, 1.0)[:, None], 0.0)
+    use = np.where(gam < 1e-15, 0.0, gam)
+    np.testing.assert_allclose(m0, use.sum(0), rtol=1e-11)
+    np.testing.assert_allclose(m1, use.T @ P, rtol=1e-10, atol=1e-14)
+    np.testing.assert_allclose(m2, np.einsum('nj,na,nb->jab', use, P, P), rtol=1e-10, atol=1e-15)
+    assert np.array_equal(labels, np.argmax(gam, axis=1))
+    np.testing.assert_allclose(q, np.log(np.maximum(g.sum(1), 1e-15)).sum(), rtol=1e-11)
+
+
+def test_fullcov_dropin_function(ctx, bunny):
+    from hgmm_amd.hgmm.hgmm_gpu import fitFullCovGMM
+    P = bunny[::8].astype(np.float64)
+    pi, mu, cov, tr = fitFullCovGMM(P, 50, ls=5.0, sig2=0.001, ctx=ctx, return_trace=True, max_iters=30)
+    assert pi.shape == (50,) and mu.shape == (50, 3) and cov.shape == (50, 3, 3)
+    assert abs(pi.sum() - 1.0) < 1e-6 or (pi == 0).any()
+    assert tr["labels"].min() >= 0 and tr["labels"].max() < 50
