@@ -94,6 +94,20 @@ def main():
     ms, n = ctx.profile_get("flat_mstep")
     print("%-28s %.4f ms  %.0f GB/s" % ("mstep(log_resp.exp())", ms / n, (4 * N * J + 12 * N) / (ms / n * 1e-3) / 1e9))
     res["mstep"] = {"ms": ms / n}
+    # flat full-covariance EM (fp64, MFMA statistics) at the same size
+    P64 = X.astype(np.float64)
+    ctx.set_points(P64)
+    ctx.fullcov_fit(J, 1e-30, 1e-4, P64[idx], 0.01, 2)
+    ctx.profile_reset(); ctx.profile_enable(True)
+    import time
+    t0 = time.perf_counter()
+    ctx.fullcov_fit(J, 1e-30, 1e-4, P64[idx], 0.01, 5)
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    pm, pn = ctx.profile_get("full_pass")
+    mm, mn = ctx.profile_get("full_moments")
+    print("fullcov J=%d N=%d: %.2f ms/iteration (pass %.3f ms, moments %.3f ms)" % (J, N, dt / 5 * 1e3, pm / pn, mm / mn))
+    res["fullcov"] = {"ms_per_iter": dt / 5 * 1e3, "pass_ms": pm / pn, "moments_ms": mm / mn}
     print(json.dumps(res))
 
 
