@@ -1,0 +1,64 @@
+"""Transformations + Gauss transform of the L2 GMMReg path (reference:
+src/python/gmmreg_gpu/transforms.py).  Host NumPy, vectorised (the reference loops over target
+rows with ``np.apply_along_axis``); J_s x J_t <= 800 x 800, so this stays on the host."""
+import abc
+
+import numpy as np
+
+
+class Transformation(abc.ABC):
+    def transform(self, points, array_type=None):
+        if array_type is not None and isinstance(points, array_type):
+            return array_type(self._transform(np.asarray(points)))
+        return self._transform(points)
+
+    @abc.abstractmethod
+    def _transform(self, points):
+        return points
+
+
+class RigidTransformation(Transformation):
+    """scale * X R^T + t   (reference transforms.py:21-40)."""
+
+    def __init__(self, rot=np.identity(3), t=np.zeros(3), scale=1.0):
+        self.rot = rot
+        self.t = t
+        self.scale = scale
+
+    def _transform(self, points):
+        return self.scale * np.dot(points, self.rot.T) + self.t
+
+    def inverse(self):
+        return RigidTransformation(self.rot.T, -np.dot(self.rot.T, self.t), 1.0 / self.scale)
+
+
+def _gauss_transform_direct(source, target, weights, h):
+    """out[i] = sum_j weights[j] exp(-|target_i - source_j|^2 / h^2)   (reference transforms.py:43-49)."""
+    d2 = np.sum(np.square(target[:, None, :] - source[None, :, :]), axis=2)
+    return np.exp(-d2 / (h * h)) @ weights
+
+
+class Direct(object):
+    def __init__(self, source, h):
+        self._source = source
+        self._h = h
+
+    def compute(self, target, weights):
+        return _gauss_transform_direct(self._source, target, weights, self._h)
+
+
+class GaussTransform(object):
+    """reference transforms.py:60-86 (direct evaluation only, like the reference)."""
+
+    def __init__(self, source, h, eps=1.0e-4, sw_h=0.01):
+        self._m = source.shape[0]
+        self._impl = Direct(source, h)
+
+    def compute(self, target, weights=None):
+        if weights is None:
+            weights = np.ones(self._m)
+        if weights.ndim == 1:
+            return self._impl.compute(target, weights)
+        if weights.ndim == 2:
+            return np.r_[[self._impl.compute(target, w) for w in weights]]
+        raise ValueError("weights.ndim must be 1 or 2.")

@@ -7,7 +7,7 @@ modules for packages this image lacks and that the EM path does not actually use
 (cupy -> NumPy array module, open3d, transformations); nothing from the reference
 is written into this repository -- the fixtures hold only inputs and outputs.
 
-    python tools/gen_golden.py [--only flat|bunny|hgmm|hgmm3|reg|fullcov]
+    python tools/gen_golden.py [--only flat|bunny|hgmm|hgmm3|reg|fullcov|gmmreg]
 
 Outputs (all small .npz, float arrays):
     bun000_xyz.npy                vertex block of data/bun000.ply (reference data file)
@@ -17,6 +17,7 @@ Outputs (all small .npz, float arrays):
     hgmm_build_L3.npz             same on bun000[::40], L=3
     hgmm_reg_L2.npz               gmmTreeRegESTep moments + GMMTree.registration trace
     fullcov_flat.npz              CPU twin with n_node=J, one level (flat full-cov EM)
+    gmmreg_l2.npz                 L2 GMMReg: d_rot, Gauss transform, cost/gradient, one registration
 """
 import argparse
 import contextlib
@@ -313,6 +314,84 @@ def gen_fullcov(ns, cp, pts):
     np.savez_compressed(os.path.join(OUT, "fullcov_flat.npz"), **out)
 
 
+# ---------------------------------------------------------------------------
+# L2 GMMReg (gmmreg_gpu) goldens: cost function, gradient, Gauss transform, one registration
+# ---------------------------------------------------------------------------
+def _quaternion_matrix(q):
+    """Stand-in for the absent third-party `transformations.quaternion_matrix` (w, x, y, z order,
+    normalising; 4x4 homogeneous) -- standard formula, written for this tool."""
+    q = np.array(q, dtype=np.float64, copy=True)
+    n = np.dot(q, q)
+    if n < np.finfo(float).eps * 4.0:
+        return np.identity(4)
+    w, x, y, z = q * np.sqrt(2.0 / n)
+    m = np.identity(4)
+    m[0, 0] = 1.0 - y * y - z * z; m[0, 1] = x * y - z * w;       m[0, 2] = x * z + y * w
+    m[1, 0] = x * y + z * w;       m[1, 1] = 1.0 - x * x - z * z; m[1, 2] = y * z - x * w
+    m[2, 0] = x * z - y * w;       m[2, 1] = y * z + x * w;       m[2, 2] = 1.0 - x * x - y * y
+    return m
+
+
+def gen_gmmreg(pts):
+    import warnings
+    warnings.simplefilter("ignore")
+    sys.modules["transformations"].quaternion_matrix = _quaternion_matrix
+    sys.modules["thundersvm"] = types.ModuleType("thundersvm")
+    refdir = os.path.join(REF, "src/python/gmmreg_gpu")
+    sys.path.insert(0, refdir)
+    for m in ("gmm", "gmm_impl", "transforms", "so", "cost_functions", "gmmreg"):
+        sys.modules.pop(m, None)
+    try:
+        import so, transforms, cost_functions
+        rs = np.random.RandomState(11)
+        out = {}
+        qs = rs.randn(5, 4)
+        qs[0] = [1, 0, 0, 0]
+        out["q"] = qs
+        out["d_rot"] = np.array([so.diff_rot_from_quaternion(q) for q in qs])
+        out["rot"] = np.array([_quaternion_matrix(q)[:3, :3] for q in qs])
+        mu_s, mu_t = rs.rand(20, 3), rs.rand(25, 3)
+        phi_s, phi_t = rs.rand(20) + 0.1, rs.rand(25) + 0.1
+        sigma = 0.37
+        f, g = cost_functions.compute_l2_dist(mu_s, phi_s, mu_t, phi_t, sigma)
+        out.update(mu_s=mu_s, mu_t=mu_t, phi_s=phi_s, phi_t=phi_t, sigma=np.float64(sigma), l2_f=np.float64(f), l2_g=g)
+        gt = transforms.GaussTransform(mu_t, 0.5)
+        out["gt_1d"] = gt.compute(mu_s, phi_t)
+        out["gt_2d"] = gt.compute(mu_s, phi_t * mu_t.T)
+        cfn = cost_functions.RigidCostFunction()
+        thetas = np.c_[qs, rs.randn(5, 3) * 0.1]
+        out["theta"] = thetas
+        fs, gs = zip(*[cfn(th, mu_s, phi_s, mu_t, phi_t, sigma) for th in thetas])
+        out["cost_f"], out["cost_g"] = np.array(fs), np.array(gs)
+        # one full registration with the reference's own (NumPy-backed) GMM features
+        with quiet():
+            import gmmreg
+        src = np.ascontiguousarray(pts[::20])
+        th = np.deg2rad(10.0)
+        Rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+        tgt = src @ Rz.T + np.array([0.01, 0.0, -0.005])
+        with quiet():
+            reg = gmmreg.RigidGMMReg(src, n_gmm_components=30)
+        feats = []
+        orig_compute = reg._feature_gen.compute
+
+        def rec_compute(data):
+            r = orig_compute(data)
+            feats.append((np.array(r[0]), np.array(r[1])))
+            return r
+        reg._feature_gen.compute = rec_compute
+        with quiet():
+            tfm = reg.registration(tgt)
+        out.update(reg_source=src, reg_target=tgt, reg_sigma0=np.float64(
+            np.power(np.linalg.det(np.dot((src - src.mean(0)).T, src - src.mean(0)) / (len(src) - 1)), 1.0 / 6.0)),
+            reg_mu_target=feats[0][0], reg_phi_target=feats[0][1], reg_mu_source=feats[1][0], reg_phi_source=feats[1][1],
+            reg_rot=np.array(tfm.rot), reg_t=np.array(tfm.t))
+        np.savez_compressed(os.path.join(OUT, "gmmreg_l2.npz"), **out)
+        print("gmmreg: f", fs[:2], "reg rot[0]", tfm.rot[0], "t", tfm.t)
+    finally:
+        sys.path.remove(refdir)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -330,6 +409,8 @@ def main():
             gen_flat_small(W, G)
         if want("bunny"):
             gen_flat_bunny(W, G, pts)
+    if want("gmmreg"):
+        gen_gmmreg(pts)
     if want("hgmm") or want("reg") or want("hgmm3") or want("fullcov"):
         ns = load_cpu_twin(cp)
         if want("hgmm") or want("reg"):
