@@ -190,6 +190,8 @@ class Context:
 
     # -- plumbing ---------------------------------------------------------------------
     def _check(self, rc):
+        if rc != 0 and not getattr(self, "h", None):
+            raise HgmmError("this Context has been closed")
         if rc != 0:
             msg = self.lib.hgmm_last_error(self.h)
             raise HgmmError("hgmm call failed (%d): %s" % (rc, msg.decode() if msg else "?"))
@@ -472,7 +474,7 @@ _default_ctx = None
 def default_context() -> Context:
     """Process-wide context on the rank's GPU (LOCAL_RANK, else device 0)."""
     global _default_ctx
-    if _default_ctx is None:
+    if _default_ctx is None or not getattr(_default_ctx, "h", None):
         _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
     return _default_ctx
 
