@@ -270,7 +270,7 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_kernel(
 // fused E+M: sufficient statistics without the N x J round trip
 //   s0_j = sum_i r_ij,  a_jd = sum_i r_ij (x_id - mu_jd),  b_jd = sum_i r_ij (x_id - mu_jd)^2
 // ------------------------------------------------------------------------------------------
-template <int NSLOT>
+template <int NSLOT, int ROWS>
 __global__ __launch_bounds__(BLOCK) void flat_fused_kernel(
     const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int J, int Jpad,
     float* __restrict__ partials, double* __restrict__ lpn_partials,
@@ -287,39 +287,67 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_kernel(
     int64_t r0, r1;
     wave_row_range(n, r0, r1);
     double lsum = 0.0;
-    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-    if (r0 < r1) { const float* xp = X + 3 * r0; x0 = xp[0]; x1 = xp[1]; x2 = xp[2]; }
-    for (int64_t row = r0; row < r1; ++row) {
-        const int64_t nrow = (row + 1 < r1) ? row + 1 : row;
-        const float* xn = X + 3 * nrow;
-        const float nx0 = xn[0], nx1 = xn[1], nx2 = xn[2];
-
-        float wl[K];
-        float m = row_wl2<0, NSLOT>(P, x0, x1, x2, wl);
-        m = wave_reduce(m, OpMax());
-        if (m == NEG_INF) m = 0.f;
-        float s = 0.f;
+    // ROWS point rows are in flight per wave: independent max / sum reduction chains interleave
+    float x[ROWS][3];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int64_t rr = (r0 + r < r1) ? r0 + r : (r1 > r0 ? r1 - 1 : 0);
+        const float* xp = X + 3 * rr;
+        x[r][0] = (r0 < r1) ? xp[0] : 0.f; x[r][1] = (r0 < r1) ? xp[1] : 0.f; x[r][2] = (r0 < r1) ? xp[2] : 0.f;
+    }
+    for (int64_t row = r0; row < r1; row += ROWS) {
+        float nx[ROWS][3];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {           // prefetch the next group of rows (scalar loads)
+            int64_t rr = row + ROWS + r;
+            rr = rr < r1 ? rr : r1 - 1;
+            const float* xn = X + 3 * rr;
+            nx[r][0] = xn[0]; nx[r][1] = xn[1]; nx[r][2] = xn[2];
+        }
+        float wl[ROWS][K];
+        float m[ROWS], s[ROWS], inv_den[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) m[r] = row_wl2<0, NSLOT>(P, x[r][0], x[r][1], x[r][2], wl[r]);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            m[r] = wave_reduce(m[r], OpMax());
+            if (m[r] == NEG_INF) m[r] = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                wl[r][k] = __builtin_amdgcn_exp2f(wl[r][k] - m[r]);
+                acc += wl[r][k];
+            }
+            s[r] = acc;
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) s[r] = wave_reduce(s[r], OpSum());
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const float lpn2 = lpn2_from(m[r], s[r], inv_den[r]);
+            const bool valid = row + r < r1;                  // wave-uniform
+            if (valid) lsum += (double)(lpn2 * LN2);
+            else inv_den[r] = 0.f;                            // padded row: contributes nothing
+        }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            wl[k] = __builtin_amdgcn_exp2f(wl[k] - m);
-            s += wl[k];
-        }
-        s = wave_reduce(s, OpSum());
-        float inv_den;
-        const float lpn2 = lpn2_from(m, s, inv_den);
-        lsum += (double)(lpn2 * LN2);
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float r = wl[k] * inv_den;
-            const float d0 = x0 - P.mu0[k], d1 = x1 - P.mu1[k], d2 = x2 - P.mu2[k];
-            const float rd0 = r * d0, rd1 = r * d1, rd2 = r * d2;
-            a_s0[k] += r;
-            a_a0[k] += rd0; a_a1[k] += rd1; a_a2[k] += rd2;
-            a_b0[k] = fmaf(rd0, d0, a_b0[k]);
-            a_b1[k] = fmaf(rd1, d1, a_b1[k]);
-            a_b2[k] = fmaf(rd2, d2, a_b2[k]);
+            for (int r = 0; r < ROWS; ++r) {
+                const float rr = wl[r][k] * inv_den[r];
+                const float d0 = x[r][0] - P.mu0[k], d1 = x[r][1] - P.mu1[k], d2 = x[r][2] - P.mu2[k];
+                const float rd0 = rr * d0, rd1 = rr * d1, rd2 = rr * d2;
+                a_s0[k] += rr;
+                a_a0[k] += rd0; a_a1[k] += rd1; a_a2[k] += rd2;
+                a_b0[k] = fmaf(rd0, d0, a_b0[k]);
+                a_b1[k] = fmaf(rd1, d1, a_b1[k]);
+                a_b2[k] = fmaf(rd2, d2, a_b2[k]);
+            }
         }
-        x0 = nx0; x1 = nx1; x2 = nx2;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { x[r][0] = nx[r][0]; x[r][1] = nx[r][1]; x[r][2] = nx[r][2]; }
     }
 
     // combine the workgroup's waves through LDS in a fixed order (deterministic), one HBM write
@@ -726,10 +754,14 @@ static int launch_fused(hgmm_ctx* c, const int* done_flag, int* grid_out, int* v
     float* part = c->f_partials.as<float>();
     double* lp = c->f_lpn_partials.as<double>();
     const int ns = (f.J + 63) / 64;
+    // ROWS = rows in flight per wave.  Measured on MI355X at N = 1e6, J = 800 (tools/kbench.py):
+    // ROWS = 1 (249 VGPRs, 2 waves/SIMD) 0.544 ms; ROWS = 2 (310 regs, 1 wave/SIMD) 0.677 ms;
+    // ROWS = 4 (424 regs) 0.772 ms -- thread-level parallelism beats in-wave ILP here, so only
+    // ROWS = 1 is instantiated.
 #define FUSED_CASE(S)                                                                           \
     do {                                                                                        \
-        flat_fused_kernel<S><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, part, lp,   \
-                                                           done_flag);                         \
+        flat_fused_kernel<S, 1><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, part,   \
+                                                              lp, done_flag);                  \
         *valid_j = S * 64;                                                                      \
     } while (0)
     ProfScope prof(c, HGMM_K_FLAT_FUSED);
