@@ -146,6 +146,20 @@ class DeviceArray:
             np.exp(out, out=out)
         return out
 
+    def get_rows(self, lo, hi):
+        """Download rows [lo, hi) of a 2-D (or entries of a 1-D) array without moving the rest."""
+        lo, hi = int(lo), int(hi)
+        if not (0 <= lo <= hi <= self.shape[0]):
+            raise IndexError("row range out of bounds")
+        row_elems = int(np.prod(self.shape[1:])) if len(self.shape) > 1 else 1
+        out = np.empty((hi - lo,) + self.shape[1:], dtype=self.dtype)
+        if out.size:
+            off = lo * row_elems * self.dtype.itemsize
+            self.ctx._d2h(out, C.c_void_p(self.ptr.value + off))
+        if self._base is not None and self.is_log and not self._base.is_log:
+            np.exp(out, out=out)
+        return out
+
     def __array__(self, dtype=None, copy=None):
         a = self.get()
         return a if dtype is None else a.astype(dtype, copy=False)
