@@ -247,6 +247,37 @@ class GMMTree():
         return MstepResult(self._tf_result.inverse(), res.q)
 
 
+def euler_matrix_xyz(ai, aj, ak):
+    """Static-frame x-y-z Euler angles -> 3x3 rotation (what the absent third-party
+    ``transformations.euler_matrix(ai, aj, ak)`` default 'sxyz' returns; hgmm_gpu.py:790)."""
+    ci, si, cj, sj, ck, sk = np.cos(ai), np.sin(ai), np.cos(aj), np.sin(aj), np.cos(ak), np.sin(ak)
+    rx = np.array([[1, 0, 0], [0, ci, -si], [0, si, ci]])
+    ry = np.array([[cj, 0, sj], [0, 1, 0], [-sj, 0, cj]])
+    rz = np.array([[ck, -sk, 0], [sk, ck, 0], [0, 0, 1.0]])
+    return rz @ ry @ rx
+
+
+def prepare_source_and_target_rigid_3d(source, noise_amp=0.001, n_random=500,
+                                       orientation=np.deg2rad([0.0, 0.0, 30.0]), translation=np.zeros(3),
+                                       voxel_size=0.005, rng=None):
+    """Noisy, cluttered, rigidly moved copy of a cloud for registration experiments
+    (hgmm_gpu.py:772-795 minus Open3D/normals): voxel down-sample, shuffle, add Gaussian noise and
+    ``n_random`` uniform outliers in a 1.5x bounding box, then rotate/translate.
+    ``source``: [N,3] array or a .ply/.pcd path.  -> (source_points, target_points)."""
+    from ..pointcloud_io import read_point_cloud, voxel_down_sample
+    rng = rng or np.random
+    src = read_point_cloud(source) if isinstance(source, str) else np.asarray(source, dtype=np.float64)
+    if voxel_size:
+        src = voxel_down_sample(src, voxel_size)
+    tp = src.copy()
+    rng.shuffle(tp)
+    rg = 1.5 * (tp.max(axis=0) - tp.min(axis=0))
+    rands = (rng.rand(n_random, 3) - 0.5) * rg + tp.mean(axis=0)
+    tgt = np.r_[tp + noise_amp * rng.randn(*tp.shape), rands]
+    rot = euler_matrix_xyz(*orientation)
+    return src, tgt @ rot.T + np.asarray(translation)
+
+
 def registration_gmmtree(source, target, maxiter=20, tol=1.0e-4, callbacks=[], **kargs):
     """hgmm_gpu.py:802-807."""
     gt = GMMTree(_points(source), **kargs)

@@ -394,3 +394,35 @@ def test_streaming_refit_harness(ctx):
     res = run_stream(frames, n_components=12, max_iter=15, cov_type='spherical', fit_every=3)
     assert res["frames"] == 7 and len(res["fit_s"]) == 3 and res["fps"] > 0
     assert all(l.shape == (3000,) and l.min() >= 0 and l.max() < 12 for l in res["labels"])
+
+
+def test_error_paths(ctx):
+    """Argument / state errors surface as HgmmError with a message (no silent fallbacks)."""
+    import hgmm_amd
+    c = hgmm_amd.Context(0)
+    try:
+        mu, w, cov = np.zeros((4, 3), np.float32), np.ones(4, np.float32) / 4, np.ones((4, 3), np.float32)
+        with pytest.raises(hgmm_amd.HgmmError, match="set_points"):
+            c.flat_train(2, 0.0, mu, cov, w)
+        with pytest.raises(hgmm_amd.HgmmError, match="positive"):
+            c.set_points(np.zeros((0, 3), np.float32))
+        with pytest.raises(ValueError):
+            c.set_points(np.zeros((5, 2), np.float32))
+        c.set_points(np.random.RandomState(0).rand(100, 3).astype(np.float32))
+        big = 1025
+        with pytest.raises(hgmm_amd.HgmmError, match="outside the supported range"):
+            c.flat_train(1, 0.0, np.zeros((big, 3), np.float32), np.ones((big, 3), np.float32), np.ones(big, np.float32))
+        with pytest.raises(hgmm_amd.HgmmError, match="diag-only"):
+            c.flat_estep(np.ones(4, np.float32), mu, w, "spherical", "G")
+        with pytest.raises(ValueError):
+            c.flat_estep(np.ones((4, 2), np.float32), mu, w, "diag", "W")
+        with pytest.raises(hgmm_amd.HgmmError, match="no tree"):
+            c.tree_reg_estep(8)
+        with pytest.raises(hgmm_amd.HgmmError, match="1..6"):
+            c.set_points(np.random.rand(50, 3)).tree_build(7, 1.0, 1e-4, np.zeros((8 * (8 ** 7 - 1) // 7, 3)), 0.01)
+        with pytest.raises(ValueError):
+            c.tree_build(2, 1.0, 1e-4, np.zeros((5, 3)), 0.01)
+    finally:
+        c.close()
+    with pytest.raises(hgmm_amd.HgmmError, match="closed"):
+        c.flat_train(2, 0.0, mu, cov, w)

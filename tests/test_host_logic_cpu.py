@@ -41,3 +41,19 @@ def test_rigid_transformation_roundtrip():
     tf = RigidTransformation(R, t, 1.0)
     X = rs.rand(10, 3)
     np.testing.assert_allclose(tf.inverse().transform(tf.transform(X)), X, atol=1e-14)
+
+
+def test_noisy_target_generator(bunny):
+    from hgmm_amd.hgmm.hgmm_gpu import prepare_source_and_target_rigid_3d, euler_matrix_xyz
+    R = euler_matrix_xyz(0.1, -0.2, 0.3)
+    np.testing.assert_allclose(R @ R.T, np.identity(3), atol=1e-14)
+    assert abs(np.linalg.det(R) - 1) < 1e-14
+    np.testing.assert_allclose(euler_matrix_xyz(0, 0, np.pi / 2) @ [1, 0, 0], [0, 1, 0], atol=1e-15)
+    rs = np.random.RandomState(0)
+    src, tgt = prepare_source_and_target_rigid_3d(bunny.astype(np.float64), n_random=100, rng=rs)
+    assert tgt.shape == (len(src) + 100, 3)
+    th = np.deg2rad(30.0)
+    Rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    back = tgt[:len(src)] @ Rz                      # undo the rotation: inliers sit on the source
+    d = np.abs(back[:, None, :] - src[None, :500, :]).sum(2).min(0)
+    assert np.median(d) < 0.01
