@@ -76,10 +76,12 @@ struct hgmm_ctx {
     hgmm::DevBuf t_mom;                       // double [T][10]
     hgmm::DevBuf t_parent, t_current;         // int32 [n]
     hgmm::DevBuf t_perm;                      // int32 [n]  points sorted by parent
+    hgmm::DevBuf t_xs3;                       // double [3][n_pad] third coordinate buffer (L > 2)
     hgmm::DevBuf t_seg;                       // int32 segment tables
     hgmm::DevBuf t_chunks;                    // int32 chunk descriptors
     hgmm::DevBuf t_partials;                  // double per-chunk partial moments
     hgmm::DevBuf t_q;                         // double per-block q partials + result
+    hgmm::DevBuf t_llp;                       // double [node chunks][n_pad] log-likelihood partial sums
     hgmm::DevBuf tgt_soa64;                   // double [3][m_pad] registration target
     int64_t tgt_n = 0, tgt_pad = 0;
 

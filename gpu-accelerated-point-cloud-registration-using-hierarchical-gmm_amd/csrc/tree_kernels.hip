@@ -190,7 +190,6 @@ __global__ __launch_bounds__(CH) void tree_estep_kernel(
     }
     // gamma = g / den if den > eps else 0; arg-max = first maximum  (C:174-187)
     const bool good = den > TREE_EPS;
-    const double inv = good ? 1.0 / den : 0.0;
     int am = 0;
     double best = -1.0;
 #pragma unroll
@@ -199,7 +198,6 @@ __global__ __launch_bounds__(CH) void tree_estep_kernel(
         if (g[k] > best) { best = g[k]; am = k; }
         if (g[k] < TREE_EPS || !active) g[k] = 0.0;      // accumulate() ignores gamma < eps (C:100)
     }
-    (void)inv;
     if (active) cur_sorted[i] = (int)(j0 + am);
 
     __shared__ double sh[CH / 64][8 * NMOM];
@@ -273,9 +271,13 @@ __global__ void tree_mstep_kernel(const double* __restrict__ mom, int64_t lb, in
 // level log-likelihood over ALL nodes of the level (logLikelihoodValue, C:72-85)
 // ------------------------------------------------------------------------------------------
 constexpr int LL_TILE = 256;
+// grid = (point blocks, node chunks).  With one chunk the per-point log is taken here; with several
+// (small clouds: not enough point blocks to fill 256 CUs) the per-chunk sums go to `partial`
+// [chunk][point] and tree_loglik_finish_kernel adds them in fixed order.
 __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restrict__ xs, int64_t n,
                                                          int64_t n_pad, const double* __restrict__ prep,
-                                                         int64_t lb, int n_level_nodes,
+                                                         int64_t lb, int n_level_nodes, int nodes_per_chunk,
+                                                         double* __restrict__ partial,
                                                          double* __restrict__ block_q) {
     __shared__ double tile[LL_TILE][10];
     __shared__ double shq[CH / 64];
@@ -284,8 +286,10 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
     double x0 = 0.0, x1 = 0.0, x2 = 0.0;
     if (active) { x0 = xs[i]; x1 = xs[n_pad + i]; x2 = xs[2 * n_pad + i]; }
     double tot = 0.0;
-    for (int base = 0; base < n_level_nodes; base += LL_TILE) {
-        const int cnt = (n_level_nodes - base < LL_TILE) ? n_level_nodes - base : LL_TILE;
+    const int node_begin = blockIdx.y * nodes_per_chunk;
+    const int node_end = (node_begin + nodes_per_chunk < n_level_nodes) ? node_begin + nodes_per_chunk : n_level_nodes;
+    for (int base = node_begin; base < node_end; base += LL_TILE) {
+        const int cnt = (node_end - base < LL_TILE) ? node_end - base : LL_TILE;
         __syncthreads();
         for (int t = threadIdx.x; t < cnt * 10; t += CH) {
             const int node = t / 10, fidx = t % 10;
@@ -304,7 +308,32 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
             if (__any(q < 1500.0)) tot += wL * exp(-0.5 * q);
         }
     }
+    if (gridDim.y > 1) {
+        if (active) partial[(size_t)blockIdx.y * n_pad + i] = tot;
+        return;
+    }
     double lq = active ? log(fmax(tot, TREE_EPS)) : 0.0;
+    lq = wave_sum_f64(lq);
+    if (lane_id() == 0) shq[wave_in_block()] = lq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < CH / 64; ++w) t += shq[w];
+        block_q[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(CH) void tree_loglik_finish_kernel(const double* __restrict__ partial, int64_t n,
+                                                                int64_t n_pad, int n_chunks,
+                                                                double* __restrict__ block_q) {
+    __shared__ double shq[CH / 64];
+    const int64_t i = (int64_t)blockIdx.x * CH + threadIdx.x;
+    double lq = 0.0;
+    if (i < n) {
+        double tot = 0.0;
+        for (int c = 0; c < n_chunks; ++c) tot += partial[(size_t)c * n_pad + i];
+        lq = log(fmax(tot, TREE_EPS));
+    }
     lq = wave_sum_f64(lq);
     if (lane_id() == 0) shq[wave_in_block()] = lq;
     __syncthreads();
@@ -602,11 +631,6 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     double* block_q = c->t_q.as<double>();
     double* q_dev = block_q + nblk(n, CH);
 
-    // the level-0 "sorted" coordinates must not alias the resident cloud once we start
-    // scattering, so keep x_soa64 read-only: first scatter goes A -> B, later ones B <-> scratch2
-    hgmm::DevBuf& xs_c_buf = c->tgt_soa64;   // reuse lazily? no: dedicated third buffer below
-    (void)xs_c_buf;
-
     HGMM_HIP(c, hipMemcpyAsync(c->scratch.p, init_mu, sizeof(double) * 3 * T, hipMemcpyHostToDevice, c->stream));
     tree_init_nodes_kernel<<<nblk(T, 256), 256, 0, c->stream>>>(c->scratch.as<double>(), sig2, T, d_pi, d_mu, d_cov);
     HGMM_TRY(tree_prep(c, 0, T));
@@ -621,14 +645,14 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
         HGMM_TRY(hgmm_comm_allreduce_f64(c, &n_total, 1, 0));
     }
 
-    // third coordinate buffer so that x_soa64 is never overwritten
-    hgmm::DevBuf xs_c_owner;
+    // the resident cloud (x_soa64 = level-0 order) is never overwritten: the first scatter goes
+    // A -> B, later ones alternate between B and a third buffer C
     double* xs_c = nullptr;
     if (L > 2) {
-        HGMM_HIP(c, hipMalloc(&xs_c_owner.p, sizeof(double) * 3 * n_pad));
-        xs_c = xs_c_owner.as<double>();
+        HGMM_TRY(ensure(c, c->t_xs3, sizeof(double) * 3 * n_pad));
+        xs_c = c->t_xs3.as<double>();
     }
-    auto cleanup = [&]() { if (xs_c_owner.p) (void)hipFree(xs_c_owner.p); };
+    auto cleanup = [&]() {};
 
     const double* xs_cur = xs_a;
     int* perm_cur = perm_a;
@@ -659,8 +683,28 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                                                                          d_pi, d_mu, d_cov);
             tree_prep_kernel<<<nblk(n_level, 256), 256, 0, c->stream>>>(d_pi, d_mu, d_cov, lb, le, d_prep);
             {
+                // small clouds do not have enough 256-point blocks to fill the chip: split the level's
+                // nodes over gridDim.y and add the per-chunk sums in a second (fixed-order) kernel
+                const int pblocks = (int)nblk(n, CH);
+                int chunks = 1;
+                if (pblocks < 4 * c->cus && n_level > LL_TILE) {
+                    chunks = (4 * c->cus + pblocks - 1) / pblocks;
+                    const int max_chunks_l = (n_level + LL_TILE - 1) / LL_TILE;
+                    if (chunks > max_chunks_l) chunks = max_chunks_l;
+                }
+                const int per_chunk = ((n_level + chunks - 1) / chunks + LL_TILE - 1) / LL_TILE * LL_TILE;
+                chunks = (n_level + per_chunk - 1) / per_chunk;
+                double* ll_partial = nullptr;
+                if (chunks > 1) {
+                    rc = ensure(c, c->t_llp, sizeof(double) * (size_t)chunks * n_pad);
+                    if (rc != HGMM_OK) break;
+                    ll_partial = c->t_llp.as<double>();
+                }
                 ProfScope prof(c, HGMM_K_TREE_LOGLIK);
-                tree_loglik_kernel<<<nblk(n, CH), CH, 0, c->stream>>>(xs_cur, n, n_pad, d_prep, lb, n_level, block_q);
+                tree_loglik_kernel<<<dim3(pblocks, chunks), CH, 0, c->stream>>>(xs_cur, n, n_pad, d_prep, lb, n_level,
+                                                                               per_chunk, ll_partial, block_q);
+                if (chunks > 1)
+                    tree_loglik_finish_kernel<<<pblocks, CH, 0, c->stream>>>(ll_partial, n, n_pad, chunks, block_q);
             }
             tree_sum_kernel<<<1, 256, 0, c->stream>>>(block_q, (int)nblk(n, CH), q_dev);
             if (c->comm) {
@@ -686,7 +730,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
             tree_hist_kernel<<<grid_chunks, CH, 0, c->stream>>>(cur, chunk_desc, n_chunks_dev, hist);
             int* seg_next = (seg_cur == seg_a) ? seg_b : seg_a;
             tree_offsets_kernel<<<nblk(P, 128), 128, 0, c->stream>>>(hist, chunk_first, seg_cur, P, chunk_off, seg_next);
-            double* xs_next = (xs_cur == xs_a) ? xs_b : ((xs_cur == xs_b) ? (xs_c ? xs_c : xs_b) : xs_b);
+            double* xs_next = (xs_cur == xs_b) ? xs_c : xs_b;     // A -> B -> C -> B -> ...
             int* perm_next = (perm_cur == perm_a) ? perm_b : perm_a;
             tree_scatter_kernel<<<grid_chunks, CH, 0, c->stream>>>(xs_cur, n_pad, perm_cur, cur, chunk_desc, n_chunks_dev,
                                                                   chunk_off, xs_next, perm_next);
