@@ -60,19 +60,7 @@ def main():
             time_estep("estep nt=%s blocks/CU=%s" % (nt, bpc))
     os.environ.pop("HGMM_ESTEP_NT"); os.environ.pop("HGMM_ESTEP_BPC")
 
-    for cull, sort in (("0", "0"), ("1", "0"), ("1", "1"), ("0", "0"), ("1", "1")):
-        os.environ["HGMM_FUSED_CULL"] = cull
-        os.environ["HGMM_FLAT_SORT"] = sort
-        ctx.flat_train_begin(0.0, mu0, cov0, w0, "diag", "W", lls_capacity=100)
-        ctx.flat_train_step(10)
-        ctx.profile_reset(); ctx.profile_enable(True)
-        ctx.flat_train_step(30)
-        ctx.profile_enable(False)
-        ms, n = ctx.profile_get("flat_fused")
-        o = ctx.flat_train_end()
-        print("%-28s %.4f ms (iterations 11-40)  lls[-1]=%.7f" % ("fused cull=%s sort=%s" % (cull, sort), ms / n, o[4][-1]))
-    os.environ.pop("HGMM_FUSED_CULL"); os.environ.pop("HGMM_FLAT_SORT")
-    for bpc in ("2",):
+    for bpc in ("1", "2", "3"):
         os.environ["HGMM_FUSED_BPC"] = bpc
         ctx.profile_reset(); ctx.profile_enable(True)
         ctx.flat_train(args.reps, 0.0, mu0, cov0, w0, "diag", "W")
