@@ -24,7 +24,6 @@
 #include "hgmm_ctx.h"
 #include "wave_ops.h"
 
-#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
@@ -275,7 +274,7 @@ template <int NSLOT, int ROWS>
 __global__ __launch_bounds__(BLOCK) void flat_fused_kernel(
     const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int J, int Jpad,
     float* __restrict__ partials, double* __restrict__ lpn_partials,
-    const int* __restrict__ done_flag, float cull) {
+    const int* __restrict__ done_flag) {
     if (done_flag && *done_flag) return;
     constexpr int K = NSLOT;
     const int lane = lane_id();
@@ -338,10 +337,6 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_kernel(
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) {
                 const float rr = wl[r][k] * inv_den[r];
-                // slot k = 64 consecutive (spatially sorted) components: when none of them holds
-                // a responsibility above `cull` for this point the whole wave skips the moment
-                // update (contributions below 1e-10 are far under float32 resolution of the sums)
-                if (__builtin_amdgcn_ballot_w64(rr > cull) == 0ull) continue;
                 const float d0 = x[r][0] - P.mu0[k], d1 = x[r][1] - P.mu1[k], d2 = x[r][2] - P.mu2[k];
                 const float rd0 = rr * d0, rd1 = rr * d1, rd2 = rr * d2;
                 a_s0[k] += rr;
@@ -759,7 +754,6 @@ static int launch_fused(hgmm_ctx* c, const int* done_flag, int* grid_out, int* v
     float* part = c->f_partials.as<float>();
     double* lp = c->f_lpn_partials.as<double>();
     const int ns = (f.J + 63) / 64;
-    const float cull = env_flag("HGMM_FUSED_CULL", true) ? 1e-10f : -1.0f;
     // ROWS = rows in flight per wave.  Measured on MI355X at N = 1e6, J = 800 (tools/kbench.py):
     // ROWS = 1 (249 VGPRs, 2 waves/SIMD) 0.544 ms; ROWS = 2 (310 regs, 1 wave/SIMD) 0.677 ms;
     // ROWS = 4 (424 regs) 0.772 ms -- thread-level parallelism beats in-wave ILP here, so only
@@ -767,7 +761,7 @@ static int launch_fused(hgmm_ctx* c, const int* done_flag, int* grid_out, int* v
 #define FUSED_CASE(S)                                                                           \
     do {                                                                                        \
         flat_fused_kernel<S, 1><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, part,   \
-                                                              lp, done_flag, cull);            \
+                                                              lp, done_flag);                  \
         *valid_j = S * 64;                                                                      \
     } while (0)
     ProfScope prof(c, HGMM_K_FLAT_FUSED);
@@ -942,47 +936,7 @@ extern "C" int hgmm_flat_train_begin(hgmm_ctx* c, int cov_type, int variant, int
     HGMM_TRY(ensure(c, c->f_lls, sizeof(float) * lls_capacity));
     FlatState& f = c->flat;
     f.tol = tol; f.lls_cap = lls_capacity; f.launched = 0; f.active = true;
-    // internal component order: Morton (Z-curve) order of the initial means, so that the 64
-    // components a slot of the fused kernel owns are spatial neighbours (enables the wave-uniform
-    // skip there).  EM has no notion of component order; results are returned in the caller's order.
-    {
-        c->flat_perm.resize(J);
-        for (int j = 0; j < J; ++j) c->flat_perm[j] = j;
-        if (env_flag("HGMM_FLAT_SORT", true) && J > 64) {
-            float lo[3] = {mu[0], mu[1], mu[2]}, hi[3] = {mu[0], mu[1], mu[2]};
-            for (int j = 0; j < J; ++j)
-                for (int d = 0; d < 3; ++d) {
-                    lo[d] = std::min(lo[d], mu[3 * j + d]);
-                    hi[d] = std::max(hi[d], mu[3 * j + d]);
-                }
-            std::vector<uint32_t> key(J);
-            for (int j = 0; j < J; ++j) {
-                uint32_t code = 0;
-                uint32_t q[3];
-                for (int d = 0; d < 3; ++d) {
-                    const float span = hi[d] - lo[d];
-                    float t = span > 0.f ? (mu[3 * j + d] - lo[d]) / span : 0.f;
-                    t = t < 0.f ? 0.f : (t > 1.f ? 1.f : t);
-                    q[d] = (uint32_t)(t * 1023.0f);
-                }
-                for (int b = 9; b >= 0; --b)
-                    for (int d = 0; d < 3; ++d) code = (code << 1) | ((q[d] >> b) & 1u);
-                key[j] = code;
-            }
-            std::stable_sort(c->flat_perm.begin(), c->flat_perm.end(),
-                             [&](int a, int b) { return key[a] < key[b]; });
-        }
-        const size_t ce = cov_type == HGMM_COV_DIAG ? 3 : 1;
-        std::vector<float> pmu((size_t)3 * J), pcov(ce * J), pw(J);
-        for (int j = 0; j < J; ++j) {
-            const int src = c->flat_perm[j];
-            for (int d = 0; d < 3; ++d) pmu[3 * j + d] = mu[3 * src + d];
-            for (size_t d = 0; d < ce; ++d) pcov[ce * j + d] = cov[ce * src + d];
-            pw[j] = w[src];
-        }
-        HGMM_TRY(flat_upload(c, pmu.data(), pcov.data(), true, pw.data()));
-        HGMM_HIP(c, hipStreamSynchronize(c->stream));      // staging vectors die at scope exit
-    }
+    HGMM_TRY(flat_upload(c, mu, cov, true, w));
     const int ne = (int)cov_elems(cov_type, J);
     flat_inv_from_cov_kernel<<<(ne + 255) / 256, 256, 0, c->stream>>>(c->f_cov.as<float>(),
                                                                      c->f_inv.as<float>(), ne);
@@ -1008,22 +962,11 @@ extern "C" int hgmm_flat_train_end(hgmm_ctx* c, float* mu, float* cov, float* w,
     int ctl[4] = {0, 0, 0, 0};
     HGMM_HIP(c, hipMemcpyAsync(ctl, c->f_ctl.p, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
     const int J = f.J;
-    const size_t ce = f.cov_type == HGMM_COV_DIAG ? 3 : 1;
-    std::vector<float> pmu((size_t)3 * J), pcov(ce * J), pw(J), pinv(ce * J);
-    HGMM_HIP(c, hipMemcpyAsync(pmu.data(), c->f_mu.p, sizeof(float) * 3 * J, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipMemcpyAsync(pcov.data(), c->f_cov.p, sizeof(float) * ce * J, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipMemcpyAsync(pw.data(), c->f_w.p, sizeof(float) * J, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipMemcpyAsync(pinv.data(), c->f_inv.p, sizeof(float) * ce * J, hipMemcpyDeviceToHost, c->stream));
+    if (mu) HGMM_HIP(c, hipMemcpyAsync(mu, c->f_mu.p, sizeof(float) * 3 * J, hipMemcpyDeviceToHost, c->stream));
+    if (cov) HGMM_HIP(c, hipMemcpyAsync(cov, c->f_cov.p, sizeof(float) * cov_elems(f.cov_type, J), hipMemcpyDeviceToHost, c->stream));
+    if (w) HGMM_HIP(c, hipMemcpyAsync(w, c->f_w.p, sizeof(float) * J, hipMemcpyDeviceToHost, c->stream));
+    if (inv_std_out) HGMM_HIP(c, hipMemcpyAsync(inv_std_out, c->f_inv.p, sizeof(float) * cov_elems(f.cov_type, J), hipMemcpyDeviceToHost, c->stream));
     HGMM_HIP(c, hipStreamSynchronize(c->stream));
-    for (int j = 0; j < J; ++j) {                       // back to the caller's component order
-        const int dst = ((int)c->flat_perm.size() == J) ? c->flat_perm[j] : j;
-        for (int d = 0; d < 3; ++d) if (mu) mu[3 * dst + d] = pmu[3 * j + d];
-        for (size_t d = 0; d < ce; ++d) {
-            if (cov) cov[ce * dst + d] = pcov[ce * j + d];
-            if (inv_std_out) inv_std_out[ce * dst + d] = pinv[ce * j + d];
-        }
-        if (w) w[dst] = pw[j];
-    }
     const int n_it = ctl[1];
     if (lls_out && n_it > 0) {
         const int cnt = n_it < f.lls_cap ? n_it : f.lls_cap;

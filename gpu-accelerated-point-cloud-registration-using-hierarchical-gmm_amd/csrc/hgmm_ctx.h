@@ -67,7 +67,6 @@ struct hgmm_ctx {
     hgmm::DevBuf f_ctl;                       // int  [4]: done, n_iter, converged, pad ; float prev
     hgmm::DevBuf f_hint;                      // float [3][Jpad] centre hint for m-step
     hgmm::DevBuf scratch;
-    std::vector<int> flat_perm;               // internal (Morton) component order of the train loop
 
     // ---- tree -------------------------------------------------------------------
     hgmm::TreeState tree;
