@@ -233,11 +233,12 @@ def main():
                                          "mstep_avg_ms": m_ms / max(m_n, 1),
                                          "mstep_GBs": (4 * N_POINTS * J_COMP + 12 * N_POINTS) / (m_ms / max(m_n, 1) * 1e-3) / 1e9}
         # what a pure 16-byte store stream of the same size reaches on this chip (write ceiling)
-        ctx.util_fill(lr, 0.0, True)
+        # (best pure-store pattern found, tools/fillbench.py: one workgroup per CU, grid-stride)
+        ctx.util_fill(lr, 0.0, False, 0, 1)
         ctx.profile_reset()
         ctx.profile_enable(True)
         for _ in range(10):
-            ctx.util_fill(lr, 0.0, True)
+            ctx.util_fill(lr, 0.0, False, 0, 1)
         ctx.profile_enable(False)
         f_ms, f_n = ctx.profile_get("util_fill")
         out["roofline"]["store_stream_ceiling_GBs"] = 4 * N_POINTS * J_COMP / (f_ms / f_n * 1e-3) / 1e9

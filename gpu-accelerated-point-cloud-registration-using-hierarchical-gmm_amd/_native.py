@@ -473,8 +473,9 @@ class Context:
     def profile_reset(self):
         self._check(self.lib.hgmm_profile_reset(self.h))
 
-    def util_fill(self, arr, value=0.0, nontemporal=True):
-        self._check(self.lib.hgmm_util_fill_f32(self.h, arr.ptr, arr.size, float(value), 1 if nontemporal else 0))
+    def util_fill(self, arr, value=0.0, nontemporal=True, mode=0, grid_mult=0):
+        flags = (1 if nontemporal else 0) | (int(mode) << 8) | (int(grid_mult) << 16)
+        self._check(self.lib.hgmm_util_fill_f32(self.h, arr.ptr, arr.size, float(value), flags))
 
     def profile_get(self, kernel):
         ms, n = C.c_double(), C.c_int64()

@@ -174,30 +174,43 @@ template <int NV4, int NV1, bool NORMALISE, bool NT>
 __global__ __launch_bounds__(BLOCK) void flat_estep_kernel(
     const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int J, int Jpad,
     float* __restrict__ log_resp, float* __restrict__ lpn_out, int32_t* __restrict__ argmax_out,
-    double* __restrict__ lpn_partials) {
+    double* __restrict__ lpn_partials, int round_robin) {
     using L = Layout<NV4, NV1>;
     constexpr int K = L::K;
     const int lane = lane_id();
     LaneParams<NV4, NV1> P;
     P.load(pack, Jpad, lane);
 
-    int64_t r0, r1;
-    wave_row_range(n, r0, r1);
+    // rows of this wave: base + it * stride, it < cnt.  round_robin = 0: one contiguous range per
+    // wave; 1: rows dealt round-robin, so that the waves in flight write one contiguous window
+    int64_t base, stride, cnt;
+    {
+        const int64_t nw = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+        const int64_t gw = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
+        if (round_robin) {
+            base = gw; stride = nw; cnt = (gw < n) ? (n - gw + nw - 1) / nw : 0;
+        } else {
+            int64_t r0, r1;
+            wave_row_range(n, r0, r1);
+            base = r0; stride = 1; cnt = r1 - r0;
+        }
+    }
     double lsum = 0.0;
     float keep_lpn = 0.f;
     int keep_arg = 0;
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-    if (r0 < r1) { const float* xp = X + 3 * r0; x0 = xp[0]; x1 = xp[1]; x2 = xp[2]; }
-    for (int64_t row = r0; row < r1; ++row) {
+    if (cnt > 0) { const float* xp = X + 3 * base; x0 = xp[0]; x1 = xp[1]; x2 = xp[2]; }
+    for (int64_t it = 0; it < cnt; ++it) {
+        const int64_t row = base + it * stride;
         // prefetch the next row's coordinates (wave-uniform scalar loads) behind this row's math
-        const int64_t nrow = (row + 1 < r1) ? row + 1 : row;
+        const int64_t nrow = (it + 1 < cnt) ? row + stride : row;
         const float* xn = X + 3 * nrow;
         const float nx0 = xn[0], nx1 = xn[1], nx2 = xn[2];
 
         float wl[K];
         float m = row_wl2<NV4, NV1>(P, x0, x1, x2, wl);
         m = wave_reduce(m, OpMax());
-        const int slot = (int)((row - r0) & 63);
+        const int slot = (int)(it & 63);
         if (NORMALISE) {
             if (m == NEG_INF) m = 0.f;            // every component has zero weight: avoid inf - inf
             float s = 0.f;
@@ -245,16 +258,129 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_kernel(
             if (best == 0x7fffffff) best = 0;
             if (lane == slot) keep_arg = best;
         }
-        if (slot == 63 || row + 1 == r1) {
-            const int64_t base = row - slot;
+        if (slot == 63 || it + 1 == cnt) {
+            // one store for the last (up to) 64 rows' scalars: lane l holds row base + (it - slot + l) * stride
             if (lane <= slot) {
-                if (NORMALISE && lpn_out) lpn_out[base + lane] = keep_lpn;
-                if (argmax_out) argmax_out[base + lane] = keep_arg;
+                const int64_t r = base + (it - slot + lane) * stride;
+                if (NORMALISE && lpn_out) lpn_out[r] = keep_lpn;
+                if (argmax_out) argmax_out[r] = keep_arg;
             }
         }
         x0 = nx0; x1 = nx1; x2 = nx2;
     }
     if (NORMALISE && lpn_partials) {
+        __shared__ double sh[WAVES_PER_BLOCK];
+        if (lane == 0) sh[wave_in_block()] = lsum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int i = 0; i < WAVES_PER_BLOCK; ++i) t += sh[i];
+            lpn_partials[blockIdx.x] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// materialising E-step, ROWS consecutive rows in flight per wave.  No accumulators live in this
+// kernel (parameters 7K + ROWS*K values), so the independent max / sum reduction chains of
+// several rows can interleave inside ONE wave; that lets the kernel run with few waves per CU,
+// and few, orderly writers is what the HBM write path rewards (tools/fillbench.py: 1024 waves
+// writing a common 1 MiB window reach 6.4 TB/s, 2048 waves 5.3 TB/s, private streams 5.5 TB/s).
+// Row groups are dealt round-robin over the waves so the waves in flight write one window.
+// ------------------------------------------------------------------------------------------
+template <int NV4, int NV1, int ROWS, bool NT>
+__global__ __launch_bounds__(BLOCK) void flat_estep_rows_kernel(
+    const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int J, int Jpad,
+    float* __restrict__ log_resp, float* __restrict__ lpn_out, int32_t* __restrict__ argmax_out,
+    double* __restrict__ lpn_partials) {
+    using L = Layout<NV4, NV1>;
+    constexpr int K = L::K;
+    const int lane = lane_id();
+    LaneParams<NV4, NV1> P;
+    P.load(pack, Jpad, lane);
+    const int64_t nw = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    const int64_t gw = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
+    const int64_t ngroups = (n + ROWS - 1) / ROWS;
+    double lsum = 0.0;
+    float x[ROWS][3];
+    auto load_group = [&](int64_t g, float (&dst)[ROWS][3]) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            int64_t row = g * ROWS + r;
+            row = row < n ? row : n - 1;
+            const float* xp = X + 3 * row;
+            dst[r][0] = xp[0]; dst[r][1] = xp[1]; dst[r][2] = xp[2];
+        }
+    };
+    if (gw < ngroups) load_group(gw, x);
+    for (int64_t g = gw; g < ngroups; g += nw) {
+        float nx[ROWS][3];
+        load_group((g + nw < ngroups) ? g + nw : g, nx);          // prefetch (scalar loads)
+        float wl[ROWS][K];
+        float m[ROWS], s[ROWS], lpn[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) m[r] = row_wl2<NV4, NV1>(P, x[r][0], x[r][1], x[r][2], wl[r]);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            m[r] = wave_reduce(m[r], OpMax());
+            if (m[r] == NEG_INF) m[r] = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc += __builtin_amdgcn_exp2f(wl[r][k] - m[r]);
+            s[r] = acc;
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) s[r] = wave_reduce(s[r], OpSum());
+        float keep_lpn = 0.f;
+        int keep_arg = 0;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int64_t row = g * ROWS + r;
+            float inv_den;
+            lpn[r] = lpn2_from(m[r], s[r], inv_den) * LN2;
+            if (row < n) {                                          // wave-uniform
+                lsum += (double)lpn[r];
+                float* out = log_resp + row * (int64_t)J;
+#pragma unroll
+                for (int v = 0; v < NV4; ++v) {
+                    const int jb = (v * 64 + lane) * 4;
+                    if (jb < J)
+                        store_f4<NT>(out + jb, fmaf(wl[r][4 * v + 0], LN2, -lpn[r]), fmaf(wl[r][4 * v + 1], LN2, -lpn[r]),
+                                     fmaf(wl[r][4 * v + 2], LN2, -lpn[r]), fmaf(wl[r][4 * v + 3], LN2, -lpn[r]));
+                }
+#pragma unroll
+                for (int v = 0; v < NV1; ++v) {
+                    const int j = 256 * NV4 + v * 64 + lane;
+                    if (j < J) store_f1<NT>(out + j, fmaf(wl[r][4 * NV4 + v], LN2, -lpn[r]));
+                }
+            }
+            if (lane == r) keep_lpn = lpn[r];
+            if (argmax_out) {
+                int best = 0x7fffffff;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const int j = L::j_of(k, lane);
+                    if (wl[r][k] == m[r] && j < J && j < best) best = j;
+                }
+                best = wave_reduce_i(best, OpMinI());
+                if (best == 0x7fffffff) best = 0;
+                if (lane == r) keep_arg = best;
+            }
+        }
+        if (lane < ROWS) {
+            const int64_t row = g * ROWS + lane;
+            if (row < n) {
+                if (lpn_out) lpn_out[row] = keep_lpn;
+                if (argmax_out) argmax_out[row] = keep_arg;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { x[r][0] = nx[r][0]; x[r][1] = nx[r][1]; x[r][2] = nx[r][2]; }
+    }
+    if (lpn_partials) {
         __shared__ double sh[WAVES_PER_BLOCK];
         if (lane == 0) sh[wave_in_block()] = lsum;
         __syncthreads();
@@ -736,7 +862,7 @@ static bool env_flag(const char* name, bool dflt) {
 template <bool NORMALISE>
 static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argmax, int* grid_out) {
     const FlatState& f = c->flat;
-    const int grid = grid_for(c, c->n, env_int("HGMM_ESTEP_BPC", 2));
+    const int grid = grid_for(c, c->n, env_int("HGMM_ESTEP1_BPC", 2));
     *grid_out = grid;
     const float* X = c->x_aos.as<float>();
     const float* pk = c->f_pack.as<float>();
@@ -744,13 +870,42 @@ static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argma
     int nv4, nv1;
     pick_layout(f.J, &nv4, &nv1);
     const bool nt = NORMALISE && env_flag("HGMM_ESTEP_NT", true);
+    const int rr = env_int("HGMM_ESTEP_RR", 0);
+    // Materialising path: 6 rows in flight per wave, ONE workgroup per CU, row groups dealt
+    // round-robin, non-temporal stores (kbench, N = 1e6, J = 800, same box: single-row kernel at 2
+    // workgroups/CU 0.667 ms; rows = 4 / 6 / 8 at 1 workgroup/CU 0.612 / 0.600 / 0.615 ms).
+    const int rows = (NORMALISE && log_resp) ? env_int("HGMM_ESTEP_ROWS", 6) : 1;
     ProfScope prof(c, HGMM_K_FLAT_ESTEP);
+    if (rows > 1) {
+        const int grid_r = grid_for(c, (c->n + 5) / 6, env_int("HGMM_ESTEP_BPC", 1));
+        *grid_out = grid_r;
+#define ESTEP_R(A, B)                                                                              \
+    flat_estep_rows_kernel<A, B, 6, true><<<grid_r, BLOCK, 0, c->stream>>>(                         \
+        X, pk, c->n, f.J, f.Jpad, log_resp, lpn, argmax, lp)
+        if (nv4 == 3 && nv1 == 1) ESTEP_R(3, 1);
+        else if (nv4 == 3 && nv1 == 0) ESTEP_R(3, 0);
+        else if (nv4 == 3 && nv1 == 2) ESTEP_R(3, 2);
+        else if (nv4 == 4 && nv1 == 0) ESTEP_R(4, 0);
+        else if (nv4 == 2 && nv1 == 0) ESTEP_R(2, 0);
+        else if (nv4 == 2 && nv1 == 1) ESTEP_R(2, 1);
+        else if (nv4 == 2 && nv1 == 2) ESTEP_R(2, 2);
+        else if (nv4 == 1 && nv1 == 0) ESTEP_R(1, 0);
+        else if (nv4 == 1 && nv1 == 1) ESTEP_R(1, 1);
+        else if (nv4 == 1 && nv1 == 2) ESTEP_R(1, 2);
+        else if (nv4 == 0 && nv1 == 1) ESTEP_R(0, 1);
+        else if (nv4 == 0 && nv1 == 2) ESTEP_R(0, 2);
+        else goto single_row;
+#undef ESTEP_R
+        HGMM_HIP(c, hipGetLastError());
+        return HGMM_OK;
+    }
+single_row:
 #define ESTEP_M(A, B)                                                                              \
     do {                                                                                           \
         if (nt) flat_estep_kernel<A, B, NORMALISE, NORMALISE><<<grid, BLOCK, 0, c->stream>>>(       \
-                    X, pk, c->n, f.J, f.Jpad, log_resp, lpn, argmax, lp);                           \
+                    X, pk, c->n, f.J, f.Jpad, log_resp, lpn, argmax, lp, rr);                       \
         else flat_estep_kernel<A, B, NORMALISE, false><<<grid, BLOCK, 0, c->stream>>>(              \
-                    X, pk, c->n, f.J, f.Jpad, log_resp, lpn, argmax, lp);                           \
+                    X, pk, c->n, f.J, f.Jpad, log_resp, lpn, argmax, lp, rr);                       \
     } while (0)
     LAYOUT_DISPATCH(nv4, nv1, ESTEP_M);
 #undef ESTEP_M

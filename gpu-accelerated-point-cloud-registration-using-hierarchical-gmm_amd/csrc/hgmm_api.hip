@@ -78,14 +78,45 @@ __global__ void f64_to_f32(const double* __restrict__ in, int64_t n, float* __re
     if (i < n) out[i] = (float)in[i];
 }
 
-template <bool NT>
+// HBM write-ceiling probe.  MODE 0: grid-stride, one 16-byte store per thread per step (every
+// wave writes 1 KiB adjacent to its neighbours').  MODE 1: each workgroup owns one contiguous
+// region and streams through it (the E-step's pattern: every wave a private sequential stream).
+// MODE 2: like 0 with four independent 16-byte stores per thread per step.
+template <bool NT, int MODE>
 __global__ __launch_bounds__(256) void util_fill_kernel(float* __restrict__ p, int64_t n4, float v) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     const f4 val = {v, v, v, v};
     f4* q = reinterpret_cast<f4*>(p);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    auto st = [&](int64_t i) {
         if (NT) __builtin_nontemporal_store(val, q + i);
         else q[i] = val;
+    };
+    if (MODE == 0) {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) st(i);
+    } else if (MODE == 1) {
+        const int64_t per = (n4 + gridDim.x - 1) / gridDim.x;
+        const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < n4) ? lo + per : n4;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) st(i);
+    } else if (MODE == 2) {
+        const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+        int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (; i + 3 * stride < n4; i += 4 * stride) { st(i); st(i + stride); st(i + 2 * stride); st(i + 3 * stride); }
+        for (; i < n4; i += stride) st(i);
+    } else {
+        // MODE 3: one writer wavefront per workgroup streams `chunk` float4 (a batch of rows) at a
+        // time, workgroups take chunks round-robin -- the store pattern of a producer/consumer
+        // E-step with a dedicated writer wave per CU
+        const int64_t chunk = (int64_t)v;              // chunk length in float4, passed through v
+        const f4 one = {1.f, 1.f, 1.f, 1.f};
+        f4* qq = reinterpret_cast<f4*>(p);
+        const int64_t nchunks = (n4 + chunk - 1) / chunk;
+        for (int64_t cidx = blockIdx.x; cidx < nchunks; cidx += gridDim.x) {
+            const int64_t lo = cidx * chunk, hi = (lo + chunk < n4) ? lo + chunk : n4;
+            for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+                if (NT) __builtin_nontemporal_store(one, qq + i);
+                else qq[i] = one;
+            }
+        }
     }
 }
 
@@ -96,11 +127,23 @@ using namespace hgmm;
 extern "C" int hgmm_util_fill_f32(hgmm_ctx* c, float* dev, int64_t n, float value, int nontemporal) {
     if (!c || !dev || n < 4) return HGMM_ERR_ARG;
     const int64_t n4 = n / 4;
-    const int grid = c->cus * 8;
+    // bits 8.. of `nontemporal` select the probe variant: mode = (flags >> 8) & 3, grid = cus * ((flags >> 16) or 8)
+    const int mode = (nontemporal >> 8) & 3;
+    const int gmul = (nontemporal >> 16) ? (nontemporal >> 16) : 8;
+    const bool nt = (nontemporal & 1) != 0;
+    const int grid = c->cus * gmul;
     {
         ProfScope prof(c, HGMM_K_UTIL_FILL);
-        if (nontemporal) util_fill_kernel<true><<<grid, 256, 0, c->stream>>>(dev, n4, value);
-        else util_fill_kernel<false><<<grid, 256, 0, c->stream>>>(dev, n4, value);
+#define FILL(NTF, M) util_fill_kernel<NTF, M><<<grid, 256, 0, c->stream>>>(dev, n4, value)
+        if (mode == 0) { if (nt) FILL(true, 0); else FILL(false, 0); }
+        else if (mode == 1) { if (nt) FILL(true, 1); else FILL(false, 1); }
+        else if (mode == 2) { if (nt) FILL(true, 2); else FILL(false, 2); }
+        else {
+            // mode 3: grid = cus * gmul workgroups of ONE wavefront
+            if (nt) util_fill_kernel<true, 3><<<grid, 64, 0, c->stream>>>(dev, n4, value);
+            else util_fill_kernel<false, 3><<<grid, 64, 0, c->stream>>>(dev, n4, value);
+        }
+#undef FILL
     }
     HGMM_HIP(c, hipGetLastError());
     return HGMM_OK;

@@ -44,21 +44,25 @@ def main():
         res[label] = {"ms": ms / n, "GBs": alg / (ms / n * 1e-3) / 1e9}
         print("%-28s %.4f ms  %.0f GB/s (%.1f%% of 8 TB/s)" % (label, ms / n, res[label]["GBs"], res[label]["GBs"] / 80))
 
-    for nt in (True, False):
-        ctx.util_fill(lr, 1.0, nt)
+    for label, nt, mode, gm in (("fill 8 WG/CU grid-stride nt", True, 0, 8), ("fill 8 WG/CU grid-stride", False, 0, 8),
+                               ("fill 1 WG/CU grid-stride", False, 0, 1), ("fill 1 WG/CU grid-stride nt", True, 0, 1),
+                               ("fill 1 WG/CU private streams", False, 1, 1)):
+        ctx.util_fill(lr, 1.0, nt, mode, gm)
         ctx.profile_reset(); ctx.profile_enable(True)
         for _ in range(args.reps):
-            ctx.util_fill(lr, 1.0, nt)
+            ctx.util_fill(lr, 1.0, nt, mode, gm)
         ctx.profile_enable(False)
         ms, n = ctx.profile_get("util_fill")
-        print("%-28s %.4f ms  %.0f GB/s  (pure 16-byte store stream, %d MB)" % ("fill nt=%d" % nt, ms / n, 4 * N * J / (ms / n * 1e-3) / 1e9, 4 * N * J >> 20))
-        res["fill_nt%d" % nt] = {"ms": ms / n, "GBs": 4 * N * J / (ms / n * 1e-3) / 1e9}
-    for nt in ("1", "0"):
-        for bpc in ("2", "3"):
-            os.environ["HGMM_ESTEP_NT"] = nt
+        print("%-32s %.4f ms  %.0f GB/s  (pure 16-byte store stream, %d MB)" % (label, ms / n, 4 * N * J / (ms / n * 1e-3) / 1e9, 4 * N * J >> 20))
+        res[label] = {"ms": ms / n, "GBs": 4 * N * J / (ms / n * 1e-3) / 1e9}
+    os.environ["HGMM_ESTEP_NT"] = "1"
+    for rnd in range(2):
+        for rows, bpc in (("1", "2"), ("6", "1"), ("6", "2")):
             os.environ["HGMM_ESTEP_BPC"] = bpc
-            time_estep("estep nt=%s blocks/CU=%s" % (nt, bpc))
-    os.environ.pop("HGMM_ESTEP_NT"); os.environ.pop("HGMM_ESTEP_BPC")
+            os.environ["HGMM_ESTEP_ROWS"] = rows
+            time_estep("estep rows=%s blocks/CU=%s" % (rows, bpc if rows != "1" else "2"))
+    for k in ("HGMM_ESTEP_ROWS", "HGMM_ESTEP_NT", "HGMM_ESTEP_BPC"):
+        os.environ.pop(k)
 
     for rs_ in ("0", "1", "0", "1"):
         os.environ["HGMM_FUSED_RUNNING_SHIFT"] = rs_
