@@ -878,7 +878,6 @@ static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argma
     ProfScope prof(c, HGMM_K_FLAT_ESTEP);
     if (rows > 1) {
         const int grid_r = grid_for(c, (c->n + 5) / 6, env_int("HGMM_ESTEP_BPC", 1));
-        *grid_out = grid_r;
 #define ESTEP_R(A, B)                                                                              \
     flat_estep_rows_kernel<A, B, 6, true><<<grid_r, BLOCK, 0, c->stream>>>(                         \
         X, pk, c->n, f.J, f.Jpad, log_resp, lpn, argmax, lp)
@@ -896,6 +895,7 @@ static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argma
         else if (nv4 == 0 && nv1 == 2) ESTEP_R(0, 2);
         else goto single_row;
 #undef ESTEP_R
+        *grid_out = grid_r;
         HGMM_HIP(c, hipGetLastError());
         return HGMM_OK;
     }
