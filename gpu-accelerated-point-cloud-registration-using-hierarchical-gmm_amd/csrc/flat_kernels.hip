@@ -24,6 +24,7 @@
 #include "hgmm_ctx.h"
 #include "wave_ops.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
@@ -531,7 +532,9 @@ template <int NV4, int NV1>
 __global__ __launch_bounds__(BLOCK) void flat_mstep_kernel(
     const float* __restrict__ X, const float* __restrict__ resp, int is_log,
     const float* __restrict__ hint /*[3][Jpad]*/, int64_t n, int J, int Jpad,
-    float* __restrict__ partials) {
+    float* __restrict__ partials, int64_t ld) {
+    // resp / hint / partials point at this launch's first column; J = valid columns from there,
+    // ld = row stride of resp (the full component count)
     using L = Layout<NV4, NV1>;
     constexpr int K = L::K;
     const int lane = lane_id();
@@ -548,7 +551,7 @@ __global__ __launch_bounds__(BLOCK) void flat_mstep_kernel(
 
     const float fill = is_log ? NEG_INF : 0.f;
     auto load_row = [&](int64_t row, float (&v)[K]) {
-        const float* in = resp + row * (int64_t)J;
+        const float* in = resp + row * ld;
 #pragma unroll
         for (int s = 0; s < NV4; ++s) {
             const int jb = (s * 64 + lane) * 4;
@@ -610,13 +613,200 @@ __global__ __launch_bounds__(BLOCK) void flat_mstep_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Large J (> 1024): the same register-resident mapping, applied to chunks of CH_J = 832
+// components (13 slots of 64).  A row's log-sum-exp is assembled from per-chunk (max, sum) pairs,
+// after which every chunk is revisited with the row's final normaliser:
+//   flat_chunk_lse_kernel      per chunk: m_c = max_j wl2, s_c = sum_j 2^(wl2 - m_c), arg-max
+//   flat_chunk_combine_kernel  per row: lpn2 = log2(sum_c s_c 2^(m_c) + eps), arg-max over chunks
+//   flat_chunk_fused_kernel    per chunk: r = 2^(wl2 - lpn2) (no reductions), statistics
+//   flat_chunk_write_kernel    per chunk: log_resp[:, chunk] = (wl2 - lpn2) ln 2
+// ------------------------------------------------------------------------------------------
+constexpr int CH_SLOTS = 13;
+constexpr int CH_J = CH_SLOTS * 64;
+
+__global__ __launch_bounds__(BLOCK) void flat_chunk_lse_kernel(
+    const float* __restrict__ X, const float* __restrict__ pack /*at the chunk's first column*/,
+    int64_t n, int jvalid, int jbase, int Jpad, float* __restrict__ cm, float* __restrict__ cs,
+    int* __restrict__ ca) {
+    constexpr int K = CH_SLOTS;
+    const int lane = lane_id();
+    LaneParams<0, CH_SLOTS> P;
+    P.load(pack, Jpad, lane);
+    int64_t r0, r1;
+    wave_row_range(n, r0, r1);
+    float keep_m = 0.f, keep_s = 0.f;
+    int keep_a = 0;
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+    if (r0 < r1) { const float* xp = X + 3 * r0; x0 = xp[0]; x1 = xp[1]; x2 = xp[2]; }
+    for (int64_t row = r0; row < r1; ++row) {
+        const int64_t nrow = (row + 1 < r1) ? row + 1 : row;
+        const float* xn = X + 3 * nrow;
+        const float nx0 = xn[0], nx1 = xn[1], nx2 = xn[2];
+        float wl[K];
+        float m = row_wl2<0, CH_SLOTS>(P, x0, x1, x2, wl);
+        m = wave_reduce(m, OpMax());
+        float s = 0.f;
+        if (m != NEG_INF) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) s += __builtin_amdgcn_exp2f(wl[k] - m);
+            s = wave_reduce(s, OpSum());
+        }
+        const int slot = (int)((row - r0) & 63);
+        if (ca) {
+            int best = 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int j = k * 64 + lane;
+                if (wl[k] == m && j < jvalid && j < best) best = j;
+            }
+            best = wave_reduce_i(best, OpMinI());
+            if (lane == slot) keep_a = (best == 0x7fffffff) ? jbase : jbase + best;
+        }
+        if (lane == slot) { keep_m = m; keep_s = s; }
+        if (slot == 63 || row + 1 == r1) {
+            const int64_t base = row - slot;
+            if (lane <= slot) {
+                cm[base + lane] = keep_m;
+                cs[base + lane] = keep_s;
+                if (ca) ca[base + lane] = keep_a;
+            }
+        }
+        x0 = nx0; x1 = nx1; x2 = nx2;
+    }
+}
+
+__global__ __launch_bounds__(256) void flat_chunk_combine_kernel(
+    const float* __restrict__ cm, const float* __restrict__ cs, const int* __restrict__ ca, int nchunks,
+    int64_t n, float* __restrict__ lpn2_out, float* __restrict__ lpn_out, int32_t* __restrict__ argmax_out,
+    double* __restrict__ lpn_partials) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double lp = 0.0;
+    if (i < n) {
+        float M = NEG_INF;
+        int best_c = 0;
+        for (int c = 0; c < nchunks; ++c) {
+            const float m = cm[(size_t)c * n + i];
+            if (m > M) { M = m; best_c = c; }           // strict >: first chunk wins ties (numpy argmax)
+        }
+        float S = 0.f;
+        if (M == NEG_INF) M = 0.f;
+        else
+            for (int c = 0; c < nchunks; ++c) {
+                const float m = cm[(size_t)c * n + i];
+                if (m != NEG_INF) S += cs[(size_t)c * n + i] * __builtin_amdgcn_exp2f(m - M);
+            }
+        float inv_den;
+        const float lpn2 = lpn2_from(M, S, inv_den);
+        lpn2_out[i] = lpn2;
+        const float lpn = lpn2 * LN2;
+        if (lpn_out) lpn_out[i] = lpn;
+        if (argmax_out) argmax_out[i] = ca ? ca[(size_t)best_c * n + i] : 0;
+        lp = (double)lpn;
+    }
+    if (lpn_partials) {
+        __shared__ double sh[4];
+        lp = wave_sum_f64(lp);
+        if (lane_id() == 0) sh[wave_in_block()] = lp;
+        __syncthreads();
+        if (threadIdx.x == 0) lpn_partials[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void flat_chunk_fused_kernel(
+    const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int Jpad,
+    const float* __restrict__ lpn2, float* __restrict__ partials /*at the chunk's first column*/,
+    const int* __restrict__ done_flag) {
+    if (done_flag && *done_flag) return;
+    constexpr int K = CH_SLOTS;
+    const int lane = lane_id();
+    LaneParams<0, CH_SLOTS> P;
+    P.load(pack, Jpad, lane);
+    float a_s0[K], a_a0[K], a_a1[K], a_a2[K], a_b0[K], a_b1[K], a_b2[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) a_s0[k] = a_a0[k] = a_a1[k] = a_a2[k] = a_b0[k] = a_b1[k] = a_b2[k] = 0.f;
+    int64_t r0, r1;
+    wave_row_range(n, r0, r1);
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f, l2 = 0.f;
+    if (r0 < r1) { const float* xp = X + 3 * r0; x0 = xp[0]; x1 = xp[1]; x2 = xp[2]; l2 = lpn2[r0]; }
+    for (int64_t row = r0; row < r1; ++row) {
+        const int64_t nrow = (row + 1 < r1) ? row + 1 : row;
+        const float* xn = X + 3 * nrow;
+        const float nx0 = xn[0], nx1 = xn[1], nx2 = xn[2], nl2 = lpn2[nrow];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float d0 = x0 - P.mu0[k], d1 = x1 - P.mu1[k], d2 = x2 - P.mu2[k];
+            float a = fmaf(-(d0 * P.g0[k]), d0, P.c[k] - l2);
+            a = fmaf(-(d1 * P.g1[k]), d1, a);
+            a = fmaf(-(d2 * P.g2[k]), d2, a);
+            const float rr = __builtin_amdgcn_exp2f(a);      // r = 2^(wl2 - lpn2) = exp(wlp - lpn)
+            const float rd0 = rr * d0, rd1 = rr * d1, rd2 = rr * d2;
+            a_s0[k] += rr;
+            a_a0[k] += rd0; a_a1[k] += rd1; a_a2[k] += rd2;
+            a_b0[k] = fmaf(rd0, d0, a_b0[k]);
+            a_b1[k] = fmaf(rd1, d1, a_b1[k]);
+            a_b2[k] = fmaf(rd2, d2, a_b2[k]);
+        }
+        x0 = nx0; x1 = nx1; x2 = nx2; l2 = nl2;
+    }
+    __shared__ float sh[FLAT_NSTAT * CH_J];
+    const int w = wave_in_block();
+    for (int turn = 0; turn < WAVES_PER_BLOCK; ++turn) {
+        if (w == turn) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                float* p = sh + k * 64 + lane;
+                constexpr int ST = CH_J;
+                if (turn == 0) {
+                    p[0 * ST] = a_s0[k]; p[1 * ST] = a_a0[k]; p[2 * ST] = a_a1[k]; p[3 * ST] = a_a2[k];
+                    p[4 * ST] = a_b0[k]; p[5 * ST] = a_b1[k]; p[6 * ST] = a_b2[k];
+                } else {
+                    p[0 * ST] += a_s0[k]; p[1 * ST] += a_a0[k]; p[2 * ST] += a_a1[k]; p[3 * ST] += a_a2[k];
+                    p[4 * ST] += a_b0[k]; p[5 * ST] += a_b1[k]; p[6 * ST] += a_b2[k];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* outp = partials + (size_t)blockIdx.x * FLAT_NSTAT * Jpad;
+    for (int idx = threadIdx.x; idx < FLAT_NSTAT * CH_J; idx += BLOCK) {
+        const int st = idx / CH_J, j = idx % CH_J;
+        outp[st * Jpad + j] = sh[idx];
+    }
+}
+
+// out[row, jbase + j] = (wl2 - lpn2[row]) ln 2   (lpn2 == nullptr: raw weighted log-probabilities)
+__global__ __launch_bounds__(BLOCK) void flat_chunk_write_kernel(
+    const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int jvalid, int Jpad,
+    const float* __restrict__ lpn2, float* __restrict__ out /*at the chunk's first column*/, int64_t ld) {
+    constexpr int K = CH_SLOTS;
+    const int lane = lane_id();
+    LaneParams<0, CH_SLOTS> P;
+    P.load(pack, Jpad, lane);
+    int64_t r0, r1;
+    wave_row_range(n, r0, r1);
+    for (int64_t row = r0; row < r1; ++row) {
+        const float* xp = X + 3 * row;
+        const float x0 = xp[0], x1 = xp[1], x2 = xp[2];
+        const float l = lpn2 ? lpn2[row] * LN2 : 0.f;
+        float wl[K];
+        (void)row_wl2<0, CH_SLOTS>(P, x0, x1, x2, wl);
+        float* o = out + row * ld;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int j = k * 64 + lane;
+            if (j < jvalid) __builtin_nontemporal_store(fmaf(wl[k], LN2, -l), o + j);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // second stage: fp64 sum of the per-workgroup partials -> stats[7][Jpad], sum lpn, n
 // ------------------------------------------------------------------------------------------
 constexpr int RED_IDX = 32;      // consecutive statistics per workgroup (one 128-byte line)
 constexpr int RED_SLICES = 8;    // partial-block slices summed in parallel, combined in fixed order
 __global__ __launch_bounds__(RED_IDX * RED_SLICES) void flat_reduce_kernel(
     const float* __restrict__ partials, const double* __restrict__ lpn_partials, int nblocks,
-    int valid_j, int Jpad, double n_local, double* __restrict__ stats,
+    int n_lpn_blocks, int valid_j, int Jpad, double n_local, double* __restrict__ stats,
     const int* __restrict__ done_flag) {
     if (done_flag && *done_flag) return;
     const int total = FLAT_NSTAT * Jpad;
@@ -650,7 +840,7 @@ __global__ __launch_bounds__(RED_IDX * RED_SLICES) void flat_reduce_kernel(
         // last workgroup: sum of the per-workgroup log-normaliser partials + the point count
         double acc = 0.0;
         if (lpn_partials)
-            for (int b = threadIdx.x; b < nblocks; b += RED_IDX * RED_SLICES) acc += lpn_partials[b];
+            for (int b = threadIdx.x; b < n_lpn_blocks; b += RED_IDX * RED_SLICES) acc += lpn_partials[b];
         acc = wave_sum_f64(acc);
         double* shw = &sh[0][0];
         if (lane_id() == 0) shw[wave_in_block()] = acc;
@@ -673,6 +863,67 @@ __global__ __launch_bounds__(RED_IDX * RED_SLICES) void flat_reduce_kernel(
 //        w = nk / N; inv_std = 1/(sqrt(cov) + eps)
 // ctl: [0] done, [1] n_iter, [2] converged; prev_ll lives in ctl_f[0].
 // ------------------------------------------------------------------------------------------
+__device__ inline void finalize_component(int j, const double* __restrict__ stats,
+                                          const float* __restrict__ centre, int J, int Jpad, int cov_type,
+                                          int variant, float* mu, float* cov, float* w, float* inv) {
+    const double eps = (double)FLAT_EPS;
+    const double n_total = stats[FLAT_NSTAT * Jpad + 1];
+    const double s0 = stats[0 * Jpad + j];
+    double nmu[3], ncov[3];
+    const double nk = (variant == HGMM_VARIANT_W) ? s0 + eps : s0;
+    const double den = (variant == HGMM_VARIANT_W) ? nk : nk + eps;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const double c = (double)centre[d * Jpad + j];
+        const double a = stats[(1 + d) * Jpad + j];
+        const double b = stats[(4 + d) * Jpad + j];
+        const double sx = a + c * s0;
+        const double sxx = b + 2.0 * c * a + c * c * s0;
+        const double m = sx / den;
+        double v = sxx / den - m * m;
+        if (variant == HGMM_VARIANT_W) v += 1e-6; else v = v < 0.0 ? 0.0 : v;
+        nmu[d] = m;
+        ncov[d] = v;
+    }
+    // round to the reference's storage type (float32) before deriving inv_std
+    float fc[3];
+    if (cov_type == HGMM_COV_SPHERICAL) {
+        const float sph = (float)((ncov[0] + ncov[1] + ncov[2]) / 3.0);
+        fc[0] = fc[1] = fc[2] = sph;
+        cov[j] = sph;
+    } else {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { fc[d] = (float)ncov[d]; cov[3 * j + d] = fc[d]; }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) mu[3 * j + d] = (float)nmu[d];
+    w[j] = (float)(nk / n_total);
+    if (inv) {
+        float fi[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const double cv = (double)fc[d];
+            fi[d] = (float)((variant == HGMM_VARIANT_W) ? 1.0 / (sqrt(cv + 1e-6) + eps)
+                                                         : 1.0 / (sqrt(cv) + eps));
+        }
+        if (cov_type == HGMM_COV_SPHERICAL) inv[j] = fi[0];
+        else { inv[3 * j + 0] = fi[0]; inv[3 * j + 1] = fi[1]; inv[3 * j + 2] = fi[2]; }
+    }
+}
+
+__device__ inline void ctl_update(const double* __restrict__ stats, int Jpad, float* lls, int lls_cap,
+                                  float tol, int* ctl, float* ctl_f) {
+    const double n_total = stats[FLAT_NSTAT * Jpad + 1];
+    const float ll = (float)(stats[FLAT_NSTAT * Jpad] / n_total);
+    const int it = ctl[1];
+    if (it < lls_cap) lls[it] = ll;
+    const float change = ll - ctl_f[0];          // prev starts at -inf (gmm_impl.py:120)
+    ctl_f[0] = ll;
+    ctl[1] = it + 1;
+    if (fabsf(change) < tol) { ctl[0] = 1; ctl[2] = 1; }
+}
+
+// single workgroup (Jpad <= 1024): M-step + next packed table + stop rule in one launch
 __global__ void flat_finalize_kernel(const double* __restrict__ stats,
                                      const float* __restrict__ centre /*[3][Jpad] or pack mu rows*/,
                                      int J, int Jpad, int cov_type, int variant,
@@ -682,62 +933,26 @@ __global__ void flat_finalize_kernel(const double* __restrict__ stats,
     const int done = ctl ? ctl[0] : 0;
     __syncthreads();
     if (done) return;
-    const double eps = (double)FLAT_EPS;
-    const double n_total = stats[FLAT_NSTAT * Jpad + 1];
-    if (j < J) {
-        const double s0 = stats[0 * Jpad + j];
-        double nmu[3], ncov[3];
-        const double nk = (variant == HGMM_VARIANT_W) ? s0 + eps : s0;
-        const double den = (variant == HGMM_VARIANT_W) ? nk : nk + eps;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const double c = (double)centre[d * Jpad + j];
-            const double a = stats[(1 + d) * Jpad + j];
-            const double b = stats[(4 + d) * Jpad + j];
-            const double sx = a + c * s0;
-            const double sxx = b + 2.0 * c * a + c * c * s0;
-            const double m = sx / den;
-            double v = sxx / den - m * m;
-            if (variant == HGMM_VARIANT_W) v += 1e-6; else v = v < 0.0 ? 0.0 : v;
-            nmu[d] = m;
-            ncov[d] = v;
-        }
-        // round to the reference's storage type (float32) before deriving inv_std
-        float fc[3];
-        if (cov_type == HGMM_COV_SPHERICAL) {
-            const float sph = (float)((ncov[0] + ncov[1] + ncov[2]) / 3.0);
-            fc[0] = fc[1] = fc[2] = sph;
-            cov[j] = sph;
-        } else {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) { fc[d] = (float)ncov[d]; cov[3 * j + d] = fc[d]; }
-        }
-#pragma unroll
-        for (int d = 0; d < 3; ++d) mu[3 * j + d] = (float)nmu[d];
-        w[j] = (float)(nk / n_total);
-        if (inv) {
-            float fi[3];
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const double cv = (double)fc[d];
-                fi[d] = (float)((variant == HGMM_VARIANT_W) ? 1.0 / (sqrt(cv + 1e-6) + eps)
-                                                             : 1.0 / (sqrt(cv) + eps));
-            }
-            if (cov_type == HGMM_COV_SPHERICAL) inv[j] = fi[0];
-            else { inv[3 * j + 0] = fi[0]; inv[3 * j + 1] = fi[1]; inv[3 * j + 2] = fi[2]; }
-        }
-    }
+    if (j < J) finalize_component(j, stats, centre, J, Jpad, cov_type, variant, mu, cov, w, inv);
     __syncthreads();
     if (pack && j < Jpad) pack_component(j, J, Jpad, cov_type, variant, mu, inv, w, pack);
-    if (j == 0 && ctl) {
-        const float ll = (float)(stats[FLAT_NSTAT * Jpad] / n_total);
-        const int it = ctl[1];
-        if (it < lls_cap) lls[it] = ll;
-        const float change = ll - ctl_f[0];          // prev starts at -inf (gmm_impl.py:120)
-        ctl_f[0] = ll;
-        ctl[1] = it + 1;
-        if (fabsf(change) < tol) { ctl[0] = 1; ctl[2] = 1; }
-    }
+    if (j == 0 && ctl) ctl_update(stats, Jpad, lls, lls_cap, tol, ctl, ctl_f);
+}
+
+// many workgroups (large J): the stop rule moves to flat_ctl_kernel, launched afterwards, so no
+// workgroup can observe a `done` flag written during this launch
+__global__ void flat_finalize_mb_kernel(const double* __restrict__ stats, const float* __restrict__ centre,
+                                        int J, int Jpad, int cov_type, int variant, float* mu, float* cov,
+                                        float* w, float* inv, float* pack, const int* ctl) {
+    if (ctl && ctl[0]) return;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < J) finalize_component(j, stats, centre, J, Jpad, cov_type, variant, mu, cov, w, inv);
+    if (pack && j < Jpad) pack_component(j, J, Jpad, cov_type, variant, mu, inv, w, pack);
+}
+__global__ void flat_ctl_kernel(const double* __restrict__ stats, int Jpad, float* lls, int lls_cap, float tol,
+                                int* ctl, float* ctl_f) {
+    if (ctl[0]) return;
+    ctl_update(stats, Jpad, lls, lls_cap, tol, ctl, ctl_f);
 }
 
 __global__ void flat_ctl_init_kernel(int* ctl, float* ctl_f) {
@@ -778,22 +993,34 @@ static int flat_check(hgmm_ctx* c, int cov_type, int variant, int J) {
         return fail(c, HGMM_ERR_ARG, "variant must be 0 (W) or 1 (G)");
     if (variant == HGMM_VARIANT_G && cov_type != HGMM_COV_DIAG)
         return fail(c, HGMM_ERR_ARG, "variant G (gmmreg_gpu) is diag-only");
-    if (J < 1 || J > FLAT_MAX_J)
-        return fail(c, HGMM_ERR_ARG, "J = %d outside the supported range 1..%d", J, FLAT_MAX_J);
+    if (J < 1 || J > FLAT_MAX_J_CHUNKED)
+        return fail(c, HGMM_ERR_ARG, "J = %d outside the supported range 1..%d", J, FLAT_MAX_J_CHUNKED);
     return HGMM_OK;
 }
 
 static int flat_setup(hgmm_ctx* c, int cov_type, int variant, int J) {
-    const int Jpad = round_up(J, 256);
+    HGMM_HIP(c, hipSetDevice(c->device));
+    const bool chunked = J > FLAT_MAX_J;
+    const int nchunks = chunked ? (J + CH_J - 1) / CH_J : 1;
+    const int Jpad = chunked ? round_up(nchunks * CH_J, 256) : round_up(J, 256);
     c->flat.cov_type = cov_type; c->flat.variant = variant; c->flat.J = J; c->flat.Jpad = Jpad;
+    c->flat.chunked = chunked; c->flat.nchunks = nchunks;
+    if (chunked) {
+        HGMM_TRY(ensure(c, c->f_cm, sizeof(float) * (size_t)nchunks * c->n));
+        HGMM_TRY(ensure(c, c->f_cs, sizeof(float) * (size_t)nchunks * c->n));
+        HGMM_TRY(ensure(c, c->f_ca, sizeof(int) * (size_t)nchunks * c->n));
+        HGMM_TRY(ensure(c, c->f_lpn2, sizeof(float) * (size_t)c->n));
+    }
     HGMM_TRY(ensure(c, c->f_mu, sizeof(float) * 3 * Jpad));
     HGMM_TRY(ensure(c, c->f_cov, sizeof(float) * 3 * Jpad));
     HGMM_TRY(ensure(c, c->f_inv, sizeof(float) * 3 * Jpad));
     HGMM_TRY(ensure(c, c->f_w, sizeof(float) * Jpad));
     HGMM_TRY(ensure(c, c->f_pack, sizeof(float) * FLAT_NSTAT * Jpad));
     HGMM_TRY(ensure(c, c->f_hint, sizeof(float) * 3 * Jpad));
-    HGMM_TRY(ensure(c, c->f_partials, sizeof(float) * (size_t)FLAT_MAX_BLOCKS * FLAT_NSTAT * Jpad));
-    HGMM_TRY(ensure(c, c->f_lpn_partials, sizeof(double) * FLAT_MAX_BLOCKS));
+    const size_t max_blocks = std::min<size_t>(FLAT_MAX_BLOCKS, (size_t)c->cus * 3);
+    HGMM_TRY(ensure(c, c->f_partials, sizeof(float) * max_blocks * FLAT_NSTAT * Jpad));
+    HGMM_TRY(ensure(c, c->f_lpn_partials,
+                    sizeof(double) * std::max<size_t>(FLAT_MAX_BLOCKS, (size_t)((c->n + 255) / 256))));
     HGMM_TRY(ensure(c, c->f_stats, sizeof(double) * (FLAT_NSTAT * Jpad + 2)));
     HGMM_TRY(ensure(c, c->f_ctl, 64));
     return HGMM_OK;
@@ -962,14 +1189,59 @@ static int launch_fused(hgmm_ctx* c, const int* done_flag, int* grid_out, int* v
     return HGMM_OK;
 }
 
-static int launch_reduce(hgmm_ctx* c, int nblocks, int valid_j, bool with_lpn, const int* done_flag) {
+static int launch_reduce(hgmm_ctx* c, int nblocks, int valid_j, bool with_lpn, const int* done_flag,
+                         int n_lpn_blocks = -1) {
     const FlatState& f = c->flat;
     const int total = FLAT_NSTAT * f.Jpad;
     flat_reduce_kernel<<<(total + RED_IDX - 1) / RED_IDX + 1, RED_IDX * RED_SLICES, 0, c->stream>>>(
         c->f_partials.as<float>(), with_lpn ? c->f_lpn_partials.as<double>() : nullptr, nblocks,
-        valid_j, f.Jpad, (double)c->n, c->f_stats.as<double>(), done_flag);
+        n_lpn_blocks < 0 ? nblocks : n_lpn_blocks, valid_j, f.Jpad, (double)c->n, c->f_stats.as<double>(),
+        done_flag);
     HGMM_HIP(c, hipGetLastError());
     if (c->comm) HGMM_TRY(allreduce_f64_dev(c, c->f_stats.as<double>(), (size_t)total + 2));
+    return HGMM_OK;
+}
+
+// ---- chunked (J > 1024) launch helpers ---------------------------------------------------------
+static int chunk_valid(const FlatState& f, int ci) {
+    const int rem = f.J - ci * CH_J;
+    return rem < CH_J ? rem : CH_J;
+}
+
+// per-chunk (max, sum[, arg-max]) + per-row combine -> f_lpn2 [, lpn_out, argmax_out, lpn partials]
+static int chunk_normalisers(hgmm_ctx* c, bool want_arg, float* lpn_out, int32_t* argmax_out,
+                             bool want_partials, int* n_lpn_blocks) {
+    const FlatState& f = c->flat;
+    const int grid = grid_for(c, c->n, 3);
+    float* cm = c->f_cm.as<float>();
+    float* cs = c->f_cs.as<float>();
+    int* ca = c->f_ca.as<int>();
+    for (int ci = 0; ci < f.nchunks; ++ci)
+        flat_chunk_lse_kernel<<<grid, BLOCK, 0, c->stream>>>(
+            c->x_aos.as<float>(), c->f_pack.as<float>() + ci * CH_J, c->n, chunk_valid(f, ci), ci * CH_J, f.Jpad,
+            cm + (size_t)ci * c->n, cs + (size_t)ci * c->n, want_arg ? ca + (size_t)ci * c->n : nullptr);
+    const int cblocks = (int)((c->n + 255) / 256);
+    flat_chunk_combine_kernel<<<cblocks, 256, 0, c->stream>>>(cm, cs, want_arg ? ca : nullptr, f.nchunks, c->n,
+                                                            c->f_lpn2.as<float>(), lpn_out, argmax_out,
+                                                            want_partials ? c->f_lpn_partials.as<double>() : nullptr);
+    HGMM_HIP(c, hipGetLastError());
+    if (n_lpn_blocks) *n_lpn_blocks = cblocks;
+    return HGMM_OK;
+}
+
+// statistics of all chunks with the rows' final normalisers -> f_partials (grid returned)
+static int chunk_statistics(hgmm_ctx* c, const int* done_flag, int* grid_out) {
+    const FlatState& f = c->flat;
+    const int grid = grid_for(c, c->n, 2);
+    {
+        ProfScope prof(c, HGMM_K_FLAT_FUSED);
+        for (int ci = 0; ci < f.nchunks; ++ci)
+            flat_chunk_fused_kernel<<<grid, BLOCK, 0, c->stream>>>(
+                c->x_aos.as<float>(), c->f_pack.as<float>() + ci * CH_J, c->n, f.Jpad, c->f_lpn2.as<float>(),
+                c->f_partials.as<float>() + ci * CH_J, done_flag);
+    }
+    HGMM_HIP(c, hipGetLastError());
+    *grid_out = grid;
     return HGMM_OK;
 }
 
@@ -979,6 +1251,21 @@ static int enqueue_em_iteration(hgmm_ctx* c) {
     int* ctl = c->f_ctl.as<int>();
     float* ctl_f = reinterpret_cast<float*>(ctl + 8);
     int grid = 0, valid_j = 0;
+    if (f.chunked) {
+        int n_lpn = 0;
+        HGMM_TRY(chunk_normalisers(c, false, nullptr, nullptr, true, &n_lpn));
+        HGMM_TRY(chunk_statistics(c, ctl, &grid));
+        HGMM_TRY(launch_reduce(c, grid, f.nchunks * CH_J, true, ctl, n_lpn));
+        flat_finalize_mb_kernel<<<(f.Jpad + 255) / 256, 256, 0, c->stream>>>(
+            c->f_stats.as<double>(), c->f_pack.as<float>() + PK_MU * f.Jpad, f.J, f.Jpad, f.cov_type, f.variant,
+            c->f_mu.as<float>(), c->f_cov.as<float>(), c->f_w.as<float>(), c->f_inv.as<float>(),
+            c->f_pack.as<float>(), ctl);
+        flat_ctl_kernel<<<1, 1, 0, c->stream>>>(c->f_stats.as<double>(), f.Jpad, c->f_lls.as<float>(), f.lls_cap,
+                                               f.tol, ctl, ctl_f);
+        HGMM_HIP(c, hipGetLastError());
+        f.launched++;
+        return HGMM_OK;
+    }
     HGMM_TRY(launch_fused(c, ctl, &grid, &valid_j));
     HGMM_TRY(launch_reduce(c, grid, valid_j, true, ctl));
     // the statistics were centred about the means the E-step used = rows PK_MU.. of pack
@@ -1007,7 +1294,21 @@ extern "C" int hgmm_flat_estep(hgmm_ctx* c, int cov_type, int variant, int J, co
     HGMM_TRY(flat_upload(c, mu, inv_std, false, w));
     launch_pack(c);
     int grid = 0;
-    HGMM_TRY(launch_estep<true>(c, dev_log_resp, dev_lpn, dev_argmax, &grid));
+    if (c->flat.chunked) {
+        const FlatState& f = c->flat;
+        ProfScope prof(c, HGMM_K_FLAT_ESTEP);
+        HGMM_TRY(chunk_normalisers(c, dev_argmax != nullptr, dev_lpn, dev_argmax, true, &grid));
+        if (dev_log_resp) {
+            const int g2 = grid_for(c, c->n, 2);
+            for (int ci = 0; ci < f.nchunks; ++ci)
+                flat_chunk_write_kernel<<<g2, BLOCK, 0, c->stream>>>(
+                    c->x_aos.as<float>(), c->f_pack.as<float>() + ci * CH_J, c->n, chunk_valid(f, ci), f.Jpad,
+                    c->f_lpn2.as<float>(), dev_log_resp + ci * CH_J, (int64_t)J);
+            HGMM_HIP(c, hipGetLastError());
+        }
+    } else {
+        HGMM_TRY(launch_estep<true>(c, dev_log_resp, dev_lpn, dev_argmax, &grid));
+    }
     if (mean_lpn_out) {
         std::vector<double> h(grid);
         HGMM_HIP(c, hipMemcpyAsync(h.data(), c->f_lpn_partials.p, sizeof(double) * grid,
@@ -1028,6 +1329,7 @@ extern "C" int hgmm_flat_predict(hgmm_ctx* c, int cov_type, int variant, int J, 
     HGMM_TRY(flat_upload(c, mu, inv_std, false, w));
     launch_pack(c);
     int grid = 0;
+    if (c->flat.chunked) return chunk_normalisers(c, true, nullptr, dev_labels, false, nullptr);
     HGMM_TRY(launch_estep<false>(c, nullptr, nullptr, dev_labels, &grid));
     return HGMM_OK;
 }
@@ -1043,6 +1345,16 @@ extern "C" int hgmm_flat_log_prob(hgmm_ctx* c, int cov_type, int J, const float*
     HGMM_HIP(c, hipStreamSynchronize(c->stream));   // `ones` is pageable host memory
     launch_pack(c);
     int grid = 0;
+    if (c->flat.chunked) {
+        const FlatState& f = c->flat;
+        const int g2 = grid_for(c, c->n, 2);
+        for (int ci = 0; ci < f.nchunks; ++ci)
+            flat_chunk_write_kernel<<<g2, BLOCK, 0, c->stream>>>(
+                c->x_aos.as<float>(), c->f_pack.as<float>() + ci * CH_J, c->n, chunk_valid(f, ci), f.Jpad, nullptr,
+                dev_log_prob + ci * CH_J, (int64_t)J);
+        HGMM_HIP(c, hipGetLastError());
+        return HGMM_OK;
+    }
     HGMM_TRY(launch_estep<false>(c, dev_log_prob, nullptr, nullptr, &grid));
     return HGMM_OK;
 }
@@ -1067,14 +1379,21 @@ extern "C" int hgmm_flat_mstep(hgmm_ctx* c, int cov_type, int variant, int J, co
     float* part = c->f_partials.as<float>();
     const float* hint = c->f_hint.as<float>();
     int valid_j = 0;
-    {
+    if (f.chunked) {
+        ProfScope prof(c, HGMM_K_FLAT_MSTEP);
+        for (int ci = 0; ci < f.nchunks; ++ci)
+            flat_mstep_kernel<0, CH_SLOTS><<<grid, BLOCK, 0, c->stream>>>(
+                X, dev_resp + ci * CH_J, is_log, hint + ci * CH_J, c->n, chunk_valid(f, ci), f.Jpad,
+                part + ci * CH_J, (int64_t)J);
+        valid_j = f.nchunks * CH_J;
+    } else {
         ProfScope prof(c, HGMM_K_FLAT_MSTEP);
         int nv4, nv1;
         pick_layout(J, &nv4, &nv1);
 #define MSTEP_M(A, B)                                                                              \
     do {                                                                                           \
         flat_mstep_kernel<A, B><<<grid, BLOCK, 0, c->stream>>>(X, dev_resp, is_log, hint, c->n, J,  \
-                                                              f.Jpad, part);                      \
+                                                              f.Jpad, part, (int64_t)J);          \
         valid_j = 256 * A + 64 * B;                                                                \
     } while (0)
         LAYOUT_DISPATCH(nv4, nv1, MSTEP_M);
@@ -1082,9 +1401,14 @@ extern "C" int hgmm_flat_mstep(hgmm_ctx* c, int cov_type, int variant, int J, co
     }
     HGMM_HIP(c, hipGetLastError());
     HGMM_TRY(launch_reduce(c, grid, valid_j, false, nullptr));
-    flat_finalize_kernel<<<1, f.Jpad, 0, c->stream>>>(
-        c->f_stats.as<double>(), hint, J, f.Jpad, cov_type, variant, c->f_mu.as<float>(),
-        c->f_cov.as<float>(), c->f_w.as<float>(), nullptr, nullptr, nullptr, 0, 0.f, nullptr, nullptr);
+    if (f.chunked)
+        flat_finalize_mb_kernel<<<(f.Jpad + 255) / 256, 256, 0, c->stream>>>(
+            c->f_stats.as<double>(), hint, J, f.Jpad, cov_type, variant, c->f_mu.as<float>(),
+            c->f_cov.as<float>(), c->f_w.as<float>(), nullptr, nullptr, nullptr);
+    else
+        flat_finalize_kernel<<<1, f.Jpad, 0, c->stream>>>(
+            c->f_stats.as<double>(), hint, J, f.Jpad, cov_type, variant, c->f_mu.as<float>(),
+            c->f_cov.as<float>(), c->f_w.as<float>(), nullptr, nullptr, nullptr, 0, 0.f, nullptr, nullptr);
     HGMM_HIP(c, hipGetLastError());
     HGMM_HIP(c, hipMemcpyAsync(mu_out, c->f_mu.p, sizeof(float) * 3 * J, hipMemcpyDeviceToHost, c->stream));
     HGMM_HIP(c, hipMemcpyAsync(cov_out, c->f_cov.p, sizeof(float) * cov_elems(cov_type, J),
@@ -1171,8 +1495,15 @@ extern "C" int hgmm_flat_stats(hgmm_ctx* c, int cov_type, int variant, int J, co
     HGMM_TRY(flat_upload(c, mu, inv_std, false, w));
     launch_pack(c);
     int grid = 0, valid_j = 0;
-    HGMM_TRY(launch_fused(c, nullptr, &grid, &valid_j));
-    HGMM_TRY(launch_reduce(c, grid, valid_j, true, nullptr));
+    if (c->flat.chunked) {
+        int n_lpn = 0;
+        HGMM_TRY(chunk_normalisers(c, false, nullptr, nullptr, true, &n_lpn));
+        HGMM_TRY(chunk_statistics(c, nullptr, &grid));
+        HGMM_TRY(launch_reduce(c, grid, c->flat.nchunks * CH_J, true, nullptr, n_lpn));
+    } else {
+        HGMM_TRY(launch_fused(c, nullptr, &grid, &valid_j));
+        HGMM_TRY(launch_reduce(c, grid, valid_j, true, nullptr));
+    }
     const FlatState& f = c->flat;
     std::vector<double> h((size_t)FLAT_NSTAT * f.Jpad + 2);
     HGMM_HIP(c, hipMemcpyAsync(h.data(), c->f_stats.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));

@@ -15,7 +15,8 @@ namespace hgmm {
 
 constexpr float FLAT_EPS = 1e-8f;     // gmm_waymo gmm_impl.py:15 / gmmreg_gpu gmm_impl.py:16
 constexpr int FLAT_NSTAT = 7;         // s0, a[3], b[3]
-constexpr int FLAT_MAX_J = 1024;      // register-resident parameter kernels
+constexpr int FLAT_MAX_J = 1024;      // single-pass kernels (all parameters of a lane in registers)
+constexpr int FLAT_MAX_J_CHUNKED = 16384;  // chunked path (832-component chunks)
 constexpr int FLAT_MAX_BLOCKS = 1024; // persistent grid upper bound (partials buffer)
 
 // A growable device buffer owned by the context.
@@ -33,6 +34,8 @@ struct FlatState {
     int lls_cap = 0;
     int launched = 0;                 // EM iterations enqueued since train_begin
     bool active = false;
+    bool chunked = false;             // J > FLAT_MAX_J: 832-component chunks
+    int nchunks = 1;
 };
 
 struct TreeState {
@@ -66,6 +69,7 @@ struct hgmm_ctx {
     hgmm::DevBuf f_lls;                       // float [cap]
     hgmm::DevBuf f_ctl;                       // int  [4]: done, n_iter, converged, pad ; float prev
     hgmm::DevBuf f_hint;                      // float [3][Jpad] centre hint for m-step
+    hgmm::DevBuf f_cm, f_cs, f_ca, f_lpn2;    // chunked path: per-chunk (max, sum, arg-max) [C][n], lpn2 [n]
     hgmm::DevBuf scratch;
 
     // ---- tree -------------------------------------------------------------------

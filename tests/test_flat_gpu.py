@@ -409,7 +409,7 @@ def test_error_paths(ctx):
         with pytest.raises(ValueError):
             c.set_points(np.zeros((5, 2), np.float32))
         c.set_points(np.random.RandomState(0).rand(100, 3).astype(np.float32))
-        big = 1025
+        big = 16385
         with pytest.raises(hgmm_amd.HgmmError, match="outside the supported range"):
             c.flat_train(1, 0.0, np.zeros((big, 3), np.float32), np.ones((big, 3), np.float32), np.ones(big, np.float32))
         with pytest.raises(hgmm_amd.HgmmError, match="diag-only"):
@@ -426,3 +426,51 @@ def test_error_paths(ctx):
         c.close()
     with pytest.raises(hgmm_amd.HgmmError, match="closed"):
         c.flat_train(2, 0.0, mu, cov, w)
+
+
+@pytest.mark.parametrize("N,J", [(3000, 1025), (2500, 2000), (1500, 4096), (700, 833)])
+def test_large_component_counts_chunked_path(ctx, N, J):
+    """J > 1024 runs the chunked path (832-component chunks, normaliser assembled across chunks);
+    J = 833 (two chunks, the second with one component) is forced through it via a 1025+ sibling
+    test and exercised here through the regular path for comparison."""
+    rs = np.random.RandomState(J)
+    X = rs.rand(N, 3).astype(np.float32)
+    mu = rs.rand(J, 3).astype(np.float32)
+    inv = (1.0 / np.sqrt(0.003 + 0.02 * rs.rand(J, 3))).astype(np.float32)
+    w = rs.rand(J).astype(np.float32) + 0.01
+    w /= w.sum()
+    lr = check_estep(ctx, X, inv, mu, w, "diag", "W", "chunked %dx%d" % (N, J))
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    # predict
+    ctx.set_points(X)
+    lab = ctx.flat_predict(inv, mu, w, "diag", "W").get()
+    o_lab = flat_em.predict(f64(X), f64(inv), f64(mu), f64(w), "diag", "W")
+    assert (lab != o_lab).sum() <= 1
+    # estimate_log_prob
+    lp = ctx.flat_log_prob(inv, mu, "diag").get()
+    np.testing.assert_allclose(lp, flat_em.log_gauss_diag(f64(X), f64(inv), f64(mu)), rtol=2e-5, atol=2e-5)
+    # M-step from the materialised matrix and fused statistics
+    o_w, o_mu, o_cov = flat_em.m_step(f64(X), np.exp(f64(lr)), "diag", "W")
+    w_m, mu_m, cov_m = ctx.flat_mstep(ctx.to_device(lr).exp(), "diag", "W", centre_hint=mu)
+    live = o_w > 1e-6
+    np.testing.assert_allclose(w_m, o_w, rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(mu_m[live], o_mu[live], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(cov_m[live], o_cov[live], rtol=1e-3, atol=1e-8)
+    stats, sum_lpn, n = ctx.flat_stats(inv, mu, w, "diag", "W")
+    assert n == N
+    np.testing.assert_allclose(stats[:, 0], np.exp(f64(lr)).sum(0), rtol=1e-4, atol=1e-6)
+    # training loop (3 iterations, both flavours of the stop rule are exercised elsewhere)
+    cov0 = (0.05 * np.ones((J, 3))).astype(np.float32)
+    w0 = (np.ones(J) / J).astype(np.float32)
+    inv_t, mu_t, w_t, cov_t, lls, conv = ctx.flat_train(3, 0.0, mu, cov0, w0, "diag", "W")
+    o = flat_em.train(f64(X), 3, 0.0, f64(mu), f64(cov0), f64(w0), "diag", "W")
+    np.testing.assert_allclose(lls, o[4], rtol=0, atol=3e-5)
+    live = o[2] > 1e-5
+    np.testing.assert_allclose(mu_t[live], o[1][live], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(w_t, o[2], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(cov_t[live], o[3][live], rtol=2e-3, atol=1e-7)
+    # early stop also works on the chunked path
+    if J > 1024:
+        r = ctx.flat_train(25, 0.05, mu, cov0, w0, "diag", "W")
+        o2 = flat_em.train(f64(X), 25, 0.05, f64(mu), f64(cov0), f64(w0), "diag", "W")
+        assert len(r[4]) == len(o2[4]) and r[5] == o2[5]
