@@ -98,11 +98,10 @@ def broadcast_from_rank0(rank: int, world: int, payload: bytes | None, transport
 
 def attach_communicator(ctx, rank: int | None = None, world: int | None = None, transport: str = "auto"):
     """Create the RCCL communicator for `ctx` (one call per rank, collective)."""
-    from ._native import Context
     r, _, w = env_rank_world()
     rank = r if rank is None else rank
     world = w if world is None else world
-    uid = Context.comm_unique_id() if rank == 0 else None
+    uid = type(ctx).comm_unique_id() if rank == 0 else None
     uid = broadcast_from_rank0(rank, world, uid, transport)
     ctx.comm_init(world, rank, uid)
     return ctx
