@@ -397,31 +397,7 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_rows_kernel(
 // fused E+M: sufficient statistics without the N x J round trip
 //   s0_j = sum_i r_ij,  a_jd = sum_i r_ij (x_id - mu_jd),  b_jd = sum_i r_ij (x_id - mu_jd)^2
 // ------------------------------------------------------------------------------------------
-// Log-sum-exp shift.  The wave maximum of wl2 is only a numerical device: any shift within ~2^60
-// of it gives the same sum to float32 precision.  With RUNNING_SHIFT the previous row's
-// log2(sum) is reused as the shift, which removes the per-row max reduction (13 v_max + a 6-step
-// DPP chain); a row whose shifted sum leaves [2^-60, 2^60] (or is not finite) is redone with the
-// exact maximum (wave-uniform branch, rare: only at abrupt density changes along the point order).
-// Measured (kbench, N = 1e6, J = 800): the retry loop costs 3 extra VGPRs, which tips the J = 800
-// instantiation over the 256-register / 2-waves-per-SIMD line (0.78 ms); forcing the occupancy
-// spills 44 B/lane and ends at 0.66 ms vs 0.545 ms for the plain exact-maximum kernel -- so the
-// exact maximum is the default (HGMM_FUSED_RUNNING_SHIFT=1 selects the variant).
-constexpr float LOG2_EPS = -26.575424759098897f;       // log2(1e-8)
-
-// lpn2 = log2( 2^t + eps ), t = m + log2(s);  r_j = 2^(wl2_j - m) * inv_den
-__device__ __forceinline__ float lpn2_from_shift(float m, float s, float& inv_den, float& t_out) {
-    const float t = m + __builtin_amdgcn_logf(s);
-    t_out = t;
-    if (!(t >= -64.0f)) {                 // also catches s == 0 (t = -inf) and NaN
-        inv_den = 0.0f;
-        return LOG2_EPS;
-    }
-    const float den = fmaf(FLAT_EPS, __builtin_amdgcn_exp2f(-t), 1.0f);
-    inv_den = __builtin_amdgcn_rcpf(s * den);
-    return t + __builtin_amdgcn_logf(den);
-}
-
-template <int NSLOT, bool RUNNING_SHIFT>
+template <int NSLOT>
 __global__ __launch_bounds__(BLOCK) void flat_fused_kernel(
     const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int J, int Jpad,
     float* __restrict__ partials, double* __restrict__ lpn_partials,
@@ -440,8 +416,6 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_kernel(
     double lsum = 0.0;
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
     if (r0 < r1) { const float* xp = X + 3 * r0; x0 = xp[0]; x1 = xp[1]; x2 = xp[2]; }
-    float shift = 0.f;
-    bool have_shift = false;                           // wave-uniform
     for (int64_t row = r0; row < r1; ++row) {
         // prefetch the next row's coordinates (wave-uniform scalar loads) behind this row's math
         const int64_t nrow = (row + 1 < r1) ? row + 1 : row;
@@ -449,33 +423,19 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_kernel(
         const float nx0 = xn[0], nx1 = xn[1], nx2 = xn[2];
 
         float wl[K];
-        float m, s;
-#pragma unroll 1
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            const float lm = row_wl2<0, NSLOT>(P, x0, x1, x2, wl);
-            const bool use_shift = RUNNING_SHIFT && have_shift;
-            if (use_shift) {
-                m = shift;
-            } else {
-                m = wave_reduce(lm, OpMax());
-                if (m == NEG_INF) m = 0.f;
-            }
-            float acc = 0.f;
+        float m = row_wl2<0, NSLOT>(P, x0, x1, x2, wl);
+        m = wave_reduce(m, OpMax());
+        if (m == NEG_INF) m = 0.f;
+        float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                wl[k] = __builtin_amdgcn_exp2f(wl[k] - m);
-                acc += wl[k];
-            }
-            s = wave_reduce(acc, OpSum());
-            // 2^-60 < s < 2^60 (false for NaN / inf): the reused shift was close enough
-            if (!use_shift || ((s > 8.7e-19f) && (s < 1.15e18f))) break;
-            have_shift = false;                        // redo this row with the exact maximum
+        for (int k = 0; k < K; ++k) {
+            wl[k] = __builtin_amdgcn_exp2f(wl[k] - m);
+            s += wl[k];
         }
-        float inv_den, t;
-        const float lpn2 = lpn2_from_shift(m, s, inv_den, t);
+        s = wave_reduce(s, OpSum());
+        float inv_den;
+        const float lpn2 = lpn2_from(m, s, inv_den);
         lsum += (double)(lpn2 * LN2);
-        have_shift = (t > -1.0e30f) && (t < 1.0e30f);
-        shift = t;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const float rr = wl[k] * inv_den;
@@ -1149,20 +1109,17 @@ static int launch_fused(hgmm_ctx* c, const int* done_flag, int* grid_out, int* v
     float* part = c->f_partials.as<float>();
     double* lp = c->f_lpn_partials.as<double>();
     const int ns = (f.J + 63) / 64;
-    // Design notes (measured on MI355X at N = 1e6, J = 800, tools/kbench.py):
+    // Design notes (measured on MI355X at N = 1e6, J = 800; see DESIGN.md section 6 for the list):
     //  * more rows in flight per wave lose: 1 row (249 VGPRs, 2 waves/SIMD) 0.544 ms, 2 rows
     //    (310 regs, 1 wave/SIMD) 0.677 ms, 4 rows (424 regs) 0.772 ms;
+    //  * reusing the previous row's log-sum as the LSE shift (no max reduction) costs 3 VGPRs,
+    //    which tips J = 800 over the 256-register line: 0.66 - 0.78 ms;
     //  * wave-uniform skipping of 64-component slots whose responsibilities are all < 1e-10
-    //    (with Morton-ordered components) never triggers while components are broad: 0 % gain.
-    const bool running = env_flag("HGMM_FUSED_RUNNING_SHIFT", false);
+    //    never triggers while components are broad: 0 % gain.
 #define FUSED_CASE(S)                                                                           \
     do {                                                                                        \
-        if (running)                                                                            \
-            flat_fused_kernel<S, true><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad,  \
-                                                                     part, lp, done_flag);     \
-        else                                                                                    \
-            flat_fused_kernel<S, false><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, \
-                                                                      part, lp, done_flag);    \
+        flat_fused_kernel<S><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, part, lp,   \
+                                                           done_flag);                         \
         *valid_j = S * 64;                                                                      \
     } while (0)
     ProfScope prof(c, HGMM_K_FLAT_FUSED);

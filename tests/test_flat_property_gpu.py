@@ -1,0 +1,57 @@
+"""Property-based GPU parity test: random cloud shapes, scales, component counts, covariance
+flavours -- E-step, statistics and one full EM iteration against the float64 oracle."""
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st, HealthCheck
+
+from oracle import flat_em
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import hgmm_amd
+    c = hgmm_amd.Context(0)
+    yield c
+    c.close()
+
+
+CASES = st.tuples(
+    st.integers(1, 3000),                                     # N
+    st.integers(1, 1300),                                     # J (crosses 64/256/832/1024 boundaries)
+    st.sampled_from([("W", "diag"), ("W", "spherical"), ("G", "diag")]),
+    st.sampled_from([1e-2, 1.0, 50.0]),                       # coordinate scale (bunny .. lidar metres)
+    st.integers(0, 2 ** 31 - 1),
+)
+
+
+@settings(max_examples=30, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(case=CASES)
+def test_random_shapes(ctx, case):
+    N, J, (variant, cov_type), scale, seed = case
+    rs = np.random.RandomState(seed)
+    centres = rs.rand(5, 3) * scale
+    X = (centres[rs.randint(5, size=N)] + 0.08 * scale * rs.randn(N, 3)).astype(np.float32)
+    mu = (centres[rs.randint(5, size=J)] + 0.1 * scale * rs.randn(J, 3)).astype(np.float32)
+    sig = (0.03 + 0.2 * rs.rand(J, 3)) * scale
+    inv = (1.0 / sig).astype(np.float32)
+    if cov_type == "spherical":
+        inv = inv[:, 0].copy()
+    w = rs.rand(J).astype(np.float32) + 0.05
+    w /= w.sum()
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    ctx.set_points(X)
+    mean, lr, lpn, am = ctx.flat_estep(inv, mu, w, cov_type, variant, want_lpn=True, want_argmax=True)
+    o_mean, o_lr, o_lpn, o_am = flat_em.e_step_full(f64(X), f64(inv), f64(mu), f64(w), cov_type, variant)
+    r, o_r = np.exp(lr.get().astype(np.float64)), np.exp(o_lr)
+    assert np.abs(r - o_r).max() <= 1e-5
+    np.testing.assert_allclose(lpn.get(), o_lpn, rtol=2e-5, atol=2e-5)
+    flips = am.get() != o_am
+    if flips.any():
+        part = np.partition(o_r[flips], -2, axis=1)
+        assert ((part[:, -1] - part[:, -2]) < 1e-5).all()
+    stats, sum_lpn, n = ctx.flat_stats(inv, mu, w, cov_type, variant)
+    assert n == N
+    np.testing.assert_allclose(stats[:, 0], o_r.sum(0), rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(sum_lpn, o_lpn.sum(), rtol=2e-5, atol=1e-3)

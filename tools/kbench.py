@@ -64,15 +64,6 @@ def main():
     for k in ("HGMM_ESTEP_ROWS", "HGMM_ESTEP_NT", "HGMM_ESTEP_BPC"):
         os.environ.pop(k)
 
-    for rs_ in ("0", "1", "0", "1"):
-        os.environ["HGMM_FUSED_RUNNING_SHIFT"] = rs_
-        ctx.flat_train(3, 0.0, mu0, cov0, w0, "diag", "W")
-        ctx.profile_reset(); ctx.profile_enable(True)
-        o = ctx.flat_train(args.reps, 0.0, mu0, cov0, w0, "diag", "W")
-        ctx.profile_enable(False)
-        ms, n = ctx.profile_get("flat_fused")
-        print("%-28s %.4f ms  lls[-1]=%.7f" % ("fused running_shift=%s" % rs_, ms / n, o[4][-1]))
-    os.environ.pop("HGMM_FUSED_RUNNING_SHIFT")
     for bpc in ("1", "2", "3"):
         os.environ["HGMM_FUSED_BPC"] = bpc
         ctx.profile_reset(); ctx.profile_enable(True)
