@@ -59,10 +59,17 @@ def cpu_baseline_main(sample_n=200_000, iters=4):
     flat_em.train(X, iters, 0.0, mu, cov, w, "diag", "W")
     dt = time.perf_counter() - t0
     it_per_s_sample = iters / dt
+    blas_threads = None
+    try:                                   # threads the GEMMs actually ran on (elementwise passes are 1 thread)
+        from threadpoolctl import threadpool_info
+        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        pass
     return {
         "value": it_per_s_sample * sample_n / N_POINTS,
         "unit": "EM it/s per 1M-pt x 800-comp frame (extrapolated linearly in N from the sample)",
-        "cores": os.cpu_count(),
+        "cores": blas_threads or os.cpu_count(),
+        "host_cpu_count": os.cpu_count(),
         "kind": "port",
         "sample": "oracle/flat_em.train (NumPy fp32, same op sequence as reference train_gmm), N=%d of the "
                   "1M-point frame, J=800, %d iterations, %.1f s" % (sample_n, iters, dt),

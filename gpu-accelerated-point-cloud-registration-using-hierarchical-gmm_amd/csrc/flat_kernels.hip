@@ -492,7 +492,7 @@ template <int NV4, int NV1>
 __global__ __launch_bounds__(BLOCK) void flat_mstep_kernel(
     const float* __restrict__ X, const float* __restrict__ resp, int is_log,
     const float* __restrict__ hint /*[3][Jpad]*/, int64_t n, int J, int Jpad,
-    float* __restrict__ partials, int64_t ld) {
+    float* __restrict__ partials, int64_t ld, int round_robin) {
     // resp / hint / partials point at this launch's first column; J = valid columns from there,
     // ld = row stride of resp (the full component count)
     using L = Layout<NV4, NV1>;
@@ -506,8 +506,20 @@ __global__ __launch_bounds__(BLOCK) void flat_mstep_kernel(
         c0[k] = hint[0 * Jpad + j]; c1[k] = hint[1 * Jpad + j]; c2[k] = hint[2 * Jpad + j];
         a_s0[k] = a_a0[k] = a_a1[k] = a_a2[k] = a_b0[k] = a_b1[k] = a_b2[k] = 0.f;
     }
-    int64_t r0, r1;
-    wave_row_range(n, r0, r1);
+    // rows of this wave: base + it * stride (contiguous range, or dealt round-robin so that the
+    // waves in flight read one contiguous window of the matrix)
+    int64_t base, stride, cnt;
+    {
+        const int64_t nw = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+        const int64_t gw = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
+        if (round_robin) {
+            base = gw; stride = nw; cnt = (gw < n) ? (n - gw + nw - 1) / nw : 0;
+        } else {
+            int64_t r0, r1;
+            wave_row_range(n, r0, r1);
+            base = r0; stride = 1; cnt = r1 - r0;
+        }
+    }
 
     const float fill = is_log ? NEG_INF : 0.f;
     auto load_row = [&](int64_t row, float (&v)[K]) {
@@ -526,9 +538,10 @@ __global__ __launch_bounds__(BLOCK) void flat_mstep_kernel(
         }
     };
     float cur[K], nxt[K];
-    if (r0 < r1) load_row(r0, cur);
-    for (int64_t row = r0; row < r1; ++row) {
-        if (row + 1 < r1) load_row(row + 1, nxt);
+    if (cnt > 0) load_row(base, cur);
+    for (int64_t it = 0; it < cnt; ++it) {
+        const int64_t row = base + it * stride;
+        if (it + 1 < cnt) load_row(row + stride, nxt);
         const float* xp = X + 3 * row;
         const float x0 = xp[0], x1 = xp[1], x2 = xp[2];
 #pragma unroll
@@ -1332,6 +1345,7 @@ extern "C" int hgmm_flat_mstep(hgmm_ctx* c, int cov_type, int variant, int J, co
                                                                           c->f_hint.as<float>());
     }
     const int grid = grid_for(c, c->n, env_int("HGMM_MSTEP_BPC", 2));
+    const int rr = env_int("HGMM_MSTEP_RR", 0);
     const float* X = c->x_aos.as<float>();
     float* part = c->f_partials.as<float>();
     const float* hint = c->f_hint.as<float>();
@@ -1341,7 +1355,7 @@ extern "C" int hgmm_flat_mstep(hgmm_ctx* c, int cov_type, int variant, int J, co
         for (int ci = 0; ci < f.nchunks; ++ci)
             flat_mstep_kernel<0, CH_SLOTS><<<grid, BLOCK, 0, c->stream>>>(
                 X, dev_resp + ci * CH_J, is_log, hint + ci * CH_J, c->n, chunk_valid(f, ci), f.Jpad,
-                part + ci * CH_J, (int64_t)J);
+                part + ci * CH_J, (int64_t)J, rr);
         valid_j = f.nchunks * CH_J;
     } else {
         ProfScope prof(c, HGMM_K_FLAT_MSTEP);
@@ -1350,7 +1364,7 @@ extern "C" int hgmm_flat_mstep(hgmm_ctx* c, int cov_type, int variant, int J, co
 #define MSTEP_M(A, B)                                                                              \
     do {                                                                                           \
         flat_mstep_kernel<A, B><<<grid, BLOCK, 0, c->stream>>>(X, dev_resp, is_log, hint, c->n, J,  \
-                                                              f.Jpad, part, (int64_t)J);          \
+                                                              f.Jpad, part, (int64_t)J, rr);      \
         valid_j = 256 * A + 64 * B;                                                                \
     } while (0)
         LAYOUT_DISPATCH(nv4, nv1, MSTEP_M);

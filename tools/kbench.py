@@ -72,16 +72,17 @@ def main():
         ms, n = ctx.profile_get("flat_fused")
         print("%-28s %.4f ms  %.3g pairs/s" % ("fused blocks/CU=%s" % bpc, ms / n, N * J / (ms / n * 1e-3)))
     os.environ.pop("HGMM_FUSED_BPC")
-    for bpc in ("1", "2", "3", "4"):
+    for rr, bpc in (("0", "2"), ("1", "1"), ("1", "2"), ("1", "3"), ("0", "2"), ("1", "2")):
         os.environ["HGMM_MSTEP_BPC"] = bpc
+        os.environ["HGMM_MSTEP_RR"] = rr
         ctx.flat_mstep(lr.exp(), "diag", "W", centre_hint=mu)
         ctx.profile_reset(); ctx.profile_enable(True)
         for _ in range(5):
             ctx.flat_mstep(lr.exp(), "diag", "W", centre_hint=mu)
         ctx.profile_enable(False)
         ms, n = ctx.profile_get("flat_mstep")
-        print("%-28s %.4f ms  %.0f GB/s" % ("mstep blocks/CU=%s" % bpc, ms / n, (4 * N * J + 12 * N) / (ms / n * 1e-3) / 1e9))
-    os.environ.pop("HGMM_MSTEP_BPC")
+        print("%-28s %.4f ms  %.0f GB/s" % ("mstep rr=%s blocks/CU=%s" % (rr, bpc), ms / n, (4 * N * J + 12 * N) / (ms / n * 1e-3) / 1e9))
+    os.environ.pop("HGMM_MSTEP_BPC"); os.environ.pop("HGMM_MSTEP_RR")
 
     ctx.profile_reset(); ctx.profile_enable(True)
     ctx.flat_train(args.reps, 0.0, mu0, cov0, w0, "diag", "W")
