@@ -82,6 +82,10 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_tree_set_target", [ctx, _vp, C.c_int64])
         _sig(lib, "hgmm_tree_reg_estep", [ctx, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp])
         _sig(lib, "hgmm_tree_node_complexity", [ctx, _vp])
+        _sig(lib, "hgmm_tree_estep", [ctx, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+        _sig(lib, "hgmm_tree_mstep", [ctx, C.c_int64, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_double, C.c_double,
+                                      _vp, _vp, _vp])
+        _sig(lib, "hgmm_tree_loglik", [ctx, C.c_int64, _vp, _vp, _vp, C.c_int64, C.c_int64, _f64p])
         _sig(lib, "hgmm_fullcov_fit", [ctx, C.c_int, C.c_double, C.c_double, _vp, C.c_double, C.c_int, _vp, _vp, _vp,
                                        _vp, _vp, C.c_int, C.POINTER(C.c_int)])
         _sig(lib, "hgmm_fullcov_estep", [ctx, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64p])
@@ -410,6 +414,42 @@ class Context:
         self._check(self.lib.hgmm_tree_reg_estep(self.h, _ptr(rot), _ptr(t), float(scale), float(lambda_c),
                                                  _ptr(m0), _ptr(m1), _ptr(m2)))
         return m0, m1, m2
+
+    @staticmethod
+    def _node_tables(pi, mu, cov):
+        pi = np.ascontiguousarray(pi, dtype=np.float64).reshape(-1)
+        T = len(pi)
+        mu = np.ascontiguousarray(mu, dtype=np.float64).reshape(T, 3)
+        cov = np.ascontiguousarray(cov, dtype=np.float64).reshape(T, 3, 3)
+        return T, pi, mu, cov
+
+    def tree_estep(self, pi, mu, cov, parent_idx):
+        T, pi, mu, cov = self._node_tables(pi, mu, cov)
+        par = np.ascontiguousarray(parent_idx, dtype=np.int32)
+        if par.shape != (self.num_points,):
+            raise ValueError("parent_idx must have one entry per point")
+        m0, m1, m2 = np.empty(T), np.empty((T, 3)), np.empty((T, 3, 3))
+        cur = np.empty(self.num_points, np.int32)
+        self._check(self.lib.hgmm_tree_estep(self.h, T, _ptr(pi), _ptr(mu), _ptr(cov), _ptr(par), _ptr(m0), _ptr(m1),
+                                             _ptr(m2), _ptr(cur)))
+        return m0, m1, m2, cur
+
+    def tree_mstep(self, m0, m1, m2, j_begin, j_end, n_points, ld, pi, mu, cov):
+        T, pi, mu, cov = self._node_tables(pi, mu, cov)
+        pi, mu, cov = pi.copy(), mu.copy(), cov.copy()
+        m0 = np.ascontiguousarray(m0, dtype=np.float64).reshape(T)
+        m1 = np.ascontiguousarray(m1, dtype=np.float64).reshape(T, 3)
+        m2 = np.ascontiguousarray(m2, dtype=np.float64).reshape(T, 3, 3)
+        self._check(self.lib.hgmm_tree_mstep(self.h, T, _ptr(m0), _ptr(m1), _ptr(m2), int(j_begin), int(j_end),
+                                             float(n_points), float(ld), _ptr(pi), _ptr(mu), _ptr(cov)))
+        return pi, mu, cov
+
+    def tree_loglik(self, pi, mu, cov, j_begin, j_end):
+        T, pi, mu, cov = self._node_tables(pi, mu, cov)
+        q = C.c_double()
+        self._check(self.lib.hgmm_tree_loglik(self.h, T, _ptr(pi), _ptr(mu), _ptr(cov), int(j_begin), int(j_end),
+                                              C.byref(q)))
+        return q.value
 
     def tree_node_complexity(self, T):
         out = np.empty(T)

@@ -1154,3 +1154,203 @@ extern "C" int hgmm_fullcov_estep(hgmm_ctx* c, int J, const double* pi, const do
     if (q_out) *q_out = q;
     return HGMM_OK;
 }
+
+// ==========================================================================================
+// Stand-alone tree steps with the reference's function granularity (the pieces buildGMMTree is
+// made of, callable one at a time):
+//   hgmm_tree_estep   <- gmmTreeEStep()        hgmm_cupy_cpu_working.py:162-191 (arbitrary parentIdx)
+//   hgmm_tree_mstep   <- gmmTreeMStep()        hgmm_cupy_cpu_working.py:193-198 (+ mlEstimator 109-119)
+//   hgmm_tree_loglik  <- logLikelihoodValue()  hgmm_cupy_cpu_working.py:72-85
+// The E-step here takes ANY parent assignment (no partition state), so lanes gather their own
+// parent's children; lanes of a wave that share a parent are combined (leader rounds) before the
+// float64 HBM atomics.  hgmm_tree_build uses the partitioned, atomic-free kernels instead.
+// ==========================================================================================
+namespace hgmm {
+
+__global__ __launch_bounds__(CH) void tree_estep_generic_kernel(const double* __restrict__ xs, int64_t n,
+                                                                int64_t n_pad, const double* __restrict__ prep,
+                                                                const int* __restrict__ parent, int64_t T,
+                                                                double* __restrict__ mom, int* __restrict__ cur) {
+    const int64_t i = (int64_t)blockIdx.x * CH + threadIdx.x;
+    const bool active = i < n;
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+    int64_t j0 = 0;
+    if (active) {
+        x0 = xs[i]; x1 = xs[n_pad + i]; x2 = xs[2 * n_pad + i];
+        j0 = 8 * ((int64_t)parent[i] + 1);
+    }
+    const bool valid = active && j0 >= 0 && j0 + 8 <= T;
+    double g[8];
+    double den = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        g[k] = 0.0;
+        if (valid) {
+            const double* pr = prep + PREP_N * (j0 + k);
+            const double wE = pr[9];
+            if (wE != 0.0) {
+                const double d0 = x0 - pr[6], d1 = x1 - pr[7], d2 = x2 - pr[8];
+                const double q = pr[0] * d0 * d0 + pr[3] * d1 * d1 + pr[5] * d2 * d2 +
+                                 2.0 * (pr[1] * d0 * d1 + pr[2] * d0 * d2 + pr[4] * d1 * d2);
+                g[k] = wE * exp(-0.5 * q);
+            }
+        }
+        den += g[k];
+    }
+    const bool good = den > TREE_EPS;
+    int am = 0;
+    double best = -1.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        g[k] = good ? g[k] / den : 0.0;
+        if (g[k] > best) { best = g[k]; am = k; }
+        if (g[k] < TREE_EPS) g[k] = 0.0;
+    }
+    if (valid) cur[i] = (int)(j0 + am);
+    const double f[NMOM] = {1.0, x0, x1, x2, x0 * x0, x0 * x1, x0 * x2, x1 * x1, x1 * x2, x2 * x2};
+    bool pending = valid;
+    for (int round = 0; round < 8; ++round) {
+        const unsigned long long pm = __ballot(pending);
+        if (pm == 0ull) break;
+        const int leader = __ffsll((long long)pm) - 1;
+        const int64_t pj0 = __shfl(j0, leader);
+        const bool mine = pending && (j0 == pj0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+            for (int m = 0; m < NMOM; ++m) {
+                const double v = wave_sum_f64(mine ? g[k] * f[m] : 0.0);
+                if (lane_id() == leader && v != 0.0) atomic_add_f64(mom + NMOM * (pj0 + k) + m, v);
+            }
+        }
+        if (mine) pending = false;
+    }
+    if (pending) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (g[k] != 0.0)
+#pragma unroll
+                for (int m = 0; m < NMOM; ++m) atomic_add_f64(mom + NMOM * (j0 + k) + m, g[k] * f[m]);
+    }
+}
+
+__global__ void tree_compact_moments_kernel(const double* __restrict__ m0, const double* __restrict__ m1,
+                                            const double* __restrict__ m2, int64_t T, double* __restrict__ mom) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= T) return;
+    double* m = mom + NMOM * j;
+    m[0] = m0[j];
+    m[1] = m1[3 * j]; m[2] = m1[3 * j + 1]; m[3] = m1[3 * j + 2];
+    const double* s = m2 + 9 * j;
+    m[4] = s[0]; m[5] = s[1]; m[6] = s[2]; m[7] = s[4]; m[8] = s[5]; m[9] = s[8];
+}
+
+}  // namespace hgmm
+
+static int tree_upload_nodes(hgmm_ctx* c, int64_t T, const double* pi, const double* mu, const double* cov) {
+    HGMM_TRY(ensure(c, c->t_pi, sizeof(double) * T));
+    HGMM_TRY(ensure(c, c->t_mu, sizeof(double) * 3 * T));
+    HGMM_TRY(ensure(c, c->t_cov, sizeof(double) * 9 * T));
+    HGMM_TRY(ensure(c, c->t_prep, sizeof(double) * PREP_N * T));
+    HGMM_TRY(ensure(c, c->t_mom, sizeof(double) * NMOM * T));
+    HGMM_HIP(c, hipMemcpyAsync(c->t_pi.p, pi, sizeof(double) * T, hipMemcpyHostToDevice, c->stream));
+    HGMM_HIP(c, hipMemcpyAsync(c->t_mu.p, mu, sizeof(double) * 3 * T, hipMemcpyHostToDevice, c->stream));
+    HGMM_HIP(c, hipMemcpyAsync(c->t_cov.p, cov, sizeof(double) * 9 * T, hipMemcpyHostToDevice, c->stream));
+    tree_prep_kernel<<<nblk(T, 256), 256, 0, c->stream>>>(c->t_pi.as<double>(), c->t_mu.as<double>(),
+                                                         c->t_cov.as<double>(), 0, T, c->t_prep.as<double>());
+    HGMM_HIP(c, hipGetLastError());
+    c->tree.nodes_ready = false;       // tables no longer describe a complete L-level tree
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_tree_estep(hgmm_ctx* c, int64_t T, const double* pi, const double* mu, const double* cov,
+                               const int32_t* parent_idx, double* m0_out, double* m1_out, double* m2_out,
+                               int32_t* current_idx_out) {
+    if (!c || !pi || !mu || !cov || !parent_idx) return c ? fail(c, HGMM_ERR_ARG, "NULL argument") : HGMM_ERR_ARG;
+    if (!c->have_f64 || c->n <= 0) return fail(c, HGMM_ERR_STATE, "tree E-step: set points first");
+    if (T < 8) return fail(c, HGMM_ERR_ARG, "node table must hold at least 8 nodes");
+    HGMM_HIP(c, hipSetDevice(c->device));
+    HGMM_TRY(tree_upload_nodes(c, T, pi, mu, cov));
+    HGMM_TRY(ensure(c, c->t_current, sizeof(int) * 2 * c->n_pad));
+    int* par = c->t_current.as<int>();
+    int* cur = par + c->n_pad;
+    HGMM_HIP(c, hipMemcpyAsync(par, parent_idx, sizeof(int) * c->n, hipMemcpyHostToDevice, c->stream));
+    HGMM_HIP(c, hipMemsetAsync(cur, 0, sizeof(int) * c->n, c->stream));
+    double* mom = c->t_mom.as<double>();
+    HGMM_HIP(c, hipMemsetAsync(mom, 0, sizeof(double) * NMOM * T, c->stream));
+    {
+        ProfScope prof(c, HGMM_K_TREE_ESTEP);
+        tree_estep_generic_kernel<<<nblk(c->n, CH), CH, 0, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
+                                                                       c->t_prep.as<double>(), par, T, mom, cur);
+    }
+    HGMM_HIP(c, hipGetLastError());
+    if (c->comm) HGMM_TRY(allreduce_f64_dev(c, mom, (size_t)NMOM * T));
+    HGMM_TRY(ensure(c, c->scratch, sizeof(double) * 13 * T));
+    double* e0 = c->scratch.as<double>();
+    double* e1 = e0 + T;
+    double* e2 = e1 + 3 * T;
+    tree_expand_moments_kernel<<<nblk(T, 256), 256, 0, c->stream>>>(mom, T, e0, e1, e2);
+    HGMM_HIP(c, hipGetLastError());
+    if (m0_out) HGMM_HIP(c, hipMemcpyAsync(m0_out, e0, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
+    if (m1_out) HGMM_HIP(c, hipMemcpyAsync(m1_out, e1, sizeof(double) * 3 * T, hipMemcpyDeviceToHost, c->stream));
+    if (m2_out) HGMM_HIP(c, hipMemcpyAsync(m2_out, e2, sizeof(double) * 9 * T, hipMemcpyDeviceToHost, c->stream));
+    if (current_idx_out) HGMM_HIP(c, hipMemcpyAsync(current_idx_out, cur, sizeof(int) * c->n, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_tree_mstep(hgmm_ctx* c, int64_t T, const double* m0, const double* m1, const double* m2,
+                               int64_t j_begin, int64_t j_end, double n_points, double ld, double* pi_inout,
+                               double* mu_inout, double* cov_inout) {
+    if (!c || !m0 || !m1 || !m2 || !pi_inout || !mu_inout || !cov_inout)
+        return c ? fail(c, HGMM_ERR_ARG, "NULL argument") : HGMM_ERR_ARG;
+    if (j_begin < 0 || j_end > T || j_begin >= j_end) return fail(c, HGMM_ERR_ARG, "bad node range");
+    HGMM_HIP(c, hipSetDevice(c->device));
+    HGMM_TRY(tree_upload_nodes(c, T, pi_inout, mu_inout, cov_inout));
+    HGMM_TRY(ensure(c, c->scratch, sizeof(double) * 13 * T));
+    double* e0 = c->scratch.as<double>();
+    double* e1 = e0 + T;
+    double* e2 = e1 + 3 * T;
+    HGMM_HIP(c, hipMemcpyAsync(e0, m0, sizeof(double) * T, hipMemcpyHostToDevice, c->stream));
+    HGMM_HIP(c, hipMemcpyAsync(e1, m1, sizeof(double) * 3 * T, hipMemcpyHostToDevice, c->stream));
+    HGMM_HIP(c, hipMemcpyAsync(e2, m2, sizeof(double) * 9 * T, hipMemcpyHostToDevice, c->stream));
+    double* mom = c->t_mom.as<double>();
+    tree_compact_moments_kernel<<<nblk(T, 256), 256, 0, c->stream>>>(e0, e1, e2, T, mom);
+    const int n_level = (int)(j_end - j_begin);
+    tree_mstep_kernel<<<nblk(n_level, 256), 256, 0, c->stream>>>(mom + NMOM * j_begin, j_begin, n_level, n_points, ld,
+                                                                 c->t_pi.as<double>(), c->t_mu.as<double>(),
+                                                                 c->t_cov.as<double>());
+    HGMM_HIP(c, hipGetLastError());
+    HGMM_HIP(c, hipMemcpyAsync(pi_inout, c->t_pi.p, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipMemcpyAsync(mu_inout, c->t_mu.p, sizeof(double) * 3 * T, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipMemcpyAsync(cov_inout, c->t_cov.p, sizeof(double) * 9 * T, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_tree_loglik(hgmm_ctx* c, int64_t T, const double* pi, const double* mu, const double* cov,
+                                int64_t j_begin, int64_t j_end, double* q_out) {
+    if (!c || !pi || !mu || !cov || !q_out) return c ? fail(c, HGMM_ERR_ARG, "NULL argument") : HGMM_ERR_ARG;
+    if (!c->have_f64 || c->n <= 0) return fail(c, HGMM_ERR_STATE, "tree log-likelihood: set points first");
+    if (j_begin < 0 || j_end > T || j_begin >= j_end) return fail(c, HGMM_ERR_ARG, "bad node range");
+    HGMM_HIP(c, hipSetDevice(c->device));
+    HGMM_TRY(tree_upload_nodes(c, T, pi, mu, cov));
+    const int pblocks = (int)nblk(c->n, CH);
+    HGMM_TRY(ensure(c, c->t_q, sizeof(double) * (pblocks + 8)));
+    double* block_q = c->t_q.as<double>();
+    double* q_dev = block_q + pblocks;
+    const int n_level = (int)(j_end - j_begin);
+    {
+        ProfScope prof(c, HGMM_K_TREE_LOGLIK);
+        tree_loglik_kernel<<<dim3(pblocks, 1), CH, 0, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
+                                                                  c->t_prep.as<double>(), j_begin, n_level,
+                                                                  (n_level + LL_TILE - 1) / LL_TILE * LL_TILE, nullptr,
+                                                                  block_q);
+    }
+    tree_sum_kernel<<<1, 256, 0, c->stream>>>(block_q, pblocks, q_dev);
+    HGMM_HIP(c, hipGetLastError());
+    if (c->comm) HGMM_TRY(allreduce_f64_dev(c, q_dev, 1));
+    HGMM_HIP(c, hipMemcpyAsync(q_out, q_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    return HGMM_OK;
+}

@@ -71,6 +71,31 @@ def buildGMMTree(points, maxTreeLevel, ls, ld, sig2=0.004, seed=72, init_idx=Non
     return pi, mu, cov
 
 
+def gmmTreeEStep(points, mixingCoeff, mean, covar, parentIdx, ctx: Context | None = None):
+    """One tree E-step for an arbitrary parent assignment (hgmm_cupy_cpu_working.py:162-191).
+    -> (momentsZero[T], momentsOne[T,3], momentsTwo[T,3,3], currentIdx[N])."""
+    ctx = ctx or default_context()
+    ctx.set_points(np.ascontiguousarray(_points(points), dtype=np.float64))
+    return ctx.tree_estep(mixingCoeff, mean, covar, parentIdx)
+
+
+def gmmTreeMStep(momentsZero, momentsOne, momentsTwo, l, mixingCoeff, mean, covar, n_points, ld,
+                 ctx: Context | None = None):
+    """ML update of the nodes of level ``l`` (hgmm_cupy_cpu_working.py:193-198 with the m0 < ld
+    rule of mlEstimator 109-119).  -> new (mixingCoeff, mean, covar)."""
+    ctx = ctx or default_context()
+    return ctx.tree_mstep(momentsZero, momentsOne, momentsTwo, int(level(l)), int(level(l + 1)), n_points, ld,
+                          mixingCoeff, mean, covar)
+
+
+def logLikelihoodValue(mixingCoeff, mean, covar, data, j0, j1, ctx: Context | None = None):
+    """sum_i log max(sum_{j0 <= j < j1, pi_j >= eps} pi_j N(x_i; j), eps)
+    (hgmm_cupy_cpu_working.py:72-85 / the Numba kernel hgmm_gpu.py:107-115 + sum_reduce)."""
+    ctx = ctx or default_context()
+    ctx.set_points(np.ascontiguousarray(_points(data), dtype=np.float64))
+    return ctx.tree_loglik(mixingCoeff, mean, covar, int(j0), int(j1))
+
+
 def fitFullCovGMM(points, n_components, ls=80.0, ld=1.0e-4, sig2=0.00034, init_idx=None, seed=None,
                   max_iters=1000, ctx: Context | None = None, return_trace=False):
     """Flat full-covariance GMM = ONE tree level with branching ``n_components`` (the reference's

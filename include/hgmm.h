@@ -155,6 +155,21 @@ int hgmm_tree_set_target(hgmm_ctx* ctx, const double* xyz, int64_t n);
  * float64 m0 [T], m1 [T,3], m2 [T,3,3].                                                 */
 int hgmm_tree_reg_estep(hgmm_ctx* ctx, const double* rot, const double* t, double scale,
                         double lambda_c, double* m0_out, double* m1_out, double* m2_out);
+/* The steps buildGMMTree is made of, one at a time (reference function granularity).  Node tables
+ * hold T nodes (any T >= 8, need not be a complete tree).
+ * hgmm_tree_estep  <- gmmTreeEStep()       hgmm_cupy_cpu_working.py:162-191: parent_idx[N] arbitrary
+ *                     (-1 = root), returns moments of ALL nodes + currentIdx[N]
+ * hgmm_tree_mstep  <- gmmTreeMStep()       hgmm_cupy_cpu_working.py:193-198: ML update (with the
+ *                     m0 < ld rule) of nodes [j_begin, j_end) in place
+ * hgmm_tree_loglik <- logLikelihoodValue() hgmm_cupy_cpu_working.py:72-85 over nodes [j_begin, j_end) */
+int hgmm_tree_estep(hgmm_ctx* ctx, int64_t T, const double* pi, const double* mu, const double* cov,
+                    const int32_t* parent_idx, double* m0_out, double* m1_out, double* m2_out,
+                    int32_t* current_idx_out);
+int hgmm_tree_mstep(hgmm_ctx* ctx, int64_t T, const double* m0, const double* m1, const double* m2,
+                    int64_t j_begin, int64_t j_end, double n_points, double ld, double* pi_inout,
+                    double* mu_inout, double* cov_inout);
+int hgmm_tree_loglik(hgmm_ctx* ctx, int64_t T, const double* pi, const double* mu, const double* cov,
+                     int64_t j_begin, int64_t j_end, double* q_out);
 /* smallest eigenvalue / trace per node (complexity(), hgmm_cupy_cpu_working.py:87-91) */
 int hgmm_tree_node_complexity(hgmm_ctx* ctx, double* cplx_out);
 

@@ -180,3 +180,39 @@ def test_registration_recovers_known_rotation(ctx, bunny):
     err = np.linalg.norm(moved - target, axis=1).mean()
     print("mean residual after registration: %.3g m" % err)
     assert err < 2e-3
+
+
+def test_standalone_tree_steps_match_oracle(ctx):
+    """gmmTreeEStep / gmmTreeMStep / logLikelihoodValue one at a time == the oracle's steps, driven
+    by hand through two levels like buildGMMTree does."""
+    from hgmm_amd.hgmm.hgmm_gpu import gmmTreeEStep, gmmTreeMStep, logLikelihoodValue
+    g = load_golden("hgmm_build_L2.npz")
+    P = g["points"]
+    L = 2
+    pi, mu, cov = hgmm_tree.init_nodes(P, L, g["init_idx"], float(g["sig2"]))
+    o_pi, o_mu, o_cov = pi.copy(), mu.copy(), cov.copy()
+    parent = -np.ones(len(P), dtype=np.int32)
+    for l in range(L):
+        for _ in range(3):
+            m0, m1, m2, cur = gmmTreeEStep(P, pi, mu, cov, parent, ctx=ctx)
+            o_m0, o_m1, o_m2, o_cur, _ = hgmm_tree.e_step(P, o_pi, o_mu, o_cov, parent)
+            np.testing.assert_allclose(m0, o_m0, rtol=1e-10, atol=1e-13)
+            np.testing.assert_allclose(m1, o_m1, rtol=1e-10, atol=1e-13)
+            np.testing.assert_allclose(m2, o_m2, rtol=1e-10, atol=1e-14)
+            assert np.array_equal(cur, o_cur)
+            pi, mu, cov = gmmTreeMStep(m0, m1, m2, l, pi, mu, cov, len(P), 1e-4, ctx=ctx)
+            hgmm_tree.m_step(o_m0, o_m1, o_m2, l, o_pi, o_mu, o_cov, len(P), 1e-4)
+            np.testing.assert_allclose(pi, o_pi, rtol=1e-10, atol=1e-14)
+            np.testing.assert_allclose(mu, o_mu, rtol=1e-10, atol=1e-13)
+            np.testing.assert_allclose(cov, o_cov, rtol=1e-8, atol=1e-15)
+            q = logLikelihoodValue(pi, mu, cov, P, hgmm_tree.level(l), hgmm_tree.level(l + 1), ctx=ctx)
+            np.testing.assert_allclose(q, hgmm_tree.log_likelihood(P, o_pi, o_mu, o_cov, l), rtol=1e-11)
+        parent = cur.copy()
+    # a scrambled (non-grouped) parent assignment takes the per-lane atomic path
+    rs = np.random.RandomState(0)
+    parent = rs.randint(-1, 8, size=len(P)).astype(np.int32)
+    m0, m1, m2, cur = gmmTreeEStep(P, pi, mu, cov, parent, ctx=ctx)
+    o_m0, o_m1, o_m2, o_cur, _ = hgmm_tree.e_step(P, pi, mu, cov, parent)
+    np.testing.assert_allclose(m0, o_m0, rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(m2, o_m2, rtol=1e-10, atol=1e-14)
+    assert np.array_equal(cur, o_cur)
