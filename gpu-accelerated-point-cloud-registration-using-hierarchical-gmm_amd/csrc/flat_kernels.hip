@@ -34,6 +34,7 @@ constexpr float NEG_INF = -__builtin_huge_valf();
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr int PK_MU = 0, PK_G = 3, PK_C = 6;   // rows of the packed parameter table
+typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int BLOCK = WAVES_PER_BLOCK * 64;
 
@@ -282,23 +283,49 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// materialising E-step, ROWS consecutive rows in flight per wave.  No accumulators live in this
-// kernel (parameters 7K + ROWS*K values), so the independent max / sum reduction chains of
-// several rows can interleave inside ONE wave; that lets the kernel run with few waves per CU,
-// and few, orderly writers is what the HBM write path rewards (tools/fillbench.py: 1024 waves
-// writing a common 1 MiB window reach 6.4 TB/s, 2048 waves 5.3 TB/s, private streams 5.5 TB/s).
-// Row groups are dealt round-robin over the waves so the waves in flight write one window.
+// materialising E-step, ROWS consecutive rows in flight per wave, components paired into float2.
+// No accumulators live in this kernel (parameters 7K + ROWS*K values), so the independent max / sum
+// reduction chains of several rows interleave inside ONE wave; that lets the kernel run with few
+// waves per CU, and few, orderly writers is what the HBM write path rewards (tools/fillbench.py:
+// 1024 waves writing a common 1 MiB window reach 6.4 TB/s, 2048 waves 5.3 TB/s, private streams
+// 5.5 TB/s).  Row groups are dealt round-robin over the waves so the waves in flight write one
+// window.  With one wave per SIMD the kernel's own instruction count matters, hence the pairing
+// (v_pk_add/mul/fma_f32): pairs (4v, 4v+1), (4v+2, 4v+3) of every vector slot, pairs of scalar-tail
+// slots, at most one trailing single.
+// Measured (kbench, N = 1e6, J = 800, same box): single-row kernel, 2 workgroups/CU 0.672 ms;
+// 6 rows unpaired 0.603 ms; paired 4 / 6 / 8 rows 0.546 / 0.561 / 0.604 ms.
 // ------------------------------------------------------------------------------------------
 template <int NV4, int NV1, int ROWS, bool NT>
-__global__ __launch_bounds__(BLOCK) void flat_estep_rows_kernel(
+__global__ __launch_bounds__(BLOCK) void flat_estep_rows_pk_kernel(
     const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int J, int Jpad,
     float* __restrict__ log_resp, float* __restrict__ lpn_out, int32_t* __restrict__ argmax_out,
     double* __restrict__ lpn_partials) {
     using L = Layout<NV4, NV1>;
     constexpr int K = L::K;
+    constexpr int KP = 2 * NV4 + NV1 / 2;          // pairs
+    constexpr bool ODD = (NV1 & 1) != 0;           // trailing single = component K - 1
     const int lane = lane_id();
-    LaneParams<NV4, NV1> P;
-    P.load(pack, Jpad, lane);
+    f2 mu0[KP + 1], mu1[KP + 1], mu2[KP + 1], g0[KP + 1], g1[KP + 1], g2[KP + 1], cc[KP + 1];
+    float mu0s = 0.f, mu1s = 0.f, mu2s = 0.f, g0s = 0.f, g1s = 0.f, g2s = 0.f, cs = NEG_INF;
+    auto ld = [&](int row, int j) { return pack[row * Jpad + j]; };
+#pragma unroll
+    for (int p = 0; p < KP; ++p) {
+        const int ka = 2 * p, kb = 2 * p + 1;
+        const int ja = L::j_of(ka, lane), jb = L::j_of(kb, lane);
+        mu0[p] = f2{ld(PK_MU + 0, ja), ld(PK_MU + 0, jb)};
+        mu1[p] = f2{ld(PK_MU + 1, ja), ld(PK_MU + 1, jb)};
+        mu2[p] = f2{ld(PK_MU + 2, ja), ld(PK_MU + 2, jb)};
+        g0[p] = f2{ld(PK_G + 0, ja), ld(PK_G + 0, jb)};
+        g1[p] = f2{ld(PK_G + 1, ja), ld(PK_G + 1, jb)};
+        g2[p] = f2{ld(PK_G + 2, ja), ld(PK_G + 2, jb)};
+        cc[p] = f2{ld(PK_C, ja), ld(PK_C, jb)};
+    }
+    if (ODD) {
+        const int j = L::j_of(K - 1, lane);
+        mu0s = ld(PK_MU + 0, j); mu1s = ld(PK_MU + 1, j); mu2s = ld(PK_MU + 2, j);
+        g0s = ld(PK_G + 0, j); g1s = ld(PK_G + 1, j); g2s = ld(PK_G + 2, j);
+        cs = ld(PK_C, j);
+    }
     const int64_t nw = (int64_t)gridDim.x * WAVES_PER_BLOCK;
     const int64_t gw = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
     const int64_t ngroups = (n + ROWS - 1) / ROWS;
@@ -317,10 +344,33 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_rows_kernel(
     for (int64_t g = gw; g < ngroups; g += nw) {
         float nx[ROWS][3];
         load_group((g + nw < ngroups) ? g + nw : g, nx);          // prefetch (scalar loads)
-        float wl[ROWS][K];
-        float m[ROWS], s[ROWS], lpn[ROWS];
+        f2 wl[ROWS][KP + 1];
+        float wls[ROWS];
+        float m[ROWS], s[ROWS];
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) m[r] = row_wl2<NV4, NV1>(P, x[r][0], x[r][1], x[r][2], wl[r]);
+        for (int r = 0; r < ROWS; ++r) {
+            const f2 X0 = f2{x[r][0], x[r][0]}, X1 = f2{x[r][1], x[r][1]}, X2 = f2{x[r][2], x[r][2]};
+            float mm = NEG_INF;
+#pragma unroll
+            for (int p = 0; p < KP; ++p) {
+                const f2 d0 = X0 - mu0[p], d1 = X1 - mu1[p], d2 = X2 - mu2[p];
+                f2 a = cc[p] - (d0 * g0[p]) * d0;
+                a = a - (d1 * g1[p]) * d1;
+                a = a - (d2 * g2[p]) * d2;
+                wl[r][p] = a;
+                mm = fmaxf(mm, fmaxf(a.x, a.y));
+            }
+            wls[r] = NEG_INF;
+            if (ODD) {
+                const float d0 = x[r][0] - mu0s, d1 = x[r][1] - mu1s, d2 = x[r][2] - mu2s;
+                float a = fmaf(-(d0 * g0s), d0, cs);
+                a = fmaf(-(d1 * g1s), d1, a);
+                a = fmaf(-(d2 * g2s), d2, a);
+                wls[r] = a;
+                mm = fmaxf(mm, a);
+            }
+            m[r] = mm;
+        }
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             m[r] = wave_reduce(m[r], OpMax());
@@ -328,10 +378,16 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_rows_kernel(
         }
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
-            float acc = 0.f;
+            const f2 M = f2{m[r], m[r]};
+            f2 acc = f2{0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < K; ++k) acc += __builtin_amdgcn_exp2f(wl[r][k] - m[r]);
-            s[r] = acc;
+            for (int p = 0; p < KP; ++p) {
+                const f2 t = wl[r][p] - M;
+                acc += f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+            }
+            float a = acc.x + acc.y;
+            if (ODD) a += __builtin_amdgcn_exp2f(wls[r] - m[r]);
+            s[r] = a;
         }
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) s[r] = wave_reduce(s[r], OpSum());
@@ -341,30 +397,33 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_rows_kernel(
         for (int r = 0; r < ROWS; ++r) {
             const int64_t row = g * ROWS + r;
             float inv_den;
-            lpn[r] = lpn2_from(m[r], s[r], inv_den) * LN2;
+            const float lpn = lpn2_from(m[r], s[r], inv_den) * LN2;
+            const f2 LNV = f2{LN2, LN2}, NL = f2{-lpn, -lpn};
             if (row < n) {                                          // wave-uniform
-                lsum += (double)lpn[r];
+                lsum += (double)lpn;
                 float* out = log_resp + row * (int64_t)J;
 #pragma unroll
                 for (int v = 0; v < NV4; ++v) {
                     const int jb = (v * 64 + lane) * 4;
-                    if (jb < J)
-                        store_f4<NT>(out + jb, fmaf(wl[r][4 * v + 0], LN2, -lpn[r]), fmaf(wl[r][4 * v + 1], LN2, -lpn[r]),
-                                     fmaf(wl[r][4 * v + 2], LN2, -lpn[r]), fmaf(wl[r][4 * v + 3], LN2, -lpn[r]));
+                    const f2 lo = wl[r][2 * v] * LNV + NL, hi = wl[r][2 * v + 1] * LNV + NL;
+                    if (jb < J) store_f4<NT>(out + jb, lo.x, lo.y, hi.x, hi.y);
                 }
 #pragma unroll
                 for (int v = 0; v < NV1; ++v) {
                     const int j = 256 * NV4 + v * 64 + lane;
-                    if (j < J) store_f1<NT>(out + j, fmaf(wl[r][4 * NV4 + v], LN2, -lpn[r]));
+                    const int k = 4 * NV4 + v;
+                    const float val = (ODD && k == K - 1) ? wls[r] : ((k & 1) ? wl[r][k >> 1].y : wl[r][k >> 1].x);
+                    if (j < J) store_f1<NT>(out + j, fmaf(val, LN2, -lpn));
                 }
             }
-            if (lane == r) keep_lpn = lpn[r];
+            if (lane == r) keep_lpn = lpn;
             if (argmax_out) {
                 int best = 0x7fffffff;
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const int j = L::j_of(k, lane);
-                    if (wl[r][k] == m[r] && j < J && j < best) best = j;
+                    const float val = (ODD && k == K - 1) ? wls[r] : ((k & 1) ? wl[r][k >> 1].y : wl[r][k >> 1].x);
+                    if (val == m[r] && j < J && j < best) best = j;
                 }
                 best = wave_reduce_i(best, OpMinI());
                 if (best == 0x7fffffff) best = 0;
@@ -476,6 +535,146 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_kernel(
     float* outp = partials + (size_t)blockIdx.x * FLAT_NSTAT * Jpad;
     for (int idx = threadIdx.x; idx < FLAT_NSTAT * NSLOT * 64; idx += BLOCK) {
         const int st = idx / (NSLOT * 64), j = idx % (NSLOT * 64);
+        outp[st * Jpad + j] = sh[idx];
+    }
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < WAVES_PER_BLOCK; ++i) t += shl[i];
+        lpn_partials[blockIdx.x] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fused E+M with explicitly paired arithmetic: components (2p, 2p+1) of a lane travel together as
+// a float2, so that the centred quadratic form and the moment update issue as v_pk_add/mul/fma_f32
+// (two components per VALU instruction; the fp32 peak of gfx950 is only reachable with packed
+// ops).  Same mathematics, statistics layout and output as flat_fused_kernel.
+// ------------------------------------------------------------------------------------------
+template <int NSLOT>
+__global__ __launch_bounds__(BLOCK) void flat_fused_pk_kernel(
+    const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int J, int Jpad,
+    float* __restrict__ partials, double* __restrict__ lpn_partials,
+    const int* __restrict__ done_flag) {
+    if (done_flag && *done_flag) return;
+    constexpr int K = NSLOT;
+    constexpr int KP = K / 2;          // full pairs
+    constexpr bool ODD = (K & 1) != 0; // one trailing single component
+    const int lane = lane_id();
+    f2 mu0[KP + 1], mu1[KP + 1], mu2[KP + 1], g0[KP + 1], g1[KP + 1], g2[KP + 1], cc[KP + 1];
+    f2 s0[KP + 1], a0[KP + 1], a1[KP + 1], a2[KP + 1], b0[KP + 1], b1[KP + 1], b2[KP + 1];
+    float mu0s = 0.f, mu1s = 0.f, mu2s = 0.f, g0s = 0.f, g1s = 0.f, g2s = 0.f, cs = NEG_INF;
+    float s0s = 0.f, a0s = 0.f, a1s = 0.f, a2s = 0.f, b0s = 0.f, b1s = 0.f, b2s = 0.f;
+#pragma unroll
+    for (int p = 0; p < KP; ++p) {
+        const int ja = (2 * p) * 64 + lane, jb = (2 * p + 1) * 64 + lane;
+        mu0[p] = f2{pack[(PK_MU + 0) * Jpad + ja], pack[(PK_MU + 0) * Jpad + jb]};
+        mu1[p] = f2{pack[(PK_MU + 1) * Jpad + ja], pack[(PK_MU + 1) * Jpad + jb]};
+        mu2[p] = f2{pack[(PK_MU + 2) * Jpad + ja], pack[(PK_MU + 2) * Jpad + jb]};
+        g0[p] = f2{pack[(PK_G + 0) * Jpad + ja], pack[(PK_G + 0) * Jpad + jb]};
+        g1[p] = f2{pack[(PK_G + 1) * Jpad + ja], pack[(PK_G + 1) * Jpad + jb]};
+        g2[p] = f2{pack[(PK_G + 2) * Jpad + ja], pack[(PK_G + 2) * Jpad + jb]};
+        cc[p] = f2{pack[PK_C * Jpad + ja], pack[PK_C * Jpad + jb]};
+        s0[p] = a0[p] = a1[p] = a2[p] = b0[p] = b1[p] = b2[p] = f2{0.f, 0.f};
+    }
+    if (ODD) {
+        const int j = (K - 1) * 64 + lane;
+        mu0s = pack[(PK_MU + 0) * Jpad + j]; mu1s = pack[(PK_MU + 1) * Jpad + j]; mu2s = pack[(PK_MU + 2) * Jpad + j];
+        g0s = pack[(PK_G + 0) * Jpad + j]; g1s = pack[(PK_G + 1) * Jpad + j]; g2s = pack[(PK_G + 2) * Jpad + j];
+        cs = pack[PK_C * Jpad + j];
+    }
+
+    int64_t r0, r1;
+    wave_row_range(n, r0, r1);
+    double lsum = 0.0;
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+    if (r0 < r1) { const float* xp = X + 3 * r0; x0 = xp[0]; x1 = xp[1]; x2 = xp[2]; }
+    for (int64_t row = r0; row < r1; ++row) {
+        const int64_t nrow = (row + 1 < r1) ? row + 1 : row;
+        const float* xn = X + 3 * nrow;
+        const float nx0 = xn[0], nx1 = xn[1], nx2 = xn[2];
+        const f2 X0 = f2{x0, x0}, X1 = f2{x1, x1}, X2 = f2{x2, x2};
+
+        f2 wl[KP + 1];
+        float wls = NEG_INF;
+        float m = NEG_INF;
+#pragma unroll
+        for (int p = 0; p < KP; ++p) {
+            const f2 d0 = X0 - mu0[p], d1 = X1 - mu1[p], d2 = X2 - mu2[p];
+            f2 a = cc[p] - (d0 * g0[p]) * d0;
+            a = a - (d1 * g1[p]) * d1;
+            a = a - (d2 * g2[p]) * d2;
+            wl[p] = a;
+            m = fmaxf(m, fmaxf(a.x, a.y));
+        }
+        if (ODD) {
+            const float d0 = x0 - mu0s, d1 = x1 - mu1s, d2 = x2 - mu2s;
+            float a = fmaf(-(d0 * g0s), d0, cs);
+            a = fmaf(-(d1 * g1s), d1, a);
+            a = fmaf(-(d2 * g2s), d2, a);
+            wls = a;
+            m = fmaxf(m, a);
+        }
+        m = wave_reduce(m, OpMax());
+        if (m == NEG_INF) m = 0.f;
+        const f2 M = f2{m, m};
+        f2 sacc = f2{0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < KP; ++p) {
+            const f2 t = wl[p] - M;
+            wl[p] = f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+            sacc += wl[p];
+        }
+        float s = sacc.x + sacc.y;
+        if (ODD) { wls = __builtin_amdgcn_exp2f(wls - m); s += wls; }
+        s = wave_reduce(s, OpSum());
+        float inv_den;
+        const float lpn2 = lpn2_from(m, s, inv_den);
+        lsum += (double)(lpn2 * LN2);
+        const f2 INV = f2{inv_den, inv_den};
+#pragma unroll
+        for (int p = 0; p < KP; ++p) {
+            const f2 rr = wl[p] * INV;
+            const f2 d0 = X0 - mu0[p], d1 = X1 - mu1[p], d2 = X2 - mu2[p];
+            const f2 rd0 = rr * d0, rd1 = rr * d1, rd2 = rr * d2;
+            s0[p] += rr;
+            a0[p] += rd0; a1[p] += rd1; a2[p] += rd2;
+            b0[p] += rd0 * d0; b1[p] += rd1 * d1; b2[p] += rd2 * d2;
+        }
+        if (ODD) {
+            const float rr = wls * inv_den;
+            const float d0 = x0 - mu0s, d1 = x1 - mu1s, d2 = x2 - mu2s;
+            const float rd0 = rr * d0, rd1 = rr * d1, rd2 = rr * d2;
+            s0s += rr;
+            a0s += rd0; a1s += rd1; a2s += rd2;
+            b0s = fmaf(rd0, d0, b0s); b1s = fmaf(rd1, d1, b1s); b2s = fmaf(rd2, d2, b2s);
+        }
+        x0 = nx0; x1 = nx1; x2 = nx2;
+    }
+
+    __shared__ float sh[FLAT_NSTAT * NSLOT * 64];
+    __shared__ double shl[WAVES_PER_BLOCK];
+    const int w = wave_in_block();
+    constexpr int ST = NSLOT * 64;
+    if (lane == 0) shl[w] = lsum;
+    auto put = [&](int k, bool first, float v0, float v1, float v2, float v3, float v4, float v5, float v6) {
+        float* q = sh + k * 64 + lane;
+        if (first) { q[0 * ST] = v0; q[1 * ST] = v1; q[2 * ST] = v2; q[3 * ST] = v3; q[4 * ST] = v4; q[5 * ST] = v5; q[6 * ST] = v6; }
+        else { q[0 * ST] += v0; q[1 * ST] += v1; q[2 * ST] += v2; q[3 * ST] += v3; q[4 * ST] += v4; q[5 * ST] += v5; q[6 * ST] += v6; }
+    };
+    for (int turn = 0; turn < WAVES_PER_BLOCK; ++turn) {
+        if (w == turn) {
+#pragma unroll
+            for (int p = 0; p < KP; ++p) {
+                put(2 * p, turn == 0, s0[p].x, a0[p].x, a1[p].x, a2[p].x, b0[p].x, b1[p].x, b2[p].x);
+                put(2 * p + 1, turn == 0, s0[p].y, a0[p].y, a1[p].y, a2[p].y, b0[p].y, b1[p].y, b2[p].y);
+            }
+            if (ODD) put(K - 1, turn == 0, s0s, a0s, a1s, a2s, b0s, b1s, b2s);
+        }
+        __syncthreads();
+    }
+    float* outp = partials + (size_t)blockIdx.x * FLAT_NSTAT * Jpad;
+    for (int idx = threadIdx.x; idx < FLAT_NSTAT * ST; idx += BLOCK) {
+        const int st = idx / ST, j = idx % ST;
         outp[st * Jpad + j] = sh[idx];
     }
     if (threadIdx.x == 0) {
@@ -1071,15 +1270,13 @@ static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argma
     pick_layout(f.J, &nv4, &nv1);
     const bool nt = NORMALISE && env_flag("HGMM_ESTEP_NT", true);
     const int rr = env_int("HGMM_ESTEP_RR", 0);
-    // Materialising path: 6 rows in flight per wave, ONE workgroup per CU, row groups dealt
-    // round-robin, non-temporal stores (kbench, N = 1e6, J = 800, same box: single-row kernel at 2
-    // workgroups/CU 0.667 ms; rows = 4 / 6 / 8 at 1 workgroup/CU 0.612 / 0.600 / 0.615 ms).
-    const int rows = (NORMALISE && log_resp) ? env_int("HGMM_ESTEP_ROWS", 6) : 1;
+    // Materialising path: 4 rows in flight per wave, ONE workgroup per CU (see the kernel's header)
+    const int rows = (NORMALISE && log_resp) ? env_int("HGMM_ESTEP_ROWS", 4) : 1;
     ProfScope prof(c, HGMM_K_FLAT_ESTEP);
     if (rows > 1) {
-        const int grid_r = grid_for(c, (c->n + 5) / 6, env_int("HGMM_ESTEP_BPC", 1));
+        const int grid_r = grid_for(c, (c->n + 3) / 4, env_int("HGMM_ESTEP_BPC", 1));
 #define ESTEP_R(A, B)                                                                              \
-    flat_estep_rows_kernel<A, B, 6, true><<<grid_r, BLOCK, 0, c->stream>>>(                         \
+    flat_estep_rows_pk_kernel<A, B, 4, true><<<grid_r, BLOCK, 0, c->stream>>>(                      \
         X, pk, c->n, f.J, f.Jpad, log_resp, lpn, argmax, lp)
         if (nv4 == 3 && nv1 == 1) ESTEP_R(3, 1);
         else if (nv4 == 3 && nv1 == 0) ESTEP_R(3, 0);
@@ -1129,10 +1326,15 @@ static int launch_fused(hgmm_ctx* c, const int* done_flag, int* grid_out, int* v
     //    which tips J = 800 over the 256-register line: 0.66 - 0.78 ms;
     //  * wave-uniform skipping of 64-component slots whose responsibilities are all < 1e-10
     //    never triggers while components are broad: 0 % gain.
+    const bool paired = env_flag("HGMM_FUSED_PK", true);
 #define FUSED_CASE(S)                                                                           \
     do {                                                                                        \
-        flat_fused_kernel<S><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, part, lp,   \
-                                                           done_flag);                         \
+        if (paired)                                                                             \
+            flat_fused_pk_kernel<S><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, part, \
+                                                                  lp, done_flag);              \
+        else                                                                                    \
+            flat_fused_kernel<S><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, part,   \
+                                                               lp, done_flag);                 \
         *valid_j = S * 64;                                                                      \
     } while (0)
     ProfScope prof(c, HGMM_K_FLAT_FUSED);

@@ -57,13 +57,22 @@ def main():
         res[label] = {"ms": ms / n, "GBs": 4 * N * J / (ms / n * 1e-3) / 1e9}
     os.environ["HGMM_ESTEP_NT"] = "1"
     for rnd in range(2):
-        for rows, bpc in (("1", "2"), ("6", "1"), ("6", "2")):
+        for rows, bpc in (("1", "1"), ("4", "1"), ("4", "2")):
             os.environ["HGMM_ESTEP_BPC"] = bpc
             os.environ["HGMM_ESTEP_ROWS"] = rows
-            time_estep("estep rows=%s blocks/CU=%s" % (rows, bpc if rows != "1" else "2"))
+            time_estep("estep rows=%s workgroups/CU=%s" % (rows, bpc if rows != "1" else "2"))
     for k in ("HGMM_ESTEP_ROWS", "HGMM_ESTEP_NT", "HGMM_ESTEP_BPC"):
         os.environ.pop(k)
 
+    for pk_ in ("0", "1", "0", "1"):
+        os.environ["HGMM_FUSED_PK"] = pk_
+        ctx.flat_train(3, 0.0, mu0, cov0, w0, "diag", "W")
+        ctx.profile_reset(); ctx.profile_enable(True)
+        o = ctx.flat_train(args.reps, 0.0, mu0, cov0, w0, "diag", "W")
+        ctx.profile_enable(False)
+        ms, n = ctx.profile_get("flat_fused")
+        print("%-28s %.4f ms  lls[-1]=%.7f" % ("fused paired=%s" % pk_, ms / n, o[4][-1]))
+    os.environ.pop("HGMM_FUSED_PK")
     for bpc in ("1", "2", "3"):
         os.environ["HGMM_FUSED_BPC"] = bpc
         ctx.profile_reset(); ctx.profile_enable(True)
