@@ -220,7 +220,7 @@ def main():
                 traffic = json.load(open(pmc)).get("flat_estep_bytes_per_launch")
             except Exception:
                 traffic = None
-        out["roofline"] = {"kernel": "flat_estep_kernel (materialising E-step, log_resp[N,J] written once)",
+        out["roofline"] = {"kernel": "flat_estep_rows_pk_kernel<3,1,4> (materialising E-step, log_resp[N,J] written once)",
                            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3,
