@@ -474,3 +474,29 @@ def test_large_component_counts_chunked_path(ctx, N, J):
         r = ctx.flat_train(25, 0.05, mu, cov0, w0, "diag", "W")
         o2 = flat_em.train(f64(X), 25, 0.05, f64(mu), f64(cov0), f64(w0), "diag", "W")
         assert len(r[4]) == len(o2[4]) and r[5] == o2[5]
+
+
+@pytest.mark.parametrize("J", [4, 64, 128, 132, 256, 300, 384, 512, 560, 640, 768, 832, 896, 1000, 1024])
+def test_every_lane_layout(ctx, J):
+    """One J per (vector slots, scalar slots) lane layout of the E-step / M-step kernels."""
+    N = 1500 + J
+    rs = np.random.RandomState(J)
+    X = rs.rand(N, 3).astype(np.float32)
+    mu = rs.rand(J, 3).astype(np.float32)
+    inv = (1.0 / np.sqrt(0.005 + 0.05 * rs.rand(J, 3))).astype(np.float32)
+    w = rs.rand(J).astype(np.float32) + 0.01
+    w /= w.sum()
+    lr = check_estep(ctx, X, inv, mu, w, "diag", "W", "layout J=%d" % J)
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    o_w, o_mu, o_cov = flat_em.m_step(f64(X), np.exp(f64(lr)), "diag", "W")
+    ctx.set_points(X)
+    w_m, mu_m, cov_m = ctx.flat_mstep(ctx.to_device(lr).exp(), "diag", "W", centre_hint=mu)
+    live = o_w > 1e-6
+    np.testing.assert_allclose(w_m, o_w, rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(mu_m[live], o_mu[live], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(cov_m[live], o_cov[live], rtol=1e-3, atol=1e-8)
+    inv_t, mu_t, w_t, cov_t, lls, _ = ctx.flat_train(2, 0.0, mu, (0.05 * np.ones((J, 3))).astype(np.float32),
+                                                      (np.ones(J) / J).astype(np.float32), "diag", "W")
+    o = flat_em.train(f64(X), 2, 0.0, f64(mu), 0.05 * np.ones((J, 3)), np.ones(J) / J, "diag", "W")
+    np.testing.assert_allclose(lls, o[4], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(mu_t, o[1], rtol=0, atol=2e-5)
