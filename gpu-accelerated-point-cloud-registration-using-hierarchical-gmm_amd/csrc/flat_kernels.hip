@@ -693,17 +693,27 @@ __global__ __launch_bounds__(BLOCK) void flat_mstep_kernel(
     const float* __restrict__ hint /*[3][Jpad]*/, int64_t n, int J, int Jpad,
     float* __restrict__ partials, int64_t ld, int round_robin) {
     // resp / hint / partials point at this launch's first column; J = valid columns from there,
-    // ld = row stride of resp (the full component count)
+    // ld = row stride of resp (the full component count).  Components are paired into float2 like
+    // in the fused kernel (pairs (4v, 4v+1), (4v+2, 4v+3), pairs of scalar slots, one single).
     using L = Layout<NV4, NV1>;
     constexpr int K = L::K;
+    constexpr int KP = 2 * NV4 + NV1 / 2;
+    constexpr bool ODD = (NV1 & 1) != 0;
     const int lane = lane_id();
-    float c0[K], c1[K], c2[K];
-    float a_s0[K], a_a0[K], a_a1[K], a_a2[K], a_b0[K], a_b1[K], a_b2[K];
+    f2 c0[KP + 1], c1[KP + 1], c2[KP + 1];
+    f2 s0[KP + 1], a0[KP + 1], a1[KP + 1], a2[KP + 1], b0[KP + 1], b1[KP + 1], b2[KP + 1];
+    float c0s = 0.f, c1s = 0.f, c2s = 0.f, s0s = 0.f, a0s = 0.f, a1s = 0.f, a2s = 0.f, b0s = 0.f, b1s = 0.f, b2s = 0.f;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int j = L::j_of(k, lane);
-        c0[k] = hint[0 * Jpad + j]; c1[k] = hint[1 * Jpad + j]; c2[k] = hint[2 * Jpad + j];
-        a_s0[k] = a_a0[k] = a_a1[k] = a_a2[k] = a_b0[k] = a_b1[k] = a_b2[k] = 0.f;
+    for (int p = 0; p < KP; ++p) {
+        const int ja = L::j_of(2 * p, lane), jb = L::j_of(2 * p + 1, lane);
+        c0[p] = f2{hint[0 * Jpad + ja], hint[0 * Jpad + jb]};
+        c1[p] = f2{hint[1 * Jpad + ja], hint[1 * Jpad + jb]};
+        c2[p] = f2{hint[2 * Jpad + ja], hint[2 * Jpad + jb]};
+        s0[p] = a0[p] = a1[p] = a2[p] = b0[p] = b1[p] = b2[p] = f2{0.f, 0.f};
+    }
+    if (ODD) {
+        const int j = L::j_of(K - 1, lane);
+        c0s = hint[0 * Jpad + j]; c1s = hint[1 * Jpad + j]; c2s = hint[2 * Jpad + j];
     }
     // rows of this wave: base + it * stride (contiguous range, or dealt round-robin so that the
     // waves in flight read one contiguous window of the matrix)
@@ -743,16 +753,27 @@ __global__ __launch_bounds__(BLOCK) void flat_mstep_kernel(
         if (it + 1 < cnt) load_row(row + stride, nxt);
         const float* xp = X + 3 * row;
         const float x0 = xp[0], x1 = xp[1], x2 = xp[2];
+        const f2 X0 = f2{x0, x0}, X1 = f2{x1, x1}, X2 = f2{x2, x2}, L2 = f2{LOG2E, LOG2E};
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float r = is_log ? __builtin_amdgcn_exp2f(cur[k] * LOG2E) : cur[k];
-            const float d0 = x0 - c0[k], d1 = x1 - c1[k], d2 = x2 - c2[k];
+        for (int p = 0; p < KP; ++p) {
+            f2 r = f2{cur[2 * p], cur[2 * p + 1]};
+            if (is_log) {
+                const f2 t = r * L2;
+                r = f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+            }
+            const f2 d0 = X0 - c0[p], d1 = X1 - c1[p], d2 = X2 - c2[p];
+            const f2 rd0 = r * d0, rd1 = r * d1, rd2 = r * d2;
+            s0[p] += r;
+            a0[p] += rd0; a1[p] += rd1; a2[p] += rd2;
+            b0[p] += rd0 * d0; b1[p] += rd1 * d1; b2[p] += rd2 * d2;
+        }
+        if (ODD) {
+            const float r = is_log ? __builtin_amdgcn_exp2f(cur[K - 1] * LOG2E) : cur[K - 1];
+            const float d0 = x0 - c0s, d1 = x1 - c1s, d2 = x2 - c2s;
             const float rd0 = r * d0, rd1 = r * d1, rd2 = r * d2;
-            a_s0[k] += r;
-            a_a0[k] += rd0; a_a1[k] += rd1; a_a2[k] += rd2;
-            a_b0[k] = fmaf(rd0, d0, a_b0[k]);
-            a_b1[k] = fmaf(rd1, d1, a_b1[k]);
-            a_b2[k] = fmaf(rd2, d2, a_b2[k]);
+            s0s += r;
+            a0s += rd0; a1s += rd1; a2s += rd2;
+            b0s = fmaf(rd0, d0, b0s); b1s = fmaf(rd1, d1, b1s); b2s = fmaf(rd2, d2, b2s);
         }
 #pragma unroll
         for (int k = 0; k < K; ++k) cur[k] = nxt[k];
@@ -760,20 +781,19 @@ __global__ __launch_bounds__(BLOCK) void flat_mstep_kernel(
     __shared__ float sh[FLAT_NSTAT * L::CAP];
     const int w = wave_in_block();
     constexpr int ST = L::CAP;
+    auto put = [&](int k, bool first, float v0, float v1, float v2, float v3, float v4, float v5, float v6) {
+        float* q = sh + L::j_of(k, lane);
+        if (first) { q[0 * ST] = v0; q[1 * ST] = v1; q[2 * ST] = v2; q[3 * ST] = v3; q[4 * ST] = v4; q[5 * ST] = v5; q[6 * ST] = v6; }
+        else { q[0 * ST] += v0; q[1 * ST] += v1; q[2 * ST] += v2; q[3 * ST] += v3; q[4 * ST] += v4; q[5 * ST] += v5; q[6 * ST] += v6; }
+    };
     for (int turn = 0; turn < WAVES_PER_BLOCK; ++turn) {
         if (w == turn) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const int j = L::j_of(k, lane);
-                float* p = sh + j;
-                if (turn == 0) {
-                    p[0 * ST] = a_s0[k]; p[1 * ST] = a_a0[k]; p[2 * ST] = a_a1[k]; p[3 * ST] = a_a2[k];
-                    p[4 * ST] = a_b0[k]; p[5 * ST] = a_b1[k]; p[6 * ST] = a_b2[k];
-                } else {
-                    p[0 * ST] += a_s0[k]; p[1 * ST] += a_a0[k]; p[2 * ST] += a_a1[k]; p[3 * ST] += a_a2[k];
-                    p[4 * ST] += a_b0[k]; p[5 * ST] += a_b1[k]; p[6 * ST] += a_b2[k];
-                }
+            for (int p = 0; p < KP; ++p) {
+                put(2 * p, turn == 0, s0[p].x, a0[p].x, a1[p].x, a2[p].x, b0[p].x, b1[p].x, b2[p].x);
+                put(2 * p + 1, turn == 0, s0[p].y, a0[p].y, a1[p].y, a2[p].y, b0[p].y, b1[p].y, b2[p].y);
             }
+            if (ODD) put(K - 1, turn == 0, s0s, a0s, a1s, a2s, b0s, b1s, b2s);
         }
         __syncthreads();
     }
