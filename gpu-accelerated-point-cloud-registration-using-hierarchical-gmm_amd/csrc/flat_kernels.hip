@@ -1294,7 +1294,8 @@ static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argma
     const int rows = (NORMALISE && log_resp) ? env_int("HGMM_ESTEP_ROWS", 4) : 1;
     ProfScope prof(c, HGMM_K_FLAT_ESTEP);
     if (rows > 1) {
-        const int grid_r = grid_for(c, (c->n + 3) / 4, env_int("HGMM_ESTEP_BPC", 1));
+        int grid_r = grid_for(c, (c->n + 3) / 4, env_int("HGMM_ESTEP_BPC", 1));
+        if (env_int("HGMM_ESTEP_GRID", 0) > 0) grid_r = std::min(grid_r, env_int("HGMM_ESTEP_GRID", 0));
 #define ESTEP_R(A, B)                                                                              \
     flat_estep_rows_pk_kernel<A, B, 4, true><<<grid_r, BLOCK, 0, c->stream>>>(                      \
         X, pk, c->n, f.J, f.Jpad, log_resp, lpn, argmax, lp)
