@@ -1171,6 +1171,8 @@ static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 static int grid_for(hgmm_ctx* c, int64_t n, int blocks_per_cu) {
     int64_t want = (n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;     // one row per wave at least
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    if (blocks_per_cu > 4) blocks_per_cu = 4;
     int64_t cap = (int64_t)c->cus * blocks_per_cu;
     if (cap > FLAT_MAX_BLOCKS) cap = FLAT_MAX_BLOCKS;
     int64_t g = want < cap ? want : cap;
@@ -1209,7 +1211,8 @@ static int flat_setup(hgmm_ctx* c, int cov_type, int variant, int J) {
     HGMM_TRY(ensure(c, c->f_w, sizeof(float) * Jpad));
     HGMM_TRY(ensure(c, c->f_pack, sizeof(float) * FLAT_NSTAT * Jpad));
     HGMM_TRY(ensure(c, c->f_hint, sizeof(float) * 3 * Jpad));
-    const size_t max_blocks = std::min<size_t>(FLAT_MAX_BLOCKS, (size_t)c->cus * 3);
+    // grid_for() never launches more than min(FLAT_MAX_BLOCKS, 4 workgroups per CU)
+    const size_t max_blocks = std::min<size_t>(FLAT_MAX_BLOCKS, (size_t)c->cus * 4);
     HGMM_TRY(ensure(c, c->f_partials, sizeof(float) * max_blocks * FLAT_NSTAT * Jpad));
     HGMM_TRY(ensure(c, c->f_lpn_partials,
                     sizeof(double) * std::max<size_t>(FLAT_MAX_BLOCKS, (size_t)((c->n + 255) / 256))));
