@@ -216,3 +216,34 @@ def test_standalone_tree_steps_match_oracle(ctx):
     np.testing.assert_allclose(m0, o_m0, rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(m2, o_m2, rtol=1e-10, atol=1e-14)
     assert np.array_equal(cur, o_cur)
+
+
+@pytest.mark.parametrize("L,n,max_iters", [(5, 20000, 2), (6, 30000, 1)])
+def test_deep_trees_properties(ctx, L, n, max_iters):
+    """Deep trees (37448 / 299592 nodes, most of them dead): the partition tables, chunk lists and
+    the 2-D log-likelihood grid at their largest, checked through oracle-free properties and one
+    oracle log-likelihood of the last level (L = 5 only; the oracle is O(N 8^L))."""
+    rs = np.random.RandomState(L)
+    centres = rs.rand(64, 3)
+    P = centres[rs.randint(64, size=n)] + 0.02 * rs.randn(n, 3)
+    T = hgmm_tree.n_total(L)
+    idx = rs.randint(n, size=T)
+    pi, mu, cov, leaf, iters, q = build(ctx, P, L, 1e-30, 1e-4, idx, 0.01, max_iters=max_iters)
+    assert list(iters) == [max_iters] * L and len(q) == L * max_iters
+    assert np.isfinite(q).all() and np.isfinite(pi).all() and np.isfinite(mu).all() and np.isfinite(cov).all()
+    assert leaf.min() >= hgmm_tree.level(L - 1) and leaf.max() < T
+    for l in range(L):
+        s = pi[hgmm_tree.level(l):hgmm_tree.level(l + 1)].sum()
+        assert 0.0 < s <= 1.0 + 1e-9, (l, s)
+    # nearly every point hangs under live ancestors (a node can only die in the M-step that follows
+    # the last assignment of its level, and then only when it holds < ld of the mass)
+    node, alive = leaf.copy(), np.ones(n, dtype=bool)
+    for l in range(L - 1, 0, -1):
+        node = (node - hgmm_tree.level(l)) // 8 + hgmm_tree.level(l - 1)
+        alive &= pi[node] > 0
+    assert node.min() >= 0 and node.max() < 8 and alive.mean() > 0.9
+    if L == 5:
+        o_q = hgmm_tree.log_likelihood(P, pi, mu, cov, L - 1)
+        assert abs(o_q - q[-1]) <= 1e-9 * abs(o_q)
+    again = build(ctx, P, L, 1e-30, 1e-4, idx, 0.01, max_iters=max_iters)
+    assert np.array_equal(again[5], q) and np.array_equal(again[3], leaf)
