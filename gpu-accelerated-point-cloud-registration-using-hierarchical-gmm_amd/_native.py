@@ -17,7 +17,8 @@ LIB_PATH = os.path.join(_HERE, "libhgmm_hip.so")
 COV_TYPES = {"diag": 0, "spherical": 1}
 VARIANTS = {"W": 0, "G": 1}
 KERNEL_IDS = {"flat_estep": 0, "flat_fused": 1, "flat_mstep": 2, "tree_estep": 3,
-              "tree_loglik": 4, "tree_reg": 5, "util_fill": 6, "full_pass": 7, "full_moments": 8}
+              "tree_loglik": 4, "tree_reg": 5, "util_fill": 6, "full_pass": 7, "full_moments": 8,
+              "kmeans_assign": 9, "kmeans_accum": 10}
 
 
 class HgmmError(RuntimeError):
@@ -89,6 +90,9 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_fullcov_fit", [ctx, C.c_int, C.c_double, C.c_double, _vp, C.c_double, C.c_int, _vp, _vp, _vp,
                                        _vp, _vp, C.c_int, C.POINTER(C.c_int)])
         _sig(lib, "hgmm_fullcov_estep", [ctx, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64p])
+        _sig(lib, "hgmm_kmeans_plusplus", [ctx, C.c_int, C.c_int64, _vp, C.c_int, _vp, _vp])
+        _sig(lib, "hgmm_kmeans_step", [ctx, C.c_int, _vp, C.c_int, _vp, _f64p, C.POINTER(C.c_int64)])
+        _sig(lib, "hgmm_kmeans_labels", [ctx, _vp, _vp])
         _sig(lib, "hgmm_comm_unique_id", [_vp])
         _sig(lib, "hgmm_comm_init_rank", [ctx, C.c_int, C.c_int, _vp])
         _sig(lib, "hgmm_comm_destroy", [ctx])
@@ -481,6 +485,37 @@ class Context:
         self._check(self.lib.hgmm_fullcov_estep(self.h, J, _ptr(pi), _ptr(mu), _ptr(cov), _ptr(m0), _ptr(m1), _ptr(m2),
                                                 _ptr(labels), C.byref(q)))
         return m0, m1, m2, labels, q.value
+
+    # -- KMeans initialiser (float64 points) -------------------------------------------------
+    def kmeans_plusplus(self, k, first_id, rand_vals):
+        """Greedy k-means++ seeding on the resident cloud.  rand_vals[(k-1), n_trials] are the
+        host-drawn uniforms of steps 1..k-1 in draw order.  Returns (ids[k] int64, centres[k,3])."""
+        k = int(k)
+        if k > 1:
+            rand_vals = np.ascontiguousarray(rand_vals, dtype=np.float64).reshape(k - 1, -1)
+        n_trials = rand_vals.shape[1] if k > 1 else 1
+        ids = np.empty(k, np.int64)
+        centres = np.empty((k, 3))
+        self._check(self.lib.hgmm_kmeans_plusplus(self.h, k, int(first_id), _ptr(rand_vals) if k > 1 else None,
+                                                  int(n_trials), _ptr(ids), _ptr(centres)))
+        return ids, centres
+
+    def kmeans_step(self, centres, reset_labels=False):
+        """One Lloyd assignment: returns (sums[k,3], counts[k], inertia, n_changed)."""
+        centres = np.ascontiguousarray(centres, dtype=np.float64).reshape(-1, 3)
+        k = len(centres)
+        sums = np.empty((k, 4))
+        inertia = C.c_double()
+        changed = C.c_int64()
+        self._check(self.lib.hgmm_kmeans_step(self.h, k, _ptr(centres), int(bool(reset_labels)), _ptr(sums),
+                                              C.byref(inertia), C.byref(changed)))
+        return sums[:, :3].copy(), sums[:, 3].copy(), inertia.value, changed.value
+
+    def kmeans_labels(self, with_distances=False):
+        labels = np.empty(self.num_points, np.int32)
+        d2 = np.empty(self.num_points) if with_distances else None
+        self._check(self.lib.hgmm_kmeans_labels(self.h, _ptr(labels), _ptr(d2) if with_distances else None))
+        return (labels, d2) if with_distances else labels
 
     # -- multi-GPU ------------------------------------------------------------------------
     @staticmethod

@@ -89,6 +89,18 @@ struct hgmm_ctx {
     hgmm::DevBuf tgt_soa64;                   // double [3][m_pad] registration target
     int64_t tgt_n = 0, tgt_pad = 0;
 
+    // ---- KMeans initialiser (float64, on x_soa64) -----------------------------------
+    hgmm::DevBuf km_closest;                  // double [n_pad] k-means++: min squared distance so far
+    hgmm::DevBuf km_block;                    // double block sums / prefix / candidate partials
+    hgmm::DevBuf km_centres;                  // double [k][3] + padded [k][4]
+    hgmm::DevBuf km_ids;                      // int64 [k] chosen point ids + candidates
+    hgmm::DevBuf km_rand;                     // double [(k-1) * trials] host-drawn uniforms
+    hgmm::DevBuf km_labels;                   // int32 [n_pad]
+    hgmm::DevBuf km_mind2;                    // double [n_pad]
+    hgmm::DevBuf km_partial;                  // double [blocks][k_alloc][4]
+    hgmm::DevBuf km_out;                      // double [4k + 2] sums, inertia, changed (+ scratch)
+    int64_t km_labels_n = -1;
+
     // ---- multi-GPU --------------------------------------------------------------
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;

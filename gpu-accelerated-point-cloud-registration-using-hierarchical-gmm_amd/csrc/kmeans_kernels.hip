@@ -1,0 +1,520 @@
+// KMeans initialiser of the GMMReg flavour for gfx950, float64 arithmetic.
+//
+// The reference seeds its flat EM with scikit-learn on the host
+// (src/python/gmmreg_gpu/gmm_impl.py:18-24: KMeans(k, random_state=1, max_iter=50, n_init=1),
+// called on the caller's float64 Open3D points, gmm.py:79).  scikit-learn's algorithm is
+// k-means++ seeding (greedy, 2 + log k local trials per centre) followed by Lloyd iterations;
+// both are O(N k) per step and dominate a fit at Waymo scale, so they run here on the resident
+// float64 cloud (x_soa64, lanes across points).  The random draws, the stop rule and the
+// empty-cluster relocation stay on the host (kmeans.py), exactly as scikit-learn orders them.
+//
+//   kmpp_first / kmpp_pick / kmpp_eval / kmpp_select / kmpp_update
+//       one seeding step per centre, no host round trip: closest[i] = min_c d2(x_i, c) is kept in
+//       HBM with one partial sum per 256-point block; 'pick' scans the block sums and walks into
+//       the block that holds each random threshold (searchsorted on the running sum), 'eval'
+//       scores the candidates, 'select' takes the one with the lowest potential, 'update' folds
+//       it into closest[].
+//   kmeans_assign_kernel   Lloyd E-step: lanes across points (2 per thread), centres through
+//       wave-uniform scalar loads, strict '<' so the first nearest centre wins.
+//   kmeans_accum_kernel    per-cluster sums: lanes across CENTRES (one wave walks a contiguous
+//       run of points; the point's label is wave-uniform, the owning lane adds into its
+//       registers), waves combined through LDS in fixed order: no atomics, deterministic.
+//   kmeans_reduce_kernel   fixed-order fp64 sum of the workgroup partials -> [k][4] (+ inertia,
+//       + number of changed labels) = the buffer an RCCL all-reduce works on.
+#include "hgmm_ctx.h"
+#include "wave_ops.h"
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace hgmm {
+
+constexpr int KM_BLOCK = 256;
+constexpr int KM_MAX_TRIALS = 16;
+constexpr int KM_ACC_SLOTS = 16;                   // 64-centre slots per accumulate pass
+constexpr int KM_MAX_K = 16384;
+
+struct OpAddI { __device__ __forceinline__ int operator()(int a, int b) const { return a + b; } };
+
+static unsigned km_nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
+
+__device__ __forceinline__ double dist2(double x, double y, double z, double cx, double cy, double cz) {
+    const double dx = x - cx, dy = y - cy, dz = z - cz;
+    return dx * dx + dy * dy + dz * dz;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ double wave_scan_f64(double v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double u = __shfl_up(v, d);
+        if (lane >= d) v += u;
+    }
+    return v;
+}
+
+// sum of one value per thread over a 256-thread workgroup, fixed order; valid in thread 0
+__device__ __forceinline__ double block_sum_256(double v, double* sh /* [4] */) {
+    const double w = wave_sum_f64(v);
+    if (lane_id() == 0) sh[wave_in_block()] = w;
+    __syncthreads();
+    const double t = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    __syncthreads();
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------
+// k-means++ seeding
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(KM_BLOCK) void kmpp_first_kernel(const double* __restrict__ xs, int64_t n,
+                                                              int64_t n_pad, int64_t first,
+                                                              double* __restrict__ closest,
+                                                              double* __restrict__ bsum,
+                                                              double* __restrict__ centres,
+                                                              int64_t* __restrict__ ids) {
+    __shared__ double sh[4];
+    const int64_t i = (int64_t)blockIdx.x * KM_BLOCK + threadIdx.x;
+    const double cx = xs[first], cy = xs[n_pad + first], cz = xs[2 * n_pad + first];
+    double d = 0.0;
+    if (i < n) d = dist2(xs[i], xs[n_pad + i], xs[2 * n_pad + i], cx, cy, cz);
+    closest[i] = d;
+    const double t = block_sum_256(d, sh);
+    if (threadIdx.x == 0) {
+        bsum[blockIdx.x] = t;
+        if (blockIdx.x == 0) {
+            centres[0] = cx; centres[1] = cy; centres[2] = cz;
+            ids[0] = first;
+        }
+    }
+}
+
+// One workgroup of 1024 threads.  Phase 1: inclusive scan of the block sums (-> bprefix, total
+// potential).  Phase 2: wave t locates random threshold t: binary search over the block prefix,
+// then a 256-element running sum inside that block (4 consecutive elements per lane).
+// = np.searchsorted(cumsum(closest), rand * pot) clipped to n - 1   (sklearn _kmeans_plusplus)
+__global__ __launch_bounds__(1024) void kmpp_pick_kernel(const double* __restrict__ closest, int64_t n,
+                                                         const double* __restrict__ bsum, int B,
+                                                         double* __restrict__ bprefix,
+                                                         const double* __restrict__ rand_c, int T,
+                                                         int64_t* __restrict__ cand,
+                                                         double* __restrict__ pot_out) {
+    __shared__ double wave_tot[16];
+    __shared__ double total_sh;
+    const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
+    const int seg = (B + 1023) / 1024;
+    const int b0 = tid * seg, b1 = min(B, b0 + seg);
+    double loc = 0.0;
+    for (int b = b0; b < b1; ++b) loc += bsum[b];
+    const double incl = wave_scan_f64(loc);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    double off = 0.0;
+    for (int w = 0; w < wave; ++w) off += wave_tot[w];
+    double run = off + (incl - loc);
+    for (int b = b0; b < b1; ++b) {
+        run += bsum[b];
+        bprefix[b] = run;
+    }
+    if (tid == 1023) total_sh = off + incl;
+    __threadfence();
+    __syncthreads();
+    const double pot = total_sh;
+    if (tid == 0) pot_out[0] = pot;
+    if (wave >= T) return;
+    const double v = rand_c[wave] * pot;
+    const volatile double* bp = bprefix;                 // written by other waves of this workgroup
+    int lo = 0, hi = B;                                  // first block whose inclusive prefix >= v
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (bp[mid] >= v) hi = mid; else lo = mid + 1;
+    }
+    int64_t found = n - 1;                               // np.clip(..., n - 1)
+    if (lo < B) {
+        const double base = lo > 0 ? bp[lo - 1] : 0.0;
+        const int64_t e0 = (int64_t)lo * KM_BLOCK + 4 * lane;
+        double c[4];
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            s += (e0 + q < n) ? closest[e0 + q] : 0.0;
+            c[q] = s;
+        }
+        const double ex = base + (wave_scan_f64(s) - s);
+        int first_q = 4;
+#pragma unroll
+        for (int q = 3; q >= 0; --q)
+            if (e0 + q < n && ex + c[q] >= v) first_q = q;
+        const unsigned long long hit = __ballot(first_q < 4);
+        if (hit) {
+            const int l = __ffsll((long long)hit) - 1;
+            const int q = __builtin_amdgcn_readlane(first_q, l);
+            found = (int64_t)lo * KM_BLOCK + 4 * l + q;
+        } else {
+            // rounding at the block's end: the threshold falls on the first element after it
+            const int64_t nxt = (int64_t)(lo + 1) * KM_BLOCK;
+            found = nxt < n ? nxt : n - 1;
+        }
+    }
+    if (lane == 0) cand[wave] = found;
+}
+
+__global__ __launch_bounds__(KM_BLOCK) void kmpp_eval_kernel(const double* __restrict__ xs, int64_t n,
+                                                             int64_t n_pad,
+                                                             const double* __restrict__ closest,
+                                                             const int64_t* __restrict__ cand, int T,
+                                                             double* __restrict__ part) {
+    __shared__ double sh[KM_MAX_TRIALS][4];
+    const int64_t i = (int64_t)blockIdx.x * KM_BLOCK + threadIdx.x;
+    const bool live = i < n;
+    const double x = xs[i], y = xs[n_pad + i], z = xs[2 * n_pad + i];
+    const double cl = closest[i];
+    for (int t = 0; t < T; ++t) {
+        const int64_t ci = cand[t];
+        const double d = dist2(x, y, z, xs[ci], xs[n_pad + ci], xs[2 * n_pad + ci]);
+        const double w = wave_sum_f64(live ? fmin(cl, d) : 0.0);
+        if (lane_id() == 0) sh[t][wave_in_block()] = w;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < T)
+        part[(size_t)blockIdx.x * KM_MAX_TRIALS + threadIdx.x] =
+            (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+
+// One workgroup of 1024 threads: wave t adds up candidate t's potential (fixed order); thread 0
+// keeps the first minimum (np.argmin) and records the new centre.
+__global__ __launch_bounds__(1024) void kmpp_select_kernel(const double* __restrict__ xs, int64_t n_pad,
+                                                           const double* __restrict__ part, int B, int T,
+                                                           const int64_t* __restrict__ cand, int c,
+                                                           double* __restrict__ centres,
+                                                           int64_t* __restrict__ ids) {
+    __shared__ double pot[KM_MAX_TRIALS];
+    const int lane = lane_id(), wave = wave_in_block();
+    if (wave < T) {
+        double s = 0.0;
+        for (int b = lane; b < B; b += 64) s += part[(size_t)b * KM_MAX_TRIALS + wave];
+        s = wave_sum_f64(s);
+        if (lane == 0) pot[wave] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int best = 0;
+        for (int t = 1; t < T; ++t)
+            if (pot[t] < pot[best]) best = t;
+        const int64_t ci = cand[best];
+        ids[c] = ci;
+        centres[3 * c + 0] = xs[ci];
+        centres[3 * c + 1] = xs[n_pad + ci];
+        centres[3 * c + 2] = xs[2 * n_pad + ci];
+    }
+}
+
+__global__ __launch_bounds__(KM_BLOCK) void kmpp_update_kernel(const double* __restrict__ xs, int64_t n,
+                                                               int64_t n_pad,
+                                                               const double* __restrict__ centres, int c,
+                                                               double* __restrict__ closest,
+                                                               double* __restrict__ bsum) {
+    __shared__ double sh[4];
+    const int64_t i = (int64_t)blockIdx.x * KM_BLOCK + threadIdx.x;
+    const double cx = centres[3 * c], cy = centres[3 * c + 1], cz = centres[3 * c + 2];
+    double d = 0.0;
+    if (i < n) d = fmin(closest[i], dist2(xs[i], xs[n_pad + i], xs[2 * n_pad + i], cx, cy, cz));
+    closest[i] = d;
+    const double t = block_sum_256(d, sh);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = t;
+}
+
+// ------------------------------------------------------------------------------------------
+// Lloyd iteration
+// ------------------------------------------------------------------------------------------
+// Two points per thread (512 per workgroup); the centre table [k][4] (x y z pad) is read with a
+// wave-uniform index, i.e. through the scalar cache.  ~10 fp64 lane-ops per (point, centre).
+__global__ __launch_bounds__(KM_BLOCK) void kmeans_assign_kernel(
+    const double* __restrict__ xs, int64_t n, int64_t n_pad, const double* __restrict__ c4, int k,
+    int32_t* __restrict__ labels, double* __restrict__ mind2, double* __restrict__ inertia_part,
+    unsigned long long* __restrict__ n_changed) {
+    __shared__ double sh[4];
+    __shared__ int shc[4];
+    const int64_t i0 = (int64_t)blockIdx.x * (2 * KM_BLOCK) + threadIdx.x;
+    const int64_t i1 = i0 + KM_BLOCK;
+    const bool l0 = i0 < n, l1 = i1 < n;
+    const int64_t j0 = l0 ? i0 : 0, j1 = l1 ? i1 : 0;
+    const double x0 = xs[j0], y0 = xs[n_pad + j0], z0 = xs[2 * n_pad + j0];
+    const double x1 = xs[j1], y1 = xs[n_pad + j1], z1 = xs[2 * n_pad + j1];
+    double b0 = INFINITY, b1 = INFINITY;
+    int a0 = 0, a1 = 0;
+#pragma unroll 4
+    for (int j = 0; j < k; ++j) {
+        const double cx = c4[4 * j], cy = c4[4 * j + 1], cz = c4[4 * j + 2];
+        const double d0 = dist2(x0, y0, z0, cx, cy, cz);
+        const double d1 = dist2(x1, y1, z1, cx, cy, cz);
+        if (d0 < b0) { b0 = d0; a0 = j; }
+        if (d1 < b1) { b1 = d1; a1 = j; }
+    }
+    int changed = 0;
+    double in = 0.0;
+    if (l0) {
+        changed += labels[i0] != a0;
+        labels[i0] = a0;
+        mind2[i0] = b0;
+        in += b0;
+    }
+    if (l1) {
+        changed += labels[i1] != a1;
+        labels[i1] = a1;
+        mind2[i1] = b1;
+        in += b1;
+    }
+    const int wc = wave_reduce_i(changed, OpAddI());
+    if (lane_id() == 0) shc[wave_in_block()] = wc;
+    const double t = block_sum_256(in, sh);
+    if (threadIdx.x == 0) {
+        inertia_part[blockIdx.x] = t;
+        const int tc = shc[0] + shc[1] + shc[2] + shc[3];
+        if (tc) atomicAdd(n_changed, (unsigned long long)tc);
+    }
+}
+
+// One wave owns a contiguous run of points and NSLOT * 64 centres starting at slot0 * 64; lane l
+// holds the sums of centres slot * 64 + l.  The 64 points of a step are loaded coalesced and then
+// visited one by one (label and coordinates broadcast with v_readlane): the label is wave-uniform,
+// so 'which register' is a scalar branch and 'which lane' an exec mask -- no atomics.
+template <int NSLOT>
+__global__ __launch_bounds__(KM_BLOCK) void kmeans_accum_kernel(const double* __restrict__ xs, int64_t n,
+                                                                int64_t n_pad,
+                                                                const int32_t* __restrict__ labels,
+                                                                int slot0, int k_alloc,
+                                                                double* __restrict__ partial) {
+    __shared__ double sh[4][64][4];
+    const int lane = lane_id(), wave = wave_in_block();
+    double ax[NSLOT], ay[NSLOT], az[NSLOT], ac[NSLOT];
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) ax[s] = ay[s] = az[s] = ac[s] = 0.0;
+    const int64_t waves = (int64_t)gridDim.x * 4;
+    const int64_t per = ((n + waves - 1) / waves + 63) / 64 * 64;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t begin = gw * per;
+    const int64_t end = begin + per < n ? begin + per : n;
+    for (int64_t base = begin; base < end; base += 64) {
+        const int64_t i = base + lane;
+        const bool ok = i < end;
+        const int64_t ii = ok ? i : 0;
+        const int rel = ok ? labels[ii] - slot0 * 64 : -1;
+        const double x = xs[ii], y = xs[n_pad + ii], z = xs[2 * n_pad + ii];
+        const int cnt = (int)(end - base < 64 ? end - base : 64);
+        for (int t = 0; t < cnt; ++t) {
+            const int r = __builtin_amdgcn_readlane(rel, t);
+            if (r < 0 || r >= NSLOT * 64) continue;
+            const double px = readlane_f64(x, t), py = readlane_f64(y, t), pz = readlane_f64(z, t);
+            const int s = r >> 6;
+            if (lane == (r & 63)) {
+#pragma unroll
+                for (int u = 0; u < NSLOT; ++u)
+                    if (u == s) { ax[u] += px; ay[u] += py; az[u] += pz; ac[u] += 1.0; }
+            }
+        }
+    }
+    double* out = partial + (size_t)blockIdx.x * k_alloc * 4;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        sh[wave][lane][0] = ax[s];
+        sh[wave][lane][1] = ay[s];
+        sh[wave][lane][2] = az[s];
+        sh[wave][lane][3] = ac[s];
+        __syncthreads();
+        const int l = threadIdx.x >> 2, f = threadIdx.x & 3;
+        out[((size_t)(slot0 + s) * 64 + l) * 4 + f] = (sh[0][l][f] + sh[1][l][f]) + (sh[2][l][f] + sh[3][l][f]);
+        __syncthreads();
+    }
+}
+
+// out[e] = sum over workgroups of partial[b][e], e < 4 k: 32 entries x 8 block slices per
+// workgroup, fixed order.  Workgroup 0 also adds up the inertia partials and appends
+// (inertia, n_changed) behind the sums.
+__global__ __launch_bounds__(KM_BLOCK) void kmeans_reduce_kernel(const double* __restrict__ partial, int nb,
+                                                                 int k_alloc, int k,
+                                                                 const double* __restrict__ inertia_part,
+                                                                 int nib,
+                                                                 const unsigned long long* __restrict__ n_changed,
+                                                                 double* __restrict__ out) {
+    __shared__ double sh[8][32];
+    __shared__ double shi[4];
+    const int e_loc = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + e_loc;
+    double s = 0.0;
+    if (e < 4 * k) {
+        const int per = (nb + 7) / 8;
+        const int b0 = slice * per, b1 = min(nb, b0 + per);
+        for (int b = b0; b < b1; ++b) s += partial[(size_t)b * k_alloc * 4 + e];
+    }
+    sh[slice][e_loc] = s;
+    __syncthreads();
+    if (slice == 0 && e < 4 * k) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += sh[q][e_loc];
+        out[e] = t;
+    }
+    if (blockIdx.x == 0) {
+        double v = 0.0;
+        for (int b = threadIdx.x; b < nib; b += KM_BLOCK) v += inertia_part[b];
+        const double t = block_sum_256(v, shi);
+        if (threadIdx.x == 0) {
+            out[4 * k] = t;
+            out[4 * k + 1] = (double)n_changed[0];
+        }
+    }
+}
+
+__global__ void kmeans_pad_centres_kernel(const double* __restrict__ c3, int k, double* __restrict__ c4) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= k) return;
+    c4[4 * j] = c3[3 * j];
+    c4[4 * j + 1] = c3[3 * j + 1];
+    c4[4 * j + 2] = c3[3 * j + 2];
+    c4[4 * j + 3] = 0.0;
+}
+
+__global__ void kmeans_reset_labels_kernel(int32_t* __restrict__ labels, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) labels[i] = -1;
+}
+
+static int km_check(hgmm_ctx* c, int k) {
+    if (!c->have_f64 || c->n <= 0) return fail(c, HGMM_ERR_STATE, "kmeans: set points first");
+    if (k < 1 || k > KM_MAX_K) return fail(c, HGMM_ERR_ARG, "kmeans: k = %d outside 1..%d", k, KM_MAX_K);
+    if (c->n > 0x7fffffff - 1024) return fail(c, HGMM_ERR_ARG, "too many points for 32-bit indices");
+    return HGMM_OK;
+}
+
+}  // namespace hgmm
+
+using namespace hgmm;
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const double* rand_vals,
+                                    int n_trials, int64_t* ids_out, double* centers_out) {
+    if (!c) return HGMM_ERR_ARG;
+    HGMM_TRY(km_check(c, k));
+    if (k > c->n) return fail(c, HGMM_ERR_ARG, "kmeans++: k = %d exceeds the %lld points", k, (long long)c->n);
+    if (n_trials < 1 || n_trials > KM_MAX_TRIALS)
+        return fail(c, HGMM_ERR_ARG, "kmeans++: n_trials = %d outside 1..%d", n_trials, KM_MAX_TRIALS);
+    if (first_id < 0 || first_id >= c->n) return fail(c, HGMM_ERR_ARG, "kmeans++: first_id out of range");
+    if (k > 1 && !rand_vals) return fail(c, HGMM_ERR_ARG, "kmeans++: rand_vals is NULL");
+    HGMM_HIP(c, hipSetDevice(c->device));
+    const int64_t n = c->n, n_pad = c->n_pad;
+    const int B = (int)km_nblk(n, KM_BLOCK);
+    HGMM_TRY(ensure(c, c->km_closest, sizeof(double) * n_pad));
+    HGMM_TRY(ensure(c, c->km_block, sizeof(double) * ((size_t)2 * B + (size_t)B * KM_MAX_TRIALS + 8)));
+    HGMM_TRY(ensure(c, c->km_centres, sizeof(double) * 7 * (size_t)k));
+    HGMM_TRY(ensure(c, c->km_ids, sizeof(int64_t) * ((size_t)k + KM_MAX_TRIALS)));
+    HGMM_TRY(ensure(c, c->km_rand, sizeof(double) * (size_t)std::max(1, (k - 1) * n_trials)));
+    const double* xs = c->x_soa64.as<double>();
+    double* closest = c->km_closest.as<double>();
+    double* bsum = c->km_block.as<double>();
+    double* bprefix = bsum + B;
+    double* part = bprefix + B;
+    double* pot = part + (size_t)B * KM_MAX_TRIALS;
+    double* centres = c->km_centres.as<double>();
+    int64_t* ids = c->km_ids.as<int64_t>();
+    int64_t* cand = ids + k;
+    double* rand_dev = c->km_rand.as<double>();
+    if (k > 1)
+        HGMM_HIP(c, hipMemcpyAsync(rand_dev, rand_vals, sizeof(double) * (size_t)(k - 1) * n_trials,
+                                   hipMemcpyHostToDevice, c->stream));
+    kmpp_first_kernel<<<B, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, first_id, closest, bsum, centres, ids);
+    for (int j = 1; j < k; ++j) {
+        kmpp_pick_kernel<<<1, 1024, 0, c->stream>>>(closest, n, bsum, B, bprefix,
+                                                    rand_dev + (size_t)(j - 1) * n_trials, n_trials, cand, pot);
+        kmpp_eval_kernel<<<B, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, closest, cand, n_trials, part);
+        kmpp_select_kernel<<<1, 1024, 0, c->stream>>>(xs, n_pad, part, B, n_trials, cand, j, centres, ids);
+        kmpp_update_kernel<<<B, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, centres, j, closest, bsum);
+    }
+    HGMM_HIP(c, hipGetLastError());
+    if (ids_out) HGMM_HIP(c, hipMemcpyAsync(ids_out, ids, sizeof(int64_t) * k, hipMemcpyDeviceToHost, c->stream));
+    if (centers_out)
+        HGMM_HIP(c, hipMemcpyAsync(centers_out, centres, sizeof(double) * 3 * k, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_kmeans_step(hgmm_ctx* c, int k, const double* centers, int reset_labels,
+                                double* sums_out, double* inertia_out, int64_t* n_changed_out) {
+    if (!c) return HGMM_ERR_ARG;
+    HGMM_TRY(km_check(c, k));
+    if (!centers) return fail(c, HGMM_ERR_ARG, "kmeans: centers is NULL");
+    HGMM_HIP(c, hipSetDevice(c->device));
+    const int64_t n = c->n, n_pad = c->n_pad;
+    const int nslot = k <= 256 ? 4 : KM_ACC_SLOTS;
+    const int k_alloc = (k + 64 * nslot - 1) / (64 * nslot) * (64 * nslot);
+    const int nb_assign = (int)km_nblk(n, 2 * KM_BLOCK);
+    const int nb_acc = (int)std::min<int64_t>(2 * (int64_t)c->cus, km_nblk(n, KM_BLOCK));
+    HGMM_TRY(ensure(c, c->km_labels, sizeof(int32_t) * n_pad));
+    HGMM_TRY(ensure(c, c->km_mind2, sizeof(double) * n_pad));
+    HGMM_TRY(ensure(c, c->km_centres, sizeof(double) * 7 * (size_t)k));
+    HGMM_TRY(ensure(c, c->km_partial, sizeof(double) * 4 * (size_t)k_alloc * nb_acc));
+    HGMM_TRY(ensure(c, c->km_out, sizeof(double) * (4 * (size_t)k + 2) + sizeof(double) * nb_assign + 16));
+    const double* xs = c->x_soa64.as<double>();
+    int32_t* labels = c->km_labels.as<int32_t>();
+    if (reset_labels || c->km_labels_n != n) {
+        kmeans_reset_labels_kernel<<<km_nblk(n, 256), 256, 0, c->stream>>>(labels, n);
+        c->km_labels_n = n;
+    }
+    double* c3 = c->km_centres.as<double>();
+    double* c4 = c3 + 3 * (size_t)k;
+    double* out = c->km_out.as<double>();
+    unsigned long long* changed = reinterpret_cast<unsigned long long*>(out + 4 * (size_t)k + 2);
+    double* inertia_part = out + 4 * (size_t)k + 3;
+    HGMM_HIP(c, hipMemcpyAsync(c3, centers, sizeof(double) * 3 * k, hipMemcpyHostToDevice, c->stream));
+    kmeans_pad_centres_kernel<<<km_nblk(k, 256), 256, 0, c->stream>>>(c3, k, c4);
+    HGMM_HIP(c, hipMemsetAsync(changed, 0, sizeof(unsigned long long), c->stream));
+    {
+        ProfScope prof(c, HGMM_K_KMEANS_ASSIGN);
+        kmeans_assign_kernel<<<nb_assign, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, c4, k, labels,
+                                                                    c->km_mind2.as<double>(), inertia_part, changed);
+    }
+    {
+        ProfScope prof(c, HGMM_K_KMEANS_ACCUM);
+        for (int slot0 = 0; slot0 * 64 < k; slot0 += nslot) {
+            if (nslot == 4)
+                kmeans_accum_kernel<4><<<nb_acc, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, labels, slot0, k_alloc,
+                                                                            c->km_partial.as<double>());
+            else
+                kmeans_accum_kernel<KM_ACC_SLOTS><<<nb_acc, KM_BLOCK, 0, c->stream>>>(
+                    xs, n, n_pad, labels, slot0, k_alloc, c->km_partial.as<double>());
+        }
+    }
+    kmeans_reduce_kernel<<<km_nblk(4 * (int64_t)k, 32), KM_BLOCK, 0, c->stream>>>(
+        c->km_partial.as<double>(), nb_acc, k_alloc, k, inertia_part, nb_assign, changed, out);
+    HGMM_HIP(c, hipGetLastError());
+    if (c->comm) HGMM_TRY(allreduce_f64_dev(c, out, 4 * (size_t)k + 2));
+    std::vector<double> tail(2);
+    if (sums_out) HGMM_HIP(c, hipMemcpyAsync(sums_out, out, sizeof(double) * 4 * k, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipMemcpyAsync(tail.data(), out + 4 * (size_t)k, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    if (inertia_out) *inertia_out = tail[0];
+    if (n_changed_out) *n_changed_out = (int64_t)tail[1];
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_kmeans_labels(hgmm_ctx* c, int32_t* labels_out, double* min_dist2_out) {
+    if (!c) return HGMM_ERR_ARG;
+    if (c->km_labels_n != c->n || c->n <= 0 || !c->km_labels.p)
+        return fail(c, HGMM_ERR_STATE, "kmeans: no assignment on the device (call hgmm_kmeans_step first)");
+    if (labels_out)
+        HGMM_HIP(c, hipMemcpyAsync(labels_out, c->km_labels.p, sizeof(int32_t) * c->n, hipMemcpyDeviceToHost, c->stream));
+    if (min_dist2_out)
+        HGMM_HIP(c, hipMemcpyAsync(min_dist2_out, c->km_mind2.p, sizeof(double) * c->n, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    return HGMM_OK;
+}

@@ -11,10 +11,11 @@ VARIANT = "G"
 
 def init_gmm_params(X, k):
     """KMeans(k, random_state=1, max_iter=50, n_init=1) centres + uniform weights
-    (reference gmm_impl.py:18-24).  Host-side, scikit-learn like the reference."""
-    from sklearn.cluster import KMeans
-    kmeans = KMeans(n_clusters=k, random_state=1, max_iter=50, n_init=1).fit(np.asarray(X))
-    return kmeans.cluster_centers_, np.ones((k)) / k
+    (reference gmm_impl.py:18-24).  The reference calls scikit-learn on the host; here the same
+    algorithm (same random stream, same seeds, same stop rule) runs on the device
+    (``hgmm_amd.kmeans``, ``csrc/kmeans_kernels.hip``)."""
+    from ..kmeans import kmeans_centres
+    return kmeans_centres(X, k, random_state=1, max_iter=50), np.ones((k)) / k
 
 
 def estimate_log_prob(X, inv_cov, means):

@@ -1,0 +1,133 @@
+"""KMeans initialiser of the GMMReg flavour on the device.
+
+The reference seeds its flat EM with ``sklearn.cluster.KMeans(n_clusters=k, random_state=1,
+max_iter=50, n_init=1).fit(X).cluster_centers_`` (``src/python/gmmreg_gpu/gmm_impl.py:18-24``).
+``KMeans`` below takes the same constructor arguments, exposes the attributes scikit-learn's
+estimator leaves behind (``cluster_centers_``, ``labels_``, ``inertia_``, ``n_iter_``) and
+follows scikit-learn 1.7's ``KMeans.fit`` step by step; the two O(N k) parts -- greedy k-means++
+seeding and the Lloyd assignment / per-cluster sums -- run in HIP kernels
+(``csrc/kmeans_kernels.hip``) on the float64 cloud, everything that touches only k x 3 numbers
+(random draws, centre update, stop rule, empty-cluster relocation) stays here in NumPy:
+
+* X is centred by its mean first, the mean is added back to the centres at the end;
+* ``tol`` is scaled by the mean per-axis variance of X;
+* the random stream is NumPy's ``RandomState(random_state)`` consumed in scikit-learn's order
+  (one ``choice`` for the first centre, then ``2 + int(log k)`` uniforms per centre), so the same
+  points are chosen as seeds;
+* Lloyd: first nearest centre, centres = sum * (1 / count), empty clusters take the points
+  farthest from their centre (``np.argpartition`` order, like scikit-learn), stop on unchanged
+  labels or summed squared centre shift <= tol, one more assignment if the stop was not strict.
+
+Arithmetic is float64 whatever the input dtype (scikit-learn keeps float32 input in float32).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ._native import Context, default_context
+
+
+def _random_state(seed):
+    if isinstance(seed, np.random.RandomState):
+        return seed
+    if seed is None:
+        return np.random.mtrand._rand
+    return np.random.RandomState(seed)
+
+
+class KMeans:
+    def __init__(self, n_clusters=8, random_state=None, max_iter=300, n_init=1, tol=1e-4,
+                 init="k-means++", ctx: Context | None = None):
+        if n_init != 1:
+            raise ValueError("only n_init=1 (what the reference uses) is supported")
+        if isinstance(init, str) and init != "k-means++":
+            raise ValueError("init must be 'k-means++' or an array of centres")
+        self.init = init
+        self.n_clusters = int(n_clusters)
+        self.random_state = random_state
+        self.max_iter = int(max_iter)
+        self.n_init = 1
+        self.tol = float(tol)
+        self._ctx = ctx
+
+    # -- seeding -------------------------------------------------------------------------
+    def _seed(self, ctx, n, rs):
+        k = self.n_clusters
+        trials = 2 + int(np.log(k))
+        w = np.ones(n)
+        first = rs.choice(n, p=w / w.sum())
+        rand = rs.uniform(size=(max(k - 1, 0), trials))       # == k-1 successive draws of `trials`
+        ids, centres = ctx.kmeans_plusplus(k, first, rand)
+        return ids, centres
+
+    # -- scikit-learn's _relocate_empty_clusters_dense ---------------------------------------
+    @staticmethod
+    def _relocate_empty(ctx, Xc, sums, counts):
+        empty = np.where(counts == 0)[0]
+        if len(empty) == 0:
+            return
+        labels, dist = ctx.kmeans_labels(with_distances=True)
+        far = np.argpartition(dist, -len(empty))[:-len(empty) - 1:-1]
+        for new_id, far_idx in zip(empty, far):
+            old_id = labels[far_idx]
+            sums[old_id] -= Xc[far_idx]
+            sums[new_id] = Xc[far_idx]
+            counts[new_id] = 1.0
+            counts[old_id] -= 1.0
+
+    def fit(self, X):
+        X = np.asarray(X.points if hasattr(X, "points") else X, dtype=np.float64)
+        if X.ndim != 2 or X.shape[1] != 3:
+            raise ValueError("expected an [N,3] array, got %s" % (X.shape,))
+        n, k = len(X), self.n_clusters
+        if n < k:
+            raise ValueError("n_samples=%d should be >= n_clusters=%d." % (n, k))
+        ctx = self._ctx or default_context()
+        tol_abs = 0.0 if self.tol == 0 else float(np.mean(np.var(X, axis=0)) * self.tol)
+        mean = X.mean(axis=0)
+        Xc = X - mean
+        ctx.set_points(Xc)
+        ctx._points_owner = None                      # supersedes any DevicePoints on this context
+        if isinstance(self.init, str):
+            rs = _random_state(self.random_state)
+            self.init_indices_, centres = self._seed(ctx, n, rs)
+        else:
+            centres = np.array(self.init, dtype=np.float64).reshape(k, 3) - mean
+            self.init_indices_ = None
+
+        strict = False
+        n_iter = 0
+        inertia = 0.0
+        for i in range(self.max_iter):
+            sums, counts, inertia, changed = ctx.kmeans_step(centres, reset_labels=(i == 0))
+            self._relocate_empty(ctx, Xc, sums, counts)
+            new = sums
+            pos = counts > 0
+            new[pos] *= (1.0 / counts[pos])[:, None]
+            shift_tot = float((np.sqrt(((new - centres) ** 2).sum(axis=1)) ** 2).sum())
+            centres = new
+            n_iter = i + 1
+            if changed == 0:
+                strict = True
+                break
+            if shift_tot <= tol_abs:
+                break
+        if not strict:
+            _, _, inertia, _ = ctx.kmeans_step(centres)
+        self.labels_ = ctx.kmeans_labels()
+        if strict:
+            # labels are those of the last assignment; inertia is measured against the final centres
+            inertia = float(((Xc - centres[self.labels_]) ** 2).sum())
+        self.inertia_ = float(inertia)
+        self.n_iter_ = n_iter
+        self.cluster_centers_ = centres + mean
+        return self
+
+    def fit_predict(self, X):
+        return self.fit(X).labels_
+
+
+def kmeans_centres(X, k, random_state=1, max_iter=50, ctx: Context | None = None):
+    """``KMeans(n_clusters=k, random_state=1, max_iter=50, n_init=1).fit(X).cluster_centers_``
+    (gmmreg_gpu/gmm_impl.py:20-21) on the device."""
+    return KMeans(n_clusters=k, random_state=random_state, max_iter=max_iter, n_init=1, ctx=ctx).fit(X).cluster_centers_

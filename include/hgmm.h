@@ -58,7 +58,9 @@ enum hgmm_kernel_id {
     HGMM_K_UTIL_FILL = 6,     /* hgmm_util_fill_f32 (HBM write-ceiling probe) */
     HGMM_K_FULL_PASS = 7,     /* full-cov flat EM: denominators + arg-max + log-likelihood */
     HGMM_K_FULL_MOMENTS = 8,  /* full-cov flat EM: fp64-MFMA sufficient statistics */
-    HGMM_K_COUNT = 9
+    HGMM_K_KMEANS_ASSIGN = 9, /* KMeans initialiser: nearest-centre assignment */
+    HGMM_K_KMEANS_ACCUM = 10, /* KMeans initialiser: per-cluster sums */
+    HGMM_K_COUNT = 11
 };
 
 /* ---- lifecycle ------------------------------------------------------------------ */
@@ -188,6 +190,29 @@ int hgmm_fullcov_fit(hgmm_ctx* ctx, int J, double ls, double ld, const double* i
 int hgmm_fullcov_estep(hgmm_ctx* ctx, int J, const double* pi, const double* mu, const double* cov,
                        double* m0_out, double* m1_out, double* m2_out, int32_t* labels_out,
                        double* q_out);
+
+/* ---- KMeans initialiser (float64, on the resident cloud) -------------------------------
+ * Replaces the scikit-learn call the GMMReg flavour seeds its EM with
+ * (gmmreg_gpu/gmm_impl.py:18-24: KMeans(n_clusters=k, random_state=1, max_iter=50, n_init=1).fit(X),
+ * X = the caller's float64 points, gmm.py:79).  The host side (kmeans.py) draws the random
+ * numbers, applies the stop rule and relocates empty clusters exactly as scikit-learn does; the
+ * two O(N k) parts run on the device:
+ * hgmm_kmeans_plusplus  greedy k-means++ seeding.  first_id = the first centre (host-drawn),
+ *                       rand_vals[(k-1) * n_trials] = the uniforms of every later step in draw
+ *                       order; per step: candidates = searchsorted(cumsum(closest), rand * pot),
+ *                       keep the candidate with the lowest potential (first minimum).
+ *                       ids_out[k] = chosen point indices, centers_out[k,3] their coordinates.
+ * hgmm_kmeans_step      one Lloyd assignment with the given centres: nearest centre per point
+ *                       (first minimum), sums_out[k,4] = (sum x, sum y, sum z, count) per cluster,
+ *                       inertia = sum of squared distances to the nearest centre, n_changed =
+ *                       labels that differ from the previous step's (reset_labels != 0: from -1).
+ *                       With a communicator attached the three results are all-reduced.
+ * hgmm_kmeans_labels    labels[n] / squared distance to the assigned centre of the last step. */
+int hgmm_kmeans_plusplus(hgmm_ctx* ctx, int k, int64_t first_id, const double* rand_vals, int n_trials,
+                         int64_t* ids_out, double* centers_out);
+int hgmm_kmeans_step(hgmm_ctx* ctx, int k, const double* centers, int reset_labels, double* sums_out,
+                     double* inertia_out, int64_t* n_changed_out);
+int hgmm_kmeans_labels(hgmm_ctx* ctx, int32_t* labels_out, double* min_dist2_out);
 
 /* ---- multi-GPU: one context per rank, RCCL over xGMI --------------------------------
  * New functionality (the reference is single-GPU).  With a communicator attached,

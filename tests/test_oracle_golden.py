@@ -112,3 +112,50 @@ def test_fullcov_flat_matches_reference():
         np.testing.assert_allclose(pi, g[tag + "pi"], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(mu, g[tag + "mu"], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(cov, g[tag + "cov"], rtol=1e-7, atol=1e-13)
+
+
+# ---------------------------------------------------------------------------------------------
+# KMeans initialiser (gmmreg_gpu/gmm_impl.py:18-24 -> scikit-learn)
+# ---------------------------------------------------------------------------------------------
+def _kmeans_case(g, name, bunny):
+    X = bunny[::10].astype(np.float64) if name == "bunny" else g[name + "_X"]
+    return X, int(g[name + "_k"])
+
+
+@pytest.mark.parametrize("name", ["uniform", "blobs", "bunny"])
+def test_kmeans_oracle_matches_reference_init(name, bunny):
+    """oracle/kmeans.py against the outputs of the reference's own init_gmm_params (same seeds,
+    same labels, same iteration count; centres to thread-order noise)."""
+    from oracle import kmeans as okm
+    g = load_golden("kmeans_init.npz")
+    X, k = _kmeans_case(g, name, bunny)
+    o = okm.fit(X, k, random_state=1, max_iter=50)
+    assert np.array_equal(o["init_indices"], g[name + "_init_indices"])
+    assert o["n_iter_"] == int(g[name + "_n_iter"])
+    assert np.array_equal(o["labels_"], g[name + "_labels"])
+    np.testing.assert_allclose(o["cluster_centers_"], g[name + "_centres"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(o["inertia_"], float(g[name + "_inertia"]), rtol=1e-12)
+    assert np.array_equal(g[name + "_weights"], np.ones(k) / k)
+
+
+def test_kmeans_oracle_relocates_empty_clusters_like_sklearn():
+    from oracle import kmeans as okm
+    g = load_golden("kmeans_init.npz")
+    X, init = g["reloc_X"], g["reloc_init"]
+    mean = X.mean(axis=0)
+    labels, inertia, centres, n_iter = okm.lloyd(X - mean, init - mean, 50, float(np.mean(np.var(X, axis=0)) * 1e-4))
+    assert n_iter == int(g["reloc_n_iter"]) and np.array_equal(labels, g["reloc_labels"])
+    np.testing.assert_allclose(centres + mean, g["reloc_centres"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(inertia, float(g["reloc_inertia"]), rtol=1e-12)
+
+
+def test_kmeans_oracle_matches_live_sklearn():
+    """Same check against whatever scikit-learn is installed where the tests run."""
+    sk = pytest.importorskip("sklearn.cluster")
+    from oracle import kmeans as okm
+    rs = np.random.RandomState(5)
+    X = rs.rand(1500, 3) * [1.0, 0.5, 0.2]
+    km = sk.KMeans(n_clusters=12, random_state=1, max_iter=50, n_init=1).fit(X)
+    o = okm.fit(X, 12)
+    assert o["n_iter_"] == km.n_iter_ and np.array_equal(o["labels_"], km.labels_)
+    np.testing.assert_allclose(o["cluster_centers_"], km.cluster_centers_, rtol=0, atol=1e-12)

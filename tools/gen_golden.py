@@ -392,6 +392,45 @@ def gen_gmmreg(pts):
         sys.path.remove(refdir)
 
 
+def gen_kmeans(G, pts):
+    """KMeans initialiser: outputs of the reference's own init_gmm_params (gmmreg_gpu/gmm_impl.py:18-24,
+    i.e. scikit-learn's KMeans(k, random_state=1, max_iter=50, n_init=1)) plus the estimator's
+    labels / iteration count / seeds for the same call, and one Lloyd run from a hand-made init
+    that leaves two clusters empty (exercises the relocation rule)."""
+    import warnings
+    import sklearn
+    from sklearn.cluster import KMeans, kmeans_plusplus
+    warnings.simplefilter("ignore")
+    rs = np.random.RandomState(11)
+    bun = pts.astype(np.float32).astype(np.float64)
+    blobs = rs.rand(12, 3)[rs.randint(12, size=3000)] + 0.02 * rs.randn(3000, 3)
+    cases = {"uniform": (rs.rand(2000, 3), 16), "blobs": (blobs, 20), "bunny": (bun[::10], 50)}
+    out = {"sklearn_version": np.array(sklearn.__version__)}
+    for name, (X, k) in cases.items():
+        means, weights = G.init_gmm_params(X, k)
+        km = KMeans(n_clusters=k, random_state=1, max_iter=50, n_init=1).fit(X)
+        assert np.allclose(km.cluster_centers_, means, rtol=0, atol=1e-12)    # thread-order noise only
+        _, idx = kmeans_plusplus(X - X.mean(axis=0), k, random_state=1)
+        if name != "bunny":
+            out[name + "_X"] = X
+        out[name + "_k"] = np.array(k)
+        out[name + "_centres"] = means
+        out[name + "_weights"] = weights
+        out[name + "_labels"] = km.labels_.astype(np.int32)
+        out[name + "_n_iter"] = np.array(km.n_iter_)
+        out[name + "_inertia"] = np.array(km.inertia_)
+        out[name + "_init_indices"] = idx.astype(np.int64)
+        print("kmeans", name, "k", k, "n_iter", km.n_iter_, "inertia", km.inertia_)
+    X = rs.rand(500, 3)
+    init = X[rs.choice(500, 6, replace=False)].copy()
+    init[2] = [50, 50, 50]
+    init[4] = [-40, 3, 3]
+    km = KMeans(n_clusters=6, init=init, n_init=1, max_iter=50).fit(X)
+    out.update(reloc_X=X, reloc_init=init, reloc_centres=km.cluster_centers_, reloc_labels=km.labels_.astype(np.int32),
+               reloc_n_iter=np.array(km.n_iter_), reloc_inertia=np.array(km.inertia_))
+    np.savez_compressed(os.path.join(OUT, "kmeans_init.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -409,6 +448,9 @@ def main():
             gen_flat_small(W, G)
         if want("bunny"):
             gen_flat_bunny(W, G, pts)
+    if want("kmeans"):
+        G = load_module("ref_gmm_impl_G", os.path.join(REF, "src/python/gmmreg_gpu/gmm_impl.py"))
+        gen_kmeans(G, pts)
     if want("gmmreg"):
         gen_gmmreg(pts)
     if want("hgmm") or want("reg") or want("hgmm3") or want("fullcov"):
