@@ -103,6 +103,35 @@ def bunny_leg(ctx):
             "gpu_it_per_s": g, "cpu_it_per_s": c, "cpu_cores": os.cpu_count(), "speedup": g / c}
 
 
+def kmeans_leg(ctx):
+    """KMeans initialiser of the GMMReg flavour (gmmreg_gpu/gmm_impl.py:18-24) at C3 size on the
+    device, and on bun000 (k = 100) next to scikit-learn (the reference's own call) when installed."""
+    from hgmm_amd.kmeans import KMeans
+    X = synth_frame(0).astype(np.float64)
+    KMeans(n_clusters=J_COMP, random_state=1, max_iter=2, ctx=ctx).fit(X[:20000])      # warm-up
+    t0 = time.perf_counter()
+    km = KMeans(n_clusters=J_COMP, random_state=1, max_iter=50, ctx=ctx).fit(X)
+    out = {"workload": "KMeans(k=800, random_state=1, max_iter=50, n_init=1) on the C3 frame, float64",
+           "fit_ms": (time.perf_counter() - t0) * 1e3, "lloyd_iterations": int(km.n_iter_),
+           "sklearn_same_box_ms": "78395 (profiles/r01/kmbench.log; not re-timed here)"}
+    path = os.path.join(ROOT, "tests", "golden", "bun000_xyz.npy")
+    if os.path.exists(path):
+        P = np.load(path).astype(np.float64)
+        KMeans(n_clusters=100, random_state=1, max_iter=50, ctx=ctx).fit(P)
+        t0 = time.perf_counter()
+        km = KMeans(n_clusters=100, random_state=1, max_iter=50, ctx=ctx).fit(P)
+        out["bun000_k100_fit_ms"] = (time.perf_counter() - t0) * 1e3
+        try:
+            from sklearn.cluster import KMeans as SK
+            t0 = time.perf_counter()
+            ref = SK(n_clusters=100, random_state=1, max_iter=50, n_init=1).fit(P)
+            out["bun000_k100_sklearn_ms"] = (time.perf_counter() - t0) * 1e3
+            out["bun000_k100_labels_identical"] = bool(np.array_equal(ref.labels_, km.labels_))
+        except ImportError:
+            pass
+    return out
+
+
 def hgmm_leg(ctx):
     """BASELINE configs[3]: 4-level GMM tree (8 + 64 + 512 + 4096 = 4680 nodes) on bun000.ply,
     CPU-twin constants (ls = 80, ld = 1e-4, sig2 = 0.00034, seed-72 initial means)."""
@@ -253,6 +282,7 @@ def main():
         lr.free()
         out["bunny"] = bunny_leg(ctx)
         out["hgmm"] = hgmm_leg(ctx)
+        out["kmeans_init"] = kmeans_leg(ctx)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_main()
     elif rank == 0:
