@@ -550,11 +550,22 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_kernel(
 // (two components per VALU instruction; the fp32 peak of gfx950 is only reachable with packed
 // ops).  Same mathematics, statistics layout and output as flat_fused_kernel.
 // ------------------------------------------------------------------------------------------
-template <int NSLOT>
+//
+// CS = constant-shift log-sum-exp.  wl2_j <= c2_j for every point (the quadratic form is <= 0),
+// so M0 = max_j c2_j bounds every row and 2^(wl2 - M0) cannot overflow: with M0 folded into the
+// constants the per-row maximum (K v_max + one wave reduction + K subtractions) disappears and the
+// exponentials are taken straight out of the quadratic form.  What the fixed shift flushes to
+// zero is < 2^(M0 - 126), i.e. < 1e-19 relative to the eps = 1e-8 of the reference's normaliser
+// while M0 <= CS_MAX_SHIFT, and the denominator stays >= eps 2^-M0 >> FLT_MIN.  A model with a
+// larger M0 (sigma < ~1e-7: only the clipped-covariance flavour can get there) is served by the
+// row-maximum variant: both are launched, each decides from the table which of the two runs.
+constexpr float CS_MAX_SHIFT = 60.0f;
+
+template <int NSLOT, bool CS>
 __global__ __launch_bounds__(BLOCK) void flat_fused_pk_kernel(
     const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int J, int Jpad,
     float* __restrict__ partials, double* __restrict__ lpn_partials,
-    const int* __restrict__ done_flag) {
+    const int* __restrict__ done_flag, int only_if_large_shift) {
     if (done_flag && *done_flag) return;
     constexpr int K = NSLOT;
     constexpr int KP = K / 2;          // full pairs
@@ -583,6 +594,21 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_pk_kernel(
         cs = pack[PK_C * Jpad + j];
     }
 
+    // largest constant of the table = upper bound of every wl2 (identical in every wave)
+    float m0 = cs;
+#pragma unroll
+    for (int p = 0; p < KP; ++p) m0 = fmaxf(m0, fmaxf(cc[p].x, cc[p].y));
+    m0 = wave_reduce(m0, OpMax());
+    const bool small_shift = m0 <= CS_MAX_SHIFT;          // false for NaN as well
+    if (CS && !small_shift) return;                        // -> the row-maximum variant
+    if (!CS && only_if_large_shift && small_shift) return; // -> the constant-shift variant
+    if (CS) {
+        const f2 M0 = f2{m0, m0};
+#pragma unroll
+        for (int p = 0; p < KP; ++p) cc[p] = cc[p] - M0;
+        cs -= m0;
+    }
+
     int64_t r0, r1;
     wave_row_range(n, r0, r1);
     double lsum = 0.0;
@@ -597,35 +623,45 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_pk_kernel(
         f2 wl[KP + 1];
         float wls = NEG_INF;
         float m = NEG_INF;
+        f2 sacc = f2{0.f, 0.f};
 #pragma unroll
         for (int p = 0; p < KP; ++p) {
             const f2 d0 = X0 - mu0[p], d1 = X1 - mu1[p], d2 = X2 - mu2[p];
             f2 a = cc[p] - (d0 * g0[p]) * d0;
             a = a - (d1 * g1[p]) * d1;
             a = a - (d2 * g2[p]) * d2;
-            wl[p] = a;
-            m = fmaxf(m, fmaxf(a.x, a.y));
+            if (CS) {
+                wl[p] = f2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+                sacc += wl[p];
+            } else {
+                wl[p] = a;
+                m = fmaxf(m, fmaxf(a.x, a.y));
+            }
         }
         if (ODD) {
             const float d0 = x0 - mu0s, d1 = x1 - mu1s, d2 = x2 - mu2s;
             float a = fmaf(-(d0 * g0s), d0, cs);
             a = fmaf(-(d1 * g1s), d1, a);
             a = fmaf(-(d2 * g2s), d2, a);
-            wls = a;
+            wls = CS ? __builtin_amdgcn_exp2f(a) : a;
             m = fmaxf(m, a);
         }
-        m = wave_reduce(m, OpMax());
-        if (m == NEG_INF) m = 0.f;
-        const f2 M = f2{m, m};
-        f2 sacc = f2{0.f, 0.f};
+        if (CS) {
+            m = m0;
+        } else {
+            m = wave_reduce(m, OpMax());
+            if (m == NEG_INF) m = 0.f;
+            const f2 M = f2{m, m};
 #pragma unroll
-        for (int p = 0; p < KP; ++p) {
-            const f2 t = wl[p] - M;
-            wl[p] = f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
-            sacc += wl[p];
+            for (int p = 0; p < KP; ++p) {
+                const f2 t = wl[p] - M;
+                wl[p] = f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                sacc += wl[p];
+            }
+            if (ODD) wls = __builtin_amdgcn_exp2f(wls - m);
         }
         float s = sacc.x + sacc.y;
-        if (ODD) { wls = __builtin_amdgcn_exp2f(wls - m); s += wls; }
+        if (ODD) s += wls;
         s = wave_reduce(s, OpSum());
         float inv_den;
         const float lpn2 = lpn2_from(m, s, inv_den);
@@ -1351,11 +1387,18 @@ static int launch_fused(hgmm_ctx* c, const int* done_flag, int* grid_out, int* v
     //  * wave-uniform skipping of 64-component slots whose responsibilities are all < 1e-10
     //    never triggers while components are broad: 0 % gain.
     const bool paired = env_flag("HGMM_FUSED_PK", true);
+    //  * constant-shift log-sum-exp (HGMM_FUSED_CS, default on): see flat_fused_pk_kernel.
+    const bool cshift = env_flag("HGMM_FUSED_CS", true);
 #define FUSED_CASE(S)                                                                           \
     do {                                                                                        \
-        if (paired)                                                                             \
-            flat_fused_pk_kernel<S><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, part, \
-                                                                  lp, done_flag);              \
+        if (paired && cshift) {                                                                 \
+            flat_fused_pk_kernel<S, true><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, \
+                                                                        part, lp, done_flag, 0);  \
+            flat_fused_pk_kernel<S, false><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, \
+                                                                         part, lp, done_flag, 1); \
+        } else if (paired)                                                                      \
+            flat_fused_pk_kernel<S, false><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, \
+                                                                         part, lp, done_flag, 0); \
         else                                                                                    \
             flat_fused_kernel<S><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, part,   \
                                                                lp, done_flag);                 \

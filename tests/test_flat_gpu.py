@@ -500,3 +500,49 @@ def test_every_lane_layout(ctx, J):
     o = flat_em.train(f64(X), 2, 0.0, f64(mu), 0.05 * np.ones((J, 3)), np.ones(J) / J, "diag", "W")
     np.testing.assert_allclose(lls, o[4], rtol=0, atol=3e-5)
     np.testing.assert_allclose(mu_t, o[1], rtol=0, atol=2e-5)
+
+
+def test_train_far_points_and_mixed_scales(ctx):
+    """The training kernel shifts the log-sum-exp by a constant (the largest component constant)
+    instead of the row maximum: rows far from every component (all exponentials tiny or zero) and
+    a mix of very tight and very broad components must still match the float64 oracle."""
+    rs = np.random.RandomState(21)
+    centres = rs.rand(6, 3)
+    X = (centres[rs.randint(6, size=3000)] + 0.01 * rs.randn(3000, 3)).astype(np.float32)
+    X[:40] += rs.choice([-1, 1], size=(40, 3)) * rs.uniform(3, 60, size=(40, 3))     # outliers
+    J = 70
+    mu0 = X[rs.choice(len(X), J, replace=False)].copy()
+    cov0 = (10.0 ** rs.uniform(-5.5, 0.5, size=(J, 3))).astype(np.float32)        # sigma 2e-3 .. 1.8
+    w0 = rs.dirichlet(np.ones(J)).astype(np.float32)
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    ctx.set_points(X)
+    for variant in ("W", "G"):
+        inv, mu, w, cov, lls, _ = ctx.flat_train(3, 0.0, mu0, cov0, w0, "diag", variant)
+        o = flat_em.train(f64(X), 3, 0.0, f64(mu0), f64(cov0), f64(w0), "diag", variant)
+        np.testing.assert_allclose(lls, o[4], rtol=2e-6, atol=2e-5)
+        np.testing.assert_allclose(w, o[2], rtol=2e-5, atol=1e-8)
+        np.testing.assert_allclose(mu, o[1], rtol=0, atol=2e-5 * np.abs(X).max())
+        np.testing.assert_allclose(cov, o[3], rtol=2e-4, atol=1e-9)
+
+
+def test_train_huge_shift_takes_the_row_maximum_variant(ctx):
+    """Component constants above 2^60 (sigma ~ 4e-8, reachable only with flavour G's clipped
+    covariance) are outside the constant-shift kernel's range; the row-maximum variant must take
+    over transparently."""
+    rs = np.random.RandomState(22)
+    centres = rs.rand(5, 3).astype(np.float32)
+    X = np.repeat(centres, 40, axis=0) + (1e-8 * rs.randn(200, 3)).astype(np.float32)
+    X = X.astype(np.float32)
+    mu0 = centres.copy()
+    cov0 = np.full((5, 3), 1e-15, dtype=np.float32)
+    w0 = np.full(5, 0.2, dtype=np.float32)
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    ctx.set_points(X)
+    inv, mu, w, cov, lls, _ = ctx.flat_train(1, 0.0, mu0, cov0, w0, "diag", "G")
+    o = flat_em.train(f64(X), 1, 0.0, f64(mu0), f64(cov0), f64(w0), "diag", "G")
+    assert np.isfinite(lls).all() and np.isfinite(mu).all()
+    np.testing.assert_allclose(w, o[2], rtol=1e-5)
+    np.testing.assert_allclose(mu, o[1], rtol=0, atol=1e-6)
+    # the oracle's expanded quadratic form (the reference's) cancels ~2.5e14-sized terms here:
+    # even in float64 its q carries ~0.03 of rounding noise, so only a loose check on lls
+    np.testing.assert_allclose(lls, o[4], rtol=0, atol=0.05)
