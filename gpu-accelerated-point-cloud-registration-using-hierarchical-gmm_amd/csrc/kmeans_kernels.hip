@@ -108,6 +108,7 @@ __global__ __launch_bounds__(1024) void kmpp_pick_kernel(const double* __restric
                                                          int64_t* __restrict__ cand,
                                                          double* __restrict__ pot_out) {
     __shared__ double wave_tot[16];
+    __shared__ double seg_end[1024];                     // inclusive prefix at the end of each thread's segment
     __shared__ double total_sh;
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
     const int seg = (B + 1023) / 1024;
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(1024) void kmpp_pick_kernel(const double* __restric
         run += bsum[b];
         bprefix[b] = run;
     }
+    seg_end[tid] = off + incl;
     if (tid == 1023) total_sh = off + incl;
     __threadfence();
     __syncthreads();
@@ -132,11 +134,15 @@ __global__ __launch_bounds__(1024) void kmpp_pick_kernel(const double* __restric
     if (wave >= T) return;
     const double v = rand_c[wave] * pot;
     const volatile double* bp = bprefix;                 // written by other waves of this workgroup
-    int lo = 0, hi = B;                                  // first block whose inclusive prefix >= v
+    int lo = 0, hi = 1024;                               // first segment whose end >= v (LDS) ...
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (bp[mid] >= v) hi = mid; else lo = mid + 1;
+        if (seg_end[mid] >= v) hi = mid; else lo = mid + 1;
     }
+    hi = min(B, (lo + 1) * seg);                         // ... then the first block inside it
+    lo = min(B, lo * seg);
+    while (lo < hi && !(bp[lo] >= v)) ++lo;
+    if (lo == hi && hi < B) lo = hi;                     // rounding at the segment's end
     int64_t found = n - 1;                               // np.clip(..., n - 1)
     if (lo < B) {
         const double base = lo > 0 ? bp[lo - 1] : 0.0;
@@ -185,30 +191,44 @@ __global__ __launch_bounds__(KM_BLOCK) void kmpp_eval_kernel(const double* __res
     }
     __syncthreads();
     if ((int)threadIdx.x < T)
-        part[(size_t)blockIdx.x * KM_MAX_TRIALS + threadIdx.x] =
+        part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
             (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
 }
 
-// One workgroup of 1024 threads: wave t adds up candidate t's potential (fixed order); thread 0
-// keeps the first minimum (np.argmin) and records the new centre.
+// One workgroup of 1024 threads: thread i adds blocks i, i + 1024, ... of every candidate (partials are
+// stored [t][B], so the reads are coalesced), waves and then the 16 wave totals are combined in
+// fixed order; thread 0 keeps the first minimum (np.argmin) and records the new centre.
 __global__ __launch_bounds__(1024) void kmpp_select_kernel(const double* __restrict__ xs, int64_t n_pad,
                                                            const double* __restrict__ part, int B, int T,
                                                            const int64_t* __restrict__ cand, int c,
                                                            double* __restrict__ centres,
                                                            int64_t* __restrict__ ids) {
-    __shared__ double pot[KM_MAX_TRIALS];
+    __shared__ double wsum[KM_MAX_TRIALS][16];
     const int lane = lane_id(), wave = wave_in_block();
-    if (wave < T) {
-        double s = 0.0;
-        for (int b = lane; b < B; b += 64) s += part[(size_t)b * KM_MAX_TRIALS + wave];
-        s = wave_sum_f64(s);
-        if (lane == 0) pot[wave] = s;
+    double acc[KM_MAX_TRIALS];
+#pragma unroll
+    for (int t = 0; t < KM_MAX_TRIALS; ++t) acc[t] = 0.0;
+    for (int b = threadIdx.x; b < B; b += 1024) {
+#pragma unroll
+        for (int t = 0; t < KM_MAX_TRIALS; ++t)
+            if (t < T) acc[t] += part[(size_t)t * B + b];
+    }
+#pragma unroll
+    for (int t = 0; t < KM_MAX_TRIALS; ++t) {
+        if (t < T) {
+            const double w = wave_sum_f64(acc[t]);
+            if (lane == 0) wsum[t][wave] = w;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         int best = 0;
-        for (int t = 1; t < T; ++t)
-            if (pot[t] < pot[best]) best = t;
+        double best_pot = 0.0;
+        for (int t = 0; t < T; ++t) {
+            double p = 0.0;
+            for (int w = 0; w < 16; ++w) p += wsum[t][w];
+            if (t == 0 || p < best_pot) { best = t; best_pot = p; }
+        }
         const int64_t ci = cand[best];
         ids[c] = ci;
         centres[3 * c + 0] = xs[ci];
