@@ -51,6 +51,9 @@ def load_library(path: str = LIB_PATH):
             raise HgmmError(
                 "HIP extension %s is missing; build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (or python <package>/build.py). There is no CPU fallback." % path)
+        # multi-process RCCL on this platform needs dmabuf IPC (the host driver does not offer the
+        # legacy IPC handles); must be in the environment before the HSA runtime starts
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
         ctx = _vp
         _sig(lib, "hgmm_version", [])
