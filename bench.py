@@ -50,7 +50,7 @@ def init_params(frame0, J=J_COMP, seed=100):
     return mu, w, cov
 
 
-def cpu_baseline_main(sample_n=200_000, iters=4):
+def cpu_baseline_main(sample_n=200_000, iters=10):
     """NumPy oracle (fp32, reference op sequence) on a bounded sample of the workload."""
     from oracle import flat_em
     X = synth_frame(0)[:sample_n]
