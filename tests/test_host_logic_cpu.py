@@ -28,6 +28,7 @@ def test_registration_mstep_matches_oracle_and_reference():
                                          np.identity(3), np.zeros(3))
         np.testing.assert_allclose(res.transformation.rot, rot, atol=1e-12)
         np.testing.assert_allclose(res.transformation.t, t, atol=1e-12)
+        np.testing.assert_allclose(res.q, q, rtol=1e-10)          # QR residual == lstsq residual
         inv = res.transformation.inverse()
         np.testing.assert_allclose(inv.rot, g[tag + "iter_rot"][0], atol=1e-9)
         np.testing.assert_allclose(inv.t, g[tag + "iter_t"][0], atol=1e-9)
