@@ -104,6 +104,35 @@ def bunny_leg(ctx):
             "gpu_it_per_s": g, "cpu_it_per_s": c, "cpu_cores": os.cpu_count(), "speedup": g / c}
 
 
+def registration_leg(ctx):
+    """End to end through the drop-in API (hgmm_gpu.py:802-807): GMM tree (L = 3, 584 nodes) on the
+    full bun000 scan, then GMMTree.registration of a copy rotated 10 deg about z and shifted by a
+    few millimetres (20 iterations max, tol 1e-4); the reference's CPU twin needs minutes for this."""
+    path = os.path.join(ROOT, "tests", "golden", "bun000_xyz.npy")
+    if not os.path.exists(path):
+        return None
+    from hgmm_amd.hgmm.hgmm_gpu import GMMTree
+    P = np.load(path).astype(np.float64)
+    th = np.deg2rad(10.0)
+    rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    target = P @ rz.T + np.array([0.005, -0.003, 0.002])
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        gt = GMMTree(P, tree_level=3, lambda_c=0.01, ls=80, sig2=0.00034, ctx=ctx)
+        t1 = time.perf_counter()
+        iters = []
+        gt.set_callbacks([lambda tf: iters.append(1)])
+        res = gt.registration(target, maxiter=20, tol=1e-4)
+        t2 = time.perf_counter()
+        if best is None or t2 - t0 < best[0]:
+            err = float(np.linalg.norm(res.transformation.transform(P) - target, axis=1).mean())
+            best = (t2 - t0, t1 - t0, t2 - t1, len(iters), err)
+    return {"workload": "bun000.ply (40256 pts) vs copy rotated 10 deg + shifted, registration_gmmtree L=3",
+            "total_ms": best[0] * 1e3, "build_ms": best[1] * 1e3, "registration_ms": best[2] * 1e3,
+            "registration_iterations": best[3], "mean_residual_m": best[4]}
+
+
 def kmeans_leg(ctx):
     """KMeans initialiser of the GMMReg flavour (gmmreg_gpu/gmm_impl.py:18-24) at C3 size on the
     device, and on bun000 (k = 100) next to scikit-learn (the reference's own call) when installed."""
@@ -288,6 +317,7 @@ def main():
         out["bunny"] = bunny_leg(ctx)
         out["hgmm"] = hgmm_leg(ctx)
         out["kmeans_init"] = kmeans_leg(ctx)
+        out["registration"] = registration_leg(ctx)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_main()
     elif rank == 0:

@@ -19,6 +19,9 @@ seeding and the Lloyd assignment / per-cluster sums -- run in HIP kernels
   labels or summed squared centre shift <= tol, one more assignment if the stop was not strict.
 
 Arithmetic is float64 whatever the input dtype (scikit-learn keeps float32 input in float32).
+With an RCCL communicator attached to the context, X is this rank's shard of one joint clustering:
+mean, variance, per-cluster sums, inertia and the changed-label count are all-reduced, the seeds
+are drawn on rank 0's shard; empty-cluster relocation stays local to each shard (single-GPU exact).
 """
 from __future__ import annotations
 
@@ -33,6 +36,35 @@ def _random_state(seed):
     if seed is None:
         return np.random.mtrand._rand
     return np.random.RandomState(seed)
+
+
+def relocate_empty_sharded(allreduce, rank, labels, dist, Xc, sums, counts):
+    """Empty-cluster relocation when the cloud is sharded over ranks: the globally farthest points
+    are found with one max-reduction per empty cluster (ties go to the lowest rank), the chosen point
+    travels as a sum with zeros elsewhere.  Every rank ends with identical sums / counts.
+    ``allreduce(values, op)`` is the communicator's reduction ("sum" / "max")."""
+    empty = np.where(counts == 0)[0]
+    if len(empty) == 0:
+        return
+    order = np.argsort(-dist, kind="stable")[:len(empty)]      # local candidates, farthest first
+    used = 0
+    for new_id in empty:
+        d_loc = float(dist[order[used]]) if used < len(order) else -1.0
+        d_max = allreduce([d_loc], "max")[0]
+        mine = d_loc == d_max
+        owner = -allreduce([-float(rank) if mine else -1.0e9], "max")[0]
+        payload = np.zeros(4)
+        if mine and owner == rank:
+            i = order[used]
+            used += 1
+            payload[:3] = Xc[i]
+            payload[3] = labels[i]
+        payload = allreduce(payload, "sum")
+        old_id = int(round(payload[3]))
+        sums[old_id] -= payload[:3]
+        sums[new_id] = payload[:3]
+        counts[new_id] = 1.0
+        counts[old_id] -= 1.0
 
 
 class KMeans:
@@ -67,6 +99,9 @@ class KMeans:
         if len(empty) == 0:
             return
         labels, dist = ctx.kmeans_labels(with_distances=True)
+        if getattr(ctx, "nranks", 1) > 1:
+            relocate_empty_sharded(lambda v, op: ctx.allreduce(v, op=op), ctx.rank, labels, dist, Xc, sums, counts)
+            return
         far = np.argpartition(dist, -len(empty))[:-len(empty) - 1:-1]
         for new_id, far_idx in zip(empty, far):
             old_id = labels[far_idx]
@@ -83,14 +118,24 @@ class KMeans:
         if n < k:
             raise ValueError("n_samples=%d should be >= n_clusters=%d." % (n, k))
         ctx = self._ctx or default_context()
-        tol_abs = 0.0 if self.tol == 0 else float(np.mean(np.var(X, axis=0)) * self.tol)
-        mean = X.mean(axis=0)
+        ranks = getattr(ctx, "nranks", 1)
+        if ranks > 1:
+            # X is this rank's shard of one joint clustering: global mean / variance / count
+            tot = ctx.allreduce(np.concatenate([[float(n)], X.sum(axis=0), (X * X).sum(axis=0)]))
+            mean = tot[1:4] / tot[0]
+            var = tot[4:7] / tot[0] - mean * mean
+        else:
+            mean = X.mean(axis=0)
+            var = np.var(X, axis=0)
+        tol_abs = 0.0 if self.tol == 0 else float(np.mean(var) * self.tol)
         Xc = X - mean
         ctx.set_points(Xc)
         ctx._points_owner = None                      # supersedes any DevicePoints on this context
         if isinstance(self.init, str):
             rs = _random_state(self.random_state)
             self.init_indices_, centres = self._seed(ctx, n, rs)
+            if ranks > 1:                             # seeds come from rank 0's shard (sum = broadcast)
+                centres = ctx.allreduce(centres if ctx.rank == 0 else np.zeros_like(centres))
         else:
             centres = np.array(self.init, dtype=np.float64).reshape(k, 3) - mean
             self.init_indices_ = None
@@ -118,6 +163,8 @@ class KMeans:
         if strict:
             # labels are those of the last assignment; inertia is measured against the final centres
             inertia = float(((Xc - centres[self.labels_]) ** 2).sum())
+            if ranks > 1:
+                inertia = float(ctx.allreduce([inertia])[0])
         self.inertia_ = float(inertia)
         self.n_iter_ = n_iter
         self.cluster_centers_ = centres + mean

@@ -96,3 +96,61 @@ def test_sharded_statistics_allreduce_equals_single_rank():
     np.testing.assert_allclose(m, o_mu, rtol=1e-10)
     np.testing.assert_allclose(cov, o_cov, rtol=1e-8)
     np.testing.assert_allclose(nk / 3000, o_w, rtol=1e-12)
+
+
+def _kmeans_reloc_worker(rank, world, port, q):
+    """One rank of a world-2 KMeans empty-cluster relocation, all-reduces over gloo."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from hgmm_amd.kmeans import relocate_empty_sharded
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    def allreduce(values, op):
+        t = torch.tensor(np.asarray(values, dtype=np.float64))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+        return t.numpy()
+
+    rs = np.random.RandomState(4)
+    X = rs.rand(400, 3)
+    centres = np.array([[0.2, 0.2, 0.2], [0.8, 0.8, 0.8], [9, 9, 9], [-7, 3, 3], [0.5, 0.5, 0.5]])
+    d = ((X[:, None, :] - centres[None]) ** 2).sum(-1)
+    labels, dist2 = d.argmin(1).astype(np.int32), d.min(1)
+    lo, hi = (0, 170) if rank == 0 else (170, 400)              # uneven shards
+    sums, counts = np.zeros((5, 3)), np.zeros(5)
+    np.add.at(sums, labels, X)
+    counts += np.bincount(labels, minlength=5)
+    relocate_empty_sharded(allreduce, rank, labels[lo:hi], dist2[lo:hi], X[lo:hi], sums, counts)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, sums, counts))
+
+
+def test_world2_kmeans_relocation_matches_single_process():
+    """Sharded relocation == scikit-learn's single-process rule (the globally farthest points move to
+    the empty clusters), and both ranks end with identical statistics."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_kmeans_reloc_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+    (_, s0, c0), (_, s1, c1) = res
+    assert np.array_equal(s0, s1) and np.array_equal(c0, c1)
+    # single-process reference (oracle = scikit-learn's rule)
+    from oracle import kmeans as okm
+    rs = np.random.RandomState(4)
+    X = rs.rand(400, 3)
+    centres = np.array([[0.2, 0.2, 0.2], [0.8, 0.8, 0.8], [9, 9, 9], [-7, 3, 3], [0.5, 0.5, 0.5]])
+    labels, _ = okm.assign(X, centres)
+    sums, counts = np.zeros((5, 3)), np.bincount(labels, minlength=5).astype(np.float64)
+    np.add.at(sums, labels, X)
+    okm._relocate_empty(X, centres, sums, counts, labels)
+    assert np.array_equal(c0, counts)
+    # the same two points move; which of the two empty clusters gets which is argpartition's order
+    moved = {tuple(np.round(s0[j], 12)) for j in (2, 3)}
+    assert moved == {tuple(np.round(sums[j], 12)) for j in (2, 3)}
+    np.testing.assert_allclose(s0[[0, 1, 4]], sums[[0, 1, 4]], atol=1e-12)
