@@ -29,8 +29,9 @@ def compute_l2_dist(mu_source, phi_source, mu_target, phi_target, sigma):
     """-> (-phi_s . G(mu_s), gradient wrt mu_s [J_s,3])   (reference cost_functions.py:29-40)."""
     z = np.power(2.0 * np.pi * sigma ** 2, mu_source.shape[1] * 0.5)
     gtrans = tf.GaussTransform(mu_target, np.sqrt(2.0) * sigma)
-    phi_j_e = gtrans.compute(mu_source, phi_target / z)
-    phi_mu_j_e = gtrans.compute(mu_source, phi_target * mu_target.T / z).T
+    # one kernel matrix for both transforms (the reference evaluates it 1 + 3 times)
+    both = gtrans.compute(mu_source, np.vstack([phi_target / z, phi_target * mu_target.T / z]))
+    phi_j_e, phi_mu_j_e = both[0], both[1:].T
     g = (phi_source * phi_j_e * mu_source.T - phi_source * phi_mu_j_e.T).T / (2.0 * sigma ** 2)
     return -np.dot(phi_source, phi_j_e), g
 

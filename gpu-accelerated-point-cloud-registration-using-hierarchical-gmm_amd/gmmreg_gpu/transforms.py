@@ -32,10 +32,24 @@ class RigidTransformation(Transformation):
         return RigidTransformation(self.rot.T, -np.dot(self.rot.T, self.t), 1.0 / self.scale)
 
 
+def _gauss_kernel(source, target, h):
+    """e[i, j] = exp(-|target_i - source_j|^2 / h^2), differences taken directly (no expanded form)."""
+    d2 = np.zeros((len(target), len(source)))
+    for a in range(source.shape[1]):
+        diff = target[:, a, None] - source[None, :, a]
+        d2 += diff * diff
+    d2 /= -(h * h)
+    return np.exp(d2, out=d2)
+
+
 def _gauss_transform_direct(source, target, weights, h):
-    """out[i] = sum_j weights[j] exp(-|target_i - source_j|^2 / h^2)   (reference transforms.py:43-49)."""
-    d2 = np.sum(np.square(target[:, None, :] - source[None, :, :]), axis=2)
-    return np.exp(-d2 / (h * h)) @ weights
+    """out[i] = sum_j weights[j] exp(-|target_i - source_j|^2 / h^2)   (reference transforms.py:43-49).
+    2-D weights [n_w, J]: all rows share ONE kernel matrix -> [n_w, n_target].  The contractions are
+    einsum (a threaded BLAS gemv on a J x J matrix costs more than the exponentials)."""
+    e = _gauss_kernel(source, target, h)
+    if weights.ndim == 1:
+        return np.einsum('ij,j->i', e, weights)
+    return np.einsum('ij,kj->ki', e, weights)
 
 
 class Direct(object):
@@ -60,5 +74,5 @@ class GaussTransform(object):
         if weights.ndim == 1:
             return self._impl.compute(target, weights)
         if weights.ndim == 2:
-            return np.r_[[self._impl.compute(target, w) for w in weights]]
+            return self._impl.compute(target, weights)
         raise ValueError("weights.ndim must be 1 or 2.")
