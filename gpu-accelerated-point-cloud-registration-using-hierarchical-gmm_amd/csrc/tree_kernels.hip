@@ -70,18 +70,11 @@ __device__ inline double sym3_min_eig_over_trace(double a00, double a01, double 
     return e_min / tr;
 }
 
-__global__ void tree_prep_kernel(const double* __restrict__ pi, const double* __restrict__ mu,
-                                 const double* __restrict__ cov, int64_t j_begin, int64_t j_end,
-                                 double* __restrict__ prep) {
-    const int64_t j = j_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= j_end) return;
-    const double* c = cov + 9 * j;
-    const double c00 = c[0], c01 = c[1], c02 = c[2], c10 = c[3], c11 = c[4], c12 = c[5], c20 = c[6],
-                 c21 = c[7], c22 = c[8];
+__device__ __forceinline__ void prep_node(double p, double m0, double m1, double m2, double c00, double c01,
+                                          double c02, double c10, double c11, double c12, double c20,
+                                          double c21, double c22, double* __restrict__ o) {
     const double det = c00 * (c11 * c22 - c12 * c21) - c01 * (c10 * c22 - c12 * c20) +
                        c02 * (c10 * c21 - c11 * c20);
-    double* o = prep + PREP_N * j;
-    const double p = pi[j];
     if (det < TREE_EPS) {           // gaussianPdf returns 0 (hgmm_cupy_cpu_working.py:65-67)
         o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = 0.0;
         o[9] = 0.0;
@@ -99,8 +92,18 @@ __global__ void tree_prep_kernel(const double* __restrict__ pi, const double* __
         o[9] = p * coef;
         o[10] = (p < TREE_EPS) ? 0.0 : p * coef;   // logLikelihoodValue skips pi < eps (C:80)
     }
-    o[6] = mu[3 * j + 0]; o[7] = mu[3 * j + 1]; o[8] = mu[3 * j + 2];
+    o[6] = m0; o[7] = m1; o[8] = m2;
     o[11] = sym3_min_eig_over_trace(c00, c01, c02, c11, c12, c22);
+}
+
+__global__ void tree_prep_kernel(const double* __restrict__ pi, const double* __restrict__ mu,
+                                 const double* __restrict__ cov, int64_t j_begin, int64_t j_end,
+                                 double* __restrict__ prep) {
+    const int64_t j = j_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= j_end) return;
+    const double* c = cov + 9 * j;
+    prep_node(pi[j], mu[3 * j], mu[3 * j + 1], mu[3 * j + 2], c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8],
+              prep + PREP_N * j);
 }
 
 __global__ void tree_init_nodes_kernel(const double* __restrict__ init_mu, double sig2, int64_t T,
@@ -222,9 +225,37 @@ __global__ __launch_bounds__(CH) void tree_estep_kernel(
 }
 
 // one wave per child node of the level: fixed-order sum of its parent's chunk partials
+// ML estimate of one node from its moments (mlEstimator, hgmm_cupy_cpu_working.py:109-119) followed by
+// the node's E-step preparation, so that no separate prep launch is needed.
+__device__ __forceinline__ void mstep_node(const double* __restrict__ m, int64_t j, double n_points_total,
+                                           double ld, double* __restrict__ pi, double* __restrict__ mu,
+                                           double* __restrict__ cov, double* __restrict__ prep) {
+    const double m0 = m[0];
+    double* c = cov + 9 * j;
+    if (m0 < ld) {
+        pi[j] = 0.0;
+        mu[3 * j] = mu[3 * j + 1] = mu[3 * j + 2] = 0.0;
+        for (int e = 0; e < 9; ++e) c[e] = (e % 4 == 0) ? 1.0 : 0.0;
+        if (prep) prep_node(0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0, prep + PREP_N * j);
+        return;
+    }
+    const double p = m0 / n_points_total;
+    pi[j] = p;
+    const double u0 = m[1] / m0, u1 = m[2] / m0, u2 = m[3] / m0;
+    mu[3 * j] = u0; mu[3 * j + 1] = u1; mu[3 * j + 2] = u2;
+    const double s00 = m[4] / m0 - u0 * u0, s01 = m[5] / m0 - u0 * u1, s02 = m[6] / m0 - u0 * u2,
+                 s11 = m[7] / m0 - u1 * u1, s12 = m[8] / m0 - u1 * u2, s22 = m[9] / m0 - u2 * u2;
+    c[0] = s00; c[1] = s01; c[2] = s02; c[3] = s01; c[4] = s11; c[5] = s12; c[6] = s02; c[7] = s12; c[8] = s22;
+    if (prep) prep_node(p, u0, u1, u2, s00, s01, s02, s01, s11, s12, s02, s12, s22, prep + PREP_N * j);
+}
+
+// fixed-order reduction of the chunk partials of one node (64 threads); with `fuse` the same
+// workgroup goes on to the node's M-step + preparation (single-GPU: no all-reduce in between)
 __global__ __launch_bounds__(64) void tree_moments_kernel(const double* __restrict__ partials,
                                                           const int* __restrict__ chunk_first,
-                                                          int n_level_nodes, double* __restrict__ mom) {
+                                                          int n_level_nodes, double* __restrict__ mom,
+                                                          int fuse, int64_t lb, double n_points_total, double ld,
+                                                          double* pi, double* mu, double* cov, double* prep) {
     const int cl = blockIdx.x;            // level-local child index
     if (cl >= n_level_nodes) return;
     const int p = cl >> 3, k = cl & 7;
@@ -238,33 +269,19 @@ __global__ __launch_bounds__(64) void tree_moments_kernel(const double* __restri
         for (int m = 0; m < NMOM; ++m) acc[m] += src[m];
     }
 #pragma unroll
-    for (int m = 0; m < NMOM; ++m) {
-        const double v = wave_sum_f64(acc[m]);
-        if (threadIdx.x == 0) mom[(size_t)cl * NMOM + m] = v;
+    for (int m = 0; m < NMOM; ++m) acc[m] = wave_sum_f64(acc[m]);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int m = 0; m < NMOM; ++m) mom[(size_t)cl * NMOM + m] = acc[m];
+        if (fuse) mstep_node(acc, lb + cl, n_points_total, ld, pi, mu, cov, prep);
     }
 }
-
-// ML estimate of the level's nodes (mlEstimator, hgmm_cupy_cpu_working.py:109-119)
 __global__ void tree_mstep_kernel(const double* __restrict__ mom, int64_t lb, int n_level_nodes,
-                                  double n_points_total, double ld, double* pi, double* mu, double* cov) {
+                                  double n_points_total, double ld, double* pi, double* mu, double* cov,
+                                  double* prep) {
     const int cl = blockIdx.x * blockDim.x + threadIdx.x;
     if (cl >= n_level_nodes) return;
-    const int64_t j = lb + cl;
-    const double* m = mom + (size_t)cl * NMOM;
-    const double m0 = m[0];
-    if (m0 < ld) {
-        pi[j] = 0.0;
-        mu[3 * j] = mu[3 * j + 1] = mu[3 * j + 2] = 0.0;
-        for (int e = 0; e < 9; ++e) cov[9 * j + e] = (e % 4 == 0) ? 1.0 : 0.0;
-        return;
-    }
-    pi[j] = m0 / n_points_total;
-    const double u0 = m[1] / m0, u1 = m[2] / m0, u2 = m[3] / m0;
-    mu[3 * j] = u0; mu[3 * j + 1] = u1; mu[3 * j + 2] = u2;
-    const double s00 = m[4] / m0 - u0 * u0, s01 = m[5] / m0 - u0 * u1, s02 = m[6] / m0 - u0 * u2,
-                 s11 = m[7] / m0 - u1 * u1, s12 = m[8] / m0 - u1 * u2, s22 = m[9] / m0 - u2 * u2;
-    double* c = cov + 9 * j;
-    c[0] = s00; c[1] = s01; c[2] = s02; c[3] = s01; c[4] = s11; c[5] = s12; c[6] = s02; c[7] = s12; c[8] = s22;
+    mstep_node(mom + (size_t)cl * NMOM, lb + cl, n_points_total, ld, pi, mu, cov, prep);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -674,14 +691,17 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                 tree_estep_kernel<<<grid_chunks, CH, 0, c->stream>>>(xs_cur, n_pad, d_prep, chunk_desc, n_chunks_dev,
                                                                     parent_first, l, partials, cur);
             }
-            tree_moments_kernel<<<n_level, 64, 0, c->stream>>>(partials, chunk_first, n_level, d_mom + NMOM * lb);
+            // single GPU: reduction, M-step and preparation of a node in one launch; with a
+            // communicator the all-reduce of the moments sits between reduction and M-step
+            tree_moments_kernel<<<n_level, 64, 0, c->stream>>>(partials, chunk_first, n_level, d_mom + NMOM * lb,
+                                                               c->comm ? 0 : 1, lb, n_total, ld, d_pi, d_mu, d_cov,
+                                                               d_prep);
             if (c->comm) {
                 rc = allreduce_f64_dev(c, d_mom + NMOM * lb, (size_t)NMOM * n_level);
                 if (rc != HGMM_OK) break;
+                tree_mstep_kernel<<<nblk(n_level, 256), 256, 0, c->stream>>>(d_mom + NMOM * lb, lb, n_level, n_total,
+                                                                             ld, d_pi, d_mu, d_cov, d_prep);
             }
-            tree_mstep_kernel<<<nblk(n_level, 256), 256, 0, c->stream>>>(d_mom + NMOM * lb, lb, n_level, n_total, ld,
-                                                                         d_pi, d_mu, d_cov);
-            tree_prep_kernel<<<nblk(n_level, 256), 256, 0, c->stream>>>(d_pi, d_mu, d_cov, lb, le, d_prep);
             {
                 // small clouds do not have enough 256-point blocks to fill the chip: split the level's
                 // nodes over gridDim.y and add the per-chunk sums in a second (fixed-order) kernel
@@ -1099,8 +1119,8 @@ extern "C" int hgmm_fullcov_fit(hgmm_ctx* c, int J, double ls, double ld, const 
     int it = 0, q_len = 0;
     while (true) {
         HGMM_TRY(fullcov_moments(c, J, J16, grid));                                   // E (moments)
-        tree_mstep_kernel<<<nblk(J, 256), 256, 0, c->stream>>>(c->t_mom.as<double>(), 0, J, n_total, ld, d_pi, d_mu, d_cov);
-        tree_prep_kernel<<<nblk(J, 256), 256, 0, c->stream>>>(d_pi, d_mu, d_cov, 0, J, d_prep);   // M
+        tree_mstep_kernel<<<nblk(J, 256), 256, 0, c->stream>>>(c->t_mom.as<double>(), 0, J, n_total, ld, d_pi, d_mu,
+                                                               d_cov, d_prep);                  // M (+ prep)
         double q = 0.0;
         HGMM_TRY(fullcov_pass(c, J, lab_nxt, &q));                                    // q (+ next E-step's den)
         ++it;
@@ -1319,7 +1339,7 @@ extern "C" int hgmm_tree_mstep(hgmm_ctx* c, int64_t T, const double* m0, const d
     const int n_level = (int)(j_end - j_begin);
     tree_mstep_kernel<<<nblk(n_level, 256), 256, 0, c->stream>>>(mom + NMOM * j_begin, j_begin, n_level, n_points, ld,
                                                                  c->t_pi.as<double>(), c->t_mu.as<double>(),
-                                                                 c->t_cov.as<double>());
+                                                                 c->t_cov.as<double>(), nullptr);
     HGMM_HIP(c, hipGetLastError());
     HGMM_HIP(c, hipMemcpyAsync(pi_inout, c->t_pi.p, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
     HGMM_HIP(c, hipMemcpyAsync(mu_inout, c->t_mu.p, sizeof(double) * 3 * T, hipMemcpyDeviceToHost, c->stream));
