@@ -214,7 +214,7 @@ extern "C" int hgmm_destroy(hgmm_ctx* c) {
                       &c->f_partials, &c->f_lpn_partials, &c->f_stats, &c->f_lls, &c->f_ctl, &c->f_hint,
                       &c->scratch, &c->t_pi, &c->t_mu, &c->t_cov, &c->t_prep, &c->t_cplx, &c->t_mom,
                       &c->t_parent, &c->t_current, &c->t_perm, &c->t_seg, &c->t_chunks, &c->t_partials,
-                      &c->t_q, &c->tgt_soa64, &c->comm_buf, &c->t_xs3, &c->t_llp, &c->f_cm, &c->f_cs, &c->f_ca, &c->f_lpn2,
+                      &c->t_q, &c->tgt_soa64, &c->comm_buf, &c->t_xs3, &c->t_llp, &c->t_qtrace, &c->f_cm, &c->f_cs, &c->f_ca, &c->f_lpn2,
                       &c->km_closest, &c->km_block, &c->km_centres, &c->km_ids, &c->km_rand, &c->km_labels,
                       &c->km_mind2, &c->km_partial, &c->km_out};
     for (DevBuf* b : bufs)

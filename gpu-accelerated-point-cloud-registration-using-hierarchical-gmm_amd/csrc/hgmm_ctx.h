@@ -86,6 +86,7 @@ struct hgmm_ctx {
     hgmm::DevBuf t_partials;                  // double per-chunk partial moments
     hgmm::DevBuf t_q;                         // double per-block q partials + result
     hgmm::DevBuf t_llp;                       // double [node chunks][n_pad] log-likelihood partial sums
+    hgmm::DevBuf t_qtrace;                    // double [max iterations per level] q of the running level
     hgmm::DevBuf tgt_soa64;                   // double [3][m_pad] registration target
     int64_t tgt_n = 0, tgt_pad = 0;
 

@@ -25,7 +25,9 @@
 #include "hgmm_ctx.h"
 #include "wave_ops.h"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace hgmm {
@@ -167,7 +169,8 @@ __global__ void tree_chunks_kernel(const int* __restrict__ seg_start, int P, int
 __global__ __launch_bounds__(CH) void tree_estep_kernel(
     const double* __restrict__ xs, int64_t n_pad, const double* __restrict__ prep,
     const int* __restrict__ chunk_desc, const int* __restrict__ n_chunks, int64_t parent_level_first,
-    int level, double* __restrict__ partials, int* __restrict__ cur_sorted) {
+    int level, double* __restrict__ partials, int* __restrict__ cur_sorted, const int* __restrict__ done) {
+    if (done && *done) return;            // the level converged in an earlier iteration of this batch
     const int c = blockIdx.x;
     if (c >= *n_chunks) return;
     const int p = chunk_desc[3 * c + 0], begin = chunk_desc[3 * c + 1], end = chunk_desc[3 * c + 2];
@@ -255,7 +258,9 @@ __global__ __launch_bounds__(64) void tree_moments_kernel(const double* __restri
                                                           const int* __restrict__ chunk_first,
                                                           int n_level_nodes, double* __restrict__ mom,
                                                           int fuse, int64_t lb, double n_points_total, double ld,
-                                                          double* pi, double* mu, double* cov, double* prep) {
+                                                          double* pi, double* mu, double* cov, double* prep,
+                                                          const int* __restrict__ done) {
+    if (done && *done) return;
     const int cl = blockIdx.x;            // level-local child index
     if (cl >= n_level_nodes) return;
     const int p = cl >> 3, k = cl & 7;
@@ -291,11 +296,45 @@ constexpr int LL_TILE = 256;
 // grid = (point blocks, node chunks).  With one chunk the per-point log is taken here; with several
 // (small clouds: not enough point blocks to fill 256 CUs) the per-chunk sums go to `partial`
 // [chunk][point] and tree_loglik_finish_kernel adds them in fixed order.
+// Stores a workgroup's share of q; with `ticket` the workgroup that finishes last also adds up all
+// shares -- in the same fixed order as tree_sum_kernel -- so that no separate reduction launch is
+// needed (the result does not depend on which workgroup happens to be last).
+__device__ __forceinline__ void store_block_q(double value, double* __restrict__ block_q, int nb,
+                                              unsigned int* __restrict__ ticket, double* __restrict__ q_out) {
+    __shared__ bool is_last;
+    __shared__ double sh_fin[4];
+    if (threadIdx.x == 0) {
+        block_q[blockIdx.x] = value;
+        is_last = false;
+        if (ticket) {
+            __threadfence();
+            is_last = atomicAdd(ticket, 1u) == (unsigned int)(nb - 1);
+        }
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    const volatile double* v = block_q;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nb; i += CH) acc += v[i];
+    acc = wave_sum_f64(acc);
+    if (lane_id() == 0) sh_fin[wave_in_block()] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *q_out = sh_fin[0] + sh_fin[1] + sh_fin[2] + sh_fin[3];
+        *ticket = 0u;
+    }
+}
+
 __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restrict__ xs, int64_t n,
                                                          int64_t n_pad, const double* __restrict__ prep,
                                                          int64_t lb, int n_level_nodes, int nodes_per_chunk,
                                                          double* __restrict__ partial,
-                                                         double* __restrict__ block_q) {
+                                                         double* __restrict__ block_q,
+                                                         unsigned int* __restrict__ ticket,
+                                                         double* __restrict__ q_out,
+                                                         const int* __restrict__ done) {
+    if (done && *done) return;
     __shared__ double tile[LL_TILE][10];
     __shared__ double shq[CH / 64];
     const int64_t i = (int64_t)blockIdx.x * CH + threadIdx.x;
@@ -333,16 +372,18 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
     lq = wave_sum_f64(lq);
     if (lane_id() == 0) shq[wave_in_block()] = lq;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int w = 0; w < CH / 64; ++w) t += shq[w];
-        block_q[blockIdx.x] = t;
-    }
+    double t = 0.0;
+    for (int w = 0; w < CH / 64; ++w) t += shq[w];
+    store_block_q(t, block_q, (int)gridDim.x, ticket, q_out);
 }
 
 __global__ __launch_bounds__(CH) void tree_loglik_finish_kernel(const double* __restrict__ partial, int64_t n,
                                                                 int64_t n_pad, int n_chunks,
-                                                                double* __restrict__ block_q) {
+                                                                double* __restrict__ block_q,
+                                                                unsigned int* __restrict__ ticket,
+                                                                double* __restrict__ q_out,
+                                                                const int* __restrict__ done) {
+    if (done && *done) return;
     __shared__ double shq[CH / 64];
     const int64_t i = (int64_t)blockIdx.x * CH + threadIdx.x;
     double lq = 0.0;
@@ -354,11 +395,25 @@ __global__ __launch_bounds__(CH) void tree_loglik_finish_kernel(const double* __
     lq = wave_sum_f64(lq);
     if (lane_id() == 0) shq[wave_in_block()] = lq;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int w = 0; w < CH / 64; ++w) t += shq[w];
-        block_q[blockIdx.x] = t;
-    }
+    double t = 0.0;
+    for (int w = 0; w < CH / 64; ++w) t += shq[w];
+    store_block_q(t, block_q, (int)gridDim.x, ticket, q_out);
+}
+
+// Device-side stop rule of one tree level (buildGMMTree, hgmm_cupy_cpu_working.py:149-157): record q,
+// stop when |q - prev_q| < ls (prev_q starts at 0) or after max_iters.  ctl = {done, iterations};
+// prev_q sits behind it.  Lets the host enqueue several iterations per synchronisation: the kernels of
+// an iteration that comes after the stop return at once.
+struct TreeCtl { int done; int it; double prev_q; };
+__global__ void tree_ctl_kernel(const double* __restrict__ q_dev, TreeCtl* __restrict__ ctl, double ls,
+                                int max_iters, double* __restrict__ trace, int trace_cap) {
+    if (ctl->done) return;
+    const double q = *q_dev;
+    const int it = ctl->it;
+    if (it < trace_cap) trace[it] = q;
+    ctl->it = it + 1;
+    if (fabs(q - ctl->prev_q) < ls || it + 1 >= max_iters) ctl->done = 1;
+    ctl->prev_q = q;
 }
 
 __global__ __launch_bounds__(256) void tree_sum_kernel(const double* __restrict__ v, int n, double* out) {
@@ -647,6 +702,14 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     double* partials = c->t_partials.as<double>();
     double* block_q = c->t_q.as<double>();
     double* q_dev = block_q + nblk(n, CH);
+    unsigned int* q_ticket = reinterpret_cast<unsigned int*>(q_dev + 1);
+    HGMM_HIP(c, hipMemsetAsync(q_ticket, 0, sizeof(unsigned int), c->stream));
+    TreeCtl* ctl = reinterpret_cast<TreeCtl*>(q_dev + 2);
+    const int trace_cap = std::min(max_iters_per_level, 1 << 20);
+    HGMM_TRY(ensure(c, c->t_qtrace, sizeof(double) * (size_t)trace_cap));
+    double* trace_dev = c->t_qtrace.as<double>();
+    int batch_iters = 8;                      // iterations enqueued per host synchronisation (1/2/4/8/16: 6.8/6.3/5.6/5.1/5.3 ms @C4)
+    if (const char* e = std::getenv("HGMM_TREE_BATCH")) batch_iters = std::max(1, std::min(64, atoi(e)));
 
     HGMM_HIP(c, hipMemcpyAsync(c->scratch.p, init_mu, sizeof(double) * 3 * T, hipMemcpyHostToDevice, c->stream));
     tree_init_nodes_kernel<<<nblk(T, 256), 256, 0, c->stream>>>(c->scratch.as<double>(), sig2, T, d_pi, d_mu, d_cov);
@@ -683,66 +746,82 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
         const int64_t parent_first = (l == 0) ? 0 : level_first(l - 1);
         tree_chunks_kernel<<<1, 1024, 0, c->stream>>>(seg_cur, P, chunk_first, chunk_desc, n_chunks_dev);
         const unsigned grid_chunks = (unsigned)(n / CH + P + 1);
-        double prev_q = 0.0;
+        // small clouds do not have enough 256-point blocks to fill the chip: split the level's nodes
+        // over gridDim.y and add the per-chunk sums in a second (fixed-order) kernel
+        const int pblocks = (int)nblk(n, CH);
+        int chunks = 1;
+        if (pblocks < 4 * c->cus && n_level > LL_TILE) {
+            chunks = (4 * c->cus + pblocks - 1) / pblocks;
+            const int max_chunks_l = (n_level + LL_TILE - 1) / LL_TILE;
+            if (chunks > max_chunks_l) chunks = max_chunks_l;
+        }
+        const int per_chunk = ((n_level + chunks - 1) / chunks + LL_TILE - 1) / LL_TILE * LL_TILE;
+        chunks = (n_level + per_chunk - 1) / per_chunk;
+        double* ll_partial = nullptr;
+        if (chunks > 1) {
+            rc = ensure(c, c->t_llp, sizeof(double) * (size_t)chunks * n_pad);
+            if (rc != HGMM_OK) break;
+            ll_partial = c->t_llp.as<double>();
+        }
+        // The stop rule runs on the device (tree_ctl_kernel); the host enqueues `batch` iterations per
+        // synchronisation and reads {done, iterations} back, so launches overlap execution.  Kernels of
+        // iterations enqueued past the stop return immediately.  With a communicator every iteration
+        // is synchronised (the all-reduces in between are not predicated).
+        HGMM_HIP(c, hipMemsetAsync(ctl, 0, sizeof(TreeCtl), c->stream));
+        const int batch = c->comm ? 1 : batch_iters;
         int it = 0;
-        while (true) {
-            {
-                ProfScope prof(c, HGMM_K_TREE_ESTEP);
-                tree_estep_kernel<<<grid_chunks, CH, 0, c->stream>>>(xs_cur, n_pad, d_prep, chunk_desc, n_chunks_dev,
-                                                                    parent_first, l, partials, cur);
-            }
-            // single GPU: reduction, M-step and preparation of a node in one launch; with a
-            // communicator the all-reduce of the moments sits between reduction and M-step
-            tree_moments_kernel<<<n_level, 64, 0, c->stream>>>(partials, chunk_first, n_level, d_mom + NMOM * lb,
-                                                               c->comm ? 0 : 1, lb, n_total, ld, d_pi, d_mu, d_cov,
-                                                               d_prep);
-            if (c->comm) {
-                rc = allreduce_f64_dev(c, d_mom + NMOM * lb, (size_t)NMOM * n_level);
-                if (rc != HGMM_OK) break;
-                tree_mstep_kernel<<<nblk(n_level, 256), 256, 0, c->stream>>>(d_mom + NMOM * lb, lb, n_level, n_total,
-                                                                             ld, d_pi, d_mu, d_cov, d_prep);
-            }
-            {
-                // small clouds do not have enough 256-point blocks to fill the chip: split the level's
-                // nodes over gridDim.y and add the per-chunk sums in a second (fixed-order) kernel
-                const int pblocks = (int)nblk(n, CH);
-                int chunks = 1;
-                if (pblocks < 4 * c->cus && n_level > LL_TILE) {
-                    chunks = (4 * c->cus + pblocks - 1) / pblocks;
-                    const int max_chunks_l = (n_level + LL_TILE - 1) / LL_TILE;
-                    if (chunks > max_chunks_l) chunks = max_chunks_l;
+        bool done = false;
+        while (!done) {
+            for (int b = 0; b < batch && rc == HGMM_OK; ++b) {
+                {
+                    ProfScope prof(c, HGMM_K_TREE_ESTEP);
+                    tree_estep_kernel<<<grid_chunks, CH, 0, c->stream>>>(xs_cur, n_pad, d_prep, chunk_desc,
+                                                                        n_chunks_dev, parent_first, l, partials, cur,
+                                                                        &ctl->done);
                 }
-                const int per_chunk = ((n_level + chunks - 1) / chunks + LL_TILE - 1) / LL_TILE * LL_TILE;
-                chunks = (n_level + per_chunk - 1) / per_chunk;
-                double* ll_partial = nullptr;
-                if (chunks > 1) {
-                    rc = ensure(c, c->t_llp, sizeof(double) * (size_t)chunks * n_pad);
+                // single GPU: reduction, M-step and preparation of a node in one launch; with a
+                // communicator the all-reduce of the moments sits between reduction and M-step
+                tree_moments_kernel<<<n_level, 64, 0, c->stream>>>(partials, chunk_first, n_level, d_mom + NMOM * lb,
+                                                                   c->comm ? 0 : 1, lb, n_total, ld, d_pi, d_mu, d_cov,
+                                                                   d_prep, &ctl->done);
+                if (c->comm) {
+                    rc = allreduce_f64_dev(c, d_mom + NMOM * lb, (size_t)NMOM * n_level);
                     if (rc != HGMM_OK) break;
-                    ll_partial = c->t_llp.as<double>();
+                    tree_mstep_kernel<<<nblk(n_level, 256), 256, 0, c->stream>>>(d_mom + NMOM * lb, lb, n_level,
+                                                                                 n_total, ld, d_pi, d_mu, d_cov, d_prep);
                 }
-                ProfScope prof(c, HGMM_K_TREE_LOGLIK);
-                tree_loglik_kernel<<<dim3(pblocks, chunks), CH, 0, c->stream>>>(xs_cur, n, n_pad, d_prep, lb, n_level,
-                                                                               per_chunk, ll_partial, block_q);
-                if (chunks > 1)
-                    tree_loglik_finish_kernel<<<pblocks, CH, 0, c->stream>>>(ll_partial, n, n_pad, chunks, block_q);
+                {
+                    ProfScope prof(c, HGMM_K_TREE_LOGLIK);
+                    // the last workgroup to finish adds up the per-block shares of q (store_block_q)
+                    tree_loglik_kernel<<<dim3(pblocks, chunks), CH, 0, c->stream>>>(xs_cur, n, n_pad, d_prep, lb,
+                                                                                   n_level, per_chunk, ll_partial,
+                                                                                   block_q, q_ticket, q_dev, &ctl->done);
+                    if (chunks > 1)
+                        tree_loglik_finish_kernel<<<pblocks, CH, 0, c->stream>>>(ll_partial, n, n_pad, chunks, block_q,
+                                                                                q_ticket, q_dev, &ctl->done);
+                }
+                if (c->comm) {
+                    rc = allreduce_f64_dev(c, q_dev, 1);
+                    if (rc != HGMM_OK) break;
+                }
+                tree_ctl_kernel<<<1, 1, 0, c->stream>>>(q_dev, ctl, ls, max_iters_per_level, trace_dev, trace_cap);
             }
-            tree_sum_kernel<<<1, 256, 0, c->stream>>>(block_q, (int)nblk(n, CH), q_dev);
-            if (c->comm) {
-                rc = allreduce_f64_dev(c, q_dev, 1);
-                if (rc != HGMM_OK) break;
-            }
-            double q = 0.0;
-            if (hipMemcpyAsync(&q, q_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            if (rc != HGMM_OK) break;
+            TreeCtl h;
+            if (hipMemcpyAsync(&h, ctl, sizeof h, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
                 hipStreamSynchronize(c->stream) != hipSuccess) {
                 rc = fail(c, HGMM_ERR_HIP, "tree build: device error: %s", hipGetErrorString(hipGetLastError()));
                 break;
             }
-            ++it;
-            if (q_trace_out && q_len < q_capacity) q_trace_out[q_len] = q;
-            ++q_len;
-            if (fabs(q - prev_q) < ls || it >= max_iters_per_level) break;   // C:155-157
-            prev_q = q;
+            it = h.it;
+            done = h.done != 0;
         }
+        if (rc == HGMM_OK && q_trace_out && q_len < q_capacity) {
+            const int take = std::min(std::min(it, trace_cap), q_capacity - q_len);
+            if (take > 0 && hipMemcpy(q_trace_out + q_len, trace_dev, sizeof(double) * take, hipMemcpyDeviceToHost) != hipSuccess)
+                rc = fail(c, HGMM_ERR_HIP, "tree build: q trace download failed");
+        }
+        q_len += it;
         if (rc != HGMM_OK) break;
         if (iters_per_level_out) iters_per_level_out[l] = it;
         if (l + 1 < L) {
@@ -1365,7 +1444,7 @@ extern "C" int hgmm_tree_loglik(hgmm_ctx* c, int64_t T, const double* pi, const 
         tree_loglik_kernel<<<dim3(pblocks, 1), CH, 0, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
                                                                   c->t_prep.as<double>(), j_begin, n_level,
                                                                   (n_level + LL_TILE - 1) / LL_TILE * LL_TILE, nullptr,
-                                                                  block_q);
+                                                                  block_q, nullptr, nullptr, nullptr);
     }
     tree_sum_kernel<<<1, 256, 0, c->stream>>>(block_q, pblocks, q_dev);
     HGMM_HIP(c, hipGetLastError());
