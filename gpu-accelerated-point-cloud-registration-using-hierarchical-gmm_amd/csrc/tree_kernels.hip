@@ -326,6 +326,11 @@ __device__ __forceinline__ void store_block_q(double value, double* __restrict__
     }
 }
 
+// PTS points per thread: the node parameters come out of LDS as wave-wide broadcast reads (10 x 8 B x
+// 64 lanes per node and wave, ~40 LDS cycles for a CU whose four SIMDs need ~12 VALU cycles each for the
+// quadratic form), so the kernel is LDS-bound at one point per thread; every further point reuses the
+// same ten values.
+template <int PTS>
 __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restrict__ xs, int64_t n,
                                                          int64_t n_pad, const double* __restrict__ prep,
                                                          int64_t lb, int n_level_nodes, int nodes_per_chunk,
@@ -337,11 +342,16 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
     if (done && *done) return;
     __shared__ double tile[LL_TILE][10];
     __shared__ double shq[CH / 64];
-    const int64_t i = (int64_t)blockIdx.x * CH + threadIdx.x;
-    const bool active = i < n;
-    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
-    if (active) { x0 = xs[i]; x1 = xs[n_pad + i]; x2 = xs[2 * n_pad + i]; }
-    double tot = 0.0;
+    int64_t i[PTS];
+    bool active[PTS];
+    double x0[PTS], x1[PTS], x2[PTS], tot[PTS];
+#pragma unroll
+    for (int p = 0; p < PTS; ++p) {
+        i[p] = ((int64_t)blockIdx.x * PTS + p) * CH + threadIdx.x;
+        active[p] = i[p] < n;
+        x0[p] = x1[p] = x2[p] = tot[p] = 0.0;
+        if (active[p]) { x0[p] = xs[i[p]]; x1[p] = xs[n_pad + i[p]]; x2[p] = xs[2 * n_pad + i[p]]; }
+    }
     const int node_begin = blockIdx.y * nodes_per_chunk;
     const int node_end = (node_begin + nodes_per_chunk < n_level_nodes) ? node_begin + nodes_per_chunk : n_level_nodes;
     for (int base = node_begin; base < node_end; base += LL_TILE) {
@@ -356,21 +366,31 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
         for (int node = 0; node < cnt; ++node) {
             const double wL = tile[node][9];
             if (wL == 0.0) continue;                                    // workgroup-uniform
-            const double d0 = x0 - tile[node][6], d1 = x1 - tile[node][7], d2 = x2 - tile[node][8];
-            const double q = tile[node][0] * d0 * d0 + tile[node][3] * d1 * d1 + tile[node][5] * d2 * d2 +
-                             2.0 * (tile[node][1] * d0 * d1 + tile[node][2] * d0 * d2 + tile[node][4] * d1 * d2);
             // (node parameters through the LDS tile: reading them with wave-uniform scalar loads
             //  instead was measured 60 % slower for the C4 build, 8.6 vs 5.2 ms)
-            // exp(-0.5 q) underflows to exactly 0 in float64 beyond q ~ 1490: skip the
-            // transcendental when no lane of the wave needs it (points are sorted spatially)
-            if (__any(q < 1500.0)) tot += wL * exp(-0.5 * q);
+            const double i00 = tile[node][0], i01 = tile[node][1], i02 = tile[node][2], i11 = tile[node][3],
+                         i12 = tile[node][4], i22 = tile[node][5], m0 = tile[node][6], m1 = tile[node][7],
+                         m2 = tile[node][8];
+#pragma unroll
+            for (int p = 0; p < PTS; ++p) {
+                const double d0 = x0[p] - m0, d1 = x1[p] - m1, d2 = x2[p] - m2;
+                const double q = i00 * d0 * d0 + i11 * d1 * d1 + i22 * d2 * d2 +
+                                 2.0 * (i01 * d0 * d1 + i02 * d0 * d2 + i12 * d1 * d2);
+                // exp(-0.5 q) underflows to exactly 0 in float64 beyond q ~ 1490: skip the
+                // transcendental when no lane of the wave needs it (points are sorted spatially)
+                if (__any(q < 1500.0)) tot[p] += wL * exp(-0.5 * q);
+            }
         }
     }
     if (gridDim.y > 1) {
-        if (active) partial[(size_t)blockIdx.y * n_pad + i] = tot;
+#pragma unroll
+        for (int p = 0; p < PTS; ++p)
+            if (active[p]) partial[(size_t)blockIdx.y * n_pad + i[p]] = tot[p];
         return;
     }
-    double lq = active ? log(fmax(tot, TREE_EPS)) : 0.0;
+    double lq = 0.0;
+#pragma unroll
+    for (int p = 0; p < PTS; ++p) lq += active[p] ? log(fmax(tot[p], TREE_EPS)) : 0.0;
     lq = wave_sum_f64(lq);
     if (lane_id() == 0) shq[wave_in_block()] = lq;
     __syncthreads();
@@ -710,6 +730,9 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     const int trace_cap = std::min(max_iters_per_level, 1 << 20);
     HGMM_TRY(ensure(c, c->t_qtrace, sizeof(double) * (size_t)trace_cap));
     double* trace_dev = c->t_qtrace.as<double>();
+    // points per thread in the log-likelihood kernel (N = 1e6, L = 4 build: 10.2 / 8.4 / 8.0 ms with 1 / 2 / 4)
+    int ll_pts = n >= 400000 ? 4 : 2;
+    if (const char* e = std::getenv("HGMM_TREE_LL_PTS")) ll_pts = atoi(e) >= 4 ? 4 : (atoi(e) >= 2 ? 2 : 1);
     int batch_iters = 8;                      // iterations enqueued per host synchronisation (1/2/4/8/16: 6.8/6.3/5.6/5.1/5.3 ms @C4)
     if (const char* e = std::getenv("HGMM_TREE_BATCH")) batch_iters = std::max(1, std::min(64, atoi(e)));
 
@@ -751,9 +774,10 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
         // small clouds do not have enough 256-point blocks to fill the chip: split the level's nodes
         // over gridDim.y and add the per-chunk sums in a second (fixed-order) kernel
         const int pblocks = (int)nblk(n, CH);
+        const int llblocks = (int)nblk(n, CH * ll_pts);        // log-likelihood grid: ll_pts points per thread
         int chunks = 1;
-        if (pblocks < 4 * c->cus && n_level > LL_TILE) {
-            chunks = (4 * c->cus + pblocks - 1) / pblocks;
+        if (llblocks < 4 * c->cus && n_level > LL_TILE) {
+            chunks = (4 * c->cus + llblocks - 1) / llblocks;
             const int max_chunks_l = (n_level + LL_TILE - 1) / LL_TILE;
             if (chunks > max_chunks_l) chunks = max_chunks_l;
         }
@@ -795,9 +819,13 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                 {
                     ProfScope prof(c, HGMM_K_TREE_LOGLIK);
                     // the last workgroup to finish adds up the per-block shares of q (store_block_q)
-                    tree_loglik_kernel<<<dim3(pblocks, chunks), CH, 0, c->stream>>>(xs_cur, n, n_pad, d_prep, lb,
-                                                                                   n_level, per_chunk, ll_partial,
-                                                                                   block_q, q_ticket, q_dev, &ctl->done);
+#define LL_LAUNCH(PTS)                                                                                     \
+    tree_loglik_kernel<PTS><<<dim3(llblocks, chunks), CH, 0, c->stream>>>(                                 \
+        xs_cur, n, n_pad, d_prep, lb, n_level, per_chunk, ll_partial, block_q, q_ticket, q_dev, &ctl->done)
+                    if (ll_pts == 4) LL_LAUNCH(4);
+                    else if (ll_pts == 2) LL_LAUNCH(2);
+                    else LL_LAUNCH(1);
+#undef LL_LAUNCH
                     if (chunks > 1)
                         tree_loglik_finish_kernel<<<pblocks, CH, 0, c->stream>>>(ll_partial, n, n_pad, chunks, block_q,
                                                                                 q_ticket, q_dev, &ctl->done);
@@ -1443,7 +1471,7 @@ extern "C" int hgmm_tree_loglik(hgmm_ctx* c, int64_t T, const double* pi, const 
     const int n_level = (int)(j_end - j_begin);
     {
         ProfScope prof(c, HGMM_K_TREE_LOGLIK);
-        tree_loglik_kernel<<<dim3(pblocks, 1), CH, 0, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
+        tree_loglik_kernel<1><<<dim3(pblocks, 1), CH, 0, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
                                                                   c->t_prep.as<double>(), j_begin, n_level,
                                                                   (n_level + LL_TILE - 1) / LL_TILE * LL_TILE, nullptr,
                                                                   block_q, nullptr, nullptr, nullptr);
