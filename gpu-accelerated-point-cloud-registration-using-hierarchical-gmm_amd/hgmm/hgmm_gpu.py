@@ -171,13 +171,20 @@ def twist_mul(tw, rot, t, linear=False):
     return np.dot(tr, rot), np.dot(t, tr.T) + tt
 
 
+_tp_controller = None
+
+
 def _small_lapack():
     """The M-step's factorizations are tall-and-skinny (3 n_nodes x 7): a threaded LAPACK spends
     its time synchronising (16 ms on 8 threads vs 0.6 ms on one for 9900 x 7), so they run on one
-    thread when threadpoolctl is there to say so."""
+    thread when threadpoolctl is there to say so.  The controller is built once (inspecting the
+    loaded libraries on every call costs more than the factorization)."""
+    global _tp_controller
     try:
-        from threadpoolctl import threadpool_limits
-        return threadpool_limits(limits=1)
+        if _tp_controller is None:
+            from threadpoolctl import ThreadpoolController
+            _tp_controller = ThreadpoolController()
+        return _tp_controller.limit(limits=1, user_api="blas")
     except Exception:                                   # pragma: no cover - optional dependency
         import contextlib
         return contextlib.nullcontext()
