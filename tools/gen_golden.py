@@ -392,6 +392,23 @@ def gen_gmmreg(pts):
         sys.path.remove(refdir)
 
 
+def gen_scan_pair():
+    """Second Stanford scan + the ground-truth scan poses of data/bun.conf (data fixtures for the
+    end-to-end registration accuracy test): bun045 vertices (float32) and, per scan, translation
+    (3) + quaternion (x, y, z, w) exactly as listed in the file."""
+    pts = read_ply_vertices(os.path.join(REF, "data/bun045.ply"))
+    np.save(os.path.join(OUT, "bun045_xyz.npy"), pts.astype(np.float32))
+    names, poses = [], []
+    with open(os.path.join(REF, "data/bun.conf")) as f:
+        for line in f:
+            tok = line.split()
+            if tok and tok[0] == "bmesh":
+                names.append(tok[1])
+                poses.append([float(v) for v in tok[2:9]])
+    np.savez(os.path.join(OUT, "bun_conf.npz"), names=np.array(names), poses=np.array(poses))
+    print("scan pair: bun045", pts.shape, "poses", len(names))
+
+
 def gen_kmeans(G, pts):
     """KMeans initialiser: outputs of the reference's own init_gmm_params (gmmreg_gpu/gmm_impl.py:18-24,
     i.e. scikit-learn's KMeans(k, random_state=1, max_iter=50, n_init=1)) plus the estimator's
@@ -448,6 +465,8 @@ def main():
             gen_flat_small(W, G)
         if want("bunny"):
             gen_flat_bunny(W, G, pts)
+    if want("scans"):
+        gen_scan_pair()
     if want("kmeans"):
         G = load_module("ref_gmm_impl_G", os.path.join(REF, "src/python/gmmreg_gpu/gmm_impl.py"))
         gen_kmeans(G, pts)
