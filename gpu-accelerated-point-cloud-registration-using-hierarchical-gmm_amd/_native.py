@@ -96,6 +96,7 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_kmeans_plusplus", [ctx, C.c_int, C.c_int64, _vp, C.c_int, _vp, _vp])
         _sig(lib, "hgmm_kmeans_step", [ctx, C.c_int, _vp, C.c_int, _vp, _f64p, C.POINTER(C.c_int64)])
         _sig(lib, "hgmm_kmeans_labels", [ctx, _vp, _vp])
+        _sig(lib, "hgmm_gauss_transform", [ctx, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_double, _vp])
         _sig(lib, "hgmm_comm_unique_id", [_vp])
         _sig(lib, "hgmm_comm_init_rank", [ctx, C.c_int, C.c_int, _vp])
         _sig(lib, "hgmm_comm_destroy", [ctx])
@@ -519,6 +520,21 @@ class Context:
         d2 = np.empty(self.num_points) if with_distances else None
         self._check(self.lib.hgmm_kmeans_labels(self.h, _ptr(labels), _ptr(d2) if with_distances else None))
         return (labels, d2) if with_distances else labels
+
+    # -- L2 GMMReg ---------------------------------------------------------------------------
+    def gauss_transform(self, centres, points, weights, h):
+        """out[k, i] = sum_j weights[k, j] exp(-|points_i - centres_j|^2 / h^2); 1-D weights -> 1-D out."""
+        centres = np.ascontiguousarray(centres, dtype=np.float64).reshape(-1, 3)
+        points = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        one = w.ndim == 1
+        w2 = w.reshape(1, -1) if one else w
+        if w2.shape[1] != len(centres):
+            raise ValueError("weights must have one column per centre")
+        out = np.empty((w2.shape[0], len(points)))
+        self._check(self.lib.hgmm_gauss_transform(self.h, _ptr(centres), len(centres), _ptr(points), len(points),
+                                                  _ptr(w2), w2.shape[0], float(h), _ptr(out)))
+        return out[0] if one else out
 
     # -- multi-GPU ------------------------------------------------------------------------
     @staticmethod

@@ -102,6 +102,9 @@ struct hgmm_ctx {
     hgmm::DevBuf km_out;                      // double [4k + 2] sums, inertia, changed (+ scratch)
     int64_t km_labels_n = -1;
 
+    // ---- L2 GMMReg Gauss transform ---------------------------------------------------
+    hgmm::DevBuf gt_buf;                      // double: centres, points, weights, per-split partial sums
+
     // ---- multi-GPU --------------------------------------------------------------
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;

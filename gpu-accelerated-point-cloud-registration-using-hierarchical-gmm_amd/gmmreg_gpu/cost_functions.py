@@ -1,5 +1,6 @@
 """L2 distance between two Gaussian mixtures + its rigid (quaternion, translation) cost
-(reference: src/python/gmmreg_gpu/cost_functions.py).  Host NumPy."""
+(reference: src/python/gmmreg_gpu/cost_functions.py).  The J_s x J_t Gauss transform runs on the
+device when the cost function holds a context, the 7-parameter chain rule stays in NumPy."""
 import abc
 
 import numpy as np
@@ -25,10 +26,11 @@ class CostFunction(abc.ABC):
         return None, None
 
 
-def compute_l2_dist(mu_source, phi_source, mu_target, phi_target, sigma):
-    """-> (-phi_s . G(mu_s), gradient wrt mu_s [J_s,3])   (reference cost_functions.py:29-40)."""
+def compute_l2_dist(mu_source, phi_source, mu_target, phi_target, sigma, ctx=None):
+    """-> (-phi_s . G(mu_s), gradient wrt mu_s [J_s,3])   (reference cost_functions.py:29-40).
+    ``ctx``: evaluate the Gauss transform on that device context instead of in NumPy."""
     z = np.power(2.0 * np.pi * sigma ** 2, mu_source.shape[1] * 0.5)
-    gtrans = tf.GaussTransform(mu_target, np.sqrt(2.0) * sigma)
+    gtrans = tf.GaussTransform(mu_target, np.sqrt(2.0) * sigma, ctx=ctx)
     # one kernel matrix for both transforms (the reference evaluates it 1 + 3 times)
     both = gtrans.compute(mu_source, np.vstack([phi_target / z, phi_target * mu_target.T / z]))
     phi_j_e, phi_mu_j_e = both[0], both[1:].T
@@ -39,8 +41,9 @@ def compute_l2_dist(mu_source, phi_source, mu_target, phi_target, sigma):
 class RigidCostFunction(CostFunction):
     """theta = (qw, qx, qy, qz, tx, ty, tz)   (reference cost_functions.py:43-68)."""
 
-    def __init__(self):
+    def __init__(self, ctx=None):
         self._tf_type = tf.RigidTransformation
+        self._ctx = ctx                     # device context for the Gauss transform (None: host NumPy)
 
     def to_transformation(self, theta):
         rot = so.quaternion_matrix(theta[:4])[:3, :3]
@@ -55,7 +58,7 @@ class RigidCostFunction(CostFunction):
         mu_source, phi_source, mu_target, phi_target, sigma = args
         tf_obj = self.to_transformation(theta)
         t_mu_source = tf_obj.transform(mu_source)
-        f, g = compute_l2_dist(t_mu_source, phi_source, mu_target, phi_target, sigma)
+        f, g = compute_l2_dist(t_mu_source, phi_source, mu_target, phi_target, sigma, ctx=self._ctx)
         d_rot = so.diff_rot_from_quaternion(theta[:4])
         gtm0 = np.dot(g.T, mu_source)
         grad = np.concatenate([(gtm0 * d_rot).sum(axis=(1, 2)), g.sum(axis=0)])

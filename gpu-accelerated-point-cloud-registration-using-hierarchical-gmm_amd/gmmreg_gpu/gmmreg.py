@@ -1,7 +1,8 @@
 """L2-distance GMM registration (GMMReg) -- drop-in for the reference's
 ``src/python/gmmreg_gpu/gmmreg.py``: both clouds are summarised by a GMM (fitted on the MI355X
 engine through ``gmm.GMM_GPU``), then a 7-parameter rigid transform is found by BFGS on the L2
-distance between the two mixtures (host SciPy, as in the reference)."""
+distance between the two mixtures (host SciPy as in the reference; the J_s x J_t Gauss transform
+behind every cost evaluation runs on the device)."""
 import time
 
 import numpy as np
@@ -89,10 +90,12 @@ class RigidGMMReg(L2DistRegistration):
     """reference gmmreg.py:138-147 (GMM_GPU feature, 10 EM iterations)."""
 
     def __init__(self, source, sigma=1.0, delta=0.9, n_gmm_components=50, use_estimated_sigma=True,
-                 verbose=False):
+                 verbose=False, ctx=None):
+        from .._native import default_context
         n_gmm_components = min(n_gmm_components, int(source.shape[0] * 0.8))
         super(RigidGMMReg, self).__init__(source, ft.GMM_GPU(n_gmm_components, max_iter=10),
-                                          cf.RigidCostFunction(), sigma, delta, use_estimated_sigma, verbose)
+                                          cf.RigidCostFunction(ctx=ctx or default_context()), sigma, delta,
+                                          use_estimated_sigma, verbose)
 
 
 def registration_gmmreg(source, target, tf_type_name='rigid', callbacks=[], **kargs):

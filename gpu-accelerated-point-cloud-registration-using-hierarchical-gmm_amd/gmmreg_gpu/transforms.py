@@ -1,6 +1,7 @@
 """Transformations + Gauss transform of the L2 GMMReg path (reference:
-src/python/gmmreg_gpu/transforms.py).  Host NumPy, vectorised (the reference loops over target
-rows with ``np.apply_along_axis``); J_s x J_t <= 800 x 800, so this stays on the host."""
+src/python/gmmreg_gpu/transforms.py).  The Gauss transform has a vectorised NumPy form (the reference
+loops over target rows with ``np.apply_along_axis``) and a device form (``hgmm_gauss_transform``) that
+the registration classes use."""
 import abc
 
 import numpy as np
@@ -53,6 +54,8 @@ def _gauss_transform_direct(source, target, weights, h):
 
 
 class Direct(object):
+    """Direct evaluation on the host (NumPy)."""
+
     def __init__(self, source, h):
         self._source = source
         self._h = h
@@ -61,12 +64,25 @@ class Direct(object):
         return _gauss_transform_direct(self._source, target, weights, self._h)
 
 
-class GaussTransform(object):
-    """reference transforms.py:60-86 (direct evaluation only, like the reference)."""
+class DeviceDirect(object):
+    """Direct evaluation on the GPU (``hgmm_gauss_transform``, csrc/gmmreg_kernels.hip)."""
 
-    def __init__(self, source, h, eps=1.0e-4, sw_h=0.01):
+    def __init__(self, source, h, ctx):
+        self._source = np.ascontiguousarray(source, dtype=np.float64)
+        self._h = h
+        self._ctx = ctx
+
+    def compute(self, target, weights):
+        return self._ctx.gauss_transform(self._source, target, weights, self._h)
+
+
+class GaussTransform(object):
+    """reference transforms.py:60-86 (direct evaluation only, like the reference).  With ``ctx``
+    (an ``hgmm_amd.Context``) the sums run on the device, otherwise in NumPy on the host."""
+
+    def __init__(self, source, h, eps=1.0e-4, sw_h=0.01, ctx=None):
         self._m = source.shape[0]
-        self._impl = Direct(source, h)
+        self._impl = Direct(source, h) if ctx is None else DeviceDirect(source, h, ctx)
 
     def compute(self, target, weights=None):
         if weights is None:

@@ -214,6 +214,15 @@ int hgmm_kmeans_step(hgmm_ctx* ctx, int k, const double* centers, int reset_labe
                      double* inertia_out, int64_t* n_changed_out);
 int hgmm_kmeans_labels(hgmm_ctx* ctx, int32_t* labels_out, double* min_dist2_out);
 
+/* ---- L2 GMMReg: Gauss transform (float64) ---------------------------------------------
+ * out[k, i] = sum_j weights[k, j] exp(-|points_i - centres_j|^2 / h^2),  k < n_weights <= 8
+ * = GaussTransform(centres, h).compute(points, weights) of gmmreg_gpu/transforms.py:43-86, which
+ * cost_functions.py:29-40 evaluates with the target means as centres, the transformed source means
+ * as points, h = sqrt(2) sigma and the weight rows phi_t / z, phi_t mu_t / z (one call = the value
+ * and the gradient of the L2 cost).  Host arrays in and out (mixture sizes).                    */
+int hgmm_gauss_transform(hgmm_ctx* ctx, const double* centres, int n_centres, const double* points,
+                         int n_points, const double* weights, int n_weights, double h, double* out);
+
 /* ---- multi-GPU: one context per rank, RCCL over xGMI --------------------------------
  * New functionality (the reference is single-GPU).  With a communicator attached,
  * hgmm_flat_train*, hgmm_flat_stats and hgmm_tree_build all-reduce their per-cluster
