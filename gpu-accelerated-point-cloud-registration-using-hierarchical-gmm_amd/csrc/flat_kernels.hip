@@ -1389,6 +1389,10 @@ static int launch_fused(hgmm_ctx* c, const int* done_flag, int* grid_out, int* v
     //  * wave-uniform skipping of 64-component slots whose responsibilities are all < 1e-10
     //    never triggers while components are broad: 0 % gain.
     const bool paired = env_flag("HGMM_FUSED_PK", true);
+    //  * two rows in flight in the constant-shift kernel (differences recomputed instead of kept, so that
+    //    only the exponentials of a row live between its phases): 216 instead of 221 instructions per row,
+    //    but 256 VGPRs + 4 AGPRs = one wave per SIMD, 0.46 - 0.48 ms; forced to two waves per SIMD it
+    //    spills 372 B per lane, 0.43 ms; one row (248 VGPRs, two waves per SIMD) stays the best, 0.405 ms;
     //  * constant-shift log-sum-exp (HGMM_FUSED_CS, default on): see flat_fused_pk_kernel;
     //    0.514 -> 0.440 ms.  The same change in the materialising E-step kernel gains nothing
     //    (0.56 - 0.62 ms either way: that kernel is bound by the HBM write path, not by VALU).
