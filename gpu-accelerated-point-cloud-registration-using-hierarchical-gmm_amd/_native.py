@@ -100,6 +100,7 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_comm_unique_id", [_vp])
         _sig(lib, "hgmm_comm_init_rank", [ctx, C.c_int, C.c_int, _vp])
         _sig(lib, "hgmm_comm_destroy", [ctx])
+        _sig(lib, "hgmm_comm_init_host", [ctx, C.c_int, C.c_int, C.c_char_p])
         _sig(lib, "hgmm_comm_allreduce_f64", [ctx, _vp, C.c_int, C.c_int])
         _sig(lib, "hgmm_profile_enable", [ctx, C.c_int])
         _sig(lib, "hgmm_profile_reset", [ctx])
@@ -549,6 +550,11 @@ class Context:
     def comm_init(self, nranks, rank, unique_id: bytes):
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._check(self.lib.hgmm_comm_init_rank(self.h, int(nranks), int(rank), buf))
+        self.nranks, self.rank = int(nranks), int(rank)
+
+    def comm_init_host(self, nranks, rank, name: str):
+        """Host shared-memory communicator (tests on a single-GPU box; see include/hgmm.h)."""
+        self._check(self.lib.hgmm_comm_init_host(self.h, int(nranks), int(rank), name.encode()))
         self.nranks, self.rank = int(nranks), int(rank)
 
     def comm_destroy(self):

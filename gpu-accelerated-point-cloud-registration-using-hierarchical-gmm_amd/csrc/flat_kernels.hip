@@ -1445,7 +1445,7 @@ static int launch_reduce(hgmm_ctx* c, int nblocks, int valid_j, bool with_lpn, c
         n_lpn_blocks < 0 ? nblocks : n_lpn_blocks, valid_j, f.Jpad, (double)c->n, c->f_stats.as<double>(),
         done_flag);
     HGMM_HIP(c, hipGetLastError());
-    if (c->comm) HGMM_TRY(allreduce_f64_dev(c, c->f_stats.as<double>(), (size_t)total + 2));
+    if (c->comm_on()) HGMM_TRY(allreduce_f64_dev(c, c->f_stats.as<double>(), (size_t)total + 2));
     return HGMM_OK;
 }
 

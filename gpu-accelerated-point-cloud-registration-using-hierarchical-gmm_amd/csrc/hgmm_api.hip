@@ -2,8 +2,18 @@
 // behind the C ABI of include/hgmm.h.
 #include "hgmm_ctx.h"
 
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 namespace hgmm {
 
@@ -55,9 +65,87 @@ int profile_collect(hgmm_ctx* c) {
     return HGMM_OK;
 }
 
+// ---- host shared-memory communicator ----------------------------------------------------------
+// A second backend behind the same all-reduce call sites, for exercising the N > 1 data path on a box
+// with ONE GPU (RCCL refuses two ranks on one device): the ranks are processes of one machine, every
+// all-reduce goes device -> POSIX shared memory -> summed in rank order -> device.  Deterministic,
+// slow, not a performance path.
+struct HostCommShm {
+    std::atomic<int> ready;
+    std::atomic<int> count;
+    std::atomic<int> generation;
+    int nranks;
+    size_t slot_doubles;
+};
+struct HostComm {
+    HostCommShm* shm = nullptr;
+    double* data = nullptr;          // [nranks][slot_doubles]
+    size_t bytes = 0;
+    std::string name;
+    bool owner = false;
+    std::vector<double> tmp;
+};
+constexpr size_t HOSTCOMM_SLOT = 1u << 18;       // doubles per rank and round
+constexpr int HOSTCOMM_TIMEOUT_S = 120;
+
+static int hostcomm_barrier(hgmm_ctx* c) {
+    HostCommShm* s = c->hcomm->shm;
+    const int gen = s->generation.load(std::memory_order_acquire);
+    if (s->count.fetch_add(1, std::memory_order_acq_rel) + 1 == s->nranks) {
+        s->count.store(0, std::memory_order_relaxed);
+        s->generation.store(gen + 1, std::memory_order_release);
+        return HGMM_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    while (s->generation.load(std::memory_order_acquire) == gen) {
+        sched_yield();
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(HOSTCOMM_TIMEOUT_S))
+            return fail(c, HGMM_ERR_STATE, "host communicator: barrier timed out (a peer rank is gone?)");
+    }
+    return HGMM_OK;
+}
+
+// in place on a DEVICE buffer (op 0 sum, 1 max), ranks combined in rank order
+static int hostcomm_allreduce_dev(hgmm_ctx* c, double* dev, size_t n, int op) {
+    HostComm* h = c->hcomm;
+    const int R = h->shm->nranks;
+    for (size_t off = 0; off < n; off += HOSTCOMM_SLOT) {
+        const size_t cnt = std::min(HOSTCOMM_SLOT, n - off);
+        double* mine = h->data + (size_t)c->rank * HOSTCOMM_SLOT;
+        HGMM_HIP(c, hipMemcpyAsync(mine, dev + off, sizeof(double) * cnt, hipMemcpyDeviceToHost, c->stream));
+        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+        HGMM_TRY(hostcomm_barrier(c));
+        h->tmp.resize(cnt);
+        for (size_t i = 0; i < cnt; ++i) {
+            double acc = h->data[i];
+            for (int r = 1; r < R; ++r) {
+                const double v = h->data[(size_t)r * HOSTCOMM_SLOT + i];
+                acc = op == 1 ? (v > acc ? v : acc) : acc + v;
+            }
+            h->tmp[i] = acc;
+        }
+        HGMM_TRY(hostcomm_barrier(c));                     // everybody has read the slots
+        HGMM_HIP(c, hipMemcpyAsync(dev + off, h->tmp.data(), sizeof(double) * cnt, hipMemcpyHostToDevice, c->stream));
+        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return HGMM_OK;
+}
+
+static void hostcomm_close(hgmm_ctx* c) {
+    HostComm* h = c->hcomm;
+    if (!h) return;
+    if (h->shm) munmap(h->shm, h->bytes);
+    if (h->owner) shm_unlink(h->name.c_str());
+    delete h;
+    c->hcomm = nullptr;
+}
+
 int allreduce_f64_dev(hgmm_ctx* c, double* dev, size_t n) {
-    if (!c->comm) return HGMM_OK;
-    HGMM_NCCL(c, ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, c->comm, c->stream));
+    if (c->comm) {
+        HGMM_NCCL(c, ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, c->comm, c->stream));
+        return HGMM_OK;
+    }
+    if (c->hcomm) return hostcomm_allreduce_dev(c, dev, n, 0);
     return HGMM_OK;
 }
 
@@ -210,6 +298,7 @@ extern "C" int hgmm_destroy(hgmm_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
+    hostcomm_close(c);
     DevBuf* bufs[] = {&c->x_aos, &c->x_soa64, &c->f_mu, &c->f_cov, &c->f_w, &c->f_inv, &c->f_pack,
                       &c->f_partials, &c->f_lpn_partials, &c->f_stats, &c->f_lls, &c->f_ctl, &c->f_hint,
                       &c->scratch, &c->t_pi, &c->t_mu, &c->t_cov, &c->t_prep, &c->t_cplx, &c->t_mom,
@@ -326,7 +415,7 @@ extern "C" int hgmm_comm_unique_id(void* id128_out) {
 extern "C" int hgmm_comm_init_rank(hgmm_ctx* c, int nranks, int rank, const void* id128) {
     if (!c || !id128) return HGMM_ERR_ARG;
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(c, HGMM_ERR_ARG, "bad rank %d / %d", rank, nranks);
-    if (c->comm) return fail(c, HGMM_ERR_STATE, "communicator already attached");
+    if (c->comm_on()) return fail(c, HGMM_ERR_STATE, "communicator already attached");
     HGMM_HIP(c, hipSetDevice(c->device));
     ncclUniqueId id;
     memcpy(&id, id128, sizeof id);
@@ -336,8 +425,74 @@ extern "C" int hgmm_comm_init_rank(hgmm_ctx* c, int nranks, int rank, const void
     return HGMM_OK;
 }
 
+extern "C" int hgmm_comm_init_host(hgmm_ctx* c, int nranks, int rank, const char* name) {
+    if (!c || !name || !name[0]) return c ? fail(c, HGMM_ERR_ARG, "host communicator: name is empty") : HGMM_ERR_ARG;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(c, HGMM_ERR_ARG, "bad rank %d / %d", rank, nranks);
+    if (c->comm_on()) return fail(c, HGMM_ERR_STATE, "communicator already attached");
+    HostComm* h = new HostComm;
+    h->name = std::string("/") + name;
+    h->bytes = sizeof(HostCommShm) + 64 + sizeof(double) * HOSTCOMM_SLOT * (size_t)nranks;
+    h->owner = rank == 0;
+    int fd = -1;
+    if (rank == 0) {
+        shm_unlink(h->name.c_str());
+        fd = shm_open(h->name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd >= 0 && ftruncate(fd, (off_t)h->bytes) != 0) { close(fd); fd = -1; }
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (fd < 0) {
+            fd = shm_open(h->name.c_str(), O_RDWR, 0600);
+            struct stat st;
+            if (fd >= 0 && (fstat(fd, &st) != 0 || (size_t)st.st_size < h->bytes)) { close(fd); fd = -1; }
+            if (fd < 0) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(HOSTCOMM_TIMEOUT_S)) break;
+                usleep(1000);
+            }
+        }
+    }
+    if (fd < 0) { delete h; return fail(c, HGMM_ERR_STATE, "host communicator: cannot open shared memory %s", name); }
+    void* p = mmap(nullptr, h->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) { delete h; return fail(c, HGMM_ERR_STATE, "host communicator: mmap failed"); }
+    h->shm = static_cast<HostCommShm*>(p);
+    h->data = reinterpret_cast<double*>(static_cast<char*>(p) + ((sizeof(HostCommShm) + 63) / 64) * 64);
+    if (rank == 0) {
+        h->shm->count.store(0);
+        h->shm->generation.store(0);
+        h->shm->nranks = nranks;
+        h->shm->slot_doubles = HOSTCOMM_SLOT;
+        h->shm->ready.store(1, std::memory_order_release);
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (h->shm->ready.load(std::memory_order_acquire) != 1) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(HOSTCOMM_TIMEOUT_S)) {
+                munmap(p, h->bytes);
+                delete h;
+                return fail(c, HGMM_ERR_STATE, "host communicator: rank 0 never initialised %s", name);
+            }
+            usleep(1000);
+        }
+        if (h->shm->nranks != nranks) {
+            munmap(p, h->bytes);
+            delete h;
+            return fail(c, HGMM_ERR_ARG, "host communicator: world size mismatch");
+        }
+    }
+    c->hcomm = h;
+    c->nranks = nranks;
+    c->rank = rank;
+    return hostcomm_barrier(c);
+}
+
 extern "C" int hgmm_comm_destroy(hgmm_ctx* c) {
     if (!c) return HGMM_ERR_ARG;
+    if (c->hcomm) {
+        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+        (void)hostcomm_barrier(c);                          // nobody unlinks while a peer still reduces
+        hostcomm_close(c);
+        c->nranks = 1;
+        c->rank = 0;
+    }
     if (c->comm) {
         HGMM_HIP(c, hipStreamSynchronize(c->stream));
         HGMM_NCCL(c, ncclCommDestroy(c->comm));
@@ -350,11 +505,14 @@ extern "C" int hgmm_comm_destroy(hgmm_ctx* c) {
 
 extern "C" int hgmm_comm_allreduce_f64(hgmm_ctx* c, double* host_inout, int n, int op) {
     if (!c || !host_inout || n < 1) return HGMM_ERR_ARG;
-    if (!c->comm) return HGMM_OK;   // single rank: identity
+    if (!c->comm_on()) return HGMM_OK;   // single rank: identity
     HGMM_TRY(ensure(c, c->comm_buf, sizeof(double) * (size_t)n));
     HGMM_HIP(c, hipMemcpyAsync(c->comm_buf.p, host_inout, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-    HGMM_NCCL(c, ncclAllReduce(c->comm_buf.p, c->comm_buf.p, (size_t)n, ncclDouble,
-                               op == 1 ? ncclMax : ncclSum, c->comm, c->stream));
+    if (c->hcomm)
+        HGMM_TRY(hostcomm_allreduce_dev(c, c->comm_buf.as<double>(), (size_t)n, op));
+    else
+        HGMM_NCCL(c, ncclAllReduce(c->comm_buf.p, c->comm_buf.p, (size_t)n, ncclDouble,
+                                   op == 1 ? ncclMax : ncclSum, c->comm, c->stream));
     HGMM_HIP(c, hipMemcpyAsync(host_inout, c->comm_buf.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
     HGMM_HIP(c, hipStreamSynchronize(c->stream));
     return HGMM_OK;

@@ -38,6 +38,8 @@ struct FlatState {
     int nchunks = 1;
 };
 
+struct HostComm;                           // hgmm_api.hip
+
 struct TreeState {
     int L = 0;
     int T = 0;
@@ -106,9 +108,11 @@ struct hgmm_ctx {
     hgmm::DevBuf gt_buf;                      // double: centres, points, weights, per-split partial sums
 
     // ---- multi-GPU --------------------------------------------------------------
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;                // RCCL over xGMI (one GPU per rank)
+    hgmm::HostComm* hcomm = nullptr;          // host shared-memory communicator (tests: ranks may share a GPU)
     int nranks = 1, rank = 0;
     hgmm::DevBuf comm_buf;
+    bool comm_on() const { return comm != nullptr || hcomm != nullptr; }
 
     // ---- profiling --------------------------------------------------------------
     bool profiling = false;

@@ -517,7 +517,7 @@ extern "C" int hgmm_kmeans_step(hgmm_ctx* c, int k, const double* centers, int r
     kmeans_reduce_kernel<<<km_nblk(4 * (int64_t)k, 32), KM_BLOCK, 0, c->stream>>>(
         c->km_partial.as<double>(), nb_acc, k_alloc, k, inertia_part, nb_assign, changed, out);
     HGMM_HIP(c, hipGetLastError());
-    if (c->comm) HGMM_TRY(allreduce_f64_dev(c, out, 4 * (size_t)k + 2));
+    if (c->comm_on()) HGMM_TRY(allreduce_f64_dev(c, out, 4 * (size_t)k + 2));
     std::vector<double> tail(2);
     if (sums_out) HGMM_HIP(c, hipMemcpyAsync(sums_out, out, sizeof(double) * 4 * k, hipMemcpyDeviceToHost, c->stream));
     HGMM_HIP(c, hipMemcpyAsync(tail.data(), out + 4 * (size_t)k, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));

@@ -753,7 +753,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
 
     // global point count (pi = m0 / N_total)
     double n_total = (double)n;
-    if (c->comm) {
+    if (c->comm_on()) {
         HGMM_TRY(hgmm_comm_allreduce_f64(c, &n_total, 1, 0));
     }
 
@@ -801,7 +801,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
         // iterations enqueued past the stop return immediately.  With a communicator every iteration
         // is synchronised (the all-reduces in between are not predicated).
         HGMM_HIP(c, hipMemsetAsync(ctl, 0, sizeof(TreeCtl), c->stream));
-        const int batch = c->comm ? 1 : batch_iters;
+        const int batch = c->comm_on() ? 1 : batch_iters;
         int it = 0;
         bool done = false;
         while (!done) {
@@ -815,9 +815,9 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                 // single GPU: reduction, M-step and preparation of a node in one launch; with a
                 // communicator the all-reduce of the moments sits between reduction and M-step
                 tree_moments_kernel<<<n_level, 64, 0, c->stream>>>(partials, chunk_first, n_level, d_mom + NMOM * lb,
-                                                                   c->comm ? 0 : 1, lb, n_total, ld, d_pi, d_mu, d_cov,
+                                                                   c->comm_on() ? 0 : 1, lb, n_total, ld, d_pi, d_mu, d_cov,
                                                                    d_prep, &ctl->done);
-                if (c->comm) {
+                if (c->comm_on()) {
                     rc = allreduce_f64_dev(c, d_mom + NMOM * lb, (size_t)NMOM * n_level);
                     if (rc != HGMM_OK) break;
                     tree_mstep_kernel<<<nblk(n_level, 256), 256, 0, c->stream>>>(d_mom + NMOM * lb, lb, n_level,
@@ -837,7 +837,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                         tree_loglik_finish_kernel<<<pblocks, CH, 0, c->stream>>>(ll_partial, n, n_pad, chunks, block_q,
                                                                                 q_ticket, q_dev, &ctl->done);
                 }
-                if (c->comm) {
+                if (c->comm_on()) {
                     rc = allreduce_f64_dev(c, q_dev, 1);
                     if (rc != HGMM_OK) break;
                 }
@@ -949,7 +949,7 @@ extern "C" int hgmm_tree_reg_estep(hgmm_ctx* c, const double* rot, const double*
                                                                         lambda_c, mom);
     }
     HGMM_HIP(c, hipGetLastError());
-    if (c->comm) HGMM_TRY(allreduce_f64_dev(c, mom, (size_t)NMOM * T));
+    if (c->comm_on()) HGMM_TRY(allreduce_f64_dev(c, mom, (size_t)NMOM * T));
     HGMM_TRY(ensure(c, c->scratch, sizeof(double) * 13 * T));
     double* e0 = c->scratch.as<double>();
     double* e1 = e0 + T;
@@ -1180,7 +1180,7 @@ static int fullcov_moments(hgmm_ctx* c, int J, int J16, int grid) {
     }
     full_reduce_kernel<<<J, 64, 0, c->stream>>>(c->t_partials.as<double>(), grid, J, J16, c->t_mom.as<double>());
     HGMM_HIP(c, hipGetLastError());
-    if (c->comm) HGMM_TRY(allreduce_f64_dev(c, c->t_mom.as<double>(), (size_t)NMOM * J));
+    if (c->comm_on()) HGMM_TRY(allreduce_f64_dev(c, c->t_mom.as<double>(), (size_t)NMOM * J));
     return HGMM_OK;
 }
 
@@ -1195,7 +1195,7 @@ static int fullcov_pass(hgmm_ctx* c, int J, int* labels, double* q_host) {
     }
     tree_sum_kernel<<<1, 256, 0, c->stream>>>(block_q, (int)nblk(c->n, CH), q_dev);
     HGMM_HIP(c, hipGetLastError());
-    if (c->comm) HGMM_TRY(allreduce_f64_dev(c, q_dev, 1));
+    if (c->comm_on()) HGMM_TRY(allreduce_f64_dev(c, q_dev, 1));
     if (q_host) {
         HGMM_HIP(c, hipMemcpyAsync(q_host, q_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HGMM_HIP(c, hipStreamSynchronize(c->stream));
@@ -1225,7 +1225,7 @@ extern "C" int hgmm_fullcov_fit(hgmm_ctx* c, int J, double ls, double ld, const 
     full_init_nodes_kernel<<<nblk(J16, 256), 256, 0, c->stream>>>(c->scratch.as<double>(), sig2, J, J16, d_pi, d_mu, d_cov);
     tree_prep_kernel<<<nblk(J16, 256), 256, 0, c->stream>>>(d_pi, d_mu, d_cov, 0, J16, d_prep);
     double n_total = (double)c->n;
-    if (c->comm) HGMM_TRY(hgmm_comm_allreduce_f64(c, &n_total, 1, 0));
+    if (c->comm_on()) HGMM_TRY(hgmm_comm_allreduce_f64(c, &n_total, 1, 0));
     // E-step quantities of the initial parameters
     HGMM_TRY(fullcov_pass(c, J, lab_a, nullptr));
     int* lab_cur = lab_a;      // arg-max of the most recent E-step
@@ -1418,7 +1418,7 @@ extern "C" int hgmm_tree_estep(hgmm_ctx* c, int64_t T, const double* pi, const d
                                                                        c->t_prep.as<double>(), par, T, mom, cur);
     }
     HGMM_HIP(c, hipGetLastError());
-    if (c->comm) HGMM_TRY(allreduce_f64_dev(c, mom, (size_t)NMOM * T));
+    if (c->comm_on()) HGMM_TRY(allreduce_f64_dev(c, mom, (size_t)NMOM * T));
     HGMM_TRY(ensure(c, c->scratch, sizeof(double) * 13 * T));
     double* e0 = c->scratch.as<double>();
     double* e1 = e0 + T;
@@ -1483,7 +1483,7 @@ extern "C" int hgmm_tree_loglik(hgmm_ctx* c, int64_t T, const double* pi, const 
     }
     tree_sum_kernel<<<1, 256, 0, c->stream>>>(block_q, pblocks, q_dev);
     HGMM_HIP(c, hipGetLastError());
-    if (c->comm) HGMM_TRY(allreduce_f64_dev(c, q_dev, 1));
+    if (c->comm_on()) HGMM_TRY(allreduce_f64_dev(c, q_dev, 1));
     HGMM_HIP(c, hipMemcpyAsync(q_out, q_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HGMM_HIP(c, hipStreamSynchronize(c->stream));
     return HGMM_OK;

@@ -230,6 +230,11 @@ int hgmm_gauss_transform(hgmm_ctx* ctx, const double* centres, int n_centres, co
 int hgmm_comm_unique_id(void* id128_out);                       /* 128 bytes */
 int hgmm_comm_init_rank(hgmm_ctx* ctx, int nranks, int rank, const void* id128);
 int hgmm_comm_destroy(hgmm_ctx* ctx);
+/* Test backend behind the same all-reduce call sites: the ranks are processes of ONE machine that
+ * meet in the POSIX shared-memory object `name` (they may share a GPU, which RCCL does not allow), every
+ * all-reduce goes device -> host -> summed in rank order -> device.  For exercising the N > 1 path on a
+ * single-GPU box; not a performance path.                                                          */
+int hgmm_comm_init_host(hgmm_ctx* ctx, int nranks, int rank, const char* name);
 int hgmm_comm_allreduce_f64(hgmm_ctx* ctx, double* host_inout, int n, int op /*0 sum,1 max*/);
 
 /* ---- profiling (hipEvent pairs around the hot kernels, on the context's stream) ---- */
