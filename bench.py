@@ -202,9 +202,14 @@ def main():
         args.gpus = world
 
     import hgmm_amd
-    ctx = hgmm_amd.Context(local_rank)
+    # HGMM_BENCH_HOSTCOMM=<name> (+ HGMM_BENCH_DEVICE): rehearsal of the N > 1 flow on a single-GPU box --
+    # all ranks on one device, joined by the host shared-memory backend instead of RCCL.  Not a measurement.
+    rehearsal = os.environ.get("HGMM_BENCH_HOSTCOMM")
+    ctx = hgmm_amd.Context(int(os.environ.get("HGMM_BENCH_DEVICE", local_rank)) if rehearsal else local_rank)
     info = ctx.device_info()
-    if world > 1:
+    if world > 1 and rehearsal:
+        ctx.comm_init_host(world, rank, rehearsal)
+    elif world > 1:
         # RCCL communicator; the 128-byte unique id travels through the launcher's rendezvous
         from hgmm_amd import parallel
         parallel.attach_communicator(ctx, rank, world, transport="torch")
@@ -256,7 +261,9 @@ def main():
                                    "tol=0; N>1: frames are shards of one joint fit, RCCL all-reduce of "
                                    "(7J+2) f64 sufficient statistics per iteration",
                        "points_per_gpu": N_POINTS, "components": J_COMP, "cov_type": "diag",
-                       "device": info["name"], "compute_units": info["compute_units"]},
+                       "device": info["name"], "compute_units": info["compute_units"],
+                       **({"rehearsal": "all ranks on ONE device, host shared-memory all-reduce -- flow check, "
+                                        "not a measurement"} if rehearsal else {})},
             "fused_kernel": {"avg_ms": fused_avg_ms, "launches": fused_n,
                              "pairs_per_s": pairs / (fused_avg_ms * 1e-3) if fused_avg_ms else None,
                              "last_lls": float(lls[-1])},
