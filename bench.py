@@ -63,7 +63,8 @@ def cpu_baseline_main(sample_n=200_000, iters=10):
     blas_threads = None
     try:                                   # threads the GEMMs actually ran on (elementwise passes are 1 thread)
         from threadpoolctl import threadpool_info
-        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        pools = [p for p in threadpool_info() if p.get("user_api") == "blas"] or threadpool_info()
+        blas_threads = max([p.get("num_threads", 1) for p in pools] or [1])
     except Exception:
         pass
     return {
