@@ -295,7 +295,9 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_kernel(
 // Measured (kbench, N = 1e6, J = 800, same box): single-row kernel, 2 workgroups/CU 0.672 ms;
 // 6 rows unpaired 0.603 ms; paired 4 / 6 / 8 rows 0.546 / 0.561 / 0.604 ms.  What counts is the number
 // of waves writing at once: 1024 waves (4 per workgroup, 1 workgroup per CU) 0.54 - 0.56 ms, 2048 waves
-// 0.65 ms whether as 8 waves per workgroup or as 2 workgroups per CU, with 2 or 4 rows each.
+// 0.65 ms whether as 8 waves per workgroup or as 2 workgroups per CU, with 2 or 4 rows each.  The 4 rows of a
+// wave must be consecutive (one 12.8 KB run): dealing single rows round-robin over the waves (each wave's 4
+// rows 3.2 MB apart) drops to 0.86 ms.
 // ------------------------------------------------------------------------------------------
 template <int NV4, int NV1, int ROWS, bool NT>
 __global__ __launch_bounds__(BLOCK) void flat_estep_rows_pk_kernel(
