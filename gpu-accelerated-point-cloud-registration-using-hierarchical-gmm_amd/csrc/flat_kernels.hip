@@ -24,6 +24,8 @@
 #include "hgmm_ctx.h"
 #include "wave_ops.h"
 
+#include <type_traits>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -562,14 +564,14 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_kernel(
 // zero is < 2^(M0 - 126), i.e. < 1e-19 relative to the eps = 1e-8 of the reference's normaliser
 // while M0 <= CS_MAX_SHIFT, and the denominator stays >= eps 2^-M0 >> FLT_MIN.  A model with a
 // larger M0 (sigma < ~1e-7: only the clipped-covariance flavour can get there) is served by the
-// row-maximum variant: both are launched, each decides from the table which of the two runs.
+// row-maximum loop of the same kernel: every wave derives the same M0 from the table and picks its loop.
 constexpr float CS_MAX_SHIFT = 60.0f;
 
-template <int NSLOT, bool CS>
+template <int NSLOT>
 __global__ __launch_bounds__(BLOCK) void flat_fused_pk_kernel(
     const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int J, int Jpad,
     float* __restrict__ partials, double* __restrict__ lpn_partials,
-    const int* __restrict__ done_flag, int only_if_large_shift) {
+    const int* __restrict__ done_flag, int allow_const_shift) {
     if (done_flag && *done_flag) return;
     constexpr int K = NSLOT;
     constexpr int KP = K / 2;          // full pairs
@@ -603,19 +605,21 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_pk_kernel(
 #pragma unroll
     for (int p = 0; p < KP; ++p) m0 = fmaxf(m0, fmaxf(cc[p].x, cc[p].y));
     m0 = wave_reduce(m0, OpMax());
-    const bool small_shift = m0 <= CS_MAX_SHIFT;          // false for NaN as well
-    if (CS && !small_shift) return;                        // -> the row-maximum variant
-    if (!CS && only_if_large_shift && small_shift) return; // -> the constant-shift variant
+    const bool small_shift = allow_const_shift && m0 <= CS_MAX_SHIFT;   // false for NaN as well
+
+    int64_t r0, r1;
+    wave_row_range(n, r0, r1);
+    double lsum = 0.0;
+    // the row loop exists twice in this kernel, once per log-sum-exp variant; the choice is uniform
+    // over the whole grid (every wave derives the same m0 from the table)
+    auto rows = [&](auto cs_tag) {
+    constexpr bool CS = decltype(cs_tag)::value;
     if (CS) {
         const f2 M0 = f2{m0, m0};
 #pragma unroll
         for (int p = 0; p < KP; ++p) cc[p] = cc[p] - M0;
         cs -= m0;
     }
-
-    int64_t r0, r1;
-    wave_row_range(n, r0, r1);
-    double lsum = 0.0;
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
     if (r0 < r1) { const float* xp = X + 3 * r0; x0 = xp[0]; x1 = xp[1]; x2 = xp[2]; }
     for (int64_t row = r0; row < r1; ++row) {
@@ -690,6 +694,9 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_pk_kernel(
         }
         x0 = nx0; x1 = nx1; x2 = nx2;
     }
+    };
+    if (small_shift) rows(std::true_type{});
+    else rows(std::false_type{});
 
     __shared__ float sh[FLAT_NSTAT * NSLOT * 64];
     __shared__ double shl[WAVES_PER_BLOCK];
@@ -1401,14 +1408,9 @@ static int launch_fused(hgmm_ctx* c, const int* done_flag, int* grid_out, int* v
     const bool cshift = env_flag("HGMM_FUSED_CS", true);
 #define FUSED_CASE(S)                                                                           \
     do {                                                                                        \
-        if (paired && cshift) {                                                                 \
-            flat_fused_pk_kernel<S, true><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, \
-                                                                        part, lp, done_flag, 0);  \
-            flat_fused_pk_kernel<S, false><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, \
-                                                                         part, lp, done_flag, 1); \
-        } else if (paired)                                                                      \
-            flat_fused_pk_kernel<S, false><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, \
-                                                                         part, lp, done_flag, 0); \
+        if (paired)                                                                             \
+            flat_fused_pk_kernel<S><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, part,  \
+                                                                  lp, done_flag, cshift ? 1 : 0); \
         else                                                                                    \
             flat_fused_kernel<S><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, part,   \
                                                                lp, done_flag);                 \
