@@ -56,7 +56,7 @@ def main():
     if res:
         e_f, e_w = kb("FETCH_SIZE", "flat_estep_rows_pk_kernel"), kb("WRITE_SIZE", "flat_estep_rows_pk_kernel")
         m_f, m_w = kb("FETCH_SIZE", "flat_mstep_kernel"), kb("WRITE_SIZE", "flat_mstep_kernel")
-        f_f, f_w = kb("FETCH_SIZE", "flat_fused_pk_kernel<13, true>"), kb("WRITE_SIZE", "flat_fused_pk_kernel<13, true>")
+        f_f, f_w = kb("FETCH_SIZE", "flat_fused_pk_kernel<13>"), kb("WRITE_SIZE", "flat_fused_pk_kernel<13>")
         summary = {
             "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 4 "
                       "--warmup 1 --estep-reps 3 --no-cpu-baseline` (tools/profile_round.sh); counters are KB; per "
