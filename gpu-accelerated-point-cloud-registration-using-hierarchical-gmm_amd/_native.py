@@ -96,6 +96,8 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_kmeans_plusplus", [ctx, C.c_int, C.c_int64, _vp, C.c_int, _vp, _vp])
         _sig(lib, "hgmm_kmeans_step", [ctx, C.c_int, _vp, C.c_int, _vp, _f64p, C.POINTER(C.c_int64)])
         _sig(lib, "hgmm_kmeans_labels", [ctx, _vp, _vp])
+        _sig(lib, "hgmm_kmeans_lloyd", [ctx, C.c_int, _vp, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int), C.POINTER(C.c_int), _vp, C.POINTER(C.c_int64)])
         _sig(lib, "hgmm_gauss_transform", [ctx, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_double, _vp])
         _sig(lib, "hgmm_comm_unique_id", [_vp])
         _sig(lib, "hgmm_comm_init_rank", [ctx, C.c_int, C.c_int, _vp])
@@ -515,6 +517,20 @@ class Context:
         self._check(self.lib.hgmm_kmeans_step(self.h, k, _ptr(centres), int(bool(reset_labels)), _ptr(sums),
                                               C.byref(inertia), C.byref(changed)))
         return sums[:, :3].copy(), sums[:, 3].copy(), inertia.value, changed.value
+
+    def kmeans_lloyd(self, centres, max_iter, tol_abs, reset_labels=True):
+        """Device-resident Lloyd loop.  Returns (centres, n_iter, strict, pending) where ``pending`` is None
+        or, when an iteration met an empty cluster, that iteration's (sums[k,3], counts[k], n_changed)."""
+        centres = np.array(centres, dtype=np.float64).reshape(-1, 3)
+        k = len(centres)
+        n_iter, strict, needs = C.c_int(), C.c_int(), C.c_int()
+        sums = np.empty((k, 4))
+        changed = C.c_int64()
+        self._check(self.lib.hgmm_kmeans_lloyd(self.h, k, _ptr(centres), int(max_iter), float(tol_abs),
+                                               int(bool(reset_labels)), C.byref(n_iter), C.byref(strict),
+                                               C.byref(needs), _ptr(sums), C.byref(changed)))
+        pending = (sums[:, :3].copy(), sums[:, 3].copy(), changed.value) if needs.value else None
+        return centres, n_iter.value, bool(strict.value), pending
 
     def kmeans_labels(self, with_distances=False):
         labels = np.empty(self.num_points, np.int32)

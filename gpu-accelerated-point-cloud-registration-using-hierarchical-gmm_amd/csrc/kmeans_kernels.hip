@@ -260,7 +260,8 @@ __global__ __launch_bounds__(KM_BLOCK) void kmpp_update_kernel(const double* __r
 __global__ __launch_bounds__(KM_BLOCK) void kmeans_assign_kernel(
     const double* __restrict__ xs, int64_t n, int64_t n_pad, const double* __restrict__ c4, int k,
     int32_t* __restrict__ labels, double* __restrict__ mind2, double* __restrict__ inertia_part,
-    unsigned long long* __restrict__ n_changed) {
+    unsigned long long* __restrict__ n_changed, const int* __restrict__ done) {
+    if (done && *done) return;
     __shared__ double sh[4];
     __shared__ int shc[4];
     const int64_t i0 = (int64_t)blockIdx.x * (2 * KM_BLOCK) + threadIdx.x;
@@ -312,7 +313,9 @@ __global__ __launch_bounds__(KM_BLOCK) void kmeans_accum_kernel(const double* __
                                                                 int64_t n_pad,
                                                                 const int32_t* __restrict__ labels,
                                                                 int slot0, int k_alloc,
-                                                                double* __restrict__ partial) {
+                                                                double* __restrict__ partial,
+                                                                const int* __restrict__ done) {
+    if (done && *done) return;
     __shared__ double sh[4][64][4];
     const int lane = lane_id(), wave = wave_in_block();
     double ax[NSLOT], ay[NSLOT], az[NSLOT], ac[NSLOT];
@@ -364,7 +367,9 @@ __global__ __launch_bounds__(KM_BLOCK) void kmeans_reduce_kernel(const double* _
                                                                  const double* __restrict__ inertia_part,
                                                                  int nib,
                                                                  const unsigned long long* __restrict__ n_changed,
-                                                                 double* __restrict__ out) {
+                                                                 double* __restrict__ out,
+                                                                 const int* __restrict__ done) {
+    if (done && *done) return;
     __shared__ double sh[8][32];
     __shared__ double shi[4];
     const int e_loc = threadIdx.x & 31, slice = threadIdx.x >> 5;
@@ -394,7 +399,9 @@ __global__ __launch_bounds__(KM_BLOCK) void kmeans_reduce_kernel(const double* _
     }
 }
 
-__global__ void kmeans_pad_centres_kernel(const double* __restrict__ c3, int k, double* __restrict__ c4) {
+__global__ void kmeans_pad_centres_kernel(const double* __restrict__ c3, int k, double* __restrict__ c4,
+                                          const int* __restrict__ done) {
+    if (done && *done) return;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= k) return;
     c4[4 * j] = c3[3 * j];
@@ -406,6 +413,47 @@ __global__ void kmeans_pad_centres_kernel(const double* __restrict__ c3, int k, 
 __global__ void kmeans_reset_labels_kernel(int32_t* __restrict__ labels, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) labels[i] = -1;
+}
+
+// Device-side tail of one Lloyd iteration (scikit-learn's _kmeans_single_lloyd, lines after lloyd_iter):
+// centres = sums * (1 / count), summed squared centre shift, then the stop rules in scikit-learn's order --
+// unchanged labels (strict), shift <= tol, iteration budget.  An empty cluster hands the iteration to the host
+// (relocation needs argpartition over all points): needs_host is raised and nothing is updated.
+struct KmCtl { int done, it, strict, needs_host; unsigned long long pad; };
+__global__ __launch_bounds__(256) void kmeans_update_kernel(const double* __restrict__ out, int k, double tol_abs,
+                                                            int max_iter, double* __restrict__ c3,
+                                                            unsigned long long* __restrict__ changed,
+                                                            KmCtl* __restrict__ ctl) {
+    if (ctl->done) return;
+    __shared__ double sh[4];
+    __shared__ int sh_empty;
+    if (threadIdx.x == 0) sh_empty = 0;
+    __syncthreads();
+    int empty = 0;
+    for (int j = threadIdx.x; j < k; j += 256) empty |= out[4 * j + 3] == 0.0;
+    if (empty) sh_empty = 1;
+    __syncthreads();
+    if (sh_empty) {
+        if (threadIdx.x == 0) { ctl->needs_host = 1; ctl->done = 1; }
+        return;
+    }
+    double shift = 0.0;
+    for (int j = threadIdx.x; j < k; j += 256) {
+        const double alpha = 1.0 / out[4 * j + 3];
+        const double n0 = out[4 * j] * alpha, n1 = out[4 * j + 1] * alpha, n2 = out[4 * j + 2] * alpha;
+        const double d0 = n0 - c3[3 * j], d1 = n1 - c3[3 * j + 1], d2 = n2 - c3[3 * j + 2];
+        const double nrm = sqrt((d0 * d0 + d1 * d1) + d2 * d2);
+        shift += nrm * nrm;
+        c3[3 * j] = n0; c3[3 * j + 1] = n1; c3[3 * j + 2] = n2;
+    }
+    const double tot = block_sum_256(shift, sh);
+    if (threadIdx.x == 0) {
+        const int it = ctl->it + 1;
+        ctl->it = it;
+        if (out[4 * k + 1] == 0.0) { ctl->strict = 1; ctl->done = 1; }
+        else if (tot <= tol_abs || it >= max_iter) ctl->done = 1;
+        *changed = 0ull;                                   // next iteration's counter
+    }
 }
 
 static int km_check(hgmm_ctx* c, int k) {
@@ -468,62 +516,132 @@ extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const 
     return HGMM_OK;
 }
 
+namespace {
+struct KmLaunch {
+    int nslot, k_alloc, nb_assign, nb_acc;
+    double *c3, *c4, *out, *inertia_part;
+    unsigned long long* changed;
+    KmCtl* ctl;
+};
+
+int km_prepare(hgmm_ctx* c, int k, int reset_labels, KmLaunch& L) {
+    HGMM_HIP(c, hipSetDevice(c->device));
+    const int64_t n = c->n, n_pad = c->n_pad;
+    L.nslot = k <= 256 ? 4 : KM_ACC_SLOTS;
+    L.k_alloc = (k + 64 * L.nslot - 1) / (64 * L.nslot) * (64 * L.nslot);
+    L.nb_assign = (int)km_nblk(n, 2 * KM_BLOCK);
+    L.nb_acc = (int)std::min<int64_t>(2 * (int64_t)c->cus, km_nblk(n, KM_BLOCK));
+    HGMM_TRY(ensure(c, c->km_labels, sizeof(int32_t) * n_pad));
+    HGMM_TRY(ensure(c, c->km_mind2, sizeof(double) * n_pad));
+    HGMM_TRY(ensure(c, c->km_centres, sizeof(double) * 7 * (size_t)k));
+    HGMM_TRY(ensure(c, c->km_partial, sizeof(double) * 4 * (size_t)L.k_alloc * L.nb_acc));
+    HGMM_TRY(ensure(c, c->km_out, sizeof(double) * (4 * (size_t)k + 8) + sizeof(double) * L.nb_assign + 16));
+    if (reset_labels || c->km_labels_n != n) {
+        kmeans_reset_labels_kernel<<<km_nblk(n, 256), 256, 0, c->stream>>>(c->km_labels.as<int32_t>(), n);
+        c->km_labels_n = n;
+    }
+    L.c3 = c->km_centres.as<double>();
+    L.c4 = L.c3 + 3 * (size_t)k;
+    L.out = c->km_out.as<double>();
+    L.changed = reinterpret_cast<unsigned long long*>(L.out + 4 * (size_t)k + 2);
+    L.ctl = reinterpret_cast<KmCtl*>(L.out + 4 * (size_t)k + 3);                 // 3 doubles
+    L.inertia_part = L.out + 4 * (size_t)k + 6;
+    return HGMM_OK;
+}
+
+// assignment + per-cluster sums + reduction with the centres in L.c3 -> L.out[4k + 2]
+int km_enqueue(hgmm_ctx* c, int k, const KmLaunch& L, const int* done) {
+    const int64_t n = c->n, n_pad = c->n_pad;
+    const double* xs = c->x_soa64.as<double>();
+    int32_t* labels = c->km_labels.as<int32_t>();
+    kmeans_pad_centres_kernel<<<km_nblk(k, 256), 256, 0, c->stream>>>(L.c3, k, L.c4, done);
+    {
+        ProfScope prof(c, HGMM_K_KMEANS_ASSIGN);
+        kmeans_assign_kernel<<<L.nb_assign, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, L.c4, k, labels,
+                                                                      c->km_mind2.as<double>(), L.inertia_part,
+                                                                      L.changed, done);
+    }
+    {
+        ProfScope prof(c, HGMM_K_KMEANS_ACCUM);
+        for (int slot0 = 0; slot0 * 64 < k; slot0 += L.nslot) {
+            if (L.nslot == 4)
+                kmeans_accum_kernel<4><<<L.nb_acc, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, labels, slot0, L.k_alloc,
+                                                                              c->km_partial.as<double>(), done);
+            else
+                kmeans_accum_kernel<KM_ACC_SLOTS><<<L.nb_acc, KM_BLOCK, 0, c->stream>>>(
+                    xs, n, n_pad, labels, slot0, L.k_alloc, c->km_partial.as<double>(), done);
+        }
+    }
+    kmeans_reduce_kernel<<<km_nblk(4 * (int64_t)k, 32), KM_BLOCK, 0, c->stream>>>(
+        c->km_partial.as<double>(), L.nb_acc, L.k_alloc, k, L.inertia_part, L.nb_assign, L.changed, L.out, done);
+    HGMM_HIP(c, hipGetLastError());
+    return HGMM_OK;
+}
+}  // namespace
+
 extern "C" int hgmm_kmeans_step(hgmm_ctx* c, int k, const double* centers, int reset_labels,
                                 double* sums_out, double* inertia_out, int64_t* n_changed_out) {
     if (!c) return HGMM_ERR_ARG;
     HGMM_TRY(km_check(c, k));
     if (!centers) return fail(c, HGMM_ERR_ARG, "kmeans: centers is NULL");
-    HGMM_HIP(c, hipSetDevice(c->device));
-    const int64_t n = c->n, n_pad = c->n_pad;
-    const int nslot = k <= 256 ? 4 : KM_ACC_SLOTS;
-    const int k_alloc = (k + 64 * nslot - 1) / (64 * nslot) * (64 * nslot);
-    const int nb_assign = (int)km_nblk(n, 2 * KM_BLOCK);
-    const int nb_acc = (int)std::min<int64_t>(2 * (int64_t)c->cus, km_nblk(n, KM_BLOCK));
-    HGMM_TRY(ensure(c, c->km_labels, sizeof(int32_t) * n_pad));
-    HGMM_TRY(ensure(c, c->km_mind2, sizeof(double) * n_pad));
-    HGMM_TRY(ensure(c, c->km_centres, sizeof(double) * 7 * (size_t)k));
-    HGMM_TRY(ensure(c, c->km_partial, sizeof(double) * 4 * (size_t)k_alloc * nb_acc));
-    HGMM_TRY(ensure(c, c->km_out, sizeof(double) * (4 * (size_t)k + 2) + sizeof(double) * nb_assign + 16));
-    const double* xs = c->x_soa64.as<double>();
-    int32_t* labels = c->km_labels.as<int32_t>();
-    if (reset_labels || c->km_labels_n != n) {
-        kmeans_reset_labels_kernel<<<km_nblk(n, 256), 256, 0, c->stream>>>(labels, n);
-        c->km_labels_n = n;
-    }
-    double* c3 = c->km_centres.as<double>();
-    double* c4 = c3 + 3 * (size_t)k;
-    double* out = c->km_out.as<double>();
-    unsigned long long* changed = reinterpret_cast<unsigned long long*>(out + 4 * (size_t)k + 2);
-    double* inertia_part = out + 4 * (size_t)k + 3;
-    HGMM_HIP(c, hipMemcpyAsync(c3, centers, sizeof(double) * 3 * k, hipMemcpyHostToDevice, c->stream));
-    kmeans_pad_centres_kernel<<<km_nblk(k, 256), 256, 0, c->stream>>>(c3, k, c4);
-    HGMM_HIP(c, hipMemsetAsync(changed, 0, sizeof(unsigned long long), c->stream));
-    {
-        ProfScope prof(c, HGMM_K_KMEANS_ASSIGN);
-        kmeans_assign_kernel<<<nb_assign, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, c4, k, labels,
-                                                                    c->km_mind2.as<double>(), inertia_part, changed);
-    }
-    {
-        ProfScope prof(c, HGMM_K_KMEANS_ACCUM);
-        for (int slot0 = 0; slot0 * 64 < k; slot0 += nslot) {
-            if (nslot == 4)
-                kmeans_accum_kernel<4><<<nb_acc, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, labels, slot0, k_alloc,
-                                                                            c->km_partial.as<double>());
-            else
-                kmeans_accum_kernel<KM_ACC_SLOTS><<<nb_acc, KM_BLOCK, 0, c->stream>>>(
-                    xs, n, n_pad, labels, slot0, k_alloc, c->km_partial.as<double>());
-        }
-    }
-    kmeans_reduce_kernel<<<km_nblk(4 * (int64_t)k, 32), KM_BLOCK, 0, c->stream>>>(
-        c->km_partial.as<double>(), nb_acc, k_alloc, k, inertia_part, nb_assign, changed, out);
-    HGMM_HIP(c, hipGetLastError());
-    if (c->comm_on()) HGMM_TRY(allreduce_f64_dev(c, out, 4 * (size_t)k + 2));
+    KmLaunch L;
+    HGMM_TRY(km_prepare(c, k, reset_labels, L));
+    HGMM_HIP(c, hipMemcpyAsync(L.c3, centers, sizeof(double) * 3 * k, hipMemcpyHostToDevice, c->stream));
+    HGMM_HIP(c, hipMemsetAsync(L.changed, 0, sizeof(unsigned long long), c->stream));
+    HGMM_TRY(km_enqueue(c, k, L, nullptr));
+    if (c->comm_on()) HGMM_TRY(allreduce_f64_dev(c, L.out, 4 * (size_t)k + 2));
     std::vector<double> tail(2);
-    if (sums_out) HGMM_HIP(c, hipMemcpyAsync(sums_out, out, sizeof(double) * 4 * k, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipMemcpyAsync(tail.data(), out + 4 * (size_t)k, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
+    if (sums_out) HGMM_HIP(c, hipMemcpyAsync(sums_out, L.out, sizeof(double) * 4 * k, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipMemcpyAsync(tail.data(), L.out + 4 * (size_t)k, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
     HGMM_HIP(c, hipStreamSynchronize(c->stream));
     if (inertia_out) *inertia_out = tail[0];
     if (n_changed_out) *n_changed_out = (int64_t)tail[1];
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_kmeans_lloyd(hgmm_ctx* c, int k, double* centers_inout, int max_iter, double tol_abs,
+                                 int reset_labels, int* n_iter_out, int* strict_out, int* needs_host_out,
+                                 double* sums_out, int64_t* n_changed_out) {
+    if (!c) return HGMM_ERR_ARG;
+    HGMM_TRY(km_check(c, k));
+    if (!centers_inout) return fail(c, HGMM_ERR_ARG, "kmeans: centers is NULL");
+    if (c->comm_on()) return fail(c, HGMM_ERR_STATE, "kmeans: the device-resident Lloyd loop is single-rank; "
+                                                     "use hgmm_kmeans_step under a communicator");
+    if (n_iter_out) *n_iter_out = 0;
+    if (strict_out) *strict_out = 0;
+    if (needs_host_out) *needs_host_out = 0;
+    if (max_iter < 1) return HGMM_OK;
+    KmLaunch L;
+    HGMM_TRY(km_prepare(c, k, reset_labels, L));
+    HGMM_HIP(c, hipMemcpyAsync(L.c3, centers_inout, sizeof(double) * 3 * k, hipMemcpyHostToDevice, c->stream));
+    HGMM_HIP(c, hipMemsetAsync(L.changed, 0, sizeof(unsigned long long) + sizeof(KmCtl), c->stream));
+    // the stop rule runs on the device; `batch` iterations are enqueued per host synchronisation and the
+    // kernels of iterations past the stop return at once (same scheme as the tree build)
+    const int batch = 8;
+    KmCtl h = {};
+    while (!h.done) {
+        for (int b = 0; b < batch; ++b) {
+            HGMM_TRY(km_enqueue(c, k, L, &L.ctl->done));
+            kmeans_update_kernel<<<1, 256, 0, c->stream>>>(L.out, k, tol_abs, max_iter, L.c3, L.changed, L.ctl);
+        }
+        HGMM_HIP(c, hipGetLastError());
+        HGMM_HIP(c, hipMemcpyAsync(&h, L.ctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    HGMM_HIP(c, hipMemcpyAsync(centers_inout, L.c3, sizeof(double) * 3 * k, hipMemcpyDeviceToHost, c->stream));
+    if (h.needs_host) {
+        // the iteration that met an empty cluster: its sums / counts / changed labels, centres untouched
+        std::vector<double> tail(2);
+        if (sums_out)
+            HGMM_HIP(c, hipMemcpyAsync(sums_out, L.out, sizeof(double) * 4 * k, hipMemcpyDeviceToHost, c->stream));
+        HGMM_HIP(c, hipMemcpyAsync(tail.data(), L.out + 4 * (size_t)k, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
+        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+        if (n_changed_out) *n_changed_out = (int64_t)tail[1];
+    }
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    if (n_iter_out) *n_iter_out = h.it;
+    if (strict_out) *strict_out = h.strict;
+    if (needs_host_out) *needs_host_out = h.needs_host;
     return HGMM_OK;
 }
 

@@ -86,8 +86,12 @@ class KMeans:
     def _seed(self, ctx, n, rs):
         k = self.n_clusters
         trials = 2 + int(np.log(k))
+        # == rs.choice(n, p=w / w.sum()) with w = 1 (the draw scikit-learn makes), without choice()'s
+        # validation passes over p: one uniform against the normalised running sum of p
         w = np.ones(n)
-        first = rs.choice(n, p=w / w.sum())
+        cdf = (w / w.sum()).cumsum()
+        cdf /= cdf[-1]
+        first = int(cdf.searchsorted(rs.random_sample(), side='right'))
         rand = rs.uniform(size=(max(k - 1, 0), trials))       # == k-1 successive draws of `trials`
         ids, centres = ctx.kmeans_plusplus(k, first, rand)
         return ids, centres
@@ -143,15 +147,29 @@ class KMeans:
         strict = False
         n_iter = 0
         inertia = 0.0
-        for i in range(self.max_iter):
-            sums, counts, inertia, changed = ctx.kmeans_step(centres, reset_labels=(i == 0))
+        first = True
+        while n_iter < self.max_iter:
+            pending = None
+            if ranks == 1:
+                # the loop runs on the device until a stop rule fires or a cluster comes up empty
+                centres, done_it, strict, pending = ctx.kmeans_lloyd(centres, self.max_iter - n_iter, tol_abs,
+                                                                     reset_labels=first)
+                n_iter += done_it
+                first = False
+                if pending is None:
+                    break
+                sums, counts, changed = pending
+            else:
+                sums, counts, inertia, changed = ctx.kmeans_step(centres, reset_labels=first)
+                first = False
+            # one iteration finished on the host (always under a communicator; after an empty cluster otherwise)
             self._relocate_empty(ctx, Xc, sums, counts)
             new = sums
             pos = counts > 0
             new[pos] *= (1.0 / counts[pos])[:, None]
             shift_tot = float((np.sqrt(((new - centres) ** 2).sum(axis=1)) ** 2).sum())
             centres = new
-            n_iter = i + 1
+            n_iter += 1
             if changed == 0:
                 strict = True
                 break

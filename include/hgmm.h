@@ -213,6 +213,16 @@ int hgmm_kmeans_plusplus(hgmm_ctx* ctx, int k, int64_t first_id, const double* r
 int hgmm_kmeans_step(hgmm_ctx* ctx, int k, const double* centers, int reset_labels, double* sums_out,
                      double* inertia_out, int64_t* n_changed_out);
 int hgmm_kmeans_labels(hgmm_ctx* ctx, int32_t* labels_out, double* min_dist2_out);
+/* hgmm_kmeans_lloyd     the whole Lloyd loop on the device (single rank): per iteration assignment, sums,
+ *                       centres = sums * (1 / count), summed squared centre shift and scikit-learn's stop
+ *                       rules in its order (unchanged labels -> strict; shift <= tol_abs; max_iter), several
+ *                       iterations enqueued per host synchronisation.  centers_inout: in = start, out = the
+ *                       centres after n_iter completed iterations.  An iteration that leaves a cluster empty
+ *                       is handed back unfinished (needs_host = 1, its sums[k,4] / changed-label count in
+ *                       sums_out / n_changed_out, centres untouched) for the host's relocation rule.        */
+int hgmm_kmeans_lloyd(hgmm_ctx* ctx, int k, double* centers_inout, int max_iter, double tol_abs,
+                      int reset_labels, int* n_iter_out, int* strict_out, int* needs_host_out,
+                      double* sums_out, int64_t* n_changed_out);
 
 /* ---- L2 GMMReg: Gauss transform (float64) ---------------------------------------------
  * out[k, i] = sum_j weights[k, j] exp(-|points_i - centres_j|^2 / h^2),  k < n_weights <= 8
