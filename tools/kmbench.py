@@ -35,9 +35,12 @@ def device_case(ctx, X, k, label):
     ctx.profile_enable(False)
     a_ms, a_n = ctx.profile_get("kmeans_assign")
     c_ms, c_n = ctx.profile_get("kmeans_accum")
-    t0 = time.perf_counter()
-    km = KMeans(n_clusters=k, random_state=1, max_iter=50, n_init=1, ctx=ctx).fit(X)
-    t_fit = time.perf_counter() - t0
+    fits = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        km = KMeans(n_clusters=k, random_state=1, max_iter=50, n_init=1, ctx=ctx).fit(X)
+        fits.append(time.perf_counter() - t0)
+    t_fit = min(fits)
     pairs = n * k
     print("%s: N=%d k=%d | seeding %.2f ms (%.1f us/centre) | Lloyd step %.3f ms (assign %.3f ms = %.2e pairs/s, "
           "accumulate %.3f ms) | fit %.1f ms, %d iterations" %
