@@ -2,27 +2,40 @@
 """Headline benchmark of the EM hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
-             --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W)
+
+N = 1 runs in this process.  N > 1 needs one process per GPU: either the caller provides them
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+bench.py --gpus N ...` -- only RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* are read, PyTorch is not imported),
+or, when WORLD_SIZE is not set, this script launches the N ranks itself.  The ranks meet over a plain TCP
+exchange of the 128-byte RCCL unique id; everything after that is RCCL over xGMI inside the library.
 
 Workload (BASELINE.json configs[2] / configs[4]): per GPU one synthetic frame of
-N = 1,000,000 uniform [0,1)^3 points (seed = rank), flat diag GMM with J = 800 components
-(flavour "W" = src/python/gmm_waymo/src/gmm_impl.py), float32.  One *step* = one full EM
-iteration (E-step responsibilities for all N x J pairs + M-step update of all parameters),
-device-resident, inputs already in HBM.  With N > 1 the frames are shards of ONE joint fit:
-every iteration all-reduces the (7 J + 2) float64 sufficient statistics over RCCL before the
-(redundant, identical) M-step -- weak scaling, `value` = frames x iterations / second.
+N = 1,000,000 uniform [0,1)^3 points (seed = rank), flat diag GMM with J = 800 components (flavour "W" =
+src/python/gmm_waymo/src/gmm_impl.py), float32.  One *step* = one full EM iteration (E-step responsibilities
+for all N x J pairs + M-step update of all parameters), device-resident, inputs already in HBM.  With N > 1
+the frames are shards of ONE joint fit: every iteration all-reduces the (7 J + 2) float64 sufficient
+statistics over RCCL before the (redundant, identical) M-step -- weak scaling, `value` = frames x iterations
+/ second.
+
+Timing: W untimed warm-up steps, then blocks of exactly K steps, each bracketed by a barrier +
+stream synchronisation on both sides and reduced with MAX over the ranks.  Blocks repeat until at least
+MIN_TIMED_S of timed work has accumulated (the chip needs tens of milliseconds of load before its clocks
+settle; a single 20-step block lasts 8 ms); `value` / `ms_per_step` are those of the MEDIAN block, the first
+(un-settled) block and the spread are reported next to it.
 
 The JSON line also carries
-  roofline      the materialising E-step kernel (the API's e_step(): writes log_resp[N,J]), HBM
-                bound; achieved = algorithmic bytes (12N + 4NJ + 4N + 28J) / mean hipEvent time
-  cpu_baseline  the NumPy oracle (same op sequence as the reference's CPU path) timed on this
-                box's host cores on a bounded sample of the same workload
-  bunny         BASELINE configs[0] (bun000.ply, J = 100, 20 iterations) GPU vs CPU it/s
+  roofline        the materialising E-step kernel (the API's e_step(): writes log_resp[N,J]): HBM bound,
+                  achieved = algorithmic bytes (12N + 4NJ + 4N + 28J) / mean hipEvent time
+  roofline_fused  the kernel the timed step spends its time in (VALU bound): fp32 FLOP/s against the vector
+                  peak and VALU instructions per cycle per SIMD, instruction counts read from the code object
+  fullcov / tree_1M / hgmm / kmeans_init / registration / bunny    the other hot kernels at their configs
+  cpu_baseline    the NumPy oracle (same op sequence as the reference's CPU path) on this box's host cores
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,15 +47,25 @@ if ROOT not in sys.path:
 
 N_POINTS = 1_000_000
 J_COMP = 800
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
-SETTLE_STEPS = 80          # untimed iterations before the warm-up steps (clock settling, see main())
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+FP32_VECTOR_PEAK_TF = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (spec)
+FP64_VECTOR_PEAK_TF = 78.6   # half the fp32 rate (valubench: v_fma_f64 issues at the v_pk_fma_f32 rate)
+SPEC_CLOCK_HZ = 2.4e9
+MIN_TIMED_S = 1.0            # timed blocks repeat until this much timed work has accumulated
+MAX_BLOCKS = 400
+RCCL_INIT_FAILED = 17        # exit code of a rank whose RCCL communicator could not be created
+
+# fused EM kernel, useful fp32 flops per (point, component) pair (fma = 2), DESIGN.md section 3:
+#   E: 3 sub + 3 mul + 3 fma = 12, exp 1, row sum 1;  M: r = e/S 1, s0 1, 3 sub + 3 mul + 3 add + 3 fma = 15
+FUSED_FLOP_PER_PAIR = 31
 
 
-def synth_frame(seed, n=N_POINTS):
-    return np.random.RandomState(seed).rand(n, 3).astype(np.float32)
+def synth_frame(seed, n=None):
+    return np.random.RandomState(seed).rand(n or N_POINTS, 3).astype(np.float32)
 
 
-def init_params(frame0, J=J_COMP, seed=100):
+def init_params(frame0, J=None, seed=100):
+    J = J or J_COMP
     idx = np.random.RandomState(seed).choice(len(frame0), J, replace=False)
     mu = frame0[idx].copy()
     w = (np.ones(J) / J).astype(np.float32)
@@ -50,6 +73,73 @@ def init_params(frame0, J=J_COMP, seed=100):
     return mu, w, cov
 
 
+# ------------------------------------------------------------------------------------------------
+# launcher: N ranks of this script on the N GPUs of this node (used when WORLD_SIZE is not set)
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv, script=None, extra_env=None, timeout=None):
+    """Start `n` ranks (RANK = LOCAL_RANK = 0..n-1, WORLD_SIZE = n, MASTER_ADDR = 127.0.0.1) of `script`
+    and wait for them.  Rank 0 inherits stdout (it prints the JSON line), the other ranks' stdout goes to
+    stderr.  Returns the first non-zero exit code, or 0."""
+    script = script or os.path.abspath(__file__)
+    timeout = timeout or float(os.environ.get("HGMM_BENCH_LAUNCH_TIMEOUT", "1500"))
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    deadline = time.time() + timeout
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is not None:
+                alive.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+        if rc != 0 or time.time() > deadline:
+            # one rank failed (or the group hangs): the others would wait in a collective for ever
+            grace = time.time() + (20 if rc != 0 else 0)
+            while alive and time.time() < grace:
+                alive = [p for p in alive if p.poll() is None]
+                time.sleep(0.1)
+            for p in alive:
+                p.kill()
+            for p in alive:
+                p.wait()
+            if rc == 0:
+                rc = 124
+            break
+        time.sleep(0.05)
+    return rc
+
+
+def self_launch(args, argv):
+    rc = launch_ranks(args.gpus, argv)
+    if rc == RCCL_INIT_FAILED and not os.environ.get("HGMM_BENCH_HOSTCOMM"):
+        # RCCL could not build a communicator on this node: measure with the library's host shared-memory
+        # all-reduce instead (every rank on its own GPU; statistics go device -> shared memory -> device)
+        sys.stderr.write("bench: RCCL communicator unavailable, re-running with the host shared-memory all-reduce\n")
+        rc = launch_ranks(args.gpus, argv, extra_env={"HGMM_BENCH_HOSTCOMM": "hgmm_bench_%d" % os.getpid(),
+                                                      "HGMM_BENCH_FALLBACK": "1"})
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
+# legs that run on rank 0 at N = 1
+# ------------------------------------------------------------------------------------------------
 def cpu_baseline_main(sample_n=200_000, iters=10):
     """NumPy oracle (fp32, reference op sequence) on a bounded sample of the workload."""
     from oracle import flat_em
@@ -131,7 +221,8 @@ def registration_leg(ctx):
             best = (t2 - t0, t1 - t0, t2 - t1, len(iters), err)
     return {"workload": "bun000.ply (40256 pts) vs copy rotated 10 deg + shifted, registration_gmmtree L=3",
             "total_ms": best[0] * 1e3, "build_ms": best[1] * 1e3, "registration_ms": best[2] * 1e3,
-            "registration_iterations": best[3], "mean_residual_m": best[4]}
+            "registration_iterations": best[3], "ms_per_registration_iteration": best[2] * 1e3 / max(best[3], 1),
+            "mean_residual_m": best[4]}
 
 
 def kmeans_leg(ctx):
@@ -144,6 +235,7 @@ def kmeans_leg(ctx):
     km = KMeans(n_clusters=J_COMP, random_state=1, max_iter=50, ctx=ctx).fit(X)
     out = {"workload": "KMeans(k=800, random_state=1, max_iter=50, n_init=1) on the C3 frame, float64",
            "fit_ms": (time.perf_counter() - t0) * 1e3, "lloyd_iterations": int(km.n_iter_),
+           "seeding_ms": getattr(km, "seeding_ms_", None),
            "sklearn_same_box_ms": "78395 (profiles/r01/kmbench.log; not re-timed here)"}
     path = os.path.join(ROOT, "tests", "golden", "bun000_xyz.npy")
     if os.path.exists(path):
@@ -185,35 +277,125 @@ def hgmm_leg(ctx):
             "level_iterations_per_s": float(iters.sum() / dt), "q_final": float(q[-1])}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--estep-reps", type=int, default=30)
-    args = ap.parse_args()
+def tree_1m_leg(ctx):
+    """HGMM build at Waymo scale: the C3 frame (N = 1e6, float64), L = 4.  The level log-likelihood over ALL
+    8^(l+1) nodes of the level (the reference's stop rule, hgmm_gpu.py:107-115, 532) dominates: N x 8^(l+1)
+    Gaussian evaluations of ~25 fp64 flops per level-iteration."""
+    P = synth_frame(0).astype(np.float64)
+    L, T = 4, 4680
+    idx = np.random.RandomState(72).randint(len(P), size=T)
+    ctx.set_points(P)
+    ctx.tree_build(L, 80.0, 1e-4, P[idx], 0.01, 4)                     # warm-up
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    pi, mu, cov, leaf, iters, q = ctx.tree_build(L, 80.0, 1e-4, P[idx], 0.01, 4)      # 4 iterations per level
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    ll_ms, ll_n = ctx.profile_get("tree_loglik")
+    es_ms, es_n = ctx.profile_get("tree_estep")
+    pairs = sum(int(it) * len(P) * 8 ** (l + 1) for l, it in enumerate(iters))
+    flop = 25.0 * pairs                     # 3 sub + 6-term quadratic form (9 fma) + scale + exp + accumulate
+    return {"workload": "uniform cloud N=1,000,000 (float64), HGMM L=4 (4680 nodes), 4 iterations per level",
+            "build_ms": dt * 1e3, "level_iterations": [int(v) for v in iters],
+            "ms_per_level_iteration": dt * 1e3 / max(int(iters.sum()), 1),
+            "loglik_kernel_ms_total": ll_ms, "estep_kernel_ms_total": es_ms,
+            "roofline": {"kernel": "tree_loglik_kernel<4>", "bound": "valu", "unit": "TFLOP/s",
+                         "achieved": flop / (ll_ms * 1e-3) / 1e12 if ll_ms else None, "peak": FP64_VECTOR_PEAK_TF,
+                         "frac": flop / (ll_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TF if ll_ms else None,
+                         "flop_per_pair": 25, "pairs": pairs}}
 
+
+def fullcov_leg(ctx):
+    """Flat FULL-covariance EM (what north_star's kernel description names: (mu, Sigma^-1, logdet, pi) per
+    component, 10-float sufficient statistics) at C3 size, float64 like the reference's CPU twin."""
+    P = synth_frame(0).astype(np.float64)
+    J = J_COMP
+    idx = np.random.RandomState(100).choice(len(P), J, replace=False)
+    ctx.set_points(P)
+    ctx.fullcov_fit(J, 1e-30, 1e-4, P[idx], 0.01, 2)                   # warm-up
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    iters = 6
+    t0 = time.perf_counter()
+    ctx.fullcov_fit(J, 1e-30, 1e-4, P[idx], 0.01, iters)
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    out = {"workload": "uniform cloud N=1,000,000 (float64), flat full-covariance GMM J=800, %d iterations" % iters,
+           "ms_per_iteration": dt * 1e3 / iters}
+    kern = {}
+    for k in ("full_pass", "full_moments", "full_fused"):
+        try:
+            ms, n = ctx.profile_get(k)
+        except KeyError:
+            continue
+        if n:
+            kern[k] = {"avg_ms": ms / n, "launches": n}
+    out["kernels"] = kern
+    # fp64 flops per pair: pdf 3 sub + 9 (quadratic form) + 2 + exp; statistics 2 x 10 (fma) on the matrix cores
+    flop = 36.0 * len(P) * J
+    out["roofline"] = {"bound": "valu+mfma (fp64)", "unit": "TFLOP/s", "achieved": flop / (dt / iters) / 1e12,
+                       "peak": FP64_VECTOR_PEAK_TF, "frac": flop / (dt / iters) / 1e12 / FP64_VECTOR_PEAK_TF,
+                       "flop_per_pair": 36}
+    return out
+
+
+def fused_roofline(avg_launch_s, cus):
+    """VALU accounting of flat_fused_pk_kernel<13> from the code object (tools/isa_count.py)."""
+    out = {"kernel": "flat_fused_pk_kernel<13> (constant-shift loop)", "bound": "valu", "unit": "TFLOP/s",
+           "peak": FP32_VECTOR_PEAK_TF, "flop_per_pair": FUSED_FLOP_PER_PAIR, "avg_launch_ms": avg_launch_s * 1e3}
+    flop = float(FUSED_FLOP_PER_PAIR) * N_POINTS * J_COMP
+    out["achieved"] = flop / avg_launch_s / 1e12
+    out["frac"] = out["achieved"] / FP32_VECTOR_PEAK_TF
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import isa_count
+        # the constant-shift row loop is the loop with exactly one wave reduction (6 DPP steps)
+        lp = isa_count.loop_profile("flat_fused_pk_kernelILi13", want=lambda l: l.get("valu_dpp", 0) == 6)
+        simds = cus * 4
+        instr_per_simd = lp["valu"] * N_POINTS / simds
+        out.update({"valu_instr_per_row": lp["valu"], "packed_fp32_instr_per_row": lp.get("valu_pk", 0),
+                    "transcendental_instr_per_row": lp.get("valu_trans", 0),
+                    "lane_components_per_row": 13 * 64,
+                    "valu_instr_per_cycle_per_simd_at_2.4GHz": instr_per_simd / (avg_launch_s * SPEC_CLOCK_HZ),
+                    "cycles_per_valu_instr_at_2.4GHz": avg_launch_s * SPEC_CLOCK_HZ / instr_per_simd,
+                    "source": "code object in libhgmm_hip.so (tools/isa_count.py); per-class issue cost measured by "
+                              "tools/valubench.hip -> profiles/r02/valubench.log"})
+    except Exception as e:                                   # llvm-objdump missing: keep the flop figures
+        out["isa_count_error"] = repr(e)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def rank_main(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
 
     import hgmm_amd
-    # HGMM_BENCH_HOSTCOMM=<name> (+ HGMM_BENCH_DEVICE): rehearsal of the N > 1 flow on a single-GPU box --
-    # all ranks on one device, joined by the host shared-memory backend instead of RCCL.  Not a measurement.
-    rehearsal = os.environ.get("HGMM_BENCH_HOSTCOMM")
-    ctx = hgmm_amd.Context(int(os.environ.get("HGMM_BENCH_DEVICE", local_rank)) if rehearsal else local_rank)
+    # HGMM_BENCH_HOSTCOMM=<name>: all-reduce through the library's host shared-memory backend instead of RCCL.
+    #   + HGMM_BENCH_DEVICE=<id>  rehearsal of the N > 1 flow on a single-GPU box (all ranks on one device;
+    #                             a flow check, not a measurement)
+    #   + HGMM_BENCH_FALLBACK=1   set by the launcher after RCCL failed to initialise (ranks on their own GPUs)
+    hostcomm = os.environ.get("HGMM_BENCH_HOSTCOMM")
+    fallback = bool(os.environ.get("HGMM_BENCH_FALLBACK"))
+    rehearsal = bool(hostcomm) and not fallback
+    device = int(os.environ.get("HGMM_BENCH_DEVICE", local_rank)) if rehearsal else local_rank
+    ctx = hgmm_amd.Context(device)
     info = ctx.device_info()
-    if world > 1 and rehearsal:
-        ctx.comm_init_host(world, rank, rehearsal)
+    collective = None
+    if world > 1 and hostcomm:
+        ctx.comm_init_host(world, rank, hostcomm)
+        collective = "host shared memory (device -> shm -> device)"
     elif world > 1:
-        # RCCL communicator; the 128-byte unique id travels through the launcher's rendezvous
         from hgmm_amd import parallel
-        parallel.attach_communicator(ctx, rank, world, transport="torch")
+        try:
+            parallel.attach_communicator(ctx, rank, world, transport="tcp")
+        except Exception as e:
+            sys.stderr.write("rank %d: RCCL communicator could not be created: %s\n" % (rank, e))
+            sys.exit(RCCL_INIT_FAILED)
+        collective = "RCCL ncclAllReduce(sum, float64) on the kernel stream"
 
     frame = synth_frame(rank)
     mu0, w0, cov0 = init_params(synth_frame(0) if rank else frame)
@@ -223,54 +405,75 @@ def main():
         ctx.synchronize()
         ctx.allreduce([0.0])
 
-    # ---- timed region: K fused EM iterations -------------------------------------------------
-    # The chip's clocks take ~25-40 ms of sustained load to settle (rocprofv3 trace, profiles/r01: the
-    # same kernel runs 477 us at launch 1 and 424 us at launch 55), so SETTLE untimed iterations of
-    # the same step precede the W warm-up steps of the contract; nothing inside the timed region changes.
-    ctx.flat_train_begin(0.0, mu0, cov0, w0, "diag", "W", lls_capacity=args.steps + args.warmup + SETTLE_STEPS + 8)
-    ctx.flat_train_step(SETTLE_STEPS)
-    ctx.flat_train_step(args.warmup)
+    # ---- timed region: blocks of K fused EM iterations ---------------------------------------------
+    K, W = args.steps, args.warmup
+    cap = W + K * (MAX_BLOCKS + 2) + 8
+    ctx.flat_train_begin(0.0, mu0, cov0, w0, "diag", "W", lls_capacity=cap)
+    ctx.flat_train_step(W)
+    blocks = []
+    while True:
+        barrier()
+        t0 = time.perf_counter()
+        ctx.flat_train_step(K)
+        barrier()
+        dt_local = time.perf_counter() - t0
+        blocks.append(float(ctx.allreduce([dt_local], op="max")[0]))        # identical on every rank
+        if (sum(blocks) >= args.min_time and len(blocks) >= 3) or len(blocks) >= MAX_BLOCKS:
+            break
+    # one more block under the hipEvent profiler (not part of the timing): kernel and all-reduce durations
     ctx.profile_reset()
     ctx.profile_enable(True)
+    ctx.flat_train_step(K)
     barrier()
-    t0 = time.perf_counter()
-    ctx.flat_train_step(args.steps)
-    barrier()
-    dt_local = time.perf_counter() - t0
     ctx.profile_enable(False)
-    dt = float(ctx.allreduce([dt_local], op="max")[0])
     fused_ms, fused_n = ctx.profile_get("flat_fused")
+    ar_ms, ar_n = ctx.profile_get("allreduce") if world > 1 else (0.0, 0)
     inv, mu, w, cov, lls, conv, n_it = ctx.flat_train_end()
-    assert n_it == args.steps + args.warmup + SETTLE_STEPS, (n_it, args.steps, args.warmup)
+    assert n_it == W + K * (len(blocks) + 1), (n_it, W, K, len(blocks))
     assert np.isfinite(lls).all()
 
     out = None
     if rank == 0:
-        pairs = N_POINTS * J_COMP
-        # fused kernel arithmetic: ~27 fp32 lane-ops (incl. 1 v_exp) per point-component pair
+        med = float(np.median(blocks))
         fused_avg_ms = fused_ms / max(fused_n, 1)
         out = {
             "metric": "EM iterations/sec (N points x J components); E-step achieved HBM GB/s",
-            "value": world * args.steps / dt,
+            "value": world * K / med,
             "unit": "EM it/s (1M-pt x 800-comp frames x iterations per second, all GPUs)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "clock_settle_steps": SETTLE_STEPS,
-            "ms_per_step": 1e3 * dt / args.steps,
+            "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * med / K,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]/[4]: uniform [0,1)^3 cloud, N=1,000,000 pts per GPU "
                                    "(seed=rank), flat diag GMM J=800 (flavour W), fused device-resident EM, "
-                                   "tol=0; N>1: frames are shards of one joint fit, RCCL all-reduce of "
+                                   "tol=0; N>1: frames are shards of one joint fit, all-reduce of "
                                    "(7J+2) f64 sufficient statistics per iteration",
                        "points_per_gpu": N_POINTS, "components": J_COMP, "cov_type": "diag",
                        "device": info["name"], "compute_units": info["compute_units"],
+                       **({"collective": collective} if collective else {}),
                        **({"rehearsal": "all ranks on ONE device, host shared-memory all-reduce -- flow check, "
-                                        "not a measurement"} if rehearsal else {})},
+                                        "not a measurement"} if rehearsal else {}),
+                       **({"fallback": "RCCL communicator could not be created on this node; statistics "
+                                       "all-reduced through host shared memory"} if fallback else {})},
+            "timing": {"blocks": len(blocks), "steps_per_block": K, "timed_s": float(sum(blocks)),
+                       "median_block_ms": med * 1e3, "first_block_it_per_s": world * K / blocks[0],
+                       "min_block_it_per_s": world * K / max(blocks), "max_block_it_per_s": world * K / min(blocks),
+                       "rule": "value = world x K / median block; every block = K steps between barrier+sync pairs, "
+                               "MAX over ranks"},
             "fused_kernel": {"avg_ms": fused_avg_ms, "launches": fused_n,
-                             "pairs_per_s": pairs / (fused_avg_ms * 1e-3) if fused_avg_ms else None,
+                             "pairs_per_s": N_POINTS * J_COMP / (fused_avg_ms * 1e-3) if fused_avg_ms else None,
                              "last_lls": float(lls[-1])},
         }
+        if world > 1:
+            out["allreduce_us"] = 1e3 * ar_ms / max(ar_n, 1)
+            out["allreduce_payload_bytes"] = 8 * (7 * 1024 + 2)        # 7 statistics x Jpad(=1024) + sum lpn + n
+            out["allreduce_launches"] = ar_n
+            out["roofline"] = None
+            out["cpu_baseline"] = None
+        if fused_avg_ms:
+            out["roofline_fused"] = fused_roofline(fused_avg_ms * 1e-3, info["compute_units"])
 
-    # ---- roofline leg (single GPU): the materialising E-step kernel ---------------------------
+    # ---- single-GPU legs --------------------------------------------------------------------------------
     if rank == 0 and world == 1:
         lr = ctx.empty((N_POINTS, J_COMP), np.float32)
         for _ in range(40):                                            # warm-up: launches 3-15 after the VALU-heavy
@@ -284,16 +487,18 @@ def main():
         avg_s = e_ms / e_n * 1e-3
         alg_bytes = 12 * N_POINTS + 4 * N_POINTS * J_COMP + 4 * N_POINTS + 28 * J_COMP
         achieved = alg_bytes / avg_s / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get("flat_estep_bytes_per_launch")
+                traffic_source = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                  "kernel (separate runs; not re-measured inside this bench run)")
             except Exception:
                 traffic = None
-        out["roofline"] = {"kernel": "flat_estep_rows_pk_kernel<3,1,4> (materialising E-step, log_resp[N,J] written once)",
+        out["roofline"] = {"kernel": "materialising E-step (flat_estep kernel, log_resp[N,J] written once)",
                            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3,
                            "launches": e_n}
         # API-faithful iteration: E-step (materialise) + M-step from the materialised log_resp
@@ -308,9 +513,13 @@ def main():
         api_dt = (time.perf_counter() - t0) / reps
         ctx.profile_enable(False)
         m_ms, m_n = ctx.profile_get("flat_mstep")
-        out["materialised_iteration"] = {"it_per_s": 1.0 / api_dt,
-                                         "mstep_avg_ms": m_ms / max(m_n, 1),
-                                         "mstep_GBs": (4 * N_POINTS * J_COMP + 12 * N_POINTS) / (m_ms / max(m_n, 1) * 1e-3) / 1e9}
+        m_avg_s = m_ms / max(m_n, 1) * 1e-3
+        m_bytes = 4 * N_POINTS * J_COMP + 12 * N_POINTS
+        out["materialised_iteration"] = {"it_per_s": 1.0 / api_dt, "mstep_avg_ms": m_avg_s * 1e3,
+                                         "mstep_GBs": m_bytes / m_avg_s / 1e9,
+                                         "roofline": {"kernel": "flat_mstep_kernel<3,1>", "bound": "hbm", "unit": "GB/s",
+                                                      "achieved": m_bytes / m_avg_s / 1e9, "peak": HBM_PEAK_GBS,
+                                                      "frac": m_bytes / m_avg_s / 1e9 / HBM_PEAK_GBS}}
         # what a pure 16-byte store stream of the same size reaches on this chip (write ceiling)
         # (best pure-store pattern found, tools/fillbench.py: one workgroup per CU, grid-stride)
         ctx.util_fill(lr, 0.0, False, 0, 1)
@@ -322,21 +531,40 @@ def main():
         f_ms, f_n = ctx.profile_get("util_fill")
         out["roofline"]["store_stream_ceiling_GBs"] = 4 * N_POINTS * J_COMP / (f_ms / f_n * 1e-3) / 1e9
         lr.free()
-        out["bunny"] = bunny_leg(ctx)
-        out["hgmm"] = hgmm_leg(ctx)
-        out["kmeans_init"] = kmeans_leg(ctx)
-        out["registration"] = registration_leg(ctx)
+        for name, leg in (("bunny", bunny_leg), ("hgmm", hgmm_leg), ("tree_1M", tree_1m_leg), ("fullcov", fullcov_leg),
+                          ("kmeans_init", kmeans_leg), ("registration", registration_leg)):
+            if name in args.skip:
+                continue
+            try:
+                out[name] = leg(ctx)
+            except Exception as e:                                    # a side leg must not lose the headline line
+                out[name] = {"error": repr(e)}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_main()
-    elif rank == 0:
-        out["roofline"] = None
-        out["cpu_baseline"] = None
 
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         ctx.comm_destroy()
     ctx.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--min-time", type=float, default=MIN_TIMED_S,
+                    help="timed K-step blocks repeat until this many seconds of timed work (default 1.0)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--estep-reps", type=int, default=30)
+    ap.add_argument("--skip", default="", help="comma-separated side legs to skip (bunny,hgmm,tree_1M,fullcov,...)")
+    args = ap.parse_args()
+    args.skip = set(s for s in args.skip.split(",") if s)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args, sys.argv[1:]))
+    rank_main(args)
 
 
 if __name__ == "__main__":

@@ -18,7 +18,7 @@ COV_TYPES = {"diag": 0, "spherical": 1}
 VARIANTS = {"W": 0, "G": 1}
 KERNEL_IDS = {"flat_estep": 0, "flat_fused": 1, "flat_mstep": 2, "tree_estep": 3,
               "tree_loglik": 4, "tree_reg": 5, "util_fill": 6, "full_pass": 7, "full_moments": 8,
-              "kmeans_assign": 9, "kmeans_accum": 10}
+              "kmeans_assign": 9, "kmeans_accum": 10, "allreduce": 11}
 
 
 class HgmmError(RuntimeError):
@@ -214,7 +214,7 @@ class Context:
                             % (device_id, rc, msg.decode() if msg else "?"))
         self.h = h
         self.device_id = device_id
-        self._points_key = None
+        self._points_owner = None
         self.nranks, self.rank = 1, 0
 
     # -- plumbing ---------------------------------------------------------------------
@@ -282,6 +282,9 @@ class Context:
             Xc = np.ascontiguousarray(X, dtype=np.float32)
             self._check(self.lib.hgmm_set_points_f32(self.h, _ptr(Xc), Xc.shape[0]))
         self.n = Xc.shape[0]
+        # every upload replaces the resident cloud: a DevicePoints handle taken before it is stale
+        # from now on (DevicePoints.__init__ claims ownership again right after its own upload)
+        self._points_owner = None
         return self
 
     @property

@@ -213,14 +213,14 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_kernel(
 
         float wl[K];
         float m = row_wl2<NV4, NV1>(P, x0, x1, x2, wl);
-        m = wave_reduce(m, OpMax());
+        m = wave_max_dpp(m);
         const int slot = (int)(it & 63);
         if (NORMALISE) {
             if (m == NEG_INF) m = 0.f;            // every component has zero weight: avoid inf - inf
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < K; ++k) s += __builtin_amdgcn_exp2f(wl[k] - m);
-            s = wave_reduce(s, OpSum());
+            s = wave_sum_dpp(s);
             float inv_den;
             const float lpn2 = lpn2_from(m, s, inv_den);
             const float lpn = lpn2 * LN2;
@@ -377,11 +377,14 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_rows_pk_kernel(
             }
             m[r] = mm;
         }
+        if constexpr (ROWS == 4) wave_max4_dpp(m);
+        else {
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            m[r] = wave_reduce(m[r], OpMax());
-            if (m[r] == NEG_INF) m[r] = 0.f;
+            for (int r = 0; r < ROWS; ++r) m[r] = wave_max_dpp(m[r]);
         }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+            if (m[r] == NEG_INF) m[r] = 0.f;
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const f2 M = f2{m[r], m[r]};
@@ -395,8 +398,11 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_rows_pk_kernel(
             if (ODD) a += __builtin_amdgcn_exp2f(wls[r] - m[r]);
             s[r] = a;
         }
+        if constexpr (ROWS == 4) wave_sum4_dpp(s);
+        else {
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) s[r] = wave_reduce(s[r], OpSum());
+            for (int r = 0; r < ROWS; ++r) s[r] = wave_sum_dpp(s[r]);
+        }
         float keep_lpn = 0.f;
         int keep_arg = 0;
 #pragma unroll
@@ -489,7 +495,7 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_kernel(
 
         float wl[K];
         float m = row_wl2<0, NSLOT>(P, x0, x1, x2, wl);
-        m = wave_reduce(m, OpMax());
+        m = wave_max_dpp(m);
         if (m == NEG_INF) m = 0.f;
         float s = 0.f;
 #pragma unroll
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_kernel(
             wl[k] = __builtin_amdgcn_exp2f(wl[k] - m);
             s += wl[k];
         }
-        s = wave_reduce(s, OpSum());
+        s = wave_sum_dpp(s);
         float inv_den;
         const float lpn2 = lpn2_from(m, s, inv_den);
         lsum += (double)(lpn2 * LN2);
@@ -604,8 +610,9 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_pk_kernel(
     float m0 = cs;
 #pragma unroll
     for (int p = 0; p < KP; ++p) m0 = fmaxf(m0, fmaxf(cc[p].x, cc[p].y));
-    m0 = wave_reduce(m0, OpMax());
-    const bool small_shift = allow_const_shift && m0 <= CS_MAX_SHIFT;   // false for NaN as well
+    m0 = wave_max_dpp(m0);
+    // (false for NaN as well; below -64 the row-maximum loop's "tiny" rule applies, see lpn2_from)
+    const bool small_shift = allow_const_shift && m0 <= CS_MAX_SHIFT && m0 >= -64.0f;
 
     int64_t r0, r1;
     wave_row_range(n, r0, r1);
@@ -620,6 +627,8 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_pk_kernel(
         for (int p = 0; p < KP; ++p) cc[p] = cc[p] - M0;
         cs -= m0;
     }
+    const float eps_scale = __builtin_amdgcn_exp2f(-m0);
+    float lacc = 0.f;                      // sum of log2(den) of the rows since the last flush
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
     if (r0 < r1) { const float* xp = X + 3 * r0; x0 = xp[0]; x1 = xp[1]; x2 = xp[2]; }
     for (int64_t row = r0; row < r1; ++row) {
@@ -657,7 +666,7 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_pk_kernel(
         if (CS) {
             m = m0;
         } else {
-            m = wave_reduce(m, OpMax());
+            m = wave_max_dpp(m);
             if (m == NEG_INF) m = 0.f;
             const f2 M = f2{m, m};
 #pragma unroll
@@ -670,10 +679,23 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_pk_kernel(
         }
         float s = sacc.x + sacc.y;
         if (ODD) s += wls;
-        s = wave_reduce(s, OpSum());
+        s = wave_sum_dpp(s);
         float inv_den;
-        const float lpn2 = lpn2_from(m, s, inv_den);
-        lsum += (double)(lpn2 * LN2);
+        if (CS) {
+            // lpn2_from with m = m0 in [-64, CS_MAX_SHIFT]: no "tiny" case, eps 2^-m0 is loop-invariant;
+            // the log-normalisers are summed in float32 over 8 rows before they join the float64 total
+            const float den = fmaf(FLAT_EPS, eps_scale, s);
+            inv_den = __builtin_amdgcn_rcpf(den);
+            lacc += __builtin_amdgcn_logf(den);
+            if (((row - r0) & 7) == 7) {
+                asm volatile("" ::: "memory");          // keeps this a (wave-uniform) branch, not selects
+                lsum += (double)lacc;
+                lacc = 0.f;
+            }
+        } else {
+            const float lpn2 = lpn2_from(m, s, inv_den);
+            lsum += (double)(lpn2 * LN2);
+        }
         const f2 INV = f2{inv_den, inv_den};
 #pragma unroll
         for (int p = 0; p < KP; ++p) {
@@ -694,6 +716,7 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_pk_kernel(
         }
         x0 = nx0; x1 = nx1; x2 = nx2;
     }
+    if (CS) lsum = (lsum + (double)lacc + (double)(r1 > r0 ? r1 - r0 : 0) * (double)m0) * (double)LN2;
     };
     if (small_shift) rows(std::true_type{});
     else rows(std::false_type{});
@@ -883,12 +906,12 @@ __global__ __launch_bounds__(BLOCK) void flat_chunk_lse_kernel(
         const float nx0 = xn[0], nx1 = xn[1], nx2 = xn[2];
         float wl[K];
         float m = row_wl2<0, CH_SLOTS>(P, x0, x1, x2, wl);
-        m = wave_reduce(m, OpMax());
+        m = wave_max_dpp(m);
         float s = 0.f;
         if (m != NEG_INF) {
 #pragma unroll
             for (int k = 0; k < K; ++k) s += __builtin_amdgcn_exp2f(wl[k] - m);
-            s = wave_reduce(s, OpSum());
+            s = wave_sum_dpp(s);
         }
         const int slot = (int)((row - r0) & 63);
         if (ca) {
@@ -1444,6 +1467,11 @@ static int launch_reduce(hgmm_ctx* c, int nblocks, int valid_j, bool with_lpn, c
                          int n_lpn_blocks = -1) {
     const FlatState& f = c->flat;
     const int total = FLAT_NSTAT * f.Jpad;
+    // Under a communicator the all-reduce below runs in place on f_stats in EVERY enqueued iteration, also
+    // the ones after the device-side stop (whose kernels return at once).  The local statistics are therefore
+    // rebuilt from the (then unchanged) partials each time instead of being left to be summed over the ranks
+    // again and again.
+    if (c->comm_on()) done_flag = nullptr;
     flat_reduce_kernel<<<(total + RED_IDX - 1) / RED_IDX + 1, RED_IDX * RED_SLICES, 0, c->stream>>>(
         c->f_partials.as<float>(), with_lpn ? c->f_lpn_partials.as<double>() : nullptr, nblocks,
         n_lpn_blocks < 0 ? nblocks : n_lpn_blocks, valid_j, f.Jpad, (double)c->n, c->f_stats.as<double>(),

@@ -141,12 +141,30 @@ static void hostcomm_close(hgmm_ctx* c) {
 }
 
 int allreduce_f64_dev(hgmm_ctx* c, double* dev, size_t n) {
+    if (!c->comm_on()) return HGMM_OK;
+    ProfScope prof(c, HGMM_K_ALLREDUCE);
     if (c->comm) {
         HGMM_NCCL(c, ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, c->comm, c->stream));
         return HGMM_OK;
     }
     if (c->hcomm) return hostcomm_allreduce_dev(c, dev, n, 0);
     return HGMM_OK;
+}
+
+// out of place: `src` keeps the rank's own values (callers that enqueue iterations past a device-side stop rely
+// on that: the skipped kernels leave `src` untouched, so the repeated all-reduce reproduces the same `dst`)
+int allreduce_f64_oop(hgmm_ctx* c, const double* src, double* dst, size_t n) {
+    if (!c->comm_on()) {
+        if (src != dst) HGMM_HIP(c, hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+        return HGMM_OK;
+    }
+    ProfScope prof(c, HGMM_K_ALLREDUCE);
+    if (c->comm) {
+        HGMM_NCCL(c, ncclAllReduce(src, dst, n, ncclDouble, ncclSum, c->comm, c->stream));
+        return HGMM_OK;
+    }
+    if (src != dst) HGMM_HIP(c, hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+    return hostcomm_allreduce_dev(c, dst, n, 0);
 }
 
 __global__ void aos_to_soa64_f32(const float* __restrict__ in, int64_t n, int64_t n_pad,
@@ -370,6 +388,7 @@ static int upload_common(hgmm_ctx* c, int64_t n) {
     c->n_pad = (n + 255) / 256 * 256;
     c->flat.active = false;
     c->tree.nodes_ready = false;
+    c->km_labels_n = -1;              // labels / distances of the previous cloud are void
     HGMM_TRY(ensure(c, c->x_aos, sizeof(float) * 3 * (size_t)n));
     HGMM_TRY(ensure(c, c->x_soa64, sizeof(double) * 3 * (size_t)c->n_pad));
     return HGMM_OK;

@@ -169,5 +169,6 @@ int profile_collect(hgmm_ctx* c);
 
 // sub-system entry points implemented in flat_kernels.hip / tree_kernels.hip
 int allreduce_f64_dev(hgmm_ctx* c, double* dev, size_t n);
+int allreduce_f64_oop(hgmm_ctx* c, const double* src, double* dst, size_t n);
 
 }  // namespace hgmm

@@ -292,7 +292,8 @@ __global__ __launch_bounds__(64) void tree_moments_kernel(const double* __restri
 }
 __global__ void tree_mstep_kernel(const double* __restrict__ mom, int64_t lb, int n_level_nodes,
                                   double n_points_total, double ld, double* pi, double* mu, double* cov,
-                                  double* prep) {
+                                  double* prep, const int* __restrict__ done = nullptr) {
+    if (done && *done) return;
     const int cl = blockIdx.x * blockDim.x + threadIdx.x;
     if (cl >= n_level_nodes) return;
     mstep_node(mom + (size_t)cl * NMOM, lb + cl, n_points_total, ld, pi, mu, cov, prep);
@@ -798,10 +799,20 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
         }
         // The stop rule runs on the device (tree_ctl_kernel); the host enqueues `batch` iterations per
         // synchronisation and reads {done, iterations} back, so launches overlap execution.  Kernels of
-        // iterations enqueued past the stop return immediately.  With a communicator every iteration
-        // is synchronised (the all-reduces in between are not predicated).
+        // iterations enqueued past the stop return immediately.  With a communicator the all-reduces of the
+        // enqueued iterations cannot be predicated, so they run out of place: rank-local moments / q stay where
+        // the (skipped) kernels left them, the reduced copies are rebuilt identically, the M-step and the stop
+        // rule read the copies -- surplus iterations are idempotent and no per-iteration host round trip is needed.
         HGMM_HIP(c, hipMemsetAsync(ctl, 0, sizeof(TreeCtl), c->stream));
-        const int batch = c->comm_on() ? 1 : batch_iters;
+        const int batch = batch_iters;
+        double* mom_g = nullptr;
+        double* q_g = q_dev;
+        if (c->comm_on()) {
+            rc = ensure(c, c->comm_buf, sizeof(double) * ((size_t)NMOM * n_level + 8));
+            if (rc != HGMM_OK) break;
+            mom_g = c->comm_buf.as<double>();
+            q_g = mom_g + (size_t)NMOM * n_level;
+        }
         int it = 0;
         bool done = false;
         while (!done) {
@@ -818,10 +829,10 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                                                                    c->comm_on() ? 0 : 1, lb, n_total, ld, d_pi, d_mu, d_cov,
                                                                    d_prep, &ctl->done);
                 if (c->comm_on()) {
-                    rc = allreduce_f64_dev(c, d_mom + NMOM * lb, (size_t)NMOM * n_level);
+                    rc = allreduce_f64_oop(c, d_mom + NMOM * lb, mom_g, (size_t)NMOM * n_level);
                     if (rc != HGMM_OK) break;
-                    tree_mstep_kernel<<<nblk(n_level, 256), 256, 0, c->stream>>>(d_mom + NMOM * lb, lb, n_level,
-                                                                                 n_total, ld, d_pi, d_mu, d_cov, d_prep);
+                    tree_mstep_kernel<<<nblk(n_level, 256), 256, 0, c->stream>>>(mom_g, lb, n_level, n_total, ld, d_pi,
+                                                                                 d_mu, d_cov, d_prep, &ctl->done);
                 }
                 {
                     ProfScope prof(c, HGMM_K_TREE_LOGLIK);
@@ -838,10 +849,10 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                                                                                 q_ticket, q_dev, &ctl->done);
                 }
                 if (c->comm_on()) {
-                    rc = allreduce_f64_dev(c, q_dev, 1);
+                    rc = allreduce_f64_oop(c, q_dev, q_g, 1);
                     if (rc != HGMM_OK) break;
                 }
-                tree_ctl_kernel<<<1, 1, 0, c->stream>>>(q_dev, ctl, ls, max_iters_per_level, trace_dev, trace_cap);
+                tree_ctl_kernel<<<1, 1, 0, c->stream>>>(q_g, ctl, ls, max_iters_per_level, trace_dev, trace_cap);
             }
             if (rc != HGMM_OK) break;
             TreeCtl h;

@@ -38,6 +38,62 @@ __device__ __forceinline__ float wave_reduce(float v, Op op) {
     v = op(v, dpp_f32<DPP_ROW_BCAST31, 0xC>(v));        // rows 2,3 += row 1 (which holds 0+1)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// ---- single-instruction DPP steps --------------------------------------------------------------
+// hipcc lowers `op(v, update_dpp(v))` to v_mov_b32 + v_mov_b32_dpp + v_add/v_max (3 VALU instructions per
+// step, 18 per wave reduction).  The ISA folds the lane permutation into the arithmetic instruction
+// (v_add_f32_dpp / v_max_f32_dpp: 1 instruction per step); lanes a row_mask excludes keep their value,
+// which is exactly the bcast15 / bcast31 tail of the reduction.  Inline asm is opaque to the
+// compiler's hazard recogniser, so the wait states the ISA requires are written out: a DPP operand
+// written by the previous VALU instruction needs 2 (s_nop 1), v_readlane of a just-written VGPR 1,
+// an SGPR written by v_readlane and read by the next VALU instruction 2.
+#define HGMM_DPP_CHAIN(INS)                                                                        \
+    "s_nop 1\n" INS " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"                  \
+    "s_nop 1\n" INS " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"                  \
+    "s_nop 1\n" INS " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"                      \
+    "s_nop 1\n" INS " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n"                           \
+    "s_nop 1\n" INS " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"                         \
+    "s_nop 1\n" INS " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"                         \
+    "s_nop 0\n v_readlane_b32 %1, %0, 63\n s_nop 1\n"
+
+// same summation / maximum order as wave_reduce (bitwise identical results)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    float r;
+    asm volatile(HGMM_DPP_CHAIN("v_add_f32_dpp") : "+v"(v), "=s"(r));
+    return r;
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    float r;
+    asm volatile(HGMM_DPP_CHAIN("v_max_f32_dpp") : "+v"(v), "=s"(r));
+    return r;
+}
+
+// four independent reductions interleaved: the three instructions between two dependent steps cover
+// the DPP wait states, so a wave that runs alone on its SIMD does not stall on s_nop
+#define HGMM_DPP_STEP4(INS, CTRL)                                                                  \
+    INS " %0, %0, %0 " CTRL "\n" INS " %1, %1, %1 " CTRL "\n" INS " %2, %2, %2 " CTRL "\n" INS       \
+        " %3, %3, %3 " CTRL "\n"
+#define HGMM_DPP_CHAIN4(INS)                                                                       \
+    "s_nop 1\n" HGMM_DPP_STEP4(INS, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")               \
+    HGMM_DPP_STEP4(INS, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")                           \
+    HGMM_DPP_STEP4(INS, "row_half_mirror row_mask:0xf bank_mask:0xf")                               \
+    HGMM_DPP_STEP4(INS, "row_mirror row_mask:0xf bank_mask:0xf")                                    \
+    HGMM_DPP_STEP4(INS, "row_bcast:15 row_mask:0xa bank_mask:0xf")                                  \
+    HGMM_DPP_STEP4(INS, "row_bcast:31 row_mask:0xc bank_mask:0xf")                                  \
+    "v_readlane_b32 %4, %0, 63\n v_readlane_b32 %5, %1, 63\n v_readlane_b32 %6, %2, 63\n"            \
+    "v_readlane_b32 %7, %3, 63\n s_nop 1\n"
+__device__ __forceinline__ void wave_sum4_dpp(float (&v)[4]) {
+    float r0, r1, r2, r3;
+    asm volatile(HGMM_DPP_CHAIN4("v_add_f32_dpp")
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "=s"(r0), "=s"(r1), "=s"(r2), "=s"(r3));
+    v[0] = r0; v[1] = r1; v[2] = r2; v[3] = r3;
+}
+__device__ __forceinline__ void wave_max4_dpp(float (&v)[4]) {
+    float r0, r1, r2, r3;
+    asm volatile(HGMM_DPP_CHAIN4("v_max_f32_dpp")
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "=s"(r0), "=s"(r1), "=s"(r2), "=s"(r3));
+    v[0] = r0; v[1] = r1; v[2] = r2; v[3] = r3;
+}
+
 template <class Op>
 __device__ __forceinline__ int wave_reduce_i(int v, Op op) {
     v = op(v, dpp_i32<DPP_QUAD_XOR1>(v));

@@ -2,11 +2,15 @@
 extractors that callers (run_gmm_static.py:35-49, run_gmm_waymo_gpu.py, gmmreg.py:71,84,144)
 use -- ``init()``, ``compute(data)``, ``predict(data)``, ``fit(X)``.
 
-Every class here runs on the MI355X engine; there is no CPU compute path in this package.
-``GMM_CPU`` / ``GMM_CPU_Base`` are kept for API compatibility (3-tuple ``compute``,
-reference gmm.py:103-149) and differ from ``GMM_GPU`` only in what they return.
+``GMM_GPU`` / ``GMM_GPU_Base`` and ``GMM_CPU`` / ``GMM_CPU_Base`` all run on the MI355X engine: this
+package has no CPU compute path.  The ``GMM_CPU`` names are kept for API compatibility (3-tuple
+``compute``, reference gmm.py:103-149); they say so once per process (``EngineNotice`` warning) so that a
+caller timing "CPU vs GPU" is not comparing the engine with itself unknowingly.  ``GMM_Sklearn`` and
+``OneClassSVM`` wrap scikit-learn exactly as the reference does (gmm.py:29-44, 151-177); scikit-learn is
+imported when ``init()`` is called.
 """
 import abc
+import warnings
 
 import numpy as np
 
@@ -69,9 +73,23 @@ class GMM_GPU_Base:
         return predict(X, self.inv_covs, self.means_, self.weights_, cov_type=self.cov_type)
 
 
+class EngineNotice(UserWarning):
+    """Raised (as a warning) when an API name promises a CPU path this package does not have."""
+
+
+def _cpu_name_notice(name):
+    warnings.warn("%s is an API-compatibility name: the fit runs on the MI355X engine (hgmm_amd has no CPU "
+                  "compute path); for a CPU run use the reference's own gmm.py" % name, EngineNotice, stacklevel=3)
+
+
 class GMM_CPU_Base(GMM_GPU_Base):
+    """reference gmm.py:120-149 -- same engine as GMM_GPU_Base, quieter (no min/max print)."""
     _label = 'CPU GMM TRAIN'
     _verbose = False
+
+    def __init__(self, *args, **kwargs):
+        _cpu_name_notice("GMM_CPU_Base")
+        super().__init__(*args, **kwargs)
 
 
 class GMM_GPU(Feature):
@@ -103,3 +121,51 @@ class GMM_CPU(GMM_GPU):
     def compute(self, data):
         self._clf.fit(data)
         return self._clf.means_, self._clf.weights_, self._clf.covariances_
+
+
+class GMM_Sklearn(Feature):
+    """reference gmm.py:29-44: scikit-learn's GaussianMixture (k-means initialisation) behind the
+    Feature protocol; ``compute`` -> (means, weights, covariances, None).  Third-party estimator on the
+    host, kept so that ``from gmm import GMM_CPU, GMM_Sklearn, GMM_GPU`` (run_gmm_static.py:5) resolves."""
+
+    def __init__(self, n_gmm_components=50, max_iter=30, tol=1e-4, cov_type='diag'):
+        self._n_gmm_components = n_gmm_components
+        self.max_iter = max_iter
+        self.tol = tol
+        self.cov_type = cov_type
+
+    def init(self):
+        from sklearn import mixture
+        self._clf = mixture.GaussianMixture(n_components=self._n_gmm_components, max_iter=self.max_iter,
+                                            init_params='kmeans', covariance_type=self.cov_type)
+
+    def compute(self, data):
+        self._clf.fit(data)
+        return self._clf.means_, self._clf.weights_, self._clf.covariances_, None
+
+    def predict(self, data):
+        return self._clf.predict(data)
+
+
+class OneClassSVM(Feature):
+    """reference gmm.py:151-177: support vectors of a one-class SVM as mixture centres, dual
+    coefficients x (2 pi sigma^2)^(ndim/2) as weights.  scikit-learn on the host."""
+
+    def __init__(self, ndim, sigma, gamma=0.5, nu=0.05, delta=10.0):
+        self._ndim = ndim
+        self._sigma = sigma
+        self._gamma = gamma
+        self._nu = nu
+        self._delta = delta
+
+    def init(self):
+        from sklearn import svm
+        self._clf = svm.OneClassSVM(nu=self._nu, kernel="rbf", gamma=self._gamma)
+
+    def compute(self, data):
+        self._clf.fit(data)
+        z = np.power(2.0 * np.pi * self._sigma ** 2, self._ndim * 0.5)
+        return self._clf.support_vectors_, self._clf.dual_coef_[0] * z
+
+    def annealing(self):
+        self._gamma *= self._delta

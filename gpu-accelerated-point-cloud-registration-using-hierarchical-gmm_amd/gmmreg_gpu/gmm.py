@@ -3,7 +3,8 @@ returns ``(means, weights)`` only (reference gmm.py:57,70); covariances start at
 (gmm.py:80); host NumPy results (gmm.py:95)."""
 import numpy as np
 
-from ..gmm_waymo.gmm import Feature  # noqa: F401
+from ..gmm_waymo.gmm import Feature, GMM_Sklearn, _cpu_name_notice  # noqa: F401
+from ..gmm_waymo.gmm import OneClassSVM as _SklearnOneClassSVM
 from . import gmm_impl
 from .gmm_impl import train_gmm, init_gmm_params, timer, predict, asarray  # noqa: F401
 
@@ -39,6 +40,10 @@ class GMM_CPU_Base(GMM_GPU_Base):
     gmmreg_gpu/gmm.py:117); this one works and, like everything here, runs on the GPU engine."""
     _label = 'CPU GMM TRAIN'
 
+    def __init__(self, *args, **kwargs):
+        _cpu_name_notice("GMM_CPU_Base")
+        super().__init__(*args, **kwargs)
+
 
 class GMM_GPU(Feature):
     _base = GMM_GPU_Base
@@ -61,3 +66,9 @@ class GMM_GPU(Feature):
 
 class GMM_CPU(GMM_GPU):
     _base = GMM_CPU_Base
+
+
+class OneClassSVM(_SklearnOneClassSVM):
+    """reference gmmreg_gpu/gmm.py:141-167.  That file imports the third-party ``thundersvm`` at module
+    level (gmm.py:12) but builds the estimator from scikit-learn's ``svm.OneClassSVM`` (gmm.py:158), which
+    is what this class does; ``RigidSVR`` / ``registration_svr`` (gmmreg.py:123-136, 159-169) use it."""

@@ -107,7 +107,29 @@ def registration_gmmreg(source, target, tf_type_name='rigid', callbacks=[], **ka
     return gmmreg.registration(_points(target))
 
 
-def registration_svr(*args, **kwargs):
-    """The reference's support-vector variant (gmmreg.py:159-169) wraps a third-party
-    thundersvm / scikit-learn OneClassSVM feature; it is outside the EM hot path."""
-    raise NotImplementedError("registration_svr relies on a third-party OneClassSVM feature; out of scope")
+class RigidSVR(L2DistRegistration):
+    """reference gmmreg.py:123-136: support-vector registration -- the two clouds are summarised by the
+    support vectors of a one-class SVM (third-party estimator, scikit-learn on the host) instead of a GMM;
+    the L2 cost, its gradient and the Gauss transform behind it are the same device path as RigidGMMReg."""
+
+    def __init__(self, source, sigma=1.0, delta=0.9, gamma=0.5, nu=0.1, use_estimated_sigma=True,
+                 verbose=False, ctx=None):
+        from .._native import default_context
+        super(RigidSVR, self).__init__(source, ft.OneClassSVM(source.shape[1], sigma, gamma, nu),
+                                       cf.RigidCostFunction(ctx=ctx or default_context()), sigma, delta,
+                                       use_estimated_sigma, verbose)
+
+    def _estimate_sigma(self, data):
+        super(RigidSVR, self)._estimate_sigma(data)
+        self._feature_gen._sigma = self._sigma
+        self._feature_gen._gamma = 1.0 / (2.0 * np.square(self._sigma))
+
+
+def registration_svr(source, target, tf_type_name='rigid', maxiter=1, tol=1.0e-3, opt_maxiter=50,
+                     opt_tol=1.0e-3, callbacks=[], **kargs):
+    """reference gmmreg.py:159-169."""
+    if tf_type_name != 'rigid':
+        raise ValueError('Unknown transform type %s' % tf_type_name)
+    svr = RigidSVR(_points(source), **kargs)
+    svr.set_callbacks(callbacks)
+    return svr.registration(_points(target), maxiter, tol, opt_maxiter, opt_tol)

@@ -223,6 +223,7 @@ class GMMTree():
 
     def set_source(self, source):
         self._source = _points(source)
+        self._eig_cache = None                       # node covariances are about to change
         t1 = time.time()
         self._mixingCoeff, self._mean, self._covar = buildGMMTree(
             self._source, self._tree_level, self._ls, self._ld, sig2=self._sig2,
@@ -234,7 +235,8 @@ class GMMTree():
         """Use an existing tree (e.g. a saved one) instead of building from a source cloud."""
         self._mixingCoeff = np.asarray(mixingCoeff, dtype=np.float64)
         self._mean = np.asarray(mean, dtype=np.float64)
-        self._covar = np.asarray(covar, dtype=np.float64)
+        self._covar = np.array(covar, dtype=np.float64)        # own copy: the eigh cache below belongs to it
+        self._eig_cache = None
 
     def set_callbacks(self, callbacks):
         self._callbacks = callbacks
@@ -256,10 +258,8 @@ class GMMTree():
         """eigh of every node covariance.  The nodes do not change during a registration, so the
         decomposition the reference recomputes per node and per iteration (hgmm_gpu.py:737) is
         done once per tree."""
-        key = (id(self._covar), self._covar.shape)
-        if getattr(self, "_eig_key", None) != key:
+        if getattr(self, "_eig_cache", None) is None:     # invalidated by set_source / set_nodes
             self._eig_cache = np.linalg.eigh(self._covar)
-            self._eig_key = key
         return self._eig_cache
 
     def maximization_step(self, estep_res, trans_p):

@@ -8,9 +8,11 @@ the redundant, identical M-step.  This module only bootstraps the communicator: 
 RCCL unique id has to travel from rank 0 to the other ranks once.
 
 Transports for that one message
-  * ``torch.distributed`` (gloo, CPU) when the process was started by ``torch.distributed.run``
-    -- the launcher the benchmark contract prescribes; torch is used for the rendezvous only;
-  * a plain TCP exchange (rank 0 listens on MASTER_ADDR:MASTER_PORT+offset) otherwise.
+  * a plain TCP exchange (default; rank 0 listens on MASTER_ADDR:MASTER_PORT+offset) -- works the same
+    under ``torch.distributed.run`` (which only has to provide RANK / WORLD_SIZE / MASTER_*), under
+    ``bench.py``'s own launcher and under any other one-process-per-GPU launcher; no PyTorch involved;
+  * ``torch.distributed`` (gloo, CPU) on request (``transport="torch"``), for callers that already
+    hold a process group.
 """
 from __future__ import annotations
 
@@ -32,35 +34,67 @@ def shard_bounds(n: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+_MAGIC = b"HGMMUID1"
+PORT_OFFSETS = (37, 1037, 2037, 3037)       # tried in order when MASTER_PORT + offset is taken
+
+
 def exchange_bytes_tcp(rank: int, world: int, payload: bytes | None, addr: str, port: int,
                        timeout: float = 120.0) -> bytes:
-    """Rank 0 sends `payload` to every other rank over plain TCP."""
+    """Rank 0 sends `payload` to every other rank over plain TCP (no third-party package).
+
+    Rank 0 listens on the first free port of ``port + PORT_OFFSETS``; the other ranks try those ports in
+    turn and accept only a peer that opens with the protocol's magic bytes, so a foreign service that
+    happens to sit on one of them is skipped instead of being taken for rank 0."""
     if world == 1:
         return payload
     if rank == 0:
-        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        srv.bind((addr, port))
+        srv = None
+        for off in PORT_OFFSETS:
+            s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                s.bind((addr, port + off))
+                srv = s
+                break
+            except OSError:
+                s.close()
+        if srv is None:
+            raise OSError("unique-id exchange: no free port among %s" % [port + o for o in PORT_OFFSETS])
         srv.listen(world)
         srv.settimeout(timeout)
         try:
-            for _ in range(world - 1):
+            served = 0
+            while served < world - 1:
                 conn, _ = srv.accept()
                 with conn:
-                    conn.sendall(struct.pack("<I", len(payload)) + payload)
+                    conn.settimeout(10.0)
+                    try:
+                        if _recv_exact(conn, len(_MAGIC)) != _MAGIC:
+                            continue                      # not one of ours
+                        conn.sendall(_MAGIC + struct.pack("<I", len(payload)) + payload)
+                        served += 1
+                    except (ConnectionError, socket.timeout, OSError):
+                        continue
         finally:
             srv.close()
         return payload
     deadline = time.time() + timeout
     while True:
-        try:
-            with socket.create_connection((addr, port), timeout=5.0) as s:
-                hdr = _recv_exact(s, 4)
-                return _recv_exact(s, struct.unpack("<I", hdr)[0])
-        except (ConnectionRefusedError, socket.timeout, OSError):
-            if time.time() > deadline:
-                raise
-            time.sleep(0.05)
+        for off in PORT_OFFSETS:
+            try:
+                with socket.create_connection((addr, port + off), timeout=5.0) as s:
+                    s.settimeout(10.0)
+                    s.sendall(_MAGIC)
+                    if _recv_exact(s, len(_MAGIC)) != _MAGIC:
+                        continue
+                    hdr = _recv_exact(s, 4)
+                    return _recv_exact(s, struct.unpack("<I", hdr)[0])
+            except (ConnectionError, socket.timeout, OSError):
+                continue
+        if time.time() > deadline:
+            raise TimeoutError("unique-id exchange: rank 0 not reachable on %s ports %s"
+                               % (addr, [port + o for o in PORT_OFFSETS]))
+        time.sleep(0.05)
 
 
 def _recv_exact(s, n):
@@ -88,7 +122,7 @@ def broadcast_from_rank0(rank: int, world: int, payload: bytes | None, transport
     if world == 1:
         return payload
     if transport == "auto":
-        transport = "torch" if os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("GROUP_RANK") else "tcp"
+        transport = "tcp"
     if transport == "torch":
         return exchange_bytes_torch(rank, world, payload)
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")

@@ -67,23 +67,33 @@ def _lzf_decompress(src: bytes, out_len: int) -> bytes:
         ip += 1
         if ctrl < 32:                                   # literal run of ctrl + 1 bytes
             run = ctrl + 1
+            if ip + run > n or op + run > out_len:
+                raise ValueError("corrupt LZF stream (literal run past the end)")
             out[op:op + run] = src[ip:ip + run]
             ip += run
             op += run
         else:                                           # back reference
             length = ctrl >> 5
             if length == 7:
+                if ip >= n:
+                    raise ValueError("corrupt LZF stream (truncated)")
                 length += src[ip]
                 ip += 1
+            if ip >= n:
+                raise ValueError("corrupt LZF stream (truncated)")
             ref = op - ((ctrl & 0x1f) << 8) - src[ip] - 1
             ip += 1
             length += 2
-            if ref < 0:
-                raise ValueError("corrupt LZF stream")
-            for _ in range(length):                     # may overlap: byte-wise copy
-                out[op] = out[ref]
-                op += 1
-                ref += 1
+            if ref < 0 or op + length > out_len:
+                raise ValueError("corrupt LZF stream (bad back reference)")
+            dist = op - ref
+            if dist >= length:                          # source and destination do not overlap
+                out[op:op + length] = out[ref:ref + length]
+            else:                                       # overlapping run = the last `dist` bytes repeated
+                pat = bytes(out[ref:op])
+                reps = -(-length // dist)
+                out[op:op + length] = (pat * reps)[:length]
+            op += length
     if op != out_len:
         raise ValueError("LZF stream decoded to %d bytes, expected %d" % (op, out_len))
     return bytes(out)

@@ -1,0 +1,29 @@
+"""One rank of bench.py with the engine replaced by the CPU stand-in of test_bench_flow_cpu.py (started by
+bench.launch_ranks in the self-launch tests; not a test module itself)."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+import hgmm_amd  # noqa: E402
+import bench  # noqa: E402
+from test_bench_flow_cpu import FakeContext  # noqa: E402
+
+
+class Ctx(FakeContext):
+    def comm_init(self, world, rank, uid):
+        if "RCCL_BROKEN" in sys.argv[-1]:
+            raise hgmm_amd.HgmmError("ncclCommInitRank failed (test)")
+        super().comm_init(world, rank, uid)
+
+
+if "FAIL_RANK_1" in sys.argv[-1] and os.environ.get("RANK") == "1":
+    sys.exit(3)
+hgmm_amd.Context = Ctx
+bench.N_POINTS = 2000
+bench.synth_frame = lambda seed, n=None: np.random.RandomState(seed).rand(2000, 3).astype(np.float32)
+bench.main()

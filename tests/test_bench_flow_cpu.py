@@ -1,7 +1,11 @@
-"""Control-flow test of bench.py's N > 1 path on CPU: two ranks (spawned like torch.distributed.run
-would: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), a stand-in engine context whose collectives go
-through gloo.  Checks the rendezvous bootstrap, barrier / max-over-ranks timing and that exactly
-rank 0 prints one well-formed JSON line.  (The real engine needs a GPU; kernels are not run here.)"""
+"""Control-flow tests of bench.py's N > 1 path on CPU (the real engine needs a GPU; kernels are not run
+here): a stand-in engine context whose collectives go through gloo.
+
+  * two ranks spawned the way torch.distributed.run would (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*):
+    the plain-TCP unique-id bootstrap, barrier / max-over-ranks block timing, exactly one well-formed JSON
+    line from rank 0 (with `allreduce_us` for N > 1);
+  * the same through bench.py's OWN launcher (`launch_ranks`, what `python bench.py --gpus N` without a
+    launcher does), including the exit-code path of a failing rank and the RCCL -> host-backend retry."""
 import json
 import multiprocessing as mp
 import os
@@ -34,6 +38,9 @@ class FakeContext:
         assert uid == bytes(range(128))
         self.world, self.rank = world, rank
 
+    def comm_init_host(self, world, rank, name):
+        self.world, self.rank, self.hostcomm = world, rank, name
+
     def comm_destroy(self):
         pass
 
@@ -51,8 +58,13 @@ class FakeContext:
         pass
 
     def allreduce(self, values, op="sum"):
+        # the stand-in's collectives ride on gloo (the product's ride on RCCL inside the library)
         import torch
         import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ["MASTER_PORT"] = str(int(os.environ["MASTER_PORT"]) + 5)
+            dist.init_process_group(backend="gloo", rank=int(os.environ["RANK"]),
+                                    world_size=int(os.environ["WORLD_SIZE"]))
         t = torch.tensor(np.asarray(values, dtype=np.float64))
         dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
         return t.numpy()
@@ -90,7 +102,7 @@ def _rank_main(rank, world, port, q):
     hgmm_amd.Context = FakeContext
     bench.N_POINTS = 2000                       # keep the synthetic frames tiny
     bench.synth_frame = lambda seed, n=2000: np.random.RandomState(seed).rand(n, 3).astype(np.float32)
-    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "3", "--warmup", "1"]
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "3", "--warmup", "1", "--min-time", "0"]
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         bench.main()
@@ -125,4 +137,52 @@ def test_bench_two_rank_flow():
         assert k in d
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["roofline"] is None and d["cpu_baseline"] is None
-    assert "workload" in d["config"]
+    assert "workload" in d["config"] and "RCCL" in d["config"]["collective"]
+    assert d["allreduce_us"] == 500.0 and d["timing"]["blocks"] >= 3 and d["timing"]["steps_per_block"] == 3
+    assert "torch" not in open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                            "bench.py")).read().split('"""', 2)[2].replace("torch.distributed.run", "")
+
+
+HELPER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bench_fake_rank.py")
+
+
+def _run_launcher(n, mode, extra_args=()):
+    """python -c 'bench.launch_ranks / self_launch' in a child so that rank 0's inherited stdout can be captured."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, types; sys.path.insert(0, %r); import bench\n"
+            "args = types.SimpleNamespace(gpus=%d)\n"
+            "argv = ['--gpus', '%d', '--steps', '2', '--warmup', '1', '--min-time', '0'] + %r\n"
+            "bench.__file__ = %r\n"
+            "import os\n"
+            "orig = bench.launch_ranks\n"
+            "bench.launch_ranks = lambda n, argv, script=None, **kw: orig(n, argv, script=%r, **kw)\n"
+            "sys.exit(bench.self_launch(args, argv) if %r == 'self' else bench.launch_ranks(%d, argv))\n"
+            % (root, n, n, list(extra_args), HELPER, HELPER, mode, n))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+
+
+def test_self_launch_two_ranks():
+    r = _run_launcher(2, "self")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and "allreduce_us" in d
+
+
+def test_self_launch_reports_a_failing_rank():
+    r = _run_launcher(2, "plain", ["--skip", "FAIL_RANK_1"])
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+
+
+def test_self_launch_retries_on_the_host_backend_when_rccl_is_unavailable():
+    r = _run_launcher(2, "self", ["--skip", "RCCL_BROKEN"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert "fallback" in d["config"] and "host shared memory" in d["config"]["collective"]

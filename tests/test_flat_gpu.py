@@ -546,3 +546,28 @@ def test_train_huge_shift_takes_the_row_maximum_variant(ctx):
     # the oracle's expanded quadratic form (the reference's) cancels ~2.5e14-sized terms here:
     # even in float64 its q carries ~0.03 of rounding noise, so only a loose check on lls
     np.testing.assert_allclose(lls, o[4], rtol=0, atol=0.05)
+
+
+def test_device_points_go_stale_after_any_other_upload(ctx, bunny):
+    """every replacement of the resident cloud -- also the ones the HGMM entry points do
+    through ctx.set_points -- must trip the stale-handle error of a DevicePoints taken before it."""
+    import hgmm_amd
+    from hgmm_amd.gmm_waymo import gmm_impl as W
+    from hgmm_amd.hgmm import hgmm_gpu as H
+    hgmm_amd.set_default_context(ctx)
+    X = bunny[::8]
+    mu0, w0, cov0 = flat_em.seeded_init(X, 8, 2)
+    dX = W.asarray(X)
+    W.train_gmm(dX, 2, 0.0, mu0, cov0, w0)                                   # fresh handle: fine
+    other = bunny[1::16].astype(np.float64)
+    H.buildGMMTree(other, 1, 80.0, 1e-4, sig2=0.00034)                        # replaces the resident cloud
+    for call in (lambda: W.train_gmm(dX, 2, 0.0, mu0, cov0, w0),
+                 lambda: W.e_step(dX, 1 / np.sqrt(cov0), mu0, w0),
+                 lambda: W.predict(dX, 1 / np.sqrt(cov0), mu0, w0)):
+        with pytest.raises(RuntimeError):
+            call()
+    dX2 = W.asarray(X)                                                        # a new upload is valid again
+    assert len(W.train_gmm(dX2, 2, 0.0, mu0, cov0, w0)[4]) == 2
+    ctx.set_points(X)                                                         # direct upload on the context
+    with pytest.raises(RuntimeError):
+        W.predict(dX2, 1 / np.sqrt(cov0), mu0, w0)

@@ -1,8 +1,12 @@
-"""The N > 1 data path on ONE GPU: two processes, each with its own context on device 0 and its own
-shard of the cloud, joined by the host shared-memory communicator (hgmm_comm_init_host -- the same
-all-reduce call sites as RCCL, which does not accept two ranks on one device).  Every sharded fit
-must reproduce the single-context fit on the whole cloud: same iteration counts and hard labels,
-parameters equal to summation-order noise."""
+"""The N > 1 data path: two processes, each with its own context and its own shard of the cloud.
+
+  * on ONE GPU the ranks are joined by the host shared-memory communicator (hgmm_comm_init_host -- the same
+    all-reduce call sites as RCCL, which does not accept two ranks on one device);
+  * with >= 2 GPUs visible the same comparison runs over RCCL (one rank per GPU, unique id shipped over the
+    package's plain-TCP bootstrap) -- skipped on a single-GPU box.
+
+Every sharded fit must reproduce the single-context fit on the whole cloud: same iteration counts and hard
+labels, parameters equal to summation-order noise."""
 import multiprocessing as mp
 import os
 
@@ -57,10 +61,17 @@ def _run_all(ctx, lo, hi):
     return out
 
 
-def _worker(rank, name, q):
+def _worker(rank, name, q, rccl_port=None):
     import hgmm_amd
-    ctx = hgmm_amd.Context(0)
-    ctx.comm_init_host(2, rank, name)
+    if rccl_port is None:
+        ctx = hgmm_amd.Context(0)
+        ctx.comm_init_host(2, rank, name)
+    else:
+        from hgmm_amd import parallel
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(rccl_port), RANK=str(rank), LOCAL_RANK=str(rank),
+                          WORLD_SIZE="2")
+        ctx = hgmm_amd.Context(rank)                       # one rank per GPU
+        parallel.attach_communicator(ctx, rank, 2, transport="tcp")
     lo, hi = (0, SPLIT) if rank == 0 else (SPLIT, N_ALL)
     res = _run_all(ctx, lo, hi)
     total = ctx.allreduce([float(hi - lo)])[0]
@@ -69,11 +80,31 @@ def _worker(rank, name, q):
 
 
 def test_two_ranks_on_one_gpu_match_the_single_context_fit():
+    _two_ranks_match_single_context(None)
+
+
+def test_rccl_two_ranks_two_gpus():
+    """Same comparison over RCCL / xGMI when the box has two GPUs (the driver's 8-GPU node; a 1-GPU box skips)."""
+    import ctypes
+    import socket
+    import hgmm_amd
+    cnt = ctypes.c_int(0)
+    hgmm_amd.load_library().hgmm_device_count(ctypes.byref(cnt))
+    if cnt.value < 2:
+        pytest.skip("needs >= 2 GPUs (found %d)" % cnt.value)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    _two_ranks_match_single_context(port)
+
+
+def _two_ranks_match_single_context(rccl_port):
     import hgmm_amd
     name = "hgmm_test_%d" % os.getpid()
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    procs = [mpc.Process(target=_worker, args=(r, name, q)) for r in range(2)]
+    procs = [mpc.Process(target=_worker, args=(r, name, q, rccl_port)) for r in range(2)]
     for p in procs:
         p.start()
     got = {}

@@ -88,6 +88,17 @@ def test_lzf_back_references():
     assert _lzf_decompress(stream, 6 + 1 + 12) == b"abcabc" + b"x" + b"x" * 12
     with pytest.raises(ValueError):
         _lzf_decompress(bytes([(1 << 5) | 0, 9]), 3)
+    # truncated / overlong streams raise ValueError instead of silently shrinking the output
+    for bad, n in ((bytes([5]) + b"ab", 6),                       # literal run longer than the stream
+                   (bytes([2]) + b"abc" + bytes([(7 << 5) | 0]), 20),     # long back reference cut before its length
+                   (bytes([2]) + b"abc" + bytes([(1 << 5) | 0]), 6),      # back reference cut before its offset
+                   (bytes([2]) + b"abc" + bytes([(1 << 5) | 0, 2]), 4),   # back reference past the output size
+                   (bytes([2]) + b"abc", 7)):                              # decodes to fewer bytes than announced
+        with pytest.raises(ValueError):
+            _lzf_decompress(bad, n)
+    # overlapping back reference with a pattern longer than one byte: "ab" repeated
+    stream = bytes([1]) + b"ab" + bytes([(5 << 5) | 0, 1])
+    assert _lzf_decompress(stream, 2 + 7) == b"ab" + b"abababa"
 
 
 def test_voxel_down_sample_properties(bunny):

@@ -1,0 +1,190 @@
+// VALU / MFMA issue-rate probe for gfx950 (MI355X): cycles per wave-instruction of the instruction
+// classes the flat EM kernels are made of, at 1 and 2 waves per SIMD.  Evidence for the roofline of
+// flat_fused_pk_kernel (VALU-bound): what a packed fp32 op, a plain fp32 op, a transcendental and a DPP
+// step cost, and whether fp32 MFMA work overlaps VALU work of the same wave.
+//
+//   hipcc --offload-arch=gfx950 -O3 -o tools/valubench tools/valubench.hip && tools/valubench
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+#define REP8(X) X X X X X X X X
+#define REP64(X) REP8(REP8(X))
+
+enum { OP_FMA = 0, OP_PKFMA, OP_PKMUL, OP_PKADD, OP_EXP, OP_RCP, OP_DPPADD, OP_FMA64, OP_MFMA, OP_MFMA_PKFMA,
+       OP_MIX_FUSED, OP_PKFMA_DEP, OP_FMA_DEP, OP_ADD, OP_COUNT };
+static const char* NAMES[] = {"v_fma_f32 (8 chains)", "v_pk_fma_f32 (8 chains)", "v_pk_mul_f32 (8 chains)",
+                              "v_pk_add_f32 (8 chains)", "v_exp_f32 (8 chains)", "v_rcp_f32 (8 chains)",
+                              "v_add_f32 dpp row_shr:1 (8 chains)", "v_fma_f64 (8 chains)",
+                              "v_mfma_f32_16x16x4_f32 (4 acc)", "mfma_f32_16x16x4 + 8 v_pk_fma_f32 per mfma",
+                              "fused-kernel mix: 24 pk + 2 exp per pair", "v_pk_fma_f32 (1 dependent chain)",
+                              "v_fma_f32 (1 dependent chain)", "v_add_f32 (8 chains)"};
+static const int INSTR_PER_BODY[] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 72, 26 * 4, 64, 64, 64};
+
+template <int OP>
+__global__ __launch_bounds__(256) void probe(float* out, long long* cyc, int iters) {
+    float s0 = threadIdx.x * 1e-3f, s1 = s0 + 1.f, s2 = s0 + 2.f, s3 = s0 + 3.f, s4 = s0 + 4.f, s5 = s0 + 5.f,
+          s6 = s0 + 6.f, s7 = s0 + 7.f;
+    f2 p0 = {s0, s1}, p1 = {s2, s3}, p2 = {s4, s5}, p3 = {s6, s7}, p4 = {s1, s0}, p5 = {s3, s2}, p6 = {s5, s4},
+       p7 = {s7, s6};
+    const f2 ka = {0.999f, 1.001f}, kb = {1e-3f, -1e-3f};
+    const float fa = 0.999f, fb = 1e-3f;
+    double d0 = s0, d1 = s1, d2 = s2, d3 = s3, d4 = s4, d5 = s5, d6 = s6, d7 = s7;
+    f4 m0 = {0, 0, 0, 0}, m1 = m0, m2 = m0, m3 = m0;
+    const long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+        if (OP == OP_FMA) {
+            REP8(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n"
+                              "v_fma_f32 %3, %3, %8, %9\n v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n"
+                              "v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                              : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7)
+                              : "v"(fa), "v"(fb));)
+        } else if (OP == OP_ADD) {
+            REP8(asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n"
+                              "v_add_f32 %3, %3, %8\n v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n"
+                              "v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8\n"
+                              : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7)
+                              : "v"(fb));)
+        } else if (OP == OP_FMA_DEP) {
+            REP64(asm volatile("v_fma_f32 %0, %0, %1, %2\n" : "+v"(s0) : "v"(fa), "v"(fb));)
+        } else if (OP == OP_PKFMA_DEP) {
+            REP64(asm volatile("v_pk_fma_f32 %0, %0, %1, %2\n" : "+v"(p0) : "v"(ka), "v"(kb));)
+        } else if (OP == OP_PKFMA || OP == OP_PKMUL || OP == OP_PKADD) {
+#define PK8(INS, TAIL)                                                                                         \
+    REP8(asm volatile(INS " %0, %0, %8" TAIL "\n" INS " %1, %1, %8" TAIL "\n" INS " %2, %2, %8" TAIL "\n" INS    \
+                          " %3, %3, %8" TAIL "\n" INS " %4, %4, %8" TAIL "\n" INS " %5, %5, %8" TAIL "\n" INS    \
+                          " %6, %6, %8" TAIL "\n" INS " %7, %7, %8" TAIL "\n"                                    \
+                      : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7)          \
+                      : "v"(ka), "v"(kb));)
+            if (OP == OP_PKFMA) { PK8("v_pk_fma_f32", ", %9") }
+            else if (OP == OP_PKMUL) { PK8("v_pk_mul_f32", "") }
+            else { PK8("v_pk_add_f32", "") }
+        } else if (OP == OP_EXP || OP == OP_RCP) {
+#define TR8(INS)                                                                                               \
+    REP8(asm volatile(INS " %0, %0\n" INS " %1, %1\n" INS " %2, %2\n" INS " %3, %3\n" INS " %4, %4\n" INS        \
+                          " %5, %5\n" INS " %6, %6\n" INS " %7, %7\n"                                            \
+                      : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7));)
+            if (OP == OP_EXP) { TR8("v_exp_f32") } else { TR8("v_rcp_f32") }
+        } else if (OP == OP_DPPADD) {
+            REP8(asm volatile("v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                              "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                              "v_add_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                              "v_add_f32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                              "v_add_f32_dpp %4, %4, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                              "v_add_f32_dpp %5, %5, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                              "v_add_f32_dpp %6, %6, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                              "v_add_f32_dpp %7, %7, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+                              : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7));)
+        } else if (OP == OP_FMA64) {
+            const double da = 0.999, db = 1e-3;
+            REP8(asm volatile("v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n"
+                              "v_fma_f64 %3, %3, %8, %9\n v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n"
+                              "v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9\n"
+                              : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7)
+                              : "v"(da), "v"(db));)
+        } else if (OP == OP_MFMA) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                m0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, m0, 0, 0, 0);
+                m1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, m1, 0, 0, 0);
+                m2 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, m2, 0, 0, 0);
+                m3 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, m3, 0, 0, 0);
+            }
+        } else if (OP == OP_MFMA_PKFMA) {
+            // 8 mfma, each followed by 8 independent packed fmas: does the VALU work hide under the matrix pipe?
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#define MF(ACC)                                                                                                 \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, ACC, 0, 0, 0);                                           \
+    asm volatile("v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n"      \
+                 "v_pk_fma_f32 %3, %3, %8, %9\n v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n"      \
+                 "v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9\n"                                    \
+                 : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7)               \
+                 : "v"(ka), "v"(kb));
+                MF(m0) MF(m1) MF(m2) MF(m3)
+            }
+        } else if (OP == OP_MIX_FUSED) {
+            // the instruction mix of one component pair of flat_fused_pk_kernel, 4 pairs per body
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                asm volatile(
+                    "v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %1, %1, %8\n v_pk_add_f32 %2, %2, %8\n"
+                    "v_pk_mul_f32 %3, %0, %8\n v_pk_mul_f32 %4, %1, %8\n v_pk_mul_f32 %5, %2, %8\n"
+                    "v_pk_fma_f32 %6, %3, %0, %9\n v_pk_fma_f32 %6, %4, %1, %6\n v_pk_fma_f32 %6, %5, %2, %6\n"
+                    "v_exp_f32 %10, %10\n v_exp_f32 %11, %11\n"
+                    "v_pk_add_f32 %7, %7, %6\n"
+                    "v_pk_mul_f32 %6, %6, %8\n"
+                    "v_pk_add_f32 %0, %0, %9\n v_pk_add_f32 %1, %1, %9\n v_pk_add_f32 %2, %2, %9\n"
+                    "v_pk_mul_f32 %3, %6, %0\n v_pk_mul_f32 %4, %6, %1\n v_pk_mul_f32 %5, %6, %2\n"
+                    "v_pk_add_f32 %7, %7, %6\n"
+                    "v_pk_add_f32 %7, %7, %3\n v_pk_add_f32 %7, %7, %4\n v_pk_add_f32 %7, %7, %5\n"
+                    "v_pk_fma_f32 %7, %3, %0, %7\n v_pk_fma_f32 %7, %4, %1, %7\n v_pk_fma_f32 %7, %5, %2, %7\n"
+                    : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7)
+                    : "v"(ka), "v"(kb), "v"(s0), "v"(s1));
+            }
+        }
+    }
+    const long long t1 = clock64();
+    float r = s0 + s1 + s2 + s3 + s4 + s5 + s6 + s7 + p0.x + p1.x + p2.x + p3.x + p4.y + p5.y + p6.y + p7.y +
+              (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7) + m0.x + m1.y + m2.z + m3.w;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int OP>
+static void run(int blocks, int iters, float* out, long long* cyc) {
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    probe<OP><<<blocks, 256>>>(out, cyc, iters);
+    hipEventRecord(a);
+    probe<OP><<<blocks, 256>>>(out, cyc, iters);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    std::vector<long long> h(blocks * 4);
+    hipMemcpy(h.data(), cyc, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+    double mean = 0;
+    for (auto v : h) mean += (double)v;
+    mean /= (double)h.size();
+    const double instr = (double)INSTR_PER_BODY[OP] * iters;
+    // s_memtime ticks at a fixed 100 MHz on gfx9 (REFCLK), so convert through wall time as well
+    const double waves_per_simd = blocks / 256.0;
+    const double wall_cyc_24 = ms * 1e-3 * 2.4e9;
+    printf("%-48s waves/SIMD %.0f  %8.3f ms  clock64/instr %7.3f  wall-cycles@2.4GHz per instr per SIMD %6.2f\n",
+           NAMES[OP], waves_per_simd, ms, mean / instr, wall_cyc_24 / (instr * waves_per_simd));
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+}
+
+int main() {
+    float* out;
+    long long* cyc;
+    hipMalloc(&out, sizeof(float) * 1024 * 256);
+    hipMalloc(&cyc, sizeof(long long) * 1024 * 4);
+    const int iters = 4000;
+    for (int rep = 0; rep < 2; ++rep)
+        for (int blocks : {256, 512}) {
+            run<OP_FMA>(blocks, iters, out, cyc);
+            run<OP_ADD>(blocks, iters, out, cyc);
+            run<OP_FMA_DEP>(blocks, iters, out, cyc);
+            run<OP_PKFMA>(blocks, iters, out, cyc);
+            run<OP_PKFMA_DEP>(blocks, iters, out, cyc);
+            run<OP_PKMUL>(blocks, iters, out, cyc);
+            run<OP_PKADD>(blocks, iters, out, cyc);
+            run<OP_EXP>(blocks, iters, out, cyc);
+            run<OP_RCP>(blocks, iters, out, cyc);
+            run<OP_DPPADD>(blocks, iters, out, cyc);
+            run<OP_FMA64>(blocks, iters, out, cyc);
+            run<OP_MFMA>(blocks, iters, out, cyc);
+            run<OP_MFMA_PKFMA>(blocks, iters, out, cyc);
+            run<OP_MIX_FUSED>(blocks, iters, out, cyc);
+        }
+    return 0;
+}
