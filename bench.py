@@ -316,7 +316,7 @@ def fullcov_leg(ctx):
     ctx.fullcov_fit(J, 1e-30, 1e-4, P[idx], 0.01, 2)                   # warm-up
     ctx.profile_reset()
     ctx.profile_enable(True)
-    iters = 6
+    iters = 20
     t0 = time.perf_counter()
     ctx.fullcov_fit(J, 1e-30, 1e-4, P[idx], 0.01, iters)
     dt = time.perf_counter() - t0

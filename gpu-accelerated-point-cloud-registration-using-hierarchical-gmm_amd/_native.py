@@ -18,7 +18,7 @@ COV_TYPES = {"diag": 0, "spherical": 1}
 VARIANTS = {"W": 0, "G": 1}
 KERNEL_IDS = {"flat_estep": 0, "flat_fused": 1, "flat_mstep": 2, "tree_estep": 3,
               "tree_loglik": 4, "tree_reg": 5, "util_fill": 6, "full_pass": 7, "full_moments": 8,
-              "kmeans_assign": 9, "kmeans_accum": 10, "allreduce": 11}
+              "kmeans_assign": 9, "kmeans_accum": 10, "allreduce": 11, "full_fused": 12}
 
 
 class HgmmError(RuntimeError):

@@ -44,12 +44,7 @@ __device__ __forceinline__ double dist2(double x, double y, double z, double cx,
     return dx * dx + dy * dy + dz * dz;
 }
 
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
-    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
+// (readlane_f64: wave_ops.h)
 
 // inclusive prefix sum over the 64 lanes
 __device__ __forceinline__ double wave_scan_f64(double v) {

@@ -26,6 +26,7 @@
 #include "wave_ops.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -1130,6 +1131,328 @@ __global__ __launch_bounds__(FULL_BLOCK) void full_moments_kernel(const double* 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// One-pass E-step of the flat full-covariance EM: every pdf (an fp64 exp) is evaluated ONCE.
+//
+// full_pass_kernel + full_moments_kernel evaluate every pi_j N(x_i; j) twice (once for the denominators, once
+// more for the statistics) and the second kernel re-streams all points once per 16-component tile.  Here a
+// workgroup (8 waves) takes FT_P = 16 points at a time and keeps the tile's un-normalised
+// g[p][j] = pi_j N(x_p; j) in LDS (16 x (J16 + 16) doubles = 104 KB at J = 800):
+//   phase A  lanes across components (<= 2 per lane, their (Sigma^-1, mu, pi coef) in registers), the tile's
+//            points wave-uniform (scalar loads): g -> LDS, point-major (conflict-free writes)
+//   phase B  each wave owns 2 of the 16 points: row sum = denominator, first arg-max, the log-likelihood
+//            term (components with pi >= eps only), the point's 10 features -> LDS
+//   phase C  M[j][f] += sum_p gamma[p][j] F[p][f] on the fp64 matrix cores (v_mfma_f64_16x16x4_f64, A = gamma
+//            read back from LDS, normalised and thresholded on the fly; B = features); wave w owns the
+//            16-component tiles w, w + 8, ... and keeps their accumulators in registers across ALL of the
+//            workgroup's points.
+// Deterministic (fixed tile -> workgroup map, fixed accumulation order); one partial per workgroup, summed by
+// full_reduce_kernel.  LDS row stride J16 + 16 == 16 (mod 32) makes the A-fragment reads conflict-free.
+// ------------------------------------------------------------------------------------------
+// exp(y) for y <= 0, branch-free (the library exp costs ~30 instructions plus exec-mask branches per call):
+// y clamped to >= -708 (results stay normal; what the clamp changes is < 3.3e-308), n = round(y log2 e) by
+// the 1.5 * 2^52 trick, r = y - n ln 2 in two steps, degree-13 Taylor polynomial on |r| <= 0.347 (remainder
+// 4e-18), 2^n added into the exponent field.  Relative error ~1e-16.
+// Four values at a time: the Horner steps 13..3 of the four polynomials are written as ONE block of three-address
+// v_fma_f64, interleaved so that consecutive instructions are independent (hipcc picks the two-address
+// v_fmac_f64 and pays a v_mov_b64 per step to copy the coefficient into the destination; a block per
+// polynomial is a chain of dependent fp64 fmas, 8+ cycles apart, that two waves per SIMD cannot cover).
+__device__ __forceinline__ void exp_nonpos4(const double (&yin)[4], double (&out)[4]) {
+    constexpr double MAGIC = 6755399441055744.0;          // 1.5 * 2^52
+    constexpr double LOG2E = 1.4426950408889634074, LN2_HI = 6.93147180369123816490e-01,
+                     LN2_LO = 1.90821492927058770002e-10;
+    double t[4], r[4], p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double y = fmax(fmin(yin[k], 0.0), -708.0);
+        t[k] = fma(y, LOG2E, MAGIC);
+        const double nf = t[k] - MAGIC;
+        r[k] = fma(nf, -LN2_LO, fma(nf, -LN2_HI, y));
+    }
+#define HGMM_H4(C)                                                                                  \
+    "v_fma_f64 %0, %0, %4, " C "\n\tv_fma_f64 %1, %1, %5, " C "\n\tv_fma_f64 %2, %2, %6, " C          \
+    "\n\tv_fma_f64 %3, %3, %7, " C "\n\t"
+    asm("v_fma_f64 %0, %8, %4, %9\n\tv_fma_f64 %1, %8, %5, %9\n\tv_fma_f64 %2, %8, %6, %9\n\t"
+        "v_fma_f64 %3, %8, %7, %9\n\t"
+        HGMM_H4("%10") HGMM_H4("%11") HGMM_H4("%12") HGMM_H4("%13") HGMM_H4("%14") HGMM_H4("%15") HGMM_H4("%16")
+        HGMM_H4("%17") HGMM_H4("%18")
+        : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3])
+        : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(1.0 / 6227020800.0), "v"(1.0 / 479001600.0),
+          "v"(1.0 / 39916800.0), "v"(1.0 / 3628800.0), "v"(1.0 / 362880.0), "v"(1.0 / 40320.0), "v"(1.0 / 5040.0),
+          "v"(1.0 / 720.0), "v"(1.0 / 120.0), "v"(1.0 / 24.0), "v"(1.0 / 6.0));
+#undef HGMM_H4
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double q = fma(p[k], r[k], 0.5);
+        q = fma(q, r[k], 1.0);
+        q = fma(q, r[k], 1.0);
+        const int n = __double2loint(t[k]);               // low mantissa word of t = n (two's complement)
+        out[k] = __hiloint2double(__double2hiint(q) + (n << 20), __double2loint(q));
+    }
+}
+
+constexpr int FT_P = 16;                 // points per tile
+constexpr int FT_WAVES = 8;
+constexpr int FT_BLOCK = FT_WAVES * 64;
+constexpr int FT_LDF = 18;               // feature rows: 16 points + 2 (conflict-free B-fragment reads)
+constexpr int FT_MAX_J16 = 1024;
+
+__host__ __device__ inline int ft_ldg(int J16) {        // doubles per point row of g: == 16 (mod 32), and room
+    return (J16 + 127) / 128 * 128 + 16;                // for whole 128-column steps (tail columns stay 0)
+}
+inline size_t ft_lds_bytes(int J16) {
+    return sizeof(double) * ((size_t)FT_P * ft_ldg(J16) + 16 * FT_LDF + 2 * FT_P + J16 + 2 * 3 * FT_P);
+}
+
+template <int CPL>
+__global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
+    const double* __restrict__ xs, int64_t n, int64_t n_pad, const double* __restrict__ prep, int J16,
+    int* __restrict__ label_out, double* __restrict__ block_q, double* __restrict__ partials /*[grid][J16][NMOM]*/,
+    int want_stats, long long* __restrict__ dbg = nullptr) {
+    extern __shared__ double lds[];
+    long long tA = 0, tB = 0, tC = 0, tW = 0, tm = 0;
+#define FT_TICK(acc) do { if (dbg) { const long long now_ = clock64(); acc += now_ - tm; tm = now_; } } while (0)
+    const int LDG = ft_ldg(J16);
+    double* G = lds;                              // [FT_P][LDG]
+    double* F = G + (size_t)FT_P * LDG;           // [16 features][FT_LDF]
+    double* INV = F + 16 * FT_LDF;                // [FT_P] 1 / denominator (0: dead point)
+    double* TOT = INV + FT_P;                     // [FT_P] sum over the components with pi >= eps (-1: dead point)
+    double* WL = TOT + FT_P;                      // [J16] 1.0 where pi_j >= eps (the component counts towards q)
+    double* XS = WL + J16;                        // [2][3][FT_P] the tile's coordinates, double-buffered
+    const int w = wave_in_block(), lane = lane_id();
+    const int tid = (int)threadIdx.x;
+
+    // this lane's components: slot 0 = tid; slot 1 (J16 > 512) = tid + 512.  When the last wave of slot 1 has at
+    // most 32 components left, its two half-waves take the SAME components for 8 points each instead of leaving
+    // half the lanes idle for 16 points (J = 800: 4.5 second-slot waves cost 4.5, not 5, wave-passes).
+    const int R = (CPL == 2) ? J16 - FT_BLOCK : 0;
+    const int w_r = R / 64, rem = R % 64;
+    const bool half_wave = CPL == 2 && w == w_r && rem > 0 && rem <= 32;
+    int jc[CPL];
+    jc[0] = tid;
+    if (CPL == 2) jc[1] = half_wave ? FT_BLOCK + 64 * w_r + (lane & 31) : tid + FT_BLOCK;
+    double s00[CPL], s01[CPL], s02[CPL], s11[CPL], s12[CPL], s22[CPL], m0[CPL], m1[CPL], m2[CPL], wE[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int j = jc[c];
+        wE[c] = 0.0;
+        s00[c] = s01[c] = s02[c] = s11[c] = s12[c] = s22[c] = m0[c] = m1[c] = m2[c] = 0.0;
+        if (j < J16) {
+            const double* pr = prep + PREP_N * j;
+            // -1/2 Sigma^-1: the quadratic form below is the (non-positive) exponent itself
+            s00[c] = -0.5 * pr[0]; s01[c] = -0.5 * pr[1]; s02[c] = -0.5 * pr[2];
+            s11[c] = -0.5 * pr[3]; s12[c] = -0.5 * pr[4]; s22[c] = -0.5 * pr[5];
+            m0[c] = pr[6]; m1[c] = pr[7]; m2[c] = pr[8]; wE[c] = pr[9];
+        }
+    }
+    // components with 0 < pi < eps take part in the E-step but not in q (C:80): rare enough that the second row
+    // sum is only formed when one exists (workgroup-uniform flag)
+    int my_small = 0;
+    for (int j = tid; j < J16; j += FT_BLOCK) {
+        const double wl = prep[PREP_N * j + 10], we = prep[PREP_N * j + 9];
+        WL[j] = (wl != 0.0) ? 1.0 : 0.0;
+        if (wl == 0.0 && we != 0.0) my_small = 1;
+    }
+    for (int e = tid; e < FT_P * LDG; e += FT_BLOCK) G[e] = 0.0;   // phase B reads whole 64-column steps
+    const bool any_small = __syncthreads_or(my_small) != 0;
+    // accumulator tiles of this wave
+    const int ntiles = J16 / 16;
+    constexpr int MAXT = (FT_MAX_J16 / 16 + FT_WAVES - 1) / FT_WAVES;     // 8
+    double4_t acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+    const int a_idx = lane & 15, b_idx = lane >> 4;
+
+    const int64_t tiles = (n + FT_P - 1) / FT_P;
+    const int64_t per = (tiles + gridDim.x - 1) / gridDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * per;
+    const int64_t t1 = (t0 + per < tiles) ? t0 + per : tiles;
+    double lq = 0.0;                              // lane 0 of each wave: sum of its points' log-likelihood terms
+
+    // coordinates of a tile -> LDS buffer `buf` (threads 0..47; rows past the end repeat the last point)
+    auto stage = [&](int64_t tile, int buf) {
+        if (tid < 3 * FT_P) {
+            const int d = tid / FT_P, p = tid % FT_P;
+            int64_t i = tile * FT_P + p;
+            i = i < n ? i : n - 1;
+            XS[(buf * 3 + d) * FT_P + p] = xs[(size_t)d * n_pad + i];
+        }
+    };
+    if (t0 < t1) stage(t0, 0);
+    __syncthreads();
+    for (int64_t tile = t0; tile < t1; ++tile) {
+        const int64_t base = tile * FT_P;
+        const int buf = (int)((tile - t0) & 1);
+        const double* X = XS + buf * 3 * FT_P;
+        if (dbg) tm = clock64();
+        // ---- phase A: g[p][j] for the lane's components, all 16 points (branch-free: a component with
+        //      pi = 0 or a singular covariance has wE = 0 and S = 0, q >= 1500 gives exp -> 0 anyway) ----------
+        // four (point, component) pairs per step
+        auto eval4 = [&](const int (&pt)[4], auto c_of) {
+            double y[4], e[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c_of(k);
+                const double d0 = X[pt[k]] - m0[c], d1 = X[FT_P + pt[k]] - m1[c], d2 = X[2 * FT_P + pt[k]] - m2[c];
+                y[k] = sym3_quad(s00[c], s01[c], s02[c], s11[c], s12[c], s22[c], d0, d1, d2);
+            }
+            exp_nonpos4(y, e);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c_of(k);
+                // (a lane's first component always exists when it has two: J16 > FT_BLOCK)
+                if ((CPL == 2 && c == 0) || jc[c] < J16) G[(size_t)pt[k] * LDG + jc[c]] = wE[c] * e[k];
+            }
+        };
+        const bool full2 = CPL == 2 && !half_wave && (w * 64 + FT_BLOCK < J16);     // wave-uniform
+        if (full2) {
+#pragma unroll 2
+            for (int p0 = 0; p0 < FT_P; p0 += 2) {
+                const int pt[4] = {p0, p0, p0 + 1, p0 + 1};
+                eval4(pt, [](int k) { return k & 1; });
+            }
+        } else {
+#pragma unroll 2
+            for (int p0 = 0; p0 < FT_P; p0 += 4) {
+                const int pt[4] = {p0, p0 + 1, p0 + 2, p0 + 3};
+                eval4(pt, [](int) { return 0; });
+            }
+            if (half_wave) {
+                const int ph = (lane >> 5) * (FT_P / 2);
+#pragma unroll
+                for (int p0 = 0; p0 < FT_P / 2; p0 += 4) {
+                    const int pt[4] = {ph + p0, ph + p0 + 1, ph + p0 + 2, ph + p0 + 3};
+                    eval4(pt, [](int) { return CPL - 1; });
+                }
+            }
+        }
+        if (tile + 1 < t1) stage(tile + 1, buf ^ 1);     // read two barriers from now, overwritten two barriers after
+        FT_TICK(tA);
+        __syncthreads();
+        FT_TICK(tW);
+        // ---- phase B: wave w owns points 2w, 2w + 1 ---------------------------------------------------------
+        {
+            // half-wave h = lane >> 5 owns point 2 w + h: 32 lanes stride through the row (two 32-lane groups read two
+            // rows: conflict-free), one 5-step DPP reduction serves both points (results in lanes 31 and 63)
+            const int h = lane >> 5, sub = lane & 31;
+            const int p = w * 2 + h;
+            const double* Gp = G + (size_t)p * LDG;
+            const int J128 = (J16 + 127) & ~127;                       // the row is zero beyond J16
+            double den = 0.0, tot = 0.0, best = -1.0;
+            int am = 0x7fffffff;
+            for (int jb = 0; jb < J128; jb += 128) {                   // four 32-column steps at a time, loads first
+                double gv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) gv[u] = Gp[jb + 32 * u + sub];
+                // pairwise, so that the compare / select chain is two deep per batch instead of four; ties keep
+                // the lower index (first maximum of the lane's subsequence)
+                const bool s01 = gv[1] > gv[0], s23 = gv[3] > gv[2];
+                const double m01 = s01 ? gv[1] : gv[0], m23 = s23 ? gv[3] : gv[2];
+                const int i01 = jb + sub + (s01 ? 32 : 0), i23 = jb + sub + (s23 ? 96 : 64);
+                const bool sb = m23 > m01;
+                const double mb = sb ? m23 : m01;
+                const int ib = sb ? i23 : i01;
+                den += (gv[0] + gv[1]) + (gv[2] + gv[3]);
+                if (mb > best) { best = mb; am = ib; }
+                if (any_small) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = jb + 32 * u + sub;
+                        tot = fma(gv[u], (j < J16) ? WL[j] : 0.0, tot);
+                    }
+                }
+            }
+            double den0, den1, bm0, bm1;
+            halfwave_sum_f64(den, den0, den1);
+            halfwave_max_f64(best, bm0, bm1);
+            const double den_h = h ? den1 : den0, bm_h = h ? bm1 : bm0;
+            // first arg-max of the row: the largest value, then the smallest index among its holders
+            int c0, c1;
+            halfwave_min_i32((best == bm_h) ? am : 0x7fffffff, c0, c1);
+            double tot_h = den_h;
+            if (any_small) {
+                double t0, t1;
+                halfwave_sum_f64(tot, t0, t1);
+                tot_h = h ? t1 : t0;
+            }
+            const double inv = 1.0 / den_h;
+            if (sub == 0) {
+                const bool live = base + p < n;
+                const bool good = den_h > TREE_EPS;
+                INV[p] = (live && good) ? inv : 0.0;
+                TOT[p] = live ? tot_h : -1.0;                          // its log is taken in phase C (one wave, 16 lanes)
+                if (live) label_out[base + p] = good ? (h ? c1 : c0) : 0;   // all gammas zero -> argmax = 0 (C:178,184)
+            }
+            if (sub < 16) {
+                const double x0 = X[p], x1 = X[FT_P + p], x2 = X[2 * FT_P + p];
+                double f = 0.0;
+                switch (sub) {
+                    case 0: f = 1.0; break;
+                    case 1: f = x0; break;
+                    case 2: f = x1; break;
+                    case 3: f = x2; break;
+                    case 4: f = x0 * x0; break;
+                    case 5: f = x0 * x1; break;
+                    case 6: f = x0 * x2; break;
+                    case 7: f = x1 * x1; break;
+                    case 8: f = x1 * x2; break;
+                    case 9: f = x2 * x2; break;
+                    default: f = 0.0;
+                }
+                F[sub * FT_LDF + p] = f;
+            }
+        }
+        FT_TICK(tB);
+        __syncthreads();
+        FT_TICK(tW);
+        // ---- phase C: statistics on the matrix cores ---------------------------------------------------------
+        if (w == FT_WAVES - 1) {                                       // the tile's log-likelihood terms, 16 lanes at once
+            const double tv = (lane < FT_P) ? TOT[lane] : -1.0;
+            double term = (tv >= 0.0) ? log(fmax(tv, TREE_EPS)) : 0.0;
+            term = wave_sum_f64(term);
+            lq += term;
+        }
+        double bfrag[4], ifrag[4];
+        if (want_stats) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bfrag[s] = F[a_idx * FT_LDF + 4 * s + b_idx];
+            ifrag[s] = INV[4 * s + b_idx];
+        }
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            const int ct = w + t * FT_WAVES;                           // wave-uniform
+            if (ct < ntiles) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    // reference: gamma = g / den (C:176); accumulate() drops gamma < eps (C:100)
+                    double a = G[(size_t)(4 * s + b_idx) * LDG + 16 * ct + a_idx] * ifrag[s];
+                    if (a < TREE_EPS) a = 0.0;
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[s], acc[t], 0, 0, 0);
+                }
+            }
+        }
+        }
+        FT_TICK(tC);
+        __syncthreads();                                               // G is overwritten by the next tile
+        FT_TICK(tW);
+    }
+    if (dbg && lane == 0 && blockIdx.x == 7) {
+        dbg[w * 4 + 0] = tA; dbg[w * 4 + 1] = tB; dbg[w * 4 + 2] = tC; dbg[w * 4 + 3] = tW;
+    }
+    // D layout (f64 16x16x4): row (component) = (lane >> 4) + 4 r, col (feature) = lane & 15
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int ct = w + t * FT_WAVES;
+        if (ct < ntiles && a_idx < NMOM) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                partials[((size_t)blockIdx.x * J16 + 16 * ct + b_idx + 4 * r) * NMOM + a_idx] = acc[t][r];
+        }
+    }
+    if (w == FT_WAVES - 1 && lane == 0) block_q[blockIdx.x] = lq;
+}
+
 // one wave per component: fixed-order sum over the workgroups' partials
 __global__ __launch_bounds__(64) void full_reduce_kernel(const double* __restrict__ partials, int nblocks,
                                                          int J, int J16, double* __restrict__ mom) {
@@ -1175,8 +1498,9 @@ static int fullcov_alloc(hgmm_ctx* c, int J, int* J16_out, int* grid_out) {
     HGMM_TRY(ensure(c, c->t_cov, sizeof(double) * 9 * J16));
     HGMM_TRY(ensure(c, c->t_prep, sizeof(double) * PREP_N * J16));
     HGMM_TRY(ensure(c, c->t_mom, sizeof(double) * NMOM * J16));
-    HGMM_TRY(ensure(c, c->t_partials, sizeof(double) * (size_t)grid * J16 * NMOM));
-    HGMM_TRY(ensure(c, c->t_q, sizeof(double) * (nblk(c->n, CH) + 8)));
+    const size_t pblocks = std::max<size_t>((size_t)grid, (size_t)c->cus);
+    HGMM_TRY(ensure(c, c->t_partials, sizeof(double) * pblocks * J16 * NMOM));
+    HGMM_TRY(ensure(c, c->t_q, sizeof(double) * (nblk(c->n, CH) + c->cus + 8)));
     HGMM_TRY(ensure(c, c->t_current, sizeof(int) * 2 * c->n_pad));
     HGMM_TRY(ensure(c, c->t_parent, sizeof(double) * c->n_pad));     // den
     c->tree.nodes_ready = false;
@@ -1192,6 +1516,58 @@ static int fullcov_moments(hgmm_ctx* c, int J, int J16, int grid) {
     full_reduce_kernel<<<J, 64, 0, c->stream>>>(c->t_partials.as<double>(), grid, J, J16, c->t_mom.as<double>());
     HGMM_HIP(c, hipGetLastError());
     if (c->comm_on()) HGMM_TRY(allreduce_f64_dev(c, c->t_mom.as<double>(), (size_t)NMOM * J));
+    return HGMM_OK;
+}
+
+// one-pass E-step (J16 <= FT_MAX_J16): denominators, arg-max, q and the statistics from ONE evaluation of the pdfs
+static bool fullcov_one_pass(int J16) {
+    if (const char* e = std::getenv("HGMM_FULLCOV_TWO_PASS")) if (e[0] == '1') return false;
+    return J16 <= FT_MAX_J16;
+}
+static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_host, bool want_stats = true) {
+    const int64_t tiles = (c->n + FT_P - 1) / FT_P;
+    const int grid = (int)std::min<int64_t>(tiles, c->cus);             // 100+ KB of LDS: one workgroup per CU
+    double* block_q = c->t_q.as<double>();
+    double* q_dev = block_q + nblk(c->n, CH) + c->cus;
+    const size_t lds = ft_lds_bytes(J16);
+    {
+        ProfScope prof(c, HGMM_K_FULL_FUSED);
+        if (J16 <= FT_BLOCK) {
+            HGMM_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&full_fused_kernel<1>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            full_fused_kernel<1><<<grid, FT_BLOCK, lds, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
+                                                                   c->t_prep.as<double>(), J16, labels, block_q,
+                                                                   c->t_partials.as<double>(), want_stats ? 1 : 0);
+        } else {
+            HGMM_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&full_fused_kernel<2>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            long long* dbg = nullptr;
+            if (std::getenv("HGMM_FT_DEBUG")) { HGMM_HIP(c, hipMalloc(&dbg, 8 * 4 * 8)); }
+            full_fused_kernel<2><<<grid, FT_BLOCK, lds, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
+                                                                   c->t_prep.as<double>(), J16, labels, block_q,
+                                                                   c->t_partials.as<double>(), want_stats ? 1 : 0, dbg);
+            if (dbg) {
+                long long h[32];
+                HGMM_HIP(c, hipStreamSynchronize(c->stream));
+                HGMM_HIP(c, hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost));
+                for (int w = 0; w < 8; ++w)
+                    fprintf(stderr, "wave %d: A %lld  B %lld  C %lld  wait %lld cycles\n", w, h[4 * w], h[4 * w + 1], h[4 * w + 2], h[4 * w + 3]);
+                (void)hipFree(dbg);
+            }
+        }
+    }
+    HGMM_HIP(c, hipGetLastError());
+    tree_sum_kernel<<<1, 256, 0, c->stream>>>(block_q, grid, q_dev);
+    full_reduce_kernel<<<J, 64, 0, c->stream>>>(c->t_partials.as<double>(), grid, J, J16, c->t_mom.as<double>());
+    HGMM_HIP(c, hipGetLastError());
+    if (c->comm_on()) {
+        HGMM_TRY(allreduce_f64_dev(c, c->t_mom.as<double>(), (size_t)NMOM * J));
+        HGMM_TRY(allreduce_f64_dev(c, q_dev, 1));
+    }
+    if (q_host) {
+        HGMM_HIP(c, hipMemcpyAsync(q_host, q_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    }
     return HGMM_OK;
 }
 
@@ -1238,17 +1614,22 @@ extern "C" int hgmm_fullcov_fit(hgmm_ctx* c, int J, double ls, double ld, const 
     double n_total = (double)c->n;
     if (c->comm_on()) HGMM_TRY(hgmm_comm_allreduce_f64(c, &n_total, 1, 0));
     // E-step quantities of the initial parameters
-    HGMM_TRY(fullcov_pass(c, J, lab_a, nullptr));
+    const bool one_pass = fullcov_one_pass(J16);
+    if (one_pass) HGMM_TRY(fullcov_fused(c, J, J16, lab_a, nullptr));
+    else HGMM_TRY(fullcov_pass(c, J, lab_a, nullptr));
     int* lab_cur = lab_a;      // arg-max of the most recent E-step
     int* lab_nxt = lab_b;
     double prev_q = 0.0;
     int it = 0, q_len = 0;
     while (true) {
-        HGMM_TRY(fullcov_moments(c, J, J16, grid));                                   // E (moments)
+        if (!one_pass) HGMM_TRY(fullcov_moments(c, J, J16, grid));                    // E (moments)
         tree_mstep_kernel<<<nblk(J, 256), 256, 0, c->stream>>>(c->t_mom.as<double>(), 0, J, n_total, ld, d_pi, d_mu,
                                                                d_cov, d_prep);                  // M (+ prep)
         double q = 0.0;
-        HGMM_TRY(fullcov_pass(c, J, lab_nxt, &q));                                    // q (+ next E-step's den)
+        // q of the new parameters; one pass: the same launch already holds the next iteration's statistics
+        // (the statistics of a call that is known to be the last one -- iteration budget reached -- are not formed)
+        if (one_pass) HGMM_TRY(fullcov_fused(c, J, J16, lab_nxt, &q, it + 1 < max_iters));
+        else HGMM_TRY(fullcov_pass(c, J, lab_nxt, &q));                               // q (+ next E-step's den)
         ++it;
         if (q_trace_out && q_len < q_capacity) q_trace_out[q_len] = q;
         ++q_len;
@@ -1284,8 +1665,12 @@ extern "C" int hgmm_fullcov_estep(hgmm_ctx* c, int J, const double* pi, const do
                                                            c->t_cov.as<double>(), 0, J16, c->t_prep.as<double>());
     int* lab = c->t_current.as<int>();
     double q = 0.0;
-    HGMM_TRY(fullcov_pass(c, J, lab, &q));
-    HGMM_TRY(fullcov_moments(c, J, J16, grid));
+    if (fullcov_one_pass(J16)) {
+        HGMM_TRY(fullcov_fused(c, J, J16, lab, &q));
+    } else {
+        HGMM_TRY(fullcov_pass(c, J, lab, &q));
+        HGMM_TRY(fullcov_moments(c, J, J16, grid));
+    }
     HGMM_TRY(ensure(c, c->scratch, sizeof(double) * 13 * J16));
     double* e0 = c->scratch.as<double>();
     double* e1 = e0 + J16;

@@ -127,6 +127,56 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+__device__ __forceinline__ double wave_max_f64(double v) {
+    v = fmax(v, dpp_f64<DPP_QUAD_XOR1>(v));
+    v = fmax(v, dpp_f64<DPP_QUAD_XOR2>(v));
+    v = fmax(v, dpp_f64<DPP_ROW_HALF_MIRROR>(v));
+    v = fmax(v, dpp_f64<DPP_ROW_MIRROR>(v));
+    v = fmax(v, dpp_f64<DPP_ROW_BCAST15, 0xA>(v));
+    v = fmax(v, dpp_f64<DPP_ROW_BCAST31, 0xC>(v));
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), 63);
+    int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Reductions over the two 32-lane halves of a wave at once (5 DPP steps instead of 6; lanes 31 and 63 end up
+// with their half's result): lo = lanes 0..31, hi = lanes 32..63.  Same combination order in both halves.
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), l);
+    int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ void halfwave_sum_f64(double v, double& lo, double& hi) {
+    v += dpp_f64<DPP_QUAD_XOR1>(v);
+    v += dpp_f64<DPP_QUAD_XOR2>(v);
+    v += dpp_f64<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_f64<DPP_ROW_MIRROR>(v);
+    v += dpp_f64<DPP_ROW_BCAST15, 0xA>(v);
+    lo = readlane_f64(v, 31);
+    hi = readlane_f64(v, 63);
+}
+__device__ __forceinline__ void halfwave_max_f64(double v, double& lo, double& hi) {
+    v = fmax(v, dpp_f64<DPP_QUAD_XOR1>(v));
+    v = fmax(v, dpp_f64<DPP_QUAD_XOR2>(v));
+    v = fmax(v, dpp_f64<DPP_ROW_HALF_MIRROR>(v));
+    v = fmax(v, dpp_f64<DPP_ROW_MIRROR>(v));
+    v = fmax(v, dpp_f64<DPP_ROW_BCAST15, 0xA>(v));
+    lo = readlane_f64(v, 31);
+    hi = readlane_f64(v, 63);
+}
+__device__ __forceinline__ void halfwave_min_i32(int v, int& lo, int& hi) {
+    OpMinI op;
+    v = op(v, dpp_i32<DPP_QUAD_XOR1>(v));
+    v = op(v, dpp_i32<DPP_QUAD_XOR2>(v));
+    v = op(v, dpp_i32<DPP_ROW_HALF_MIRROR>(v));
+    v = op(v, dpp_i32<DPP_ROW_MIRROR>(v));
+    v = op(v, dpp_i32<DPP_ROW_BCAST15, 0xA>(v));
+    lo = __builtin_amdgcn_readlane(v, 31);
+    hi = __builtin_amdgcn_readlane(v, 63);
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int wave_in_block() {
     return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

@@ -61,7 +61,8 @@ enum hgmm_kernel_id {
     HGMM_K_KMEANS_ASSIGN = 9, /* KMeans initialiser: nearest-centre assignment */
     HGMM_K_KMEANS_ACCUM = 10, /* KMeans initialiser: per-cluster sums */
     HGMM_K_ALLREDUCE = 11,    /* the sufficient-statistics all-reduce (RCCL / host backend), N > 1 only */
-    HGMM_K_COUNT = 12
+    HGMM_K_FULL_FUSED = 12,   /* full-cov flat EM, one pass: denominators + arg-max + q + fp64-MFMA statistics */
+    HGMM_K_COUNT = 13
 };
 
 /* ---- lifecycle ------------------------------------------------------------------ */

@@ -58,6 +58,8 @@ def disassemble(lib=LIB):
 
 def classify(mn, text):
     if mn.startswith("v_"):
+        if mn.startswith(("v_mfma", "v_smfma")):
+            return "mfma"
         if mn.startswith("v_pk_"):
             return "valu_pk"
         if mn.startswith(TRANS):
