@@ -85,6 +85,7 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_tree_set_nodes", [ctx, C.c_int, _vp, _vp, _vp])
         _sig(lib, "hgmm_tree_set_target", [ctx, _vp, C.c_int64])
         _sig(lib, "hgmm_tree_reg_estep", [ctx, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp])
+        _sig(lib, "hgmm_tree_reg_normal", [ctx, _vp, _vp, C.c_double, C.c_double, _vp])
         _sig(lib, "hgmm_tree_node_complexity", [ctx, _vp])
         _sig(lib, "hgmm_tree_estep", [ctx, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
         _sig(lib, "hgmm_tree_mstep", [ctx, C.c_int64, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_double, C.c_double,
@@ -428,6 +429,18 @@ class Context:
         self._check(self.lib.hgmm_tree_reg_estep(self.h, _ptr(rot), _ptr(t), float(scale), float(lambda_c),
                                                  _ptr(m0), _ptr(m1), _ptr(m2)))
         return m0, m1, m2
+
+    def tree_reg_normal(self, rot=None, t=None, scale=1.0, lambda_c=0.01):
+        """E-step + normal equations of one registration iteration on the device (hgmm_tree_reg_normal).
+        -> (AtA[6,6], Atb[6], btb) of the reference's stacked twist system (hgmm_gpu.py:729-752)."""
+        rot = None if rot is None else np.ascontiguousarray(rot, dtype=np.float64).reshape(3, 3)
+        t = None if t is None else np.ascontiguousarray(t, dtype=np.float64).reshape(3)
+        out = np.empty(28)
+        self._check(self.lib.hgmm_tree_reg_normal(self.h, _ptr(rot), _ptr(t), float(scale), float(lambda_c), _ptr(out)))
+        ata = np.zeros((6, 6))
+        ata[np.triu_indices(6)] = out[:21]
+        ata = ata + np.triu(ata, 1).T
+        return ata, out[21:27].copy(), float(out[27])
 
     @staticmethod
     def _node_tables(pi, mu, cov):

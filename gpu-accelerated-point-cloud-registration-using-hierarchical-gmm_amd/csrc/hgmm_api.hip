@@ -116,6 +116,15 @@ static int hostcomm_allreduce_dev(hgmm_ctx* c, double* dev, size_t n, int op) {
         HGMM_HIP(c, hipStreamSynchronize(c->stream));
         HGMM_TRY(hostcomm_barrier(c));
         h->tmp.resize(cnt);
+        if (op == 2) {                                      // the words are int64: exact sums
+            const long long* src = reinterpret_cast<const long long*>(h->data);
+            long long* dst = reinterpret_cast<long long*>(h->tmp.data());
+            for (size_t i = 0; i < cnt; ++i) {
+                long long acc = src[i];
+                for (int r = 1; r < R; ++r) acc += src[(size_t)r * HOSTCOMM_SLOT + i];
+                dst[i] = acc;
+            }
+        } else
         for (size_t i = 0; i < cnt; ++i) {
             double acc = h->data[i];
             for (int r = 1; r < R; ++r) {
@@ -149,6 +158,16 @@ int allreduce_f64_dev(hgmm_ctx* c, double* dev, size_t n) {
     }
     if (c->hcomm) return hostcomm_allreduce_dev(c, dev, n, 0);
     return HGMM_OK;
+}
+
+int allreduce_i64_dev(hgmm_ctx* c, long long* dev, size_t n) {
+    if (!c->comm_on()) return HGMM_OK;
+    ProfScope prof(c, HGMM_K_ALLREDUCE);
+    if (c->comm) {
+        HGMM_NCCL(c, ncclAllReduce(dev, dev, n, ncclInt64, ncclSum, c->comm, c->stream));
+        return HGMM_OK;
+    }
+    return hostcomm_allreduce_dev(c, reinterpret_cast<double*>(dev), n, 2);
 }
 
 // out of place: `src` keeps the rank's own values (callers that enqueue iterations past a device-side stop rely
@@ -323,7 +342,7 @@ extern "C" int hgmm_destroy(hgmm_ctx* c) {
                       &c->t_parent, &c->t_current, &c->t_perm, &c->t_seg, &c->t_chunks, &c->t_partials,
                       &c->t_q, &c->tgt_soa64, &c->comm_buf, &c->t_xs3, &c->t_llp, &c->t_qtrace, &c->f_cm, &c->f_cs, &c->f_ca, &c->f_lpn2,
                       &c->km_closest, &c->km_block, &c->km_centres, &c->km_ids, &c->km_rand, &c->km_labels,
-                      &c->km_mind2, &c->km_partial, &c->km_out, &c->gt_buf};
+                      &c->km_mind2, &c->km_partial, &c->km_out, &c->gt_buf, &c->t_momq};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }

@@ -44,6 +44,8 @@ struct TreeState {
     int L = 0;
     int T = 0;
     bool nodes_ready = false;
+    double mu_rmax = -1.0;            // largest |mu_j| of the node table (< 0: not known on the host yet)
+    bool momq_dirty = true;           // the fixed-point moment words hold sums nobody has cleared yet
 };
 
 }  // namespace hgmm
@@ -80,6 +82,7 @@ struct hgmm_ctx {
     hgmm::DevBuf t_prep;                      // double [T][12] : inv(6) coef logc pi mu(3) -> see tree_kernels
     hgmm::DevBuf t_cplx;                      // double [T]
     hgmm::DevBuf t_mom;                       // double [T][10]
+    hgmm::DevBuf t_momq;                      // uint64 [T][10]  registration E-step: fixed-point moments
     hgmm::DevBuf t_parent, t_current;         // int32 [n]
     hgmm::DevBuf t_perm;                      // int32 [n]  points sorted by parent
     hgmm::DevBuf t_xs3;                       // double [3][n_pad] third coordinate buffer (L > 2)
@@ -91,6 +94,7 @@ struct hgmm_ctx {
     hgmm::DevBuf t_qtrace;                    // double [max iterations per level] q of the running level
     hgmm::DevBuf tgt_soa64;                   // double [3][m_pad] registration target
     int64_t tgt_n = 0, tgt_pad = 0;
+    double tgt_rmax = 0.0;                    // largest |x| of the target (extent bound of the fixed-point moments)
 
     // ---- KMeans initialiser (float64, on x_soa64) -----------------------------------
     hgmm::DevBuf km_closest;                  // double [n_pad] k-means++: min squared distance so far
@@ -170,5 +174,6 @@ int profile_collect(hgmm_ctx* c);
 // sub-system entry points implemented in flat_kernels.hip / tree_kernels.hip
 int allreduce_f64_dev(hgmm_ctx* c, double* dev, size_t n);
 int allreduce_f64_oop(hgmm_ctx* c, const double* src, double* dst, size_t n);
+int allreduce_i64_dev(hgmm_ctx* c, long long* dev, size_t n);      // exact (integer) sum, in place
 
 }  // namespace hgmm

@@ -564,10 +564,47 @@ struct Rigid { double r[9]; double t[3]; double s; };
 
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
 
+// The moment accumulation of this E-step is the one place of the library where contributions from arbitrary
+// workgroups meet in the same memory words (a target point may land in any node; the points are not grouped by
+// node, and their tree paths change with every (R, t)).  Floating-point atomics would make the result depend on
+// arrival order, so the sums are taken in 64-bit FIXED POINT, where addition is associative: every run, every
+// grid shape and every sharding of the target gives bit-identical moments.
+//   * moments are taken about the node's own mean and scaled by the extent D (a power of two >= any |x - mu|):
+//     gamma (x - mu) / D and gamma (x - mu)(x - mu)^T / D^2 lie in [-1, 1], gamma in [0, 1];
+//   * scale 2^F, F = 62 - ceil(log2(n + 1)): n terms cannot overflow, resolution 2^-F (n = 40 k: 1.4e-14,
+//     n = 1 M: 2.3e-13, relative to D resp. D^2) -- below the 1e-12 the parity tests allow;
+//   * the registration M-step needs exactly these centred quantities (s - mu = c1 / m0), see tree_reg_normal_kernel.
+// NMQ = 10 (m0, c1[3], C2 unique[6]) for the API's full moment set, 4 (m0, c1) inside the registration loop.
+template <int CTRL, int MASK>
+__device__ __forceinline__ long long dpp_i64_or0(long long x) {           // lanes outside the row mask read 0
+    int lo = (int)(x & 0xffffffffLL), hi = (int)(x >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, MASK, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, MASK, 0xF, true);
+    return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v) {          // exact: integer adds, any order
+    v += dpp_i64_or0<DPP_QUAD_XOR1, 0xF>(v);
+    v += dpp_i64_or0<DPP_QUAD_XOR2, 0xF>(v);
+    v += dpp_i64_or0<DPP_ROW_HALF_MIRROR, 0xF>(v);
+    v += dpp_i64_or0<DPP_ROW_MIRROR, 0xF>(v);
+    v += dpp_i64_or0<DPP_ROW_BCAST15, 0xA>(v);
+    v += dpp_i64_or0<DPP_ROW_BCAST31, 0xC>(v);
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffLL), 63);
+    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
+    return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
+}
+
+template <int NMQ>
 __global__ __launch_bounds__(CH) void tree_reg_estep_kernel(const double* __restrict__ tg, int64_t n,
                                                             int64_t n_pad, Rigid tf,
                                                             const double* __restrict__ prep, int L,
-                                                            double lambda_c, double* __restrict__ mom) {
+                                                            double lambda_c, double inv_d, double fix_scale,
+                                                            unsigned long long* __restrict__ momq) {
+    constexpr int LDS_NODES = 584;                       // levels 0..2 (8 + 64 + 512 nodes)
+    __shared__ unsigned long long tab[LDS_NODES * NMQ];
+    const int lds_nodes = (int)(level_first(L < 3 ? L : 3));
+    for (int e = threadIdx.x; e < lds_nodes * NMQ; e += CH) tab[e] = 0ull;
+    __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * CH + threadIdx.x;
     bool alive = i < n;
     double x0 = 0.0, x1 = 0.0, x2 = 0.0;
@@ -615,28 +652,145 @@ __global__ __launch_bounds__(CH) void tree_reg_estep_kernel(const double* __rest
                 contribute = !(gs < TREE_EPS);
             }
         }
-        // combine lanes that hit the same node before touching HBM: up to 8 leader rounds of
-        // wave reductions, whatever is left goes out as per-lane atomics
-        const double f[NMOM] = {1.0, x0, x1, x2, x0 * x0, x0 * x1, x0 * x2, x1 * x1, x1 * x2, x2 * x2};
-        bool pending = contribute;
-        for (int round = 0; round < 8; ++round) {
-            const unsigned long long pm = __ballot(pending);
-            if (pm == 0ull) break;
-            const int leader = __ffsll((long long)pm) - 1;
-            const int64_t node = __shfl(s, leader);
-            const bool mine = pending && (s == node);
+        // this lane's contribution in fixed point, about the node's mean, in units of D
+        long long q[NMQ];
 #pragma unroll
-            for (int m = 0; m < NMOM; ++m) {
-                const double v = wave_sum_f64(mine ? gs * f[m] : 0.0);
-                if (lane_id() == leader) atomic_add_f64(mom + NMOM * node + m, v);
+        for (int m = 0; m < NMQ; ++m) q[m] = 0;
+        if (contribute) {
+            const double* pr = prep + PREP_N * s;
+            const double u0 = (x0 - pr[6]) * inv_d, u1 = (x1 - pr[7]) * inv_d, u2 = (x2 - pr[8]) * inv_d;
+            const double gq = gs * fix_scale;
+            q[0] = __double2ll_rn(gq);
+            q[1] = __double2ll_rn(gq * u0); q[2] = __double2ll_rn(gq * u1); q[3] = __double2ll_rn(gq * u2);
+            if (NMQ == 10) {
+                q[4] = __double2ll_rn(gq * u0 * u0); q[5] = __double2ll_rn(gq * u0 * u1);
+                q[6] = __double2ll_rn(gq * u0 * u2); q[7] = __double2ll_rn(gq * u1 * u1);
+                q[8] = __double2ll_rn(gq * u1 * u2); q[9] = __double2ll_rn(gq * u2 * u2);
             }
-            if (mine) pending = false;
         }
-        if (pending) {
+        // The upper levels (few nodes, every workgroup hits all of them) are summed in LDS first and flushed once
+        // per workgroup; deeper nodes are spread thinly enough for direct atomics.  Integer adds commute, so
+        // neither the LDS order nor the arrival order of the global atomics can change the totals.
+        if (contribute) {
+            if (s < lds_nodes) {
 #pragma unroll
-            for (int m = 0; m < NMOM; ++m) atomic_add_f64(mom + NMOM * s + m, gs * f[m]);
+                for (int m = 0; m < NMQ; ++m) atomicAdd(tab + NMQ * s + m, (unsigned long long)q[m]);
+            } else {
+#pragma unroll
+                for (int m = 0; m < NMQ; ++m) atomicAdd(momq + NMQ * s + m, (unsigned long long)q[m]);
+            }
         }
     }
+    __syncthreads();
+    for (int e = threadIdx.x; e < lds_nodes * NMQ; e += CH) {
+        const unsigned long long v = tab[e];
+        if (v != 0ull) atomicAdd(momq + e, v);
+    }
+}
+
+// fixed point -> float64, still centred: cm[T][NMQ] = (m0, c1 = sum gamma (x - mu), C2 = sum gamma (x - mu)(x - mu)^T)
+template <int NMQ>
+__global__ void tree_reg_unpack_kernel(const unsigned long long* __restrict__ momq, int64_t T, double d,
+                                       double inv_scale, double* __restrict__ cm) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= T * NMQ) return;
+    const int m = (int)(e % NMQ);
+    const double unit = (m == 0) ? inv_scale : (m < 4 ? d * inv_scale : d * d * inv_scale);
+    cm[e] = (double)(long long)momq[e] * unit;
+}
+__global__ void tree_reg_clear_kernel(unsigned long long* __restrict__ momq, int64_t count) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < count) momq[e] = 0ull;
+}
+
+// centred moments -> the reference's raw layout m0[T], m1[T,3], m2[T,3,3] (momentsZero/One/Two, C:202-228):
+//   m1 = c1 + m0 mu,  m2 = C2 + mu c1^T + c1 mu^T + m0 mu mu^T
+__global__ void tree_reg_expand_kernel(const double* __restrict__ cm, const double* __restrict__ prep, int64_t T,
+                                       double* m0, double* m1, double* m2) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= T) return;
+    const double* c = cm + NMOM * j;
+    const double u[3] = {prep[PREP_N * j + 6], prep[PREP_N * j + 7], prep[PREP_N * j + 8]};
+    const double z = c[0];
+    m0[j] = z;
+    for (int a = 0; a < 3; ++a) m1[3 * j + a] = c[1 + a] + z * u[a];
+    const int idx[3][3] = {{4, 5, 6}, {5, 7, 8}, {6, 8, 9}};
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+            m2[9 * j + 3 * a + b] = c[idx[a][b]] + u[a] * c[1 + b] + c[1 + a] * u[b] + z * u[a] * u[b];
+}
+
+// Normal equations of the registration M-step (GMMTree.maximization_step, hgmm_gpu.py:729-752).  The reference
+// stacks, for every node i with m0_i >= float32 eps, the three rows  [ s_i x n_c | n_c ] x = n_c . (mu_i - s_i),
+// n_c = the columns of V_i sqrt(m0_i / lambda_i)  (eigh of Sigma_i), s_i = m1_i / m0_i, and solves by lstsq.
+// Since sum_c n_c n_c^T = m0_i Sigma_i^-1 =: W_i (no eigen-decomposition needed) the normal equations are
+//   A^T A = sum_i P_i W_i P_i^T,  A^T b = sum_i P_i W_i d_i,  b^T b = sum_i d_i^T W_i d_i,   P_i = [ [s_i]_x ; I ],
+//   d_i = mu_i - s_i = -c1_i / m0_i.
+// out[28] = 21 upper-triangle entries of A^T A (row-major), 6 of A^T b, b^T b.  One workgroup, fixed order.
+// Input: the fixed-point sums (m0, c1) [T][4] themselves (already all-reduced over the ranks); they are set back
+// to zero here, so that the next iteration's E-step needs no separate clearing launch.
+__global__ __launch_bounds__(256) void tree_reg_normal_kernel(unsigned long long* __restrict__ momq /*[T][4]*/,
+                                                              double d_ext, double inv_scale,
+                                                              const double* __restrict__ prep, int64_t T,
+                                                              double* __restrict__ out) {
+    double acc[28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+    for (int64_t j = threadIdx.x; j < T; j += 256) {
+        const double z = (double)(long long)momq[4 * j] * inv_scale;
+        const double c10 = (double)(long long)momq[4 * j + 1] * (d_ext * inv_scale);
+        const double c11 = (double)(long long)momq[4 * j + 2] * (d_ext * inv_scale);
+        const double c12 = (double)(long long)momq[4 * j + 3] * (d_ext * inv_scale);
+        momq[4 * j] = momq[4 * j + 1] = momq[4 * j + 2] = momq[4 * j + 3] = 0ull;
+        if (z < 1.1920928955078125e-07) continue;                  // np.finfo(np.float32).eps (hgmm_gpu.py:733)
+        const double* pr = prep + PREP_N * j;
+        const double w00 = z * pr[0], w01 = z * pr[1], w02 = z * pr[2], w11 = z * pr[3], w12 = z * pr[4], w22 = z * pr[5];
+        const double iz = 1.0 / z;
+        const double d0 = -c10 * iz, d1 = -c11 * iz, d2 = -c12 * iz;
+        const double s0 = pr[6] - d0, s1 = pr[7] - d1, s2 = pr[8] - d2;
+        const double W[3][3] = {{w00, w01, w02}, {w01, w11, w12}, {w02, w12, w22}};
+        // SW = [s]_x W : column c of SW = s x W[:,c]
+        double SW[3][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            SW[0][c] = s1 * W[2][c] - s2 * W[1][c];
+            SW[1][c] = s2 * W[0][c] - s0 * W[2][c];
+            SW[2][c] = s0 * W[1][c] - s1 * W[0][c];
+        }
+        // SWS^T = SW [s]_x^T : row r of it = -(SW[r,:] x s) ... (SW S^T)[r][c] = sum_k SW[r][k] S[c][k]
+        const double S[3][3] = {{0.0, -s2, s1}, {s2, 0.0, -s0}, {-s1, s0, 0.0}};
+        double TL[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) TL[r][c] = SW[r][0] * S[c][0] + SW[r][1] * S[c][1] + SW[r][2] * S[c][2];
+        const double Wd[3] = {W[0][0] * d0 + W[0][1] * d1 + W[0][2] * d2, W[1][0] * d0 + W[1][1] * d1 + W[1][2] * d2,
+                              W[2][0] * d0 + W[2][1] * d1 + W[2][2] * d2};
+        const double SWd[3] = {s1 * Wd[2] - s2 * Wd[1], s2 * Wd[0] - s0 * Wd[2], s0 * Wd[1] - s1 * Wd[0]};
+        // upper triangle of the 6x6, row-major: rows 0-2 = [TL | SW], rows 3-5 = [. | W]
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) {
+                double v;
+                if (r < 3 && c < 3) v = TL[r][c];
+                else if (r < 3) v = SW[r][c - 3];
+                else v = W[r - 3][c - 3];
+                acc[k++] += v;
+            }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { acc[21 + r] += SWd[r]; acc[24 + r] += Wd[r]; }
+        acc[27] += d0 * Wd[0] + d1 * Wd[1] + d2 * Wd[2];
+    }
+    __shared__ double sh[4][28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) {
+        const double v = wave_sum_f64(acc[k]);
+        if (lane_id() == 0) sh[wave_in_block()][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 28) out[threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
 
 // expand the 10 unique moments into the reference layout m0[T], m1[T,3], m2[T,3,3]
@@ -906,7 +1060,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     }
     cleanup();
     if (q_len_out) *q_len_out = q_len < q_capacity ? q_len : q_capacity;
-    if (rc == HGMM_OK) c->tree.nodes_ready = true;
+    if (rc == HGMM_OK) { c->tree.nodes_ready = true; c->tree.mu_rmax = -1.0; }
     return rc;
 }
 
@@ -921,6 +1075,12 @@ extern "C" int hgmm_tree_set_nodes(hgmm_ctx* c, int L, const double* pi, const d
     HGMM_HIP(c, hipMemcpyAsync(c->t_cov.p, cov, sizeof(double) * 9 * T, hipMemcpyHostToDevice, c->stream));
     HGMM_TRY(tree_prep(c, 0, T));
     HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    double m2max = 0.0;
+    for (int64_t j = 0; j < T; ++j) {
+        const double v = mu[3 * j] * mu[3 * j] + mu[3 * j + 1] * mu[3 * j + 1] + mu[3 * j + 2] * mu[3 * j + 2];
+        if (v > m2max) m2max = v;
+    }
+    c->tree.mu_rmax = std::sqrt(m2max);
     c->tree.nodes_ready = true;
     return HGMM_OK;
 }
@@ -932,8 +1092,13 @@ extern "C" int hgmm_tree_set_target(hgmm_ctx* c, const double* xyz, int64_t n) {
     const int64_t n_pad = (n + 255) / 256 * 256;
     HGMM_TRY(ensure(c, c->tgt_soa64, sizeof(double) * 3 * n_pad));
     std::vector<double> soa((size_t)3 * n_pad, 0.0);
-    for (int64_t i = 0; i < n; ++i)
-        for (int d = 0; d < 3; ++d) soa[(size_t)d * n_pad + i] = xyz[3 * i + d];
+    double r2max = 0.0;                                         // largest |x|^2: bounds the extent of the moved cloud
+    for (int64_t i = 0; i < n; ++i) {
+        double r2 = 0.0;
+        for (int d = 0; d < 3; ++d) { soa[(size_t)d * n_pad + i] = xyz[3 * i + d]; r2 += xyz[3 * i + d] * xyz[3 * i + d]; }
+        if (r2 > r2max) r2max = r2;
+    }
+    c->tgt_rmax = std::sqrt(r2max);
     HGMM_HIP(c, hipMemcpyAsync(c->tgt_soa64.p, soa.data(), sizeof(double) * soa.size(), hipMemcpyHostToDevice, c->stream));
     HGMM_HIP(c, hipStreamSynchronize(c->stream));
     c->tgt_n = n;
@@ -941,9 +1106,11 @@ extern "C" int hgmm_tree_set_target(hgmm_ctx* c, const double* xyz, int64_t n) {
     return HGMM_OK;
 }
 
-extern "C" int hgmm_tree_reg_estep(hgmm_ctx* c, const double* rot, const double* t, double scale,
-                                   double lambda_c, double* m0_out, double* m1_out, double* m2_out) {
-    if (!c) return HGMM_ERR_ARG;
+// fixed-point moments of the resident target under (rot, t, scale) -> c->t_momq [T][NMQ] (all-reduced over the
+// ranks as integers: still exact); *d_out / *f_out = extent and fractional bits of the encoding
+template <int NMQ>
+static int reg_estep_fixed(hgmm_ctx* c, const double* rot, const double* t, double scale, double lambda_c,
+                           double* d_out, int* f_out) {
     if (!c->tree.nodes_ready) return fail(c, HGMM_ERR_STATE, "registration E-step: no tree (build or set_nodes first)");
     if (c->tgt_n <= 0) return fail(c, HGMM_ERR_STATE, "registration E-step: call hgmm_tree_set_target first");
     HGMM_HIP(c, hipSetDevice(c->device));
@@ -952,25 +1119,93 @@ extern "C" int hgmm_tree_reg_estep(hgmm_ctx* c, const double* rot, const double*
     for (int i = 0; i < 9; ++i) tf.r[i] = rot ? rot[i] : ((i % 4 == 0) ? 1.0 : 0.0);
     for (int i = 0; i < 3; ++i) tf.t[i] = t ? t[i] : 0.0;
     tf.s = scale;
-    double* mom = c->t_mom.as<double>();
-    HGMM_HIP(c, hipMemsetAsync(mom, 0, sizeof(double) * NMOM * T, c->stream));
+    // extent: |s R x + t - mu| <= |s| (Frobenius bound on R) max|x| + |t| + max|mu|, rounded up to a power of two
+    if (c->tree.mu_rmax < 0.0) {                                  // tree built on the device: means not seen by the host
+        std::vector<double> mu((size_t)3 * T);
+        HGMM_HIP(c, hipMemcpyAsync(mu.data(), c->t_mu.p, sizeof(double) * 3 * T, hipMemcpyDeviceToHost, c->stream));
+        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+        double m2 = 0.0;
+        for (int64_t j = 0; j < T; ++j) {
+            const double v = mu[3 * j] * mu[3 * j] + mu[3 * j + 1] * mu[3 * j + 1] + mu[3 * j + 2] * mu[3 * j + 2];
+            if (v > m2 && std::isfinite(v)) m2 = v;
+        }
+        c->tree.mu_rmax = std::sqrt(m2);
+    }
+    double rn = 0.0, tn = 0.0;
+    for (int i = 0; i < 9; ++i) rn += tf.r[i] * tf.r[i];
+    for (int i = 0; i < 3; ++i) tn += tf.t[i] * tf.t[i];
+    double ext = std::fabs(scale) * std::sqrt(rn) * c->tgt_rmax + std::sqrt(tn) + c->tree.mu_rmax;
+    if (c->comm_on()) {                                           // every rank must use the same encoding
+        double e = ext;
+        HGMM_TRY(hgmm_comm_allreduce_f64(c, &e, 1, 1));
+        ext = e;
+    }
+    if (!(ext > 0.0) || !std::isfinite(ext)) ext = 1.0;
+    int e2 = 0;
+    (void)std::frexp(ext, &e2);                                   // ext < 2^e2
+    const double D = std::ldexp(1.0, e2);
+    double n_all = (double)c->tgt_n;
+    if (c->comm_on()) HGMM_TRY(hgmm_comm_allreduce_f64(c, &n_all, 1, 0));
+    int nbits = 1;
+    while (std::ldexp(1.0, nbits) <= n_all) ++nbits;
+    const int F = 62 - nbits;
+    const size_t want = sizeof(unsigned long long) * NMOM * T;
+    if (c->t_momq.cap < want || !c->t_momq.p || c->tree.momq_dirty) {
+        HGMM_TRY(ensure(c, c->t_momq, want));
+        HGMM_HIP(c, hipMemsetAsync(c->t_momq.p, 0, want, c->stream));
+        c->tree.momq_dirty = false;
+    }
+    unsigned long long* mq = c->t_momq.as<unsigned long long>();
     {
         ProfScope prof(c, HGMM_K_TREE_REG);
-        tree_reg_estep_kernel<<<nblk(c->tgt_n, CH), CH, 0, c->stream>>>(c->tgt_soa64.as<double>(), c->tgt_n, c->tgt_pad,
-                                                                        tf, c->t_prep.as<double>(), c->tree.L,
-                                                                        lambda_c, mom);
+        tree_reg_estep_kernel<NMQ><<<nblk(c->tgt_n, CH), CH, 0, c->stream>>>(
+            c->tgt_soa64.as<double>(), c->tgt_n, c->tgt_pad, tf, c->t_prep.as<double>(), c->tree.L, lambda_c, 1.0 / D,
+            std::ldexp(1.0, F), mq);
     }
     HGMM_HIP(c, hipGetLastError());
-    if (c->comm_on()) HGMM_TRY(allreduce_f64_dev(c, mom, (size_t)NMOM * T));
+    c->tree.momq_dirty = true;                                    // until a consumer has cleared what it read
+    if (c->comm_on()) HGMM_TRY(allreduce_i64_dev(c, reinterpret_cast<long long*>(mq), (size_t)NMQ * T));
+    *d_out = D;
+    *f_out = F;
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_tree_reg_estep(hgmm_ctx* c, const double* rot, const double* t, double scale,
+                                   double lambda_c, double* m0_out, double* m1_out, double* m2_out) {
+    if (!c) return HGMM_ERR_ARG;
+    double D = 1.0;
+    int F = 0;
+    HGMM_TRY(reg_estep_fixed<NMOM>(c, rot, t, scale, lambda_c, &D, &F));
+    const int64_t T = c->tree.T;
+    double* cm = c->t_mom.as<double>();
+    tree_reg_unpack_kernel<NMOM><<<nblk(T * NMOM, 256), 256, 0, c->stream>>>(c->t_momq.as<unsigned long long>(), T, D,
+                                                                            std::ldexp(1.0, -F), cm);
     HGMM_TRY(ensure(c, c->scratch, sizeof(double) * 13 * T));
     double* e0 = c->scratch.as<double>();
     double* e1 = e0 + T;
     double* e2 = e1 + 3 * T;
-    tree_expand_moments_kernel<<<nblk(T, 256), 256, 0, c->stream>>>(mom, T, e0, e1, e2);
+    tree_reg_expand_kernel<<<nblk(T, 256), 256, 0, c->stream>>>(cm, c->t_prep.as<double>(), T, e0, e1, e2);
     HGMM_HIP(c, hipGetLastError());
     if (m0_out) HGMM_HIP(c, hipMemcpyAsync(m0_out, e0, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
     if (m1_out) HGMM_HIP(c, hipMemcpyAsync(m1_out, e1, sizeof(double) * 3 * T, hipMemcpyDeviceToHost, c->stream));
     if (m2_out) HGMM_HIP(c, hipMemcpyAsync(m2_out, e2, sizeof(double) * 9 * T, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_tree_reg_normal(hgmm_ctx* c, const double* rot, const double* t, double scale,
+                                    double lambda_c, double* out28) {
+    if (!c || !out28) return c ? fail(c, HGMM_ERR_ARG, "out28 is NULL") : HGMM_ERR_ARG;
+    double D = 1.0;
+    int F = 0;
+    HGMM_TRY(reg_estep_fixed<4>(c, rot, t, scale, lambda_c, &D, &F));
+    const int64_t T = c->tree.T;
+    HGMM_TRY(ensure(c, c->scratch, sizeof(double) * 32));
+    tree_reg_normal_kernel<<<1, 256, 0, c->stream>>>(c->t_momq.as<unsigned long long>(), D, std::ldexp(1.0, -F),
+                                                    c->t_prep.as<double>(), T, c->scratch.as<double>());
+    HGMM_HIP(c, hipGetLastError());
+    c->tree.momq_dirty = false;                                   // the kernel zeroed the [T][4] words it consumed
+    HGMM_HIP(c, hipMemcpyAsync(out28, c->scratch.p, sizeof(double) * 28, hipMemcpyDeviceToHost, c->stream));
     HGMM_HIP(c, hipStreamSynchronize(c->stream));
     return HGMM_OK;
 }

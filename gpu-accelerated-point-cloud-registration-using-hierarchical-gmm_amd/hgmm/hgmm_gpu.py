@@ -211,6 +211,7 @@ class GMMTree():
         self._callbacks = []
         self._ctx_arg = ctx
         self._verbose = verbose
+        self._device_mstep = True            # False: every iteration through expectation_step + maximization_step
         self._target_id = None
         if source is not None:
             self.set_source(source)
@@ -306,6 +307,24 @@ class GMMTree():
         rot, t = twist_mul(x, trans_p.rot, trans_p.t)
         return MstepResult(RigidTransformation(rot, t), q)
 
+    def _device_iteration(self):
+        """One registration iteration with E-step AND the M-step's least-squares system on the device: the host
+        receives the 6 x 6 normal equations (28 numbers), solves them and composes the twist.  The system is the
+        reference's (hgmm_gpu.py:729-752) -- sum_c n_c n_c^T = m0 Sigma^-1 makes the per-node eigh unnecessary.
+        Returns None when the system is too ill-conditioned for normal equations (the caller then takes the
+        reference's stacked least-squares path)."""
+        tf = self._tf_result
+        ata, atb, btb = self._ctx.tree_reg_normal(tf.rot, tf.t, tf.scale, self._lambda_c)
+        if not (np.isfinite(ata).all() and np.isfinite(atb).all()):
+            return None
+        lam = np.linalg.eigvalsh(ata)
+        if not lam[-1] > 0.0 or lam[0] <= 1e-11 * lam[-1]:
+            return None
+        x = np.linalg.solve(ata, atb)
+        q = np.array([max(btb - float(x @ atb), 0.0)])
+        rot, t = twist_mul(x, tf.rot, tf.t)
+        return MstepResult(RigidTransformation(rot, t), q)
+
     def registration(self, target, maxiter=20, tol=1.0e-4):
         """-> MstepResult(tf.inverse(), q)   (hgmm_gpu.py:754-768)."""
         self._ctx.tree_set_nodes(self._tree_level, self._mixingCoeff, self._mean, self._covar)
@@ -313,8 +332,10 @@ class GMMTree():
         q = None
         res = None
         for _ in range(maxiter):
-            estep_res = self.expectation_step()          # target transformed on the device
-            res = self.maximization_step(estep_res, self._tf_result)
+            res = self._device_iteration() if self._device_mstep else None
+            if res is None:
+                estep_res = self.expectation_step()      # target transformed on the device
+                res = self.maximization_step(estep_res, self._tf_result)
             self._tf_result = res.transformation
             for c in self._callbacks:
                 c(self._tf_result.inverse())

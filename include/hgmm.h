@@ -159,6 +159,13 @@ int hgmm_tree_set_target(hgmm_ctx* ctx, const double* xyz, int64_t n);
  * float64 m0 [T], m1 [T,3], m2 [T,3,3].                                                 */
 int hgmm_tree_reg_estep(hgmm_ctx* ctx, const double* rot, const double* t, double scale,
                         double lambda_c, double* m0_out, double* m1_out, double* m2_out);
+/* E-step + normal equations of one registration iteration (GMMTree.expectation_step + the least-squares
+ * system of GMMTree.maximization_step, hgmm/hgmm_gpu.py:722-752), entirely on the device: out28 (host) =
+ * the 21 upper-triangle entries (row-major) of A^T A, the 6 of A^T b, and b^T b of the reference's stacked
+ * twist system  [ s_i x n | n ] x = n . (mu_i - s_i); the caller solves the 6 x 6 system and composes the
+ * twist (hgmm_gpu.py:620-664), residual q = b^T b - x . A^T b.  Deterministic (fixed-point moment sums). */
+int hgmm_tree_reg_normal(hgmm_ctx* ctx, const double* rot, const double* t, double scale,
+                         double lambda_c, double* out28);
 /* The steps buildGMMTree is made of, one at a time (reference function granularity).  Node tables
  * hold T nodes (any T >= 8, need not be a complete tree).
  * hgmm_tree_estep  <- gmmTreeEStep()       hgmm_cupy_cpu_working.py:162-191: parent_idx[N] arbitrary

@@ -280,3 +280,76 @@ def test_registration_real_scan_pair_against_bun_conf(ctx, bunny):
     err = np.linalg.norm(res.transformation.transform(a) - truth, axis=1).mean()
     print("real scan pair: mean misalignment %.1f mm -> %.1f mm" % (start * 1e3, err * 1e3))
     assert start > 0.012 and err < 0.005 and err < 0.35 * start
+
+
+def _host_normal_equations(m0, m1, mu, cov):
+    """A^T A, A^T b, b^T b of the reference's stacked twist system (hgmm_gpu.py:729-752), built the reference's
+    way: per-node eigh, rows [s x n | n], right-hand side n . (mu - s)."""
+    live = np.nonzero(~(m0 < np.finfo(np.float32).eps))[0]
+    rows, rhs = [], []
+    for i in live:
+        lam, v = np.linalg.eigh(cov[i])
+        s = m1[i] / m0[i]
+        nn = (v * np.sqrt(m0[i] / lam)).T                    # rows = scaled eigenvectors
+        for n_c in nn:
+            rows.append(np.concatenate([np.cross(s, n_c), n_c]))
+            rhs.append(n_c @ (mu[i] - s))
+    A, b = np.array(rows), np.array(rhs)
+    return A.T @ A, A.T @ b, float(b @ b), A, b
+
+
+def test_registration_normal_equations_on_device(ctx):
+    """hgmm_tree_reg_normal == the reference's least-squares system assembled from the oracle's E-step moments;
+    its solution == lstsq of the stacked system; everything bit-identical from run to run (fixed-point sums)."""
+    g = load_golden("hgmm_reg_L2.npz")
+    L, lc = int(g["L"]), float(g["lambda_c"])
+    T = hgmm_tree.n_total(L)
+    ctx.tree_set_nodes(L, g["pi"], g["mu"], g["cov"])
+    th = 0.07
+    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1.0, 0], [-np.sin(th), 0, np.cos(th)]])
+    t = np.array([0.004, 0.002, -0.006])
+    for deg in (10, 30):
+        target = g["rot%d_target" % deg]
+        ctx.tree_set_target(target)
+        ata, atb, btb = ctx.tree_reg_normal(R, t, 1.0, lc)
+        o_m0, o_m1, _ = hgmm_tree.reg_e_step(target @ R.T + t, g["pi"], g["mu"], g["cov"], L, lc)
+        h_ata, h_atb, h_btb, A, b = _host_normal_equations(o_m0, o_m1, g["mu"], g["cov"])
+        scale = np.sqrt(np.outer(np.diag(h_ata), np.diag(h_ata)))
+        assert np.abs(ata - h_ata).max() <= 1e-9 * scale.max()
+        np.testing.assert_allclose(ata / scale, h_ata / scale, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(atb, h_atb, rtol=1e-8, atol=1e-9 * np.abs(h_atb).max())
+        np.testing.assert_allclose(btb, h_btb, rtol=1e-9)
+        x_ref, res, _, _ = np.linalg.lstsq(A, b, rcond=-1)
+        x = np.linalg.solve(ata, atb)
+        np.testing.assert_allclose(x, x_ref, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(btb - x @ atb, res[0], rtol=1e-7, atol=1e-9)
+        # bitwise reproducibility: same call, and the full-moment E-step, twice
+        again = ctx.tree_reg_normal(R, t, 1.0, lc)
+        assert np.array_equal(ata, again[0]) and np.array_equal(atb, again[1]) and btb == again[2]
+        m_a = ctx.tree_reg_estep(T, R, t, 1.0, lc)
+        m_b = ctx.tree_reg_estep(T, R, t, 1.0, lc)
+        for x_a, x_b in zip(m_a, m_b):
+            assert np.array_equal(x_a, x_b)
+
+
+def test_registration_device_and_host_mstep_agree(ctx, bunny):
+    """The loop with the device-side normal equations follows the same trajectory as the loop through
+    expectation_step + the host twist least squares (the reference's own formulation)."""
+    from hgmm_amd.hgmm.hgmm_gpu import GMMTree
+    P = bunny[::6].astype(np.float64)
+    th = np.deg2rad(9.0)
+    Rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    target = P @ Rz.T + np.array([0.004, -0.002, 0.003])
+    traces = {}
+    for dev in (True, False):
+        gt = GMMTree(P, tree_level=3, lambda_c=0.01, ls=80, sig2=0.00034, ctx=ctx)
+        gt._device_mstep = dev
+        tr = []
+        gt.set_callbacks([lambda tf: tr.append((tf.rot.copy(), tf.t.copy()))])
+        res = gt.registration(target, maxiter=12, tol=0.0)
+        traces[dev] = (tr, res.q)
+    assert len(traces[True][0]) == len(traces[False][0]) == 12
+    for (r_a, t_a), (r_b, t_b) in zip(traces[True][0], traces[False][0]):
+        np.testing.assert_allclose(r_a, r_b, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(t_a, t_b, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(traces[True][1], traces[False][1], rtol=1e-5, atol=1e-8)
