@@ -16,11 +16,13 @@ from ..pointcloud_io import read_point_cloud, voxel_down_sample
 
 def run_stream(frames, n_components=50, max_iter=50, cov_type='spherical', fit_every=10, tol=1e-4,
                voxel_size=None, seed=0, verbose=False):
-    """frames: iterable of [N,3] arrays.  -> dict(labels=[...], fps=float, fit_s=[...])."""
+    """frames: iterable of [N,3] arrays.  -> dict(labels=[...], fps=float, fit_s=[...], models=[...]):
+    ``models[k]`` = (means, weights, covariances, inv_covs) of the k-th refit, i.e. the parameters frame i was
+    labelled with are ``models[i // fit_every]``."""
     gmm = GMM_GPU(n_gmm_components=n_components, max_iter=max_iter, tol=tol, cov_type=cov_type)
     gmm.init()
     gmm._clf._verbose = verbose
-    labels, fit_s = [], []
+    labels, fit_s, models = [], [], []
     np.random.seed(seed)
     t0 = time.perf_counter()
     n = 0
@@ -30,12 +32,13 @@ def run_stream(frames, n_components=50, max_iter=50, cov_type='spherical', fit_e
             pts = voxel_down_sample(pts, voxel_size)
         if i % fit_every == 0:
             t1 = time.perf_counter()
-            gmm.compute(pts)
+            models.append(tuple(np.array(a) for a in gmm.compute(pts)))
             fit_s.append(time.perf_counter() - t1)
         labels.append(gmm.predict(pts))
         n += 1
     dt = time.perf_counter() - t0
-    return {"labels": labels, "fps": n / dt if dt > 0 else float("inf"), "fit_s": fit_s, "frames": n}
+    return {"labels": labels, "fps": n / dt if dt > 0 else float("inf"), "fit_s": fit_s, "frames": n,
+            "models": models}
 
 
 def main(argv=None):

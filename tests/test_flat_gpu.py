@@ -68,28 +68,46 @@ def test_estep_small_golden(ctx, variant, cov_type):
     assert (lab != g["it5_predict"]).sum() <= 1
 
 
+FLAVOURS = [("W", "diag"), ("W", "spherical"), ("G", "diag")]
+
+
+def bunny_golden(J, variant, cov_type):
+    name = "flat_bunny_J%d.npz" % J if (variant, cov_type) == ("W", "diag") else \
+        "flat_bunny_J%d_%s_%s.npz" % (J, variant, cov_type)
+    return load_golden(name)
+
+
+@pytest.mark.parametrize("variant,cov_type", FLAVOURS)
 @pytest.mark.parametrize("J", [100, 800])
-def test_estep_bunny(ctx, bunny, J):
+def test_estep_bunny(ctx, bunny, J, variant, cov_type):
     """BASELINE configs 1/2: bun000.ply, J=100 / J=800, at the initial and at the 20-iteration
-    parameters of the reference run."""
-    g = load_golden("flat_bunny_J%d.npz" % J)
+    parameters of the reference run -- every flavour the reference has (gmm_waymo diag / spherical,
+    gmmreg_gpu diag)."""
+    g = bunny_golden(J, variant, cov_type)
     X = bunny
     w0 = (np.ones(J) / J).astype(np.float32)
-    inv0 = (1 / np.sqrt(0.1 * np.ones((J, 3)))).astype(np.float32)
+    inv0 = (1 / np.sqrt(0.1 * np.ones((J, 3) if cov_type == "diag" else (J,)))).astype(np.float32)
     for tag, (inv, mu, w) in {"init": (inv0, X[g["init_idx"]], w0),
                               "final": (g["inv"], g["mu"], g["w"])}.items():
-        lr = check_estep(ctx, X, inv, mu, w, "diag", "W", "bunny J=%d %s" % (J, tag))
+        lr = check_estep(ctx, X, inv, mu, w, cov_type, variant, "bunny J=%d %s/%s %s" % (J, variant, cov_type, tag))
         rows = g["rows"]
         d64 = np.abs(np.exp(lr[rows].astype(np.float64)) - g[tag + "_resp64_rows"]).max()
         d32 = np.abs(np.exp(lr[rows]) - g[tag + "_resp32_rows"]).max()
+        noise = float(g[tag + "_noise_max_abs_dresp"])
         print("   vs reference fp64 rows %.3g ; vs reference fp32 rows %.3g (reference fp32-vs-fp64 noise %.3g)"
-              % (d64, d32, float(g[tag + "_noise_max_abs_dresp"])))
+              % (d64, d32, noise))
         assert d64 <= RESP_TOL
+        # against the reference's own float32 output: no further away than that output is from the reference's
+        # float64 run (its noise floor, stored with the fixture) plus the 1e-5 bar
+        assert d32 <= noise + RESP_TOL
         # hard assignments vs the reference's float64 run
         ctx.set_points(X)
-        lab = ctx.flat_predict(inv, mu, w, "diag", "W").get()
+        lab = ctx.flat_predict(inv, mu, w, cov_type, variant).get()
         flips = lab != g[tag + "_argmax64"].astype(np.int64)
         assert (g[tag + "_top2gap64"][flips] < RESP_TOL).all()
+        # ... and vs its float32 run: flips only where the float32 reference itself is within its noise of a tie
+        flips32 = lab != g[tag + "_argmax32"].astype(np.int64)
+        assert (g[tag + "_top2gap64"][flips32] <= 2 * noise + RESP_TOL).all()
 
 
 @pytest.mark.parametrize("variant,cov_type", [("W", "diag"), ("W", "spherical"), ("G", "diag")])
@@ -148,33 +166,39 @@ def test_train_early_stop(ctx):
     np.testing.assert_allclose(mu, o[1], rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("variant,cov_type", FLAVOURS)
 @pytest.mark.parametrize("J", [100, 800])
-def test_train_bunny_20_iterations(ctx, bunny, J):
+def test_train_bunny_20_iterations(ctx, bunny, J, variant, cov_type):
     """BASELINE config 1/2 end to end: 20 EM iterations, tol=0, same seeded init as the
-    reference run behind the golden file."""
-    g = load_golden("flat_bunny_J%d.npz" % J)
+    reference run behind the golden file, all three flavours."""
+    g = bunny_golden(J, variant, cov_type)
     X = bunny
     mu0 = X[g["init_idx"]]
     w0 = (np.ones(J) / J).astype(np.float32)
-    cov0 = (0.1 * np.ones((J, 3))).astype(np.float32)
+    cov0 = (0.1 * np.ones((J, 3) if cov_type == "diag" else (J,))).astype(np.float32)
     ctx.set_points(X)
-    inv, mu, w, cov, lls, conv = ctx.flat_train(20, 0.0, mu0, cov0, w0, "diag", "W")
+    inv, mu, w, cov, lls, conv = ctx.flat_train(20, 0.0, mu0, cov0, w0, cov_type, variant)
     assert len(lls) == 20
     f64 = lambda a: np.asarray(a, dtype=np.float64)
-    o_inv, o_mu, o_w, o_cov, o_lls, _ = flat_em.train(f64(X), 20, 0.0, f64(mu0), f64(cov0), f64(w0), "diag", "W")
+    o_inv, o_mu, o_w, o_cov, o_lls, _ = flat_em.train(f64(X), 20, 0.0, f64(mu0), f64(cov0), f64(w0), cov_type, variant)
     d_ll = np.abs(lls - np.array(o_lls)).max()
     d_ref = np.abs(lls - g["lls"]).max()
     d_refref = np.abs(np.array(o_lls) - g["lls"]).max()
-    print("J=%d lls: |gpu-oracle64| %.3g  |gpu-ref32| %.3g  |ref32-oracle64| %.3g" % (J, d_ll, d_ref, d_refref))
-    # trajectories: GPU fp32 (centred form) vs fp64 oracle stay together; the reference's fp32
-    # trajectory drifts from its own fp64 run by d_refref -- we must be no further than that
-    assert d_ll <= max(5e-4, 2 * d_refref)
+    print("J=%d %s/%s lls: |gpu-oracle64| %.3g  |gpu-ref32| %.3g  |ref32-oracle64| %.3g"
+          % (J, variant, cov_type, d_ll, d_ref, d_refref))
+    # The GPU's float32-state trajectory stays with the float64 oracle (measured 1.5e-6 .. 3e-6 for flavour W);
+    # the reference's own float32 trajectory is d_refref (~1e-3) away from that oracle, and the GPU must be no
+    # further from the reference than the oracle is (+ the same small margin).  Flavour G clips the covariance
+    # at 0 without a floor, so its late iterations amplify float32 state rounding: bound relative to d_refref.
+    tol_ll = 2e-5 if variant == "W" else max(2e-5, 0.25 * d_refref)
+    assert d_ll <= tol_ll, (d_ll, tol_ll)
+    assert d_ref <= d_refref + tol_ll
     live = o_w > 1e-4
     d_mu = np.abs(mu - o_mu)[live].max()
     d_mu_ref = np.abs(g["mu"] - o_mu)[live].max()
     print("J=%d means: |gpu-oracle64| %.3g  |ref32-oracle64| %.3g" % (J, d_mu, d_mu_ref))
-    assert d_mu <= max(1e-4, 2 * d_mu_ref)
-    np.testing.assert_allclose(w[live], o_w[live], rtol=0, atol=max(1e-5, 2 * np.abs(g["w"] - o_w).max()))
+    assert d_mu <= max(2e-5, 0.5 * d_mu_ref)
+    np.testing.assert_allclose(w[live], o_w[live], rtol=0, atol=max(1e-5, 0.5 * np.abs(g["w"] - o_w).max()))
 
 
 @pytest.mark.parametrize("N,J", [(1, 1), (63, 5), (65, 37), (1000, 64), (777, 257), (300, 1023), (500, 1024)])
@@ -571,3 +595,53 @@ def test_device_points_go_stale_after_any_other_upload(ctx, bunny):
     ctx.set_points(X)                                                         # direct upload on the context
     with pytest.raises(RuntimeError):
         W.predict(dX2, 1 / np.sqrt(cov0), mu0, w0)
+
+
+def test_streaming_harness_matches_the_oracle_on_the_reference_frames(ctx):
+    """the loop of run_gmm_waymo_gpu.py:32-61 (refit every k frames, predict every frame) on the five
+    Waymo frames the reference ships.  Replayed with the oracle: same RNG stream -> same initial parameters ->
+    float64 EM; the refit models must agree with it, and EVERY frame's labels must be the oracle's predict under
+    the model in force (flips only at genuine near-ties)."""
+    import hgmm_amd
+    from hgmm_amd.gmm_waymo.run_gmm_stream import run_stream
+    from hgmm_amd.gmm_waymo.gmm_impl import init_gmm_params
+    hgmm_amd.set_default_context(ctx)
+    fr = load_golden("waymo_frames.npz")
+    frames = [fr["waymo%d" % k] for k in (1, 2, 5, 10, 50)]
+    K, iters, every = 50, 50, 2                                  # the driver's NUM_COMPONENTS / MAX_ITER; refits 0, 2, 4
+    res = run_stream(frames, n_components=K, max_iter=iters, cov_type='spherical', fit_every=every, tol=1e-4, seed=5)
+    assert res["frames"] == 5 and len(res["models"]) == 3
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    np.random.seed(5)                                            # run_gmm_waymo_gpu.py:30
+    for i, pts in enumerate(frames):
+        X = pts.astype(np.float32)
+        means, weights, covs, inv = res["models"][i // every]
+        if i % every == 0:
+            mu0, w0, cov0 = init_gmm_params(X, K, cov_type='spherical')        # same draw as inside the harness
+            o = flat_em.train(f64(X), iters, 1e-4, f64(mu0), f64(cov0), f64(w0), "spherical", "W")
+            o_inv, o_mu, o_w, o_cov, o_lls, o_conv = o
+            lls = np.asarray(res_lls(hgmm_amd, X, mu0, cov0, w0, iters))
+            # same number of iterations up to the tol = 1e-4 stop (a change of 1e-4 can fall either side by one)
+            assert abs(len(lls) - len(o_lls)) <= 1
+            m = min(len(lls), len(o_lls))
+            np.testing.assert_allclose(lls[:m], np.array(o_lls)[:m], rtol=0, atol=5e-5)
+            if len(lls) == len(o_lls):
+                live = o_w > 1e-4
+                np.testing.assert_allclose(means[live], o_mu[live], rtol=0, atol=2e-3 * np.abs(X).max())
+                np.testing.assert_allclose(weights[live], o_w[live], rtol=0, atol=2e-4)
+        lab = res["labels"][i]
+        assert lab.shape == (len(X),) and lab.dtype == np.int64
+        ref = flat_em.predict(f64(X), f64(inv), f64(means), f64(weights), "spherical", "W")
+        bad = np.flatnonzero(lab != ref)
+        if len(bad):
+            _, lr, _, _ = flat_em.e_step_full(f64(X)[bad], f64(inv), f64(means), f64(weights), "spherical", "W")
+            assert flat_em.near_tie_mask(lr, 1e-5).all(), (i, len(bad))
+        assert len(bad) <= 1e-3 * len(X)
+
+
+def res_lls(hgmm_amd, X, mu0, cov0, w0, iters):
+    """log-likelihood trace of the engine's fit from explicit initial parameters (what GMM_GPU_Base.fit stores)."""
+    from hgmm_amd.gmm_waymo.gmm import GMM_GPU_Base
+    b = GMM_GPU_Base(len(mu0), max_iter=iters, tol=1e-4, cov_type='spherical')
+    b._verbose = False
+    return b.fit(X, init=(mu0, w0, cov0)).lls

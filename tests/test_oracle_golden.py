@@ -38,27 +38,30 @@ def test_flat_small_matches_reference_bitwise(variant, cov_type):
         assert np.array_equal(flat_em.predict(X, inv, mu, w, cov_type, variant), g[pre + "predict"])
 
 
+@pytest.mark.parametrize("variant,cov_type", [("W", "diag"), ("W", "spherical"), ("G", "diag")])
 @pytest.mark.parametrize("J", [100, 800])
-def test_flat_bunny_matches_reference(bunny, J):
-    """bun000.ply, seeded init, 20 iterations, tol=0 (BASELINE configs 1/2)."""
-    g = load_golden("flat_bunny_J%d.npz" % J)
+def test_flat_bunny_matches_reference(bunny, J, variant, cov_type):
+    """bun000.ply, seeded init, 20 iterations, tol=0 (BASELINE configs 1/2), every flavour of the reference."""
+    name = "flat_bunny_J%d.npz" % J if (variant, cov_type) == ("W", "diag") else \
+        "flat_bunny_J%d_%s_%s.npz" % (J, variant, cov_type)
+    g = load_golden(name)
     X = bunny
     mu0 = X[g["init_idx"]].copy()
     w0 = (np.ones(J) / J).astype(np.float32)
-    cov0 = (0.1 * np.ones((J, 3))).astype(np.float32)
-    iters = 20 if J == 100 else 3          # keep the CPU suite short; J=800 checks a prefix
-    inv, mu, w, cov, lls, _ = flat_em.train(X, iters, 0.0, mu0, cov0, w0, "diag", "W")
+    cov0 = (0.1 * np.ones((J, 3) if cov_type == "diag" else (J,))).astype(np.float32)
+    iters = 20 if (J == 100 and variant == "W" and cov_type == "diag") else 3   # keep the CPU suite short: prefixes
+    inv, mu, w, cov, lls, _ = flat_em.train(X, iters, 0.0, mu0, cov0, w0, cov_type, variant)
     # BLAS threading may change GEMM summation order => allow fp32 round-off, not more
     np.testing.assert_allclose(np.array(lls, dtype=np.float32), g["lls"][:iters], rtol=2e-5, atol=2e-5)
     if iters == 20:
         np.testing.assert_allclose(mu, g["mu"], rtol=0, atol=2e-4)
         np.testing.assert_allclose(w, g["w"], rtol=0, atol=1e-5)
     rows = g["rows"]
-    inv0 = flat_em.inv_std_from_cov(cov0, "W", initial=True)
+    inv0 = flat_em.inv_std_from_cov(cov0, variant, initial=True)
     for tag, (a, b, c) in {"init": (inv0, X[g["init_idx"]], w0),
                            "final": (g["inv"], g["mu"], g["w"])}.items():
         _, lr = flat_em.e_step(X[rows].astype(np.float64), a.astype(np.float64),
-                               b.astype(np.float64), c.astype(np.float64), "diag", "W")
+                               b.astype(np.float64), c.astype(np.float64), cov_type, variant)
         np.testing.assert_allclose(np.exp(lr), g[tag + "_resp64_rows"], rtol=0, atol=1e-12)
 
 

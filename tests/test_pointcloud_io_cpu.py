@@ -3,6 +3,8 @@ here in every encoding the reference's data uses (ASCII/binary PLY, PCD ascii/bi
 binary_compressed)."""
 import struct
 
+import os
+
 import numpy as np
 import pytest
 
@@ -117,3 +119,61 @@ def test_voxel_down_sample_properties(bunny):
             np.testing.assert_allclose(Q[k], P[members].mean(0), rtol=1e-12, atol=1e-15)
     one = voxel_down_sample(P, 10.0)
     np.testing.assert_allclose(one, P.mean(0)[None], rtol=1e-12)
+
+
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference checkout only exists in the build container")
+def test_readers_on_the_reference_s_own_files(bunny):
+    """the package's readers on the files the reference ships, against fixtures that were written
+    by an independent parse (tools/gen_golden.py: read_ply_vertices / gen_waymo_frames) -- ASCII PLY with a range
+    grid after the vertex block, binary PCD, and the organised binary_compressed (LZF) PCD with NaN holes."""
+    from conftest import GOLDEN
+    from hgmm_amd.pointcloud_io import read_point_cloud, read_pcd
+    P = read_point_cloud(os.path.join(REF, "data/bun000.ply"))
+    assert P.dtype == np.float64 and np.array_equal(P.astype(np.float32), bunny)
+    P45 = read_point_cloud(os.path.join(REF, "data/bun045.ply"))
+    assert np.array_equal(P45.astype(np.float32), np.load(os.path.join(GOLDEN, "bun045_xyz.npy")))
+    # in-test independent parse of the PLY vertex block (header says how many lines to take)
+    lines = open(os.path.join(REF, "data/bun045.ply")).read().split("\n")
+    n_v = int([l for l in lines if l.startswith("element vertex")][0].split()[-1])
+    body = lines[lines.index("end_header") + 1:][:n_v]
+    raw = np.array([[float(v) for v in l.split()[:3]] for l in body])
+    assert np.array_equal(P45, raw)
+    # the three copies of bunny.pcd (512 x 400 organised grid, LZF-compressed, 164544 NaN holes) hold exactly the
+    # vertices of bun000.ply, in the same order
+    for sub in ("gmmreg_gpu", "hgmm", "gmm_waymo/data"):
+        path = os.path.join(REF, "src/python", sub, "bunny.pcd")
+        Q = read_point_cloud(path)
+        assert np.array_equal(Q.astype(np.float32), bunny)
+        full = read_pcd(path, drop_nan=False)
+        assert full.shape == (204800, 3) and int(np.isnan(full).any(axis=1).sum()) == 204800 - 40256
+    frames = np.load(os.path.join(GOLDEN, "waymo_frames.npz"))
+    for k in (1, 2, 5, 10, 50):
+        W = read_point_cloud(os.path.join(REF, "src/python/gmmreg_gpu/waymo%d.pcd" % k))
+        assert W.dtype == np.float64 and np.array_equal(W.astype(np.float32), frames["waymo%d" % k])
+    for k in (1, 2):                                     # the hgmm directory holds copies of two of them
+        W = read_point_cloud(os.path.join(REF, "src/python/hgmm/waymo%d.pcd" % k))
+        assert np.array_equal(W.astype(np.float32), frames["waymo%d" % k])
+    D = read_point_cloud(os.path.join(REF, "src/python/gmm_waymo/data/dragon.ply"))
+    assert D.shape == (41841, 3) and np.isfinite(D).all()
+
+
+def test_voxel_down_sample_hand_computed():
+    """Open3D's documented rule (PointCloud::VoxelDownSample): voxel index = floor((p - (min_bound - voxel / 2)) /
+    voxel), output = the mean of the points of each occupied voxel.  Seven points, voxel 1.0, worked by hand:
+    min_bound = (0, 0, 0) -> grid origin (-0.5, -0.5, -0.5); indices: (0,0,0) for the first three points,
+    (1,0,0) for the next two, (2,3,0) and (0,0,1) for the last two."""
+    from hgmm_amd.pointcloud_io import voxel_down_sample
+    P = np.array([[0.0, 0.0, 0.0], [0.4, 0.2, 0.1], [0.2, 0.4, 0.2],        # voxel (0,0,0)
+                  [0.6, 0.0, 0.0], [1.4, 0.4, 0.3],                          # voxel (1,0,0): 1.1 and 1.9 -> floor 1
+                  [2.2, 2.6, 0.1],                                           # voxel (2,3,0): 2.7, 3.1
+                  [0.1, 0.2, 0.5]])                                          # voxel (0,0,1): z + 0.5 = 1.0 -> floor 1
+    want = np.array([[0.2, 0.2, 0.1], [1.0, 0.2, 0.15], [2.2, 2.6, 0.1], [0.1, 0.2, 0.5]])
+    got = voxel_down_sample(P, 1.0)
+    assert got.shape == (4, 3)
+    order = lambda a: a[np.lexsort(a.T[::-1])]
+    np.testing.assert_allclose(order(got), order(want), rtol=0, atol=1e-15)
+    # a point exactly on a voxel face belongs to the upper voxel (floor), and a shifted cloud shifts the grid with it
+    np.testing.assert_allclose(order(voxel_down_sample(P + 7.25, 1.0)), order(want + 7.25), rtol=0, atol=1e-12)

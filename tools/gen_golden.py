@@ -147,41 +147,47 @@ def gen_flat_small(W, G):
             print("flat_small", variant, cov_type, "lls", out["it5_lls"])
 
 
-def gen_flat_bunny(W, G, pts):
+def gen_flat_bunny(W, G, pts, flavours=(("W", "diag"),)):
+    """BASELINE configs 1/2 (bun000.ply, J = 100 / 800, 20 iterations, tol = 0).  ("W", "diag") is the original
+    fixture pair flat_bunny_J<J>.npz; the other flavours -- gmm_waymo spherical, gmmreg_gpu diag -- go to
+    flat_bunny_J<J>_<variant>_<cov>.npz with 64 instead of 256 sampled responsibility rows."""
     X = pts.astype(np.float32)
     N = len(X)
-    for J in (100, 800):
-        rs = np.random.RandomState(0)
-        idx = rs.choice(N, J, replace=False)
-        mu0 = X[idx].copy()
-        w0 = (np.ones(J) / J).astype(np.float32)
-        cov0 = (0.1 * np.ones((J, 3))).astype(np.float32)
-        with quiet():
-            inv, mu, w, cov, lls = W.train_gmm(X, 20, 0.0, mu0.copy(), cov0.copy(), w0.copy(),
-                                                cov_type="diag")
-        out = {"init_idx": idx.astype(np.int32), "lls": np.array(lls, dtype=np.float32),
-               "inv": inv, "mu": mu, "w": w, "cov": cov}
-        rows = np.random.RandomState(1).choice(N, 256, replace=False)
-        rows.sort()
-        out["rows"] = rows.astype(np.int32)
-        inv0 = 1 / np.sqrt(cov0)
-        for tag, (a, b, c) in {"init": (inv0, mu0, w0), "final": (inv, mu, w)}.items():
-            ll32, lr32 = W.e_step(X, a, b, c, cov_type="diag")
-            ll64, lr64 = W.e_step(X.astype(np.float64), a.astype(np.float64), b.astype(np.float64),
-                                  c.astype(np.float64), cov_type="diag")
-            out[tag + "_ll32"], out[tag + "_ll64"] = np.float32(ll32), np.float64(ll64)
-            out[tag + "_resp32_rows"] = np.exp(lr32[rows])
-            out[tag + "_resp64_rows"] = np.exp(lr64[rows])
-            out[tag + "_argmax32"] = lr32.argmax(1).astype(np.uint16)
-            out[tag + "_argmax64"] = lr64.argmax(1).astype(np.uint16)
-            r64 = np.exp(lr64)
-            part = np.partition(r64, -2, axis=1)
-            out[tag + "_top2gap64"] = (part[:, -1] - part[:, -2]).astype(np.float32)
-            out[tag + "_noise_max_abs_dresp"] = np.float64(np.abs(np.exp(lr32.astype(np.float64)) - r64).max())
-        out["predict"] = W.predict(X, inv, mu, w, cov_type="diag").astype(np.uint16)
-        np.savez_compressed(os.path.join(OUT, "flat_bunny_J%d.npz" % J), **out)
-        print("flat_bunny J", J, "lls[-1]", lls[-1], "fp32-vs-fp64 noise",
-              out["final_noise_max_abs_dresp"])
+    for variant, cov_type in flavours:
+        mod = W if variant == "W" else G
+        kw = {"cov_type": cov_type} if variant == "W" else {}
+        base = (variant, cov_type) == ("W", "diag")
+        for J in (100, 800):
+            rs = np.random.RandomState(0)
+            idx = rs.choice(N, J, replace=False)
+            mu0 = X[idx].copy()
+            w0 = (np.ones(J) / J).astype(np.float32)
+            cov0 = (0.1 * np.ones((J, 3) if cov_type == "diag" else (J,))).astype(np.float32)
+            with quiet():
+                inv, mu, w, cov, lls = mod.train_gmm(X, 20, 0.0, mu0.copy(), cov0.copy(), w0.copy(), **kw)
+            out = {"init_idx": idx.astype(np.int32), "lls": np.array(lls, dtype=np.float32),
+                   "inv": inv, "mu": mu, "w": w, "cov": cov}
+            rows = np.random.RandomState(1).choice(N, 256 if base else 64, replace=False)
+            rows.sort()
+            out["rows"] = rows.astype(np.int32)
+            inv0 = 1 / np.sqrt(cov0)
+            for tag, (a, b, c) in {"init": (inv0, mu0, w0), "final": (inv, mu, w)}.items():
+                ll32, lr32 = mod.e_step(X, a, b, c, **kw)
+                ll64, lr64 = mod.e_step(X.astype(np.float64), a.astype(np.float64), b.astype(np.float64),
+                                        c.astype(np.float64), **kw)
+                out[tag + "_ll32"], out[tag + "_ll64"] = np.float32(ll32), np.float64(ll64)
+                out[tag + "_resp32_rows"] = np.exp(lr32[rows])
+                out[tag + "_resp64_rows"] = np.exp(lr64[rows])
+                out[tag + "_argmax32"] = lr32.argmax(1).astype(np.uint16)
+                out[tag + "_argmax64"] = lr64.argmax(1).astype(np.uint16)
+                r64 = np.exp(lr64)
+                part = np.partition(r64, -2, axis=1)
+                out[tag + "_top2gap64"] = (part[:, -1] - part[:, -2]).astype(np.float32)
+                out[tag + "_noise_max_abs_dresp"] = np.float64(np.abs(np.exp(lr32.astype(np.float64)) - r64).max())
+            out["predict"] = mod.predict(X, inv, mu, w, **kw).astype(np.uint16)
+            name = "flat_bunny_J%d.npz" % J if base else "flat_bunny_J%d_%s_%s.npz" % (J, variant, cov_type)
+            np.savez_compressed(os.path.join(OUT, name), **out)
+            print(name, "lls[-1]", lls[-1], "fp32-vs-fp64 noise", out["final_noise_max_abs_dresp"])
 
 
 # ---------------------------------------------------------------------------
@@ -392,6 +398,23 @@ def gen_gmmreg(pts):
         sys.path.remove(refdir)
 
 
+def gen_waymo_frames():
+    """The five Waymo LIDAR frames the reference ships (src/python/gmmreg_gpu/waymo{1,2,5,10,50}.pcd, binary PCD,
+    xyz float32) as plain arrays -- parsed HERE with a few lines of NumPy, independently of the package's
+    pointcloud_io reader, which tests/test_pointcloud_io_cpu.py then checks against them; they are also the frames
+    of the streaming-harness parity test (run_gmm_waymo_gpu.py:32-61)."""
+    out = {}
+    for k in (1, 2, 5, 10, 50):
+        raw = open(os.path.join(REF, "src/python/gmmreg_gpu/waymo%d.pcd" % k), "rb").read()
+        head, _, body = raw.partition(b"DATA binary\n")
+        fields = dict(l.split(None, 1) for l in head.decode("ascii").splitlines() if l and not l.startswith("#"))
+        assert fields["FIELDS"].split() == ["x", "y", "z"] and fields["SIZE"].split() == ["4", "4", "4"]
+        n = int(fields["POINTS"])
+        out["waymo%d" % k] = np.frombuffer(body, dtype="<f4", count=3 * n).reshape(n, 3).copy()
+        print("waymo%d" % k, out["waymo%d" % k].shape)
+    np.savez_compressed(os.path.join(OUT, "waymo_frames.npz"), **out)
+
+
 def gen_scan_pair():
     """Second Stanford scan + the ground-truth scan poses of data/bun.conf (data fixtures for the
     end-to-end registration accuracy test): bun045 vertices (float32) and, per scan, translation
@@ -458,15 +481,19 @@ def main():
     assert pts.shape == (40256, 3)
     np.save(os.path.join(OUT, "bun000_xyz.npy"), pts.astype(np.float32))
     want = lambda k: args.only in (None, k)
-    if want("flat") or want("bunny"):
+    if want("flat") or want("bunny") or want("bunny_flavours"):
         W = load_module("ref_gmm_impl_W", os.path.join(REF, "src/python/gmm_waymo/src/gmm_impl.py"))
         G = load_module("ref_gmm_impl_G", os.path.join(REF, "src/python/gmmreg_gpu/gmm_impl.py"))
         if want("flat"):
             gen_flat_small(W, G)
         if want("bunny"):
             gen_flat_bunny(W, G, pts)
+        if want("bunny_flavours"):
+            gen_flat_bunny(W, G, pts, flavours=(("W", "spherical"), ("G", "diag")))
     if want("scans"):
         gen_scan_pair()
+    if want("frames"):
+        gen_waymo_frames()
     if want("kmeans"):
         G = load_module("ref_gmm_impl_G", os.path.join(REF, "src/python/gmmreg_gpu/gmm_impl.py"))
         gen_kmeans(G, pts)
