@@ -248,6 +248,181 @@ __global__ __launch_bounds__(KM_BLOCK) void kmpp_update_kernel(const double* __r
 }
 
 // ------------------------------------------------------------------------------------------
+// Fused seeding step: ONE pass over the points per centre instead of two (eval + update).
+//
+// The potential of candidate t,  sum_i min(closest_i, |x_i - cand_t|^2),  is accumulated per 256-point block
+// (`part[t][b]`) -- and those block sums ARE the block sums of the closest-distance array after cand_t has been
+// accepted.  So the winner's row of `part` replaces the separate update pass as far as the next draw's prefix
+// search is concerned; the element-wise minimum itself is folded into the NEXT step's pass (`fold` = the centre
+// accepted last), and inside the one block the search lands in it is formed on the fly.  Per centre:
+//   kmpp_step_kernel   closest <- min(closest, d(., centre fold)); part[t][b] for the T candidates     (grid B)
+//   kmpp_tail_kernel   winner = first arg-min_t sum_b part[t][b]  ->  centre j;  prefix scan of its row; the T
+//                      candidates of centre j + 1 by np.searchsorted(cumsum, rand * pot)        (one workgroup)
+// Same sums in the same order as the four-kernel form (kmpp_pick / eval / select / update, kept for reference
+// and used by nothing else), hence the same seeds.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(KM_BLOCK) void kmpp_step_kernel(const double* __restrict__ xs, int64_t n, int64_t n_pad,
+                                                             double* __restrict__ closest,
+                                                             const double* __restrict__ centres, int fold,
+                                                             const double* __restrict__ cand_xyz, int T,
+                                                             double* __restrict__ part) {
+    __shared__ double sh[KM_MAX_TRIALS][4];
+    const int64_t i = (int64_t)blockIdx.x * KM_BLOCK + threadIdx.x;
+    const bool live = i < n;
+    const double x = xs[i], y = xs[n_pad + i], z = xs[2 * n_pad + i];
+    double cl = closest[i];
+    if (fold >= 0) {
+        const double d = dist2(x, y, z, centres[3 * fold], centres[3 * fold + 1], centres[3 * fold + 2]);
+        cl = live ? fmin(cl, d) : 0.0;
+        closest[i] = cl;
+    }
+    for (int t = 0; t < T; ++t) {
+        const double d = dist2(x, y, z, cand_xyz[3 * t], cand_xyz[3 * t + 1], cand_xyz[3 * t + 2]);   // scalar loads
+        const double w = wave_sum_f64(live ? fmin(cl, d) : 0.0);
+        if (lane_id() == 0) sh[t][wave_in_block()] = w;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < T)
+        part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
+            (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+
+// One workgroup of 1024 threads.  `select`: pick the winner among the T candidates of centre j from `part`.
+// `draw`: draw the T candidates of the next centre from the block sums `bs` (= the winner's row of `part`, or the
+// first kernel's `bsum`); `closest` lacks the fold of centre `pend` (-1: it is current), applied on the fly.
+constexpr int KM_TAIL_LDS_BLOCKS = 7168;                 // block-prefix table kept in LDS up to this many 256-point blocks
+__global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restrict__ xs, int64_t n, int64_t n_pad,
+                                                         const double* __restrict__ closest,
+                                                         const double* __restrict__ part,
+                                                         const double* __restrict__ bsum0, int B, int T, int j,
+                                                         int select, int draw, const double* __restrict__ rand_c,
+                                                         int64_t* __restrict__ cand, double* __restrict__ cand_xyz,
+                                                         double* __restrict__ centres,
+                                                         int64_t* __restrict__ ids, double* __restrict__ bprefix) {
+    __shared__ double wsum[KM_MAX_TRIALS][16];
+    __shared__ double wave_tot[16];
+    __shared__ double seg_end[1024];
+    __shared__ double pre_sh[KM_TAIL_LDS_BLOCKS];       // inclusive prefix of the block sums (global `bprefix` beyond)
+    __shared__ double total_sh;
+    __shared__ int best_sh;
+    const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
+    const bool in_lds = B <= KM_TAIL_LDS_BLOCKS;
+    // the uniforms and (when there is no selection) nothing else can be fetched before the sums arrive
+    const double my_rand = (draw && wave < T) ? rand_c[wave] : 0.0;
+    if (select) {
+        double acc[KM_MAX_TRIALS];
+#pragma unroll
+        for (int t = 0; t < KM_MAX_TRIALS; ++t) acc[t] = 0.0;
+        for (int b = tid; b < B; b += 1024) {
+#pragma unroll
+            for (int t = 0; t < KM_MAX_TRIALS; ++t)
+                if (t < T) acc[t] += part[(size_t)t * B + b];
+        }
+#pragma unroll
+        for (int t = 0; t < KM_MAX_TRIALS; ++t) {
+            if (t < T) {
+                const double w = wave_sum_f64(acc[t]);
+                if (lane == 0) wsum[t][wave] = w;
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // lanes 0..T-1 add up their candidate's 16 wave totals (fixed order); first minimum wins (np.argmin)
+            double p = 0.0;
+            if (tid < T)
+                for (int w = 0; w < 16; ++w) p += wsum[tid][w];
+            int best = 0;
+            double best_pot = __shfl(p, 0);
+            for (int t = 1; t < T; ++t) {
+                const double pt = __shfl(p, t);
+                if (pt < best_pot) { best = t; best_pot = pt; }
+            }
+            if (tid == 0) best_sh = best;
+        }
+        __syncthreads();
+    }
+    int64_t win = 0;
+    double pcx = 0.0, pcy = 0.0, pcz = 0.0;
+    if (select) {
+        win = cand[best_sh];
+        pcx = cand_xyz[3 * best_sh]; pcy = cand_xyz[3 * best_sh + 1]; pcz = cand_xyz[3 * best_sh + 2];
+        if (tid == 0) {
+            ids[j] = win;
+            centres[3 * j + 0] = pcx; centres[3 * j + 1] = pcy; centres[3 * j + 2] = pcz;
+        }
+    }
+    if (!draw) return;
+    const double* bs = select ? part + (size_t)best_sh * B : bsum0;
+    const int pend = select ? j : -1;                       // centre whose fold `closest` is still missing
+    const int seg = (B + 1023) / 1024;
+    const int b0 = tid * seg, b1 = min(B, b0 + seg);
+    double loc = 0.0;
+    for (int b = b0; b < b1; ++b) loc += bs[b];
+    const double incl = wave_scan_f64(loc);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();                                        // (also: everybody has read cand[best] before it is overwritten)
+    double off = 0.0;
+    for (int w = 0; w < wave; ++w) off += wave_tot[w];
+    double run = off + (incl - loc);
+    for (int b = b0; b < b1; ++b) {
+        run += bs[b];
+        if (in_lds) pre_sh[b] = run; else bprefix[b] = run;
+    }
+    seg_end[tid] = off + incl;
+    if (tid == 1023) total_sh = off + incl;
+    if (!in_lds) __threadfence();
+    __syncthreads();
+    const double pot = total_sh;
+    if (wave >= T) return;
+    const double v = my_rand * pot;
+    const volatile double* bp = bprefix;                 // written by other waves of this workgroup
+    auto pre = [&](int b) -> double { return in_lds ? pre_sh[b] : bp[b]; };
+    int lo = 0, hi = 1024;                               // first segment whose end >= v (LDS) ...
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (seg_end[mid] >= v) hi = mid; else lo = mid + 1;
+    }
+    hi = min(B, (lo + 1) * seg);                         // ... then the first block inside it
+    lo = min(B, lo * seg);
+    while (lo < hi && !(pre(lo) >= v)) ++lo;
+    if (lo == hi && hi < B) lo = hi;                     // rounding at the segment's end
+    int64_t found = n - 1;                               // np.clip(..., n - 1)
+    if (lo < B) {
+        const double base = lo > 0 ? pre(lo - 1) : 0.0;
+        const int64_t e0 = (int64_t)lo * KM_BLOCK + 4 * lane;
+        double c[4];
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double val = 0.0;
+            if (e0 + q < n) {
+                val = closest[e0 + q];
+                if (pend >= 0) val = fmin(val, dist2(xs[e0 + q], xs[n_pad + e0 + q], xs[2 * n_pad + e0 + q], pcx, pcy, pcz));
+            }
+            s += val;
+            c[q] = s;
+        }
+        const double ex = base + (wave_scan_f64(s) - s);
+        int first_q = 4;
+#pragma unroll
+        for (int q = 3; q >= 0; --q)
+            if (e0 + q < n && ex + c[q] >= v) first_q = q;
+        const unsigned long long hit = __ballot(first_q < 4);
+        if (hit) {
+            const int l = __ffsll((long long)hit) - 1;
+            const int q = __builtin_amdgcn_readlane(first_q, l);
+            found = (int64_t)lo * KM_BLOCK + 4 * l + q;
+        } else {
+            // rounding at the block's end: the threshold falls on the first element after it
+            const int64_t nxt = (int64_t)(lo + 1) * KM_BLOCK;
+            found = nxt < n ? nxt : n - 1;
+        }
+    }
+    if (lane < 3) cand_xyz[3 * wave + lane] = xs[(size_t)lane * n_pad + found];     // for the next step + tail
+    if (lane == 0) cand[wave] = found;
+}
+
+// ------------------------------------------------------------------------------------------
 // Lloyd iteration
 // ------------------------------------------------------------------------------------------
 // Two points per thread (512 per workgroup); the centre table [k][4] (x y z pad) is read with a
@@ -479,7 +654,7 @@ extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const 
     const int B = (int)km_nblk(n, KM_BLOCK);
     HGMM_TRY(ensure(c, c->km_closest, sizeof(double) * n_pad));
     HGMM_TRY(ensure(c, c->km_block, sizeof(double) * ((size_t)2 * B + (size_t)B * KM_MAX_TRIALS + 8)));
-    HGMM_TRY(ensure(c, c->km_centres, sizeof(double) * 7 * (size_t)k));
+    HGMM_TRY(ensure(c, c->km_centres, sizeof(double) * (7 * (size_t)k + 3 * KM_MAX_TRIALS)));
     HGMM_TRY(ensure(c, c->km_ids, sizeof(int64_t) * ((size_t)k + KM_MAX_TRIALS)));
     HGMM_TRY(ensure(c, c->km_rand, sizeof(double) * (size_t)std::max(1, (k - 1) * n_trials)));
     const double* xs = c->x_soa64.as<double>();
@@ -496,13 +671,29 @@ extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const 
         HGMM_HIP(c, hipMemcpyAsync(rand_dev, rand_vals, sizeof(double) * (size_t)(k - 1) * n_trials,
                                    hipMemcpyHostToDevice, c->stream));
     kmpp_first_kernel<<<B, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, first_id, closest, bsum, centres, ids);
-    for (int j = 1; j < k; ++j) {
-        kmpp_pick_kernel<<<1, 1024, 0, c->stream>>>(closest, n, bsum, B, bprefix,
-                                                    rand_dev + (size_t)(j - 1) * n_trials, n_trials, cand, pot);
-        kmpp_eval_kernel<<<B, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, closest, cand, n_trials, part);
-        kmpp_select_kernel<<<1, 1024, 0, c->stream>>>(xs, n_pad, part, B, n_trials, cand, j, centres, ids);
-        kmpp_update_kernel<<<B, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, centres, j, closest, bsum);
+    if (std::getenv("HGMM_KMPP_UNFUSED")) {
+        for (int j = 1; j < k; ++j) {
+            kmpp_pick_kernel<<<1, 1024, 0, c->stream>>>(closest, n, bsum, B, bprefix,
+                                                        rand_dev + (size_t)(j - 1) * n_trials, n_trials, cand, pot);
+            kmpp_eval_kernel<<<B, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, closest, cand, n_trials, part);
+            kmpp_select_kernel<<<1, 1024, 0, c->stream>>>(xs, n_pad, part, B, n_trials, cand, j, centres, ids);
+            kmpp_update_kernel<<<B, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, centres, j, closest, bsum);
+        }
+    } else if (k > 1) {
+        // two launches per centre: the pass over the points (fold of the previous centre + candidate potentials),
+        // then one workgroup that names the winner and draws the next centre's candidates
+        double* cand_xyz = centres + 7 * (size_t)k;             // [T][3], behind the centre tables
+        kmpp_tail_kernel<<<1, 1024, 0, c->stream>>>(xs, n, n_pad, closest, part, bsum, B, n_trials, 0, 0, 1, rand_dev,
+                                                    cand, cand_xyz, centres, ids, bprefix);
+        for (int j = 1; j < k; ++j) {
+            kmpp_step_kernel<<<B, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, closest, centres, j >= 2 ? j - 1 : -1,
+                                                           cand_xyz, n_trials, part);
+            kmpp_tail_kernel<<<1, 1024, 0, c->stream>>>(xs, n, n_pad, closest, part, bsum, B, n_trials, j, 1,
+                                                        j + 1 < k ? 1 : 0, rand_dev + (size_t)j * n_trials, cand,
+                                                        cand_xyz, centres, ids, bprefix);
+        }
     }
+    (void)pot;
     HGMM_HIP(c, hipGetLastError());
     if (ids_out) HGMM_HIP(c, hipMemcpyAsync(ids_out, ids, sizeof(int64_t) * k, hipMemcpyDeviceToHost, c->stream));
     if (centers_out)
@@ -528,7 +719,7 @@ int km_prepare(hgmm_ctx* c, int k, int reset_labels, KmLaunch& L) {
     L.nb_acc = (int)std::min<int64_t>(2 * (int64_t)c->cus, km_nblk(n, KM_BLOCK));
     HGMM_TRY(ensure(c, c->km_labels, sizeof(int32_t) * n_pad));
     HGMM_TRY(ensure(c, c->km_mind2, sizeof(double) * n_pad));
-    HGMM_TRY(ensure(c, c->km_centres, sizeof(double) * 7 * (size_t)k));
+    HGMM_TRY(ensure(c, c->km_centres, sizeof(double) * (7 * (size_t)k + 3 * KM_MAX_TRIALS)));
     HGMM_TRY(ensure(c, c->km_partial, sizeof(double) * 4 * (size_t)L.k_alloc * L.nb_acc));
     HGMM_TRY(ensure(c, c->km_out, sizeof(double) * (4 * (size_t)k + 8) + sizeof(double) * L.nb_assign + 16));
     if (reset_labels || c->km_labels_n != n) {

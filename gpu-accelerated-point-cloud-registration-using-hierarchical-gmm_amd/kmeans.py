@@ -93,7 +93,10 @@ class KMeans:
         cdf /= cdf[-1]
         first = int(cdf.searchsorted(rs.random_sample(), side='right'))
         rand = rs.uniform(size=(max(k - 1, 0), trials))       # == k-1 successive draws of `trials`
+        import time
+        t0 = time.perf_counter()
         ids, centres = ctx.kmeans_plusplus(k, first, rand)
+        self.seeding_ms_ = (time.perf_counter() - t0) * 1e3     # device k-means++ incl. the transfer of the draws
         return ids, centres
 
     # -- scikit-learn's _relocate_empty_clusters_dense ---------------------------------------
