@@ -17,8 +17,7 @@ SOURCES = ["hgmm_api.hip", "flat_kernels.hip", "tree_kernels.hip", "kmeans_kerne
 HEADERS = ["hgmm_ctx.h", "wave_ops.h", os.path.join("..", "..", "include", "hgmm.h")]
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
-         "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
 def _newer(src, dst):

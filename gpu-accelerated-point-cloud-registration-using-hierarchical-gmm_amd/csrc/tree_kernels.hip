@@ -29,6 +29,7 @@
 #include <type_traits>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace hgmm {
@@ -562,7 +563,6 @@ __global__ void tree_unsort_kernel(const int* __restrict__ perm, const int* __re
 // ------------------------------------------------------------------------------------------
 struct Rigid { double r[9]; double t[3]; double s; };
 
-__device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
 
 // The moment accumulation of this E-step is the one place of the library where contributions from arbitrary
 // workgroups meet in the same memory words (a target point may land in any node; the points are not grouped by
@@ -1936,7 +1936,20 @@ namespace hgmm {
 __global__ __launch_bounds__(CH) void tree_estep_generic_kernel(const double* __restrict__ xs, int64_t n,
                                                                 int64_t n_pad, const double* __restrict__ prep,
                                                                 const int* __restrict__ parent, int64_t T,
-                                                                double* __restrict__ mom, int* __restrict__ cur) {
+                                                                double inv_d, double fix_scale,
+                                                                unsigned long long* __restrict__ momq,
+                                                                int* __restrict__ cur) {
+    // Fixed-point moment sums about each child's mean, as in tree_reg_estep_kernel: deterministic for any parent
+    // assignment.  This entry point feeds an M-step directly (mu = m1 / m0 also for nodes of mass 1e-4), so every
+    // contribution is carried in TWO words: hi = round(v 2^F), lo = round((v 2^F - hi) 2^32) -- resolution
+    // 2^-(F+32) of the extent, far below float64 round-off of the sums themselves.  momq = [T][NMOM][2].
+    // Nodes of the first two levels are summed in LDS and flushed once per workgroup.
+    constexpr int LDS_NODES = 72;
+    constexpr int NW = 2 * NMOM;
+    __shared__ unsigned long long tab[LDS_NODES * NW];
+    const int lds_nodes = (int)(T < LDS_NODES ? T : LDS_NODES);
+    for (int e = threadIdx.x; e < lds_nodes * NW; e += CH) tab[e] = 0ull;
+    __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * CH + threadIdx.x;
     const bool active = i < n;
     double x0 = 0.0, x1 = 0.0, x2 = 0.0;
@@ -1972,31 +1985,51 @@ __global__ __launch_bounds__(CH) void tree_estep_generic_kernel(const double* __
         if (g[k] < TREE_EPS) g[k] = 0.0;
     }
     if (valid) cur[i] = (int)(j0 + am);
-    const double f[NMOM] = {1.0, x0, x1, x2, x0 * x0, x0 * x1, x0 * x2, x1 * x1, x1 * x2, x2 * x2};
-    bool pending = valid;
-    for (int round = 0; round < 8; ++round) {
-        const unsigned long long pm = __ballot(pending);
-        if (pm == 0ull) break;
-        const int leader = __ffsll((long long)pm) - 1;
-        const int64_t pj0 = __shfl(j0, leader);
-        const bool mine = pending && (j0 == pj0);
+    if (valid) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
+            if (g[k] == 0.0) continue;
+            const int64_t node = j0 + k;
+            const double* pr = prep + PREP_N * node;
+            const double u0 = (x0 - pr[6]) * inv_d, u1 = (x1 - pr[7]) * inv_d, u2 = (x2 - pr[8]) * inv_d;
+            const double gq = g[k] * fix_scale;
+            const double v[NMOM] = {gq, gq * u0, gq * u1, gq * u2, gq * u0 * u0, gq * u0 * u1, gq * u0 * u2,
+                                    gq * u1 * u1, gq * u1 * u2, gq * u2 * u2};
+            unsigned long long* dst = (node < lds_nodes) ? tab + NW * node : momq + NW * node;
 #pragma unroll
             for (int m = 0; m < NMOM; ++m) {
-                const double v = wave_sum_f64(mine ? g[k] * f[m] : 0.0);
-                if (lane_id() == leader && v != 0.0) atomic_add_f64(mom + NMOM * (pj0 + k) + m, v);
+                const long long hi = __double2ll_rn(v[m]);
+                const long long lo = __double2ll_rn((v[m] - (double)hi) * 4294967296.0);     // exact remainder x 2^32
+                atomicAdd(dst + 2 * m, (unsigned long long)hi);
+                atomicAdd(dst + 2 * m + 1, (unsigned long long)lo);
             }
         }
-        if (mine) pending = false;
     }
-    if (pending) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (g[k] != 0.0)
-#pragma unroll
-                for (int m = 0; m < NMOM; ++m) atomic_add_f64(mom + NMOM * (j0 + k) + m, g[k] * f[m]);
+    __syncthreads();
+    for (int e = threadIdx.x; e < lds_nodes * NW; e += CH) {
+        const unsigned long long v = tab[e];
+        if (v != 0ull) atomicAdd(momq + e, v);
     }
+}
+
+// two-word fixed point -> float64, still centred (cm[T][NMOM])
+__global__ void tree_unpack2_kernel(const unsigned long long* __restrict__ momq, int64_t T, double d,
+                                    double inv_scale, double* __restrict__ cm) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= T * NMOM) return;
+    const int m = (int)(e % NMOM);
+    const double unit = (m == 0) ? inv_scale : (m < 4 ? d * inv_scale : d * d * inv_scale);
+    const double hi = (double)(long long)momq[2 * e], lo = (double)(long long)momq[2 * e + 1];
+    cm[e] = (hi + lo * (1.0 / 4294967296.0)) * unit;
+}
+
+// largest |x|^2 over the resident cloud (bit pattern of a non-negative double is order-preserving as uint64)
+__global__ void tree_rmax_kernel(const double* __restrict__ xs, int64_t n, int64_t n_pad, unsigned long long* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double r2 = 0.0;
+    if (i < n) r2 = xs[i] * xs[i] + xs[n_pad + i] * xs[n_pad + i] + xs[2 * n_pad + i] * xs[2 * n_pad + i];
+    r2 = wave_max_f64(r2);
+    if (lane_id() == 0 && r2 > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(r2));
 }
 
 __global__ void tree_compact_moments_kernel(const double* __restrict__ m0, const double* __restrict__ m1,
@@ -2041,20 +2074,50 @@ extern "C" int hgmm_tree_estep(hgmm_ctx* c, int64_t T, const double* pi, const d
     int* cur = par + c->n_pad;
     HGMM_HIP(c, hipMemcpyAsync(par, parent_idx, sizeof(int) * c->n, hipMemcpyHostToDevice, c->stream));
     HGMM_HIP(c, hipMemsetAsync(cur, 0, sizeof(int) * c->n, c->stream));
-    double* mom = c->t_mom.as<double>();
-    HGMM_HIP(c, hipMemsetAsync(mom, 0, sizeof(double) * NMOM * T, c->stream));
+    // extent of the fixed-point encoding: max |x| (device reduction) + max |mu| (host), a power of two
+    HGMM_TRY(ensure(c, c->t_momq, sizeof(unsigned long long) * (2 * NMOM * T + 1)));
+    unsigned long long* mq = c->t_momq.as<unsigned long long>();
+    HGMM_HIP(c, hipMemsetAsync(mq, 0, sizeof(unsigned long long) * (2 * NMOM * T + 1), c->stream));
+    c->tree.momq_dirty = true;
+    tree_rmax_kernel<<<nblk(c->n, 256), 256, 0, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad, mq + 2 * NMOM * T);
+    unsigned long long r2bits = 0;
+    HGMM_HIP(c, hipMemcpyAsync(&r2bits, mq + 2 * NMOM * T, sizeof r2bits, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    double r2 = 0.0;
+    memcpy(&r2, &r2bits, sizeof r2);
+    double m2max = 0.0;
+    for (int64_t j = 0; j < T; ++j) {
+        const double v = mu[3 * j] * mu[3 * j] + mu[3 * j + 1] * mu[3 * j + 1] + mu[3 * j + 2] * mu[3 * j + 2];
+        if (v > m2max && std::isfinite(v)) m2max = v;
+    }
+    double ext = std::sqrt(r2) + std::sqrt(m2max);
+    double n_all = (double)c->n;
+    if (c->comm_on()) {
+        HGMM_TRY(hgmm_comm_allreduce_f64(c, &ext, 1, 1));
+        HGMM_TRY(hgmm_comm_allreduce_f64(c, &n_all, 1, 0));
+    }
+    if (!(ext > 0.0) || !std::isfinite(ext)) ext = 1.0;
+    int e2x = 0;
+    (void)std::frexp(ext, &e2x);
+    const double D = std::ldexp(1.0, e2x);
+    int nbits = 1;
+    while (std::ldexp(1.0, nbits) <= n_all) ++nbits;
+    const int F = 62 - nbits;
     {
         ProfScope prof(c, HGMM_K_TREE_ESTEP);
         tree_estep_generic_kernel<<<nblk(c->n, CH), CH, 0, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
-                                                                       c->t_prep.as<double>(), par, T, mom, cur);
+                                                                       c->t_prep.as<double>(), par, T, 1.0 / D,
+                                                                       std::ldexp(1.0, F), mq, cur);
     }
     HGMM_HIP(c, hipGetLastError());
-    if (c->comm_on()) HGMM_TRY(allreduce_f64_dev(c, mom, (size_t)NMOM * T));
+    if (c->comm_on()) HGMM_TRY(allreduce_i64_dev(c, reinterpret_cast<long long*>(mq), (size_t)2 * NMOM * T));
+    double* mom = c->t_mom.as<double>();
+    tree_unpack2_kernel<<<nblk(T * NMOM, 256), 256, 0, c->stream>>>(mq, T, D, std::ldexp(1.0, -F), mom);
     HGMM_TRY(ensure(c, c->scratch, sizeof(double) * 13 * T));
     double* e0 = c->scratch.as<double>();
     double* e1 = e0 + T;
     double* e2 = e1 + 3 * T;
-    tree_expand_moments_kernel<<<nblk(T, 256), 256, 0, c->stream>>>(mom, T, e0, e1, e2);
+    tree_reg_expand_kernel<<<nblk(T, 256), 256, 0, c->stream>>>(mom, c->t_prep.as<double>(), T, e0, e1, e2);
     HGMM_HIP(c, hipGetLastError());
     if (m0_out) HGMM_HIP(c, hipMemcpyAsync(m0_out, e0, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
     if (m1_out) HGMM_HIP(c, hipMemcpyAsync(m1_out, e1, sizeof(double) * 3 * T, hipMemcpyDeviceToHost, c->stream));

@@ -197,6 +197,9 @@ def test_standalone_tree_steps_match_oracle(ctx):
             m0, m1, m2, cur = gmmTreeEStep(P, pi, mu, cov, parent, ctx=ctx)
             o_m0, o_m1, o_m2, o_cur, _ = hgmm_tree.e_step(P, o_pi, o_mu, o_cov, parent)
             np.testing.assert_allclose(m0, o_m0, rtol=1e-10, atol=1e-13)
+            # fixed-point accumulation: bit-identical from call to call (no floating-point atomics anywhere)
+            again = gmmTreeEStep(P, pi, mu, cov, parent, ctx=ctx)
+            assert all(np.array_equal(x, y) for x, y in zip((m0, m1, m2, cur), again))
             np.testing.assert_allclose(m1, o_m1, rtol=1e-10, atol=1e-13)
             np.testing.assert_allclose(m2, o_m2, rtol=1e-10, atol=1e-14)
             assert np.array_equal(cur, o_cur)
