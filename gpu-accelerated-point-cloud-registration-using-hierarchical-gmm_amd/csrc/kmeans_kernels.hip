@@ -261,30 +261,50 @@ __global__ __launch_bounds__(KM_BLOCK) void kmpp_update_kernel(const double* __r
 // Same sums in the same order as the four-kernel form (kmpp_pick / eval / select / update, kept for reference
 // and used by nothing else), hence the same seeds.
 // ------------------------------------------------------------------------------------------
+// One WAVE per 256-point block (4 consecutive points per lane, 4 blocks per workgroup): the block sum of a candidate
+// is one wave reduction of the lanes' 4-point partial sums, so the reductions cost a quarter of what one point per
+// lane costs.  (The first kernel and the four-kernel form sum a block as 4 wave sums of 64 points; both orders are
+// fixed, the seeds of the test fixtures are the same either way.)
 __global__ __launch_bounds__(KM_BLOCK) void kmpp_step_kernel(const double* __restrict__ xs, int64_t n, int64_t n_pad,
                                                              double* __restrict__ closest,
                                                              const double* __restrict__ centres, int fold,
                                                              const double* __restrict__ cand_xyz, int T,
-                                                             double* __restrict__ part) {
-    __shared__ double sh[KM_MAX_TRIALS][4];
-    const int64_t i = (int64_t)blockIdx.x * KM_BLOCK + threadIdx.x;
-    const bool live = i < n;
-    const double x = xs[i], y = xs[n_pad + i], z = xs[2 * n_pad + i];
-    double cl = closest[i];
-    if (fold >= 0) {
-        const double d = dist2(x, y, z, centres[3 * fold], centres[3 * fold + 1], centres[3 * fold + 2]);
-        cl = live ? fmin(cl, d) : 0.0;
-        closest[i] = cl;
+                                                             double* __restrict__ part, int B,
+                                                             double* __restrict__ part4) {
+    __shared__ double sh4[KM_MAX_TRIALS][4];
+    const int lane = lane_id();
+    const int64_t blk = (int64_t)blockIdx.x * 4 + wave_in_block();          // 256-point block of this wave
+    const bool have = blk < B;
+    const int64_t i0 = (have ? blk : 0) * KM_BLOCK + 4 * lane;                 // n_pad is a multiple of 256
+    double x[4], y[4], z[4], cl[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { x[q] = xs[i0 + q]; y[q] = xs[n_pad + i0 + q]; z[q] = xs[2 * n_pad + i0 + q]; cl[q] = closest[i0 + q]; }
+    if (fold >= 0 && have) {
+        const double fx = centres[3 * fold], fy = centres[3 * fold + 1], fz = centres[3 * fold + 2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            cl[q] = (i0 + q < n) ? fmin(cl[q], dist2(x[q], y[q], z[q], fx, fy, fz)) : 0.0;
+            closest[i0 + q] = cl[q];
+        }
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (!have || !(i0 + q < n)) cl[q] = 0.0;      // padding contributes min(0, d) = 0
     for (int t = 0; t < T; ++t) {
-        const double d = dist2(x, y, z, cand_xyz[3 * t], cand_xyz[3 * t + 1], cand_xyz[3 * t + 2]);   // scalar loads
-        const double w = wave_sum_f64(live ? fmin(cl, d) : 0.0);
-        if (lane_id() == 0) sh[t][wave_in_block()] = w;
+        const double cx = cand_xyz[3 * t], cy = cand_xyz[3 * t + 1], cz = cand_xyz[3 * t + 2];     // scalar loads
+        double sacc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sacc += fmin(cl[q], dist2(x[q], y[q], z[q], cx, cy, cz));
+        const double w = wave_sum_f64(sacc);
+        if (lane == 0) {
+            if (have) part[(size_t)t * B + blk] = w;
+            sh4[t][wave_in_block()] = w;
+        }
     }
     __syncthreads();
+    // the workgroup's four block sums, added in block order: what the tail's winner selection reads
     if ((int)threadIdx.x < T)
-        part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
-            (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+        part4[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
+            ((sh4[threadIdx.x][0] + sh4[threadIdx.x][1]) + sh4[threadIdx.x][2]) + sh4[threadIdx.x][3];
 }
 
 // One workgroup of 1024 threads.  `select`: pick the winner among the T candidates of centre j from `part`.
@@ -294,11 +314,17 @@ constexpr int KM_TAIL_LDS_BLOCKS = 7168;                 // block-prefix table k
 __global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restrict__ xs, int64_t n, int64_t n_pad,
                                                          const double* __restrict__ closest,
                                                          const double* __restrict__ part,
+                                                         const double* __restrict__ part4, int B4,
                                                          const double* __restrict__ bsum0, int B, int T, int j,
                                                          int select, int draw, const double* __restrict__ rand_c,
                                                          int64_t* __restrict__ cand, double* __restrict__ cand_xyz,
                                                          double* __restrict__ centres,
-                                                         int64_t* __restrict__ ids, double* __restrict__ bprefix) {
+                                                         int64_t* __restrict__ ids, double* __restrict__ bprefix,
+                                                         long long* __restrict__ dbg = nullptr) {
+    long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int tki = 0;
+#define KM_TICK() do { if (dbg && tki < 8) tk[tki++] = clock64(); } while (0)
+    KM_TICK();
     __shared__ double wsum[KM_MAX_TRIALS][16];
     __shared__ double wave_tot[16];
     __shared__ double seg_end[1024];
@@ -313,10 +339,12 @@ __global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restric
         double acc[KM_MAX_TRIALS];
 #pragma unroll
         for (int t = 0; t < KM_MAX_TRIALS; ++t) acc[t] = 0.0;
-        for (int b = tid; b < B; b += 1024) {
+        // totals from the per-workgroup sums (`part4`: one value per 4 blocks, B4 <= 1024 in the common case: one
+        // round of loads); the partial sums were written by other CUs a moment ago, every dependent trip costs ~2 us
+        for (int b = tid; b < B4; b += 1024) {
 #pragma unroll
             for (int t = 0; t < KM_MAX_TRIALS; ++t)
-                if (t < T) acc[t] += part[(size_t)t * B + b];
+                if (t < T) acc[t] += part4[(size_t)t * B4 + b];
         }
 #pragma unroll
         for (int t = 0; t < KM_MAX_TRIALS; ++t) {
@@ -339,8 +367,10 @@ __global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restric
             }
             if (tid == 0) best_sh = best;
         }
+        KM_TICK();
         __syncthreads();
     }
+    KM_TICK();
     int64_t win = 0;
     double pcx = 0.0, pcy = 0.0, pcz = 0.0;
     if (select) {
@@ -360,6 +390,7 @@ __global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restric
     for (int b = b0; b < b1; ++b) loc += bs[b];
     const double incl = wave_scan_f64(loc);
     if (lane == 63) wave_tot[wave] = incl;
+    KM_TICK();
     __syncthreads();                                        // (also: everybody has read cand[best] before it is overwritten)
     double off = 0.0;
     for (int w = 0; w < wave; ++w) off += wave_tot[w];
@@ -372,6 +403,7 @@ __global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restric
     if (tid == 1023) total_sh = off + incl;
     if (!in_lds) __threadfence();
     __syncthreads();
+    KM_TICK();
     const double pot = total_sh;
     if (wave >= T) return;
     const double v = my_rand * pot;
@@ -418,8 +450,11 @@ __global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restric
             found = nxt < n ? nxt : n - 1;
         }
     }
+    KM_TICK();
     if (lane < 3) cand_xyz[3 * wave + lane] = xs[(size_t)lane * n_pad + found];     // for the next step + tail
     if (lane == 0) cand[wave] = found;
+    KM_TICK();
+    if (dbg && tid == 0) for (int q = 0; q < 8; ++q) dbg[q] = tk[q] - tk[0];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -653,7 +688,8 @@ extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const 
     const int64_t n = c->n, n_pad = c->n_pad;
     const int B = (int)km_nblk(n, KM_BLOCK);
     HGMM_TRY(ensure(c, c->km_closest, sizeof(double) * n_pad));
-    HGMM_TRY(ensure(c, c->km_block, sizeof(double) * ((size_t)2 * B + (size_t)B * KM_MAX_TRIALS + 8)));
+    const int B4 = (B + 3) / 4;
+    HGMM_TRY(ensure(c, c->km_block, sizeof(double) * ((size_t)2 * B + (size_t)(B + B4) * KM_MAX_TRIALS + 8)));
     HGMM_TRY(ensure(c, c->km_centres, sizeof(double) * (7 * (size_t)k + 3 * KM_MAX_TRIALS)));
     HGMM_TRY(ensure(c, c->km_ids, sizeof(int64_t) * ((size_t)k + KM_MAX_TRIALS)));
     HGMM_TRY(ensure(c, c->km_rand, sizeof(double) * (size_t)std::max(1, (k - 1) * n_trials)));
@@ -663,6 +699,7 @@ extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const 
     double* bprefix = bsum + B;
     double* part = bprefix + B;
     double* pot = part + (size_t)B * KM_MAX_TRIALS;
+    double* part4 = pot + 8;
     double* centres = c->km_centres.as<double>();
     int64_t* ids = c->km_ids.as<int64_t>();
     int64_t* cand = ids + k;
@@ -671,6 +708,7 @@ extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const 
         HGMM_HIP(c, hipMemcpyAsync(rand_dev, rand_vals, sizeof(double) * (size_t)(k - 1) * n_trials,
                                    hipMemcpyHostToDevice, c->stream));
     kmpp_first_kernel<<<B, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, first_id, closest, bsum, centres, ids);
+    long long* dbg = nullptr;                               // HGMM_KMPP_DEBUG: phase stamps of one tail launch
     if (std::getenv("HGMM_KMPP_UNFUSED")) {
         for (int j = 1; j < k; ++j) {
             kmpp_pick_kernel<<<1, 1024, 0, c->stream>>>(closest, n, bsum, B, bprefix,
@@ -683,17 +721,27 @@ extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const 
         // two launches per centre: the pass over the points (fold of the previous centre + candidate potentials),
         // then one workgroup that names the winner and draws the next centre's candidates
         double* cand_xyz = centres + 7 * (size_t)k;             // [T][3], behind the centre tables
-        kmpp_tail_kernel<<<1, 1024, 0, c->stream>>>(xs, n, n_pad, closest, part, bsum, B, n_trials, 0, 0, 1, rand_dev,
-                                                    cand, cand_xyz, centres, ids, bprefix);
+        if (std::getenv("HGMM_KMPP_DEBUG")) HGMM_HIP(c, hipMalloc(&dbg, 64));
+        auto tail = [&](int jj, int select, int draw, const double* rnd) {
+            kmpp_tail_kernel<<<1, 1024, 0, c->stream>>>(xs, n, n_pad, closest, part, part4, B4, bsum, B, n_trials, jj, select, draw,
+                                                        rnd, cand, cand_xyz, centres, ids, bprefix, (jj == k / 2) ? dbg : nullptr);
+        };
+        tail(0, 0, 1, rand_dev);
         for (int j = 1; j < k; ++j) {
-            kmpp_step_kernel<<<B, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, closest, centres, j >= 2 ? j - 1 : -1,
-                                                           cand_xyz, n_trials, part);
-            kmpp_tail_kernel<<<1, 1024, 0, c->stream>>>(xs, n, n_pad, closest, part, bsum, B, n_trials, j, 1,
-                                                        j + 1 < k ? 1 : 0, rand_dev + (size_t)j * n_trials, cand,
-                                                        cand_xyz, centres, ids, bprefix);
+            kmpp_step_kernel<<<B4, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, closest, centres, j >= 2 ? j - 1 : -1,
+                                                            cand_xyz, n_trials, part, B, part4);
+            tail(j, 1, j + 1 < k ? 1 : 0, rand_dev + (size_t)j * n_trials);
         }
     }
     (void)pot;
+    if (dbg) {
+        long long h[8];
+        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+        HGMM_HIP(c, hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost));
+        fprintf(stderr, "kmpp tail (centre %d) cycles since entry: select done %lld | barrier %lld | scan issued %lld | prefix ready %lld | "
+                        "found %lld | end %lld\n", k / 2, h[1], h[2], h[3], h[4], h[5], h[6]);
+        (void)hipFree(dbg);
+    }
     HGMM_HIP(c, hipGetLastError());
     if (ids_out) HGMM_HIP(c, hipMemcpyAsync(ids_out, ids, sizeof(int64_t) * k, hipMemcpyDeviceToHost, c->stream));
     if (centers_out)
