@@ -56,6 +56,81 @@ __device__ __forceinline__ double sym3_quad(double s00, double s01, double s02, 
     return fma(d2, s22 * d2, fma(d1, t1, d0 * t0));
 }
 
+// exp(y) for y <= 0, branch-free (the library exp costs ~30 instructions plus exec-mask branches per call):
+// y clamped to >= -708 (results stay normal; what the clamp changes is < 3.3e-308), n = round(y log2 e) by
+// the 1.5 * 2^52 trick, r = y - n ln 2 in two steps, degree-13 Taylor polynomial on |r| <= 0.347 (remainder
+// 4e-18), 2^n added into the exponent field.  Relative error ~1e-16.
+// Four values at a time: the Horner steps 13..3 of the four polynomials are written as ONE block of three-address
+// v_fma_f64, interleaved so that consecutive instructions are independent (hipcc picks the two-address
+// v_fmac_f64 and pays a v_mov_b64 per step to copy the coefficient into the destination; a block per
+// polynomial is a chain of dependent fp64 fmas, 8+ cycles apart, that two waves per SIMD cannot cover).
+__device__ __forceinline__ void exp_nonpos4(const double (&yin)[4], double (&out)[4]) {
+    constexpr double MAGIC = 6755399441055744.0;          // 1.5 * 2^52
+    constexpr double LOG2E = 1.4426950408889634074, LN2_HI = 6.93147180369123816490e-01,
+                     LN2_LO = 1.90821492927058770002e-10;
+    double t[4], r[4], p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double y = fmax(fmin(yin[k], 0.0), -708.0);
+        t[k] = fma(y, LOG2E, MAGIC);
+        const double nf = t[k] - MAGIC;
+        r[k] = fma(nf, -LN2_LO, fma(nf, -LN2_HI, y));
+    }
+#define HGMM_H4(C)                                                                                  \
+    "v_fma_f64 %0, %0, %4, " C "\n\tv_fma_f64 %1, %1, %5, " C "\n\tv_fma_f64 %2, %2, %6, " C          \
+    "\n\tv_fma_f64 %3, %3, %7, " C "\n\t"
+    asm("v_fma_f64 %0, %8, %4, %9\n\tv_fma_f64 %1, %8, %5, %9\n\tv_fma_f64 %2, %8, %6, %9\n\t"
+        "v_fma_f64 %3, %8, %7, %9\n\t"
+        HGMM_H4("%10") HGMM_H4("%11") HGMM_H4("%12") HGMM_H4("%13") HGMM_H4("%14") HGMM_H4("%15") HGMM_H4("%16")
+        HGMM_H4("%17") HGMM_H4("%18")
+        : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3])
+        : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(1.0 / 6227020800.0), "v"(1.0 / 479001600.0),
+          "v"(1.0 / 39916800.0), "v"(1.0 / 3628800.0), "v"(1.0 / 362880.0), "v"(1.0 / 40320.0), "v"(1.0 / 5040.0),
+          "v"(1.0 / 720.0), "v"(1.0 / 120.0), "v"(1.0 / 24.0), "v"(1.0 / 6.0));
+#undef HGMM_H4
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double q = fma(p[k], r[k], 0.5);
+        q = fma(q, r[k], 1.0);
+        q = fma(q, r[k], 1.0);
+        const int n = __double2loint(t[k]);               // low mantissa word of t = n (two's complement)
+        out[k] = __hiloint2double(__double2hiint(q) + (n << 20), __double2loint(q));
+    }
+}
+
+// Two values at a time (same arithmetic; used where a thread has only two independent arguments).
+__device__ __forceinline__ void exp_nonpos2(const double (&yin)[2], double (&out)[2]) {
+    const double y4[4] = {yin[0], yin[1], yin[0], yin[1]};
+    constexpr double MAGIC = 6755399441055744.0;
+    constexpr double LOG2E = 1.4426950408889634074, LN2_HI = 6.93147180369123816490e-01,
+                     LN2_LO = 1.90821492927058770002e-10;
+    double t[2], r[2], p[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const double y = fmax(fmin(y4[k], 0.0), -708.0);
+        t[k] = fma(y, LOG2E, MAGIC);
+        const double nf = t[k] - MAGIC;
+        r[k] = fma(nf, -LN2_LO, fma(nf, -LN2_HI, y));
+    }
+#define HGMM_H2(C) "v_fma_f64 %0, %0, %2, " C "\n\tv_fma_f64 %1, %1, %3, " C "\n\t"
+    asm("v_fma_f64 %0, %4, %2, %5\n\tv_fma_f64 %1, %4, %3, %5\n\t"
+        HGMM_H2("%6") HGMM_H2("%7") HGMM_H2("%8") HGMM_H2("%9") HGMM_H2("%10") HGMM_H2("%11") HGMM_H2("%12")
+        HGMM_H2("%13") HGMM_H2("%14")
+        : "=&v"(p[0]), "=&v"(p[1])
+        : "v"(r[0]), "v"(r[1]), "v"(1.0 / 6227020800.0), "v"(1.0 / 479001600.0), "v"(1.0 / 39916800.0),
+          "v"(1.0 / 3628800.0), "v"(1.0 / 362880.0), "v"(1.0 / 40320.0), "v"(1.0 / 5040.0), "v"(1.0 / 720.0),
+          "v"(1.0 / 120.0), "v"(1.0 / 24.0), "v"(1.0 / 6.0));
+#undef HGMM_H2
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        double q = fma(p[k], r[k], 0.5);
+        q = fma(q, r[k], 1.0);
+        q = fma(q, r[k], 1.0);
+        const int n = __double2loint(t[k]);
+        out[k] = __hiloint2double(__double2hiint(q) + (n << 20), __double2loint(q));
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // per-node preparation
 // ------------------------------------------------------------------------------------------
@@ -196,14 +271,29 @@ __global__ __launch_bounds__(CH) void tree_estep_kernel(
 
     double g[8];
     double den = 0.0;
+    {
+        // the 8 children's exponents, then two interleaved branch-free exponentials of four (a child with
+        // wE = 0 -- pi = 0 or a singular covariance -- has an all-zero inverse: exponent 0, weight 0)
+        double yv[8], ev[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const double* pr = prep + PREP_N * (j0 + k);
-        const double d0 = x0 - pr[6], d1 = x1 - pr[7], d2 = x2 - pr[8];
-        const double q = sym3_quad(pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], d0, d1, d2);
-        const double wE = pr[9];
-        g[k] = (wE == 0.0) ? 0.0 : wE * exp(-0.5 * q);
-        den += g[k];
+        for (int k = 0; k < 8; ++k) {
+            const double* pr = prep + PREP_N * (j0 + k);
+            const double d0 = x0 - pr[6], d1 = x1 - pr[7], d2 = x2 - pr[8];
+            yv[k] = -0.5 * sym3_quad(pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], d0, d1, d2);
+        }
+        const double ya[4] = {yv[0], yv[1], yv[2], yv[3]}, yb[4] = {yv[4], yv[5], yv[6], yv[7]};
+        double ea[4], eb[4];
+        exp_nonpos4(ya, ea);
+        exp_nonpos4(yb, eb);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ev[k] = ea[k]; ev[4 + k] = eb[k]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double wE = prep[PREP_N * (j0 + k) + 9];
+            // below the exponent range the library exp returns exactly 0; keep that (the clamp gives 3e-308)
+            g[k] = (wE == 0.0 || yv[k] < -745.0) ? 0.0 : wE * ev[k];
+            den += g[k];
+        }
     }
     // gamma = g / den if den > eps else 0; arg-max = first maximum  (C:174-187)
     const bool good = den > TREE_EPS;
@@ -372,7 +462,8 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
         for (int t = threadIdx.x; t < cnt * 10; t += CH) {
             const int node = t / 10, fidx = t % 10;
             const double* pr = prep + PREP_N * (lb + base + node);
-            tile[node][fidx] = (fidx < 9) ? pr[fidx] : pr[10];
+            // -1/2 Sigma^-1: the quadratic form is then the (non-positive) exponent itself
+            tile[node][fidx] = (fidx < 6) ? -0.5 * pr[fidx] : ((fidx < 9) ? pr[fidx] : pr[10]);
         }
         __syncthreads();
         for (int node = 0; node < cnt; ++node) {
@@ -383,13 +474,34 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
             const double i00 = tile[node][0], i01 = tile[node][1], i02 = tile[node][2], i11 = tile[node][3],
                          i12 = tile[node][4], i22 = tile[node][5], m0 = tile[node][6], m1 = tile[node][7],
                          m2 = tile[node][8];
+            double yv[PTS];
+            bool need = false;
 #pragma unroll
             for (int p = 0; p < PTS; ++p) {
                 const double d0 = x0[p] - m0, d1 = x1[p] - m1, d2 = x2[p] - m2;
-                const double q = sym3_quad(i00, i01, i02, i11, i12, i22, d0, d1, d2);
-                // exp(-0.5 q) underflows to exactly 0 in float64 beyond q ~ 1490: skip the
-                // transcendental when no lane of the wave needs it (points are sorted spatially)
-                if (__any(q < 1500.0)) tot[p] += wL * exp(-0.5 * q);
+                yv[p] = sym3_quad(i00, i01, i02, i11, i12, i22, d0, d1, d2);      // = -q / 2
+                need = need || (yv[p] > -750.0);
+            }
+            // exp(-q / 2) underflows to exactly 0 in float64 beyond q ~ 1490: skip the exponentials when no lane
+            // of the wave needs one (points are sorted spatially); otherwise all PTS of them go through the
+            // branch-free interleaved exp (an argument below the range comes back as < 3.3e-308: nothing)
+            if (__any(need)) {
+                if constexpr (PTS == 4) {
+                    double e[4];
+                    exp_nonpos4(yv, e);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) tot[p] = fma(wL, e[p], tot[p]);
+                } else if constexpr (PTS == 2) {
+                    double e[2];
+                    exp_nonpos2(yv, e);
+                    tot[0] = fma(wL, e[0], tot[0]);
+                    tot[1] = fma(wL, e[1], tot[1]);
+                } else {
+                    const double y2[2] = {yv[0], yv[0]};
+                    double e[2];
+                    exp_nonpos2(y2, e);
+                    tot[0] = fma(wL, e[0], tot[0]);
+                }
             }
         }
     }
@@ -1384,48 +1496,6 @@ __global__ __launch_bounds__(FULL_BLOCK) void full_moments_kernel(const double* 
 // Deterministic (fixed tile -> workgroup map, fixed accumulation order); one partial per workgroup, summed by
 // full_reduce_kernel.  LDS row stride J16 + 16 == 16 (mod 32) makes the A-fragment reads conflict-free.
 // ------------------------------------------------------------------------------------------
-// exp(y) for y <= 0, branch-free (the library exp costs ~30 instructions plus exec-mask branches per call):
-// y clamped to >= -708 (results stay normal; what the clamp changes is < 3.3e-308), n = round(y log2 e) by
-// the 1.5 * 2^52 trick, r = y - n ln 2 in two steps, degree-13 Taylor polynomial on |r| <= 0.347 (remainder
-// 4e-18), 2^n added into the exponent field.  Relative error ~1e-16.
-// Four values at a time: the Horner steps 13..3 of the four polynomials are written as ONE block of three-address
-// v_fma_f64, interleaved so that consecutive instructions are independent (hipcc picks the two-address
-// v_fmac_f64 and pays a v_mov_b64 per step to copy the coefficient into the destination; a block per
-// polynomial is a chain of dependent fp64 fmas, 8+ cycles apart, that two waves per SIMD cannot cover).
-__device__ __forceinline__ void exp_nonpos4(const double (&yin)[4], double (&out)[4]) {
-    constexpr double MAGIC = 6755399441055744.0;          // 1.5 * 2^52
-    constexpr double LOG2E = 1.4426950408889634074, LN2_HI = 6.93147180369123816490e-01,
-                     LN2_LO = 1.90821492927058770002e-10;
-    double t[4], r[4], p[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const double y = fmax(fmin(yin[k], 0.0), -708.0);
-        t[k] = fma(y, LOG2E, MAGIC);
-        const double nf = t[k] - MAGIC;
-        r[k] = fma(nf, -LN2_LO, fma(nf, -LN2_HI, y));
-    }
-#define HGMM_H4(C)                                                                                  \
-    "v_fma_f64 %0, %0, %4, " C "\n\tv_fma_f64 %1, %1, %5, " C "\n\tv_fma_f64 %2, %2, %6, " C          \
-    "\n\tv_fma_f64 %3, %3, %7, " C "\n\t"
-    asm("v_fma_f64 %0, %8, %4, %9\n\tv_fma_f64 %1, %8, %5, %9\n\tv_fma_f64 %2, %8, %6, %9\n\t"
-        "v_fma_f64 %3, %8, %7, %9\n\t"
-        HGMM_H4("%10") HGMM_H4("%11") HGMM_H4("%12") HGMM_H4("%13") HGMM_H4("%14") HGMM_H4("%15") HGMM_H4("%16")
-        HGMM_H4("%17") HGMM_H4("%18")
-        : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3])
-        : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(1.0 / 6227020800.0), "v"(1.0 / 479001600.0),
-          "v"(1.0 / 39916800.0), "v"(1.0 / 3628800.0), "v"(1.0 / 362880.0), "v"(1.0 / 40320.0), "v"(1.0 / 5040.0),
-          "v"(1.0 / 720.0), "v"(1.0 / 120.0), "v"(1.0 / 24.0), "v"(1.0 / 6.0));
-#undef HGMM_H4
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        double q = fma(p[k], r[k], 0.5);
-        q = fma(q, r[k], 1.0);
-        q = fma(q, r[k], 1.0);
-        const int n = __double2loint(t[k]);               // low mantissa word of t = n (two's complement)
-        out[k] = __hiloint2double(__double2hiint(q) + (n << 20), __double2loint(q));
-    }
-}
-
 constexpr int FT_P = 16;                 // points per tile
 constexpr int FT_WAVES = 8;
 constexpr int FT_BLOCK = FT_WAVES * 64;
