@@ -16,7 +16,6 @@ to the Numba file's (seed 72, sig2 = 0.004, hgmm_gpu.py:469-477) and can be over
 """
 from __future__ import annotations
 
-import abc
 import time
 from collections import namedtuple
 
@@ -124,51 +123,35 @@ def gmmTreeRegESTep(points, mixingCoeff, mean, covar, maxTreeLevel, lc, ctx: Con
     return ctx.tree_reg_estep(n_total_nodes(maxTreeLevel), lambda_c=lc)
 
 
-class Transformation(abc.ABC):
-    def transform(self, points, array_type=None):
-        if array_type is not None and isinstance(points, array_type):
-            return array_type(self._transform(np.asarray(points)))
-        return self._transform(points)
-
-    @abc.abstractmethod
-    def _transform(self, points):
-        return points
-
-
-class RigidTransformation(Transformation):
-    """scale * X R^T + t   (hgmm_gpu.py:599-618)."""
-
-    def __init__(self, rot=np.identity(3), t=np.zeros(3), scale=1.0):
-        self.rot = rot
-        self.t = t
-        self.scale = scale
-
-    def _transform(self, points):
-        return self.scale * np.dot(points, self.rot.T) + self.t
-
-    def inverse(self):
-        return RigidTransformation(self.rot.T, -np.dot(self.rot.T, self.t), 1.0 / self.scale)
+# RigidTransformation (hgmm_gpu.py:599-618: x -> scale R x + t on row vectors, ``inverse()``) is the same
+# object the GMMReg mirror uses
+from ..gmmreg_gpu.transforms import Transformation, RigidTransformation  # noqa: E402,F401
 
 
 def skew(x):
-    return np.array([[0.0, -x[2], x[1]], [x[2], 0.0, -x[0]], [-x[1], x[0], 0.0]])
+    """[x]_x, the cross-product matrix (hgmm_gpu.py:620-624)."""
+    a, b, c = x
+    return np.array([[0.0, -c, b], [c, 0.0, -a], [-b, a, 0.0]])
 
 
 def twist_trans(tw, linear=False):
-    """twist -> (R, t), Rodrigues (hgmm_gpu.py:646-664)."""
+    """6-twist (omega, v) -> (R, t): exp of omega by Rodrigues' formula, or its first-order form I + [omega]_x with
+    ``linear`` (hgmm_gpu.py:646-664).  The translation part is passed through as is."""
+    omega, v = np.asarray(tw[:3], dtype=np.float64), tw[3:]
     if linear:
-        return np.identity(3) + skew(tw[:3]), tw[3:]
-    twd = np.linalg.norm(tw[:3])
-    if twd == 0.0:
-        return np.identity(3), tw[3:]
-    ntw = tw[:3] / twd
-    c, s = np.cos(twd), np.sin(twd)
-    return c * np.identity(3) + (1.0 - c) * np.outer(ntw, ntw) + s * skew(ntw), tw[3:]
+        return np.identity(3) + skew(omega), v
+    angle = np.linalg.norm(omega)
+    if angle == 0.0:
+        return np.identity(3), v
+    axis = omega / angle
+    k = skew(axis)
+    return np.identity(3) + np.sin(angle) * k + (1.0 - np.cos(angle)) * (k @ k), v
 
 
 def twist_mul(tw, rot, t, linear=False):
-    tr, tt = twist_trans(tw, linear=linear)
-    return np.dot(tr, rot), np.dot(t, tr.T) + tt
+    """Compose the twist's motion with (rot, t): (dR rot, dR t + dt)   (hgmm_gpu.py:634-644)."""
+    d_rot, d_t = twist_trans(tw, linear=linear)
+    return d_rot @ rot, d_rot @ t + d_t
 
 
 _tp_controller = None
