@@ -46,14 +46,24 @@ __device__ __forceinline__ double dist2(double x, double y, double z, double cx,
 
 // (readlane_f64: wave_ops.h)
 
-// inclusive prefix sum over the 64 lanes
+// inclusive prefix sum over the 64 lanes: Hillis-Steele inside each DPP row of 16 (row_shr 1, 2, 4, 8 with zero
+// fill), then the row totals carried across with row_bcast 15 / 31 -- no LDS round trips (ds_bpermute costs a
+// dependent ~130 cycles per step, and the seeding tail is nothing but a latency chain)
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double dpp_f64_zero(double v) {
+    const long long b = __double_as_longlong(v);
+    int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ double wave_scan_f64(double v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const double u = __shfl_up(v, d);
-        if (lane >= d) v += u;
-    }
+    v += dpp_f64_zero<0x111>(v);                  // row_shr:1
+    v += dpp_f64_zero<0x112>(v);                  // row_shr:2
+    v += dpp_f64_zero<0x114>(v);                  // row_shr:4
+    v += dpp_f64_zero<0x118>(v);                  // row_shr:8
+    v += dpp_f64_zero<DPP_ROW_BCAST15, 0xA>(v);   // rows 1, 3 += total of rows 0, 2
+    v += dpp_f64_zero<DPP_ROW_BCAST31, 0xC>(v);   // rows 2, 3 += total of rows 0 + 1
     return v;
 }
 
@@ -255,25 +265,42 @@ __global__ __launch_bounds__(KM_BLOCK) void kmpp_update_kernel(const double* __r
 // accepted.  So the winner's row of `part` replaces the separate update pass as far as the next draw's prefix
 // search is concerned; the element-wise minimum itself is folded into the NEXT step's pass (`fold` = the centre
 // accepted last), and inside the one block the search lands in it is formed on the fly.  Per centre:
-//   kmpp_step_kernel   closest <- min(closest, d(., centre fold)); part[t][b] for the T candidates     (grid B)
-//   kmpp_tail_kernel   winner = first arg-min_t sum_b part[t][b]  ->  centre j;  prefix scan of its row; the T
-//                      candidates of centre j + 1 by np.searchsorted(cumsum, rand * pot)        (one workgroup)
-// Same sums in the same order as the four-kernel form (kmpp_pick / eval / select / update, kept for reference
-// and used by nothing else), hence the same seeds.
+//   kmpp_step_kernel   closest <- min(closest, d(., centre fold)); part[t][b] for the T candidates, and their sums
+//                      over the workgroup's 16 blocks, part16[t][g]                              (grid G = B / 16)
+//   kmpp_tail_kernel   winner = first arg-min_t sum_g part16[t][g]  ->  centre j;  prefix scan of its part16 row;
+//                      the T candidates of centre j + 1 by np.searchsorted(cumsum, rand * pot): group, then block
+//                      inside the group (16 sums of `part`), then point inside the block         (one workgroup)
+// The tail is ONE workgroup on ONE CU reading what 245 other CUs wrote a moment ago: every cache line it touches
+// is a trip through the fabric, and a CU keeps only so many of them in flight.  The two-level layout keeps the
+// lines on its critical path to ~120 (all part16 rows) + 2 per draw + the 64 lines of the block a draw lands in;
+// a flat per-block table (3907 sums per row at N = 1M) cost twice the time.
+// Fixed summation orders throughout, hence the same seeds run to run; the four-kernel form (kmpp_pick / eval /
+// select / update) is kept as the readable statement of the same algorithm and is used by nothing else.
 // ------------------------------------------------------------------------------------------
-// One WAVE per 256-point block (4 consecutive points per lane, 4 blocks per workgroup): the block sum of a candidate
-// is one wave reduction of the lanes' 4-point partial sums, so the reductions cost a quarter of what one point per
-// lane costs.  (The first kernel and the four-kernel form sum a block as 4 wave sums of 64 points; both orders are
-// fixed, the seeds of the test fixtures are the same either way.)
-__global__ __launch_bounds__(KM_BLOCK) void kmpp_step_kernel(const double* __restrict__ xs, int64_t n, int64_t n_pad,
-                                                             double* __restrict__ closest,
-                                                             const double* __restrict__ centres, int fold,
-                                                             const double* __restrict__ cand_xyz, int T,
-                                                             double* __restrict__ part, int B,
-                                                             double* __restrict__ part4) {
-    __shared__ double sh4[KM_MAX_TRIALS][4];
+constexpr int KM_GROUP = 16;                             // 256-point blocks per step workgroup (one per wave)
+constexpr int KM_STEP_BLOCK = 64 * KM_GROUP;
+
+// group sums of the first kernel's block sums, in the order the step kernel uses (sequential over the 16 blocks)
+__global__ void kmpp_group_kernel(const double* __restrict__ bsum, int B, int G, double* __restrict__ g16) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    double s = 0.0;
+    for (int q = 0; q < KM_GROUP; ++q) s += (g * KM_GROUP + q < B) ? bsum[g * KM_GROUP + q] : 0.0;
+    g16[g] = s;
+}
+
+// One WAVE per 256-point block (4 consecutive points per lane): the block sum of a candidate is one wave reduction
+// of the lanes' 4-point partial sums.
+template <int TMAX>                       // unrolled candidate slots (8 covers k <= 1096 under scikit-learn's 2 + log k)
+__global__ __launch_bounds__(KM_STEP_BLOCK) void kmpp_step_kernel(const double* __restrict__ xs, int64_t n, int64_t n_pad,
+                                                                  double* __restrict__ closest,
+                                                                  const double* __restrict__ centres, int fold,
+                                                                  const double* __restrict__ cand_xyz, int T,
+                                                                  double* __restrict__ part, int B,
+                                                                  double* __restrict__ part16) {
+    __shared__ double shg[KM_MAX_TRIALS][KM_GROUP];
     const int lane = lane_id();
-    const int64_t blk = (int64_t)blockIdx.x * 4 + wave_in_block();          // 256-point block of this wave
+    const int64_t blk = (int64_t)blockIdx.x * KM_GROUP + wave_in_block();     // 256-point block of this wave
     const bool have = blk < B;
     const int64_t i0 = (have ? blk : 0) * KM_BLOCK + 4 * lane;                 // n_pad is a multiple of 256
     double x[4], y[4], z[4], cl[4];
@@ -283,71 +310,77 @@ __global__ __launch_bounds__(KM_BLOCK) void kmpp_step_kernel(const double* __res
         const double fx = centres[3 * fold], fy = centres[3 * fold + 1], fz = centres[3 * fold + 2];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            cl[q] = (i0 + q < n) ? fmin(cl[q], dist2(x[q], y[q], z[q], fx, fy, fz)) : 0.0;
-            closest[i0 + q] = cl[q];
+            const double d = dist2(x[q], y[q], z[q], fx, fy, fz);
+            if (i0 + q < n && d < cl[q]) { cl[q] = d; closest[i0 + q] = d; }   // few points move once j is large
         }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) if (!have || !(i0 + q < n)) cl[q] = 0.0;      // padding contributes min(0, d) = 0
-    for (int t = 0; t < T; ++t) {
-        const double cx = cand_xyz[3 * t], cy = cand_xyz[3 * t + 1], cz = cand_xyz[3 * t + 2];     // scalar loads
-        double sacc = 0.0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sacc += fmin(cl[q], dist2(x[q], y[q], z[q], cx, cy, cz));
-        const double w = wave_sum_f64(sacc);
-        if (lane == 0) {
-            if (have) part[(size_t)t * B + blk] = w;
-            sh4[t][wave_in_block()] = w;
+    for (int t = 0; t < TMAX; ++t) {
+        if (t < T) {
+            const double cx = cand_xyz[3 * t], cy = cand_xyz[3 * t + 1], cz = cand_xyz[3 * t + 2];
+            double sacc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sacc += fmin(cl[q], dist2(x[q], y[q], z[q], cx, cy, cz));
+            const double w = wave_sum_f64(sacc);
+            if (lane == 0) {
+                if (have) part[(size_t)t * B + blk] = w;
+                shg[t][wave_in_block()] = have ? w : 0.0;
+            }
         }
     }
     __syncthreads();
-    // the workgroup's four block sums, added in block order: what the tail's winner selection reads
-    if ((int)threadIdx.x < T)
-        part4[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
-            ((sh4[threadIdx.x][0] + sh4[threadIdx.x][1]) + sh4[threadIdx.x][2]) + sh4[threadIdx.x][3];
+    // the workgroup's 16 block sums, added in block order: what the tail's winner selection and group search read
+    if ((int)threadIdx.x < T) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < KM_GROUP; ++q) s += shg[threadIdx.x][q];
+        part16[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s;
+    }
 }
 
-// One workgroup of 1024 threads.  `select`: pick the winner among the T candidates of centre j from `part`.
-// `draw`: draw the T candidates of the next centre from the block sums `bs` (= the winner's row of `part`, or the
-// first kernel's `bsum`); `closest` lacks the fold of centre `pend` (-1: it is current), applied on the fly.
-constexpr int KM_TAIL_LDS_BLOCKS = 7168;                 // block-prefix table kept in LDS up to this many 256-point blocks
+// One workgroup of 1024 threads.  `select`: pick the winner among the T candidates of centre j from `part16`.
+// `draw`: draw the T candidates of the next centre from the winner's rows of `part16` / `part` (or, for the first
+// centre, the first kernel's sums `g0` / `bsum0`); `closest` lacks the fold of centre `pend` (-1: it is current),
+// applied on the fly inside the blocks the draws land in.
+constexpr int KM_TAIL_LDS_GROUPS = 4096;                 // group-prefix table kept in LDS up to this many groups
+template <int TMAX>
 __global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restrict__ xs, int64_t n, int64_t n_pad,
                                                          const double* __restrict__ closest,
                                                          const double* __restrict__ part,
-                                                         const double* __restrict__ part4, int B4,
-                                                         const double* __restrict__ bsum0, int B, int T, int j,
+                                                         const double* __restrict__ part16, int G,
+                                                         const double* __restrict__ bsum0,
+                                                         const double* __restrict__ g0, int B, int T, int j,
                                                          int select, int draw, const double* __restrict__ rand_c,
                                                          int64_t* __restrict__ cand, double* __restrict__ cand_xyz,
                                                          double* __restrict__ centres,
-                                                         int64_t* __restrict__ ids, double* __restrict__ bprefix,
-                                                         long long* __restrict__ dbg = nullptr) {
-    long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int tki = 0;
-#define KM_TICK() do { if (dbg && tki < 8) tk[tki++] = clock64(); } while (0)
-    KM_TICK();
+                                                         int64_t* __restrict__ ids, double* __restrict__ gprefix) {
     __shared__ double wsum[KM_MAX_TRIALS][16];
     __shared__ double wave_tot[16];
     __shared__ double seg_end[1024];
-    __shared__ double pre_sh[KM_TAIL_LDS_BLOCKS];       // inclusive prefix of the block sums (global `bprefix` beyond)
+    __shared__ double pre_sh[KM_TAIL_LDS_GROUPS];       // inclusive prefix of the group sums (global `gprefix` beyond)
     __shared__ double total_sh;
     __shared__ int best_sh;
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
-    const bool in_lds = B <= KM_TAIL_LDS_BLOCKS;
-    // the uniforms and (when there is no selection) nothing else can be fetched before the sums arrive
+    const bool in_lds = G <= KM_TAIL_LDS_GROUPS;
     const double my_rand = (draw && wave < T) ? rand_c[wave] : 0.0;
+    const int seg = (G + 1023) / 1024;                      // groups per thread in the prefix scan (1 up to N = 4M)
+    const int g_lo = tid * seg, g_hi = min(G, g_lo + seg);
+    double loc = 0.0;                                       // the thread's run of the winner's group sums
     if (select) {
-        double acc[KM_MAX_TRIALS];
+        double acc[TMAX];
 #pragma unroll
-        for (int t = 0; t < KM_MAX_TRIALS; ++t) acc[t] = 0.0;
-        // totals from the per-workgroup sums (`part4`: one value per 4 blocks, B4 <= 1024 in the common case: one
-        // round of loads); the partial sums were written by other CUs a moment ago, every dependent trip costs ~2 us
-        for (int b = tid; b < B4; b += 1024) {
+        for (int t = 0; t < TMAX; ++t) acc[t] = 0.0;
+        // thread tid owns groups [g_lo, g_hi) of every row: the totals AND (for the winner) its piece of the prefix
+        // scan come from this one round of loads
+        for (int g = g_lo; g < g_hi; ++g) {
 #pragma unroll
-            for (int t = 0; t < KM_MAX_TRIALS; ++t)
-                if (t < T) acc[t] += part4[(size_t)t * B4 + b];
+            for (int t = 0; t < TMAX; ++t)
+                if (t < T) acc[t] += part16[(size_t)t * G + g];
         }
 #pragma unroll
-        for (int t = 0; t < KM_MAX_TRIALS; ++t) {
+        for (int t = 0; t < TMAX; ++t) {
             if (t < T) {
                 const double w = wave_sum_f64(acc[t]);
                 if (lane == 0) wsum[t][wave] = w;
@@ -360,101 +393,120 @@ __global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restric
             if (tid < T)
                 for (int w = 0; w < 16; ++w) p += wsum[tid][w];
             int best = 0;
-            double best_pot = __shfl(p, 0);
-            for (int t = 1; t < T; ++t) {
-                const double pt = __shfl(p, t);
-                if (pt < best_pot) { best = t; best_pot = pt; }
+            double best_pot = readlane_f64(p, 0);
+#pragma unroll
+            for (int t = 1; t < TMAX; ++t) {
+                const double pt = readlane_f64(p, t);
+                if (t < T && pt < best_pot) { best = t; best_pot = pt; }
             }
             if (tid == 0) best_sh = best;
         }
-        KM_TICK();
         __syncthreads();
+        const int best = best_sh;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) if (t == best) loc = acc[t];
+    } else if (draw) {
+        for (int g = g_lo; g < g_hi; ++g) loc += g0[g];
     }
-    KM_TICK();
     int64_t win = 0;
     double pcx = 0.0, pcy = 0.0, pcz = 0.0;
+    const int best = select ? best_sh : 0;
     if (select) {
-        win = cand[best_sh];
-        pcx = cand_xyz[3 * best_sh]; pcy = cand_xyz[3 * best_sh + 1]; pcz = cand_xyz[3 * best_sh + 2];
+        win = cand[best];
+        pcx = cand_xyz[3 * best]; pcy = cand_xyz[3 * best + 1]; pcz = cand_xyz[3 * best + 2];
         if (tid == 0) {
             ids[j] = win;
             centres[3 * j + 0] = pcx; centres[3 * j + 1] = pcy; centres[3 * j + 2] = pcz;
         }
     }
     if (!draw) return;
-    const double* bs = select ? part + (size_t)best_sh * B : bsum0;
+    const double* gs = select ? part16 + (size_t)best * G : g0;      // group sums of the winner
+    const double* bs = select ? part + (size_t)best * B : bsum0;     // its block sums
     const int pend = select ? j : -1;                       // centre whose fold `closest` is still missing
-    const int seg = (B + 1023) / 1024;
-    const int b0 = tid * seg, b1 = min(B, b0 + seg);
-    double loc = 0.0;
-    for (int b = b0; b < b1; ++b) loc += bs[b];
     const double incl = wave_scan_f64(loc);
     if (lane == 63) wave_tot[wave] = incl;
-    KM_TICK();
     __syncthreads();                                        // (also: everybody has read cand[best] before it is overwritten)
     double off = 0.0;
     for (int w = 0; w < wave; ++w) off += wave_tot[w];
-    double run = off + (incl - loc);
-    for (int b = b0; b < b1; ++b) {
-        run += bs[b];
-        if (in_lds) pre_sh[b] = run; else bprefix[b] = run;
+    if (seg == 1) {
+        if (g_lo < g_hi) pre_sh[g_lo] = off + incl;
+    } else {
+        double run = off + (incl - loc);
+        for (int g = g_lo; g < g_hi; ++g) {
+            run += gs[g];                                   // a re-read of lines this CU fetched a moment ago
+            if (in_lds) pre_sh[g] = run; else gprefix[g] = run;
+        }
     }
     seg_end[tid] = off + incl;
     if (tid == 1023) total_sh = off + incl;
     if (!in_lds) __threadfence();
     __syncthreads();
-    KM_TICK();
     const double pot = total_sh;
     if (wave >= T) return;
     const double v = my_rand * pot;
-    const volatile double* bp = bprefix;                 // written by other waves of this workgroup
-    auto pre = [&](int b) -> double { return in_lds ? pre_sh[b] : bp[b]; };
-    int lo = 0, hi = 1024;                               // first segment whose end >= v (LDS) ...
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (seg_end[mid] >= v) hi = mid; else lo = mid + 1;
-    }
-    hi = min(B, (lo + 1) * seg);                         // ... then the first block inside it
-    lo = min(B, lo * seg);
+    const volatile double* gp = gprefix;                 // written by other waves of this workgroup
+    auto pre = [&](int g) -> double { return in_lds ? pre_sh[g] : gp[g]; };
+    // first thread segment whose end >= v = number of segment ends below v (the ends never decrease): the wave
+    // counts them 64 at a time instead of walking a dependent binary search through LDS
+    int lo = 0;
+    const int nseg = min(1024, (G + seg - 1) / seg);     // segments that hold groups; the rest repeat the total
+    for (int sbase = 0; sbase < nseg; sbase += 64)
+        lo += __popcll(__ballot(sbase + lane < nseg && seg_end[sbase + lane] < v));
+    int hi = min(G, (lo + 1) * seg);                     // ... then the first group inside it
+    lo = min(G, lo * seg);
     while (lo < hi && !(pre(lo) >= v)) ++lo;
-    if (lo == hi && hi < B) lo = hi;                     // rounding at the segment's end
+    if (lo == hi && hi < G) lo = hi;                     // rounding at the segment's end
     int64_t found = n - 1;                               // np.clip(..., n - 1)
-    if (lo < B) {
-        const double base = lo > 0 ? pre(lo - 1) : 0.0;
-        const int64_t e0 = (int64_t)lo * KM_BLOCK + 4 * lane;
-        double c[4];
-        double s = 0.0;
+    if (lo < G) {
+        // the block inside group `lo`: running sum of its 16 block sums in the order the step kernel added them
+        const double gbase = lo > 0 ? pre(lo - 1) : 0.0;
+        const int bfirst = lo * KM_GROUP;
+        const double mine = (lane < KM_GROUP && bfirst + lane < B) ? bs[bfirst + lane] : 0.0;
+        double run = 0.0, before = 0.0;
+        int blk = -1;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            double val = 0.0;
-            if (e0 + q < n) {
-                val = closest[e0 + q];
-                if (pend >= 0) val = fmin(val, dist2(xs[e0 + q], xs[n_pad + e0 + q], xs[2 * n_pad + e0 + q], pcx, pcy, pcz));
-            }
-            s += val;
-            c[q] = s;
+        for (int q = 0; q < KM_GROUP; ++q) {
+            before = run;
+            run += readlane_f64(mine, q);
+            if (blk < 0 && bfirst + q < B && gbase + run >= v) { blk = bfirst + q; break; }
         }
-        const double ex = base + (wave_scan_f64(s) - s);
-        int first_q = 4;
-#pragma unroll
-        for (int q = 3; q >= 0; --q)
-            if (e0 + q < n && ex + c[q] >= v) first_q = q;
-        const unsigned long long hit = __ballot(first_q < 4);
-        if (hit) {
-            const int l = __ffsll((long long)hit) - 1;
-            const int q = __builtin_amdgcn_readlane(first_q, l);
-            found = (int64_t)lo * KM_BLOCK + 4 * l + q;
-        } else {
-            // rounding at the block's end: the threshold falls on the first element after it
-            const int64_t nxt = (int64_t)(lo + 1) * KM_BLOCK;
+        if (blk < 0) {                                   // rounding at the group's end: first element after it
+            const int64_t nxt = (int64_t)min(B, bfirst + KM_GROUP) * KM_BLOCK;
             found = nxt < n ? nxt : n - 1;
+        } else {
+            const double base = gbase + before;
+            const int64_t e0 = (int64_t)blk * KM_BLOCK + 4 * lane;
+            double c[4];
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double val = 0.0;
+                if (e0 + q < n) {
+                    val = closest[e0 + q];
+                    if (pend >= 0) val = fmin(val, dist2(xs[e0 + q], xs[n_pad + e0 + q], xs[2 * n_pad + e0 + q], pcx, pcy, pcz));
+                }
+                s += val;
+                c[q] = s;
+            }
+            const double ex = base + (wave_scan_f64(s) - s);
+            int first_q = 4;
+#pragma unroll
+            for (int q = 3; q >= 0; --q)
+                if (e0 + q < n && ex + c[q] >= v) first_q = q;
+            const unsigned long long hit = __ballot(first_q < 4);
+            if (hit) {
+                const int l = __ffsll((long long)hit) - 1;
+                const int q = __builtin_amdgcn_readlane(first_q, l);
+                found = (int64_t)blk * KM_BLOCK + 4 * l + q;
+            } else {
+                // rounding at the block's end: the threshold falls on the first element after it
+                const int64_t nxt = (int64_t)(blk + 1) * KM_BLOCK;
+                found = nxt < n ? nxt : n - 1;
+            }
         }
     }
-    KM_TICK();
     if (lane < 3) cand_xyz[3 * wave + lane] = xs[(size_t)lane * n_pad + found];     // for the next step + tail
     if (lane == 0) cand[wave] = found;
-    KM_TICK();
-    if (dbg && tid == 0) for (int q = 0; q < 8; ++q) dbg[q] = tk[q] - tk[0];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -688,8 +740,8 @@ extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const 
     const int64_t n = c->n, n_pad = c->n_pad;
     const int B = (int)km_nblk(n, KM_BLOCK);
     HGMM_TRY(ensure(c, c->km_closest, sizeof(double) * n_pad));
-    const int B4 = (B + 3) / 4;
-    HGMM_TRY(ensure(c, c->km_block, sizeof(double) * ((size_t)2 * B + (size_t)(B + B4) * KM_MAX_TRIALS + 8)));
+    const int G = (B + KM_GROUP - 1) / KM_GROUP;
+    HGMM_TRY(ensure(c, c->km_block, sizeof(double) * ((size_t)2 * B + (size_t)(B + G) * KM_MAX_TRIALS + 2 * (size_t)G + 8)));
     HGMM_TRY(ensure(c, c->km_centres, sizeof(double) * (7 * (size_t)k + 3 * KM_MAX_TRIALS)));
     HGMM_TRY(ensure(c, c->km_ids, sizeof(int64_t) * ((size_t)k + KM_MAX_TRIALS)));
     HGMM_TRY(ensure(c, c->km_rand, sizeof(double) * (size_t)std::max(1, (k - 1) * n_trials)));
@@ -699,7 +751,9 @@ extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const 
     double* bprefix = bsum + B;
     double* part = bprefix + B;
     double* pot = part + (size_t)B * KM_MAX_TRIALS;
-    double* part4 = pot + 8;
+    double* part16 = pot + 8;
+    double* g0 = part16 + (size_t)G * KM_MAX_TRIALS;
+    double* gprefix = g0 + G;
     double* centres = c->km_centres.as<double>();
     int64_t* ids = c->km_ids.as<int64_t>();
     int64_t* cand = ids + k;
@@ -708,7 +762,6 @@ extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const 
         HGMM_HIP(c, hipMemcpyAsync(rand_dev, rand_vals, sizeof(double) * (size_t)(k - 1) * n_trials,
                                    hipMemcpyHostToDevice, c->stream));
     kmpp_first_kernel<<<B, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, first_id, closest, bsum, centres, ids);
-    long long* dbg = nullptr;                               // HGMM_KMPP_DEBUG: phase stamps of one tail launch
     if (std::getenv("HGMM_KMPP_UNFUSED")) {
         for (int j = 1; j < k; ++j) {
             kmpp_pick_kernel<<<1, 1024, 0, c->stream>>>(closest, n, bsum, B, bprefix,
@@ -721,27 +774,30 @@ extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const 
         // two launches per centre: the pass over the points (fold of the previous centre + candidate potentials),
         // then one workgroup that names the winner and draws the next centre's candidates
         double* cand_xyz = centres + 7 * (size_t)k;             // [T][3], behind the centre tables
-        if (std::getenv("HGMM_KMPP_DEBUG")) HGMM_HIP(c, hipMalloc(&dbg, 64));
+        const bool t8 = n_trials <= 8;
         auto tail = [&](int jj, int select, int draw, const double* rnd) {
-            kmpp_tail_kernel<<<1, 1024, 0, c->stream>>>(xs, n, n_pad, closest, part, part4, B4, bsum, B, n_trials, jj, select, draw,
-                                                        rnd, cand, cand_xyz, centres, ids, bprefix, (jj == k / 2) ? dbg : nullptr);
+            if (t8)
+                kmpp_tail_kernel<8><<<1, 1024, 0, c->stream>>>(xs, n, n_pad, closest, part, part16, G, bsum, g0, B, n_trials, jj,
+                                                               select, draw, rnd, cand, cand_xyz, centres, ids, gprefix);
+            else
+                kmpp_tail_kernel<KM_MAX_TRIALS><<<1, 1024, 0, c->stream>>>(xs, n, n_pad, closest, part, part16, G, bsum, g0, B,
+                                                                           n_trials, jj, select, draw, rnd, cand, cand_xyz,
+                                                                           centres, ids, gprefix);
         };
+        kmpp_group_kernel<<<km_nblk(G, 256), 256, 0, c->stream>>>(bsum, B, G, g0);
         tail(0, 0, 1, rand_dev);
         for (int j = 1; j < k; ++j) {
-            kmpp_step_kernel<<<B4, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, closest, centres, j >= 2 ? j - 1 : -1,
-                                                            cand_xyz, n_trials, part, B, part4);
+            const int fold = j >= 2 ? j - 1 : -1;
+            if (t8)
+                kmpp_step_kernel<8><<<G, KM_STEP_BLOCK, 0, c->stream>>>(xs, n, n_pad, closest, centres, fold, cand_xyz, n_trials,
+                                                                        part, B, part16);
+            else
+                kmpp_step_kernel<KM_MAX_TRIALS><<<G, KM_STEP_BLOCK, 0, c->stream>>>(xs, n, n_pad, closest, centres, fold, cand_xyz,
+                                                                                    n_trials, part, B, part16);
             tail(j, 1, j + 1 < k ? 1 : 0, rand_dev + (size_t)j * n_trials);
         }
     }
     (void)pot;
-    if (dbg) {
-        long long h[8];
-        HGMM_HIP(c, hipStreamSynchronize(c->stream));
-        HGMM_HIP(c, hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost));
-        fprintf(stderr, "kmpp tail (centre %d) cycles since entry: select done %lld | barrier %lld | scan issued %lld | prefix ready %lld | "
-                        "found %lld | end %lld\n", k / 2, h[1], h[2], h[3], h[4], h[5], h[6]);
-        (void)hipFree(dbg);
-    }
     HGMM_HIP(c, hipGetLastError());
     if (ids_out) HGMM_HIP(c, hipMemcpyAsync(ids_out, ids, sizeof(int64_t) * k, hipMemcpyDeviceToHost, c->stream));
     if (centers_out)
