@@ -303,6 +303,16 @@ __global__ __launch_bounds__(KM_STEP_BLOCK) void kmpp_step_kernel(const double* 
     const int64_t blk = (int64_t)blockIdx.x * KM_GROUP + wave_in_block();     // 256-point block of this wave
     const bool have = blk < B;
     const int64_t i0 = (have ? blk : 0) * KM_BLOCK + 4 * lane;                 // n_pad is a multiple of 256
+    // every candidate's coordinates through ONE batch of scalar loads (index clamped, not branched on, so that the
+    // loads can leave the per-candidate blocks): the tail's CU wrote them a moment ago and each cache line of them
+    // is a trip through the fabric -- a load per loop iteration would chain those trips
+    // (issued before the points' loads so that the two kinds of trip overlap)
+    double cc[TMAX][3];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        const int tt = t < T ? t : T - 1;
+        cc[t][0] = cand_xyz[3 * tt]; cc[t][1] = cand_xyz[3 * tt + 1]; cc[t][2] = cand_xyz[3 * tt + 2];
+    }
     double x[4], y[4], z[4], cl[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { x[q] = xs[i0 + q]; y[q] = xs[n_pad + i0 + q]; z[q] = xs[2 * n_pad + i0 + q]; cl[q] = closest[i0 + q]; }
@@ -319,7 +329,7 @@ __global__ __launch_bounds__(KM_STEP_BLOCK) void kmpp_step_kernel(const double* 
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) {
         if (t < T) {
-            const double cx = cand_xyz[3 * t], cy = cand_xyz[3 * t + 1], cz = cand_xyz[3 * t + 2];
+            const double cx = cc[t][0], cy = cc[t][1], cz = cc[t][2];
             double sacc = 0.0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) sacc += fmin(cl[q], dist2(x[q], y[q], z[q], cx, cy, cz));
@@ -364,7 +374,6 @@ __global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restric
     __shared__ int best_sh;
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
     const bool in_lds = G <= KM_TAIL_LDS_GROUPS;
-    const double my_rand = (draw && wave < T) ? rand_c[wave] : 0.0;
     const int seg = (G + 1023) / 1024;                      // groups per thread in the prefix scan (1 up to N = 4M)
     const int g_lo = tid * seg, g_hi = min(G, g_lo + seg);
     double loc = 0.0;                                       // the thread's run of the winner's group sums
@@ -374,10 +383,13 @@ __global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restric
         for (int t = 0; t < TMAX; ++t) acc[t] = 0.0;
         // thread tid owns groups [g_lo, g_hi) of every row: the totals AND (for the winner) its piece of the prefix
         // scan come from this one round of loads
+        // (row index clamped instead of branched on: the loads of one group are issued together, not one trip each)
         for (int g = g_lo; g < g_hi; ++g) {
+            double v[TMAX];
 #pragma unroll
-            for (int t = 0; t < TMAX; ++t)
-                if (t < T) acc[t] += part16[(size_t)t * G + g];
+            for (int t = 0; t < TMAX; ++t) v[t] = part16[(size_t)(t < T ? t : T - 1) * G + g];
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t) acc[t] += (t < T) ? v[t] : 0.0;
         }
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) {
@@ -443,7 +455,7 @@ __global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restric
     __syncthreads();
     const double pot = total_sh;
     if (wave >= T) return;
-    const double v = my_rand * pot;
+    const double v = rand_c[wave] * pot;
     const volatile double* gp = gprefix;                 // written by other waves of this workgroup
     auto pre = [&](int g) -> double { return in_lds ? pre_sh[g] : gp[g]; };
     // first thread segment whose end >= v = number of segment ends below v (the ends never decrease): the wave
