@@ -46,24 +46,19 @@ constexpr int BLOCK = WAVES_PER_BLOCK * 64;
 //   c2_j = log2(e) * ( -0.5 * 3 * log(2 pi) + sum_d log(inv_std_jd + eps) + log(w_j [+ eps]) )
 // (estimate_log_prob / estimate_log_prob_spherical / e_step, gmm_waymo gmm_impl.py:53-116)
 // ------------------------------------------------------------------------------------------
-__device__ inline void pack_component(int j, int J, int Jpad, int cov_type, int variant,
-                                      const float* mu, const float* inv, const float* w,
-                                      float* pack) {
+// (m, i: the component's mean and inverse standard deviations, spherical already expanded to three axes)
+__device__ inline void pack_values(int j, bool valid, int Jpad, int variant, const float (&m)[3], const float (&i)[3],
+                                   float wj, float* pack) {
     float m0 = 0.f, m1 = 0.f, m2 = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, c = NEG_INF;
-    if (j < J) {
+    if (valid) {
         const double eps = (double)FLAT_EPS;
         const double l2e = 1.4426950408889634074;
-        double i0, i1, i2;
-        if (cov_type == HGMM_COV_DIAG) {
-            i0 = inv[3 * j + 0]; i1 = inv[3 * j + 1]; i2 = inv[3 * j + 2];
-        } else {
-            i0 = i1 = i2 = inv[j];
-        }
+        const double i0 = i[0], i1 = i[1], i2 = i[2];
         const double log2pi = (double)1.8378770351409912f;   // reference casts log(2 pi) to float32
         double half_log_det = log(i0 + eps) + log(i1 + eps) + log(i2 + eps);
-        double lw = (variant == HGMM_VARIANT_W) ? log((double)w[j] + eps) : log((double)w[j]);
+        double lw = (variant == HGMM_VARIANT_W) ? log((double)wj + eps) : log((double)wj);
         double cc = (-0.5 * 3.0 * log2pi + half_log_det + lw) * l2e;
-        m0 = mu[3 * j + 0]; m1 = mu[3 * j + 1]; m2 = mu[3 * j + 2];
+        m0 = m[0]; m1 = m[1]; m2 = m[2];
         g0 = (float)(0.5 * l2e * i0 * i0); g1 = (float)(0.5 * l2e * i1 * i1); g2 = (float)(0.5 * l2e * i2 * i2);
         c = (cc != cc) ? NEG_INF : (float)cc;
     }
@@ -74,6 +69,18 @@ __device__ inline void pack_component(int j, int J, int Jpad, int cov_type, int 
     pack[(PK_G + 1) * Jpad + j] = g1;
     pack[(PK_G + 2) * Jpad + j] = g2;
     pack[PK_C * Jpad + j] = c;
+}
+__device__ inline void pack_component(int j, int J, int Jpad, int cov_type, int variant,
+                                      const float* mu, const float* inv, const float* w,
+                                      float* pack) {
+    float m[3] = {0.f, 0.f, 0.f}, i[3] = {0.f, 0.f, 0.f}, wj = 0.f;
+    if (j < J) {
+        if (cov_type == HGMM_COV_DIAG) { i[0] = inv[3 * j + 0]; i[1] = inv[3 * j + 1]; i[2] = inv[3 * j + 2]; }
+        else i[0] = i[1] = i[2] = inv[j];
+        m[0] = mu[3 * j + 0]; m[1] = mu[3 * j + 1]; m[2] = mu[3 * j + 2];
+        wj = w[j];
+    }
+    pack_values(j, j < J, Jpad, variant, m, i, wj, pack);
 }
 
 __global__ void flat_pack_kernel(int J, int Jpad, int cov_type, int variant, const float* mu,
@@ -1065,12 +1072,22 @@ __global__ __launch_bounds__(BLOCK) void flat_chunk_write_kernel(
 // second stage: fp64 sum of the per-workgroup partials -> stats[7][Jpad], sum lpn, n
 // ------------------------------------------------------------------------------------------
 constexpr int RED_IDX = 32;      // consecutive statistics per workgroup (one 128-byte line)
-constexpr int RED_SLICES = 8;    // partial-block slices summed in parallel, combined in fixed order
+constexpr int RED_SLICES = 32;   // partial-block slices summed in parallel, combined in fixed order
+constexpr int RED_BATCH = 16;    // loads a thread has in flight: 512 workgroups' partials = ONE round of loads
+// This kernel sits between two EM iterations and is nothing but latency: every load is issued before the first
+// add (index clamped, value masked -- no branch between the loads), the stop flag is fetched alongside and only
+// gates the store.
 __global__ __launch_bounds__(RED_IDX * RED_SLICES) void flat_reduce_kernel(
     const float* __restrict__ partials, const double* __restrict__ lpn_partials, int nblocks,
     int n_lpn_blocks, int valid_j, int Jpad, double n_local, double* __restrict__ stats,
     const int* __restrict__ done_flag) {
-    if (done_flag && *done_flag) return;
+    // (an atomic load is a VECTOR load: it is waited for where `done` is used, a scalar load would be waited for
+    //  at the next kernel-argument fetch, i.e. before the partials' loads are even issued)
+    // (fetched through a per-lane address the compiler cannot prove uniform: a uniform value would be moved to an
+    //  SGPR -- and waited for -- on the spot)
+    int lane_zero = 0;
+    asm volatile("" : "+v"(lane_zero));
+    const int done = __hip_atomic_load(done_flag + lane_zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // never null
     const int total = FLAT_NSTAT * Jpad;
     const int stat_blocks = (total + RED_IDX - 1) / RED_IDX;
     __shared__ double sh[RED_SLICES][RED_IDX];
@@ -1080,19 +1097,20 @@ __global__ __launch_bounds__(RED_IDX * RED_SLICES) void flat_reduce_kernel(
         double acc = 0.0;
         if (idx < total && (idx % Jpad) < valid_j) {
             const float* src = partials + idx;
-            int b = slice;
-            for (; b + 3 * RED_SLICES < nblocks; b += 4 * RED_SLICES) {
-                const float v0 = src[(size_t)b * total];
-                const float v1 = src[(size_t)(b + RED_SLICES) * total];
-                const float v2 = src[(size_t)(b + 2 * RED_SLICES) * total];
-                const float v3 = src[(size_t)(b + 3 * RED_SLICES) * total];
-                acc += (double)v0; acc += (double)v1; acc += (double)v2; acc += (double)v3;
+            for (int b0 = slice; b0 < nblocks; b0 += RED_BATCH * RED_SLICES) {
+                float v[RED_BATCH];
+#pragma unroll
+                for (int u = 0; u < RED_BATCH; ++u) {
+                    const int b = b0 + u * RED_SLICES;
+                    v[u] = src[(size_t)(b < nblocks ? b : nblocks - 1) * total];
+                }
+#pragma unroll
+                for (int u = 0; u < RED_BATCH; ++u) acc += (b0 + u * RED_SLICES < nblocks) ? (double)v[u] : 0.0;
             }
-            for (; b < nblocks; b += RED_SLICES) acc += (double)src[(size_t)b * total];
         }
         sh[slice][li] = acc;
         __syncthreads();
-        if (slice == 0 && idx < total) {
+        if (slice == 0 && idx < total && !done) {
             double t = 0.0;
 #pragma unroll
             for (int s = 0; s < RED_SLICES; ++s) t += sh[s][li];
@@ -1107,7 +1125,7 @@ __global__ __launch_bounds__(RED_IDX * RED_SLICES) void flat_reduce_kernel(
         double* shw = &sh[0][0];
         if (lane_id() == 0) shw[wave_in_block()] = acc;
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0 && !done) {
             double t = 0.0;
             for (int w = 0; w < RED_IDX * RED_SLICES / 64; ++w) t += shw[w];
             stats[total] = t;
@@ -1125,20 +1143,27 @@ __global__ __launch_bounds__(RED_IDX * RED_SLICES) void flat_reduce_kernel(
 //        w = nk / N; inv_std = 1/(sqrt(cov) + eps)
 // ctl: [0] done, [1] n_iter, [2] converged; prev_ll lives in ctl_f[0].
 // ------------------------------------------------------------------------------------------
-__device__ inline void finalize_component(int j, const double* __restrict__ stats,
-                                          const float* __restrict__ centre, int J, int Jpad, int cov_type,
-                                          int variant, float* mu, float* cov, float* w, float* inv) {
+struct FlatComponent { float mu[3], cov[3], inv[3], w; };
+
+// the new parameters of component j, rounded to the reference's storage type (float32) before inv_std is derived
+__device__ inline FlatComponent finalize_values(int j, const double* __restrict__ stats,
+                                                const float* __restrict__ centre, int Jpad, int cov_type, int variant) {
     const double eps = (double)FLAT_EPS;
     const double n_total = stats[FLAT_NSTAT * Jpad + 1];
     const double s0 = stats[0 * Jpad + j];
+    double st_a[3], st_b[3], ce[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {                      // every load before the first divide
+        ce[d] = (double)centre[d * Jpad + j];
+        st_a[d] = stats[(1 + d) * Jpad + j];
+        st_b[d] = stats[(4 + d) * Jpad + j];
+    }
     double nmu[3], ncov[3];
     const double nk = (variant == HGMM_VARIANT_W) ? s0 + eps : s0;
     const double den = (variant == HGMM_VARIANT_W) ? nk : nk + eps;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        const double c = (double)centre[d * Jpad + j];
-        const double a = stats[(1 + d) * Jpad + j];
-        const double b = stats[(4 + d) * Jpad + j];
+        const double c = ce[d], a = st_a[d], b = st_b[d];
         const double sx = a + c * s0;
         const double sxx = b + 2.0 * c * a + c * c * s0;
         const double m = sx / den;
@@ -1147,30 +1172,39 @@ __device__ inline void finalize_component(int j, const double* __restrict__ stat
         nmu[d] = m;
         ncov[d] = v;
     }
-    // round to the reference's storage type (float32) before deriving inv_std
-    float fc[3];
+    FlatComponent r;
     if (cov_type == HGMM_COV_SPHERICAL) {
         const float sph = (float)((ncov[0] + ncov[1] + ncov[2]) / 3.0);
-        fc[0] = fc[1] = fc[2] = sph;
-        cov[j] = sph;
+        r.cov[0] = r.cov[1] = r.cov[2] = sph;
     } else {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { fc[d] = (float)ncov[d]; cov[3 * j + d] = fc[d]; }
+        for (int d = 0; d < 3; ++d) r.cov[d] = (float)ncov[d];
     }
 #pragma unroll
-    for (int d = 0; d < 3; ++d) mu[3 * j + d] = (float)nmu[d];
-    w[j] = (float)(nk / n_total);
+    for (int d = 0; d < 3; ++d) r.mu[d] = (float)nmu[d];
+    r.w = (float)(nk / n_total);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const double cv = (double)r.cov[d];
+        r.inv[d] = (float)((variant == HGMM_VARIANT_W) ? 1.0 / (sqrt(cv + 1e-6) + eps) : 1.0 / (sqrt(cv) + eps));
+    }
+    return r;
+}
+__device__ inline void store_component(int j, const FlatComponent& r, int cov_type, float* mu, float* cov, float* w,
+                                       float* inv) {
+    if (cov_type == HGMM_COV_SPHERICAL) cov[j] = r.cov[0];
+    else { cov[3 * j + 0] = r.cov[0]; cov[3 * j + 1] = r.cov[1]; cov[3 * j + 2] = r.cov[2]; }
+    mu[3 * j + 0] = r.mu[0]; mu[3 * j + 1] = r.mu[1]; mu[3 * j + 2] = r.mu[2];
+    w[j] = r.w;
     if (inv) {
-        float fi[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const double cv = (double)fc[d];
-            fi[d] = (float)((variant == HGMM_VARIANT_W) ? 1.0 / (sqrt(cv + 1e-6) + eps)
-                                                         : 1.0 / (sqrt(cv) + eps));
-        }
-        if (cov_type == HGMM_COV_SPHERICAL) inv[j] = fi[0];
-        else { inv[3 * j + 0] = fi[0]; inv[3 * j + 1] = fi[1]; inv[3 * j + 2] = fi[2]; }
+        if (cov_type == HGMM_COV_SPHERICAL) inv[j] = r.inv[0];
+        else { inv[3 * j + 0] = r.inv[0]; inv[3 * j + 1] = r.inv[1]; inv[3 * j + 2] = r.inv[2]; }
     }
+}
+__device__ inline void finalize_component(int j, const double* __restrict__ stats,
+                                          const float* __restrict__ centre, int J, int Jpad, int cov_type,
+                                          int variant, float* mu, float* cov, float* w, float* inv) {
+    store_component(j, finalize_values(j, stats, centre, Jpad, cov_type, variant), cov_type, mu, cov, w, inv);
 }
 
 __device__ inline void ctl_update(const double* __restrict__ stats, int Jpad, float* lls, int lls_cap,
@@ -1185,19 +1219,24 @@ __device__ inline void ctl_update(const double* __restrict__ stats, int Jpad, fl
     if (fabsf(change) < tol) { ctl[0] = 1; ctl[2] = 1; }
 }
 
-// single workgroup (Jpad <= 1024): M-step + next packed table + stop rule in one launch
+// single workgroup (Jpad <= 1024): M-step + next packed table + stop rule in one launch.  Like the reduction this is
+// a latency chain between two iterations: the stop flag is fetched WITH the statistics and only gates the stores, and
+// the packed table is formed from the registers that hold the new parameters (no store -> barrier -> re-load).
 __global__ void flat_finalize_kernel(const double* __restrict__ stats,
                                      const float* __restrict__ centre /*[3][Jpad] or pack mu rows*/,
                                      int J, int Jpad, int cov_type, int variant,
                                      float* mu, float* cov, float* w, float* inv, float* pack,
-                                     float* lls, int lls_cap, float tol, int* ctl, float* ctl_f) {
+                                     float* lls, int lls_cap, float tol, int* ctl, float* ctl_f,
+                                     const int* stop /*never null: ctl, or the always-zero word*/) {
     const int j = threadIdx.x;
-    const int done = ctl ? ctl[0] : 0;
+    const int done = __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // vector load, see flat_reduce_kernel
+    FlatComponent r = {};
+    if (j < J) r = finalize_values(j, stats, centre, Jpad, cov_type, variant);
+    // every thread has read `centre` (= the mu rows of pack) and ctl[0] before anybody overwrites them
     __syncthreads();
     if (done) return;
-    if (j < J) finalize_component(j, stats, centre, J, Jpad, cov_type, variant, mu, cov, w, inv);
-    __syncthreads();
-    if (pack && j < Jpad) pack_component(j, J, Jpad, cov_type, variant, mu, inv, w, pack);
+    if (j < J) store_component(j, r, cov_type, mu, cov, w, inv);
+    if (pack && j < Jpad) pack_values(j, j < J, Jpad, variant, r.mu, r.inv, r.w, pack);
     if (j == 0 && ctl) ctl_update(stats, Jpad, lls, lls_cap, tol, ctl, ctl_f);
 }
 
@@ -1287,7 +1326,10 @@ static int flat_setup(hgmm_ctx* c, int cov_type, int variant, int J) {
     HGMM_TRY(ensure(c, c->f_lpn_partials,
                     sizeof(double) * std::max<size_t>(FLAT_MAX_BLOCKS, (size_t)((c->n + 255) / 256))));
     HGMM_TRY(ensure(c, c->f_stats, sizeof(double) * (FLAT_NSTAT * Jpad + 2)));
-    HGMM_TRY(ensure(c, c->f_ctl, 64));
+    const bool fresh_ctl = c->f_ctl.p == nullptr;
+    HGMM_TRY(ensure(c, c->f_ctl, 256));
+    // int [16] of the buffer is never written again: the "not stopped" flag for launches outside a device loop
+    if (fresh_ctl) HGMM_HIP(c, hipMemsetAsync(c->f_ctl.p, 0, 256, c->stream));
     return HGMM_OK;
 }
 
@@ -1471,7 +1513,7 @@ static int launch_reduce(hgmm_ctx* c, int nblocks, int valid_j, bool with_lpn, c
     // the ones after the device-side stop (whose kernels return at once).  The local statistics are therefore
     // rebuilt from the (then unchanged) partials each time instead of being left to be summed over the ranks
     // again and again.
-    if (c->comm_on()) done_flag = nullptr;
+    if (c->comm_on() || !done_flag) done_flag = c->f_ctl.as<int>() + 16;        // always 0 (flat_setup)
     flat_reduce_kernel<<<(total + RED_IDX - 1) / RED_IDX + 1, RED_IDX * RED_SLICES, 0, c->stream>>>(
         c->f_partials.as<float>(), with_lpn ? c->f_lpn_partials.as<double>() : nullptr, nblocks,
         n_lpn_blocks < 0 ? nblocks : n_lpn_blocks, valid_j, f.Jpad, (double)c->n, c->f_stats.as<double>(),
@@ -1554,7 +1596,7 @@ static int enqueue_em_iteration(hgmm_ctx* c) {
     flat_finalize_kernel<<<1, f.Jpad, 0, c->stream>>>(
         c->f_stats.as<double>(), c->f_pack.as<float>() + PK_MU * f.Jpad, f.J, f.Jpad, f.cov_type,
         f.variant, c->f_mu.as<float>(), c->f_cov.as<float>(), c->f_w.as<float>(), c->f_inv.as<float>(),
-        c->f_pack.as<float>(), c->f_lls.as<float>(), f.lls_cap, f.tol, ctl, ctl_f);
+        c->f_pack.as<float>(), c->f_lls.as<float>(), f.lls_cap, f.tol, ctl, ctl_f, ctl);
     HGMM_HIP(c, hipGetLastError());
     f.launched++;
     return HGMM_OK;
@@ -1691,7 +1733,8 @@ extern "C" int hgmm_flat_mstep(hgmm_ctx* c, int cov_type, int variant, int J, co
     else
         flat_finalize_kernel<<<1, f.Jpad, 0, c->stream>>>(
             c->f_stats.as<double>(), hint, J, f.Jpad, cov_type, variant, c->f_mu.as<float>(),
-            c->f_cov.as<float>(), c->f_w.as<float>(), nullptr, nullptr, nullptr, 0, 0.f, nullptr, nullptr);
+            c->f_cov.as<float>(), c->f_w.as<float>(), nullptr, nullptr, nullptr, 0, 0.f, nullptr, nullptr,
+            c->f_ctl.as<int>() + 16);
     HGMM_HIP(c, hipGetLastError());
     HGMM_HIP(c, hipMemcpyAsync(mu_out, c->f_mu.p, sizeof(float) * 3 * J, hipMemcpyDeviceToHost, c->stream));
     HGMM_HIP(c, hipMemcpyAsync(cov_out, c->f_cov.p, sizeof(float) * cov_elems(cov_type, J),
