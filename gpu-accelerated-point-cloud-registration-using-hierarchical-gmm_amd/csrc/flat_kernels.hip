@@ -148,6 +148,7 @@ __device__ __forceinline__ float row_wl2(const LaneParams<NV4, NV1>& P, float x0
 //   lpn2 = mc + log2( S' + eps 2^-mc ),  mc = max(m2, -64),  S' = S (or 0 when m2 < -64: then
 //   sum_j exp(wlp_j) < 1e-19 J is below float32 resolution of eps = 1e-8).
 // inv_den satisfies  r_j = 2^(wl2_j - m2) * inv_den.
+constexpr float CS_MAX_SHIFT = 60.0f;      // constant-shift log-sum-exp is used while max_j c2_j <= this (flat_fused_pk_kernel)
 __device__ __forceinline__ float lpn2_from(float m2, float s, float& inv_den) {
     const bool tiny = m2 < -64.0f;
     const float mc = tiny ? -64.0f : m2;
@@ -312,7 +313,7 @@ template <int NV4, int NV1, int ROWS, bool NT>
 __global__ __launch_bounds__(BLOCK) void flat_estep_rows_pk_kernel(
     const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int J, int Jpad,
     float* __restrict__ log_resp, float* __restrict__ lpn_out, int32_t* __restrict__ argmax_out,
-    double* __restrict__ lpn_partials) {
+    double* __restrict__ lpn_partials, int allow_const_shift) {
     using L = Layout<NV4, NV1>;
     constexpr int K = L::K;
     constexpr int KP = 2 * NV4 + NV1 / 2;          // pairs
@@ -339,6 +340,17 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_rows_pk_kernel(
         g0s = ld(PK_G + 0, j); g1s = ld(PK_G + 1, j); g2s = ld(PK_G + 2, j);
         cs = ld(PK_C, j);
     }
+    // constant-shift log-sum-exp (see flat_fused_pk_kernel): M0 = max_j c2_j bounds every wl2, so with M0 folded into
+    // the constants the per-row maximum (2 v_max per pair, a wave reduction, one subtraction per pair) disappears.
+    // With ONE wave per SIMD -- what the HBM write path wants -- a wave issues one VALU instruction per ~5 cycles
+    // whatever its ILP, and this kernel was bound by exactly that (0.52 ms with its stores switched off, 0.55 with
+    // them): fewer instructions is the only lever.  The arg-max output needs the row maximum: generic loop.
+    float m0 = cs;
+#pragma unroll
+    for (int p = 0; p < KP; ++p) m0 = fmaxf(m0, fmaxf(cc[p].x, cc[p].y));
+    m0 = wave_max_dpp(m0);
+    const bool small_shift = allow_const_shift && !argmax_out && m0 <= CS_MAX_SHIFT && m0 >= -64.0f;
+
     const int64_t nw = (int64_t)gridDim.x * WAVES_PER_BLOCK;
     const int64_t gw = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
     const int64_t ngroups = (n + ROWS - 1) / ROWS;
@@ -353,6 +365,15 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_rows_pk_kernel(
             dst[r][0] = xp[0]; dst[r][1] = xp[1]; dst[r][2] = xp[2];
         }
     };
+    auto groups = [&](auto cs_tag) {
+    constexpr bool CS = decltype(cs_tag)::value;
+    if (CS) {
+        const f2 M0 = f2{m0, m0};
+#pragma unroll
+        for (int p = 0; p < KP; ++p) cc[p] = cc[p] - M0;
+        cs -= m0;
+    }
+    const float eps_scale = __builtin_amdgcn_exp2f(-m0);
     if (gw < ngroups) load_group(gw, x);
     for (int64_t g = gw; g < ngroups; g += nw) {
         float nx[ROWS][3];
@@ -364,6 +385,7 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_rows_pk_kernel(
         for (int r = 0; r < ROWS; ++r) {
             const f2 X0 = f2{x[r][0], x[r][0]}, X1 = f2{x[r][1], x[r][1]}, X2 = f2{x[r][2], x[r][2]};
             float mm = NEG_INF;
+            f2 acc = f2{0.f, 0.f};
 #pragma unroll
             for (int p = 0; p < KP; ++p) {
                 const f2 d0 = X0 - mu0[p], d1 = X1 - mu1[p], d2 = X2 - mu2[p];
@@ -371,7 +393,8 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_rows_pk_kernel(
                 a = a - (d1 * g1[p]) * d1;
                 a = a - (d2 * g2[p]) * d2;
                 wl[r][p] = a;
-                mm = fmaxf(mm, fmaxf(a.x, a.y));
+                if (CS) acc += f2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+                else mm = fmaxf(mm, fmaxf(a.x, a.y));
             }
             wls[r] = NEG_INF;
             if (ODD) {
@@ -383,27 +406,34 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_rows_pk_kernel(
                 mm = fmaxf(mm, a);
             }
             m[r] = mm;
-        }
-        if constexpr (ROWS == 4) wave_max4_dpp(m);
-        else {
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) m[r] = wave_max_dpp(m[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r)
-            if (m[r] == NEG_INF) m[r] = 0.f;
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            const f2 M = f2{m[r], m[r]};
-            f2 acc = f2{0.f, 0.f};
-#pragma unroll
-            for (int p = 0; p < KP; ++p) {
-                const f2 t = wl[r][p] - M;
-                acc += f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+            if (CS) {
+                float a = acc.x + acc.y;
+                if (ODD) a += __builtin_amdgcn_exp2f(wls[r]);
+                s[r] = a;
             }
-            float a = acc.x + acc.y;
-            if (ODD) a += __builtin_amdgcn_exp2f(wls[r] - m[r]);
-            s[r] = a;
+        }
+        if (!CS) {
+            if constexpr (ROWS == 4) wave_max4_dpp(m);
+            else {
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) m[r] = wave_max_dpp(m[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+                if (m[r] == NEG_INF) m[r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const f2 M = f2{m[r], m[r]};
+                f2 acc = f2{0.f, 0.f};
+#pragma unroll
+                for (int p = 0; p < KP; ++p) {
+                    const f2 t = wl[r][p] - M;
+                    acc += f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                }
+                float a = acc.x + acc.y;
+                if (ODD) a += __builtin_amdgcn_exp2f(wls[r] - m[r]);
+                s[r] = a;
+            }
         }
         if constexpr (ROWS == 4) wave_sum4_dpp(s);
         else {
@@ -415,9 +445,19 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_rows_pk_kernel(
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const int64_t row = g * ROWS + r;
-            float inv_den;
-            const float lpn = lpn2_from(m[r], s[r], inv_den) * LN2;
-            const f2 LNV = f2{LN2, LN2}, NL = f2{-lpn, -lpn};
+            float lpn;          // the row's log-normaliser
+            float sub;          // what is subtracted from wl * ln 2 (wl carries the shift -M0 under CS)
+            if (CS) {
+                // lpn2_from with m = m0 in [-64, CS_MAX_SHIFT]: no "tiny" case, eps 2^-m0 is loop-invariant
+                const float lden = __builtin_amdgcn_logf(fmaf(FLAT_EPS, eps_scale, s[r]));
+                lpn = (m0 + lden) * LN2;
+                sub = lden * LN2;
+            } else {
+                float inv_den;
+                lpn = lpn2_from(m[r], s[r], inv_den) * LN2;
+                sub = lpn;
+            }
+            const f2 LNV = f2{LN2, LN2}, NL = f2{-sub, -sub};
             if (row < n) {                                          // wave-uniform
                 lsum += (double)lpn;
                 float* out = log_resp + row * (int64_t)J;
@@ -432,11 +472,11 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_rows_pk_kernel(
                     const int j = 256 * NV4 + v * 64 + lane;
                     const int k = 4 * NV4 + v;
                     const float val = (ODD && k == K - 1) ? wls[r] : ((k & 1) ? wl[r][k >> 1].y : wl[r][k >> 1].x);
-                    if (j < J) store_f1<NT>(out + j, fmaf(val, LN2, -lpn));
+                    if (j < J) store_f1<NT>(out + j, fmaf(val, LN2, -sub));
                 }
             }
             if (lane == r) keep_lpn = lpn;
-            if (argmax_out) {
+            if (!CS && argmax_out) {
                 int best = 0x7fffffff;
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
@@ -453,12 +493,15 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_rows_pk_kernel(
             const int64_t row = g * ROWS + lane;
             if (row < n) {
                 if (lpn_out) lpn_out[row] = keep_lpn;
-                if (argmax_out) argmax_out[row] = keep_arg;
+                if (!CS && argmax_out) argmax_out[row] = keep_arg;
             }
         }
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) { x[r][0] = nx[r][0]; x[r][1] = nx[r][1]; x[r][2] = nx[r][2]; }
     }
+    };
+    if (small_shift) groups(std::true_type{});
+    else groups(std::false_type{});
     if (lpn_partials) {
         __shared__ double sh[WAVES_PER_BLOCK];
         if (lane == 0) sh[wave_in_block()] = lsum;
@@ -578,7 +621,6 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_kernel(
 // while M0 <= CS_MAX_SHIFT, and the denominator stays >= eps 2^-M0 >> FLT_MIN.  A model with a
 // larger M0 (sigma < ~1e-7: only the clipped-covariance flavour can get there) is served by the
 // row-maximum loop of the same kernel: every wave derives the same M0 from the table and picks its loop.
-constexpr float CS_MAX_SHIFT = 60.0f;
 
 template <int NSLOT>
 __global__ __launch_bounds__(BLOCK) void flat_fused_pk_kernel(
@@ -1393,6 +1435,47 @@ static bool env_flag(const char* name, bool dflt) {
         }                                                                                      \
     } while (0)
 
+// the 4-rows-per-wave materialising kernel for one (layout, grid, log-sum-exp variant); false: layout not instantiated
+static bool launch_estep_rows(hgmm_ctx* c, int nv4, int nv1, int grid_r, bool cshift, float* log_resp, float* lpn,
+                              int32_t* argmax) {
+    const FlatState& f = c->flat;
+    const float* X = c->x_aos.as<float>();
+    const float* pk = c->f_pack.as<float>();
+    double* lp = c->f_lpn_partials.as<double>();
+#define ESTEP_R(A, B)                                                                              \
+    flat_estep_rows_pk_kernel<A, B, 4, true><<<grid_r, BLOCK, 0, c->stream>>>(                      \
+        X, pk, c->n, f.J, f.Jpad, log_resp, lpn, argmax, lp, cshift ? 1 : 0)
+    if (nv4 == 3 && nv1 == 1) ESTEP_R(3, 1);
+    else if (nv4 == 3 && nv1 == 0) ESTEP_R(3, 0);
+    else if (nv4 == 3 && nv1 == 2) ESTEP_R(3, 2);
+    else if (nv4 == 4 && nv1 == 0) ESTEP_R(4, 0);
+    else if (nv4 == 2 && nv1 == 0) ESTEP_R(2, 0);
+    else if (nv4 == 2 && nv1 == 1) ESTEP_R(2, 1);
+    else if (nv4 == 2 && nv1 == 2) ESTEP_R(2, 2);
+    else if (nv4 == 1 && nv1 == 0) ESTEP_R(1, 0);
+    else if (nv4 == 1 && nv1 == 1) ESTEP_R(1, 1);
+    else if (nv4 == 1 && nv1 == 2) ESTEP_R(1, 2);
+    else if (nv4 == 0 && nv1 == 1) ESTEP_R(0, 1);
+    else if (nv4 == 0 && nv1 == 2) ESTEP_R(0, 2);
+    else return false;
+#undef ESTEP_R
+    return true;
+}
+
+// Number of workgroups of the materialising E-step.  The kernel sits where two limits meet: with one wave per SIMD
+// its arithmetic is issue-bound, and the HBM write path delivers LESS the more waves write at once (fillbench) --
+// so there is a best grid and it is sharp: constant-shift loop 0.559 / 0.543 / 0.559 / 0.580 / 0.616 ms at 184 / 192 /
+// 200 / 208 / 256 workgroups, row-maximum loop 0.576 / 0.540 / 0.565 / 0.589 at 208 / 224 / 240 / 256 (one box; the
+// generic loop's optimum sat at 256 on the next one, the constant-shift loop's at 192 on all three that were tried:
+// 0.543 / 0.556 / 0.538 ms against 0.589 / 0.564 / 0.551 for the round-1 shape).  Timing the candidates at first
+// use was tried and dropped: two launches after an idle moment run at other clocks than a stream of them, and picked
+// 176.  Per-row results do not depend on the grid; the mean log-normaliser's summation order does (last bits).
+static int estep_rows_grid(hgmm_ctx* c, bool cshift) {
+    const int full = grid_for(c, (c->n + 3) / 4, env_int("HGMM_ESTEP_BPC", 1));
+    if (env_int("HGMM_ESTEP_GRID", 0) > 0) return std::min(full, env_int("HGMM_ESTEP_GRID", 0));
+    return cshift ? std::min(full, std::max(1, c->cus * 3 / 4)) : full;
+}
+
 template <bool NORMALISE>
 static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argmax, int* grid_out) {
     const FlatState& f = c->flat;
@@ -1405,34 +1488,19 @@ static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argma
     pick_layout(f.J, &nv4, &nv1);
     const bool nt = NORMALISE && env_flag("HGMM_ESTEP_NT", true);
     const int rr = env_int("HGMM_ESTEP_RR", 0);
-    // Materialising path: 4 rows in flight per wave, ONE workgroup per CU (see the kernel's header)
+    // Materialising path: 4 rows in flight per wave, at most ONE workgroup per CU (see the kernel's header)
     const int rows = (NORMALISE && log_resp) ? env_int("HGMM_ESTEP_ROWS", 4) : 1;
-    ProfScope prof(c, HGMM_K_FLAT_ESTEP);
     if (rows > 1) {
-        int grid_r = grid_for(c, (c->n + 3) / 4, env_int("HGMM_ESTEP_BPC", 1));
-        if (env_int("HGMM_ESTEP_GRID", 0) > 0) grid_r = std::min(grid_r, env_int("HGMM_ESTEP_GRID", 0));
-#define ESTEP_R(A, B)                                                                              \
-    flat_estep_rows_pk_kernel<A, B, 4, true><<<grid_r, BLOCK, 0, c->stream>>>(                      \
-        X, pk, c->n, f.J, f.Jpad, log_resp, lpn, argmax, lp)
-        if (nv4 == 3 && nv1 == 1) ESTEP_R(3, 1);
-        else if (nv4 == 3 && nv1 == 0) ESTEP_R(3, 0);
-        else if (nv4 == 3 && nv1 == 2) ESTEP_R(3, 2);
-        else if (nv4 == 4 && nv1 == 0) ESTEP_R(4, 0);
-        else if (nv4 == 2 && nv1 == 0) ESTEP_R(2, 0);
-        else if (nv4 == 2 && nv1 == 1) ESTEP_R(2, 1);
-        else if (nv4 == 2 && nv1 == 2) ESTEP_R(2, 2);
-        else if (nv4 == 1 && nv1 == 0) ESTEP_R(1, 0);
-        else if (nv4 == 1 && nv1 == 1) ESTEP_R(1, 1);
-        else if (nv4 == 1 && nv1 == 2) ESTEP_R(1, 2);
-        else if (nv4 == 0 && nv1 == 1) ESTEP_R(0, 1);
-        else if (nv4 == 0 && nv1 == 2) ESTEP_R(0, 2);
-        else goto single_row;
-#undef ESTEP_R
-        *grid_out = grid_r;
-        HGMM_HIP(c, hipGetLastError());
-        return HGMM_OK;
+        const bool cshift = env_flag("HGMM_ESTEP_CS", true) && !argmax;
+        const int grid_r = estep_rows_grid(c, cshift);
+        ProfScope prof(c, HGMM_K_FLAT_ESTEP);
+        if (launch_estep_rows(c, nv4, nv1, grid_r, cshift, log_resp, lpn, argmax)) {
+            *grid_out = grid_r;
+            HGMM_HIP(c, hipGetLastError());
+            return HGMM_OK;
+        }
     }
-single_row:
+    ProfScope prof(c, HGMM_K_FLAT_ESTEP);
 #define ESTEP_M(A, B)                                                                              \
     do {                                                                                           \
         if (nt) flat_estep_kernel<A, B, NORMALISE, NORMALISE><<<grid, BLOCK, 0, c->stream>>>(       \

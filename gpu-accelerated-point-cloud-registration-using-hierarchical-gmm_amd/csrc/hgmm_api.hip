@@ -227,6 +227,21 @@ __global__ __launch_bounds__(256) void util_fill_kernel(float* __restrict__ p, i
         int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         for (; i + 3 * stride < n4; i += 4 * stride) { st(i); st(i + stride); st(i + 2 * stride); st(i + 3 * stride); }
         for (; i < n4; i += stride) st(i);
+    } else if (MODE == 5) {
+        // MODE 5: rows of 200 float4 (J = 800); a workgroup takes `chunk` consecutive rows per step, workgroups
+        // round-robin; thread t writes float4 t of every row (threads 200.. idle): wave q owns piece q of a row --
+        // the store pattern of an E-step whose four waves split the COMPONENTS of a row
+        const int rows = (int)v;
+        const f4 one = {1.f, 1.f, 1.f, 1.f};
+        const int64_t nrows = n4 / 200;
+        for (int64_t r0 = (int64_t)blockIdx.x * rows; r0 < nrows; r0 += (int64_t)gridDim.x * rows) {
+            for (int r = 0; r < rows; ++r) {
+                if (threadIdx.x < 200 && r0 + r < nrows) {
+                    if (NT) __builtin_nontemporal_store(one, q + (r0 + r) * 200 + threadIdx.x);
+                    else q[(r0 + r) * 200 + threadIdx.x] = one;
+                }
+            }
+        }
     } else {
         // MODE 3: one writer wavefront per workgroup streams `chunk` float4 (a batch of rows) at a
         // time, workgroups take chunks round-robin -- the store pattern of a producer/consumer
@@ -253,7 +268,7 @@ extern "C" int hgmm_util_fill_f32(hgmm_ctx* c, float* dev, int64_t n, float valu
     if (!c || !dev || n < 4) return HGMM_ERR_ARG;
     const int64_t n4 = n / 4;
     // bits 8.. of `nontemporal` select the probe variant: mode = (flags >> 8) & 3, grid = cus * ((flags >> 16) or 8)
-    const int mode = (nontemporal >> 8) & 3;
+    const int mode = (nontemporal >> 8) & 7;
     const int gmul = (nontemporal >> 16) ? (nontemporal >> 16) : 8;
     const bool nt = (nontemporal & 1) != 0;
     const int grid = c->cus * gmul;
@@ -263,7 +278,13 @@ extern "C" int hgmm_util_fill_f32(hgmm_ctx* c, float* dev, int64_t n, float valu
         if (mode == 0) { if (nt) FILL(true, 0); else FILL(false, 0); }
         else if (mode == 1) { if (nt) FILL(true, 1); else FILL(false, 1); }
         else if (mode == 2) { if (nt) FILL(true, 2); else FILL(false, 2); }
-        else {
+        else if (mode == 4) {       // mode 3's chunks written by a whole 256-thread workgroup
+            if (nt) util_fill_kernel<true, 3><<<grid, 256, 0, c->stream>>>(dev, n4, value);
+            else util_fill_kernel<false, 3><<<grid, 256, 0, c->stream>>>(dev, n4, value);
+        } else if (mode == 5) {
+            if (nt) util_fill_kernel<true, 5><<<grid, 256, 0, c->stream>>>(dev, n4, value);
+            else util_fill_kernel<false, 5><<<grid, 256, 0, c->stream>>>(dev, n4, value);
+        } else {
             // mode 3: grid = cus * gmul workgroups of ONE wavefront
             if (nt) util_fill_kernel<true, 3><<<grid, 64, 0, c->stream>>>(dev, n4, value);
             else util_fill_kernel<false, 3><<<grid, 64, 0, c->stream>>>(dev, n4, value);
