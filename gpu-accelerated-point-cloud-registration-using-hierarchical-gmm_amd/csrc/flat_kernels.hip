@@ -1767,7 +1767,8 @@ extern "C" int hgmm_flat_mstep(hgmm_ctx* c, int cov_type, int variant, int J, co
         flat_hint_const_kernel<<<(f.Jpad + 255) / 256, 256, 0, c->stream>>>(0.f, 0.f, 0.f, f.Jpad,
                                                                           c->f_hint.as<float>());
     }
-    const int grid = grid_for(c, c->n, env_int("HGMM_MSTEP_BPC", 2));
+    int grid = grid_for(c, c->n, env_int("HGMM_MSTEP_BPC", 2));
+    if (env_int("HGMM_MSTEP_GRID", 0) > 0) grid = std::min(grid_for(c, c->n, 4), env_int("HGMM_MSTEP_GRID", 0));
     const int rr = env_int("HGMM_MSTEP_RR", 0);
     const float* X = c->x_aos.as<float>();
     float* part = c->f_partials.as<float>();

@@ -32,9 +32,17 @@ def oracle64_estep(X, inv, mu, w, cov_type, variant):
 
 def check_estep(ctx, X, inv, mu, w, cov_type, variant, label=""):
     ctx.set_points(X)
+    o_mean, o_lr, o_lpn, o_am = oracle64_estep(X, inv, mu, w, cov_type, variant)
+    # Without the arg-max output the materialising kernel takes its constant-shift loop (no row maximum), with it
+    # the row-maximum loop: BOTH are held to the oracle, the first here, the second below.
+    mean_cs, lr_cs, lpn_cs, _ = ctx.flat_estep(inv, mu, w, cov_type, variant, want_lpn=True, want_argmax=False)
+    lr_cs, lpn_cs = lr_cs.get(), lpn_cs.get()
+    assert np.abs(np.exp(lr_cs.astype(np.float64)) - np.exp(o_lr)).max() <= RESP_TOL
+    assert np.abs(lpn_cs - o_lpn).max() <= 2e-5 * max(1.0, np.abs(o_lpn).max())
+    assert abs(mean_cs - o_mean) <= 1e-5 * max(1.0, abs(o_mean))
+    np.testing.assert_allclose(lr_cs[o_lr > -30], o_lr[o_lr > -30], rtol=2e-5, atol=2e-5)
     mean, lr, lpn, am = ctx.flat_estep(inv, mu, w, cov_type, variant, want_lpn=True, want_argmax=True)
     lr, lpn, am = lr.get(), lpn.get(), am.get()
-    o_mean, o_lr, o_lpn, o_am = oracle64_estep(X, inv, mu, w, cov_type, variant)
     r, o_r = np.exp(lr.astype(np.float64)), np.exp(o_lr)
     d_resp = np.abs(r - o_r).max()
     d_lpn = np.abs(lpn - o_lpn).max()
@@ -547,6 +555,34 @@ def test_train_far_points_and_mixed_scales(ctx):
         np.testing.assert_allclose(w, o[2], rtol=2e-5, atol=1e-8)
         np.testing.assert_allclose(mu, o[1], rtol=0, atol=2e-5 * np.abs(X).max())
         np.testing.assert_allclose(cov, o[3], rtol=2e-4, atol=1e-9)
+
+
+def test_estep_constant_shift_loop_far_points_mixed_scales_and_fallback(ctx):
+    """The materialising E-step's constant-shift loop (taken when no arg-max is asked for) on rows far from every
+    component and on a mix of very tight and very broad components; and a table whose largest constant is out of
+    the loop's range (sigma ~ 3e-8), which must fall back to the row-maximum loop transparently."""
+    rs = np.random.RandomState(23)
+    centres = rs.rand(6, 3)
+    X = (centres[rs.randint(6, size=2000)] + 0.01 * rs.randn(2000, 3)).astype(np.float32)
+    X[:40] += rs.choice([-1, 1], size=(40, 3)) * rs.uniform(3, 60, size=(40, 3))     # outliers
+    J = 70
+    mu = X[rs.choice(len(X), J, replace=False)].copy()
+    cov = (10.0 ** rs.uniform(-5.5, 0.5, size=(J, 3))).astype(np.float32)
+    w = rs.dirichlet(np.ones(J)).astype(np.float32)
+    for variant in ("W", "G"):
+        inv = flat_em.inv_std_from_cov(cov, variant, initial=True)
+        check_estep(ctx, X, inv, mu, w, "diag", variant, "far points %s" % variant)
+    # out-of-range constants: both calls must run the same (row-maximum) loop -> bit-identical outputs
+    X2 = (np.repeat(rs.rand(5, 3), 40, axis=0) + 1e-8 * rs.randn(200, 3)).astype(np.float32)
+    mu2 = X2[::40].copy()
+    inv2 = np.full((5, 3), 3e7, np.float32)
+    w2 = np.full(5, 0.2, np.float32)
+    ctx.set_points(X2)
+    _, a, la, _ = ctx.flat_estep(inv2, mu2, w2, "diag", "G", want_lpn=True, want_argmax=False)
+    _, b, lb, _ = ctx.flat_estep(inv2, mu2, w2, "diag", "G", want_lpn=True, want_argmax=True)
+    a, b, la, lb = a.get(), b.get(), la.get(), lb.get()
+    assert np.isfinite(la).all()
+    assert np.array_equal(a, b) and np.array_equal(la, lb)
 
 
 def test_train_huge_shift_takes_the_row_maximum_variant(ctx):
