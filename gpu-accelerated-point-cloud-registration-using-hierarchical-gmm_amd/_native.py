@@ -109,6 +109,7 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_profile_reset", [ctx])
         _sig(lib, "hgmm_profile_get", [ctx, C.c_int, _f64p, C.POINTER(C.c_int64)])
         _sig(lib, "hgmm_util_fill_f32", [ctx, _vp, C.c_int64, C.c_float, C.c_int])
+        _sig(lib, "hgmm_kmeans_center_f64", [_vp, C.c_int64, _vp, _vp, _vp])
         _lib = lib
         return lib
 

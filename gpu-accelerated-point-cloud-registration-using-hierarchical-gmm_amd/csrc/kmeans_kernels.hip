@@ -739,6 +739,30 @@ using namespace hgmm;
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
+// Host helper: column means, variances and the centred copy of an [n,3] cloud in the summation order NumPy uses for
+// X.mean(axis=0) / np.var(X, axis=0) on a C-ordered array (a running sum per column, row by row; product and sum
+// rounded separately) -- scikit-learn centres by the one and scales tol by the other, and the initialiser has to
+// work on the very same doubles.  Three independent add chains per pass: ~1 ns per point instead of NumPy's 25.
+#pragma clang fp contract(off)
+extern "C" int hgmm_kmeans_center_f64(const double* x, int64_t n, double* mean3, double* var3, double* xc_out) {
+    if (!x || n < 1 || !mean3 || !var3 || !xc_out) return HGMM_ERR_ARG;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int64_t i = 0; i < n; ++i) { s0 += x[3 * i]; s1 += x[3 * i + 1]; s2 += x[3 * i + 2]; }
+    const double dn = (double)n;
+    const double m0 = s0 / dn, m1 = s1 / dn, m2 = s2 / dn;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double d0 = x[3 * i] - m0, d1 = x[3 * i + 1] - m1, d2 = x[3 * i + 2] - m2;
+        xc_out[3 * i] = d0; xc_out[3 * i + 1] = d1; xc_out[3 * i + 2] = d2;
+        const double q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2;
+        v0 += q0; v1 += q1; v2 += q2;
+    }
+    mean3[0] = m0; mean3[1] = m1; mean3[2] = m2;
+    var3[0] = v0 / dn; var3[1] = v1 / dn; var3[2] = v2 / dn;
+    return HGMM_OK;
+}
+#pragma clang fp contract(fast)
+
 extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const double* rand_vals,
                                     int n_trials, int64_t* ids_out, double* centers_out) {
     if (!c) return HGMM_ERR_ARG;

@@ -83,17 +83,19 @@ def _uniform_cdf(n):
 
 
 def column_mean_var(X):
-    """``X.mean(axis=0)``, ``np.var(X, axis=0)`` and ``X - mean`` of an [N,3] float64 array, bit for bit, in a
-    quarter of the time: NumPy reduces a C-ordered [N,3] array over axis 0 row by row (a plain running sum per
-    column, 3 elements per inner loop -- 25 ms per million points for the variance alone), which is what
-    ``cumsum`` of a contiguous column computes at memory speed.  (tests/test_kmeans_cpu.py holds the equality.)"""
-    n = len(X)
-    cols = np.array(X.T, order="C", copy=True)          # (a copy also when X.T is contiguous already: edited in place below)
-    mean = np.array([np.cumsum(c)[-1] for c in cols]) / n
-    Xc = X - mean
-    cols -= mean[:, None]
-    np.multiply(cols, cols, out=cols)
-    var = np.array([np.cumsum(c)[-1] for c in cols]) / n
+    """``X.mean(axis=0)``, ``np.var(X, axis=0)`` and ``X - mean`` of an [N,3] float64 array, bit for bit, at memory
+    speed: NumPy reduces a C-ordered [N,3] array over axis 0 row by row (a plain running sum per column, 3 elements
+    per inner loop -- 25 ms per million points for the variance alone); the library's host helper
+    ``hgmm_kmeans_center_f64`` runs the same three add chains in ~3 ms.  (tests/test_kmeans_cpu.py holds the
+    equality.)"""
+    import ctypes as C
+    from ._native import load_library
+    Xd = np.ascontiguousarray(X, dtype=np.float64)
+    mean, var, Xc = np.empty(3), np.empty(3), np.empty_like(Xd)
+    rc = load_library().hgmm_kmeans_center_f64(Xd.ctypes.data_as(C.c_void_p), len(Xd), mean.ctypes.data_as(C.c_void_p),
+                                               var.ctypes.data_as(C.c_void_p), Xc.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise ValueError("hgmm_kmeans_center_f64 failed (%d) on an array of shape %s" % (rc, X.shape))
     return mean, var, Xc
 
 

@@ -217,6 +217,10 @@ int hgmm_fullcov_estep(hgmm_ctx* ctx, int J, const double* pi, const double* mu,
  *                       labels that differ from the previous step's (reset_labels != 0: from -1).
  *                       With a communicator attached the three results are all-reduced.
  * hgmm_kmeans_labels    labels[n] / squared distance to the assigned centre of the last step. */
+/* Host-side (no device work): column means / variances / centred copy of an [n,3] float64 cloud, bit for bit what
+ * NumPy's X.mean(axis=0), np.var(X, axis=0), X - mean give on a C-ordered array -- the preprocessing of
+ * sklearn.cluster.KMeans.fit behind src/python/gmmreg_gpu/gmm_impl.py:20-21. */
+int hgmm_kmeans_center_f64(const double* x_host, int64_t n, double* mean3, double* var3, double* xc_out);
 int hgmm_kmeans_plusplus(hgmm_ctx* ctx, int k, int64_t first_id, const double* rand_vals, int n_trials,
                          int64_t* ids_out, double* centers_out);
 int hgmm_kmeans_step(hgmm_ctx* ctx, int k, const double* centers, int reset_labels, double* sums_out,
