@@ -212,16 +212,21 @@ def registration_leg(ctx):
         t0 = time.perf_counter()
         gt = GMMTree(P, tree_level=3, lambda_c=0.01, ls=80, sig2=0.00034, ctx=ctx)
         t1 = time.perf_counter()
-        iters = []
-        gt.set_callbacks([lambda tf: iters.append(1)])
-        res = gt.registration(target, maxiter=20, tol=1e-4)
+        res = gt.registration(target, maxiter=20, tol=1e-4)          # no callbacks: the loop runs inside the library
         t2 = time.perf_counter()
         if best is None or t2 - t0 < best[0]:
             err = float(np.linalg.norm(res.transformation.transform(P) - target, axis=1).mean())
-            best = (t2 - t0, t1 - t0, t2 - t1, len(iters), err)
+            best = (t2 - t0, t1 - t0, t2 - t1, int(gt.n_iter_), err)
+    # the same registration with a callback per iteration (the reference's visualisation hook): Python per iteration
+    seen = []
+    gt.set_callbacks([lambda tf: seen.append(1)])
+    t0 = time.perf_counter()
+    gt.registration(target, maxiter=20, tol=1e-4)
+    with_cb = time.perf_counter() - t0
     return {"workload": "bun000.ply (40256 pts) vs copy rotated 10 deg + shifted, registration_gmmtree L=3",
             "total_ms": best[0] * 1e3, "build_ms": best[1] * 1e3, "registration_ms": best[2] * 1e3,
             "registration_iterations": best[3], "ms_per_registration_iteration": best[2] * 1e3 / max(best[3], 1),
+            "registration_ms_with_per_iteration_callbacks": with_cb * 1e3, "callback_iterations": len(seen),
             "mean_residual_m": best[4]}
 
 

@@ -110,6 +110,8 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_profile_get", [ctx, C.c_int, _f64p, C.POINTER(C.c_int64)])
         _sig(lib, "hgmm_util_fill_f32", [ctx, _vp, C.c_int64, C.c_float, C.c_int])
         _sig(lib, "hgmm_kmeans_center_f64", [_vp, C.c_int64, _vp, _vp, _vp])
+        _sig(lib, "hgmm_tree_register", [ctx, _vp, _vp, C.c_double, C.c_double, C.c_int, C.c_double, _vp,
+                                         C.POINTER(C.c_int), C.POINTER(C.c_int), _vp])
         _lib = lib
         return lib
 
@@ -442,6 +444,20 @@ class Context:
         ata[np.triu_indices(6)] = out[:21]
         ata = ata + np.triu(ata, 1).T
         return ata, out[21:27].copy(), float(out[27])
+
+    def tree_register(self, rot, t, scale=1.0, lambda_c=0.01, max_iter=20, tol=1.0e-4, q_prev=None, want_trace=False):
+        """Up to ``max_iter`` registration iterations inside the library (hgmm_tree_register).
+        -> (rot[3,3], t[3], iterations done, q of the last one or ``q_prev``, status, trace or None);
+        status 0: budget used up, 1: stopped by ``tol``, 2: the next iteration needs the host M-step."""
+        rot = np.array(rot, dtype=np.float64).reshape(3, 3)
+        t = np.array(t, dtype=np.float64).reshape(3)
+        q = np.array([np.nan if q_prev is None else float(q_prev)])
+        trace = np.zeros((max(int(max_iter), 1), 13)) if want_trace else None
+        done, status = C.c_int(), C.c_int()
+        self._check(self.lib.hgmm_tree_register(self.h, _ptr(rot), _ptr(t), float(scale), float(lambda_c), int(max_iter),
+                                                float(tol), _ptr(q), C.byref(done), C.byref(status), _ptr(trace)))
+        q_out = None if np.isnan(q[0]) else float(q[0])
+        return rot, t, done.value, q_out, status.value, (None if trace is None else trace[:done.value])
 
     @staticmethod
     def _node_tables(pi, mu, cov):

@@ -1322,6 +1322,127 @@ extern "C" int hgmm_tree_reg_normal(hgmm_ctx* c, const double* rot, const double
     return HGMM_OK;
 }
 
+// ---- the registration loop (hgmm_gpu.py:754-768) with its 6 x 6 M-step on the host side of this library ----------
+namespace {
+// eigenvalue range of a symmetric 6 x 6 matrix by cyclic Jacobi sweeps (for the conditioning test only)
+void sym6_eig_range(const double (&A)[6][6], double* lo, double* hi) {
+    double a[6][6];
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) a[i][j] = A[i][j];
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0;
+        for (int i = 0; i < 6; ++i) for (int j = i + 1; j < 6; ++j) off += a[i][j] * a[i][j];
+        if (off == 0.0) break;
+        for (int p = 0; p < 6; ++p)
+            for (int q = p + 1; q < 6; ++q) {
+                if (a[p][q] == 0.0) continue;
+                const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / std::sqrt(tt * tt + 1.0), sn = tt * cs;
+                for (int k = 0; k < 6; ++k) {
+                    const double akp = a[k][p], akq = a[k][q];
+                    a[k][p] = cs * akp - sn * akq;
+                    a[k][q] = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < 6; ++k) {
+                    const double apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = cs * apk - sn * aqk;
+                    a[q][k] = sn * apk + cs * aqk;
+                }
+            }
+    }
+    *lo = *hi = a[0][0];
+    for (int i = 1; i < 6; ++i) { *lo = std::min(*lo, a[i][i]); *hi = std::max(*hi, a[i][i]); }
+}
+// A x = b by Gaussian elimination with partial pivoting (what LAPACK's gesv does); false: singular
+bool solve6(const double (&A)[6][6], const double (&b)[6], double (&x)[6]) {
+    double m[6][7];
+    for (int i = 0; i < 6; ++i) { for (int j = 0; j < 6; ++j) m[i][j] = A[i][j]; m[i][6] = b[i]; }
+    for (int col = 0; col < 6; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 6; ++r) if (std::fabs(m[r][col]) > std::fabs(m[piv][col])) piv = r;
+        if (m[piv][col] == 0.0) return false;
+        if (piv != col) for (int j = 0; j < 7; ++j) std::swap(m[piv][j], m[col][j]);
+        for (int r = col + 1; r < 6; ++r) {
+            const double f = m[r][col] / m[col][col];
+            for (int j = col; j < 7; ++j) m[r][j] -= f * m[col][j];
+        }
+    }
+    for (int i = 5; i >= 0; --i) {
+        double s = m[i][6];
+        for (int j = i + 1; j < 6; ++j) s -= m[i][j] * x[j];
+        x[i] = s / m[i][i];
+    }
+    return true;
+}
+// (rot, t) <- (dR rot, dR t + v), dR = exp([omega]_x) by Rodrigues' formula   (twist_mul, hgmm_gpu.py:634-664)
+void twist_compose(const double (&x)[6], double* rot, double* t) {
+    const double w0 = x[0], w1 = x[1], w2 = x[2];
+    const double angle = std::sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+    double d[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    if (angle != 0.0) {
+        const double a = w0 / angle, b = w1 / angle, c = w2 / angle;
+        const double k[3][3] = {{0.0, -c, b}, {c, 0.0, -a}, {-b, a, 0.0}};
+        const double sn = std::sin(angle), oc = 1.0 - std::cos(angle);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double kk = 0.0;
+                for (int l = 0; l < 3; ++l) kk += k[i][l] * k[l][j];
+                d[i][j] += sn * k[i][j] + oc * kk;
+            }
+    }
+    double r2[9], t2[3];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            double v = 0.0;
+            for (int l = 0; l < 3; ++l) v += d[i][l] * rot[3 * l + j];
+            r2[3 * i + j] = v;
+        }
+        double v = 0.0;
+        for (int l = 0; l < 3; ++l) v += d[i][l] * t[l];
+        t2[i] = v + x[3 + i];
+    }
+    for (int i = 0; i < 9; ++i) rot[i] = r2[i];
+    for (int i = 0; i < 3; ++i) t[i] = t2[i];
+}
+}  // namespace
+
+extern "C" int hgmm_tree_register(hgmm_ctx* c, double* rot, double* t, double scale, double lambda_c, int max_iter,
+                                  double tol, double* q_prev_inout, int* iters_out, int* status_out,
+                                  double* trace /*[max_iter][13] or NULL*/) {
+    if (!c || !rot || !t || !q_prev_inout || !iters_out || !status_out)
+        return c ? fail(c, HGMM_ERR_ARG, "tree_register: NULL argument") : HGMM_ERR_ARG;
+    *iters_out = 0;
+    *status_out = 0;                                  // 0: iteration budget used up, 1: |dq| < tol, 2: host M-step needed
+    for (int it = 0; it < max_iter; ++it) {
+        double o[28];
+        HGMM_TRY(hgmm_tree_reg_normal(c, rot, t, scale, lambda_c, o));
+        double A[6][6], b[6], x[6];
+        bool finite = true;
+        for (int i = 0, k = 0; i < 6; ++i)
+            for (int j = i; j < 6; ++j, ++k) { A[i][j] = A[j][i] = o[k]; finite = finite && std::isfinite(o[k]); }
+        for (int i = 0; i < 6; ++i) { b[i] = o[21 + i]; finite = finite && std::isfinite(b[i]); }
+        double lo = 0.0, hi = 0.0;
+        if (finite) sym6_eig_range(A, &lo, &hi);
+        // too ill-conditioned for normal equations: the caller takes the reference's stacked least-squares M-step
+        if (!finite || !(hi > 0.0) || lo <= 1e-11 * hi || !solve6(A, b, x)) { *status_out = 2; return HGMM_OK; }
+        double xb = 0.0;
+        for (int i = 0; i < 6; ++i) xb += x[i] * b[i];
+        const double q = std::max(o[27] - xb, 0.0);
+        twist_compose(x, rot, t);
+        if (trace) {
+            double* tr = trace + (size_t)13 * it;
+            for (int i = 0; i < 9; ++i) tr[i] = rot[i];
+            for (int i = 0; i < 3; ++i) tr[9 + i] = t[i];
+            tr[12] = q;
+        }
+        *iters_out = it + 1;
+        const double qp = *q_prev_inout;
+        *q_prev_inout = q;
+        if (qp == qp && std::fabs(q - qp) < tol) { *status_out = 1; return HGMM_OK; }      // (NaN: no previous q)
+    }
+    return HGMM_OK;
+}
+
 extern "C" int hgmm_tree_node_complexity(hgmm_ctx* c, double* cplx_out) {
     if (!c || !cplx_out) return c ? fail(c, HGMM_ERR_ARG, "cplx_out is NULL") : HGMM_ERR_ARG;
     if (!c->tree.nodes_ready) return fail(c, HGMM_ERR_STATE, "no tree");

@@ -308,13 +308,47 @@ class GMMTree():
         rot, t = twist_mul(x, tf.rot, tf.t)
         return MstepResult(RigidTransformation(rot, t), q)
 
+    def _registration_in_library(self, maxiter, tol):
+        """The loop of :meth:`registration` without per-iteration Python: ``hgmm_tree_register`` iterates (E-step and
+        normal equations on the device, 6 x 6 solve / twist / stop rule on the library's host side) until it stops or
+        meets a system too ill-conditioned for normal equations; that one iteration is then done here with the
+        reference's stacked least squares, and the library carries on.  Same arithmetic per iteration as
+        :meth:`_device_iteration` (used when callbacks want every intermediate transformation)."""
+        tf = self._tf_result
+        rot, t = np.asarray(tf.rot, dtype=np.float64), np.asarray(tf.t, dtype=np.float64)
+        q = None
+        it = 0
+        while it < maxiter:
+            rot, t, done, q_new, status, _ = self._ctx.tree_register(rot, t, tf.scale, self._lambda_c, maxiter - it, tol, q)
+            it += done
+            if done:
+                q = q_new
+            self._tf_result = RigidTransformation(rot, t, tf.scale)
+            if status != 2:
+                break
+            res = self.maximization_step(self.expectation_step(), self._tf_result)      # host M-step, one iteration
+            self._tf_result = res.transformation
+            rot, t = np.asarray(res.transformation.rot, dtype=np.float64), np.asarray(res.transformation.t, dtype=np.float64)
+            it += 1
+            q_host = float(np.ravel(res.q)[0]) if np.size(res.q) else None
+            if q is not None and q_host is not None and abs(q_host - q) < tol:
+                q = q_host
+                break
+            q = q_host
+        self.n_iter_ = it
+        return MstepResult(self._tf_result.inverse(), np.array([q]) if q is not None else np.array([]))
+
     def registration(self, target, maxiter=20, tol=1.0e-4):
         """-> MstepResult(tf.inverse(), q)   (hgmm_gpu.py:754-768)."""
         self._ctx.tree_set_nodes(self._tree_level, self._mixingCoeff, self._mean, self._covar)
         self._ctx.tree_set_target(_points(target))
+        if self._device_mstep and not self._callbacks:
+            return self._registration_in_library(maxiter, tol)
         q = None
         res = None
+        self.n_iter_ = 0
         for _ in range(maxiter):
+            self.n_iter_ += 1
             res = self._device_iteration() if self._device_mstep else None
             if res is None:
                 estep_res = self.expectation_step()      # target transformed on the device

@@ -166,6 +166,15 @@ int hgmm_tree_reg_estep(hgmm_ctx* ctx, const double* rot, const double* t, doubl
  * twist (hgmm_gpu.py:620-664), residual q = b^T b - x . A^T b.  Deterministic (fixed-point moment sums). */
 int hgmm_tree_reg_normal(hgmm_ctx* ctx, const double* rot, const double* t, double scale,
                          double lambda_c, double* out28);
+/* The registration loop of GMMTree.registration (src/python/hgmm/hgmm_gpu.py:754-768) run by the library: per
+ * iteration hgmm_tree_reg_normal on the device, then on the host the 6 x 6 solve, q = max(b'b - x.A'b, 0), the
+ * composition of the twist with (rot, t) (twist_mul, hgmm_gpu.py:634-664) and the reference's stop rule
+ * |q - q_prev| < tol.  rot [9] row-major and t [3] are updated in place; *q_prev_inout: NaN = no previous q.
+ * status: 0 = max_iter iterations done, 1 = stopped by tol, 2 = the normal equations of the NEXT iteration are too
+ * ill-conditioned (or not finite): the caller runs that iteration with the reference's stacked least squares
+ * (eigh + QR on the host) and may call again.  trace (optional): per iteration rot, t, q.              */
+int hgmm_tree_register(hgmm_ctx* ctx, double* rot, double* t, double scale, double lambda_c, int max_iter, double tol,
+                       double* q_prev_inout, int* iters_out, int* status_out, double* trace);
 /* The steps buildGMMTree is made of, one at a time (reference function granularity).  Node tables
  * hold T nodes (any T >= 8, need not be a complete tree).
  * hgmm_tree_estep  <- gmmTreeEStep()       hgmm_cupy_cpu_working.py:162-191: parent_idx[N] arbitrary

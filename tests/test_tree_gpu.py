@@ -356,3 +356,59 @@ def test_registration_device_and_host_mstep_agree(ctx, bunny):
         np.testing.assert_allclose(r_a, r_b, rtol=0, atol=1e-8)
         np.testing.assert_allclose(t_a, t_b, rtol=0, atol=1e-8)
     np.testing.assert_allclose(traces[True][1], traces[False][1], rtol=1e-5, atol=1e-8)
+
+
+def test_registration_loop_inside_the_library(ctx, bunny):
+    """GMMTree.registration without callbacks runs hgmm_tree_register (E-step + normal equations on the device, 6 x 6
+    solve / twist / stop rule on the library's host side).  It must follow the per-iteration Python path -- which
+    the reference's recorded transforms pin -- step by step, stop where that path stops, and repeat bit for bit."""
+    from hgmm_amd.hgmm.hgmm_gpu import GMMTree
+    g = load_golden("hgmm_reg_L2.npz")
+    L, lc = int(g["L"]), float(g["lambda_c"])
+    for deg in (10, 30):
+        tag = "rot%d_" % deg
+        gt = GMMTree(None, tree_level=L, lambda_c=lc, ctx=ctx)
+        gt.set_nodes(g["pi"], g["mu"], g["cov"])
+        res = gt.registration(g[tag + "target"], 5, 1.0e-4)            # no callbacks -> library loop
+        np.testing.assert_allclose(res.transformation.rot, g[tag + "final_rot"], atol=1e-8)
+        np.testing.assert_allclose(res.transformation.t, g[tag + "final_t"], atol=1e-8)
+        np.testing.assert_allclose(res.q, g[tag + "final_q"], rtol=1e-6)
+        # the trace of the library loop against the reference's per-iteration transforms (stored as inverses)
+        ctx.tree_set_nodes(L, g["pi"], g["mu"], g["cov"])
+        ctx.tree_set_target(g[tag + "target"])
+        rot, t, done, q, status, trace = ctx.tree_register(np.identity(3), np.zeros(3), 1.0, lc, 5, 1.0e-4,
+                                                            want_trace=True)
+        assert done == len(g[tag + "iter_rot"]) and status in (0, 1)
+        for k in range(done):
+            r_k, t_k = trace[k, :9].reshape(3, 3), trace[k, 9:12]
+            np.testing.assert_allclose(r_k.T, g[tag + "iter_rot"][k], rtol=0, atol=1e-8)
+            np.testing.assert_allclose(-(r_k.T @ t_k), g[tag + "iter_t"][k], rtol=0, atol=1e-8)
+        rot2, t2, done2, q2, status2, _ = ctx.tree_register(np.identity(3), np.zeros(3), 1.0, lc, 5, 1.0e-4)
+        assert done2 == done and status2 == status and q2 == q
+        assert np.array_equal(rot2, rot) and np.array_equal(t2, t)
+
+    # a longer run on the bunny: same trajectory and the same stopping iteration as the callback (Python) path
+    P = bunny[::6].astype(np.float64)
+    th = np.deg2rad(9.0)
+    Rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    target = P @ Rz.T + np.array([0.004, -0.002, 0.003])
+    gt = GMMTree(P, tree_level=3, lambda_c=0.01, ls=80, sig2=0.00034, ctx=ctx)
+    tr = []
+    gt.set_callbacks([lambda tf: tr.append((tf.rot.copy(), tf.t.copy()))])
+    res_py = gt.registration(target, maxiter=40, tol=1.0e-4)
+    gt2 = GMMTree(None, tree_level=3, lambda_c=0.01, ctx=ctx)
+    gt2.set_nodes(gt._mixingCoeff, gt._mean, gt._covar)
+    res_lib = gt2.registration(target, maxiter=40, tol=1.0e-4)
+    np.testing.assert_allclose(res_lib.transformation.rot, res_py.transformation.rot, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(res_lib.transformation.t, res_py.transformation.t, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(res_lib.q, res_py.q, rtol=1e-8, atol=1e-12)
+    ctx.tree_set_target(target)
+    _, _, done, _, status, _ = ctx.tree_register(np.identity(3), np.zeros(3), 1.0, 0.01, 40, 1.0e-4)
+    assert done == len(tr)
+    assert status == (1 if len(tr) < 40 else 0)
+    # budget split over two calls == one call (q_prev carried over)
+    r1, t1, d1, q1, s1, _ = ctx.tree_register(np.identity(3), np.zeros(3), 1.0, 0.01, 3, 0.0)
+    r2, t2, d2, q2, s2, _ = ctx.tree_register(r1, t1, 1.0, 0.01, 4, 0.0, q_prev=q1)
+    r7, t7, d7, q7, s7, _ = ctx.tree_register(np.identity(3), np.zeros(3), 1.0, 0.01, 7, 0.0)
+    assert d1 == 3 and d2 == 4 and d7 == 7
+    assert np.array_equal(r2, r7) and np.array_equal(t2, t7) and q2 == q7
