@@ -540,6 +540,16 @@ def rank_main(args):
         ctx.profile_enable(False)
         f_ms, f_n = ctx.profile_get("util_fill")
         out["roofline"]["store_stream_ceiling_GBs"] = 4 * N_POINTS * J_COMP / (f_ms / f_n * 1e-3) / 1e9
+        # ... and what the same bytes reach when they are written as 3200-byte ROWS (fillbench mode 5: a workgroup
+        # takes 4 consecutive rows per step, its waves split a row): the pattern class the E-step's output is in
+        ctx.util_fill(lr, 4.0, False, 5, 1)
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        for _ in range(10):
+            ctx.util_fill(lr, 4.0, False, 5, 1)
+        ctx.profile_enable(False)
+        f_ms, f_n = ctx.profile_get("util_fill")
+        out["roofline"]["row_pitch_store_ceiling_GBs"] = 4 * N_POINTS * J_COMP / (f_ms / f_n * 1e-3) / 1e9
         lr.free()
         for name, leg in (("bunny", bunny_leg), ("hgmm", hgmm_leg), ("tree_1M", tree_1m_leg), ("fullcov", fullcov_leg),
                           ("kmeans_init", kmeans_leg), ("registration", registration_leg)):

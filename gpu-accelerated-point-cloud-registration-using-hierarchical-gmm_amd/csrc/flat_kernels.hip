@@ -304,7 +304,7 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_kernel(
 // slots, at most one trailing single.
 // Measured (kbench, N = 1e6, J = 800, same box): single-row kernel, 2 workgroups/CU 0.672 ms;
 // 6 rows unpaired 0.603 ms; paired 4 / 6 / 8 rows 0.546 / 0.561 / 0.604 ms.  What counts is the number
-// of waves writing at once: 1024 waves (4 per workgroup, 1 workgroup per CU) 0.54 - 0.56 ms, 2048 waves
+// of waves writing at once (row-maximum loop): 1024 waves (4 per workgroup, 1 workgroup per CU) 0.54 - 0.56 ms, 2048 waves
 // 0.65 ms whether as 8 waves per workgroup or as 2 workgroups per CU, with 2 or 4 rows each.  The 4 rows of a
 // wave must be consecutive (one 12.8 KB run): dealing single rows round-robin over the waves (each wave's 4
 // rows 3.2 MB apart) drops to 0.86 ms.
@@ -1537,8 +1537,9 @@ static int launch_fused(hgmm_ctx* c, const int* done_flag, int* grid_out, int* v
     //    but 256 VGPRs + 4 AGPRs = one wave per SIMD, 0.46 - 0.48 ms; forced to two waves per SIMD it
     //    spills 372 B per lane, 0.43 ms; one row (248 VGPRs, two waves per SIMD) stays the best, 0.405 ms;
     //  * constant-shift log-sum-exp (HGMM_FUSED_CS, default on): see flat_fused_pk_kernel;
-    //    0.514 -> 0.440 ms.  The same change in the materialising E-step kernel gains nothing
-    //    (0.56 - 0.62 ms either way: that kernel is bound by the HBM write path, not by VALU).
+    //    0.514 -> 0.440 ms.  (Round 1 saw no gain from the same change in the materialising E-step; with one
+    //    workgroup per CU that kernel turned out to be issue-bound, and the shorter loop pays once the grid is cut
+    //    to 3/4 of the CUs -- see estep_rows_grid.)
     const bool cshift = env_flag("HGMM_FUSED_CS", true);
 #define FUSED_CASE(S)                                                                           \
     do {                                                                                        \

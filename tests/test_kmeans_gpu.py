@@ -94,6 +94,26 @@ def test_seeding_and_step_vs_oracle(ctx, n, k):
     assert changed2 == 0
 
 
+@pytest.mark.parametrize("n", [4_300_000, 16_900_000])
+def test_seeding_large_clouds_take_the_multi_group_paths(ctx, n):
+    """More than 1024 step workgroups (a thread of the tail owns two group sums) and more than 4096 (the group
+    prefix leaves LDS for global memory): seeds still the oracle's."""
+    k = 5
+    rs = np.random.RandomState(n % 1000)
+    X = rs.rand(n, 3) * [1.0, 2.0, 0.5]
+    Xc = X - X.mean(axis=0)
+    del X
+    ctx.set_points(Xc)
+    seeds = np.random.RandomState(1)
+    trials = okm.n_local_trials(k)
+    first = seeds.choice(n, p=np.ones(n) / n)
+    rand = seeds.uniform(size=(k - 1, trials))
+    ids, centres = ctx.kmeans_plusplus(k, first, rand)
+    o_centres, o_ids = okm.kmeans_plusplus(Xc, k, np.random.RandomState(1))
+    assert np.array_equal(ids, o_ids)
+    assert np.array_equal(centres, o_centres)
+
+
 def test_live_sklearn_agrees(ctx):
     sk = pytest.importorskip("sklearn.cluster")
     from hgmm_amd.kmeans import KMeans
