@@ -56,80 +56,122 @@ __device__ __forceinline__ double sym3_quad(double s00, double s01, double s02, 
     return fma(d2, s22 * d2, fma(d1, t1, d0 * t0));
 }
 
-// exp(y) for y <= 0, branch-free (the library exp costs ~30 instructions plus exec-mask branches per call):
-// y clamped to >= -708 (results stay normal; what the clamp changes is < 3.3e-308), n = round(y log2 e) by
-// the 1.5 * 2^52 trick, r = y - n ln 2 in two steps, degree-13 Taylor polynomial on |r| <= 0.347 (remainder
-// 4e-18), 2^n added into the exponent field.  Relative error ~1e-16.
-// Four values at a time: the Horner steps 13..3 of the four polynomials are written as ONE block of three-address
-// v_fma_f64, interleaved so that consecutive instructions are independent (hipcc picks the two-address
-// v_fmac_f64 and pays a v_mov_b64 per step to copy the coefficient into the destination; a block per
-// polynomial is a chain of dependent fp64 fmas, 8+ cycles apart, that two waves per SIMD cannot cover).
-__device__ __forceinline__ void exp_nonpos4(const double (&yin)[4], double (&out)[4]) {
-    constexpr double MAGIC = 6755399441055744.0;          // 1.5 * 2^52
-    constexpr double LOG2E = 1.4426950408889634074, LN2_HI = 6.93147180369123816490e-01,
-                     LN2_LO = 1.90821492927058770002e-10;
-    double t[4], r[4], p[4];
+// exp(y) for y <= 0, branch-free, <= 1 ulp, four (or two) independent evaluations interleaved in one asm block so
+// that the dependent v_fma_f64 chain of one hides behind the others.
+//   n = round(y * 128 / ln 2)  (add / subtract 1.5 * 2^52: the integer sits in the low mantissa word),
+//   r = y - n ln2/128 in two pieces (|r| <= ln2/256 = 0.0027),   n = 128 m + j,
+//   exp(y) = 2^m * T[j] * e^r,  T[j] = 2^(j/128) from a 1 KB table in LDS (any 64 lanes hit distinct banks or the
+//   same word), e^r - 1 = r (1 + r (1/2 + r (1/6 + r (1/24 + r/120)))): degree 5 is enough at that range
+//   (r^6/720 < 6e-19), the result is formed as fma(T, e^r - 1, T) and 2^m goes into the exponent field.
+// 16 VALU instructions per value; the degree-13 polynomial on |r| <= ln2/2 that this replaces took 21.
+// Arguments below -708 are clamped (result < 3.3e-308, i.e. nothing); NaN comes back as garbage-free NaN.
+__device__ const double EXP2_TAB[128] = {
+    0x1.0000000000000p+0, 0x1.0163da9fb3335p+0, 0x1.02c9a3e778061p+0, 0x1.04315e86e7f85p+0,
+    0x1.059b0d3158574p+0, 0x1.0706b29ddf6dep+0, 0x1.0874518759bc8p+0, 0x1.09e3ecac6f383p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0cc922b7247f7p+0, 0x1.0e3ec32d3d1a2p+0, 0x1.0fb66affed31bp+0,
+    0x1.11301d0125b51p+0, 0x1.12abdc06c31ccp+0, 0x1.1429aaea92de0p+0, 0x1.15a98c8a58e51p+0,
+    0x1.172b83c7d517bp+0, 0x1.18af9388c8deap+0, 0x1.1a35beb6fcb75p+0, 0x1.1bbe084045cd4p+0,
+    0x1.1d4873168b9aap+0, 0x1.1ed5022fcd91dp+0, 0x1.2063b88628cd6p+0, 0x1.21f49917ddc96p+0,
+    0x1.2387a6e756238p+0, 0x1.251ce4fb2a63fp+0, 0x1.26b4565e27cddp+0, 0x1.284dfe1f56381p+0,
+    0x1.29e9df51fdee1p+0, 0x1.2b87fd0dad990p+0, 0x1.2d285a6e4030bp+0, 0x1.2ecafa93e2f56p+0,
+    0x1.306fe0a31b715p+0, 0x1.32170fc4cd831p+0, 0x1.33c08b26416ffp+0, 0x1.356c55f929ff1p+0,
+    0x1.371a7373aa9cbp+0, 0x1.38cae6d05d866p+0, 0x1.3a7db34e59ff7p+0, 0x1.3c32dc313a8e5p+0,
+    0x1.3dea64c123422p+0, 0x1.3fa4504ac801cp+0, 0x1.4160a21f72e2ap+0, 0x1.431f5d950a897p+0,
+    0x1.44e086061892dp+0, 0x1.46a41ed1d0057p+0, 0x1.486a2b5c13cd0p+0, 0x1.4a32af0d7d3dep+0,
+    0x1.4bfdad5362a27p+0, 0x1.4dcb299fddd0dp+0, 0x1.4f9b2769d2ca7p+0, 0x1.516daa2cf6642p+0,
+    0x1.5342b569d4f82p+0, 0x1.551a4ca5d920fp+0, 0x1.56f4736b527dap+0, 0x1.58d12d497c7fdp+0,
+    0x1.5ab07dd485429p+0, 0x1.5c9268a5946b7p+0, 0x1.5e76f15ad2148p+0, 0x1.605e1b976dc09p+0,
+    0x1.6247eb03a5585p+0, 0x1.6434634ccc320p+0, 0x1.6623882552225p+0, 0x1.68155d44ca973p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6c012750bdabfp+0, 0x1.6dfb23c651a2fp+0, 0x1.6ff7df9519484p+0,
+    0x1.71f75e8ec5f74p+0, 0x1.73f9a48a58174p+0, 0x1.75feb564267c9p+0, 0x1.780694fde5d3fp+0,
+    0x1.7a11473eb0187p+0, 0x1.7c1ed0130c132p+0, 0x1.7e2f336cf4e62p+0, 0x1.80427543e1a12p+0,
+    0x1.82589994cce13p+0, 0x1.8471a4623c7adp+0, 0x1.868d99b4492edp+0, 0x1.88ac7d98a6699p+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8cf3216b5448cp+0, 0x1.8f1ae99157736p+0, 0x1.9145b0b91ffc6p+0,
+    0x1.93737b0cdc5e5p+0, 0x1.95a44cbc8520fp+0, 0x1.97d829fde4e50p+0, 0x1.9a0f170ca07bap+0,
+    0x1.9c49182a3f090p+0, 0x1.9e86319e32323p+0, 0x1.a0c667b5de565p+0, 0x1.a309bec4a2d33p+0,
+    0x1.a5503b23e255dp+0, 0x1.a799e1330b358p+0, 0x1.a9e6b5579fdbfp+0, 0x1.ac36bbfd3f37ap+0,
+    0x1.ae89f995ad3adp+0, 0x1.b0e07298db666p+0, 0x1.b33a2b84f15fbp+0, 0x1.b59728de5593ap+0,
+    0x1.b7f76f2fb5e47p+0, 0x1.ba5b030a1064ap+0, 0x1.bcc1e904bc1d2p+0, 0x1.bf2c25bd71e09p+0,
+    0x1.c199bdd85529cp+0, 0x1.c40ab5fffd07ap+0, 0x1.c67f12e57d14bp+0, 0x1.c8f6d9406e7b5p+0,
+    0x1.cb720dcef9069p+0, 0x1.cdf0b555dc3fap+0, 0x1.d072d4a07897cp+0, 0x1.d2f87080d89f2p+0,
+    0x1.d5818dcfba487p+0, 0x1.d80e316c98398p+0, 0x1.da9e603db3285p+0, 0x1.dd321f301b460p+0,
+    0x1.dfc97337b9b5fp+0, 0x1.e264614f5a129p+0, 0x1.e502ee78b3ff6p+0, 0x1.e7a51fbc74c83p+0,
+    0x1.ea4afa2a490dap+0, 0x1.ecf482d8e67f1p+0, 0x1.efa1bee615a27p+0, 0x1.f252b376bba97p+0,
+    0x1.f50765b6e4540p+0, 0x1.f7bfdad9cbe14p+0, 0x1.fa7c1819e90d8p+0, 0x1.fd3c22b8f71f1p+0,
+};
+constexpr int EXP_TAB_N = 128;
+// copy the table into LDS (first 128 threads of the workgroup; the caller synchronises)
+__device__ __forceinline__ void exp_tab_load(double* __restrict__ tab_lds) {
+    if (threadIdx.x < EXP_TAB_N) tab_lds[threadIdx.x] = EXP2_TAB[threadIdx.x];
+}
+
+#define HGMM_EXP_CONSTS                                                                                       \
+    constexpr double MAGIC = 6755399441055744.0;          /* 1.5 * 2^52 */                                      \
+    constexpr double INV = 184.6649652337873;             /* 128 / ln 2 */                                      \
+    constexpr double C_HI = 6.93147180369123816490e-01 / 128.0, C_LO = 1.90821492927058770002e-10 / 128.0
+
+__device__ __forceinline__ void exp_nonpos4(const double (&yin)[4], double (&out)[4], const double* __restrict__ tab) {
+    HGMM_EXP_CONSTS;
+    double r[4], T[4], q[4];
+    int m[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const double y = fmax(fmin(yin[k], 0.0), -708.0);
-        t[k] = fma(y, LOG2E, MAGIC);
-        const double nf = t[k] - MAGIC;
-        r[k] = fma(nf, -LN2_LO, fma(nf, -LN2_HI, y));
+        const double t = fma(y, INV, MAGIC);
+        const double nf = t - MAGIC;
+        r[k] = fma(nf, -C_LO, fma(nf, -C_HI, y));
+        const int n = __double2loint(t);                  // low mantissa word of t = n (two's complement)
+        T[k] = tab[n & (EXP_TAB_N - 1)];
+        m[k] = n >> 7;
     }
-#define HGMM_H4(C)                                                                                  \
-    "v_fma_f64 %0, %0, %4, " C "\n\tv_fma_f64 %1, %1, %5, " C "\n\tv_fma_f64 %2, %2, %6, " C          \
-    "\n\tv_fma_f64 %3, %3, %7, " C "\n\t"
-    asm("v_fma_f64 %0, %8, %4, %9\n\tv_fma_f64 %1, %8, %5, %9\n\tv_fma_f64 %2, %8, %6, %9\n\t"
-        "v_fma_f64 %3, %8, %7, %9\n\t"
-        HGMM_H4("%10") HGMM_H4("%11") HGMM_H4("%12") HGMM_H4("%13") HGMM_H4("%14") HGMM_H4("%15") HGMM_H4("%16")
-        HGMM_H4("%17") HGMM_H4("%18")
-        : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3])
-        : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(1.0 / 6227020800.0), "v"(1.0 / 479001600.0),
-          "v"(1.0 / 39916800.0), "v"(1.0 / 3628800.0), "v"(1.0 / 362880.0), "v"(1.0 / 40320.0), "v"(1.0 / 5040.0),
-          "v"(1.0 / 720.0), "v"(1.0 / 120.0), "v"(1.0 / 24.0), "v"(1.0 / 6.0));
-#undef HGMM_H4
+    // (one block of three-address v_fma_f64, consecutive instructions independent: hipcc would pick the two-address
+    //  v_fmac_f64 and pay a v_mov_b64 per step, and a block per value is a chain of dependent fp64 fmas)
+    asm("v_fma_f64 %0, %4, %12, %13\n\tv_fma_f64 %1, %5, %12, %13\n\tv_fma_f64 %2, %6, %12, %13\n\t"
+        "v_fma_f64 %3, %7, %12, %13\n\t"
+        "v_fma_f64 %0, %0, %4, %14\n\tv_fma_f64 %1, %1, %5, %14\n\tv_fma_f64 %2, %2, %6, %14\n\t"
+        "v_fma_f64 %3, %3, %7, %14\n\t"
+        "v_fma_f64 %0, %0, %4, 0.5\n\tv_fma_f64 %1, %1, %5, 0.5\n\tv_fma_f64 %2, %2, %6, 0.5\n\t"
+        "v_fma_f64 %3, %3, %7, 0.5\n\t"
+        "v_fma_f64 %0, %0, %4, 1.0\n\tv_fma_f64 %1, %1, %5, 1.0\n\tv_fma_f64 %2, %2, %6, 1.0\n\t"
+        "v_fma_f64 %3, %3, %7, 1.0\n\t"
+        "v_mul_f64 %0, %0, %4\n\tv_mul_f64 %1, %1, %5\n\tv_mul_f64 %2, %2, %6\n\tv_mul_f64 %3, %3, %7\n\t"
+        "v_fma_f64 %0, %8, %0, %8\n\tv_fma_f64 %1, %9, %1, %9\n\tv_fma_f64 %2, %10, %2, %10\n\t"
+        "v_fma_f64 %3, %11, %3, %11"
+        : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3])
+        : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]),
+          "v"(1.0 / 120.0), "v"(1.0 / 24.0), "v"(1.0 / 6.0));
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        double q = fma(p[k], r[k], 0.5);
-        q = fma(q, r[k], 1.0);
-        q = fma(q, r[k], 1.0);
-        const int n = __double2loint(t[k]);               // low mantissa word of t = n (two's complement)
-        out[k] = __hiloint2double(__double2hiint(q) + (n << 20), __double2loint(q));
-    }
+    for (int k = 0; k < 4; ++k)
+        out[k] = __hiloint2double(__double2hiint(q[k]) + (m[k] << 20), __double2loint(q[k]));
 }
 
-// Two values at a time (same arithmetic; used where a thread has only two independent arguments).
-__device__ __forceinline__ void exp_nonpos2(const double (&yin)[2], double (&out)[2]) {
-    const double y4[4] = {yin[0], yin[1], yin[0], yin[1]};
-    constexpr double MAGIC = 6755399441055744.0;
-    constexpr double LOG2E = 1.4426950408889634074, LN2_HI = 6.93147180369123816490e-01,
-                     LN2_LO = 1.90821492927058770002e-10;
-    double t[2], r[2], p[2];
+__device__ __forceinline__ void exp_nonpos2(const double (&yin)[2], double (&out)[2], const double* __restrict__ tab) {
+    HGMM_EXP_CONSTS;
+    double r[2], T[2], q[2];
+    int m[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const double y = fmax(fmin(y4[k], 0.0), -708.0);
-        t[k] = fma(y, LOG2E, MAGIC);
-        const double nf = t[k] - MAGIC;
-        r[k] = fma(nf, -LN2_LO, fma(nf, -LN2_HI, y));
+        const double y = fmax(fmin(yin[k], 0.0), -708.0);
+        const double t = fma(y, INV, MAGIC);
+        const double nf = t - MAGIC;
+        r[k] = fma(nf, -C_LO, fma(nf, -C_HI, y));
+        const int n = __double2loint(t);
+        T[k] = tab[n & (EXP_TAB_N - 1)];
+        m[k] = n >> 7;
     }
-#define HGMM_H2(C) "v_fma_f64 %0, %0, %2, " C "\n\tv_fma_f64 %1, %1, %3, " C "\n\t"
-    asm("v_fma_f64 %0, %4, %2, %5\n\tv_fma_f64 %1, %4, %3, %5\n\t"
-        HGMM_H2("%6") HGMM_H2("%7") HGMM_H2("%8") HGMM_H2("%9") HGMM_H2("%10") HGMM_H2("%11") HGMM_H2("%12")
-        HGMM_H2("%13") HGMM_H2("%14")
-        : "=&v"(p[0]), "=&v"(p[1])
-        : "v"(r[0]), "v"(r[1]), "v"(1.0 / 6227020800.0), "v"(1.0 / 479001600.0), "v"(1.0 / 39916800.0),
-          "v"(1.0 / 3628800.0), "v"(1.0 / 362880.0), "v"(1.0 / 40320.0), "v"(1.0 / 5040.0), "v"(1.0 / 720.0),
-          "v"(1.0 / 120.0), "v"(1.0 / 24.0), "v"(1.0 / 6.0));
-#undef HGMM_H2
+    asm("v_fma_f64 %0, %2, %6, %7\n\tv_fma_f64 %1, %3, %6, %7\n\t"
+        "v_fma_f64 %0, %0, %2, %8\n\tv_fma_f64 %1, %1, %3, %8\n\t"
+        "v_fma_f64 %0, %0, %2, 0.5\n\tv_fma_f64 %1, %1, %3, 0.5\n\t"
+        "v_fma_f64 %0, %0, %2, 1.0\n\tv_fma_f64 %1, %1, %3, 1.0\n\t"
+        "v_mul_f64 %0, %0, %2\n\tv_mul_f64 %1, %1, %3\n\t"
+        "v_fma_f64 %0, %4, %0, %4\n\tv_fma_f64 %1, %5, %1, %5"
+        : "=&v"(q[0]), "=&v"(q[1])
+        : "v"(r[0]), "v"(r[1]), "v"(T[0]), "v"(T[1]), "v"(1.0 / 120.0), "v"(1.0 / 24.0), "v"(1.0 / 6.0));
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        double q = fma(p[k], r[k], 0.5);
-        q = fma(q, r[k], 1.0);
-        q = fma(q, r[k], 1.0);
-        const int n = __double2loint(t[k]);
-        out[k] = __hiloint2double(__double2hiint(q) + (n << 20), __double2loint(q));
-    }
+    for (int k = 0; k < 2; ++k)
+        out[k] = __hiloint2double(__double2hiint(q[k]) + (m[k] << 20), __double2loint(q[k]));
 }
+#undef HGMM_EXP_CONSTS
 
 // ------------------------------------------------------------------------------------------
 // per-node preparation
@@ -260,6 +302,8 @@ __global__ __launch_bounds__(CH) void tree_estep_kernel(
     if (done && *done) return;            // the level converged in an earlier iteration of this batch
     const int c = blockIdx.x;
     if (c >= *n_chunks) return;
+    __shared__ double exp_tab[EXP_TAB_N];
+    exp_tab_load(exp_tab);                         // (synchronised below, once the points' loads are on their way)
     const int p = chunk_desc[3 * c + 0], begin = chunk_desc[3 * c + 1], end = chunk_desc[3 * c + 2];
     // node id of the parent: level 0 -> pseudo-parent -1; child(j) = 8 (j + 1)
     const int64_t parent_node = (level == 0) ? -1 : parent_level_first + p;
@@ -268,6 +312,7 @@ __global__ __launch_bounds__(CH) void tree_estep_kernel(
     const bool active = i < end;
     double x0 = 0.0, x1 = 0.0, x2 = 0.0;
     if (active) { x0 = xs[i]; x1 = xs[n_pad + i]; x2 = xs[2 * n_pad + i]; }
+    __syncthreads();                               // exp_tab
 
     double g[8];
     double den = 0.0;
@@ -283,8 +328,8 @@ __global__ __launch_bounds__(CH) void tree_estep_kernel(
         }
         const double ya[4] = {yv[0], yv[1], yv[2], yv[3]}, yb[4] = {yv[4], yv[5], yv[6], yv[7]};
         double ea[4], eb[4];
-        exp_nonpos4(ya, ea);
-        exp_nonpos4(yb, eb);
+        exp_nonpos4(ya, ea, exp_tab);
+        exp_nonpos4(yb, eb, exp_tab);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { ev[k] = ea[k]; ev[4 + k] = eb[k]; }
 #pragma unroll
@@ -444,6 +489,8 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
     if (done && *done) return;
     __shared__ double tile[LL_TILE][10];
     __shared__ double shq[CH / 64];
+    __shared__ double exp_tab[EXP_TAB_N];
+    exp_tab_load(exp_tab);                                 // (the tile loop's first barrier covers it)
     int64_t i[PTS];
     bool active[PTS];
     double x0[PTS], x1[PTS], x2[PTS], tot[PTS];
@@ -488,18 +535,18 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
             if (__any(need)) {
                 if constexpr (PTS == 4) {
                     double e[4];
-                    exp_nonpos4(yv, e);
+                    exp_nonpos4(yv, e, exp_tab);
 #pragma unroll
                     for (int p = 0; p < 4; ++p) tot[p] = fma(wL, e[p], tot[p]);
                 } else if constexpr (PTS == 2) {
                     double e[2];
-                    exp_nonpos2(yv, e);
+                    exp_nonpos2(yv, e, exp_tab);
                     tot[0] = fma(wL, e[0], tot[0]);
                     tot[1] = fma(wL, e[1], tot[1]);
                 } else {
                     const double y2[2] = {yv[0], yv[0]};
                     double e[2];
-                    exp_nonpos2(y2, e);
+                    exp_nonpos2(y2, e, exp_tab);
                     tot[0] = fma(wL, e[0], tot[0]);
                 }
             }
@@ -1627,7 +1674,7 @@ __host__ __device__ inline int ft_ldg(int J16) {        // doubles per point row
     return (J16 + 127) / 128 * 128 + 16;                // for whole 128-column steps (tail columns stay 0)
 }
 inline size_t ft_lds_bytes(int J16) {
-    return sizeof(double) * ((size_t)FT_P * ft_ldg(J16) + 16 * FT_LDF + 2 * FT_P + J16 + 2 * 3 * FT_P);
+    return sizeof(double) * ((size_t)FT_P * ft_ldg(J16) + 16 * FT_LDF + 2 * FT_P + J16 + 2 * 3 * FT_P + EXP_TAB_N);
 }
 
 template <int CPL>
@@ -1645,8 +1692,10 @@ __global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
     double* TOT = INV + FT_P;                     // [FT_P] sum over the components with pi >= eps (-1: dead point)
     double* WL = TOT + FT_P;                      // [J16] 1.0 where pi_j >= eps (the component counts towards q)
     double* XS = WL + J16;                        // [2][3][FT_P] the tile's coordinates, double-buffered
+    double* EXPT = XS + 2 * 3 * FT_P;             // [128] 2^(j/128) for exp_nonpos4
     const int w = wave_in_block(), lane = lane_id();
     const int tid = (int)threadIdx.x;
+    exp_tab_load(EXPT);                           // (the barrier behind the WL / G initialisation covers it)
 
     // this lane's components: slot 0 = tid; slot 1 (J16 > 512) = tid + 512.  When the last wave of slot 1 has at
     // most 32 components left, its two half-waves take the SAME components for 8 points each instead of leaving
@@ -1722,7 +1771,7 @@ __global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
                 const double d0 = X[pt[k]] - m0[c], d1 = X[FT_P + pt[k]] - m1[c], d2 = X[2 * FT_P + pt[k]] - m2[c];
                 y[k] = sym3_quad(s00[c], s01[c], s02[c], s11[c], s12[c], s22[c], d0, d1, d2);
             }
-            exp_nonpos4(y, e);
+            exp_nonpos4(y, e, EXPT);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int c = c_of(k);
