@@ -1250,7 +1250,7 @@ __device__ inline void finalize_component(int j, const double* __restrict__ stat
 }
 
 __device__ inline void ctl_update(const double* __restrict__ stats, int Jpad, float* lls, int lls_cap,
-                                  float tol, int* ctl, float* ctl_f) {
+                                  float tol, int* ctl, float* ctl_f, int* stop_out) {
     const double n_total = stats[FLAT_NSTAT * Jpad + 1];
     const float ll = (float)(stats[FLAT_NSTAT * Jpad] / n_total);
     const int it = ctl[1];
@@ -1258,28 +1258,35 @@ __device__ inline void ctl_update(const double* __restrict__ stats, int Jpad, fl
     const float change = ll - ctl_f[0];          // prev starts at -inf (gmm_impl.py:120)
     ctl_f[0] = ll;
     ctl[1] = it + 1;
-    if (fabsf(change) < tol) { ctl[0] = 1; ctl[2] = 1; }
+    if (fabsf(change) < tol) { *stop_out = 1; ctl[2] = 1; }
 }
 
-// single workgroup (Jpad <= 1024): M-step + next packed table + stop rule in one launch.  Like the reduction this is
-// a latency chain between two iterations: the stop flag is fetched WITH the statistics and only gates the stores, and
-// the packed table is formed from the registers that hold the new parameters (no store -> barrier -> re-load).
-__global__ void flat_finalize_kernel(const double* __restrict__ stats,
+// M-step + next packed table + stop rule in one launch (Jpad <= 1024: Jpad / 256 workgroups, a component per thread).
+// Like the reduction this is a latency chain between two iterations: the stop flag is fetched WITH the statistics
+// and only gates the stores, the packed table is formed from the registers that hold the new parameters (no store
+// -> barrier -> re-load), and the ~800 fp64 instructions per component (divides, square roots, four logarithms)
+// are spread over several CUs instead of queueing 16 waves deep on one.
+// The stop flag is double-buffered by iteration parity: the launch of iteration k reads `stop` = flag[k & 1] -- which
+// nothing in this launch writes -- and thread 0 records its verdict in `stop_next` = flag[(k + 1) & 1], the word
+// the kernels of iteration k + 1 look at.  (With ONE flag a workgroup that starts late could see the verdict of its
+// own launch and skip its share of the update.)
+__global__ __launch_bounds__(256) void flat_finalize_kernel(const double* __restrict__ stats,
                                      const float* __restrict__ centre /*[3][Jpad] or pack mu rows*/,
                                      int J, int Jpad, int cov_type, int variant,
                                      float* mu, float* cov, float* w, float* inv, float* pack,
                                      float* lls, int lls_cap, float tol, int* ctl, float* ctl_f,
-                                     const int* stop /*never null: ctl, or the always-zero word*/) {
-    const int j = threadIdx.x;
+                                     const int* stop /*never null*/, int* stop_next /*null: no device loop*/) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int done = __hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // vector load, see flat_reduce_kernel
     FlatComponent r = {};
     if (j < J) r = finalize_values(j, stats, centre, Jpad, cov_type, variant);
-    // every thread has read `centre` (= the mu rows of pack) and ctl[0] before anybody overwrites them
-    __syncthreads();
-    if (done) return;
+    if (done) {
+        if (j == 0 && stop_next) *stop_next = 1;           // stays stopped
+        return;
+    }
     if (j < J) store_component(j, r, cov_type, mu, cov, w, inv);
     if (pack && j < Jpad) pack_values(j, j < J, Jpad, variant, r.mu, r.inv, r.w, pack);
-    if (j == 0 && ctl) ctl_update(stats, Jpad, lls, lls_cap, tol, ctl, ctl_f);
+    if (j == 0 && ctl) ctl_update(stats, Jpad, lls, lls_cap, tol, ctl, ctl_f, stop_next);
 }
 
 // many workgroups (large J): the stop rule moves to flat_ctl_kernel, launched afterwards, so no
@@ -1295,7 +1302,7 @@ __global__ void flat_finalize_mb_kernel(const double* __restrict__ stats, const 
 __global__ void flat_ctl_kernel(const double* __restrict__ stats, int Jpad, float* lls, int lls_cap, float tol,
                                 int* ctl, float* ctl_f) {
     if (ctl[0]) return;
-    ctl_update(stats, Jpad, lls, lls_cap, tol, ctl, ctl_f);
+    ctl_update(stats, Jpad, lls, lls_cap, tol, ctl, ctl_f, ctl);
 }
 
 __global__ void flat_ctl_init_kernel(int* ctl, float* ctl_f) {
@@ -1657,16 +1664,19 @@ static int enqueue_em_iteration(hgmm_ctx* c) {
         f.launched++;
         return HGMM_OK;
     }
-    HGMM_TRY(launch_fused(c, ctl, &grid, &valid_j));
-    HGMM_TRY(launch_reduce(c, grid, valid_j, true, ctl));
+    // stop flag of this iteration / of the next one (see flat_finalize_kernel): ctl[0] and ctl[3] in turn
+    int* stop = ctl + ((f.launched & 1) ? 3 : 0);
+    int* stop_next = ctl + ((f.launched & 1) ? 0 : 3);
+    HGMM_TRY(launch_fused(c, stop, &grid, &valid_j));
+    HGMM_TRY(launch_reduce(c, grid, valid_j, true, stop));
     // (reduction + finalisation in ONE launch -- the last workgroup to finish, found by a ticket, runs the
     //  M-step -- was measured no faster: 0.4253 vs 0.4254 ms per iteration at C3, 35 - 36 k vs 38 k it/s
     //  on bun000 J = 100: the serial tail in one 256-thread workgroup costs what the launch saved)
     // the statistics were centred about the means the E-step used = rows PK_MU.. of pack
-    flat_finalize_kernel<<<1, f.Jpad, 0, c->stream>>>(
+    flat_finalize_kernel<<<f.Jpad / 256, 256, 0, c->stream>>>(
         c->f_stats.as<double>(), c->f_pack.as<float>() + PK_MU * f.Jpad, f.J, f.Jpad, f.cov_type,
         f.variant, c->f_mu.as<float>(), c->f_cov.as<float>(), c->f_w.as<float>(), c->f_inv.as<float>(),
-        c->f_pack.as<float>(), c->f_lls.as<float>(), f.lls_cap, f.tol, ctl, ctl_f, ctl);
+        c->f_pack.as<float>(), c->f_lls.as<float>(), f.lls_cap, f.tol, ctl, ctl_f, stop, stop_next);
     HGMM_HIP(c, hipGetLastError());
     f.launched++;
     return HGMM_OK;
@@ -1802,10 +1812,10 @@ extern "C" int hgmm_flat_mstep(hgmm_ctx* c, int cov_type, int variant, int J, co
             c->f_stats.as<double>(), hint, J, f.Jpad, cov_type, variant, c->f_mu.as<float>(),
             c->f_cov.as<float>(), c->f_w.as<float>(), nullptr, nullptr, nullptr);
     else
-        flat_finalize_kernel<<<1, f.Jpad, 0, c->stream>>>(
+        flat_finalize_kernel<<<f.Jpad / 256, 256, 0, c->stream>>>(
             c->f_stats.as<double>(), hint, J, f.Jpad, cov_type, variant, c->f_mu.as<float>(),
             c->f_cov.as<float>(), c->f_w.as<float>(), nullptr, nullptr, nullptr, 0, 0.f, nullptr, nullptr,
-            c->f_ctl.as<int>() + 16);
+            c->f_ctl.as<int>() + 16, nullptr);
     HGMM_HIP(c, hipGetLastError());
     HGMM_HIP(c, hipMemcpyAsync(mu_out, c->f_mu.p, sizeof(float) * 3 * J, hipMemcpyDeviceToHost, c->stream));
     HGMM_HIP(c, hipMemcpyAsync(cov_out, c->f_cov.p, sizeof(float) * cov_elems(cov_type, J),
