@@ -17,14 +17,15 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define REP64(X) REP8(REP8(X))
 
 enum { OP_FMA = 0, OP_PKFMA, OP_PKMUL, OP_PKADD, OP_EXP, OP_RCP, OP_DPPADD, OP_FMA64, OP_MFMA, OP_MFMA_PKFMA,
-       OP_MIX_FUSED, OP_PKFMA_DEP, OP_FMA_DEP, OP_ADD, OP_COUNT };
+       OP_MIX_FUSED, OP_PKFMA_DEP, OP_FMA_DEP, OP_ADD, OP_MIX_PK_SP, OP_MIX_SP_EXP, OP_COUNT };
 static const char* NAMES[] = {"v_fma_f32 (8 chains)", "v_pk_fma_f32 (8 chains)", "v_pk_mul_f32 (8 chains)",
                               "v_pk_add_f32 (8 chains)", "v_exp_f32 (8 chains)", "v_rcp_f32 (8 chains)",
                               "v_add_f32 dpp row_shr:1 (8 chains)", "v_fma_f64 (8 chains)",
                               "v_mfma_f32_16x16x4_f32 (4 acc)", "mfma_f32_16x16x4 + 8 v_pk_fma_f32 per mfma",
                               "fused-kernel mix: 24 pk + 2 exp per pair", "v_pk_fma_f32 (1 dependent chain)",
-                              "v_fma_f32 (1 dependent chain)", "v_add_f32 (8 chains)"};
-static const int INSTR_PER_BODY[] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 72, 26 * 4, 64, 64, 64};
+                              "v_fma_f32 (1 dependent chain)", "v_add_f32 (8 chains)",
+                              "4 v_pk_fma_f32 + 4 v_fma_f32 interleaved", "6 v_fma_f32 + 2 v_exp_f32 interleaved"};
+static const int INSTR_PER_BODY[] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 72, 26 * 4, 64, 64, 64, 64, 64};
 
 template <int OP>
 __global__ __launch_bounds__(256) void probe(float* out, long long* cyc, int iters) {
@@ -108,6 +109,19 @@ __global__ __launch_bounds__(256) void probe(float* out, long long* cyc, int ite
                  : "v"(ka), "v"(kb));
                 MF(m0) MF(m1) MF(m2) MF(m3)
             }
+        } else if (OP == OP_MIX_PK_SP) {
+            // do packed (64-bit datapath) and plain fp32 operations share one pipe?
+            REP8(asm volatile("v_pk_fma_f32 %0, %0, %8, %9\n v_fma_f32 %4, %4, %10, %11\n v_pk_fma_f32 %1, %1, %8, %9\n"
+                              "v_fma_f32 %5, %5, %10, %11\n v_pk_fma_f32 %2, %2, %8, %9\n v_fma_f32 %6, %6, %10, %11\n"
+                              "v_pk_fma_f32 %3, %3, %8, %9\n v_fma_f32 %7, %7, %10, %11\n"
+                              : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7)
+                              : "v"(ka), "v"(kb), "v"(fa), "v"(fb));)
+        } else if (OP == OP_MIX_SP_EXP) {
+            REP8(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n"
+                              "v_exp_f32 %6, %6\n v_fma_f32 %3, %3, %8, %9\n v_fma_f32 %4, %4, %8, %9\n"
+                              "v_fma_f32 %5, %5, %8, %9\n v_exp_f32 %7, %7\n"
+                              : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(s4), "+v"(s5), "+v"(s6), "+v"(s7)
+                              : "v"(fa), "v"(fb));)
         } else if (OP == OP_MIX_FUSED) {
             // the instruction mix of one component pair of flat_fused_pk_kernel, 4 pairs per body
 #pragma unroll
@@ -169,6 +183,17 @@ int main() {
     hipMalloc(&out, sizeof(float) * 1024 * 256);
     hipMalloc(&cyc, sizeof(long long) * 1024 * 4);
     const int iters = 4000;
+    if (getenv("VALUBENCH_MIX")) {                 // the pipe-sharing questions only, 1..4 waves per SIMD
+        for (int blocks : {256, 512, 768, 1024}) {
+            run<OP_FMA>(blocks, iters, out, cyc);
+            run<OP_PKFMA>(blocks, iters, out, cyc);
+            run<OP_EXP>(blocks, iters, out, cyc);
+            run<OP_MIX_PK_SP>(blocks, iters, out, cyc);
+            run<OP_MIX_SP_EXP>(blocks, iters, out, cyc);
+            run<OP_MIX_FUSED>(blocks, iters, out, cyc);
+        }
+        return 0;
+    }
     for (int rep = 0; rep < 2; ++rep)
         for (int blocks : {256, 512}) {
             run<OP_FMA>(blocks, iters, out, cyc);
