@@ -628,6 +628,62 @@ __global__ __launch_bounds__(KM_BLOCK) void kmeans_accum_kernel(const double* __
     }
 }
 
+// k <= 1024: the sums live in LDS instead of registers.  Every wave owns a private table [k][4] (x, y, z, count)
+// and walks its contiguous run of points; a point is ONE ds_add_f64 by four lanes (lane f adds feature f) at the
+// address its label selects -- no 16-way predicated register update, no exec-mask juggling: ~5 instructions per
+// point instead of ~80.  The table is private to the wave and LDS executes a wave's operations in order, so the
+// additions happen in point order: deterministic, like the register form.  The four tables of a workgroup are added
+// in fixed order on the way out.  One workgroup per CU (4 x 32 KB at k = 1024).
+__global__ __launch_bounds__(KM_BLOCK) void kmeans_accum_lds_kernel(const double* __restrict__ xs, int64_t n,
+                                                                    int64_t n_pad,
+                                                                    const int32_t* __restrict__ labels, int k_alloc,
+                                                                    double* __restrict__ partial,
+                                                                    const int* __restrict__ done) {
+    if (done && *done) return;
+    extern __shared__ double km_lds[];
+    const int lane = lane_id(), wave = wave_in_block();
+    const int tsz = k_alloc * 4;
+    double* T = km_lds + (size_t)wave * tsz;              // this wave's sums
+    double* S = km_lds + (size_t)4 * tsz + wave * 256;    // [64 points][4] staging of the current batch
+    for (int e = lane; e < tsz; e += 64) T[e] = 0.0;
+    const int64_t waves = (int64_t)gridDim.x * 4;
+    const int64_t per = ((n + waves - 1) / waves + 63) / 64 * 64;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t begin = gw * per;
+    const int64_t end = begin + per < n ? begin + per : n;
+    const int f = lane & 3;
+    for (int64_t base = begin; base < end; base += 64) {
+        const int64_t i = base + lane;
+        const bool ok = i < end;
+        const int64_t ii = ok ? i : 0;
+        const int lab = ok ? labels[ii] : 0;
+        const double x = xs[ii], y = xs[n_pad + ii], z = xs[2 * n_pad + ii];
+        S[lane * 4 + 0] = x; S[lane * 4 + 1] = y; S[lane * 4 + 2] = z; S[lane * 4 + 3] = 1.0;
+        const int cnt = (int)(end - base < 64 ? end - base : 64);
+        if (lane < 4) {
+            int t = 0;
+            for (; t + 8 <= cnt; t += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = S[(t + u) * 4 + f];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int r = __builtin_amdgcn_readlane(lab, t + u);
+                    (void)__hip_atomic_fetch_add(&T[r * 4 + f], v[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            for (; t < cnt; ++t) {
+                const int r = __builtin_amdgcn_readlane(lab, t);
+                (void)__hip_atomic_fetch_add(&T[r * 4 + f], S[t * 4 + f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    __syncthreads();
+    double* out = partial + (size_t)blockIdx.x * tsz;
+    for (int e = threadIdx.x; e < tsz; e += KM_BLOCK)
+        out[e] = (km_lds[e] + km_lds[tsz + e]) + (km_lds[2 * tsz + e] + km_lds[3 * tsz + e]);
+}
+
 // out[e] = sum over workgroups of partial[b][e], e < 4 k: 32 entries x 8 block slices per
 // workgroup, fixed order.  Workgroup 0 also adds up the inertia partials and appends
 // (inertia, n_changed) behind the sums.
@@ -845,6 +901,7 @@ extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const 
 namespace {
 struct KmLaunch {
     int nslot, k_alloc, nb_assign, nb_acc;
+    bool acc_lds;                                   // per-wave LDS tables (k <= 1024) instead of register slots
     double *c3, *c4, *out, *inertia_part;
     unsigned long long* changed;
     KmCtl* ctl;
@@ -856,7 +913,8 @@ int km_prepare(hgmm_ctx* c, int k, int reset_labels, KmLaunch& L) {
     L.nslot = k <= 256 ? 4 : KM_ACC_SLOTS;
     L.k_alloc = (k + 64 * L.nslot - 1) / (64 * L.nslot) * (64 * L.nslot);
     L.nb_assign = (int)km_nblk(n, 2 * KM_BLOCK);
-    L.nb_acc = (int)std::min<int64_t>(2 * (int64_t)c->cus, km_nblk(n, KM_BLOCK));
+    L.acc_lds = k <= 1024 && !std::getenv("HGMM_KMEANS_ACC_REGS");
+    L.nb_acc = (int)std::min<int64_t>((L.acc_lds ? 1 : 2) * (int64_t)c->cus, km_nblk(n, KM_BLOCK));
     HGMM_TRY(ensure(c, c->km_labels, sizeof(int32_t) * n_pad));
     HGMM_TRY(ensure(c, c->km_mind2, sizeof(double) * n_pad));
     HGMM_TRY(ensure(c, c->km_centres, sizeof(double) * (7 * (size_t)k + 3 * KM_MAX_TRIALS)));
@@ -889,6 +947,13 @@ int km_enqueue(hgmm_ctx* c, int k, const KmLaunch& L, const int* done) {
     }
     {
         ProfScope prof(c, HGMM_K_KMEANS_ACCUM);
+        if (L.acc_lds) {
+            const size_t lds = sizeof(double) * ((size_t)4 * 4 * L.k_alloc + 4 * 256);
+            HGMM_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&kmeans_accum_lds_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            kmeans_accum_lds_kernel<<<L.nb_acc, KM_BLOCK, lds, c->stream>>>(xs, n, n_pad, labels, L.k_alloc,
+                                                                           c->km_partial.as<double>(), done);
+        } else
         for (int slot0 = 0; slot0 * 64 < k; slot0 += L.nslot) {
             if (L.nslot == 4)
                 kmeans_accum_kernel<4><<<L.nb_acc, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, labels, slot0, L.k_alloc,
