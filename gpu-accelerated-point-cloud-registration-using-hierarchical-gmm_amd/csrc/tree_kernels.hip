@@ -647,32 +647,84 @@ __global__ __launch_bounds__(CH) void tree_hist_kernel(const int* __restrict__ c
     }
 }
 
-// one thread per parent: new segment sizes + per-chunk write offsets (relative to the parent's
-// segment start, children laid out k = 0..7 inside it)
-__global__ void tree_offsets_kernel(const int* __restrict__ hist, const int* __restrict__ chunk_first,
-                                    const int* __restrict__ seg_start, int P,
-                                    int* __restrict__ chunk_off /*[chunks][8]*/,
-                                    int* __restrict__ new_seg_start /*[8P+1]*/) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+struct OpAddInt { __device__ __forceinline__ int operator()(int a, int b) const { return a + b; } };
+// inclusive prefix sum of one int per lane over the wave (DPP row_shr with zero fill + row broadcasts, no LDS)
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_i32_zero(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, true);
+}
+__device__ __forceinline__ int wave_scan_i32(int v) {
+    v += dpp_i32_zero<0x111>(v);                  // row_shr:1
+    v += dpp_i32_zero<0x112>(v);                  // row_shr:2
+    v += dpp_i32_zero<0x114>(v);                  // row_shr:4
+    v += dpp_i32_zero<0x118>(v);                  // row_shr:8
+    v += dpp_i32_zero<DPP_ROW_BCAST15, 0xA>(v);
+    v += dpp_i32_zero<DPP_ROW_BCAST31, 0xC>(v);
+    return v;
+}
+
+// one WORKGROUP per parent: new segment sizes + per-chunk write offsets (relative to the parent's segment start,
+// children laid out k = 0..7 inside it).  Level 0 has ONE parent owning every chunk of the cloud (3907 at N = 1M):
+// a thread per parent walked them one by one, 0.3 ms of dependent loads per pass; here the chunks are spread over
+// the 256 threads, child totals by a reduction, offsets by a tiled scan.
+constexpr int OFF_BLOCK = 256;
+__global__ __launch_bounds__(OFF_BLOCK) void tree_offsets_kernel(const int* __restrict__ hist,
+                                                                 const int* __restrict__ chunk_first,
+                                                                 const int* __restrict__ seg_start, int P,
+                                                                 int* __restrict__ chunk_off /*[chunks][8]*/,
+                                                                 int* __restrict__ new_seg_start /*[8P+1]*/) {
+    const int p = blockIdx.x;
     if (p >= P) return;
+    __shared__ int wsum[OFF_BLOCK / 64][8];
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_in_block();
     const int c0 = chunk_first[p], c1 = chunk_first[p + 1];
-    int tot[8];
+    // pass 1: children's totals
+    int t[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) tot[k] = 0;
-    for (int c = c0; c < c1; ++c)
+    for (int k = 0; k < 8; ++k) t[k] = 0;
+    for (int c = c0 + tid; c < c1; c += OFF_BLOCK)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) tot[k] += hist[c * 8 + k];
-    int start[8];
-    int run = seg_start[p];
+        for (int k = 0; k < 8; ++k) t[k] += hist[c * 8 + k];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { start[k] = run; new_seg_start[8 * p + k] = run; run += tot[k]; }
-    if (p == P - 1) new_seg_start[8 * P] = run;
-    int acc[8];
+    for (int k = 0; k < 8; ++k) {
+        const int s = wave_reduce_i(t[k], OpAddInt());
+        if (lane == 0) wsum[w][k] = s;
+    }
+    __syncthreads();
+    int run[8];                                   // running write offset of child k (every thread keeps a copy)
+    {
+        int acc = seg_start[p];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = start[k];
-    for (int c = c0; c < c1; ++c)
+        for (int k = 0; k < 8; ++k) {
+            run[k] = acc;
+            if (tid == 0) new_seg_start[8 * p + k] = acc;
+            acc += (wsum[0][k] + wsum[1][k]) + (wsum[2][k] + wsum[3][k]);
+        }
+        if (tid == 0 && p == P - 1) new_seg_start[8 * P] = acc;
+    }
+    __syncthreads();
+    // pass 2: exclusive prefix over the parent's chunks, 256 at a time
+    for (int base = c0; base < c1; base += OFF_BLOCK) {
+        const int c = base + tid;
+        const bool ok = c < c1;
+        int v[8], incl[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { chunk_off[c * 8 + k] = acc[k]; acc[k] += hist[c * 8 + k]; }
+        for (int k = 0; k < 8; ++k) v[k] = ok ? hist[c * 8 + k] : 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            incl[k] = wave_scan_i32(v[k]);
+            if (lane == 63) wsum[w][k] = incl[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int off = 0;
+            for (int ww = 0; ww < w; ++ww) off += wsum[ww][k];
+            if (ok) chunk_off[c * 8 + k] = run[k] + off + incl[k] - v[k];
+            run[k] += (wsum[0][k] + wsum[1][k]) + (wsum[2][k] + wsum[3][k]);
+        }
+        __syncthreads();
+    }
 }
 
 // stable scatter of coordinates / permutation / (as the new parent) child index
@@ -1190,7 +1242,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
             // partition for the next level
             tree_hist_kernel<<<grid_chunks, CH, 0, c->stream>>>(cur, chunk_desc, n_chunks_dev, hist);
             int* seg_next = (seg_cur == seg_a) ? seg_b : seg_a;
-            tree_offsets_kernel<<<nblk(P, 128), 128, 0, c->stream>>>(hist, chunk_first, seg_cur, P, chunk_off, seg_next);
+            tree_offsets_kernel<<<P, OFF_BLOCK, 0, c->stream>>>(hist, chunk_first, seg_cur, P, chunk_off, seg_next);
             double* xs_next = (xs_cur == xs_b) ? xs_c : xs_b;     // A -> B -> C -> B -> ...
             int* perm_next = (perm_cur == perm_a) ? perm_b : perm_a;
             tree_scatter_kernel<<<grid_chunks, CH, 0, c->stream>>>(xs_cur, n_pad, perm_cur, cur, chunk_desc, n_chunks_dev,
