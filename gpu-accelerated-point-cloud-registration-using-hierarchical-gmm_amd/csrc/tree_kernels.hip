@@ -446,8 +446,22 @@ constexpr int LL_TILE = 256;
 // Stores a workgroup's share of q; with `ticket` the workgroup that finishes last also adds up all
 // shares -- in the same fixed order as tree_sum_kernel -- so that no separate reduction launch is
 // needed (the result does not depend on which workgroup happens to be last).
+struct TreeCtl { int done; int it; double prev_q; };
+struct TreeStop { TreeCtl* ctl; double ls; int max_iters; double* trace; int trace_cap; };   // ctl == nullptr: not here
+// the stop rule of one tree level (see tree_ctl_kernel); one thread
+__device__ __forceinline__ void tree_ctl_update(double q, const TreeStop& st) {
+    TreeCtl* ctl = st.ctl;
+    const int it = ctl->it;
+    if (it < st.trace_cap) st.trace[it] = q;
+    ctl->it = it + 1;
+    if (fabs(q - ctl->prev_q) < st.ls || it + 1 >= st.max_iters) ctl->done = 1;
+    ctl->prev_q = q;
+}
+// (With `stop.ctl` set the workgroup that finishes last also applies the level's stop rule -- every other workgroup
+//  of the launch has passed its own look at the flag by then -- which saves the one-thread launch per iteration.)
 __device__ __forceinline__ void store_block_q(double value, double* __restrict__ block_q, int nb,
-                                              unsigned int* __restrict__ ticket, double* __restrict__ q_out) {
+                                              unsigned int* __restrict__ ticket, double* __restrict__ q_out,
+                                              const TreeStop& stop) {
     __shared__ bool is_last;
     __shared__ double sh_fin[4];
     if (threadIdx.x == 0) {
@@ -468,8 +482,10 @@ __device__ __forceinline__ void store_block_q(double value, double* __restrict__
     if (lane_id() == 0) sh_fin[wave_in_block()] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        *q_out = sh_fin[0] + sh_fin[1] + sh_fin[2] + sh_fin[3];
+        const double q = sh_fin[0] + sh_fin[1] + sh_fin[2] + sh_fin[3];
+        *q_out = q;
         *ticket = 0u;
+        if (stop.ctl) tree_ctl_update(q, stop);
     }
 }
 
@@ -485,7 +501,7 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
                                                          double* __restrict__ block_q,
                                                          unsigned int* __restrict__ ticket,
                                                          double* __restrict__ q_out,
-                                                         const int* __restrict__ done) {
+                                                         const int* __restrict__ done, TreeStop stop) {
     if (done && *done) return;
     __shared__ double tile[LL_TILE][10];
     __shared__ double shq[CH / 64];
@@ -566,7 +582,7 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
     __syncthreads();
     double t = 0.0;
     for (int w = 0; w < CH / 64; ++w) t += shq[w];
-    store_block_q(t, block_q, (int)gridDim.x, ticket, q_out);
+    store_block_q(t, block_q, (int)gridDim.x, ticket, q_out, stop);
 }
 
 __global__ __launch_bounds__(CH) void tree_loglik_finish_kernel(const double* __restrict__ partial, int64_t n,
@@ -574,7 +590,7 @@ __global__ __launch_bounds__(CH) void tree_loglik_finish_kernel(const double* __
                                                                 double* __restrict__ block_q,
                                                                 unsigned int* __restrict__ ticket,
                                                                 double* __restrict__ q_out,
-                                                                const int* __restrict__ done) {
+                                                                const int* __restrict__ done, TreeStop stop) {
     if (done && *done) return;
     __shared__ double shq[CH / 64];
     const int64_t i = (int64_t)blockIdx.x * CH + threadIdx.x;
@@ -589,23 +605,17 @@ __global__ __launch_bounds__(CH) void tree_loglik_finish_kernel(const double* __
     __syncthreads();
     double t = 0.0;
     for (int w = 0; w < CH / 64; ++w) t += shq[w];
-    store_block_q(t, block_q, (int)gridDim.x, ticket, q_out);
+    store_block_q(t, block_q, (int)gridDim.x, ticket, q_out, stop);
 }
 
 // Device-side stop rule of one tree level (buildGMMTree, hgmm_cupy_cpu_working.py:149-157): record q,
 // stop when |q - prev_q| < ls (prev_q starts at 0) or after max_iters.  ctl = {done, iterations};
 // prev_q sits behind it.  Lets the host enqueue several iterations per synchronisation: the kernels of
 // an iteration that comes after the stop return at once.
-struct TreeCtl { int done; int it; double prev_q; };
 __global__ void tree_ctl_kernel(const double* __restrict__ q_dev, TreeCtl* __restrict__ ctl, double ls,
                                 int max_iters, double* __restrict__ trace, int trace_cap) {
     if (ctl->done) return;
-    const double q = *q_dev;
-    const int it = ctl->it;
-    if (it < trace_cap) trace[it] = q;
-    ctl->it = it + 1;
-    if (fabs(q - ctl->prev_q) < ls || it + 1 >= max_iters) ctl->done = 1;
-    ctl->prev_q = q;
+    tree_ctl_update(*q_dev, TreeStop{ctl, ls, max_iters, trace, trace_cap});
 }
 
 __global__ __launch_bounds__(256) void tree_sum_kernel(const double* __restrict__ v, int n, double* out) {
@@ -1203,22 +1213,27 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                 {
                     ProfScope prof(c, HGMM_K_TREE_LOGLIK);
                     // the last workgroup to finish adds up the per-block shares of q (store_block_q)
+                    // ... and, on a single GPU, applies the level's stop rule (with a communicator q is all-reduced
+                    // first and tree_ctl_kernel does it)
+                    const TreeStop no_stop{nullptr, 0.0, 0, nullptr, 0};
+                    const TreeStop stop = c->comm_on() ? no_stop : TreeStop{ctl, ls, max_iters_per_level, trace_dev, trace_cap};
 #define LL_LAUNCH(PTS)                                                                                     \
     tree_loglik_kernel<PTS><<<dim3(llblocks, chunks), CH, 0, c->stream>>>(                                 \
-        xs_cur, n, n_pad, d_prep, lb, n_level, per_chunk, ll_partial, block_q, q_ticket, q_dev, &ctl->done)
+        xs_cur, n, n_pad, d_prep, lb, n_level, per_chunk, ll_partial, block_q, q_ticket, q_dev, &ctl->done, \
+        chunks > 1 ? no_stop : stop)
                     if (ll_pts == 4) LL_LAUNCH(4);
                     else if (ll_pts == 2) LL_LAUNCH(2);
                     else LL_LAUNCH(1);
 #undef LL_LAUNCH
                     if (chunks > 1)
                         tree_loglik_finish_kernel<<<pblocks, CH, 0, c->stream>>>(ll_partial, n, n_pad, chunks, block_q,
-                                                                                q_ticket, q_dev, &ctl->done);
+                                                                                q_ticket, q_dev, &ctl->done, stop);
                 }
                 if (c->comm_on()) {
                     rc = allreduce_f64_oop(c, q_dev, q_g, 1);
                     if (rc != HGMM_OK) break;
+                    tree_ctl_kernel<<<1, 1, 0, c->stream>>>(q_g, ctl, ls, max_iters_per_level, trace_dev, trace_cap);
                 }
-                tree_ctl_kernel<<<1, 1, 0, c->stream>>>(q_g, ctl, ls, max_iters_per_level, trace_dev, trace_cap);
             }
             if (rc != HGMM_OK) break;
             TreeCtl h;
@@ -2465,7 +2480,8 @@ extern "C" int hgmm_tree_loglik(hgmm_ctx* c, int64_t T, const double* pi, const 
         tree_loglik_kernel<1><<<dim3(pblocks, 1), CH, 0, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
                                                                   c->t_prep.as<double>(), j_begin, n_level,
                                                                   (n_level + LL_TILE - 1) / LL_TILE * LL_TILE, nullptr,
-                                                                  block_q, nullptr, nullptr, nullptr);
+                                                                  block_q, nullptr, nullptr, nullptr,
+                                                                  TreeStop{nullptr, 0.0, 0, nullptr, 0});
     }
     tree_sum_kernel<<<1, 256, 0, c->stream>>>(block_q, pblocks, q_dev);
     HGMM_HIP(c, hipGetLastError());
