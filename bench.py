@@ -127,7 +127,9 @@ def launch_ranks(n, argv, script=None, extra_env=None, timeout=None):
 
 
 def self_launch(args, argv):
-    rc = launch_ranks(args.gpus, argv)
+    # (the ranks are told who started them: under this launcher a rank that cannot get an RCCL communicator exits and
+    #  everybody is restarted on the fallback; under an external launcher the ranks fall back in place)
+    rc = launch_ranks(args.gpus, argv, extra_env={"HGMM_BENCH_LAUNCHER": "self"})
     if rc == RCCL_INIT_FAILED and not os.environ.get("HGMM_BENCH_HOSTCOMM"):
         # RCCL could not build a communicator on this node: measure with the library's host shared-memory
         # all-reduce instead (every rank on its own GPU; statistics go device -> shared memory -> device)
@@ -402,10 +404,16 @@ def rank_main(args):
         from hgmm_amd import parallel
         try:
             parallel.attach_communicator(ctx, rank, world, transport="tcp")
+            collective = "RCCL ncclAllReduce(sum, float64) on the kernel stream"
         except Exception as e:
             sys.stderr.write("rank %d: RCCL communicator could not be created: %s\n" % (rank, e))
-            sys.exit(RCCL_INIT_FAILED)
-        collective = "RCCL ncclAllReduce(sum, float64) on the kernel stream"
+            if os.environ.get("HGMM_BENCH_LAUNCHER") == "self":
+                sys.exit(RCCL_INIT_FAILED)               # the launcher restarts every rank on the fallback
+            # started by an external launcher: communicator creation is collective, so every rank is here;
+            # carry on with the library's host shared-memory all-reduce rather than lose the measurement
+            ctx.comm_init_host(world, rank, "hgmm_bench_fb_%s" % os.environ.get("MASTER_PORT", "0"))
+            collective = "host shared memory (device -> shm -> device)"
+            fallback = True
 
     frame = synth_frame(rank)
     mu0, w0, cov0 = init_params(synth_frame(0) if rank else frame)

@@ -179,6 +179,18 @@ def test_self_launch_reports_a_failing_rank():
     assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
 
 
+def test_ranks_of_an_external_launcher_fall_back_in_place_when_rccl_is_unavailable():
+    """Started by something that is not bench.py's own launcher (torchrun in the driver's N > 1 runs): no restart is
+    possible, every rank switches to the host shared-memory all-reduce and the line is still produced."""
+    r = _run_launcher(2, "plain", ["--skip", "RCCL_BROKEN"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert "fallback" in d["config"] and "host shared memory" in d["config"]["collective"]
+
+
 def test_self_launch_retries_on_the_host_backend_when_rccl_is_unavailable():
     r = _run_launcher(2, "self", ["--skip", "RCCL_BROKEN"])
     assert r.returncode == 0, r.stderr[-2000:]
