@@ -55,9 +55,12 @@ MIN_TIMED_S = 1.0            # timed blocks repeat until this much timed work ha
 MAX_BLOCKS = 400
 RCCL_INIT_FAILED = 17        # exit code of a rank whose RCCL communicator could not be created
 
-# fused EM kernel, useful fp32 flops per (point, component) pair (fma = 2), DESIGN.md section 3:
-#   E: 3 sub + 3 mul + 3 fma = 12, exp 1, row sum 1;  M: r = e/S 1, s0 1, 3 sub + 3 mul + 3 add + 3 fma = 15
-FUSED_FLOP_PER_PAIR = 31
+# fused EM kernel, USEFUL fp32 flops per (point, component) pair (fma = 2), DESIGN.md section 3:
+#   E: 3 sub + 3 mul + 3 fma = 12, exp 1, row sum 1;  M: r = e/S 1, s0 1, 3 mul + 3 add + 3 fma = 12  -> 28
+# The kernel also RE-computes the three (x - mu) subtractions in its M-phase (keeping them costs more registers than
+# it saves, profiles/r02/fused_isa_accounting.md): 3 executed-but-redundant flops per pair, reported separately.
+FUSED_FLOP_PER_PAIR = 28
+FUSED_RECOMPUTED_FLOP_PER_PAIR = 3
 
 
 def synth_frame(seed, n=None):
@@ -244,7 +247,8 @@ def kmeans_leg(ctx):
            "fit_ms": (time.perf_counter() - t0) * 1e3, "lloyd_iterations": int(km.n_iter_),
            "seeding_ms": getattr(km, "seeding_ms_", None),
            "fit_ms_note": "first call on this context: includes the device buffers' allocation",
-           "sklearn_same_box_ms": "78395 (profiles/r01/kmbench.log; not re-timed here)"}
+           "sklearn_k800_1M": {"ms": 78395, "source": "profiles/r01/kmbench.log (round-1 box, NOT re-timed in this "
+                                                      "run: 78 s of host time; k = 100 on bun000 is re-timed below)"}}
     t0 = time.perf_counter()
     km = KMeans(n_clusters=J_COMP, random_state=1, max_iter=50, ctx=ctx).fit(X)
     out["fit_ms_warm"] = (time.perf_counter() - t0) * 1e3
@@ -352,6 +356,74 @@ def fullcov_leg(ctx):
     return out
 
 
+def estep_roofline_leg(ctx, lr, init, fitted, args):
+    """`roofline` of the JSON line: the materialising E-step kernel (the API's e_step(): log_resp[N,J] written once).
+    STEADY figure: mean hipEvent time of `--estep-reps` launches after 40 warm-up launches.  COLD figures: what a
+    caller of e_step() gets right after a fit -- the first launches behind the VALU-heavy fused loop run at other
+    clocks (up to 25 % slower): a 50-iteration fit, then 15 launches timed one by one."""
+    inv, mu, w = fitted
+    mu0, cov0, w0 = init
+    ctx.flat_train(50, 0.0, mu0, cov0, w0, "diag", "W")
+    cold = []
+    for _ in range(15):
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        ctx.flat_estep(inv, mu, w, "diag", "W", out=lr)
+        ctx.profile_enable(False)
+        cold.append(ctx.profile_get("flat_estep")[0])
+    for _ in range(25):
+        ctx.flat_estep(inv, mu, w, "diag", "W", out=lr)
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    for _ in range(args.estep_reps):
+        ctx.flat_estep(inv, mu, w, "diag", "W", out=lr)
+    ctx.profile_enable(False)
+    e_ms, e_n = ctx.profile_get("flat_estep")
+    avg_s = e_ms / e_n * 1e-3
+    alg_bytes = 12 * N_POINTS + 4 * N_POINTS * J_COMP + 4 * N_POINTS + 28 * J_COMP
+    achieved = alg_bytes / avg_s / 1e9
+    traffic, traffic_source = None, None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("flat_estep_bytes_per_launch")
+            traffic_source = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                              "kernel (separate runs; not re-measured inside this bench run)")
+        except Exception:
+            traffic = None
+    cold_avg = float(np.mean(cold))
+    return {"kernel": "materialising E-step (flat_estep kernel, log_resp[N,J] written once)",
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": e_n,
+            "steady_state_rule": "40 untimed launches (15 of them the cold ones below) precede the timed ones",
+            "first_launch_ms": cold[0], "cold_avg_ms": cold_avg, "cold_max_ms": float(np.max(cold)),
+            "cold_frac": alg_bytes / (cold_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "cold_rule": "15 launches timed one by one (hipEvents) straight after a 50-iteration fused fit"}
+
+
+def materialised_iteration_leg(ctx, lr, inv, mu, w):
+    """API-faithful iteration: e_step() (materialise log_resp) + m_step(X, exp(log_resp)) as the reference's module
+    functions are called (gmm_impl.py:105-116, 90-103)."""
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        ctx.flat_estep(inv, mu, w, "diag", "W", out=lr)
+        ctx.flat_mstep(lr.exp(), "diag", "W", centre_hint=mu)
+    ctx.synchronize()
+    api_dt = (time.perf_counter() - t0) / reps
+    ctx.profile_enable(False)
+    m_ms, m_n = ctx.profile_get("flat_mstep")
+    m_avg_s = m_ms / max(m_n, 1) * 1e-3
+    m_bytes = 4 * N_POINTS * J_COMP + 12 * N_POINTS
+    return {"it_per_s": 1.0 / api_dt, "mstep_avg_ms": m_avg_s * 1e3, "mstep_GBs": m_bytes / m_avg_s / 1e9,
+            "roofline": {"kernel": "flat_mstep_kernel<3,1>", "bound": "hbm", "unit": "GB/s",
+                         "achieved": m_bytes / m_avg_s / 1e9, "peak": HBM_PEAK_GBS,
+                         "frac": m_bytes / m_avg_s / 1e9 / HBM_PEAK_GBS}}
+
+
 def fused_roofline(avg_launch_s, cus):
     """VALU accounting of flat_fused_pk_kernel<13> from the code object (tools/isa_count.py)."""
     out = {"kernel": "flat_fused_pk_kernel<13> (constant-shift loop)", "bound": "valu", "unit": "TFLOP/s",
@@ -359,6 +431,9 @@ def fused_roofline(avg_launch_s, cus):
     flop = float(FUSED_FLOP_PER_PAIR) * N_POINTS * J_COMP
     out["achieved"] = flop / avg_launch_s / 1e12
     out["frac"] = out["achieved"] / FP32_VECTOR_PEAK_TF
+    out["recomputed_flop_per_pair"] = FUSED_RECOMPUTED_FLOP_PER_PAIR
+    out["frac_counting_recomputed"] = (out["achieved"] * (FUSED_FLOP_PER_PAIR + FUSED_RECOMPUTED_FLOP_PER_PAIR)
+                                       / FUSED_FLOP_PER_PAIR / FP32_VECTOR_PEAK_TF)
     try:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import isa_count
@@ -402,16 +477,33 @@ def rank_main(args):
         collective = "host shared memory (device -> shm -> device)"
     elif world > 1:
         from hgmm_amd import parallel
+        err = None
         try:
             parallel.attach_communicator(ctx, rank, world, transport="tcp")
-            collective = "RCCL ncclAllReduce(sum, float64) on the kernel stream"
         except Exception as e:
+            err = e
             sys.stderr.write("rank %d: RCCL communicator could not be created: %s\n" % (rank, e))
+        # Communicator creation can fail on SOME ranks only: the backend is chosen collectively.  Every rank reports
+        # (ok flag, hostname, rank 0 adds a job-unique token) over a plain TCP all-gather before anybody decides.
+        token = ("%08x" % (int.from_bytes(os.urandom(4), "little"))) if rank == 0 else ""
+        mine = ("%d|%s|%s" % (0 if err else 1, socket.gethostname(), token)).encode()
+        reports = [r.decode().split("|") for r in parallel.allgather_bytes_tcp(rank, world, mine)]
+        all_ok = all(r[0] == "1" for r in reports)
+        if all_ok:
+            collective = "RCCL ncclAllReduce(sum, float64) on the kernel stream"
+        else:
             if os.environ.get("HGMM_BENCH_LAUNCHER") == "self":
                 sys.exit(RCCL_INIT_FAILED)               # the launcher restarts every rank on the fallback
-            # started by an external launcher: communicator creation is collective, so every rank is here;
-            # carry on with the library's host shared-memory all-reduce rather than lose the measurement
-            ctx.comm_init_host(world, rank, "hgmm_bench_fb_%s" % os.environ.get("MASTER_PORT", "0"))
+            # started by an external launcher: nobody can restart the group, so every rank moves to the library's
+            # host shared-memory all-reduce in place -- possible only when all ranks share one host
+            hosts = sorted(set(r[1] for r in reports))
+            if len(hosts) > 1:
+                sys.stderr.write("rank %d: no RCCL communicator and the ranks span %s: the host shared-memory "
+                                 "fallback needs one host\n" % (rank, hosts))
+                sys.exit(RCCL_INIT_FAILED)
+            if not err:
+                ctx.comm_destroy()                        # this rank's communicator is useless without the others
+            ctx.comm_init_host(world, rank, "hgmm_bench_fb_%s" % reports[0][2])
             collective = "host shared memory (device -> shm -> device)"
             fallback = True
 
@@ -450,6 +542,19 @@ def rank_main(args):
     assert n_it == W + K * (len(blocks) + 1), (n_it, W, K, len(blocks))
     assert np.isfinite(lls).all()
 
+    # every rank must hold the same model after the joint fit: checksum of (mu, cov, w, inv) as raw 32-bit words
+    # (exact in float64), all-reduced with max and with min -- equal on all ranks iff max == min
+    words = np.concatenate([np.ascontiguousarray(a).view(np.uint32).ravel() for a in (mu, cov, w, inv)]).astype(np.float64)
+    sums = np.array([words.sum(), (words * (1.0 + np.arange(len(words)) % 1021)).sum()])
+    hi = ctx.allreduce(sums, op="max")
+    lo = -ctx.allreduce(-sums, op="max")
+    consistent = bool(np.array_equal(hi, lo))
+    if not consistent:
+        sys.stderr.write("rank %d: model checksums differ across ranks: max %s min %s\n" % (rank, hi, lo))
+    barrier()
+    if world > 1:
+        ctx.comm_destroy()                     # the legs below run on rank 0 alone
+
     out = None
     if rank == 0:
         med = float(np.median(blocks))
@@ -478,6 +583,10 @@ def rank_main(args):
                        "min_block_it_per_s": world * K / max(blocks), "max_block_it_per_s": world * K / min(blocks),
                        "rule": "value = world x K / median block; every block = K steps between barrier+sync pairs, "
                                "MAX over ranks"},
+            "it_per_s_per_gpu": K / med,
+            "rank_consistency": {"identical_model_on_all_ranks": consistent, "checksum": [float(v) for v in hi],
+                                 "rule": "sum of the raw 32-bit words of (mu, cov, w, inv_std), plain and position-"
+                                         "weighted, all-reduced with max and min over the ranks"},
             "fused_kernel": {"avg_ms": fused_avg_ms, "launches": fused_n,
                              "pairs_per_s": N_POINTS * J_COMP / (fused_avg_ms * 1e-3) if fused_avg_ms else None,
                              "last_lls": float(lls[-1])},
@@ -486,58 +595,19 @@ def rank_main(args):
             out["allreduce_us"] = 1e3 * ar_ms / max(ar_n, 1)
             out["allreduce_payload_bytes"] = 8 * (7 * 1024 + 2)        # 7 statistics x Jpad(=1024) + sum lpn + n
             out["allreduce_launches"] = ar_n
-            out["roofline"] = None
-            out["cpu_baseline"] = None
         if fused_avg_ms:
             out["roofline_fused"] = fused_roofline(fused_avg_ms * 1e-3, info["compute_units"])
+        if not consistent:
+            out["error"] = "ranks ended the joint fit with different parameters"
 
-    # ---- single-GPU legs --------------------------------------------------------------------------------
-    if rank == 0 and world == 1:
+    # ---- rank-0 legs (every N): the materialising E-step's roofline; N = 1: the other hot kernels at their configs ----
+    if rank == 0:
         lr = ctx.empty((N_POINTS, J_COMP), np.float32)
-        for _ in range(40):                                            # warm-up: launches 3-15 after the VALU-heavy
-            ctx.flat_estep(inv, mu, w, "diag", "W", out=lr)            # loop run up to 25 % slow (trace in profiles/r01)
-        ctx.profile_reset()
-        ctx.profile_enable(True)
-        for _ in range(args.estep_reps):
-            ctx.flat_estep(inv, mu, w, "diag", "W", out=lr)
-        ctx.profile_enable(False)
-        e_ms, e_n = ctx.profile_get("flat_estep")
-        avg_s = e_ms / e_n * 1e-3
-        alg_bytes = 12 * N_POINTS + 4 * N_POINTS * J_COMP + 4 * N_POINTS + 28 * J_COMP
-        achieved = alg_bytes / avg_s / 1e9
-        traffic, traffic_source = None, None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("flat_estep_bytes_per_launch")
-                traffic_source = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                  "kernel (separate runs; not re-measured inside this bench run)")
-            except Exception:
-                traffic = None
-        out["roofline"] = {"kernel": "materialising E-step (flat_estep kernel, log_resp[N,J] written once)",
-                           "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                           "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3,
-                           "launches": e_n}
-        # API-faithful iteration: E-step (materialise) + M-step from the materialised log_resp
-        ctx.profile_reset()
-        ctx.profile_enable(True)
-        t0 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
-            ctx.flat_estep(inv, mu, w, "diag", "W", out=lr)
-            ctx.flat_mstep(lr.exp(), "diag", "W", centre_hint=mu)
-        ctx.synchronize()
-        api_dt = (time.perf_counter() - t0) / reps
-        ctx.profile_enable(False)
-        m_ms, m_n = ctx.profile_get("flat_mstep")
-        m_avg_s = m_ms / max(m_n, 1) * 1e-3
-        m_bytes = 4 * N_POINTS * J_COMP + 12 * N_POINTS
-        out["materialised_iteration"] = {"it_per_s": 1.0 / api_dt, "mstep_avg_ms": m_avg_s * 1e3,
-                                         "mstep_GBs": m_bytes / m_avg_s / 1e9,
-                                         "roofline": {"kernel": "flat_mstep_kernel<3,1>", "bound": "hbm", "unit": "GB/s",
-                                                      "achieved": m_bytes / m_avg_s / 1e9, "peak": HBM_PEAK_GBS,
-                                                      "frac": m_bytes / m_avg_s / 1e9 / HBM_PEAK_GBS}}
+        out["roofline"] = estep_roofline_leg(ctx, lr, (mu0, cov0, w0), (inv, mu, w), args)
+        if world > 1:
+            out["roofline"]["scope"] = "one launch on rank 0's GPU after the joint fit (the kernel is rank-local)"
+    if rank == 0 and world == 1:
+        out["materialised_iteration"] = materialised_iteration_leg(ctx, lr, inv, mu, w)
         # what a pure 16-byte store stream of the same size reaches on this chip (write ceiling)
         # (best pure-store pattern found, tools/fillbench.py: one workgroup per CU, grid-stride)
         ctx.util_fill(lr, 0.0, False, 0, 1)
@@ -567,15 +637,18 @@ def rank_main(args):
                 out[name] = leg(ctx)
             except Exception as e:                                    # a side leg must not lose the headline line
                 out[name] = {"error": repr(e)}
+    if rank == 0:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_main()
-
-    if rank == 0:
+            if world > 1:
+                out["cpu_baseline"]["scope"] = "timed on rank 0's host cores after the joint fit (other ranks idle)"
+        else:
+            out["cpu_baseline"] = None
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
-        ctx.comm_destroy()
     ctx.close()
+    if not consistent:
+        sys.exit(3)
 
 
 def main():

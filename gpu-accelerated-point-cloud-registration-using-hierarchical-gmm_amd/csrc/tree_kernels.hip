@@ -1375,10 +1375,14 @@ static int reg_estep_fixed(hgmm_ctx* c, const double* rot, const double* t, doub
     int nbits = 1;
     while (std::ldexp(1.0, nbits) <= n_all) ++nbits;
     const int F = 62 - nbits;
+    // Invariant: momq_dirty == false  <=>  EVERY word of the buffer (its whole capacity, not just the words of the
+    // current tree) is zero.  Earlier uses may have been larger (hgmm_tree_estep writes 2 NMOM T + 1 two-word sums,
+    // hgmm_tree_reg_estep leaves [T][10] behind, a deeper tree has more nodes): clearing only this tree's words and
+    // then calling the buffer clean would let a later, larger use add onto stale sums.
     const size_t want = sizeof(unsigned long long) * NMOM * T;
     if (c->t_momq.cap < want || !c->t_momq.p || c->tree.momq_dirty) {
         HGMM_TRY(ensure(c, c->t_momq, want));
-        HGMM_HIP(c, hipMemsetAsync(c->t_momq.p, 0, want, c->stream));
+        HGMM_HIP(c, hipMemsetAsync(c->t_momq.p, 0, c->t_momq.cap, c->stream));
         c->tree.momq_dirty = false;
     }
     unsigned long long* mq = c->t_momq.as<unsigned long long>();

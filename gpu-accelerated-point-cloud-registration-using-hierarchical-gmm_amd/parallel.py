@@ -7,12 +7,11 @@ runs the same kernels, and the library all-reduces the per-cluster sufficient st
 the redundant, identical M-step.  This module only bootstraps the communicator: the 128-byte
 RCCL unique id has to travel from rank 0 to the other ranks once.
 
-Transports for that one message
-  * a plain TCP exchange (default; rank 0 listens on MASTER_ADDR:MASTER_PORT+offset) -- works the same
-    under ``torch.distributed.run`` (which only has to provide RANK / WORLD_SIZE / MASTER_*), under
-    ``bench.py``'s own launcher and under any other one-process-per-GPU launcher; no PyTorch involved;
-  * ``torch.distributed`` (gloo, CPU) on request (``transport="torch"``), for callers that already
-    hold a process group.
+Transport for that one message: a plain TCP exchange (rank 0 listens on MASTER_ADDR:MASTER_PORT+offset) --
+works the same under ``torch.distributed.run`` (which only has to provide RANK / WORLD_SIZE / MASTER_*), under
+``bench.py``'s own launcher and under any other one-process-per-GPU launcher.  No PyTorch anywhere in this
+package (a caller that already holds a torch process group can pass its own ``exchange`` callable to
+``attach_communicator``; tests/test_parallel_cpu.py shows one over gloo).
 """
 from __future__ import annotations
 
@@ -34,7 +33,8 @@ def shard_bounds(n: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-_MAGIC = b"HGMMUID1"
+_MAGIC = b"HGMMUID2"
+_ACK = b"HGMMACK2"
 PORT_OFFSETS = (37, 1037, 2037, 3037)       # tried in order when MASTER_PORT + offset is taken
 
 
@@ -62,17 +62,24 @@ def exchange_bytes_tcp(rank: int, world: int, payload: bytes | None, addr: str, 
             raise OSError("unique-id exchange: no free port among %s" % [port + o for o in PORT_OFFSETS])
         srv.listen(world)
         srv.settimeout(timeout)
+        served = 0
         try:
-            served = 0
             while served < world - 1:
-                conn, _ = srv.accept()
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    raise TimeoutError("unique-id exchange: only %d of %d ranks fetched the id from rank 0 within "
+                                       "%.0f s (%s:%d)" % (served, world - 1, timeout, addr, srv.getsockname()[1]))
                 with conn:
                     conn.settimeout(10.0)
                     try:
                         if _recv_exact(conn, len(_MAGIC)) != _MAGIC:
                             continue                      # not one of ours
                         conn.sendall(_MAGIC + struct.pack("<I", len(payload)) + payload)
-                        served += 1
+                        # a rank counts as served only once it has CONFIRMED the payload: a client that times out
+                        # or resets while reading retries, and must still find the listener
+                        if _recv_exact(conn, len(_ACK)) == _ACK:
+                            served += 1
                     except (ConnectionError, socket.timeout, OSError):
                         continue
         finally:
@@ -88,7 +95,9 @@ def exchange_bytes_tcp(rank: int, world: int, payload: bytes | None, addr: str, 
                     if _recv_exact(s, len(_MAGIC)) != _MAGIC:
                         continue
                     hdr = _recv_exact(s, 4)
-                    return _recv_exact(s, struct.unpack("<I", hdr)[0])
+                    data = _recv_exact(s, struct.unpack("<I", hdr)[0])
+                    s.sendall(_ACK)
+                    return data
             except (ConnectionError, socket.timeout, OSError):
                 continue
         if time.time() > deadline:
@@ -107,35 +116,87 @@ def _recv_exact(s, n):
     return buf
 
 
-def exchange_bytes_torch(rank: int, world: int, payload: bytes | None) -> bytes:
-    """Same, through torch.distributed's rendezvous (gloo backend, no GPU tensors)."""
-    import torch.distributed as dist
-    if not dist.is_initialized():
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    obj = [payload if rank == 0 else None]
-    dist.broadcast_object_list(obj, src=0)
-    return obj[0]
-
-
-def broadcast_from_rank0(rank: int, world: int, payload: bytes | None, transport: str = "auto",
-                         port_offset: int = 37) -> bytes:
+def broadcast_from_rank0(rank: int, world: int, payload: bytes | None, transport: str = "tcp",
+                         port_offset: int = 37, exchange=None) -> bytes:
+    """``exchange(rank, world, payload) -> bytes``: caller-provided transport (e.g. over an existing process group)."""
     if world == 1:
         return payload
-    if transport == "auto":
-        transport = "tcp"
-    if transport == "torch":
-        return exchange_bytes_torch(rank, world, payload)
+    if exchange is not None:
+        return exchange(rank, world, payload)
+    if transport not in ("auto", "tcp"):
+        raise ValueError("unknown transport %r (this package ships the TCP exchange only; pass exchange=...)" % transport)
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = int(os.environ.get("MASTER_PORT", "29500")) + port_offset
     return exchange_bytes_tcp(rank, world, payload, addr, port)
 
 
-def attach_communicator(ctx, rank: int | None = None, world: int | None = None, transport: str = "auto"):
+def allgather_bytes_tcp(rank: int, world: int, payload: bytes, port_offset: int = 137, timeout: float = 120.0):
+    """Every rank's (short) ``payload`` on every rank, in rank order: rank 0 collects them over plain TCP and sends
+    the list back.  Used to AGREE on decisions that must be collective (bench.py: which all-reduce backend to use
+    after a communicator could not be built on some rank)."""
+    if world == 1:
+        return [payload]
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("MASTER_PORT", "29500")) + port_offset
+    if rank == 0:
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((addr, port))
+        srv.listen(world)
+        srv.settimeout(timeout)
+        got = {0: payload}
+        conns = []
+        try:
+            while len(got) < world:
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    raise TimeoutError("all-gather: %d of %d ranks reported within %.0f s" % (len(got), world, timeout))
+                conn.settimeout(10.0)
+                try:
+                    if _recv_exact(conn, len(_MAGIC)) != _MAGIC:
+                        conn.close()
+                        continue
+                    r, n = struct.unpack("<II", _recv_exact(conn, 8))
+                    got[r] = _recv_exact(conn, n)
+                    conns.append(conn)
+                except (ConnectionError, socket.timeout, OSError):
+                    conn.close()
+            out = [got[r] for r in range(world)]
+            blob = b"".join(struct.pack("<I", len(b)) + b for b in out)
+            for conn in conns:
+                conn.sendall(struct.pack("<I", len(blob)) + blob)
+            return out
+        finally:
+            for conn in conns:
+                conn.close()
+            srv.close()
+    deadline = time.time() + timeout
+    while True:
+        try:
+            with socket.create_connection((addr, port), timeout=5.0) as s:
+                s.settimeout(timeout)
+                s.sendall(_MAGIC + struct.pack("<II", rank, len(payload)) + payload)
+                blob = _recv_exact(s, struct.unpack("<I", _recv_exact(s, 4))[0])
+                out, off = [], 0
+                while off < len(blob):
+                    n = struct.unpack("<I", blob[off:off + 4])[0]
+                    out.append(blob[off + 4:off + 4 + n])
+                    off += 4 + n
+                return out
+        except (ConnectionError, socket.timeout, OSError):
+            if time.time() > deadline:
+                raise TimeoutError("all-gather: rank 0 not reachable on %s:%d" % (addr, port))
+            time.sleep(0.05)
+
+
+def attach_communicator(ctx, rank: int | None = None, world: int | None = None, transport: str = "tcp",
+                        exchange=None):
     """Create the RCCL communicator for `ctx` (one call per rank, collective)."""
     r, _, w = env_rank_world()
     rank = r if rank is None else rank
     world = w if world is None else world
     uid = type(ctx).comm_unique_id() if rank == 0 else None
-    uid = broadcast_from_rank0(rank, world, uid, transport)
+    uid = broadcast_from_rank0(rank, world, uid, transport, exchange=exchange)
     ctx.comm_init(world, rank, uid)
     return ctx

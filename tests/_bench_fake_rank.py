@@ -16,7 +16,8 @@ from test_bench_flow_cpu import FakeContext  # noqa: E402
 
 class Ctx(FakeContext):
     def comm_init(self, world, rank, uid):
-        if "RCCL_BROKEN" in sys.argv[-1]:
+        broken = sys.argv[-1]
+        if broken == "RCCL_BROKEN" or (broken == "RCCL_BROKEN_ON_RANK_1" and rank == 1):
             raise hgmm_amd.HgmmError("ncclCommInitRank failed (test)")
         super().comm_init(world, rank, uid)
 

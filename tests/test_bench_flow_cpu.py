@@ -80,6 +80,19 @@ class FakeContext:
         z = np.zeros((J, 3), np.float32)
         return z, z, np.zeros(J, np.float32), z, np.zeros(self.n_it, np.float32), False, self.n_it
 
+    def flat_train(self, max_iter, tol, mu, cov, w, cov_type="diag", variant="W"):
+        z = np.zeros_like(np.asarray(mu, dtype=np.float32))
+        return z, z, np.zeros(len(z), np.float32), z, np.zeros(max_iter, np.float32), False
+
+    def empty(self, shape, dtype=np.float32):
+        class _Arr:
+            def free(self_inner):
+                pass
+        return _Arr()
+
+    def flat_estep(self, inv, mu, w, cov_type="diag", variant="W", out=None, **kw):
+        return 0.0, out, None, None
+
     def profile_reset(self):
         pass
 
@@ -136,7 +149,11 @@ def test_bench_two_rank_flow():
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
-    assert d["value"] > 0 and d["roofline"] is None and d["cpu_baseline"] is None
+    # an N > 1 line must not read as "unmeasured": roofline (rank 0's E-step launch) and cpu_baseline are objects
+    assert d["value"] > 0 and d["it_per_s_per_gpu"] * 2 == d["value"]
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0 and "cold_frac" in d["roofline"]
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    assert d["rank_consistency"]["identical_model_on_all_ranks"] is True
     assert "workload" in d["config"] and "RCCL" in d["config"]["collective"]
     assert d["allreduce_us"] == 500.0 and d["timing"]["blocks"] >= 3 and d["timing"]["steps_per_block"] == 3
     assert "torch" not in open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
@@ -198,3 +215,15 @@ def test_self_launch_retries_on_the_host_backend_when_rccl_is_unavailable():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert "fallback" in d["config"] and "host shared memory" in d["config"]["collective"]
+
+
+def test_partial_rccl_failure_is_agreed_on_collectively():
+    """communicator creation failing on ONE rank only must not leave the ranks on different backends --
+    the ok flags are all-gathered over TCP first, then every rank falls back together."""
+    r = _run_launcher(2, "plain", ["--skip", "RCCL_BROKEN_ON_RANK_1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert "fallback" in d["config"] and "host shared memory" in d["config"]["collective"]
+    assert d["rank_consistency"]["identical_model_on_all_ranks"] is True

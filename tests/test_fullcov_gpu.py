@@ -79,3 +79,64 @@ def test_fullcov_dropin_function(ctx, bunny):
     assert pi.shape == (50,) and mu.shape == (50, 3) and cov.shape == (50, 3, 3)
     assert abs(pi.sum() - 1.0) < 1e-6 or (pi == 0).any()
     assert tr["labels"].min() >= 0 and tr["labels"].max() < 50
+
+
+def _label_checksum(cur):
+    cur = np.asarray(cur).astype(np.uint64)
+    pos = np.arange(1, len(cur) + 1, dtype=np.uint64)
+    return int((cur * pos).sum(dtype=np.uint64)), int((cur * cur * pos).sum(dtype=np.uint64))
+
+
+def test_fullcov_1M_matches_oracle_fixture(ctx):
+    """The size bench.py's `fullcov` leg times (uniform cloud N = 1e6, J = 800) against the oracle's op sequence
+    run on the SAME million points (tools/gen_oracle_fixtures.py --only fullcov1m; 3 iterations): q trace,
+    parameters, all 10^6 hard assignments (population per component, checksum, 20 000 sampled labels).  Then the
+    size-independent properties: sum_j m0 = N, the statistics of the whole cloud == the sum of the statistics
+    of 16 shards (every shard size launches other grids / tile maps), one shard against the oracle, bitwise rerun."""
+    g = load_golden("fullcov_uniform1M_J800_oracle.npz")
+    N, J, iters = int(g["n_points"]), int(g["J"]), int(g["max_iters"])
+    P = np.random.RandomState(int(g["cloud_seed"])).rand(N, 3).astype(np.float32).astype(np.float64)
+    idx = np.random.RandomState(int(g["init_seed"])).choice(N, J, replace=False)
+    ctx.set_points(P)
+    pi, mu, cov, labels, q = ctx.fullcov_fit(J, float(g["ls"]), float(g["ld"]), P[idx], float(g["sig2"]), iters)
+    assert len(q) == iters
+    np.testing.assert_allclose(q, g["q_trace"], rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(pi, g["pi"], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(mu, g["mu"], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(cov, g["cov"], rtol=1e-6, atol=1e-14)
+    assert np.array_equal(labels[g["sample"]], g["labels_sample"])
+    assert np.array_equal(np.bincount(labels, minlength=J), g["population"])
+    assert _label_checksum(labels) == tuple(int(v) for v in g["checksum"])
+    again = ctx.fullcov_fit(J, float(g["ls"]), float(g["ld"]), P[idx], float(g["sig2"]), iters)
+    assert np.array_equal(again[4], q) and np.array_equal(again[3], labels) and np.array_equal(again[2], cov)
+    # E-step statistics at the fitted parameters
+    m0, m1, m2, lab_e, q_e = ctx.fullcov_estep(pi, mu, cov)
+    assert abs(m0.sum() - N) <= 1e-9 * N
+    s0, s1, s2, sq = np.zeros(J), np.zeros((J, 3)), np.zeros((J, 3, 3)), 0.0
+    bounds = np.linspace(0, N, 17).astype(int)
+    bounds[1] += 37                                              # ragged shard sizes
+    bounds[5] -= 1001
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        ctx.set_points(P[a:b])
+        t0, t1, t2, lab_s, q_s = ctx.fullcov_estep(pi, mu, cov)
+        assert np.array_equal(lab_s, lab_e[a:b])
+        s0 += t0; s1 += t1; s2 += t2; sq += q_s
+    np.testing.assert_allclose(s0, m0, rtol=1e-11)
+    np.testing.assert_allclose(s1, m1, rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(s2, m2, rtol=1e-10, atol=1e-9)
+    assert abs(sq - q_e) <= 1e-11 * abs(q_e)
+    # the first 20 000 points as their own cloud against the oracle's E-step
+    Ps = P[:20000]
+    ctx.set_points(Ps)
+    t0, t1, t2, lab_s, q_s = ctx.fullcov_estep(pi, mu, cov)
+    ok, inv, coef = hgmm_tree.node_prep(cov)
+    gm = pi[None, :] * hgmm_tree.pdf_pairs(Ps[:, None, :], mu[None], inv[None], coef[None])
+    den = gm.sum(1)
+    gam = np.where((den > 1e-15)[:, None], gm / np.where(den > 1e-15, den, 1.0)[:, None], 0.0)
+    use = np.where(gam < 1e-15, 0.0, gam)
+    np.testing.assert_allclose(t0, use.sum(0), rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(t1, use.T @ Ps, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(t2, np.einsum('nj,na,nb->jab', use, Ps, Ps), rtol=1e-10, atol=1e-12)
+    assert np.array_equal(lab_s, np.argmax(gam, axis=1))
+    assert np.array_equal(lab_s, lab_e[:20000])
+    np.testing.assert_allclose(q_s, np.log(np.maximum(gm.sum(1), 1e-15)).sum(), rtol=1e-11)

@@ -19,12 +19,30 @@ def _free_port():
     return p
 
 
+def exchange_bytes_torch(rank, world, payload):
+    """A caller-provided transport for the unique id: torch.distributed's rendezvous (gloo, CPU).  Lives in the
+    tests, not in the product package (north_star: no PyTorch)."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    obj = [payload if rank == 0 else None]
+    dist.broadcast_object_list(obj, src=0)
+    return obj[0]
+
+
 def _worker(rank, world, port, transport, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     from hgmm_amd import parallel
     payload = bytes(range(128)) if rank == 0 else None
-    got = parallel.broadcast_from_rank0(rank, world, payload, transport=transport)
+    if transport == "torch":
+        got = parallel.broadcast_from_rank0(rank, world, payload, exchange=exchange_bytes_torch)
+    else:
+        got = parallel.broadcast_from_rank0(rank, world, payload, transport=transport)
+    if transport == "tcp":
+        # the agreement round bench.py uses before choosing an all-reduce backend
+        flags = parallel.allgather_bytes_tcp(rank, world, b"ok%d" % rank)
+        assert flags == [b"ok%d" % r for r in range(world)]
     extra = None
     if transport == "torch":
         # the barrier / max-over-ranks reduction pattern bench.py uses, on gloo
@@ -154,3 +172,20 @@ def test_world2_kmeans_relocation_matches_single_process():
     moved = {tuple(np.round(s0[j], 12)) for j in (2, 3)}
     assert moved == {tuple(np.round(sums[j], 12)) for j in (2, 3)}
     np.testing.assert_allclose(s0[[0, 1, 4]], sums[[0, 1, 4]], atol=1e-12)
+
+
+def test_product_package_is_torch_free():
+    """north_star: host code is NumPy + ctypes; PyTorch may start the ranks, it is never imported by the package."""
+    import hgmm_amd
+    root = os.path.dirname(os.path.abspath(hgmm_amd.__file__))
+    pkg = os.path.realpath(os.path.join(root, os.pardir, "gpu-accelerated-point-cloud-registration-using-hierarchical-gmm_amd"))
+    hits = []
+    for base in {os.path.realpath(root), pkg}:
+        for d, _, files in os.walk(base):
+            for f in files:
+                if f.endswith(".py"):
+                    for n, line in enumerate(open(os.path.join(d, f)), 1):
+                        t = line.strip()
+                        if t.startswith(("import torch", "from torch")):
+                            hits.append("%s:%d" % (os.path.join(d, f), n))
+    assert not hits, hits

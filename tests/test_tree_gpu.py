@@ -412,3 +412,117 @@ def test_registration_loop_inside_the_library(ctx, bunny):
     r7, t7, d7, q7, s7, _ = ctx.tree_register(np.identity(3), np.zeros(3), 1.0, 0.01, 7, 0.0)
     assert d1 == 3 and d2 == 4 and d7 == 7
     assert np.array_equal(r2, r7) and np.array_equal(t2, t7) and q2 == q7
+
+
+def test_moment_words_reused_across_tree_depths(ctx, bunny):
+    """the fixed-point moment words are shared by the registration E-step ([T][4] or [T][10]
+    words) and the standalone tree E-step (2 x 10 x T + 1 words).  A use on a deeper tree followed by a
+    registration on a shallower one used to clear only the shallower tree's words and still call the buffer
+    clean, so that the next registration on the deeper tree added onto stale sums.  Sequence L=3, L=2, L=3 on ONE
+    context, every result bit-identical to what a fresh context returns."""
+    import hgmm_amd
+    P = bunny[::8].astype(np.float64)
+    th = np.deg2rad(7.0)
+    Rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    target = P @ Rz.T + np.array([0.003, -0.002, 0.001])
+    trees = {}
+    for L in (3, 2):
+        T = hgmm_tree.n_total(L)
+        idx = np.random.RandomState(72).randint(T, size=T)
+        pi, mu, cov = build(ctx, P, L, 80.0, 1e-4, idx, 0.00034)[:3]
+        trees[L] = (pi, mu, cov)
+
+    def normal(c, L):
+        c.tree_set_nodes(L, *trees[L])
+        c.tree_set_target(target)
+        return c.tree_reg_normal(np.identity(3), np.zeros(3), 1.0, 0.01)
+
+    fresh = {}
+    for L in (3, 2):
+        c2 = hgmm_amd.Context(0)
+        try:
+            fresh[L] = normal(c2, L)
+        finally:
+            c2.close()
+
+    def same(a, b):
+        return np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+
+    # (i) a full-moment registration E-step at L = 3 leaves [T3][10] words behind
+    ctx.tree_set_nodes(3, *trees[3])
+    ctx.tree_set_target(target)
+    ctx.tree_reg_estep(hgmm_tree.n_total(3), np.identity(3), np.zeros(3), 1.0, 0.01)
+    assert same(normal(ctx, 2), fresh[2])
+    assert same(normal(ctx, 3), fresh[3])
+    # (ii) the standalone E-step (two-word sums) at L = 3, then L = 2, then L = 3
+    ctx.set_points(P)
+    parent = np.random.RandomState(1).randint(-1, 72, size=len(P)).astype(np.int32)
+    ctx.tree_estep(*trees[3], parent)
+    assert same(normal(ctx, 2), fresh[2])
+    assert same(normal(ctx, 3), fresh[3])
+    # (iii) alternating depths back to back
+    for L in (3, 2, 3, 2):
+        assert same(normal(ctx, L), fresh[L])
+
+
+def test_build_full_bunny_L4_matches_oracle_fixture(ctx, bunny):
+    """BASELINE config 4 at FULL size against the ORACLE, not properties: tests/golden/hgmm_build_bun000_L4_oracle.npz
+    holds oracle.hgmm_tree.build_tree on all 40 256 points (tools/gen_oracle_fixtures.py --only c4): iteration
+    counts, the whole q trace, currentIdx of every level, pi / mu / cov."""
+    g = load_golden("hgmm_build_bun000_L4_oracle.npz")
+    P = bunny.astype(np.float64)
+    assert len(P) == int(g["n_points"])
+    L = int(g["L"])
+    T = hgmm_tree.n_total(L)
+    idx = np.random.RandomState(int(g["init_seed"])).randint(T, size=T)
+    assert np.array_equal(idx, g["init_idx"])
+    pi, mu, cov, leaf, iters, q = build(ctx, P, L, float(g["ls"]), float(g["ld"]), idx, float(g["sig2"]))
+    assert list(iters) == list(g["iters_per_level"])
+    np.testing.assert_allclose(q, g["q_trace"], rtol=1e-9, atol=1e-6)
+    assert np.array_equal(leaf, g["current_idx_L%d" % (L - 1)])
+    # the leaf determines the path: parent(c) = c // 8 - 1 must reproduce the oracle's currentIdx of every level
+    node = leaf.astype(np.int64)
+    for l in range(L - 2, -1, -1):
+        node = node // 8 - 1
+        assert np.array_equal(node, g["current_idx_L%d" % l]), l
+    np.testing.assert_allclose(pi, g["pi"], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(mu, g["mu"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(cov, g["cov"], rtol=1e-6, atol=1e-14)
+    assert int((pi == 0).sum()) == int((g["pi"] == 0).sum())
+
+
+def _label_checksum(cur):
+    cur = np.asarray(cur).astype(np.uint64)
+    pos = np.arange(1, len(cur) + 1, dtype=np.uint64)
+    return int((cur * pos).sum(dtype=np.uint64)), int((cur * cur * pos).sum(dtype=np.uint64))
+
+
+def test_tree_1M_matches_oracle_fixture(ctx):
+    """The size bench.py's `tree_1M` leg times (uniform cloud N = 1e6, L = 4, 4 iterations per level) against
+    oracle.hgmm_tree.build_tree run on the SAME million points (tools/gen_oracle_fixtures.py --only tree1m):
+    q trace, parameters, the node populations of every level, a checksum over all 10^6 leaf assignments per
+    level and the paths of 20 000 sampled points; plus the per-level mixing sums and a bitwise rerun."""
+    g = load_golden("hgmm_build_uniform1M_L4_oracle.npz")
+    N = int(g["n_points"])
+    P = np.random.RandomState(int(g["cloud_seed"])).rand(N, 3).astype(np.float32).astype(np.float64)
+    L = int(g["L"])
+    T = hgmm_tree.n_total(L)
+    idx = np.random.RandomState(int(g["init_seed"])).randint(N, size=T)
+    k = int(g["max_iters_per_level"])
+    pi, mu, cov, leaf, iters, q = build(ctx, P, L, float(g["ls"]), float(g["ld"]), idx, float(g["sig2"]), max_iters=k)
+    assert list(iters) == list(g["iters_per_level"])
+    np.testing.assert_allclose(q, g["q_trace"], rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(pi, g["pi"], rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(mu, g["mu"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(cov, g["cov"], rtol=1e-6, atol=1e-14)
+    node = leaf.astype(np.int64)
+    for l in range(L - 1, -1, -1):
+        assert np.array_equal(np.bincount(node, minlength=T), g["population_L%d" % l]), l
+        assert _label_checksum(node) == tuple(int(v) for v in g["checksum_L%d" % l]), l
+        assert np.array_equal(node[g["sample"]], g["current_idx_sample_L%d" % l]), l
+        node = node // 8 - 1
+    for l in range(L):
+        s = pi[hgmm_tree.level(l):hgmm_tree.level(l + 1)].sum()
+        assert abs(s - 1.0) < 1e-9, (l, s)         # uniform cloud: no mass is dropped anywhere
+    again = build(ctx, P, L, float(g["ls"]), float(g["ld"]), idx, float(g["sig2"]), max_iters=k)
+    assert np.array_equal(again[5], q) and np.array_equal(again[3], leaf) and np.array_equal(again[2], cov)
