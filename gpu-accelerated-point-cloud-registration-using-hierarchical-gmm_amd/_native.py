@@ -91,6 +91,7 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_tree_mstep", [ctx, C.c_int64, _vp, _vp, _vp, C.c_int64, C.c_int64, C.c_double, C.c_double,
                                       _vp, _vp, _vp])
         _sig(lib, "hgmm_tree_loglik", [ctx, C.c_int64, _vp, _vp, _vp, C.c_int64, C.c_int64, _f64p])
+        _sig(lib, "hgmm_tree_stats", [ctx, C.POINTER(C.c_uint64), C.POINTER(C.c_int)])
         _sig(lib, "hgmm_fullcov_fit", [ctx, C.c_int, C.c_double, C.c_double, _vp, C.c_double, C.c_int, _vp, _vp, _vp,
                                        _vp, _vp, C.c_int, C.POINTER(C.c_int)])
         _sig(lib, "hgmm_fullcov_estep", [ctx, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64p])
@@ -494,6 +495,12 @@ class Context:
         self._check(self.lib.hgmm_tree_loglik(self.h, T, _ptr(pi), _ptr(mu), _ptr(cov), int(j_begin), int(j_end),
                                               C.byref(q)))
         return q.value
+
+    def tree_stats(self):
+        """(pdf evaluations done by the level log-likelihood kernels since the node table was last set up, flags)."""
+        pairs, flags = C.c_uint64(), C.c_int()
+        self._check(self.lib.hgmm_tree_stats(self.h, C.byref(pairs), C.byref(flags)))
+        return int(pairs.value), int(flags.value)
 
     def tree_node_complexity(self, T):
         out = np.empty(T)

@@ -36,7 +36,16 @@ namespace hgmm {
 
 constexpr double TREE_EPS = 1.0e-15;                 // hgmm_cupy_cpu_working.py:29
 constexpr double TWO_PI_POW_1_5 = 15.749609945722419; // (2 pi)^(3/2)
-constexpr int PREP_N = 12;   // i00 i01 i02 i11 i12 i22 | mu0 mu1 mu2 | wE | wL | complexity
+constexpr int PREP_N = 20;   // i00 i01 i02 i11 i12 i22 | mu0 mu1 mu2 | wE | wL | complexity | r00 r01 r02 r11 r12 r22 | kappa | -
+// [12..17] R: upper-triangular factor of Sigma^-1 / 2 (R^T R = Sigma^-1 / 2), so that the exponent of the pdf is
+//          -(x-mu)^T Sigma^-1 (x-mu) / 2 = -|R (x - mu)|^2 : 9 fma/mul for a point given in coordinates where R mu is
+//          precomputed, against 14 for the symmetric form (tree_loglik_kernel, full_fused_kernel).
+// [18]     kappa = 1 / (2 lambda_max(Sigma)): the exponent is <= -kappa |x - mu|^2 for every x -- a whole node can be
+//          rejected for a whole box of points once kappa dist(box, mu)^2 passes the underflow threshold.
+// A node whose Sigma^-1 is not numerically positive definite although det >= eps (cannot happen for a covariance
+// estimated from moments; a caller-supplied table may hold anything) raises bit 0 of the context's tree flags and the
+// consumers fall back to the symmetric form.
+constexpr int PREP_R = 12, PREP_KAPPA = 18;
 constexpr int CH = 256;      // points per chunk = threads per workgroup
 constexpr int NMOM = 10;     // m0, m1[3], m2 unique[6] (xx xy xz yy yz zz)
 
@@ -201,11 +210,28 @@ __device__ inline double sym3_min_eig_over_trace(double a00, double a01, double 
     return e_min / tr;
 }
 
+// largest eigenvalue of a symmetric 3x3 (same closed form as above)
+__device__ inline double sym3_max_eig(double a00, double a01, double a02, double a11, double a12, double a22) {
+    const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
+    if (p1 == 0.0) return fmax(a00, fmax(a11, a22));
+    const double q = (a00 + a11 + a22) / 3.0;
+    const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
+    const double p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * p1;
+    const double p = sqrt(p2 / 6.0);
+    const double ip = 1.0 / p;
+    const double c00 = b00 * ip, c01 = a01 * ip, c02 = a02 * ip, c11 = b11 * ip, c12 = a12 * ip, c22 = b22 * ip;
+    double r = 0.5 * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02));
+    r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
+    return q + 2.0 * p * cos(acos(r) / 3.0);
+}
+
 __device__ __forceinline__ void prep_node(double p, double m0, double m1, double m2, double c00, double c01,
                                           double c02, double c10, double c11, double c12, double c20,
-                                          double c21, double c22, double* __restrict__ o) {
+                                          double c21, double c22, double* __restrict__ o, int* __restrict__ flags) {
     const double det = c00 * (c11 * c22 - c12 * c21) - c01 * (c10 * c22 - c12 * c20) +
                        c02 * (c10 * c21 - c11 * c20);
+#pragma unroll
+    for (int e = PREP_R; e < PREP_N; ++e) o[e] = 0.0;
     if (det < TREE_EPS) {           // gaussianPdf returns 0 (hgmm_cupy_cpu_working.py:65-67)
         o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = 0.0;
         o[9] = 0.0;
@@ -222,6 +248,25 @@ __device__ __forceinline__ void prep_node(double p, double m0, double m1, double
         const double coef = 1.0 / (sqrt(det) * TWO_PI_POW_1_5);
         o[9] = p * coef;
         o[10] = (p < TREE_EPS) ? 0.0 : p * coef;   // logLikelihoodValue skips pi < eps (C:80)
+        // Cholesky factor of A = Sigma^-1 / 2:  A = R^T R, R upper triangular
+        const double a00 = 0.5 * o[0], a01 = 0.5 * o[1], a02 = 0.5 * o[2], a11 = 0.5 * o[3], a12 = 0.5 * o[4],
+                     a22 = 0.5 * o[5];
+        const double r00 = sqrt(a00);
+        const double r01 = a01 / r00, r02 = a02 / r00;
+        const double r11 = sqrt(a11 - r01 * r01);
+        const double r12 = (a12 - r01 * r02) / r11;
+        const double r22 = sqrt(a22 - r02 * r02 - r12 * r12);
+        const bool pd = (a00 > 0.0) && (r11 > 0.0) && (r22 > 0.0) && (r22 == r22) && (r11 == r11) &&
+                        (fabs(r12) < 1.0e300) && (fabs(r02) < 1.0e300);
+        if (pd) {
+            o[PREP_R + 0] = r00; o[PREP_R + 1] = r01; o[PREP_R + 2] = r02;
+            o[PREP_R + 3] = r11; o[PREP_R + 4] = r12; o[PREP_R + 5] = r22;
+            const double lmax = sym3_max_eig(c00, c01, c02, c11, c12, c22);
+            // (1 - 1e-9): the closed form's rounding must never make the bound optimistic
+            o[PREP_KAPPA] = (lmax > 0.0 && lmax == lmax) ? 0.5 / lmax * (1.0 - 1.0e-9) : 0.0;
+        } else if (flags) {
+            atomicOr(flags, 1);
+        }
     }
     o[6] = m0; o[7] = m1; o[8] = m2;
     o[11] = sym3_min_eig_over_trace(c00, c01, c02, c11, c12, c22);
@@ -229,12 +274,12 @@ __device__ __forceinline__ void prep_node(double p, double m0, double m1, double
 
 __global__ void tree_prep_kernel(const double* __restrict__ pi, const double* __restrict__ mu,
                                  const double* __restrict__ cov, int64_t j_begin, int64_t j_end,
-                                 double* __restrict__ prep) {
+                                 double* __restrict__ prep, int* __restrict__ flags) {
     const int64_t j = j_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= j_end) return;
     const double* c = cov + 9 * j;
     prep_node(pi[j], mu[3 * j], mu[3 * j + 1], mu[3 * j + 2], c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8],
-              prep + PREP_N * j);
+              prep + PREP_N * j, flags);
 }
 
 __global__ void tree_init_nodes_kernel(const double* __restrict__ init_mu, double sig2, int64_t T,
@@ -378,14 +423,15 @@ __global__ __launch_bounds__(CH) void tree_estep_kernel(
 // the node's E-step preparation, so that no separate prep launch is needed.
 __device__ __forceinline__ void mstep_node(const double* __restrict__ m, int64_t j, double n_points_total,
                                            double ld, double* __restrict__ pi, double* __restrict__ mu,
-                                           double* __restrict__ cov, double* __restrict__ prep) {
+                                           double* __restrict__ cov, double* __restrict__ prep,
+                                           int* __restrict__ flags) {
     const double m0 = m[0];
     double* c = cov + 9 * j;
     if (m0 < ld) {
         pi[j] = 0.0;
         mu[3 * j] = mu[3 * j + 1] = mu[3 * j + 2] = 0.0;
         for (int e = 0; e < 9; ++e) c[e] = (e % 4 == 0) ? 1.0 : 0.0;
-        if (prep) prep_node(0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0, prep + PREP_N * j);
+        if (prep) prep_node(0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0, prep + PREP_N * j, flags);
         return;
     }
     const double p = m0 / n_points_total;
@@ -395,7 +441,7 @@ __device__ __forceinline__ void mstep_node(const double* __restrict__ m, int64_t
     const double s00 = m[4] / m0 - u0 * u0, s01 = m[5] / m0 - u0 * u1, s02 = m[6] / m0 - u0 * u2,
                  s11 = m[7] / m0 - u1 * u1, s12 = m[8] / m0 - u1 * u2, s22 = m[9] / m0 - u2 * u2;
     c[0] = s00; c[1] = s01; c[2] = s02; c[3] = s01; c[4] = s11; c[5] = s12; c[6] = s02; c[7] = s12; c[8] = s22;
-    if (prep) prep_node(p, u0, u1, u2, s00, s01, s02, s01, s11, s12, s02, s12, s22, prep + PREP_N * j);
+    if (prep) prep_node(p, u0, u1, u2, s00, s01, s02, s01, s11, s12, s02, s12, s22, prep + PREP_N * j, flags);
 }
 
 // fixed-order reduction of the chunk partials of one node (64 threads); with `fuse` the same
@@ -405,7 +451,7 @@ __global__ __launch_bounds__(64) void tree_moments_kernel(const double* __restri
                                                           int n_level_nodes, double* __restrict__ mom,
                                                           int fuse, int64_t lb, double n_points_total, double ld,
                                                           double* pi, double* mu, double* cov, double* prep,
-                                                          const int* __restrict__ done) {
+                                                          int* __restrict__ flags, const int* __restrict__ done) {
     if (done && *done) return;
     const int cl = blockIdx.x;            // level-local child index
     if (cl >= n_level_nodes) return;
@@ -424,16 +470,16 @@ __global__ __launch_bounds__(64) void tree_moments_kernel(const double* __restri
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int m = 0; m < NMOM; ++m) mom[(size_t)cl * NMOM + m] = acc[m];
-        if (fuse) mstep_node(acc, lb + cl, n_points_total, ld, pi, mu, cov, prep);
+        if (fuse) mstep_node(acc, lb + cl, n_points_total, ld, pi, mu, cov, prep, flags);
     }
 }
 __global__ void tree_mstep_kernel(const double* __restrict__ mom, int64_t lb, int n_level_nodes,
                                   double n_points_total, double ld, double* pi, double* mu, double* cov,
-                                  double* prep, const int* __restrict__ done = nullptr) {
+                                  double* prep, int* __restrict__ flags, const int* __restrict__ done = nullptr) {
     if (done && *done) return;
     const int cl = blockIdx.x * blockDim.x + threadIdx.x;
     if (cl >= n_level_nodes) return;
-    mstep_node(mom + (size_t)cl * NMOM, lb + cl, n_points_total, ld, pi, mu, cov, prep);
+    mstep_node(mom + (size_t)cl * NMOM, lb + cl, n_points_total, ld, pi, mu, cov, prep, flags);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -493,6 +539,23 @@ __device__ __forceinline__ void store_block_q(double value, double* __restrict__
 // 64 lanes per node and wave, ~40 LDS cycles for a CU whose four SIMDs need ~12 VALU cycles each for the
 // quadratic form), so the kernel is LDS-bound at one point per thread; every further point reuses the
 // same ten values.
+//
+// Round 3:
+//   * LOCAL ORIGIN + TRIANGULAR FORM.  A workgroup's points are neighbours (the cloud is regrouped per parent at every
+//     level), so they are expressed relative to the workgroup's first point c; the exponent is taken as
+//     -|R (x - c) - R (mu - c)|^2 with R^T R = Sigma^-1 / 2 (prep[12..17]) and b = R (mu - c) formed once per node and
+//     workgroup while the tile is loaded: 9 fma / mul per (point, node) pair instead of 14 (3 subtractions + the
+//     symmetric form).  Both terms are of the size of the workgroup's extent, so nothing is lost to cancellation
+//     (the global-coordinate version of the same form would lose |x| / sigma).
+//   * DEAD AND OUT-OF-REACH NODES NEVER ENTER THE TILE.  While a 256-node tile is loaded every thread looks at one
+//     node: pi < eps / singular nodes (weight 0) are dropped, and so is a node whose pdf underflows for EVERY point
+//     of the workgroup: exponent <= -kappa dist(box, mu)^2 with kappa = 1 / (2 lambda_max(Sigma)) and box = the
+//     bounding box of the workgroup's points.  Terms skipped this way are terms the wave-uniform test below would
+//     have skipped too (they are exactly 0 in float64), so q does not change by a bit.  The survivors are compacted
+//     in node order (ballot + popcount), the inner loop runs over them without a test per node.
+//   pair_count (optional): += (points of this workgroup) x (nodes that entered its tiles) -- the pairs actually evaluated.
+constexpr double LL_SKIP = -750.0;       // exp(y) == 0 in float64 below this exponent (denormals end at -745.13)
+constexpr double LL_CULL = 751.0;        // a node is out of reach when kappa dist^2 exceeds this (margin over LL_SKIP)
 template <int PTS>
 __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restrict__ xs, int64_t n,
                                                          int64_t n_pad, const double* __restrict__ prep,
@@ -501,49 +564,127 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
                                                          double* __restrict__ block_q,
                                                          unsigned int* __restrict__ ticket,
                                                          double* __restrict__ q_out,
-                                                         const int* __restrict__ done, TreeStop stop) {
+                                                         const int* __restrict__ done, TreeStop stop,
+                                                         const int* __restrict__ flags,
+                                                         unsigned long long* __restrict__ pair_count) {
     if (done && *done) return;
     __shared__ double tile[LL_TILE][10];
     __shared__ double shq[CH / 64];
     __shared__ double exp_tab[EXP_TAB_N];
+    __shared__ double shbox[CH / 64][6];
+    __shared__ int wcnt[CH / 64];
     exp_tab_load(exp_tab);                                 // (the tile loop's first barrier covers it)
+    const bool use_chol = !(flags && (*flags & 1));        // kernel-uniform
+    const int w = wave_in_block(), lane = lane_id();
+    // origin: the workgroup's first point
+    const int64_t i_first = (int64_t)blockIdx.x * PTS * CH;
+    const int64_t i_c = i_first < n ? i_first : n - 1;
+    const double c0 = xs[i_c], c1 = xs[n_pad + i_c], c2 = xs[2 * n_pad + i_c];
     int64_t i[PTS];
     bool active[PTS];
     double x0[PTS], x1[PTS], x2[PTS], tot[PTS];
+    double lo0 = 0.0, lo1 = 0.0, lo2 = 0.0, hi0 = 0.0, hi1 = 0.0, hi2 = 0.0;    // the origin itself is in the box
 #pragma unroll
     for (int p = 0; p < PTS; ++p) {
-        i[p] = ((int64_t)blockIdx.x * PTS + p) * CH + threadIdx.x;
+        i[p] = i_first + (int64_t)p * CH + threadIdx.x;
         active[p] = i[p] < n;
-        x0[p] = x1[p] = x2[p] = tot[p] = 0.0;
-        if (active[p]) { x0[p] = xs[i[p]]; x1[p] = xs[n_pad + i[p]]; x2[p] = xs[2 * n_pad + i[p]]; }
+        x0[p] = x1[p] = x2[p] = tot[p] = 0.0;              // inactive slots sit on the origin
+        if (active[p]) {
+            x0[p] = xs[i[p]] - c0; x1[p] = xs[n_pad + i[p]] - c1; x2[p] = xs[2 * n_pad + i[p]] - c2;
+        }
+        lo0 = fmin(lo0, x0[p]); hi0 = fmax(hi0, x0[p]);
+        lo1 = fmin(lo1, x1[p]); hi1 = fmax(hi1, x1[p]);
+        lo2 = fmin(lo2, x2[p]); hi2 = fmax(hi2, x2[p]);
     }
+    {
+        const double b0 = -wave_max_f64(-lo0), b1 = -wave_max_f64(-lo1), b2 = -wave_max_f64(-lo2);
+        const double b3 = wave_max_f64(hi0), b4 = wave_max_f64(hi1), b5 = wave_max_f64(hi2);
+        if (lane == 0) {
+            shbox[w][0] = b0; shbox[w][1] = b1; shbox[w][2] = b2; shbox[w][3] = b3; shbox[w][4] = b4; shbox[w][5] = b5;
+        }
+    }
+    __syncthreads();
+    lo0 = fmin(fmin(shbox[0][0], shbox[1][0]), fmin(shbox[2][0], shbox[3][0]));
+    lo1 = fmin(fmin(shbox[0][1], shbox[1][1]), fmin(shbox[2][1], shbox[3][1]));
+    lo2 = fmin(fmin(shbox[0][2], shbox[1][2]), fmin(shbox[2][2], shbox[3][2]));
+    hi0 = fmax(fmax(shbox[0][3], shbox[1][3]), fmax(shbox[2][3], shbox[3][3]));
+    hi1 = fmax(fmax(shbox[0][4], shbox[1][4]), fmax(shbox[2][4], shbox[3][4]));
+    hi2 = fmax(fmax(shbox[0][5], shbox[1][5]), fmax(shbox[2][5], shbox[3][5]));
+
     const int node_begin = blockIdx.y * nodes_per_chunk;
     const int node_end = (node_begin + nodes_per_chunk < n_level_nodes) ? node_begin + nodes_per_chunk : n_level_nodes;
+    int entered = 0;                                       // nodes that made it into this workgroup's tiles
     for (int base = node_begin; base < node_end; base += LL_TILE) {
-        const int cnt = (node_end - base < LL_TILE) ? node_end - base : LL_TILE;
-        __syncthreads();
-        for (int t = threadIdx.x; t < cnt * 10; t += CH) {
-            const int node = t / 10, fidx = t % 10;
-            const double* pr = prep + PREP_N * (lb + base + node);
-            // -1/2 Sigma^-1: the quadratic form is then the (non-positive) exponent itself
-            tile[node][fidx] = (fidx < 6) ? -0.5 * pr[fidx] : ((fidx < 9) ? pr[fidx] : pr[10]);
+        // ---- this thread's node of the tile: weight, reach test, parameters in workgroup coordinates ----
+        const int node = base + (int)threadIdx.x;
+        bool live = false;
+        double v[10];
+#pragma unroll
+        for (int e = 0; e < 10; ++e) v[e] = 0.0;
+        if (node < node_end) {
+            const double* pr = prep + PREP_N * (lb + node);
+            const double wL = pr[10];
+            if (wL != 0.0) {
+                const double m0 = pr[6] - c0, m1 = pr[7] - c1, m2 = pr[8] - c2;     // mean relative to the origin
+                const double g0 = fmax(fmax(lo0 - m0, m0 - hi0), 0.0), g1 = fmax(fmax(lo1 - m1, m1 - hi1), 0.0),
+                             g2 = fmax(fmax(lo2 - m2, m2 - hi2), 0.0);
+                const double d2 = g0 * g0 + g1 * g1 + g2 * g2;                      // squared distance box <-> mean
+                live = !(pr[PREP_KAPPA] * d2 > LL_CULL);
+                if (live) {
+                    if (use_chol) {
+                        const double r00 = pr[PREP_R], r01 = pr[PREP_R + 1], r02 = pr[PREP_R + 2], r11 = pr[PREP_R + 3],
+                                     r12 = pr[PREP_R + 4], r22 = pr[PREP_R + 5];
+                        v[0] = r00; v[1] = r01; v[2] = r02; v[3] = r11; v[4] = r12; v[5] = r22;
+                        v[6] = -fma(r02, m2, fma(r01, m1, r00 * m0));               // -b = -R (mu - c)
+                        v[7] = -fma(r12, m2, r11 * m1);
+                        v[8] = -(r22 * m2);
+                    } else {
+                        // -1/2 Sigma^-1: the symmetric form is then the (non-positive) exponent itself
+                        v[0] = -0.5 * pr[0]; v[1] = -0.5 * pr[1]; v[2] = -0.5 * pr[2]; v[3] = -0.5 * pr[3];
+                        v[4] = -0.5 * pr[4]; v[5] = -0.5 * pr[5];
+                        v[6] = m0; v[7] = m1; v[8] = m2;
+                    }
+                    v[9] = wL;
+                }
+            }
+        }
+        const unsigned long long mask = __ballot(live);
+        const int before = __popcll(mask & ((1ull << lane) - 1ull));
+        // (wcnt of the previous tile was read before that tile's second barrier, which every wave has passed)
+        if (lane == 0) wcnt[w] = __popcll(mask);
+        __syncthreads();                                   // also: every wave is done with the previous tile
+        int off = 0, cnt = 0;
+#pragma unroll
+        for (int ww = 0; ww < CH / 64; ++ww) {
+            const int t = wcnt[ww];
+            if (ww < w) off += t;
+            cnt += t;
+        }
+        if (live) {
+            double* dst = tile[off + before];
+#pragma unroll
+            for (int e = 0; e < 10; ++e) dst[e] = v[e];
         }
         __syncthreads();
-        for (int node = 0; node < cnt; ++node) {
-            const double wL = tile[node][9];
-            if (wL == 0.0) continue;                                    // workgroup-uniform
+        entered += cnt;
+        for (int k = 0; k < cnt; ++k) {
             // (node parameters through the LDS tile: reading them with wave-uniform scalar loads
             //  instead was measured 60 % slower for the C4 build, 8.6 vs 5.2 ms)
-            const double i00 = tile[node][0], i01 = tile[node][1], i02 = tile[node][2], i11 = tile[node][3],
-                         i12 = tile[node][4], i22 = tile[node][5], m0 = tile[node][6], m1 = tile[node][7],
-                         m2 = tile[node][8];
+            const double t0 = tile[k][0], t1 = tile[k][1], t2 = tile[k][2], t3 = tile[k][3], t4 = tile[k][4],
+                         t5 = tile[k][5], t6 = tile[k][6], t7 = tile[k][7], t8 = tile[k][8], wL = tile[k][9];
             double yv[PTS];
             bool need = false;
 #pragma unroll
             for (int p = 0; p < PTS; ++p) {
-                const double d0 = x0[p] - m0, d1 = x1[p] - m1, d2 = x2[p] - m2;
-                yv[p] = sym3_quad(i00, i01, i02, i11, i12, i22, d0, d1, d2);      // = -q / 2
-                need = need || (yv[p] > -750.0);
+                if (use_chol) {
+                    const double z0 = fma(t2, x2[p], fma(t1, x1[p], fma(t0, x0[p], t6)));
+                    const double z1 = fma(t4, x2[p], fma(t3, x1[p], t7));
+                    const double z2 = fma(t5, x2[p], t8);
+                    yv[p] = -fma(z2, z2, fma(z1, z1, z0 * z0));                    // = -q / 2
+                } else {
+                    yv[p] = sym3_quad(t0, t1, t2, t3, t4, t5, x0[p] - t6, x1[p] - t7, x2[p] - t8);
+                }
+                need = need || (yv[p] > LL_SKIP);
             }
             // exp(-q / 2) underflows to exactly 0 in float64 beyond q ~ 1490: skip the exponentials when no lane
             // of the wave needs one (points are sorted spatially); otherwise all PTS of them go through the
@@ -568,6 +709,11 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
             }
         }
     }
+    if (pair_count && threadIdx.x == 0) {
+        const int64_t rest = n - i_first;
+        const int64_t pts = rest <= 0 ? 0 : (rest < (int64_t)PTS * CH ? rest : (int64_t)PTS * CH);
+        atomicAdd(pair_count, (unsigned long long)(pts * entered));
+    }
     if (gridDim.y > 1) {
 #pragma unroll
         for (int p = 0; p < PTS; ++p)
@@ -578,10 +724,11 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
 #pragma unroll
     for (int p = 0; p < PTS; ++p) lq += active[p] ? log(fmax(tot[p], TREE_EPS)) : 0.0;
     lq = wave_sum_f64(lq);
+    __syncthreads();                                       // (shq is not aliased, but keep the tile loop's last readers behind)
     if (lane_id() == 0) shq[wave_in_block()] = lq;
     __syncthreads();
     double t = 0.0;
-    for (int w = 0; w < CH / 64; ++w) t += shq[w];
+    for (int ww = 0; ww < CH / 64; ++ww) t += shq[ww];
     store_block_q(t, block_q, (int)gridDim.x, ticket, q_out, stop);
 }
 
@@ -1036,6 +1183,7 @@ __global__ void tree_copy_cplx_kernel(const double* __restrict__ prep, int64_t T
 // ------------------------------------------------------------------------------------------
 static unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
+static int tree_flags(hgmm_ctx* c, bool reset);
 static int tree_alloc_nodes(hgmm_ctx* c, int L) {
     const int64_t T = level_first(L);
     c->tree.L = L;
@@ -1048,10 +1196,22 @@ static int tree_alloc_nodes(hgmm_ctx* c, int L) {
     return HGMM_OK;
 }
 
+// tree flags (int[4]: bit 0 of [0] = some node's Sigma^-1 failed the Cholesky test) + the executed-pair counter of the
+// level log-likelihood (uint64 at byte 16); `reset`: a new node table is about to be prepared
+static int tree_flags(hgmm_ctx* c, bool reset) {
+    HGMM_TRY(ensure(c, c->t_flags, 64));
+    if (reset) HGMM_HIP(c, hipMemsetAsync(c->t_flags.p, 0, 64, c->stream));
+    return HGMM_OK;
+}
+static inline int* flags_ptr(hgmm_ctx* c) { return c->t_flags.as<int>(); }
+static inline unsigned long long* pairs_ptr(hgmm_ctx* c) {
+    return reinterpret_cast<unsigned long long*>(c->t_flags.as<char>() + 16);
+}
+
 static int tree_prep(hgmm_ctx* c, int64_t jb, int64_t je) {
     tree_prep_kernel<<<nblk(je - jb, 256), 256, 0, c->stream>>>(c->t_pi.as<double>(), c->t_mu.as<double>(),
                                                                c->t_cov.as<double>(), jb, je,
-                                                               c->t_prep.as<double>());
+                                                               c->t_prep.as<double>(), flags_ptr(c));
     HGMM_HIP(c, hipGetLastError());
     return HGMM_OK;
 }
@@ -1203,12 +1363,12 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                 // communicator the all-reduce of the moments sits between reduction and M-step
                 tree_moments_kernel<<<n_level, 64, 0, c->stream>>>(partials, chunk_first, n_level, d_mom + NMOM * lb,
                                                                    c->comm_on() ? 0 : 1, lb, n_total, ld, d_pi, d_mu, d_cov,
-                                                                   d_prep, &ctl->done);
+                                                                   d_prep, flags_ptr(c), &ctl->done);
                 if (c->comm_on()) {
                     rc = allreduce_f64_oop(c, d_mom + NMOM * lb, mom_g, (size_t)NMOM * n_level);
                     if (rc != HGMM_OK) break;
                     tree_mstep_kernel<<<nblk(n_level, 256), 256, 0, c->stream>>>(mom_g, lb, n_level, n_total, ld, d_pi,
-                                                                                 d_mu, d_cov, d_prep, &ctl->done);
+                                                                                 d_mu, d_cov, d_prep, flags_ptr(c), &ctl->done);
                 }
                 {
                     ProfScope prof(c, HGMM_K_TREE_LOGLIK);
@@ -1220,7 +1380,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
 #define LL_LAUNCH(PTS)                                                                                     \
     tree_loglik_kernel<PTS><<<dim3(llblocks, chunks), CH, 0, c->stream>>>(                                 \
         xs_cur, n, n_pad, d_prep, lb, n_level, per_chunk, ll_partial, block_q, q_ticket, q_dev, &ctl->done, \
-        chunks > 1 ? no_stop : stop)
+        chunks > 1 ? no_stop : stop, flags_ptr(c), pairs_ptr(c))
                     if (ll_pts == 4) LL_LAUNCH(4);
                     else if (ll_pts == 2) LL_LAUNCH(2);
                     else LL_LAUNCH(1);
@@ -2049,6 +2209,7 @@ static int fullcov_alloc(hgmm_ctx* c, int J, int* J16_out, int* grid_out) {
     HGMM_TRY(ensure(c, c->t_q, sizeof(double) * (nblk(c->n, CH) + c->cus + 8)));
     HGMM_TRY(ensure(c, c->t_current, sizeof(int) * 2 * c->n_pad));
     HGMM_TRY(ensure(c, c->t_parent, sizeof(double) * c->n_pad));     // den
+    HGMM_TRY(tree_flags(c, true));
     c->tree.nodes_ready = false;
     return HGMM_OK;
 }
@@ -2156,7 +2317,7 @@ extern "C" int hgmm_fullcov_fit(hgmm_ctx* c, int J, double ls, double ld, const 
     int* lab_b = lab_a + c->n_pad;
     HGMM_HIP(c, hipMemcpyAsync(c->scratch.p, init_mu, sizeof(double) * 3 * J, hipMemcpyHostToDevice, c->stream));
     full_init_nodes_kernel<<<nblk(J16, 256), 256, 0, c->stream>>>(c->scratch.as<double>(), sig2, J, J16, d_pi, d_mu, d_cov);
-    tree_prep_kernel<<<nblk(J16, 256), 256, 0, c->stream>>>(d_pi, d_mu, d_cov, 0, J16, d_prep);
+    tree_prep_kernel<<<nblk(J16, 256), 256, 0, c->stream>>>(d_pi, d_mu, d_cov, 0, J16, d_prep, flags_ptr(c));
     double n_total = (double)c->n;
     if (c->comm_on()) HGMM_TRY(hgmm_comm_allreduce_f64(c, &n_total, 1, 0));
     // E-step quantities of the initial parameters
@@ -2170,7 +2331,7 @@ extern "C" int hgmm_fullcov_fit(hgmm_ctx* c, int J, double ls, double ld, const 
     while (true) {
         if (!one_pass) HGMM_TRY(fullcov_moments(c, J, J16, grid));                    // E (moments)
         tree_mstep_kernel<<<nblk(J, 256), 256, 0, c->stream>>>(c->t_mom.as<double>(), 0, J, n_total, ld, d_pi, d_mu,
-                                                               d_cov, d_prep);                  // M (+ prep)
+                                                               d_cov, d_prep, flags_ptr(c));    // M (+ prep)
         double q = 0.0;
         // q of the new parameters; one pass: the same launch already holds the next iteration's statistics
         // (the statistics of a call that is known to be the last one -- iteration budget reached -- are not formed)
@@ -2208,7 +2369,7 @@ extern "C" int hgmm_fullcov_estep(hgmm_ctx* c, int J, const double* pi, const do
     HGMM_HIP(c, hipMemcpyAsync(c->t_mu.p, mu, sizeof(double) * 3 * J, hipMemcpyHostToDevice, c->stream));
     HGMM_HIP(c, hipMemcpyAsync(c->t_cov.p, cov, sizeof(double) * 9 * J, hipMemcpyHostToDevice, c->stream));
     tree_prep_kernel<<<nblk(J16, 256), 256, 0, c->stream>>>(c->t_pi.as<double>(), c->t_mu.as<double>(),
-                                                           c->t_cov.as<double>(), 0, J16, c->t_prep.as<double>());
+                                                           c->t_cov.as<double>(), 0, J16, c->t_prep.as<double>(), flags_ptr(c));
     int* lab = c->t_current.as<int>();
     double q = 0.0;
     if (fullcov_one_pass(J16)) {
@@ -2362,11 +2523,12 @@ static int tree_upload_nodes(hgmm_ctx* c, int64_t T, const double* pi, const dou
     HGMM_TRY(ensure(c, c->t_cov, sizeof(double) * 9 * T));
     HGMM_TRY(ensure(c, c->t_prep, sizeof(double) * PREP_N * T));
     HGMM_TRY(ensure(c, c->t_mom, sizeof(double) * NMOM * T));
+    HGMM_TRY(tree_flags(c, true));
     HGMM_HIP(c, hipMemcpyAsync(c->t_pi.p, pi, sizeof(double) * T, hipMemcpyHostToDevice, c->stream));
     HGMM_HIP(c, hipMemcpyAsync(c->t_mu.p, mu, sizeof(double) * 3 * T, hipMemcpyHostToDevice, c->stream));
     HGMM_HIP(c, hipMemcpyAsync(c->t_cov.p, cov, sizeof(double) * 9 * T, hipMemcpyHostToDevice, c->stream));
     tree_prep_kernel<<<nblk(T, 256), 256, 0, c->stream>>>(c->t_pi.as<double>(), c->t_mu.as<double>(),
-                                                         c->t_cov.as<double>(), 0, T, c->t_prep.as<double>());
+                                                         c->t_cov.as<double>(), 0, T, c->t_prep.as<double>(), flags_ptr(c));
     HGMM_HIP(c, hipGetLastError());
     c->tree.nodes_ready = false;       // tables no longer describe a complete L-level tree
     return HGMM_OK;
@@ -2458,7 +2620,7 @@ extern "C" int hgmm_tree_mstep(hgmm_ctx* c, int64_t T, const double* m0, const d
     const int n_level = (int)(j_end - j_begin);
     tree_mstep_kernel<<<nblk(n_level, 256), 256, 0, c->stream>>>(mom + NMOM * j_begin, j_begin, n_level, n_points, ld,
                                                                  c->t_pi.as<double>(), c->t_mu.as<double>(),
-                                                                 c->t_cov.as<double>(), nullptr);
+                                                                 c->t_cov.as<double>(), nullptr, nullptr);
     HGMM_HIP(c, hipGetLastError());
     HGMM_HIP(c, hipMemcpyAsync(pi_inout, c->t_pi.p, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
     HGMM_HIP(c, hipMemcpyAsync(mu_inout, c->t_mu.p, sizeof(double) * 3 * T, hipMemcpyDeviceToHost, c->stream));
@@ -2485,12 +2647,24 @@ extern "C" int hgmm_tree_loglik(hgmm_ctx* c, int64_t T, const double* pi, const 
                                                                   c->t_prep.as<double>(), j_begin, n_level,
                                                                   (n_level + LL_TILE - 1) / LL_TILE * LL_TILE, nullptr,
                                                                   block_q, nullptr, nullptr, nullptr,
-                                                                  TreeStop{nullptr, 0.0, 0, nullptr, 0});
+                                                                  TreeStop{nullptr, 0.0, 0, nullptr, 0}, flags_ptr(c), nullptr);
     }
     tree_sum_kernel<<<1, 256, 0, c->stream>>>(block_q, pblocks, q_dev);
     HGMM_HIP(c, hipGetLastError());
     if (c->comm_on()) HGMM_TRY(allreduce_f64_dev(c, q_dev, 1));
     HGMM_HIP(c, hipMemcpyAsync(q_out, q_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_tree_stats(hgmm_ctx* c, unsigned long long* pairs_out, int* flags_out) {
+    if (!c) return HGMM_ERR_ARG;
+    HGMM_HIP(c, hipSetDevice(c->device));
+    HGMM_TRY(tree_flags(c, false));
+    unsigned char h[64];
+    HGMM_HIP(c, hipMemcpyAsync(h, c->t_flags.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    if (flags_out) memcpy(flags_out, h, sizeof(int));
+    if (pairs_out) memcpy(pairs_out, h + 16, sizeof(unsigned long long));
     return HGMM_OK;
 }

@@ -190,6 +190,13 @@ int hgmm_tree_mstep(hgmm_ctx* ctx, int64_t T, const double* m0, const double* m1
                     double* mu_inout, double* cov_inout);
 int hgmm_tree_loglik(hgmm_ctx* ctx, int64_t T, const double* pi, const double* mu, const double* cov,
                      int64_t j_begin, int64_t j_end, double* q_out);
+/* Work actually done by the level log-likelihood kernels since the last hgmm_tree_build / hgmm_tree_set_nodes /
+ * stand-alone step started (measurement aid for bench.py, no reference counterpart): *pairs_out = number of
+ * (point, node) pairs whose pdf was evaluated -- the reference's logLikelihoodValue (hgmm_gpu.py:107-115) visits all
+ * N x 8^(l+1); nodes with pi < eps contribute exactly 0 there and nodes whose pdf underflows to 0.0 for every point
+ * of a workgroup are rejected per workgroup here, so the count is smaller --, *flags_out bit 0 = some node's
+ * Sigma^-1 was not numerically positive definite (the kernels then evaluate the symmetric quadratic form). */
+int hgmm_tree_stats(hgmm_ctx* ctx, unsigned long long* pairs_out, int* flags_out);
 /* smallest eigenvalue / trace per node (complexity(), hgmm_cupy_cpu_working.py:87-91) */
 int hgmm_tree_node_complexity(hgmm_ctx* ctx, double* cplx_out);
 
