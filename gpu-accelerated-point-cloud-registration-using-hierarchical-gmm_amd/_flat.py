@@ -66,8 +66,10 @@ def estimate_log_prob(X, inv_cov, means, cov_type):
 
 def e_step(X, inv_cov, means, weights, cov_type, variant):
     ctx = _ctx_for(X)
-    mean_lpn, log_resp, _, _ = ctx.flat_estep(_host(inv_cov), _host(means), _host(weights), cov_type, variant)
-    return np.float32(mean_lpn), log_resp
+    # like the reference under CuPy nothing waits here: the mean is a device scalar, read when it is looked at
+    mean_lpn, log_resp, _, _ = ctx.flat_estep(_host(inv_cov), _host(means), _host(weights), cov_type, variant,
+                                              lazy_mean=True)
+    return mean_lpn, log_resp
 
 
 def m_step(X, resp, cov_type, variant, centre_hint=None):

@@ -71,6 +71,7 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_set_points_f64", [ctx, _vp, C.c_int64])
         _sig(lib, "hgmm_num_points", [ctx], C.c_int64)
         _sig(lib, "hgmm_flat_estep", [ctx, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _f64p])
+        _sig(lib, "hgmm_flat_estep_async", [ctx, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
         _sig(lib, "hgmm_flat_predict", [ctx, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp])
         _sig(lib, "hgmm_flat_log_prob", [ctx, C.c_int, C.c_int, _vp, _vp, _vp])
         _sig(lib, "hgmm_flat_mstep", [ctx, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp])
@@ -206,6 +207,52 @@ class DeviceArray:
             pass
 
 
+class DeviceScalar(DeviceArray):
+    """A float64 scalar living in HBM that is read when somebody looks at it (what a 0-d CuPy array was to the
+    reference: ``e_step`` returns ``xp.mean(log_prob_norm)`` without synchronising, gmm_impl.py:114-116).
+    ``float(s)``, arithmetic, comparisons and ``np.float32(s)`` download it (one stream synchronisation)."""
+
+    def __init__(self, ctx):
+        super().__init__(ctx, (1,), np.float64)
+        self._value = None
+
+    def item(self):
+        if self._value is None:
+            self._value = float(self.get()[0])
+        return self._value
+
+    def __float__(self):
+        return self.item()
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self.item(), dtype=dtype or np.float64)
+
+    def __repr__(self):
+        return "DeviceScalar(%r)" % self.item()
+
+    def __format__(self, spec):
+        return format(self.item(), spec)
+
+    def __abs__(self):
+        return abs(self.item())
+
+    def __neg__(self):
+        return -self.item()
+
+
+def _scalar_op(name):
+    def f(self, other):
+        return getattr(self.item(), name)(float(other))
+    f.__name__ = name
+    return f
+
+
+for _n in ("__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", "__truediv__", "__rtruediv__",
+           "__lt__", "__le__", "__gt__", "__ge__", "__eq__", "__ne__"):
+    setattr(DeviceScalar, _n, _scalar_op(_n))
+DeviceScalar.__hash__ = lambda self: id(self)
+
+
 class Context:
     """One engine context = one GPU (one rank).  Thin, explicit wrapper over the C ABI."""
 
@@ -308,8 +355,10 @@ class Context:
         return J, mu, ic, w
 
     def flat_estep(self, inv_std, mu, w, cov_type="diag", variant="W", want_log_resp=True,
-                   want_lpn=False, want_argmax=False, out=None):
-        """``out``: optional pre-allocated DeviceArray [N,J] float32 to write log_resp into."""
+                   want_lpn=False, want_argmax=False, out=None, lazy_mean=False):
+        """``out``: optional pre-allocated DeviceArray [N,J] float32 to write log_resp into.
+        ``lazy_mean``: do not wait for the kernel -- the mean log-normaliser comes back as a ``DeviceScalar``
+        that is downloaded when it is looked at (hgmm_flat_estep_async)."""
         J, mu, inv_std, w = self._flat_args(mu, inv_std, w, cov_type)
         n = self.num_points
         if out is not None and (out.shape != (n, J) or out.dtype != np.float32):
@@ -317,6 +366,12 @@ class Context:
         lr = out if out is not None else (self.empty((n, J), np.float32) if want_log_resp else None)
         lpn = self.empty((n,), np.float32) if want_lpn else None
         am = self.empty((n,), np.int32) if want_argmax else None
+        if lazy_mean:
+            ms = DeviceScalar(self)
+            self._check(self.lib.hgmm_flat_estep_async(
+                self.h, COV_TYPES[cov_type], VARIANTS[variant], J, _ptr(mu), _ptr(inv_std), _ptr(w),
+                None if lr is None else lr.ptr, None if lpn is None else lpn.ptr, None if am is None else am.ptr, ms.ptr))
+            return ms, lr, lpn, am
         mean = C.c_double()
         self._check(self.lib.hgmm_flat_estep(
             self.h, COV_TYPES[cov_type], VARIANTS[variant], J, _ptr(mu), _ptr(inv_std), _ptr(w),

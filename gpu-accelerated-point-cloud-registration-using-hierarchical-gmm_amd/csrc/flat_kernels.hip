@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 namespace hgmm {
 
@@ -1388,12 +1389,41 @@ static int flat_setup(hgmm_ctx* c, int cov_type, int variant, int J) {
 
 static size_t cov_elems(int cov_type, int J) { return cov_type == HGMM_COV_DIAG ? (size_t)3 * J : (size_t)J; }
 
+// ---- pinned staging ring ----------------------------------------------------------------------
+// Small host <-> device transfers of the API-granular calls (parameters in, M-step results out) go through a
+// pinned ring owned by the context: the host side is a memcpy, the device side a genuinely asynchronous DMA
+// that queues behind the kernels already on the stream -- so hgmm_flat_estep_enqueue returns while its kernel
+// runs and the next call's host work overlaps it.  A region is reused only after a stream synchronisation.
+constexpr size_t STAGE_BYTES = 4u << 20;
+static int stage_reserve(hgmm_ctx* c, size_t bytes, void** out) {
+    if (!c->h_stage) {
+        HGMM_HIP(c, hipHostMalloc(&c->h_stage, STAGE_BYTES, hipHostMallocDefault));
+        c->h_stage_cap = STAGE_BYTES;
+        c->h_stage_off = 0;
+    }
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes > c->h_stage_cap) return fail(c, HGMM_ERR_ARG, "staging request of %zu bytes", bytes);
+    if (c->h_stage_off + bytes > c->h_stage_cap) {
+        HGMM_HIP(c, hipStreamSynchronize(c->stream));         // every earlier region has been consumed
+        c->h_stage_off = 0;
+    }
+    *out = static_cast<char*>(c->h_stage) + c->h_stage_off;
+    c->h_stage_off += bytes;
+    return HGMM_OK;
+}
+static int stage_h2d(hgmm_ctx* c, void* dev, const void* host, size_t bytes) {
+    void* st = nullptr;
+    HGMM_TRY(stage_reserve(c, bytes, &st));
+    std::memcpy(st, host, bytes);
+    HGMM_HIP(c, hipMemcpyAsync(dev, st, bytes, hipMemcpyHostToDevice, c->stream));
+    return HGMM_OK;
+}
+
 static int flat_upload(hgmm_ctx* c, const float* mu, const float* inv_or_cov, bool is_cov, const float* w) {
     const int J = c->flat.J;
-    HGMM_HIP(c, hipMemcpyAsync(c->f_mu.p, mu, sizeof(float) * 3 * J, hipMemcpyHostToDevice, c->stream));
-    HGMM_HIP(c, hipMemcpyAsync(is_cov ? c->f_cov.p : c->f_inv.p, inv_or_cov,
-                               sizeof(float) * cov_elems(c->flat.cov_type, J), hipMemcpyHostToDevice, c->stream));
-    HGMM_HIP(c, hipMemcpyAsync(c->f_w.p, w, sizeof(float) * J, hipMemcpyHostToDevice, c->stream));
+    HGMM_TRY(stage_h2d(c, c->f_mu.p, mu, sizeof(float) * 3 * J));
+    HGMM_TRY(stage_h2d(c, is_cov ? c->f_cov.p : c->f_inv.p, inv_or_cov, sizeof(float) * cov_elems(c->flat.cov_type, J)));
+    HGMM_TRY(stage_h2d(c, c->f_w.p, w, sizeof(float) * J));
     return HGMM_OK;
 }
 
@@ -1693,10 +1723,20 @@ using namespace hgmm;
 // ==========================================================================================
 // C ABI
 // ==========================================================================================
-extern "C" int hgmm_flat_estep(hgmm_ctx* c, int cov_type, int variant, int J, const float* mu,
-                               const float* inv_std, const float* w, float* dev_log_resp,
-                               float* dev_lpn, int32_t* dev_argmax, double* mean_lpn_out) {
-    if (!c) return HGMM_ERR_ARG;
+// mean of the per-point normalisers from the per-workgroup partial sums (fixed order), one workgroup
+__global__ __launch_bounds__(256) void flat_mean_lpn_kernel(const double* __restrict__ partials, int nblocks, double n,
+                                                            double* __restrict__ out) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) acc += partials[i];
+    acc = wave_sum_f64(acc);
+    if (lane_id() == 0) sh[wave_in_block()] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (sh[0] + sh[1] + sh[2] + sh[3]) / n;
+}
+
+static int flat_estep_enqueue(hgmm_ctx* c, int cov_type, int variant, int J, const float* mu, const float* inv_std,
+                              const float* w, float* dev_log_resp, float* dev_lpn, int32_t* dev_argmax, int* grid_out) {
     HGMM_TRY(flat_check(c, cov_type, variant, J));
     HGMM_TRY(flat_setup(c, cov_type, variant, J));
     HGMM_TRY(flat_upload(c, mu, inv_std, false, w));
@@ -1717,6 +1757,16 @@ extern "C" int hgmm_flat_estep(hgmm_ctx* c, int cov_type, int variant, int J, co
     } else {
         HGMM_TRY(launch_estep<true>(c, dev_log_resp, dev_lpn, dev_argmax, &grid));
     }
+    *grid_out = grid;
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_flat_estep(hgmm_ctx* c, int cov_type, int variant, int J, const float* mu,
+                               const float* inv_std, const float* w, float* dev_log_resp,
+                               float* dev_lpn, int32_t* dev_argmax, double* mean_lpn_out) {
+    if (!c) return HGMM_ERR_ARG;
+    int grid = 0;
+    HGMM_TRY(flat_estep_enqueue(c, cov_type, variant, J, mu, inv_std, w, dev_log_resp, dev_lpn, dev_argmax, &grid));
     if (mean_lpn_out) {
         std::vector<double> h(grid);
         HGMM_HIP(c, hipMemcpyAsync(h.data(), c->f_lpn_partials.p, sizeof(double) * grid,
@@ -1727,6 +1777,19 @@ extern "C" int hgmm_flat_estep(hgmm_ctx* c, int cov_type, int variant, int J, co
         *mean_lpn_out = t / (double)c->n;
     }
     return HGMM_OK;
+}
+
+extern "C" int hgmm_flat_estep_async(hgmm_ctx* c, int cov_type, int variant, int J, const float* mu,
+                                     const float* inv_std, const float* w, float* dev_log_resp,
+                                     float* dev_lpn, int32_t* dev_argmax, double* dev_mean_lpn) {
+    if (!c) return HGMM_ERR_ARG;
+    int grid = 0;
+    HGMM_TRY(flat_estep_enqueue(c, cov_type, variant, J, mu, inv_std, w, dev_log_resp, dev_lpn, dev_argmax, &grid));
+    if (dev_mean_lpn) {
+        flat_mean_lpn_kernel<<<1, 256, 0, c->stream>>>(c->f_lpn_partials.as<double>(), grid, (double)c->n, dev_mean_lpn);
+        HGMM_HIP(c, hipGetLastError());
+    }
+    return HGMM_OK;                                   // nothing waited for: the caller's arrays were copied to the ring
 }
 
 extern "C" int hgmm_flat_predict(hgmm_ctx* c, int cov_type, int variant, int J, const float* mu,
@@ -1775,7 +1838,7 @@ extern "C" int hgmm_flat_mstep(hgmm_ctx* c, int cov_type, int variant, int J, co
     HGMM_TRY(flat_setup(c, cov_type, variant, J));
     FlatState& f = c->flat;
     if (centre_hint) {
-        HGMM_HIP(c, hipMemcpyAsync(c->f_mu.p, centre_hint, sizeof(float) * 3 * J, hipMemcpyHostToDevice, c->stream));
+        HGMM_TRY(stage_h2d(c, c->f_mu.p, centre_hint, sizeof(float) * 3 * J));
         flat_hint_kernel<<<(f.Jpad + 255) / 256, 256, 0, c->stream>>>(c->f_mu.as<float>(), J, f.Jpad,
                                                                     c->f_hint.as<float>());
     } else {
@@ -1821,11 +1884,19 @@ extern "C" int hgmm_flat_mstep(hgmm_ctx* c, int cov_type, int variant, int J, co
             c->f_cov.as<float>(), c->f_w.as<float>(), nullptr, nullptr, nullptr, 0, 0.f, nullptr, nullptr,
             c->f_ctl.as<int>() + 16, nullptr);
     HGMM_HIP(c, hipGetLastError());
-    HGMM_HIP(c, hipMemcpyAsync(mu_out, c->f_mu.p, sizeof(float) * 3 * J, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipMemcpyAsync(cov_out, c->f_cov.p, sizeof(float) * cov_elems(cov_type, J),
-                               hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipMemcpyAsync(w_out, c->f_w.p, sizeof(float) * J, hipMemcpyDeviceToHost, c->stream));
+    // results: three DMA packets into the pinned ring, ONE synchronisation, then plain memcpys
+    const size_t b_mu = sizeof(float) * 3 * J, b_cov = sizeof(float) * cov_elems(cov_type, J), b_w = sizeof(float) * J;
+    void* st = nullptr;
+    HGMM_TRY(stage_reserve(c, b_mu + b_cov + b_w, &st));
+    char* h = static_cast<char*>(st);
+    HGMM_HIP(c, hipMemcpyAsync(h, c->f_mu.p, b_mu, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipMemcpyAsync(h + b_mu, c->f_cov.p, b_cov, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipMemcpyAsync(h + b_mu + b_cov, c->f_w.p, b_w, hipMemcpyDeviceToHost, c->stream));
     HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    c->h_stage_off = 0;                                    // the stream is idle: every region of the ring is free
+    std::memcpy(mu_out, h, b_mu);
+    std::memcpy(cov_out, h + b_mu, b_cov);
+    std::memcpy(w_out, h + b_mu + b_cov, b_w);
     return HGMM_OK;
 }
 

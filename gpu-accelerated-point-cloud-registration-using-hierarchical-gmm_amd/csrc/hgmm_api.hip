@@ -366,6 +366,7 @@ extern "C" int hgmm_destroy(hgmm_ctx* c) {
                       &c->km_mind2, &c->km_partial, &c->km_out, &c->gt_buf, &c->t_momq, &c->t_flags};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (auto& p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     (void)hipStreamDestroy(c->stream);
     delete c;

@@ -75,6 +75,10 @@ struct hgmm_ctx {
     hgmm::DevBuf f_hint;                      // float [3][Jpad] centre hint for m-step
     hgmm::DevBuf f_cm, f_cs, f_ca, f_lpn2;    // chunked path: per-chunk (max, sum, arg-max) [C][n], lpn2 [n]
     hgmm::DevBuf scratch;
+    // pinned host ring for small parameter uploads / result downloads (flat_kernels.hip: stage_*): a pageable
+    // hipMemcpyAsync is staged by the runtime behind the stream's pending work, a pinned one is a plain DMA packet
+    void* h_stage = nullptr;
+    size_t h_stage_cap = 0, h_stage_off = 0;
 
     // ---- tree -------------------------------------------------------------------
     hgmm::TreeState tree;

@@ -340,6 +340,8 @@ __global__ void tree_chunks_kernel(const int* __restrict__ seg_start, int P, int
 // ------------------------------------------------------------------------------------------
 // E-step of one tree level
 // ------------------------------------------------------------------------------------------
+constexpr int ES_LD = 66;            // LDS row stride (doubles) of the moment contraction's operands: conflict-free fragment reads
+typedef double double4_es __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(CH) void tree_estep_kernel(
     const double* __restrict__ xs, int64_t n_pad, const double* __restrict__ prep,
     const int* __restrict__ chunk_desc, const int* __restrict__ n_chunks, int64_t parent_level_first,
@@ -397,16 +399,36 @@ __global__ __launch_bounds__(CH) void tree_estep_kernel(
     }
     if (active) cur_sorted[i] = (int)(j0 + am);
 
+    // The wave's 8 x 10 moment sums  M[k][m] = sum_lanes gamma[k] f[m]  as ONE dense contraction on the fp64 matrix
+    // cores: gamma and the features go through LDS (component- / feature-major, one row per child resp. feature),
+    // 16 v_mfma_f64_16x16x4_f64 walk the wave's 64 points four at a time.  (Round 2 took 80 DPP wave reductions here,
+    // ~1400 dependent fp64 instructions per wave -- a third of this latency-bound kernel's time at C4.)  Rows 8..15 of
+    // the A operand and columns 10..15 of B alias rows that exist: their products land in accumulator entries nobody reads.
     __shared__ double sh[CH / 64][8 * NMOM];
+    __shared__ double GS[CH / 64][8][ES_LD];
+    __shared__ double FS[CH / 64][NMOM][ES_LD];
     const int w = wave_in_block();
     const int lane = lane_id();
-    const double f[NMOM] = {1.0, x0, x1, x2, x0 * x0, x0 * x1, x0 * x2, x1 * x1, x1 * x2, x2 * x2};
+    {
+        const double f[NMOM] = {1.0, x0, x1, x2, x0 * x0, x0 * x1, x0 * x2, x1 * x1, x1 * x2, x2 * x2};
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 8; ++k) GS[w][k][lane] = g[k];
 #pragma unroll
-        for (int m = 0; m < NMOM; ++m) {
-            const double v = wave_sum_f64(g[k] * f[m]);
-            if (lane == 0) sh[w][k * NMOM + m] = v;
+        for (int m = 0; m < NMOM; ++m) FS[w][m][lane] = f[m];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int a_idx = lane & 15, b_idx = lane >> 4;
+        const double* ga = &GS[w][a_idx & 7][b_idx];
+        const double* fb = &FS[w][a_idx < NMOM ? a_idx : NMOM - 1][b_idx];
+        double4_es acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int st = 0; st < 16; ++st) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[4 * st], fb[4 * st], acc, 0, 0, 0);
+        // D layout (f64 16x16x4): row (child) = (lane >> 4) + 4 r, column (feature) = lane & 15
+        if (a_idx < NMOM) {
+            sh[w][b_idx * NMOM + a_idx] = acc[0];
+            sh[w][(b_idx + 4) * NMOM + a_idx] = acc[1];
         }
     }
     __syncthreads();
@@ -1193,6 +1215,7 @@ static int tree_alloc_nodes(hgmm_ctx* c, int L) {
     HGMM_TRY(ensure(c, c->t_cov, sizeof(double) * 9 * T));
     HGMM_TRY(ensure(c, c->t_prep, sizeof(double) * PREP_N * T));
     HGMM_TRY(ensure(c, c->t_mom, sizeof(double) * NMOM * T));
+    HGMM_TRY(tree_flags(c, true));
     return HGMM_OK;
 }
 
@@ -1200,7 +1223,12 @@ static int tree_alloc_nodes(hgmm_ctx* c, int L) {
 // level log-likelihood (uint64 at byte 16); `reset`: a new node table is about to be prepared
 static int tree_flags(hgmm_ctx* c, bool reset) {
     HGMM_TRY(ensure(c, c->t_flags, 64));
-    if (reset) HGMM_HIP(c, hipMemsetAsync(c->t_flags.p, 0, 64, c->stream));
+    if (reset) {
+        HGMM_HIP(c, hipMemsetAsync(c->t_flags.p, 0, 64, c->stream));
+        // HGMM_TREE_NO_CHOL=1: take the symmetric-form fallback everywhere (lets the tests hold both forms to the oracle)
+        if (const char* e = std::getenv("HGMM_TREE_NO_CHOL"))
+            if (e[0] == '1') HGMM_HIP(c, hipMemsetAsync(c->t_flags.p, 1, 1, c->stream));
+    }
     return HGMM_OK;
 }
 static inline int* flags_ptr(hgmm_ctx* c) { return c->t_flags.as<int>(); }
@@ -1905,25 +1933,32 @@ __host__ __device__ inline int ft_ldg(int J16) {        // doubles per point row
     return (J16 + 127) / 128 * 128 + 16;                // for whole 128-column steps (tail columns stay 0)
 }
 inline size_t ft_lds_bytes(int J16) {
-    return sizeof(double) * ((size_t)FT_P * ft_ldg(J16) + 16 * FT_LDF + 2 * FT_P + J16 + 2 * 3 * FT_P + EXP_TAB_N);
+    return sizeof(double) * ((size_t)FT_P * ft_ldg(J16) + 16 * FT_LDF + 3 * FT_P + J16 + 4 * 3 * FT_P + EXP_TAB_N);
 }
 
-template <int CPL>
-__global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
+// The kernel's body, specialised at compile time on the form of the exponent:
+//   CHOL   triangular form -|R (x - o) - R (mu - o)|^2 with R^T R = Sigma^-1 / 2 (prep[12..17]) and o = the cloud's first
+//          point: 9 fma / mul per pair against 14 for 3 subtractions + the symmetric form; R (mu - o) is formed once per
+//          component at the start.  (All points share ONE origin -- the flat fit's cloud is not spatially sorted --, so the
+//          form carries a relative error of ~ eps |x - o| / sigma in the exponent: 1e-13 for millimetre clusters in a
+//          metre-sized cloud, far inside the parity tolerances.)
+//   !CHOL  the symmetric form, for node tables with a Sigma^-1 that failed the Cholesky test (flags bit 0).
+template <int CPL, bool CHOL>
+__device__ __forceinline__ void full_fused_body(
     const double* __restrict__ xs, int64_t n, int64_t n_pad, const double* __restrict__ prep, int J16,
     int* __restrict__ label_out, double* __restrict__ block_q, double* __restrict__ partials /*[grid][J16][NMOM]*/,
-    int want_stats, long long* __restrict__ dbg = nullptr) {
-    extern __shared__ double lds[];
+    int want_stats, long long* __restrict__ dbg, double* lds) {
     long long tA = 0, tB = 0, tC = 0, tW = 0, tm = 0;
 #define FT_TICK(acc) do { if (dbg) { const long long now_ = clock64(); acc += now_ - tm; tm = now_; } } while (0)
     const int LDG = ft_ldg(J16);
     double* G = lds;                              // [FT_P][LDG]
     double* F = G + (size_t)FT_P * LDG;           // [16 features][FT_LDF]
     double* INV = F + 16 * FT_LDF;                // [FT_P] 1 / denominator (0: dead point)
-    double* TOT = INV + FT_P;                     // [FT_P] sum over the components with pi >= eps (-1: dead point)
-    double* WL = TOT + FT_P;                      // [J16] 1.0 where pi_j >= eps (the component counts towards q)
-    double* XS = WL + J16;                        // [2][3][FT_P] the tile's coordinates, double-buffered
-    double* EXPT = XS + 2 * 3 * FT_P;             // [128] 2^(j/128) for exp_nonpos4
+    double* TOT = INV + FT_P;                     // [2][FT_P] sum over the components with pi >= eps (-1: dead point), by tile parity
+    double* WL = TOT + 2 * FT_P;                  // [J16] 1.0 where pi_j >= eps (the component counts towards q)
+    double* XS = WL + J16;                        // [2][3][FT_P] the tile's coordinates relative to the origin, double-buffered
+    double* XA = XS + 2 * 3 * FT_P;               // [2][3][FT_P] ... and as given (the statistics' features)
+    double* EXPT = XA + 2 * 3 * FT_P;             // [128] 2^(j/128) for exp_nonpos4
     const int w = wave_in_block(), lane = lane_id();
     const int tid = (int)threadIdx.x;
     exp_tab_load(EXPT);                           // (the barrier behind the WL / G initialisation covers it)
@@ -1937,6 +1972,8 @@ __global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
     int jc[CPL];
     jc[0] = tid;
     if (CPL == 2) jc[1] = half_wave ? FT_BLOCK + 64 * w_r + (lane & 31) : tid + FT_BLOCK;
+    const double o0 = xs[0], o1 = xs[n_pad], o2 = xs[2 * n_pad];
+    // CHOL: s* = R, m* = -R (mu - o);   !CHOL: s* = -Sigma^-1 / 2, m* = mu - o
     double s00[CPL], s01[CPL], s02[CPL], s11[CPL], s12[CPL], s22[CPL], m0[CPL], m1[CPL], m2[CPL], wE[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
@@ -1945,10 +1982,19 @@ __global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
         s00[c] = s01[c] = s02[c] = s11[c] = s12[c] = s22[c] = m0[c] = m1[c] = m2[c] = 0.0;
         if (j < J16) {
             const double* pr = prep + PREP_N * j;
-            // -1/2 Sigma^-1: the quadratic form below is the (non-positive) exponent itself
-            s00[c] = -0.5 * pr[0]; s01[c] = -0.5 * pr[1]; s02[c] = -0.5 * pr[2];
-            s11[c] = -0.5 * pr[3]; s12[c] = -0.5 * pr[4]; s22[c] = -0.5 * pr[5];
-            m0[c] = pr[6]; m1[c] = pr[7]; m2[c] = pr[8]; wE[c] = pr[9];
+            const double u0 = pr[6] - o0, u1 = pr[7] - o1, u2 = pr[8] - o2;
+            if (CHOL) {
+                s00[c] = pr[PREP_R]; s01[c] = pr[PREP_R + 1]; s02[c] = pr[PREP_R + 2];
+                s11[c] = pr[PREP_R + 3]; s12[c] = pr[PREP_R + 4]; s22[c] = pr[PREP_R + 5];
+                m0[c] = -fma(s02[c], u2, fma(s01[c], u1, s00[c] * u0));
+                m1[c] = -fma(s12[c], u2, s11[c] * u1);
+                m2[c] = -(s22[c] * u2);
+            } else {
+                s00[c] = -0.5 * pr[0]; s01[c] = -0.5 * pr[1]; s02[c] = -0.5 * pr[2];
+                s11[c] = -0.5 * pr[3]; s12[c] = -0.5 * pr[4]; s22[c] = -0.5 * pr[5];
+                m0[c] = u0; m1[c] = u1; m2[c] = u2;
+            }
+            wE[c] = pr[9];
         }
     }
     // components with 0 < pi < eps take part in the E-step but not in q (C:80): rare enough that the second row
@@ -1959,7 +2005,7 @@ __global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
         WL[j] = (wl != 0.0) ? 1.0 : 0.0;
         if (wl == 0.0 && we != 0.0) my_small = 1;
     }
-    for (int e = tid; e < FT_P * LDG; e += FT_BLOCK) G[e] = 0.0;   // phase B reads whole 64-column steps
+    for (int e = tid; e < FT_P * LDG; e += FT_BLOCK) G[e] = 0.0;   // phase B reads whole 128-column steps
     const bool any_small = __syncthreads_or(my_small) != 0;
     // accumulator tiles of this wave
     const int ntiles = J16 / 16;
@@ -1973,16 +2019,27 @@ __global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
     const int64_t per = (tiles + gridDim.x - 1) / gridDim.x;
     const int64_t t0 = (int64_t)blockIdx.x * per;
     const int64_t t1 = (t0 + per < tiles) ? t0 + per : tiles;
-    double lq = 0.0;                              // lane 0 of each wave: sum of its points' log-likelihood terms
+    double lq = 0.0;                              // wave FT_WAVES - 1: sum of the workgroup's log-likelihood terms
 
     // coordinates of a tile -> LDS buffer `buf` (threads 0..47; rows past the end repeat the last point)
+    const int st_d = tid / FT_P, st_p = tid % FT_P;                      // the staging threads' (coordinate, point)
+    const double st_o = (tid < 3 * FT_P) ? xs[(size_t)st_d * n_pad] : 0.0;    // ... and their coordinate of the origin
     auto stage = [&](int64_t tile, int buf) {
         if (tid < 3 * FT_P) {
-            const int d = tid / FT_P, p = tid % FT_P;
-            int64_t i = tile * FT_P + p;
+            int64_t i = tile * FT_P + st_p;
             i = i < n ? i : n - 1;
-            XS[(buf * 3 + d) * FT_P + p] = xs[(size_t)d * n_pad + i];
+            const double v = xs[(size_t)st_d * n_pad + i];
+            XA[(buf * 3 + st_d) * FT_P + st_p] = v;
+            XS[(buf * 3 + st_d) * FT_P + st_p] = v - st_o;
         }
+    };
+    // the log-likelihood terms of one tile (its TOT row), 16 lanes at once; taken by the last wave -- which has the
+    // lightest phase A -- at the START of the next tile's phase A, i.e. off the critical path of phase C
+    auto tile_loglik = [&](int par) {
+        const double tv = (lane < FT_P) ? TOT[par * FT_P + lane] : -1.0;
+        double term = (tv >= 0.0) ? log(fmax(tv, TREE_EPS)) : 0.0;
+        term = wave_sum_f64(term);
+        lq += term;
     };
     if (t0 < t1) stage(t0, 0);
     __syncthreads();
@@ -1991,6 +2048,7 @@ __global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
         const int buf = (int)((tile - t0) & 1);
         const double* X = XS + buf * 3 * FT_P;
         if (dbg) tm = clock64();
+        if (w == FT_WAVES - 1 && tile > t0) tile_loglik(buf ^ 1);
         // ---- phase A: g[p][j] for the lane's components, all 16 points (branch-free: a component with
         //      pi = 0 or a singular covariance has wE = 0 and S = 0, q >= 1500 gives exp -> 0 anyway) ----------
         // four (point, component) pairs per step
@@ -1999,8 +2057,15 @@ __global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int c = c_of(k);
-                const double d0 = X[pt[k]] - m0[c], d1 = X[FT_P + pt[k]] - m1[c], d2 = X[2 * FT_P + pt[k]] - m2[c];
-                y[k] = sym3_quad(s00[c], s01[c], s02[c], s11[c], s12[c], s22[c], d0, d1, d2);
+                const double a0 = X[pt[k]], a1 = X[FT_P + pt[k]], a2 = X[2 * FT_P + pt[k]];
+                if (CHOL) {
+                    const double z0 = fma(s02[c], a2, fma(s01[c], a1, fma(s00[c], a0, m0[c])));
+                    const double z1 = fma(s12[c], a2, fma(s11[c], a1, m1[c]));
+                    const double z2 = fma(s22[c], a2, m2[c]);
+                    y[k] = -fma(z2, z2, fma(z1, z1, z0 * z0));
+                } else {
+                    y[k] = sym3_quad(s00[c], s01[c], s02[c], s11[c], s12[c], s22[c], a0 - m0[c], a1 - m1[c], a2 - m2[c]);
+                }
             }
             exp_nonpos4(y, e, EXPT);
 #pragma unroll
@@ -2039,27 +2104,24 @@ __global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
         // ---- phase B: wave w owns points 2w, 2w + 1 ---------------------------------------------------------
         {
             // half-wave h = lane >> 5 owns point 2 w + h: 32 lanes stride through the row (two 32-lane groups read two
-            // rows: conflict-free), one 5-step DPP reduction serves both points (results in lanes 31 and 63)
+            // rows: conflict-free), one 5-step DPP reduction serves both points (results in lanes 31 and 63).
+            // Per 128 columns a lane takes 4 values: row sum, running maximum and -- instead of an index per value --
+            // the 128-column step in which its maximum was last raised (strictly: the first such step wins); the step's
+            // four values are looked at again afterwards.  9 VALU instructions per 4 values (round 2: ~25).
             const int h = lane >> 5, sub = lane & 31;
             const int p = w * 2 + h;
             const double* Gp = G + (size_t)p * LDG;
             const int J128 = (J16 + 127) & ~127;                       // the row is zero beyond J16
             double den = 0.0, tot = 0.0, best = -1.0;
-            int am = 0x7fffffff;
+            int jbest = 0;
             for (int jb = 0; jb < J128; jb += 128) {                   // four 32-column steps at a time, loads first
                 double gv[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) gv[u] = Gp[jb + 32 * u + sub];
-                // pairwise, so that the compare / select chain is two deep per batch instead of four; ties keep
-                // the lower index (first maximum of the lane's subsequence)
-                const bool s01 = gv[1] > gv[0], s23 = gv[3] > gv[2];
-                const double m01 = s01 ? gv[1] : gv[0], m23 = s23 ? gv[3] : gv[2];
-                const int i01 = jb + sub + (s01 ? 32 : 0), i23 = jb + sub + (s23 ? 96 : 64);
-                const bool sb = m23 > m01;
-                const double mb = sb ? m23 : m01;
-                const int ib = sb ? i23 : i01;
+                const double m4 = fmax(fmax(gv[0], gv[1]), fmax(gv[2], gv[3]));
                 den += (gv[0] + gv[1]) + (gv[2] + gv[3]);
-                if (mb > best) { best = mb; am = ib; }
+                jbest = (m4 > best) ? jb : jbest;
+                best = fmax(best, m4);
                 if (any_small) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -2067,6 +2129,12 @@ __global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
                         tot = fma(gv[u], (j < J16) ? WL[j] : 0.0, tot);
                     }
                 }
+            }
+            // the lane's first column holding its maximum: the first of the step's four values equal to it
+            int am;
+            {
+                const double g0 = Gp[jbest + sub], g1 = Gp[jbest + 32 + sub], g2 = Gp[jbest + 64 + sub];
+                am = jbest + sub + ((g0 == best) ? 0 : ((g1 == best) ? 32 : ((g2 == best) ? 64 : 96)));
             }
             double den0, den1, bm0, bm1;
             halfwave_sum_f64(den, den0, den1);
@@ -2077,20 +2145,21 @@ __global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
             halfwave_min_i32((best == bm_h) ? am : 0x7fffffff, c0, c1);
             double tot_h = den_h;
             if (any_small) {
-                double t0, t1;
-                halfwave_sum_f64(tot, t0, t1);
-                tot_h = h ? t1 : t0;
+                double t0s, t1s;
+                halfwave_sum_f64(tot, t0s, t1s);
+                tot_h = h ? t1s : t0s;
             }
             const double inv = 1.0 / den_h;
             if (sub == 0) {
                 const bool live = base + p < n;
                 const bool good = den_h > TREE_EPS;
                 INV[p] = (live && good) ? inv : 0.0;
-                TOT[p] = live ? tot_h : -1.0;                          // its log is taken in phase C (one wave, 16 lanes)
+                TOT[buf * FT_P + p] = live ? tot_h : -1.0;             // its log is taken during the next tile's phase A
                 if (live) label_out[base + p] = good ? (h ? c1 : c0) : 0;   // all gammas zero -> argmax = 0 (C:178,184)
             }
             if (sub < 16) {
-                const double x0 = X[p], x1 = X[FT_P + p], x2 = X[2 * FT_P + p];
+                const double* A = XA + buf * 3 * FT_P;                 // cloud coordinates
+                const double x0 = A[p], x1 = A[FT_P + p], x2 = A[2 * FT_P + p];
                 double f = 0.0;
                 switch (sub) {
                     case 0: f = 1.0; break;
@@ -2112,12 +2181,6 @@ __global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
         __syncthreads();
         FT_TICK(tW);
         // ---- phase C: statistics on the matrix cores ---------------------------------------------------------
-        if (w == FT_WAVES - 1) {                                       // the tile's log-likelihood terms, 16 lanes at once
-            const double tv = (lane < FT_P) ? TOT[lane] : -1.0;
-            double term = (tv >= 0.0) ? log(fmax(tv, TREE_EPS)) : 0.0;
-            term = wave_sum_f64(term);
-            lq += term;
-        }
         double bfrag[4], ifrag[4];
         if (want_stats) {
 #pragma unroll
@@ -2143,6 +2206,7 @@ __global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
         __syncthreads();                                               // G is overwritten by the next tile
         FT_TICK(tW);
     }
+    if (w == FT_WAVES - 1 && t0 < t1) tile_loglik((int)((t1 - 1 - t0) & 1));      // the last tile's terms
     if (dbg && lane == 0 && blockIdx.x == 7) {
         dbg[w * 4 + 0] = tA; dbg[w * 4 + 1] = tB; dbg[w * 4 + 2] = tC; dbg[w * 4 + 3] = tW;
     }
@@ -2157,6 +2221,19 @@ __global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
         }
     }
     if (w == FT_WAVES - 1 && lane == 0) block_q[blockIdx.x] = lq;
+#undef FT_TICK
+}
+
+template <int CPL>
+__global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
+    const double* __restrict__ xs, int64_t n, int64_t n_pad, const double* __restrict__ prep, int J16,
+    int* __restrict__ label_out, double* __restrict__ block_q, double* __restrict__ partials /*[grid][J16][NMOM]*/,
+    int want_stats, const int* __restrict__ flags, long long* __restrict__ dbg = nullptr) {
+    extern __shared__ double lds[];
+    if (flags && (*flags & 1))                     // kernel-uniform: some Sigma^-1 failed the Cholesky test
+        full_fused_body<CPL, false>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds);
+    else
+        full_fused_body<CPL, true>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds);
 }
 
 // one wave per component: fixed-order sum over the workgroups' partials
@@ -2244,7 +2321,8 @@ static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_hos
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             full_fused_kernel<1><<<grid, FT_BLOCK, lds, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
                                                                    c->t_prep.as<double>(), J16, labels, block_q,
-                                                                   c->t_partials.as<double>(), want_stats ? 1 : 0);
+                                                                   c->t_partials.as<double>(), want_stats ? 1 : 0,
+                                                                   flags_ptr(c));
         } else {
             HGMM_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&full_fused_kernel<2>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2252,7 +2330,8 @@ static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_hos
             if (std::getenv("HGMM_FT_DEBUG")) { HGMM_HIP(c, hipMalloc(&dbg, 8 * 4 * 8)); }
             full_fused_kernel<2><<<grid, FT_BLOCK, lds, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
                                                                    c->t_prep.as<double>(), J16, labels, block_q,
-                                                                   c->t_partials.as<double>(), want_stats ? 1 : 0, dbg);
+                                                                   c->t_partials.as<double>(), want_stats ? 1 : 0,
+                                                                   flags_ptr(c), dbg);
             if (dbg) {
                 long long h[32];
                 HGMM_HIP(c, hipStreamSynchronize(c->stream));

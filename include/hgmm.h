@@ -101,6 +101,14 @@ int hgmm_flat_estep(hgmm_ctx* ctx, int cov_type, int variant, int J,
                     const float* mu, const float* inv_std, const float* w,
                     float* dev_log_resp, float* dev_lpn, int32_t* dev_argmax,
                     double* mean_lpn_out);
+/* The same E-step without waiting for it: the kernels are enqueued on the context's stream, the host parameter
+ * arrays have been copied to the context's pinned staging ring when the call returns (the caller may reuse them),
+ * and the mean log-normaliser is written to the DEVICE double dev_mean_lpn (or NULL) by a one-workgroup kernel
+ * behind the E-step.  This is what the reference's e_step() is under CuPy (gmm_impl.py:105-116 returns device
+ * arrays, nothing synchronises): a following hgmm_flat_mstep overlaps its host work with this kernel. */
+int hgmm_flat_estep_async(hgmm_ctx* ctx, int cov_type, int variant, int J,
+                          const float* mu, const float* inv_std, const float* w,
+                          float* dev_log_resp, float* dev_lpn, int32_t* dev_argmax, double* dev_mean_lpn);
 /* Un-normalised per-pair log-densities log N(x_i; mu_j, diag) -> dev_log_prob [N,J]
  * (estimate_log_prob / estimate_log_prob_spherical, gmm_waymo gmm_impl.py:53-78). */
 int hgmm_flat_log_prob(hgmm_ctx* ctx, int cov_type, int J, const float* mu, const float* inv_std,

@@ -732,3 +732,46 @@ def res_lls(hgmm_amd, X, mu0, cov0, w0, iters):
     b = GMM_GPU_Base(len(mu0), max_iter=iters, tol=1e-4, cov_type='spherical')
     b._verbose = False
     return b.fit(X, init=(mu0, w0, cov0)).lls
+
+
+def test_async_estep_and_device_scalar(ctx, bunny):
+    """hgmm_flat_estep_async: nothing waits for the kernel, the host arrays may be reused at once (they were copied to
+    the pinned ring), the mean log-normaliser is a DeviceScalar read on demand; results equal the blocking call's.
+    Then the API-faithful loop (e_step -> m_step -> inv_cov on the host) against the oracle's."""
+    import hgmm_amd
+    X = bunny[::3]
+    J = 100
+    mu0, w0, cov0 = flat_em.seeded_init(X, J, 5)
+    inv0 = (1.0 / np.sqrt(cov0)).astype(np.float32)
+    ctx.set_points(X)
+    mean_b, lr_b, _, _ = ctx.flat_estep(inv0, mu0, w0, "diag", "W")
+    a_inv, a_mu, a_w = inv0.copy(), mu0.copy(), w0.copy()
+    mean_a, lr_a, lpn_a, am_a = ctx.flat_estep(a_inv, a_mu, a_w, "diag", "W", want_lpn=True, want_argmax=True, lazy_mean=True)
+    a_inv[:] = np.nan; a_mu[:] = np.nan; a_w[:] = np.nan          # the call has returned: its inputs are ours again
+    assert isinstance(mean_a, hgmm_amd.DeviceScalar)
+    assert float(mean_a) == mean_b and abs(mean_a - mean_b) == 0.0 and np.float32(mean_a) == np.float32(mean_b)
+    assert np.array_equal(lr_a.get(), lr_b.get())
+    assert abs(lpn_a.get().astype(np.float64).mean() - float(mean_a)) < 1e-5
+    # many un-synchronised calls in a row wrap the staging ring (it synchronises before reusing a region)
+    last = None
+    for k in range(400):
+        last = ctx.flat_estep(inv0, mu0 + np.float32(1e-4 * (k % 7)), w0, "diag", "W", want_log_resp=False, lazy_mean=True)[0]
+    o_mean, _ = flat_em.e_step(X.astype(np.float64), inv0.astype(np.float64), (mu0 + np.float32(1e-4 * (399 % 7))).astype(np.float64),
+                               w0.astype(np.float64), "diag", "W")
+    assert abs(float(last) - o_mean) < 1e-5
+    # the module-level loop of a caller of the reference's functions, 6 iterations, against the oracle's same loop
+    from hgmm_amd.gmm_waymo import gmm_impl as W
+    dX = W.asarray(X, ctx)
+    inv, mu, w = inv0, mu0, w0
+    oi, om, ow = inv0.astype(np.float64), mu0.astype(np.float64), w0.astype(np.float64)
+    X64 = X.astype(np.float64)
+    for _ in range(6):
+        ll, lr = W.e_step(dX, inv, mu, w)
+        w, mu, cov = W.m_step(dX, lr.exp(), centre_hint=mu)
+        inv = (1.0 / (np.sqrt(cov + np.float32(1e-6)) + np.float32(1e-8))).astype(np.float32)
+        o_ll, o_lr = flat_em.e_step(X64, oi, om, ow, "diag", "W")
+        ow, om, oc = flat_em.m_step(X64, np.exp(o_lr), "diag", "W")
+        oi = 1.0 / (np.sqrt(oc + 1e-6) + 1e-8)
+        assert abs(ll - o_ll) < 2e-5
+    np.testing.assert_allclose(mu, om, atol=2e-5)
+    np.testing.assert_allclose(w, ow, rtol=1e-3, atol=1e-6)

@@ -526,3 +526,48 @@ def test_tree_1M_matches_oracle_fixture(ctx):
         assert abs(s - 1.0) < 1e-9, (l, s)         # uniform cloud: no mass is dropped anywhere
     again = build(ctx, P, L, float(g["ls"]), float(g["ld"]), idx, float(g["sig2"]), max_iters=k)
     assert np.array_equal(again[5], q) and np.array_equal(again[3], leaf) and np.array_equal(again[2], cov)
+
+
+def test_symmetric_form_fallback_and_pair_counter(ctx, bunny, monkeypatch):
+    """The level log-likelihood and the one-pass full-covariance kernel evaluate the exponent in a triangular form
+    (R^T R = Sigma^-1 / 2) and fall back to the symmetric form when a node's Sigma^-1 fails the Cholesky test.
+    Both forms are held to the oracle: the fallback is forced with HGMM_TREE_NO_CHOL=1.  Also hgmm_tree_stats: the
+    pdf evaluations really done never exceed the reference's N x 8^(l+1) per iteration, and skipping is exact."""
+    P = bunny[::8].astype(np.float64)
+    L = 3
+    T = hgmm_tree.n_total(L)
+    idx = np.random.RandomState(72).randint(T, size=T)
+    o_pi, o_mu, o_cov, tr = hgmm_tree.build_tree(P, L, 80.0, 1e-4, idx, 0.00034)
+    J = 40
+    jdx = np.random.RandomState(3).choice(len(P), J, replace=False)
+    o_full = hgmm_tree.build_flat_fullcov(P, J, 1.0, 1e-4, jdx, 0.0005, max_iters=8)
+    for forced in (False, True):
+        if forced:
+            monkeypatch.setenv("HGMM_TREE_NO_CHOL", "1")
+        pi, mu, cov, leaf, iters, q = build(ctx, P, L, 80.0, 1e-4, idx, 0.00034)
+        pairs, flags = ctx.tree_stats()
+        assert flags == (1 if forced else 0)
+        assert list(iters) == list(tr.iters_per_level)
+        np.testing.assert_allclose(q, tr.q, rtol=1e-9, atol=1e-6)
+        assert np.array_equal(leaf, tr.current_idx_per_level[-1])
+        np.testing.assert_allclose(cov, o_cov, rtol=1e-6, atol=1e-14)
+        reference_pairs = sum(int(it) * len(P) * 8 ** (l + 1) for l, it in enumerate(iters))
+        assert 0 < pairs <= reference_pairs
+        print("forced symmetric form" if forced else "triangular form", "evaluated pairs %d of %d (%.1f %%)"
+              % (pairs, reference_pairs, 100.0 * pairs / reference_pairs))
+        ctx.set_points(P)
+        f_pi, f_mu, f_cov, f_lab, f_q = ctx.fullcov_fit(J, 1.0, 1e-4, P[jdx], 0.0005, 8)
+        np.testing.assert_allclose(f_q, o_full[3], rtol=1e-9, atol=1e-6)
+        assert np.array_equal(f_lab, o_full[4])
+        np.testing.assert_allclose(f_cov, o_full[2], rtol=1e-6, atol=1e-14)
+    monkeypatch.delenv("HGMM_TREE_NO_CHOL")
+    # a caller-supplied table with an indefinite "covariance" whose determinant is positive raises the flag
+    pi8 = np.full(8, 1.0 / 8)
+    mu8 = P[:8].copy()
+    cov8 = np.tile(np.identity(3) * 1e-3, (8, 1, 1))
+    cov8[5] = np.diag([-1e-3, -1e-3, 1e-3])
+    ctx.tree_set_nodes(1, pi8, mu8, cov8)
+    assert ctx.tree_stats()[1] == 1
+    cov8[5] = np.identity(3) * 1e-3
+    ctx.tree_set_nodes(1, pi8, mu8, cov8)
+    assert ctx.tree_stats()[1] == 0

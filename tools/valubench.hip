@@ -177,11 +177,111 @@ static void run(int blocks, int iters, float* out, long long* cyc) {
     hipEventDestroy(b);
 }
 
+
+// ---- cross-wave overlap of the matrix pipe with the vector pipe ----------------------------------------------------
+// 512-thread workgroups, one per CU: waves 0-3 (one per SIMD) run stream A, waves 4-7 stream B (or nothing).  If the
+// two pipes of a SIMD work concurrently for DIFFERENT waves, T(A and B) ~ max(T(A), T(B)); if they serialise, the sum.
+//   PAIR 0: A = v_mfma_f32_4x4x1_16b_f32 (the shape a fused-kernel moment update would use), B = v_pk_fma_f32
+//   PAIR 1: A = v_mfma_f32_16x16x4_f32,                                                      B = v_pk_fma_f32
+//   PAIR 2: A = v_mfma_f64_16x16x4_f64 (full-covariance statistics),                         B = v_fma_f64
+typedef double d4 __attribute__((ext_vector_type(4)));
+template <int PAIR>
+__global__ __launch_bounds__(512) void probe_split(float* out, long long* cyc, int iters, int run_a, int run_b) {
+    const int w = threadIdx.x >> 6;
+    float s0 = threadIdx.x * 1e-3f;
+    f2 p0 = {s0, s0 + 1.f}, p1 = {s0 + 2.f, s0}, p2 = p0, p3 = p1, p4 = p0, p5 = p1, p6 = p0, p7 = p1;
+    const f2 ka = {0.999f, 1.001f}, kb = {1e-3f, -1e-3f};
+    double d0 = s0, d1 = s0 + 1, d2 = s0 + 2, d3 = s0 + 3, d4v = s0 + 4, d5 = s0 + 5, d6 = s0 + 6, d7 = s0 + 7;
+    f4 m0 = {0, 0, 0, 0}, m1 = m0, m2 = m0, m3 = m0;
+    d4 q0 = {0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;
+    const float fa = 0.999f, fb = 1e-3f;
+    const double da = 0.999, db = 1e-3;
+    const long long t0 = clock64();
+    if (w < 4) {
+        if (run_a)
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (PAIR == 0) {
+                        m0 = __builtin_amdgcn_mfma_f32_4x4x1f32(fa, fb, m0, 0, 0, 0);
+                        m1 = __builtin_amdgcn_mfma_f32_4x4x1f32(fa, fb, m1, 0, 0, 0);
+                        m2 = __builtin_amdgcn_mfma_f32_4x4x1f32(fa, fb, m2, 0, 0, 0);
+                        m3 = __builtin_amdgcn_mfma_f32_4x4x1f32(fa, fb, m3, 0, 0, 0);
+                    } else if (PAIR == 1) {
+                        m0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, m0, 0, 0, 0);
+                        m1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, m1, 0, 0, 0);
+                        m2 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, m2, 0, 0, 0);
+                        m3 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, m3, 0, 0, 0);
+                    } else {
+                        q0 = __builtin_amdgcn_mfma_f64_16x16x4f64(da, db, q0, 0, 0, 0);
+                        q1 = __builtin_amdgcn_mfma_f64_16x16x4f64(da, db, q1, 0, 0, 0);
+                        q2 = __builtin_amdgcn_mfma_f64_16x16x4f64(da, db, q2, 0, 0, 0);
+                        q3 = __builtin_amdgcn_mfma_f64_16x16x4f64(da, db, q3, 0, 0, 0);
+                    }
+                }
+            }
+    } else if (run_b) {
+        for (int it = 0; it < iters; ++it) {
+            if (PAIR < 2) {
+                REP8(asm volatile("v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n"
+                                  "v_pk_fma_f32 %3, %3, %8, %9\n v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n"
+                                  "v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9\n"
+                                  : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7)
+                                  : "v"(ka), "v"(kb));)
+            } else {
+                REP8(asm volatile("v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n"
+                                  "v_fma_f64 %3, %3, %8, %9\n v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n"
+                                  "v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9\n"
+                                  : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4v), "+v"(d5), "+v"(d6), "+v"(d7)
+                                  : "v"(da), "v"(db));)
+            }
+        }
+    }
+    const long long t1 = clock64();
+    float r = p0.x + p1.x + p2.x + p3.x + p4.y + p5.y + p6.y + p7.y + m0.x + m1.y + m2.z + m3.w +
+              (float)(d0 + d1 + d2 + d3 + d4v + d5 + d6 + d7 + q0.x + q1.y + q2.z + q3.w);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + w] = t1 - t0;
+}
+
+template <int PAIR>
+static void run_split(float* out, long long* cyc, const char* name_a, int instr_a, const char* name_b) {
+    const int iters = 2000;
+    float ms[3];
+    for (int mode = 0; mode < 3; ++mode) {                 // A alone, B alone, both
+        const int ra = mode != 1, rb = mode != 0;
+        hipEvent_t a, b;
+        hipEventCreate(&a);
+        hipEventCreate(&b);
+        probe_split<PAIR><<<256, 512>>>(out, cyc, iters, ra, rb);
+        hipEventRecord(a);
+        probe_split<PAIR><<<256, 512>>>(out, cyc, iters, ra, rb);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        hipEventElapsedTime(&ms[mode], a, b);
+        hipEventDestroy(a);
+        hipEventDestroy(b);
+    }
+    printf("cross-wave overlap  A = %-28s (%d per wave)  B = %-14s (%d per wave):  A alone %.3f ms  B alone %.3f ms  "
+           "A and B on different waves of every SIMD %.3f ms  -> %s (sum %.3f, max %.3f)\n",
+           name_a, instr_a * iters, name_b, 64 * iters, ms[0], ms[1], ms[2],
+           ms[2] < 0.5 * (ms[0] + ms[1] + (ms[0] > ms[1] ? ms[0] : ms[1])) ? "OVERLAP" : "SERIALISED",
+           ms[0] + ms[1], ms[0] > ms[1] ? ms[0] : ms[1]);
+}
+
 int main() {
     float* out;
     long long* cyc;
-    hipMalloc(&out, sizeof(float) * 1024 * 256);
-    hipMalloc(&cyc, sizeof(long long) * 1024 * 4);
+    hipMalloc(&out, sizeof(float) * 1024 * 512);
+    hipMalloc(&cyc, sizeof(long long) * 1024 * 8);
+    if (getenv("VALUBENCH_SPLIT")) {
+        for (int rep = 0; rep < 2; ++rep) {
+            run_split<0>(out, cyc, "v_mfma_f32_4x4x1_16b_f32", 16, "v_pk_fma_f32");
+            run_split<1>(out, cyc, "v_mfma_f32_16x16x4_f32", 16, "v_pk_fma_f32");
+            run_split<2>(out, cyc, "v_mfma_f64_16x16x4_f64", 16, "v_fma_f64");
+        }
+        return 0;
+    }
     const int iters = 4000;
     if (getenv("VALUBENCH_MIX")) {                 // the pipe-sharing questions only, 1..4 waves per SIMD
         for (int blocks : {256, 512, 768, 1024}) {
