@@ -210,24 +210,31 @@ __device__ inline double sym3_min_eig_over_trace(double a00, double a01, double 
     return e_min / tr;
 }
 
-// largest eigenvalue of a symmetric 3x3 (same closed form as above)
-__device__ inline double sym3_max_eig(double a00, double a01, double a02, double a11, double a12, double a22) {
-    const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
-    if (p1 == 0.0) return fmax(a00, fmax(a11, a22));
-    const double q = (a00 + a11 + a22) / 3.0;
-    const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
-    const double p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * p1;
-    const double p = sqrt(p2 / 6.0);
-    const double ip = 1.0 / p;
-    const double c00 = b00 * ip, c01 = a01 * ip, c02 = a02 * ip, c11 = b11 * ip, c12 = a12 * ip, c22 = b22 * ip;
-    double r = 0.5 * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02));
-    r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
-    return q + 2.0 * p * cos(acos(r) / 3.0);
+// An upper bound of the largest eigenvalue of a symmetric 3x3 that converges to it: Newton's iteration on the
+// characteristic polynomial started at the Frobenius norm (>= the spectral radius).  To the right of the largest
+// root the polynomial is increasing and convex, so the iterates decrease monotonically towards the root and EVERY
+// iterate is a valid bound -- which is all the reach test of the log-likelihood kernel needs.  ~60 flops; the
+// closed form (sqrt, acos, cos) this replaces cost more than the whole rest of a node's M-step.
+__device__ inline double sym3_max_eig_upper(double a00, double a01, double a02, double a11, double a12, double a22) {
+    const double c2 = a00 + a11 + a22;
+    const double c1 = (a00 * a11 - a01 * a01) + (a00 * a22 - a02 * a02) + (a11 * a22 - a12 * a12);
+    const double c0 = a00 * (a11 * a22 - a12 * a12) - a01 * (a01 * a22 - a12 * a02) + a02 * (a01 * a12 - a11 * a02);
+    double lam = sqrt(a00 * a00 + a11 * a11 + a22 * a22 + 2.0 * (a01 * a01 + a02 * a02 + a12 * a12));
+    if (!(lam > 0.0)) return lam;
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const double pv = fma(fma(lam - c2, lam, c1), lam, -c0);                 // p(lam)
+        const double dv = fma(fma(3.0, lam, -2.0 * c2), lam, c1);                // p'(lam)
+        const double nxt = (dv > 0.0) ? lam - pv / dv : lam;
+        lam = (nxt < lam && nxt > 0.0) ? nxt : lam;                              // never move up, never leave the right branch
+    }
+    return lam * (1.0 + 1.0e-9);
 }
 
 __device__ __forceinline__ void prep_node(double p, double m0, double m1, double m2, double c00, double c01,
                                           double c02, double c10, double c11, double c12, double c20,
-                                          double c21, double c22, double* __restrict__ o, int* __restrict__ flags) {
+                                          double c21, double c22, double* __restrict__ o, int* __restrict__ flags,
+                                          bool with_complexity = true) {
     const double det = c00 * (c11 * c22 - c12 * c21) - c01 * (c10 * c22 - c12 * c20) +
                        c02 * (c10 * c21 - c11 * c20);
 #pragma unroll
@@ -261,15 +268,15 @@ __device__ __forceinline__ void prep_node(double p, double m0, double m1, double
         if (pd) {
             o[PREP_R + 0] = r00; o[PREP_R + 1] = r01; o[PREP_R + 2] = r02;
             o[PREP_R + 3] = r11; o[PREP_R + 4] = r12; o[PREP_R + 5] = r22;
-            const double lmax = sym3_max_eig(c00, c01, c02, c11, c12, c22);
-            // (1 - 1e-9): the closed form's rounding must never make the bound optimistic
-            o[PREP_KAPPA] = (lmax > 0.0 && lmax == lmax) ? 0.5 / lmax * (1.0 - 1.0e-9) : 0.0;
+            const double lmax = sym3_max_eig_upper(c00, c01, c02, c11, c12, c22);
+            o[PREP_KAPPA] = (lmax > 0.0 && lmax == lmax && lmax < 1.0e300) ? 0.5 / lmax : 0.0;
         } else if (flags) {
             atomicOr(flags, 1);
         }
     }
     o[6] = m0; o[7] = m1; o[8] = m2;
-    o[11] = sym3_min_eig_over_trace(c00, c01, c02, c11, c12, c22);
+    // (the 'complexity' ratio feeds the registration E-step only: the build takes it once, when the tree is finished)
+    if (with_complexity) o[11] = sym3_min_eig_over_trace(c00, c01, c02, c11, c12, c22);
 }
 
 __global__ void tree_prep_kernel(const double* __restrict__ pi, const double* __restrict__ mu,
@@ -280,6 +287,15 @@ __global__ void tree_prep_kernel(const double* __restrict__ pi, const double* __
     const double* c = cov + 9 * j;
     prep_node(pi[j], mu[3 * j], mu[3 * j + 1], mu[3 * j + 2], c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8],
               prep + PREP_N * j, flags);
+}
+
+// the 'complexity' ratios of nodes [j_begin, j_end) (prep[11]) from their covariances: one pass when a build is done
+__global__ void tree_complexity_kernel(const double* __restrict__ cov, int64_t j_begin, int64_t j_end,
+                                       double* __restrict__ prep) {
+    const int64_t j = j_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= j_end) return;
+    const double* c = cov + 9 * j;
+    prep[PREP_N * j + 11] = sym3_min_eig_over_trace(c[0], c[1], c[2], c[4], c[5], c[8]);
 }
 
 __global__ void tree_init_nodes_kernel(const double* __restrict__ init_mu, double sig2, int64_t T,
@@ -316,24 +332,33 @@ __global__ void tree_chunks_kernel(const int* __restrict__ seg_start, int P, int
             sh[threadIdx.x] += v;
             __syncthreads();
         }
-        const int first = carry + sh[threadIdx.x] - cnt;
-        if (p < P) {
-            chunk_first[p] = first;
-            const int s0 = seg_start[p], s1 = seg_start[p + 1];
-            for (int k = 0; k < cnt; ++k) {
-                int* d = chunk_desc + 3 * (first + k);
-                d[0] = p;
-                d[1] = s0 + k * CH;
-                d[2] = (s0 + (k + 1) * CH < s1) ? s0 + (k + 1) * CH : s1;
-            }
-        }
+        if (p < P) chunk_first[p] = carry + sh[threadIdx.x] - cnt;
         __syncthreads();
         if (threadIdx.x == 1023) carry += sh[1023];
         __syncthreads();
     }
+    const int total = carry;
     if (threadIdx.x == 0) {
-        chunk_first[P] = carry;
-        *n_chunks_out = carry;
+        chunk_first[P] = total;
+        *n_chunks_out = total;
+    }
+    __syncthreads();                       // chunk_first[] is complete and visible to this workgroup
+    // descriptors: every thread takes chunks tid, tid + 1024, ... and finds the chunk's parent by bisection in
+    // chunk_first (round 2 let the parent's thread write all of its chunks one after the other: level 0 of a
+    // million-point cloud is ONE parent with 3907 chunks -- 165 us of a single thread's stores)
+    for (int ch = threadIdx.x; ch < total; ch += 1024) {
+        int lo = 0, hi = P - 1;            // last parent with chunk_first[p] <= ch (parents without points share a value)
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (chunk_first[mid] <= ch) lo = mid; else hi = mid - 1;
+        }
+        // (among parents with the same chunk_first only the last one owns chunks: the bisection lands on it)
+        const int s0 = seg_start[lo], s1 = seg_start[lo + 1];
+        const int k = ch - chunk_first[lo];
+        int* d = chunk_desc + 3 * ch;
+        d[0] = lo;
+        d[1] = s0 + k * CH;
+        d[2] = (s0 + (k + 1) * CH < s1) ? s0 + (k + 1) * CH : s1;
     }
 }
 
@@ -446,14 +471,15 @@ __global__ __launch_bounds__(CH) void tree_estep_kernel(
 __device__ __forceinline__ void mstep_node(const double* __restrict__ m, int64_t j, double n_points_total,
                                            double ld, double* __restrict__ pi, double* __restrict__ mu,
                                            double* __restrict__ cov, double* __restrict__ prep,
-                                           int* __restrict__ flags) {
+                                           int* __restrict__ flags, bool with_complexity = true) {
     const double m0 = m[0];
     double* c = cov + 9 * j;
     if (m0 < ld) {
         pi[j] = 0.0;
         mu[3 * j] = mu[3 * j + 1] = mu[3 * j + 2] = 0.0;
         for (int e = 0; e < 9; ++e) c[e] = (e % 4 == 0) ? 1.0 : 0.0;
-        if (prep) prep_node(0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0, prep + PREP_N * j, flags);
+        if (prep) prep_node(0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0, prep + PREP_N * j, flags,
+                            with_complexity);
         return;
     }
     const double p = m0 / n_points_total;
@@ -463,7 +489,8 @@ __device__ __forceinline__ void mstep_node(const double* __restrict__ m, int64_t
     const double s00 = m[4] / m0 - u0 * u0, s01 = m[5] / m0 - u0 * u1, s02 = m[6] / m0 - u0 * u2,
                  s11 = m[7] / m0 - u1 * u1, s12 = m[8] / m0 - u1 * u2, s22 = m[9] / m0 - u2 * u2;
     c[0] = s00; c[1] = s01; c[2] = s02; c[3] = s01; c[4] = s11; c[5] = s12; c[6] = s02; c[7] = s12; c[8] = s22;
-    if (prep) prep_node(p, u0, u1, u2, s00, s01, s02, s01, s11, s12, s02, s12, s22, prep + PREP_N * j, flags);
+    if (prep) prep_node(p, u0, u1, u2, s00, s01, s02, s01, s11, s12, s02, s12, s22, prep + PREP_N * j, flags,
+                        with_complexity);
 }
 
 // fixed-order reduction of the chunk partials of one node (64 threads); with `fuse` the same
@@ -492,16 +519,17 @@ __global__ __launch_bounds__(64) void tree_moments_kernel(const double* __restri
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int m = 0; m < NMOM; ++m) mom[(size_t)cl * NMOM + m] = acc[m];
-        if (fuse) mstep_node(acc, lb + cl, n_points_total, ld, pi, mu, cov, prep, flags);
+        if (fuse) mstep_node(acc, lb + cl, n_points_total, ld, pi, mu, cov, prep, flags, /*with_complexity=*/false);
     }
 }
 __global__ void tree_mstep_kernel(const double* __restrict__ mom, int64_t lb, int n_level_nodes,
                                   double n_points_total, double ld, double* pi, double* mu, double* cov,
-                                  double* prep, int* __restrict__ flags, const int* __restrict__ done = nullptr) {
+                                  double* prep, int* __restrict__ flags, const int* __restrict__ done = nullptr,
+                                  int with_complexity = 1) {
     if (done && *done) return;
     const int cl = blockIdx.x * blockDim.x + threadIdx.x;
     if (cl >= n_level_nodes) return;
-    mstep_node(mom + (size_t)cl * NMOM, lb + cl, n_points_total, ld, pi, mu, cov, prep, flags);
+    mstep_node(mom + (size_t)cl * NMOM, lb + cl, n_points_total, ld, pi, mu, cov, prep, flags, with_complexity != 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1303,7 +1331,9 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     HGMM_TRY(ensure(c, c->t_qtrace, sizeof(double) * (size_t)trace_cap));
     double* trace_dev = c->t_qtrace.as<double>();
     // points per thread in the log-likelihood kernel (N = 1e6, L = 4 build: 10.2 / 8.4 / 8.0 ms with 1 / 2 / 4)
-    int ll_pts = n >= 400000 ? 4 : 2;
+    // (a small cloud takes one point per thread: its workgroups are too few to fill the chip and the kernel's time is
+    //  the serial work of a single wave -- C4 level 1: 64 nodes x 2 points x 27 instructions at one issue per ~5 cycles)
+    int ll_pts = n >= 400000 ? 4 : ((int64_t)nblk(n, CH * 2) >= c->cus ? 2 : 1);
     if (const char* e = std::getenv("HGMM_TREE_LL_PTS")) ll_pts = atoi(e) >= 4 ? 4 : (atoi(e) >= 2 ? 2 : 1);
     int batch_iters = 8;                      // iterations enqueued per host synchronisation (1/2/4/8/16: 6.8/6.3/5.6/5.1/5.3 ms @C4)
     if (const char* e = std::getenv("HGMM_TREE_BATCH")) batch_iters = std::max(1, std::min(64, atoi(e)));
@@ -1348,7 +1378,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
         const int pblocks = (int)nblk(n, CH);
         const int llblocks = (int)nblk(n, CH * ll_pts);        // log-likelihood grid: ll_pts points per thread
         int chunks = 1;
-        if (llblocks < 4 * c->cus && n_level > LL_TILE) {
+        if (llblocks < 2 * c->cus && n_level > LL_TILE) {     // (N = 1e6: 977 workgroups are plenty -- no split, no finish pass)
             chunks = (4 * c->cus + llblocks - 1) / llblocks;
             const int max_chunks_l = (n_level + LL_TILE - 1) / LL_TILE;
             if (chunks > max_chunks_l) chunks = max_chunks_l;
@@ -1396,7 +1426,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                     rc = allreduce_f64_oop(c, d_mom + NMOM * lb, mom_g, (size_t)NMOM * n_level);
                     if (rc != HGMM_OK) break;
                     tree_mstep_kernel<<<nblk(n_level, 256), 256, 0, c->stream>>>(mom_g, lb, n_level, n_total, ld, d_pi,
-                                                                                 d_mu, d_cov, d_prep, flags_ptr(c), &ctl->done);
+                                                                                 d_mu, d_cov, d_prep, flags_ptr(c), &ctl->done, 0);
                 }
                 {
                     ProfScope prof(c, HGMM_K_TREE_LOGLIK);
@@ -1463,6 +1493,8 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
         }
     }
     if (rc == HGMM_OK) {
+        // the per-iteration M-steps skip the 'complexity' ratio (registration only): all nodes at once, now
+        tree_complexity_kernel<<<nblk(T, 256), 256, 0, c->stream>>>(d_cov, 0, T, d_prep);
         hipError_t e = hipSuccess;
         if (pi_out) e = hipMemcpyAsync(pi_out, d_pi, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess && mu_out) e = hipMemcpyAsync(mu_out, d_mu, sizeof(double) * 3 * T, hipMemcpyDeviceToHost, c->stream);
@@ -1964,14 +1996,22 @@ __device__ __forceinline__ void full_fused_body(
     exp_tab_load(EXPT);                           // (the barrier behind the WL / G initialisation covers it)
 
     // this lane's components: slot 0 = tid; slot 1 (J16 > 512) = tid + 512.  When the last wave of slot 1 has at
-    // most 32 components left, its two half-waves take the SAME components for 8 points each instead of leaving
-    // half the lanes idle for 16 points (J = 800: 4.5 second-slot waves cost 4.5, not 5, wave-passes).
+    // most 32 components left, they are a TAIL BLOCK of 32 components x 16 points that is dealt out over the waves
+    // behind the full ones (which have nothing else in slot 1): each of `nw` such waves holds the same 32 components
+    // in both half-waves and evaluates them for 16 / (2 nw) points per half-wave.  J = 800: waves 0-3 take 64 second
+    // components each, waves 4-7 the tail, 2 points per lane -- every SIMD (waves w and w + 4) then carries 50 of
+    // the tile's 200 wave-evaluations (round 2: one wave took the whole tail, its SIMD 56: phase A waited for it).
     const int R = (CPL == 2) ? J16 - FT_BLOCK : 0;
     const int w_r = R / 64, rem = R % 64;
-    const bool half_wave = CPL == 2 && w == w_r && rem > 0 && rem <= 32;
+    const bool tail_exists = CPL == 2 && rem > 0 && rem <= 32;
+    const int free_w = FT_WAVES - w_r;                                   // waves without a full second block (>= 1)
+    const int nw = tail_exists ? (free_w >= 8 ? 8 : (free_w >= 4 ? 4 : (free_w >= 2 ? 2 : 1))) : 0;
+    const bool tail_wave = tail_exists && w >= w_r && w < w_r + nw;      // wave-uniform
+    const int tail_pts = tail_exists ? FT_P / (2 * nw) : 0;              // points per half-wave: 8, 4, 2 or 1
+    const int tail_p0 = tail_wave ? (w - w_r) * 2 * tail_pts + (lane >> 5) * tail_pts : 0;
     int jc[CPL];
     jc[0] = tid;
-    if (CPL == 2) jc[1] = half_wave ? FT_BLOCK + 64 * w_r + (lane & 31) : tid + FT_BLOCK;
+    if (CPL == 2) jc[1] = tail_wave ? FT_BLOCK + 64 * w_r + (lane & 31) : tid + FT_BLOCK;
     const double o0 = xs[0], o1 = xs[n_pad], o2 = xs[2 * n_pad];
     // CHOL: s* = R, m* = -R (mu - o);   !CHOL: s* = -Sigma^-1 / 2, m* = mu - o
     double s00[CPL], s01[CPL], s02[CPL], s11[CPL], s12[CPL], s22[CPL], m0[CPL], m1[CPL], m2[CPL], wE[CPL];
@@ -2075,7 +2115,30 @@ __device__ __forceinline__ void full_fused_body(
                 if ((CPL == 2 && c == 0) || jc[c] < J16) G[(size_t)pt[k] * LDG + jc[c]] = wE[c] * e[k];
             }
         };
-        const bool full2 = CPL == 2 && !half_wave && (w * 64 + FT_BLOCK < J16);     // wave-uniform
+        // two pairs of the tail block (one or two of its points, second component)
+        auto eval2 = [&](int pa, int pb) {
+            constexpr int c = CPL - 1;
+            double y[2], e[2];
+            const int pt[2] = {pa, pb};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const double a0 = X[pt[k]], a1 = X[FT_P + pt[k]], a2 = X[2 * FT_P + pt[k]];
+                if (CHOL) {
+                    const double z0 = fma(s02[c], a2, fma(s01[c], a1, fma(s00[c], a0, m0[c])));
+                    const double z1 = fma(s12[c], a2, fma(s11[c], a1, m1[c]));
+                    const double z2 = fma(s22[c], a2, m2[c]);
+                    y[k] = -fma(z2, z2, fma(z1, z1, z0 * z0));
+                } else {
+                    y[k] = sym3_quad(s00[c], s01[c], s02[c], s11[c], s12[c], s22[c], a0 - m0[c], a1 - m1[c], a2 - m2[c]);
+                }
+            }
+            exp_nonpos2(y, e, EXPT);
+            if (jc[c] < J16) {
+                G[(size_t)pa * LDG + jc[c]] = wE[c] * e[0];
+                if (pb != pa) G[(size_t)pb * LDG + jc[c]] = wE[c] * e[1];
+            }
+        };
+        const bool full2 = CPL == 2 && !tail_wave && (w * 64 + FT_BLOCK < J16);     // wave-uniform
         if (full2) {
 #pragma unroll 2
             for (int p0 = 0; p0 < FT_P; p0 += 2) {
@@ -2088,12 +2151,16 @@ __device__ __forceinline__ void full_fused_body(
                 const int pt[4] = {p0, p0 + 1, p0 + 2, p0 + 3};
                 eval4(pt, [](int) { return 0; });
             }
-            if (half_wave) {
-                const int ph = (lane >> 5) * (FT_P / 2);
-#pragma unroll
-                for (int p0 = 0; p0 < FT_P / 2; p0 += 4) {
-                    const int pt[4] = {ph + p0, ph + p0 + 1, ph + p0 + 2, ph + p0 + 3};
-                    eval4(pt, [](int) { return CPL - 1; });
+            if (tail_wave) {                                              // (tail_pts is workgroup-uniform)
+                if (tail_pts >= 4) {
+                    for (int p0 = 0; p0 < tail_pts; p0 += 4) {
+                        const int pt[4] = {tail_p0 + p0, tail_p0 + p0 + 1, tail_p0 + p0 + 2, tail_p0 + p0 + 3};
+                        eval4(pt, [](int) { return CPL - 1; });
+                    }
+                } else if (tail_pts == 2) {
+                    eval2(tail_p0, tail_p0 + 1);
+                } else {
+                    eval2(tail_p0, tail_p0);
                 }
             }
         }
@@ -2114,19 +2181,30 @@ __device__ __forceinline__ void full_fused_body(
             const int J128 = (J16 + 127) & ~127;                       // the row is zero beyond J16
             double den = 0.0, tot = 0.0, best = -1.0;
             int jbest = 0;
-            for (int jb = 0; jb < J128; jb += 128) {                   // four 32-column steps at a time, loads first
-                double gv[4];
+            // (the whole row is requested before the first value is used: this phase is a chain of LDS round trips
+            //  for a wave that has a SIMD almost to itself, not arithmetic; 512 columns = 16 values per batch)
+            for (int jq = 0; jq < J128; jq += 512) {
+                double gv[4][4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) gv[u] = Gp[jb + 32 * u + sub];
-                const double m4 = fmax(fmax(gv[0], gv[1]), fmax(gv[2], gv[3]));
-                den += (gv[0] + gv[1]) + (gv[2] + gv[3]);
-                jbest = (m4 > best) ? jb : jbest;
-                best = fmax(best, m4);
-                if (any_small) {
+                for (int st = 0; st < 4; ++st)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int j = jb + 32 * u + sub;
-                        tot = fma(gv[u], (j < J16) ? WL[j] : 0.0, tot);
+                    for (int u = 0; u < 4; ++u)
+                        gv[st][u] = (jq + 128 * st < J128) ? Gp[jq + 128 * st + 32 * u + sub] : 0.0;
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int jb = jq + 128 * st;
+                    if (jb < J128) {                                       // workgroup-uniform
+                        const double m4 = fmax(fmax(gv[st][0], gv[st][1]), fmax(gv[st][2], gv[st][3]));
+                        den += (gv[st][0] + gv[st][1]) + (gv[st][2] + gv[st][3]);
+                        jbest = (m4 > best) ? jb : jbest;
+                        best = fmax(best, m4);
+                        if (any_small) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int j = jb + 32 * u + sub;
+                                tot = fma(gv[st][u], (j < J16) ? WL[j] : 0.0, tot);
+                            }
+                        }
                     }
                 }
             }

@@ -48,6 +48,22 @@ def test_fullcov_vs_oracle(ctx, bunny, N, J):
     np.testing.assert_allclose(cov, o_cov, rtol=1e-6, atol=1e-14)
 
 
+@pytest.mark.parametrize("J", [513, 528, 540, 560, 576, 600, 737, 860, 990, 1024])
+def test_fullcov_component_layouts_vs_oracle(ctx, bunny, J):
+    """Every way the one-pass kernel deals the components beyond 512 out over its waves: a tail block of <= 32
+    components shared by 8 / 4 / 2 / 1 waves (1, 2, 4, 8 points per half-wave), a partly filled last wave, none."""
+    P = bunny[::30][:1300].astype(np.float64)
+    idx = np.random.RandomState(J).choice(len(P), J, replace=False)
+    ctx.set_points(P)
+    pi, mu, cov, labels, q = ctx.fullcov_fit(J, 1e-30, 1e-4, P[idx], 0.0005, 3)
+    o_pi, o_mu, o_cov, o_q, o_cur = hgmm_tree.build_flat_fullcov(P, J, 1e-30, 1e-4, idx, 0.0005, max_iters=3)
+    np.testing.assert_allclose(q, o_q, rtol=1e-9, atol=1e-6)
+    assert np.array_equal(labels, o_cur)
+    np.testing.assert_allclose(pi, o_pi, rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(mu, o_mu, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(cov, o_cov, rtol=1e-6, atol=1e-14)
+
+
 def test_fullcov_estep_moments_layout(ctx, bunny):
     """hgmm_fullcov_estep: the 10-float statistics expanded to the reference's m0/m1/m2 layout."""
     P = bunny[::16].astype(np.float64)

@@ -523,7 +523,8 @@ def test_tree_1M_matches_oracle_fixture(ctx):
         node = node // 8 - 1
     for l in range(L):
         s = pi[hgmm_tree.level(l):hgmm_tree.level(l + 1)].sum()
-        assert abs(s - 1.0) < 1e-9, (l, s)         # uniform cloud: no mass is dropped anywhere
+        assert 0.999 < s <= 1.0 + 1e-9, (l, s)     # (responsibilities below eps are dropped: level 3 keeps 0.999998)
+        assert abs(s - g["pi"][hgmm_tree.level(l):hgmm_tree.level(l + 1)].sum()) < 1e-12
     again = build(ctx, P, L, float(g["ls"]), float(g["ld"]), idx, float(g["sig2"]), max_iters=k)
     assert np.array_equal(again[5], q) and np.array_equal(again[3], leaf) and np.array_equal(again[2], cov)
 
