@@ -555,32 +555,39 @@ __device__ __forceinline__ void tree_ctl_update(double q, const TreeStop& st) {
 }
 // (With `stop.ctl` set the workgroup that finishes last also applies the level's stop rule -- every other workgroup
 //  of the launch has passed its own look at the flag by then -- which saves the one-thread launch per iteration.)
+// Hand-off between workgroups without fences (guide, inter-workgroup visibility: "8-byte agent-scope atomics on both
+// sides" is a complete protocol): a share is published with ONE relaxed agent-scope atomic store (write-through to
+// memory, not parked in this XCD's L2), the publishing lane drains its store, then takes a ticket; the workgroup
+// that draws the last ticket reads the shares back with relaxed agent-scope atomic loads (served below the L1 of its
+// CU).  Round 2 used __threadfence() on both sides -- L2 write-back + L1 invalidate, ~3.5 us each on this chip:
+// most of the duration of these microsecond kernels at C4.
 __device__ __forceinline__ void store_block_q(double value, double* __restrict__ block_q, int nb,
                                               unsigned int* __restrict__ ticket, double* __restrict__ q_out,
                                               const TreeStop& stop) {
     __shared__ bool is_last;
     __shared__ double sh_fin[4];
     if (threadIdx.x == 0) {
-        block_q[blockIdx.x] = value;
         is_last = false;
         if (ticket) {
-            __threadfence();
-            is_last = atomicAdd(ticket, 1u) == (unsigned int)(nb - 1);
+            __hip_atomic_store(block_q + blockIdx.x, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the share has left this CU before the ticket does
+            is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)(nb - 1);
+        } else {
+            block_q[blockIdx.x] = value;
         }
     }
     __syncthreads();
     if (!is_last) return;
-    __threadfence();
-    const volatile double* v = block_q;
     double acc = 0.0;
-    for (int i = threadIdx.x; i < nb; i += CH) acc += v[i];
+    for (int i = threadIdx.x; i < nb; i += CH)
+        acc += __hip_atomic_load(block_q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     acc = wave_sum_f64(acc);
     if (lane_id() == 0) sh_fin[wave_in_block()] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
         const double q = sh_fin[0] + sh_fin[1] + sh_fin[2] + sh_fin[3];
         *q_out = q;
-        *ticket = 0u;
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (stop.ctl) tree_ctl_update(q, stop);
     }
 }
@@ -673,25 +680,28 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
         for (int e = 0; e < 10; ++e) v[e] = 0.0;
         if (node < node_end) {
             const double* pr = prep + PREP_N * (lb + node);
-            const double wL = pr[10];
+            // (every field requested at once: two dependent rounds of loads are two trips to memory in a kernel
+            //  that lasts a handful of them)
+            const double wL = pr[10], kap = pr[PREP_KAPPA], u0 = pr[6], u1 = pr[7], u2 = pr[8];
+            const int fo = use_chol ? PREP_R : 0;
+            const double f0 = pr[fo], f1 = pr[fo + 1], f2 = pr[fo + 2], f3 = pr[fo + 3], f4 = pr[fo + 4], f5 = pr[fo + 5];
             if (wL != 0.0) {
-                const double m0 = pr[6] - c0, m1 = pr[7] - c1, m2 = pr[8] - c2;     // mean relative to the origin
+                const double m0 = u0 - c0, m1 = u1 - c1, m2 = u2 - c2;              // mean relative to the origin
                 const double g0 = fmax(fmax(lo0 - m0, m0 - hi0), 0.0), g1 = fmax(fmax(lo1 - m1, m1 - hi1), 0.0),
                              g2 = fmax(fmax(lo2 - m2, m2 - hi2), 0.0);
                 const double d2 = g0 * g0 + g1 * g1 + g2 * g2;                      // squared distance box <-> mean
-                live = !(pr[PREP_KAPPA] * d2 > LL_CULL);
+                live = !(kap * d2 > LL_CULL);
                 if (live) {
                     if (use_chol) {
-                        const double r00 = pr[PREP_R], r01 = pr[PREP_R + 1], r02 = pr[PREP_R + 2], r11 = pr[PREP_R + 3],
-                                     r12 = pr[PREP_R + 4], r22 = pr[PREP_R + 5];
+                        const double r00 = f0, r01 = f1, r02 = f2, r11 = f3, r12 = f4, r22 = f5;
                         v[0] = r00; v[1] = r01; v[2] = r02; v[3] = r11; v[4] = r12; v[5] = r22;
                         v[6] = -fma(r02, m2, fma(r01, m1, r00 * m0));               // -b = -R (mu - c)
                         v[7] = -fma(r12, m2, r11 * m1);
                         v[8] = -(r22 * m2);
                     } else {
                         // -1/2 Sigma^-1: the symmetric form is then the (non-positive) exponent itself
-                        v[0] = -0.5 * pr[0]; v[1] = -0.5 * pr[1]; v[2] = -0.5 * pr[2]; v[3] = -0.5 * pr[3];
-                        v[4] = -0.5 * pr[4]; v[5] = -0.5 * pr[5];
+                        v[0] = -0.5 * f0; v[1] = -0.5 * f1; v[2] = -0.5 * f2; v[3] = -0.5 * f3;
+                        v[4] = -0.5 * f4; v[5] = -0.5 * f5;
                         v[6] = m0; v[7] = m1; v[8] = m2;
                     }
                     v[9] = wL;
@@ -1331,9 +1341,9 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     HGMM_TRY(ensure(c, c->t_qtrace, sizeof(double) * (size_t)trace_cap));
     double* trace_dev = c->t_qtrace.as<double>();
     // points per thread in the log-likelihood kernel (N = 1e6, L = 4 build: 10.2 / 8.4 / 8.0 ms with 1 / 2 / 4)
-    // (a small cloud takes one point per thread: its workgroups are too few to fill the chip and the kernel's time is
-    //  the serial work of a single wave -- C4 level 1: 64 nodes x 2 points x 27 instructions at one issue per ~5 cycles)
-    int ll_pts = n >= 400000 ? 4 : ((int64_t)nblk(n, CH * 2) >= c->cus ? 2 : 1);
+    // (one point per thread for small clouds was tried in round 3: C4 level 0 / 1 got slower, 11.5 / 16.0 vs 9.2 / 15.4 us --
+    //  these launches are chains of memory round trips, not arithmetic)
+    int ll_pts = n >= 400000 ? 4 : 2;
     if (const char* e = std::getenv("HGMM_TREE_LL_PTS")) ll_pts = atoi(e) >= 4 ? 4 : (atoi(e) >= 2 ? 2 : 1);
     int batch_iters = 8;                      // iterations enqueued per host synchronisation (1/2/4/8/16: 6.8/6.3/5.6/5.1/5.3 ms @C4)
     if (const char* e = std::getenv("HGMM_TREE_BATCH")) batch_iters = std::max(1, std::min(64, atoi(e)));
@@ -2050,16 +2060,20 @@ __device__ __forceinline__ void full_fused_body(
     // accumulator tiles of this wave
     const int ntiles = J16 / 16;
     constexpr int MAXT = (FT_MAX_J16 / 16 + FT_WAVES - 1) / FT_WAVES;     // 8
-    double4_t acc[MAXT];
+    double acc[MAXT][3];                          // per tile: three 4-feature blocks (4 x 4 x 4 products)
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+    for (int t = 0; t < MAXT; ++t) acc[t][0] = acc[t][1] = acc[t][2] = 0.0;
     const int a_idx = lane & 15, b_idx = lane >> 4;
 
     const int64_t tiles = (n + FT_P - 1) / FT_P;
     const int64_t per = (tiles + gridDim.x - 1) / gridDim.x;
     const int64_t t0 = (int64_t)blockIdx.x * per;
     const int64_t t1 = (t0 + per < tiles) ? t0 + per : tiles;
-    double lq = 0.0;                              // wave FT_WAVES - 1: sum of the workgroup's log-likelihood terms
+    // the wave that takes the tiles' log-likelihood terms: with the tail block dealt out, the waves behind the full second
+    // blocks carry 16 + 2 evaluations per lane against 32 of the first ones -- but those share their SIMDs; measured,
+    // wave 1 (32 evaluations, SIMD 1) finishes phase A 0.2 M cycles ahead of the critical wave and has room for the logs
+    constexpr int LQ_WAVE = 1;
+    double lq = 0.0;                              // wave LQ_WAVE: sum of the workgroup's log-likelihood terms
 
     // coordinates of a tile -> LDS buffer `buf` (threads 0..47; rows past the end repeat the last point)
     const int st_d = tid / FT_P, st_p = tid % FT_P;                      // the staging threads' (coordinate, point)
@@ -2073,8 +2087,8 @@ __device__ __forceinline__ void full_fused_body(
             XS[(buf * 3 + st_d) * FT_P + st_p] = v - st_o;
         }
     };
-    // the log-likelihood terms of one tile (its TOT row), 16 lanes at once; taken by the last wave -- which has the
-    // lightest phase A -- at the START of the next tile's phase A, i.e. off the critical path of phase C
+    // the log-likelihood terms of one tile (its TOT row), 16 lanes at once; taken by wave LQ_WAVE at the START of the
+    // next tile's phase A, i.e. off the critical path of phase C
     auto tile_loglik = [&](int par) {
         const double tv = (lane < FT_P) ? TOT[par * FT_P + lane] : -1.0;
         double term = (tv >= 0.0) ? log(fmax(tv, TREE_EPS)) : 0.0;
@@ -2088,7 +2102,7 @@ __device__ __forceinline__ void full_fused_body(
         const int buf = (int)((tile - t0) & 1);
         const double* X = XS + buf * 3 * FT_P;
         if (dbg) tm = clock64();
-        if (w == FT_WAVES - 1 && tile > t0) tile_loglik(buf ^ 1);
+        if (w == LQ_WAVE && tile > t0) tile_loglik(buf ^ 1);
         // ---- phase A: g[p][j] for the lane's components, all 16 points (branch-free: a component with
         //      pi = 0 or a singular covariance has wE = 0 and S = 0, q >= 1500 gives exp -> 0 anyway) ----------
         // four (point, component) pairs per step
@@ -2181,30 +2195,21 @@ __device__ __forceinline__ void full_fused_body(
             const int J128 = (J16 + 127) & ~127;                       // the row is zero beyond J16
             double den = 0.0, tot = 0.0, best = -1.0;
             int jbest = 0;
-            // (the whole row is requested before the first value is used: this phase is a chain of LDS round trips
-            //  for a wave that has a SIMD almost to itself, not arithmetic; 512 columns = 16 values per batch)
-            for (int jq = 0; jq < J128; jq += 512) {
-                double gv[4][4];
+            // (requesting the whole row before using any of it -- 16 predicated loads per batch -- was tried and is
+            //  slower: 1.05-1.19 M cycles per wave for this phase against 0.80-0.93 M for the plain loop)
+            for (int jb = 0; jb < J128; jb += 128) {                   // four 32-column steps at a time, loads first
+                double gv[4];
 #pragma unroll
-                for (int st = 0; st < 4; ++st)
+                for (int u = 0; u < 4; ++u) gv[u] = Gp[jb + 32 * u + sub];
+                const double m4 = fmax(fmax(gv[0], gv[1]), fmax(gv[2], gv[3]));
+                den += (gv[0] + gv[1]) + (gv[2] + gv[3]);
+                jbest = (m4 > best) ? jb : jbest;
+                best = fmax(best, m4);
+                if (any_small) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        gv[st][u] = (jq + 128 * st < J128) ? Gp[jq + 128 * st + 32 * u + sub] : 0.0;
-#pragma unroll
-                for (int st = 0; st < 4; ++st) {
-                    const int jb = jq + 128 * st;
-                    if (jb < J128) {                                       // workgroup-uniform
-                        const double m4 = fmax(fmax(gv[st][0], gv[st][1]), fmax(gv[st][2], gv[st][3]));
-                        den += (gv[st][0] + gv[st][1]) + (gv[st][2] + gv[st][3]);
-                        jbest = (m4 > best) ? jb : jbest;
-                        best = fmax(best, m4);
-                        if (any_small) {
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const int j = jb + 32 * u + sub;
-                                tot = fma(gv[st][u], (j < J16) ? WL[j] : 0.0, tot);
-                            }
-                        }
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = jb + 32 * u + sub;
+                        tot = fma(gv[u], (j < J16) ? WL[j] : 0.0, tot);
                     }
                 }
             }
@@ -2259,12 +2264,20 @@ __device__ __forceinline__ void full_fused_body(
         __syncthreads();
         FT_TICK(tW);
         // ---- phase C: statistics on the matrix cores ---------------------------------------------------------
-        double bfrag[4], ifrag[4];
+        // v_mfma_f64_4x4x4_4b_f64: four independent 4 x 4 x 4 products per instruction.  Operand layout measured with
+        // tools/mfma_layout.hip (profiles/r03/mfma_f64_4x4x4_layout.txt): A[b][i][k] in lane i + 4 b + 16 k,
+        // B[b][k][j] in lane j + 4 b + 16 k, D[b][i][j] in lane j + 4 b + 16 i.  Block b = components 4 b .. 4 b + 3 of the
+        // wave's 16-component tile, i = component, k = point, j = feature: the A operand is read from G exactly as
+        // the 16 x 16 x 4 form read it (column 16 ct + (lane & 15), row 4 s + (lane >> 4)) and serves THREE products,
+        // one per block of four features -- 10 features cost 12 columns instead of 16: 48 instead of 64 matrix cycles
+        // per (tile, four points), and 3 instead of 4 accumulator registers per tile.
+        double bfrag[3][4], ifrag[4];
         if (want_stats) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            bfrag[s] = F[a_idx * FT_LDF + 4 * s + b_idx];
             ifrag[s] = INV[4 * s + b_idx];
+#pragma unroll
+            for (int fb = 0; fb < 3; ++fb) bfrag[fb][s] = F[(4 * fb + (lane & 3)) * FT_LDF + 4 * s + b_idx];
         }
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
@@ -2275,7 +2288,9 @@ __device__ __forceinline__ void full_fused_body(
                     // reference: gamma = g / den (C:176); accumulate() drops gamma < eps (C:100)
                     double a = G[(size_t)(4 * s + b_idx) * LDG + 16 * ct + a_idx] * ifrag[s];
                     if (a < TREE_EPS) a = 0.0;
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[s], acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int fb = 0; fb < 3; ++fb)
+                        acc[t][fb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bfrag[fb][s], acc[t][fb], 0, 0, 0);
                 }
             }
         }
@@ -2284,21 +2299,24 @@ __device__ __forceinline__ void full_fused_body(
         __syncthreads();                                               // G is overwritten by the next tile
         FT_TICK(tW);
     }
-    if (w == FT_WAVES - 1 && t0 < t1) tile_loglik((int)((t1 - 1 - t0) & 1));      // the last tile's terms
+    if (w == LQ_WAVE && t0 < t1) tile_loglik((int)((t1 - 1 - t0) & 1));      // the last tile's terms
     if (dbg && lane == 0 && blockIdx.x == 7) {
         dbg[w * 4 + 0] = tA; dbg[w * 4 + 1] = tB; dbg[w * 4 + 2] = tC; dbg[w * 4 + 3] = tW;
     }
-    // D layout (f64 16x16x4): row (component) = (lane >> 4) + 4 r, col (feature) = lane & 15
+    // D layout (f64 4x4x4, 4 blocks): lane = j + 4 b + 16 i  ->  component 16 ct + 4 b + i, feature 4 fb + j
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
         const int ct = w + t * FT_WAVES;
-        if (ct < ntiles && a_idx < NMOM) {
+        if (ct < ntiles) {
+            const int comp = 16 * ct + 4 * ((lane >> 2) & 3) + (lane >> 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                partials[((size_t)blockIdx.x * J16 + 16 * ct + b_idx + 4 * r) * NMOM + a_idx] = acc[t][r];
+            for (int fb = 0; fb < 3; ++fb) {
+                const int feat = 4 * fb + (lane & 3);
+                if (feat < NMOM) partials[((size_t)blockIdx.x * J16 + comp) * NMOM + feat] = acc[t][fb];
+            }
         }
     }
-    if (w == FT_WAVES - 1 && lane == 0) block_q[blockIdx.x] = lq;
+    if (w == LQ_WAVE && lane == 0) block_q[blockIdx.x] = lq;
 #undef FT_TICK
 }
 
