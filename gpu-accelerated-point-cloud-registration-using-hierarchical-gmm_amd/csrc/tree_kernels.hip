@@ -792,6 +792,131 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
     store_block_q(t, block_q, (int)gridDim.x, ticket, q_out, stop);
 }
 
+// Level log-likelihood for SMALL clouds (fewer 512-point blocks than CUs: C4's 40 256 points are 79).  There the
+// kernel above is a single wave per SIMD walking the level's nodes one after the other -- its time is that wave's
+// serial chain (64 nodes at level 1: 15 us), whatever the chip could do in parallel.  Here a workgroup takes only 64
+// points and its four waves split the NODES: every wave holds the same 64 points (one per lane) and evaluates every
+// fourth entry of the compacted node tile, four entries at a time (one interleaved exp for the four); the four
+// partial sums of a point are added in wave order.  629 workgroups instead of 79 at C4 (2-3 waves per SIMD), a
+// quarter of the serial work per wave, a bounding box of 64 instead of 512 points for the reach test, and no split
+// of the level's nodes over gridDim.y -- hence no partial-sum buffer and no finish pass at levels 2 and 3.
+constexpr int LLS_PTS = 64;
+__global__ __launch_bounds__(CH) void tree_loglik_small_kernel(const double* __restrict__ xs, int64_t n, int64_t n_pad,
+                                                               const double* __restrict__ prep, int64_t lb,
+                                                               int n_level_nodes, double* __restrict__ block_q,
+                                                               unsigned int* __restrict__ ticket,
+                                                               double* __restrict__ q_out, const int* __restrict__ done,
+                                                               TreeStop stop, const int* __restrict__ flags,
+                                                               unsigned long long* __restrict__ pair_count) {
+    if (done && *done) return;
+    __shared__ double tile[LL_TILE + 16][10];              // (+16: the tile is padded with weightless entries to 16 k)
+    __shared__ double exp_tab[EXP_TAB_N];
+    __shared__ double tot_sh[CH / 64][LLS_PTS];
+    __shared__ int wcnt[CH / 64];
+    exp_tab_load(exp_tab);
+    const bool use_chol = !(flags && (*flags & 1));        // kernel-uniform
+    const int w = wave_in_block(), lane = lane_id();
+    const int64_t i_first = (int64_t)blockIdx.x * LLS_PTS;
+    const int64_t i = i_first + lane;
+    const bool active = i < n;
+    const double c0 = xs[i_first], c1 = xs[n_pad + i_first], c2 = xs[2 * n_pad + i_first];   // (i_first < n: grid = ceil(n / 64))
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0;                    // inactive lanes sit on the origin
+    if (active) { x0 = xs[i] - c0; x1 = xs[n_pad + i] - c1; x2 = xs[2 * n_pad + i] - c2; }
+    // bounding box of the 64 points (every wave forms the same one: no exchange needed)
+    const double lo0 = -wave_max_f64(-x0), lo1 = -wave_max_f64(-x1), lo2 = -wave_max_f64(-x2);
+    const double hi0 = wave_max_f64(x0), hi1 = wave_max_f64(x1), hi2 = wave_max_f64(x2);
+    double tot = 0.0;
+    int entered = 0;
+    for (int base = 0; base < n_level_nodes; base += LL_TILE) {
+        const int node = base + (int)threadIdx.x;
+        bool live = false;
+        double v[10];
+#pragma unroll
+        for (int e = 0; e < 10; ++e) v[e] = 0.0;
+        if (node < n_level_nodes) {
+            const double* pr = prep + PREP_N * (lb + node);
+            const double wL = pr[10], kap = pr[PREP_KAPPA], u0 = pr[6], u1 = pr[7], u2 = pr[8];
+            const int fo = use_chol ? PREP_R : 0;
+            const double f0 = pr[fo], f1 = pr[fo + 1], f2 = pr[fo + 2], f3 = pr[fo + 3], f4 = pr[fo + 4], f5 = pr[fo + 5];
+            if (wL != 0.0) {
+                const double m0 = u0 - c0, m1 = u1 - c1, m2 = u2 - c2;
+                const double g0 = fmax(fmax(lo0 - m0, m0 - hi0), 0.0), g1 = fmax(fmax(lo1 - m1, m1 - hi1), 0.0),
+                             g2 = fmax(fmax(lo2 - m2, m2 - hi2), 0.0);
+                live = !(kap * (g0 * g0 + g1 * g1 + g2 * g2) > LL_CULL);
+                if (live) {
+                    if (use_chol) {
+                        v[0] = f0; v[1] = f1; v[2] = f2; v[3] = f3; v[4] = f4; v[5] = f5;
+                        v[6] = -fma(f2, m2, fma(f1, m1, f0 * m0));
+                        v[7] = -fma(f4, m2, f3 * m1);
+                        v[8] = -(f5 * m2);
+                    } else {
+                        v[0] = -0.5 * f0; v[1] = -0.5 * f1; v[2] = -0.5 * f2; v[3] = -0.5 * f3; v[4] = -0.5 * f4; v[5] = -0.5 * f5;
+                        v[6] = m0; v[7] = m1; v[8] = m2;
+                    }
+                    v[9] = wL;
+                }
+            }
+        }
+        const unsigned long long mask = __ballot(live);
+        const int before = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[w] = __popcll(mask);
+        __syncthreads();                                   // also: every wave is done with the previous tile
+        int off = 0, cnt = 0;
+#pragma unroll
+        for (int ww = 0; ww < CH / 64; ++ww) {
+            const int t = wcnt[ww];
+            if (ww < w) off += t;
+            cnt += t;
+        }
+        if (live) {
+            double* dst = tile[off + before];
+#pragma unroll
+            for (int e = 0; e < 10; ++e) dst[e] = v[e];
+        }
+        const int cnt16 = (cnt + 15) & ~15;
+        if ((int)threadIdx.x < (cnt16 - cnt) * 10) (&tile[cnt][0])[threadIdx.x] = 0.0;      // weightless padding
+        __syncthreads();
+        entered += cnt;
+        for (int k0 = w; k0 < cnt16; k0 += 16) {           // this wave's entries k0, k0 + 4, k0 + 8, k0 + 12
+            double yv[4], wl[4];
+            bool need = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double* t = tile[k0 + 4 * q];
+                wl[q] = t[9];
+                if (use_chol) {
+                    const double z0 = fma(t[2], x2, fma(t[1], x1, fma(t[0], x0, t[6])));
+                    const double z1 = fma(t[4], x2, fma(t[3], x1, t[7]));
+                    const double z2 = fma(t[5], x2, t[8]);
+                    yv[q] = -fma(z2, z2, fma(z1, z1, z0 * z0));
+                } else {
+                    yv[q] = sym3_quad(t[0], t[1], t[2], t[3], t[4], t[5], x0 - t[6], x1 - t[7], x2 - t[8]);
+                }
+                need = need || (wl[q] != 0.0 && yv[q] > LL_SKIP);
+            }
+            if (__any(need)) {
+                double e[4];
+                exp_nonpos4(yv, e, exp_tab);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tot = fma(wl[q], e[q], tot);
+            }
+        }
+    }
+    if (pair_count && threadIdx.x == 0) {
+        const int64_t rest = n - i_first;
+        atomicAdd(pair_count, (unsigned long long)((rest < LLS_PTS ? rest : (int64_t)LLS_PTS) * entered));
+    }
+    tot_sh[w][lane] = tot;
+    __syncthreads();
+    double t = 0.0;
+    if (w == 0) {
+        const double all = ((tot_sh[0][lane] + tot_sh[1][lane]) + tot_sh[2][lane]) + tot_sh[3][lane];
+        const double lq = active ? log(fmax(all, TREE_EPS)) : 0.0;
+        t = wave_sum_f64(lq);
+    }
+    store_block_q(t, block_q, (int)gridDim.x, ticket, q_out, stop);
+}
+
 __global__ __launch_bounds__(CH) void tree_loglik_finish_kernel(const double* __restrict__ partial, int64_t n,
                                                                 int64_t n_pad, int n_chunks,
                                                                 double* __restrict__ block_q,
@@ -1311,7 +1436,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     HGMM_TRY(ensure(c, c->t_seg, sizeof(int) * (2 * (8 * maxP + 2) + 2 * (maxP + 2) + 8)));
     HGMM_TRY(ensure(c, c->t_chunks, sizeof(int) * (size_t)(3 + 8 + 8) * max_chunks));
     HGMM_TRY(ensure(c, c->t_partials, sizeof(double) * (size_t)8 * NMOM * max_chunks));
-    HGMM_TRY(ensure(c, c->t_q, sizeof(double) * (nblk(n, CH) + 8)));
+    HGMM_TRY(ensure(c, c->t_q, sizeof(double) * (nblk(n, LLS_PTS) + 8)));
 
     double* d_pi = c->t_pi.as<double>();
     double* d_mu = c->t_mu.as<double>();
@@ -1333,7 +1458,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     int* chunk_off = hist + 8 * max_chunks;
     double* partials = c->t_partials.as<double>();
     double* block_q = c->t_q.as<double>();
-    double* q_dev = block_q + nblk(n, CH);
+    double* q_dev = block_q + nblk(n, LLS_PTS);
     unsigned int* q_ticket = reinterpret_cast<unsigned int*>(q_dev + 1);
     HGMM_HIP(c, hipMemsetAsync(q_ticket, 0, sizeof(unsigned int), c->stream));
     TreeCtl* ctl = reinterpret_cast<TreeCtl*>(q_dev + 2);
@@ -1345,6 +1470,9 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     //  these launches are chains of memory round trips, not arithmetic)
     int ll_pts = n >= 400000 ? 4 : 2;
     if (const char* e = std::getenv("HGMM_TREE_LL_PTS")) ll_pts = atoi(e) >= 4 ? 4 : (atoi(e) >= 2 ? 2 : 1);
+    // small clouds: the 64-point / node-split form of the log-likelihood (tree_loglik_small_kernel)
+    bool ll_small = (int64_t)nblk(n, CH * 2) < 2 * (int64_t)c->cus;
+    if (const char* e = std::getenv("HGMM_TREE_LL_SMALL")) ll_small = e[0] == '1';
     int batch_iters = 8;                      // iterations enqueued per host synchronisation (1/2/4/8/16: 6.8/6.3/5.6/5.1/5.3 ms @C4)
     if (const char* e = std::getenv("HGMM_TREE_BATCH")) batch_iters = std::max(1, std::min(64, atoi(e)));
 
@@ -1388,7 +1516,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
         const int pblocks = (int)nblk(n, CH);
         const int llblocks = (int)nblk(n, CH * ll_pts);        // log-likelihood grid: ll_pts points per thread
         int chunks = 1;
-        if (llblocks < 2 * c->cus && n_level > LL_TILE) {     // (N = 1e6: 977 workgroups are plenty -- no split, no finish pass)
+        if (!ll_small && llblocks < 2 * c->cus && n_level > LL_TILE) {     // (N = 1e6: 977 workgroups are plenty -- no split, no finish pass)
             chunks = (4 * c->cus + llblocks - 1) / llblocks;
             const int max_chunks_l = (n_level + LL_TILE - 1) / LL_TILE;
             if (chunks > max_chunks_l) chunks = max_chunks_l;
@@ -1449,7 +1577,11 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     tree_loglik_kernel<PTS><<<dim3(llblocks, chunks), CH, 0, c->stream>>>(                                 \
         xs_cur, n, n_pad, d_prep, lb, n_level, per_chunk, ll_partial, block_q, q_ticket, q_dev, &ctl->done, \
         chunks > 1 ? no_stop : stop, flags_ptr(c), pairs_ptr(c))
-                    if (ll_pts == 4) LL_LAUNCH(4);
+                    if (ll_small)
+                        tree_loglik_small_kernel<<<nblk(n, LLS_PTS), CH, 0, c->stream>>>(
+                            xs_cur, n, n_pad, d_prep, lb, n_level, block_q, q_ticket, q_dev, &ctl->done, stop, flags_ptr(c),
+                            pairs_ptr(c));
+                    else if (ll_pts == 4) LL_LAUNCH(4);
                     else if (ll_pts == 2) LL_LAUNCH(2);
                     else LL_LAUNCH(1);
 #undef LL_LAUNCH
@@ -2279,14 +2411,23 @@ __device__ __forceinline__ void full_fused_body(
 #pragma unroll
             for (int fb = 0; fb < 3; ++fb) bfrag[fb][s] = F[(4 * fb + (lane & 3)) * FT_LDF + 4 * s + b_idx];
         }
+        // (the next tile's four A values are requested before the current tile's are consumed: round 3's first version
+        //  read one value, waited for it, used it -- 28 LDS round trips in a row per wave and phase)
+        double araw[2][4];
+        auto load_a = [&](int ct, double (&dst)[4]) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) dst[s] = G[(size_t)(4 * s + b_idx) * LDG + 16 * ct + a_idx];
+        };
+        if (w < ntiles) load_a(w, araw[0]);
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
             const int ct = w + t * FT_WAVES;                           // wave-uniform
             if (ct < ntiles) {
+                if (t + 1 < MAXT && ct + FT_WAVES < ntiles) load_a(ct + FT_WAVES, araw[(t + 1) & 1]);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     // reference: gamma = g / den (C:176); accumulate() drops gamma < eps (C:100)
-                    double a = G[(size_t)(4 * s + b_idx) * LDG + 16 * ct + a_idx] * ifrag[s];
+                    double a = araw[t & 1][s] * ifrag[s];
                     if (a < TREE_EPS) a = 0.0;
 #pragma unroll
                     for (int fb = 0; fb < 3; ++fb)
