@@ -182,6 +182,46 @@ __device__ __forceinline__ void exp_nonpos2(const double (&yin)[2], double (&out
 }
 #undef HGMM_EXP_CONSTS
 
+// The same construction on a 2048-entry table (16 KB of LDS) for the throughput-bound kernels: n = round(y 2048 / ln 2),
+// |r| <= ln2 / 4096 = 1.7e-4, so e^r - 1 = r (1 + r (1/2 + r / 6)) is enough (r^4 / 24 < 3.5e-17): 4 instead of 6
+// instructions for the polynomial; and for exponents that are NON-POSITIVE BY CONSTRUCTION (-|R d|^2) the upper clamp
+// goes: 14 VALU instructions per value instead of 17.  The table (correctly rounded 2^(j/2048), formed in long double
+// on the host) lives in a context buffer and is copied to LDS by the kernel.
+constexpr int EXP_TAB2_BITS = 11;
+constexpr int EXP_TAB2_N = 1 << EXP_TAB2_BITS;
+template <bool NONPOS>
+__device__ __forceinline__ void exp_t11_4(const double (&yin)[4], double (&out)[4], const double* __restrict__ tab) {
+    constexpr double MAGIC = 6755399441055744.0;          /* 1.5 * 2^52 */
+    constexpr double INV = 2954.6394437405972;            /* 2048 / ln 2 */
+    constexpr double C_HI = 6.93147180369123816490e-01 / 2048.0, C_LO = 1.90821492927058770002e-10 / 2048.0;
+    double r[4], T[4], q[4];
+    int mh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double y = NONPOS ? fmax(yin[k], -708.0) : fmax(fmin(yin[k], 0.0), -708.0);
+        const double t = fma(y, INV, MAGIC);
+        const double nf = t - MAGIC;
+        r[k] = fma(nf, -C_LO, fma(nf, -C_HI, y));
+        const int n = __double2loint(t);                  // low mantissa word of t = n (two's complement)
+        T[k] = tab[n & (EXP_TAB2_N - 1)];
+        mh[k] = (int)((unsigned int)(n & ~(EXP_TAB2_N - 1)) << (20 - EXP_TAB2_BITS));   // (n >> 11) << 20: exponent-field increment
+    }
+    asm("v_fma_f64 %0, %4, %12, 0.5\n\tv_fma_f64 %1, %5, %12, 0.5\n\tv_fma_f64 %2, %6, %12, 0.5\n\t"
+        "v_fma_f64 %3, %7, %12, 0.5\n\t"
+        "v_fma_f64 %0, %0, %4, 1.0\n\tv_fma_f64 %1, %1, %5, 1.0\n\tv_fma_f64 %2, %2, %6, 1.0\n\t"
+        "v_fma_f64 %3, %3, %7, 1.0\n\t"
+        "v_mul_f64 %0, %0, %4\n\tv_mul_f64 %1, %1, %5\n\tv_mul_f64 %2, %2, %6\n\tv_mul_f64 %3, %3, %7\n\t"
+        "v_fma_f64 %0, %8, %0, %8\n\tv_fma_f64 %1, %9, %1, %9\n\tv_fma_f64 %2, %10, %2, %10\n\t"
+        "v_fma_f64 %3, %11, %3, %11"
+        : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3])
+        : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]), "v"(1.0 / 6.0));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = __hiloint2double(__double2hiint(q[k]) + mh[k], __double2loint(q[k]));
+}
+__device__ __forceinline__ void exp_tab2_load(double* __restrict__ tab_lds, const double* __restrict__ tab_g) {
+    for (int e = threadIdx.x; e < EXP_TAB2_N; e += blockDim.x) tab_lds[e] = tab_g[e];
+}
+
 // ------------------------------------------------------------------------------------------
 // per-node preparation
 // ------------------------------------------------------------------------------------------
@@ -561,6 +601,11 @@ __device__ __forceinline__ void tree_ctl_update(double q, const TreeStop& st) {
 // that draws the last ticket reads the shares back with relaxed agent-scope atomic loads (served below the L1 of its
 // CU).  Round 2 used __threadfence() on both sides -- L2 write-back + L1 invalidate, ~3.5 us each on this chip:
 // most of the duration of these microsecond kernels at C4.
+// Tickets are taken in TWO levels: workgroup b draws from counter 1 + (b mod NG), the workgroup that completes a
+// group draws from counter 0, the one that completes counter 0 is last.  Agent-scope atomics on ONE address are
+// served one after the other at ~20 ns each on this chip: with a single counter the 629 workgroups of the
+// small-cloud log-likelihood spent 12 us queueing for their tickets (measured: 15.5 us for an 8-node level).
+constexpr int TICKET_GROUPS = 64;                        // ticket[0] = top level, ticket[1 .. 64] = groups
 __device__ __forceinline__ void store_block_q(double value, double* __restrict__ block_q, int nb,
                                               unsigned int* __restrict__ ticket, double* __restrict__ q_out,
                                               const TreeStop& stop) {
@@ -571,7 +616,13 @@ __device__ __forceinline__ void store_block_q(double value, double* __restrict__
         if (ticket) {
             __hip_atomic_store(block_q + blockIdx.x, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the share has left this CU before the ticket does
-            is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)(nb - 1);
+            const int ng = nb < TICKET_GROUPS ? nb : TICKET_GROUPS;
+            const int g = (int)(blockIdx.x % (unsigned)ng);
+            const unsigned int members = (unsigned int)((nb - g + ng - 1) / ng);
+            if (__hip_atomic_fetch_add(ticket + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+                __hip_atomic_store(ticket + 1 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)(ng - 1);
+            }
         } else {
             block_q[blockIdx.x] = value;
         }
@@ -613,7 +664,7 @@ __device__ __forceinline__ void store_block_q(double value, double* __restrict__
 //   pair_count (optional): += (points of this workgroup) x (nodes that entered its tiles) -- the pairs actually evaluated.
 constexpr double LL_SKIP = -750.0;       // exp(y) == 0 in float64 below this exponent (denormals end at -745.13)
 constexpr double LL_CULL = 751.0;        // a node is out of reach when kappa dist^2 exceeds this (margin over LL_SKIP)
-template <int PTS>
+template <int PTS, bool BIGTAB = false>
 __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restrict__ xs, int64_t n,
                                                          int64_t n_pad, const double* __restrict__ prep,
                                                          int64_t lb, int n_level_nodes, int nodes_per_chunk,
@@ -623,14 +674,15 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
                                                          double* __restrict__ q_out,
                                                          const int* __restrict__ done, TreeStop stop,
                                                          const int* __restrict__ flags,
-                                                         unsigned long long* __restrict__ pair_count) {
+                                                         unsigned long long* __restrict__ pair_count,
+                                                         const double* __restrict__ exp2_tab = nullptr) {
     if (done && *done) return;
     __shared__ double tile[LL_TILE][10];
     __shared__ double shq[CH / 64];
-    __shared__ double exp_tab[EXP_TAB_N];
+    __shared__ double exp_tab[BIGTAB ? EXP_TAB2_N : EXP_TAB_N];
     __shared__ double shbox[CH / 64][6];
     __shared__ int wcnt[CH / 64];
-    exp_tab_load(exp_tab);                                 // (the tile loop's first barrier covers it)
+    if (BIGTAB) exp_tab2_load(exp_tab, exp2_tab); else exp_tab_load(exp_tab);   // (the tile loop's first barrier covers it)
     const bool use_chol = !(flags && (*flags & 1));        // kernel-uniform
     const int w = wave_in_block(), lane = lane_id();
     // origin: the workgroup's first point
@@ -752,7 +804,11 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
             if (__any(need)) {
                 if constexpr (PTS == 4) {
                     double e[4];
-                    exp_nonpos4(yv, e, exp_tab);
+                    if constexpr (BIGTAB) {
+                        if (use_chol) exp_t11_4<true>(yv, e, exp_tab); else exp_t11_4<false>(yv, e, exp_tab);
+                    } else {
+                        exp_nonpos4(yv, e, exp_tab);
+                    }
 #pragma unroll
                     for (int p = 0; p < 4; ++p) tot[p] = fma(wL, e[p], tot[p]);
                 } else if constexpr (PTS == 2) {
@@ -1384,10 +1440,11 @@ static int tree_alloc_nodes(hgmm_ctx* c, int L) {
 
 // tree flags (int[4]: bit 0 of [0] = some node's Sigma^-1 failed the Cholesky test) + the executed-pair counter of the
 // level log-likelihood (uint64 at byte 16); `reset`: a new node table is about to be prepared
+constexpr size_t TREE_FLAGS_BYTES = 64 + sizeof(unsigned int) * (1 + TICKET_GROUPS);      // + the tickets of store_block_q
 static int tree_flags(hgmm_ctx* c, bool reset) {
-    HGMM_TRY(ensure(c, c->t_flags, 64));
+    HGMM_TRY(ensure(c, c->t_flags, TREE_FLAGS_BYTES));
     if (reset) {
-        HGMM_HIP(c, hipMemsetAsync(c->t_flags.p, 0, 64, c->stream));
+        HGMM_HIP(c, hipMemsetAsync(c->t_flags.p, 0, TREE_FLAGS_BYTES, c->stream));
         // HGMM_TREE_NO_CHOL=1: take the symmetric-form fallback everywhere (lets the tests hold both forms to the oracle)
         if (const char* e = std::getenv("HGMM_TREE_NO_CHOL"))
             if (e[0] == '1') HGMM_HIP(c, hipMemsetAsync(c->t_flags.p, 1, 1, c->stream));
@@ -1397,6 +1454,18 @@ static int tree_flags(hgmm_ctx* c, bool reset) {
 static inline int* flags_ptr(hgmm_ctx* c) { return c->t_flags.as<int>(); }
 static inline unsigned long long* pairs_ptr(hgmm_ctx* c) {
     return reinterpret_cast<unsigned long long*>(c->t_flags.as<char>() + 16);
+}
+static inline unsigned int* tickets_ptr(hgmm_ctx* c) { return reinterpret_cast<unsigned int*>(c->t_flags.as<char>() + 64); }
+
+// 2^(j / 2048), j = 0 .. 2047, correctly rounded (formed in the x87 80-bit format), once per context
+static int ensure_exp_tab2(hgmm_ctx* c) {
+    if (c->exp_tab2.p) return HGMM_OK;
+    HGMM_TRY(ensure(c, c->exp_tab2, sizeof(double) * EXP_TAB2_N));
+    std::vector<double> h(EXP_TAB2_N);
+    for (int j = 0; j < EXP_TAB2_N; ++j) h[j] = (double)exp2l((long double)j / (long double)EXP_TAB2_N);
+    HGMM_HIP(c, hipMemcpyAsync(c->exp_tab2.p, h.data(), sizeof(double) * EXP_TAB2_N, hipMemcpyHostToDevice, c->stream));
+    HGMM_HIP(c, hipStreamSynchronize(c->stream));              // `h` is pageable host memory
+    return HGMM_OK;
 }
 
 static int tree_prep(hgmm_ctx* c, int64_t jb, int64_t je) {
@@ -1459,8 +1528,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     double* partials = c->t_partials.as<double>();
     double* block_q = c->t_q.as<double>();
     double* q_dev = block_q + nblk(n, LLS_PTS);
-    unsigned int* q_ticket = reinterpret_cast<unsigned int*>(q_dev + 1);
-    HGMM_HIP(c, hipMemsetAsync(q_ticket, 0, sizeof(unsigned int), c->stream));
+    unsigned int* q_ticket = tickets_ptr(c);                  // (zeroed by tree_alloc_nodes -> tree_flags; every launch leaves them zero)
     TreeCtl* ctl = reinterpret_cast<TreeCtl*>(q_dev + 2);
     const int trace_cap = std::min(max_iters_per_level, 1 << 20);
     HGMM_TRY(ensure(c, c->t_qtrace, sizeof(double) * (size_t)trace_cap));
@@ -1473,6 +1541,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     // small clouds: the 64-point / node-split form of the log-likelihood (tree_loglik_small_kernel)
     bool ll_small = (int64_t)nblk(n, CH * 2) < 2 * (int64_t)c->cus;
     if (const char* e = std::getenv("HGMM_TREE_LL_SMALL")) ll_small = e[0] == '1';
+    if (ll_pts == 4 && !ll_small) HGMM_TRY(ensure_exp_tab2(c));
     int batch_iters = 8;                      // iterations enqueued per host synchronisation (1/2/4/8/16: 6.8/6.3/5.6/5.1/5.3 ms @C4)
     if (const char* e = std::getenv("HGMM_TREE_BATCH")) batch_iters = std::max(1, std::min(64, atoi(e)));
 
@@ -1581,7 +1650,10 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                         tree_loglik_small_kernel<<<nblk(n, LLS_PTS), CH, 0, c->stream>>>(
                             xs_cur, n, n_pad, d_prep, lb, n_level, block_q, q_ticket, q_dev, &ctl->done, stop, flags_ptr(c),
                             pairs_ptr(c));
-                    else if (ll_pts == 4) LL_LAUNCH(4);
+                    else if (ll_pts == 4)
+                        tree_loglik_kernel<4, true><<<dim3(llblocks, chunks), CH, 0, c->stream>>>(
+                            xs_cur, n, n_pad, d_prep, lb, n_level, per_chunk, ll_partial, block_q, q_ticket, q_dev, &ctl->done,
+                            chunks > 1 ? no_stop : stop, flags_ptr(c), pairs_ptr(c), c->exp_tab2.as<double>());
                     else if (ll_pts == 2) LL_LAUNCH(2);
                     else LL_LAUNCH(1);
 #undef LL_LAUNCH
@@ -2107,7 +2179,7 @@ __host__ __device__ inline int ft_ldg(int J16) {        // doubles per point row
     return (J16 + 127) / 128 * 128 + 16;                // for whole 128-column steps (tail columns stay 0)
 }
 inline size_t ft_lds_bytes(int J16) {
-    return sizeof(double) * ((size_t)FT_P * ft_ldg(J16) + 16 * FT_LDF + 3 * FT_P + J16 + 4 * 3 * FT_P + EXP_TAB_N);
+    return sizeof(double) * ((size_t)FT_P * ft_ldg(J16) + 16 * FT_LDF + 3 * FT_P + J16 + 4 * 3 * FT_P + EXP_TAB2_N);
 }
 
 // The kernel's body, specialised at compile time on the form of the exponent:
@@ -2121,7 +2193,7 @@ template <int CPL, bool CHOL>
 __device__ __forceinline__ void full_fused_body(
     const double* __restrict__ xs, int64_t n, int64_t n_pad, const double* __restrict__ prep, int J16,
     int* __restrict__ label_out, double* __restrict__ block_q, double* __restrict__ partials /*[grid][J16][NMOM]*/,
-    int want_stats, long long* __restrict__ dbg, double* lds) {
+    int want_stats, long long* __restrict__ dbg, double* lds, const double* __restrict__ exp2_tab) {
     long long tA = 0, tB = 0, tC = 0, tW = 0, tm = 0;
 #define FT_TICK(acc) do { if (dbg) { const long long now_ = clock64(); acc += now_ - tm; tm = now_; } } while (0)
     const int LDG = ft_ldg(J16);
@@ -2132,10 +2204,10 @@ __device__ __forceinline__ void full_fused_body(
     double* WL = TOT + 2 * FT_P;                  // [J16] 1.0 where pi_j >= eps (the component counts towards q)
     double* XS = WL + J16;                        // [2][3][FT_P] the tile's coordinates relative to the origin, double-buffered
     double* XA = XS + 2 * 3 * FT_P;               // [2][3][FT_P] ... and as given (the statistics' features)
-    double* EXPT = XA + 2 * 3 * FT_P;             // [128] 2^(j/128) for exp_nonpos4
+    double* EXPT = XA + 2 * 3 * FT_P;             // [2048] 2^(j/2048) for exp_t11_4
     const int w = wave_in_block(), lane = lane_id();
     const int tid = (int)threadIdx.x;
-    exp_tab_load(EXPT);                           // (the barrier behind the WL / G initialisation covers it)
+    exp_tab2_load(EXPT, exp2_tab);                // (the barrier behind the WL / G initialisation covers it)
 
     // this lane's components: slot 0 = tid; slot 1 (J16 > 512) = tid + 512.  When the last wave of slot 1 has at
     // most 32 components left, they are a TAIL BLOCK of 32 components x 16 points that is dealt out over the waves
@@ -2253,7 +2325,7 @@ __device__ __forceinline__ void full_fused_body(
                     y[k] = sym3_quad(s00[c], s01[c], s02[c], s11[c], s12[c], s22[c], a0 - m0[c], a1 - m1[c], a2 - m2[c]);
                 }
             }
-            exp_nonpos4(y, e, EXPT);
+            exp_t11_4<CHOL>(y, e, EXPT);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int c = c_of(k);
@@ -2264,7 +2336,7 @@ __device__ __forceinline__ void full_fused_body(
         // two pairs of the tail block (one or two of its points, second component)
         auto eval2 = [&](int pa, int pb) {
             constexpr int c = CPL - 1;
-            double y[2], e[2];
+            double y[4], e[4];
             const int pt[2] = {pa, pb};
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -2278,7 +2350,8 @@ __device__ __forceinline__ void full_fused_body(
                     y[k] = sym3_quad(s00[c], s01[c], s02[c], s11[c], s12[c], s22[c], a0 - m0[c], a1 - m1[c], a2 - m2[c]);
                 }
             }
-            exp_nonpos2(y, e, EXPT);
+            y[2] = y[3] = y[1];
+            exp_t11_4<CHOL>(y, e, EXPT);
             if (jc[c] < J16) {
                 G[(size_t)pa * LDG + jc[c]] = wE[c] * e[0];
                 if (pb != pa) G[(size_t)pb * LDG + jc[c]] = wE[c] * e[1];
@@ -2465,12 +2538,13 @@ template <int CPL>
 __global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
     const double* __restrict__ xs, int64_t n, int64_t n_pad, const double* __restrict__ prep, int J16,
     int* __restrict__ label_out, double* __restrict__ block_q, double* __restrict__ partials /*[grid][J16][NMOM]*/,
-    int want_stats, const int* __restrict__ flags, long long* __restrict__ dbg = nullptr) {
+    int want_stats, const int* __restrict__ flags, const double* __restrict__ exp2_tab,
+    long long* __restrict__ dbg = nullptr) {
     extern __shared__ double lds[];
     if (flags && (*flags & 1))                     // kernel-uniform: some Sigma^-1 failed the Cholesky test
-        full_fused_body<CPL, false>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds);
+        full_fused_body<CPL, false>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds, exp2_tab);
     else
-        full_fused_body<CPL, true>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds);
+        full_fused_body<CPL, true>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds, exp2_tab);
 }
 
 // one wave per component: fixed-order sum over the workgroups' partials
@@ -2551,6 +2625,7 @@ static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_hos
     double* block_q = c->t_q.as<double>();
     double* q_dev = block_q + nblk(c->n, CH) + c->cus;
     const size_t lds = ft_lds_bytes(J16);
+    HGMM_TRY(ensure_exp_tab2(c));
     {
         ProfScope prof(c, HGMM_K_FULL_FUSED);
         if (J16 <= FT_BLOCK) {
@@ -2559,7 +2634,7 @@ static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_hos
             full_fused_kernel<1><<<grid, FT_BLOCK, lds, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
                                                                    c->t_prep.as<double>(), J16, labels, block_q,
                                                                    c->t_partials.as<double>(), want_stats ? 1 : 0,
-                                                                   flags_ptr(c));
+                                                                   flags_ptr(c), c->exp_tab2.as<double>());
         } else {
             HGMM_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&full_fused_kernel<2>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2568,7 +2643,7 @@ static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_hos
             full_fused_kernel<2><<<grid, FT_BLOCK, lds, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
                                                                    c->t_prep.as<double>(), J16, labels, block_q,
                                                                    c->t_partials.as<double>(), want_stats ? 1 : 0,
-                                                                   flags_ptr(c), dbg);
+                                                                   flags_ptr(c), c->exp_tab2.as<double>(), dbg);
             if (dbg) {
                 long long h[32];
                 HGMM_HIP(c, hipStreamSynchronize(c->stream));

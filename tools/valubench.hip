@@ -194,6 +194,7 @@ __global__ __launch_bounds__(512) void probe_split(float* out, long long* cyc, i
     double d0 = s0, d1 = s0 + 1, d2 = s0 + 2, d3 = s0 + 3, d4v = s0 + 4, d5 = s0 + 5, d6 = s0 + 6, d7 = s0 + 7;
     f4 m0 = {0, 0, 0, 0}, m1 = m0, m2 = m0, m3 = m0;
     d4 q0 = {0, 0, 0, 0}, q1 = q0, q2 = q0, q3 = q0;
+    double r0 = 0, r1 = 0, r2 = 0, r3 = 0;
     const float fa = 0.999f, fb = 1e-3f;
     const double da = 0.999, db = 1e-3;
     const long long t0 = clock64();
@@ -212,6 +213,11 @@ __global__ __launch_bounds__(512) void probe_split(float* out, long long* cyc, i
                         m1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, m1, 0, 0, 0);
                         m2 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, m2, 0, 0, 0);
                         m3 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, m3, 0, 0, 0);
+                    } else if (PAIR == 3) {
+                        r0 = __builtin_amdgcn_mfma_f64_4x4x4f64(da, db, r0, 0, 0, 0);
+                        r1 = __builtin_amdgcn_mfma_f64_4x4x4f64(da, db, r1, 0, 0, 0);
+                        r2 = __builtin_amdgcn_mfma_f64_4x4x4f64(da, db, r2, 0, 0, 0);
+                        r3 = __builtin_amdgcn_mfma_f64_4x4x4f64(da, db, r3, 0, 0, 0);
                     } else {
                         q0 = __builtin_amdgcn_mfma_f64_16x16x4f64(da, db, q0, 0, 0, 0);
                         q1 = __builtin_amdgcn_mfma_f64_16x16x4f64(da, db, q1, 0, 0, 0);
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(512) void probe_split(float* out, long long* cyc, i
     }
     const long long t1 = clock64();
     float r = p0.x + p1.x + p2.x + p3.x + p4.y + p5.y + p6.y + p7.y + m0.x + m1.y + m2.z + m3.w +
-              (float)(d0 + d1 + d2 + d3 + d4v + d5 + d6 + d7 + q0.x + q1.y + q2.z + q3.w);
+              (float)(d0 + d1 + d2 + d3 + d4v + d5 + d6 + d7 + q0.x + q1.y + q2.z + q3.w + r0 + r1 + r2 + r3);
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + w] = t1 - t0;
 }
@@ -279,6 +285,7 @@ int main() {
             run_split<0>(out, cyc, "v_mfma_f32_4x4x1_16b_f32", 16, "v_pk_fma_f32");
             run_split<1>(out, cyc, "v_mfma_f32_16x16x4_f32", 16, "v_pk_fma_f32");
             run_split<2>(out, cyc, "v_mfma_f64_16x16x4_f64", 16, "v_fma_f64");
+            run_split<3>(out, cyc, "v_mfma_f64_4x4x4_4b_f64", 16, "v_fma_f64");
         }
         return 0;
     }
