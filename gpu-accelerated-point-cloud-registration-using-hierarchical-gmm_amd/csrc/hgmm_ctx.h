@@ -85,7 +85,10 @@ struct hgmm_ctx {
     hgmm::DevBuf t_pi, t_mu, t_cov;           // double node tables [T], [T,3], [T,9]
     hgmm::DevBuf t_prep;                      // double [T][12] : inv(6) coef logc pi mu(3) -> see tree_kernels
     hgmm::DevBuf t_cplx;                      // double [T]
+    void* tree_hctl = nullptr;                // pinned host copy of the level control words (2 slots)
+    hipEvent_t tree_ev[2] = {nullptr, nullptr};
     hgmm::DevBuf exp_tab2;                    // double [2048] 2^(j/2048) for the throughput kernels' exp (tree_kernels.hip)
+    hgmm::DevBuf t_tickets;                   // uint: two-level arrival counters of the last-workgroup reductions, 4 KB apart
     hgmm::DevBuf t_flags;                     // int [4] tree flags + uint64 executed-pair counter (tree_kernels.hip)
     hgmm::DevBuf t_mom;                       // double [T][10]
     hgmm::DevBuf t_momq;                      // uint64 [T][10]  registration E-step: fixed-point moments

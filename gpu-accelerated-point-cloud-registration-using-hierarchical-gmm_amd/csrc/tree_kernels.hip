@@ -605,7 +605,10 @@ __device__ __forceinline__ void tree_ctl_update(double q, const TreeStop& st) {
 // group draws from counter 0, the one that completes counter 0 is last.  Agent-scope atomics on ONE address are
 // served one after the other at ~20 ns each on this chip: with a single counter the 629 workgroups of the
 // small-cloud log-likelihood spent 12 us queueing for their tickets (measured: 15.5 us for an 8-node level).
-constexpr int TICKET_GROUPS = 64;                        // ticket[0] = top level, ticket[1 .. 64] = groups
+constexpr int TICKET_GROUPS = 64;                        // counter 0 = top level, counters 1 .. 64 = groups
+// ... and the counters sit 4 KB apart: device-scope atomics are executed at the memory side, one queue per channel --
+// 65 counters in three cache lines still queued behind each other (15.3 us for the 8-node level, unchanged).
+constexpr int TICKET_STRIDE = 1024;                      // unsigned ints between two counters
 __device__ __forceinline__ void store_block_q(double value, double* __restrict__ block_q, int nb,
                                               unsigned int* __restrict__ ticket, double* __restrict__ q_out,
                                               const TreeStop& stop) {
@@ -619,8 +622,9 @@ __device__ __forceinline__ void store_block_q(double value, double* __restrict__
             const int ng = nb < TICKET_GROUPS ? nb : TICKET_GROUPS;
             const int g = (int)(blockIdx.x % (unsigned)ng);
             const unsigned int members = (unsigned int)((nb - g + ng - 1) / ng);
-            if (__hip_atomic_fetch_add(ticket + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
-                __hip_atomic_store(ticket + 1 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            unsigned int* mine = ticket + (size_t)(1 + g) * TICKET_STRIDE;
+            if (__hip_atomic_fetch_add(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+                __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);             // ready for the next launch
                 is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)(ng - 1);
             }
         } else {
@@ -1440,9 +1444,14 @@ static int tree_alloc_nodes(hgmm_ctx* c, int L) {
 
 // tree flags (int[4]: bit 0 of [0] = some node's Sigma^-1 failed the Cholesky test) + the executed-pair counter of the
 // level log-likelihood (uint64 at byte 16); `reset`: a new node table is about to be prepared
-constexpr size_t TREE_FLAGS_BYTES = 64 + sizeof(unsigned int) * (1 + TICKET_GROUPS);      // + the tickets of store_block_q
+constexpr size_t TREE_FLAGS_BYTES = 64;
+constexpr size_t TREE_TICKET_BYTES = sizeof(unsigned int) * TICKET_STRIDE * (1 + TICKET_GROUPS);   // the tickets of store_block_q
 static int tree_flags(hgmm_ctx* c, bool reset) {
     HGMM_TRY(ensure(c, c->t_flags, TREE_FLAGS_BYTES));
+    const bool fresh_tickets = c->t_tickets.p == nullptr;
+    HGMM_TRY(ensure(c, c->t_tickets, TREE_TICKET_BYTES));
+    // (every launch leaves its counters at zero; a kernel that died mid-way is the exception -> cleared with the flags)
+    if (fresh_tickets || reset) HGMM_HIP(c, hipMemsetAsync(c->t_tickets.p, 0, TREE_TICKET_BYTES, c->stream));
     if (reset) {
         HGMM_HIP(c, hipMemsetAsync(c->t_flags.p, 0, TREE_FLAGS_BYTES, c->stream));
         // HGMM_TREE_NO_CHOL=1: take the symmetric-form fallback everywhere (lets the tests hold both forms to the oracle)
@@ -1455,7 +1464,7 @@ static inline int* flags_ptr(hgmm_ctx* c) { return c->t_flags.as<int>(); }
 static inline unsigned long long* pairs_ptr(hgmm_ctx* c) {
     return reinterpret_cast<unsigned long long*>(c->t_flags.as<char>() + 16);
 }
-static inline unsigned int* tickets_ptr(hgmm_ctx* c) { return reinterpret_cast<unsigned int*>(c->t_flags.as<char>() + 64); }
+static inline unsigned int* tickets_ptr(hgmm_ctx* c) { return c->t_tickets.as<unsigned int>(); }
 
 // 2^(j / 2048), j = 0 .. 2047, correctly rounded (formed in the x87 80-bit format), once per context
 static int ensure_exp_tab2(hgmm_ctx* c) {
@@ -1465,6 +1474,17 @@ static int ensure_exp_tab2(hgmm_ctx* c) {
     for (int j = 0; j < EXP_TAB2_N; ++j) h[j] = (double)exp2l((long double)j / (long double)EXP_TAB2_N);
     HGMM_HIP(c, hipMemcpyAsync(c->exp_tab2.p, h.data(), sizeof(double) * EXP_TAB2_N, hipMemcpyHostToDevice, c->stream));
     HGMM_HIP(c, hipStreamSynchronize(c->stream));              // `h` is pageable host memory
+    return HGMM_OK;
+}
+
+// pinned {done, iterations} slots + events for the build's look-ahead batches
+static int tree_host_ctl(hgmm_ctx* c, TreeCtl** out) {
+    if (!c->tree_hctl) {
+        HGMM_HIP(c, hipHostMalloc(&c->tree_hctl, 256, hipHostMallocDefault));
+        HGMM_HIP(c, hipEventCreateWithFlags(&c->tree_ev[0], hipEventDisableTiming));
+        HGMM_HIP(c, hipEventCreateWithFlags(&c->tree_ev[1], hipEventDisableTiming));
+    }
+    *out = static_cast<TreeCtl*>(c->tree_hctl);
     return HGMM_OK;
 }
 
@@ -1531,8 +1551,9 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     unsigned int* q_ticket = tickets_ptr(c);                  // (zeroed by tree_alloc_nodes -> tree_flags; every launch leaves them zero)
     TreeCtl* ctl = reinterpret_cast<TreeCtl*>(q_dev + 2);
     const int trace_cap = std::min(max_iters_per_level, 1 << 20);
-    HGMM_TRY(ensure(c, c->t_qtrace, sizeof(double) * (size_t)trace_cap));
-    double* trace_dev = c->t_qtrace.as<double>();
+    HGMM_TRY(ensure(c, c->t_qtrace, sizeof(double) * (size_t)trace_cap * L));     // one segment per level, read back at the end
+    double* trace_base = c->t_qtrace.as<double>();
+    std::vector<int> level_iters(L, 0);
     // points per thread in the log-likelihood kernel (N = 1e6, L = 4 build: 10.2 / 8.4 / 8.0 ms with 1 / 2 / 4)
     // (one point per thread for small clouds was tried in round 3: C4 level 0 / 1 got slower, 11.5 / 16.0 vs 9.2 / 15.4 us --
     //  these launches are chains of memory round trips, not arithmetic)
@@ -1578,6 +1599,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
         const int64_t lb = level_first(l), le = level_first(l + 1);
         const int n_level = (int)(le - lb);
         const int64_t parent_first = (l == 0) ? 0 : level_first(l - 1);
+        double* trace_dev = trace_base + (size_t)l * trace_cap;
         tree_chunks_kernel<<<1, 1024, 0, c->stream>>>(seg_cur, P, chunk_first, chunk_desc, n_chunks_dev);
         const unsigned grid_chunks = (unsigned)(n / CH + P + 1);
         // small clouds do not have enough 256-point blocks to fill the chip: split the level's nodes
@@ -1614,10 +1636,10 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
             mom_g = c->comm_buf.as<double>();
             q_g = mom_g + (size_t)NMOM * n_level;
         }
-        int it = 0;
-        bool done = false;
-        while (!done) {
-            for (int b = 0; b < batch && rc == HGMM_OK; ++b) {
+        // One EM iteration of the level, enqueued (every kernel looks at ctl->done first and returns at once when the level
+        // has stopped).
+        auto enqueue_iteration = [&]() -> int {
+            int rc = HGMM_OK;
                 {
                     ProfScope prof(c, HGMM_K_TREE_ESTEP);
                     tree_estep_kernel<<<grid_chunks, CH, 0, c->stream>>>(xs_cur, n_pad, d_prep, chunk_desc,
@@ -1631,7 +1653,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                                                                    d_prep, flags_ptr(c), &ctl->done);
                 if (c->comm_on()) {
                     rc = allreduce_f64_oop(c, d_mom + NMOM * lb, mom_g, (size_t)NMOM * n_level);
-                    if (rc != HGMM_OK) break;
+                    if (rc != HGMM_OK) return rc;
                     tree_mstep_kernel<<<nblk(n_level, 256), 256, 0, c->stream>>>(mom_g, lb, n_level, n_total, ld, d_pi,
                                                                                  d_mu, d_cov, d_prep, flags_ptr(c), &ctl->done, 0);
                 }
@@ -1663,27 +1685,54 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                 }
                 if (c->comm_on()) {
                     rc = allreduce_f64_oop(c, q_dev, q_g, 1);
-                    if (rc != HGMM_OK) break;
+                    if (rc != HGMM_OK) return rc;
                     tree_ctl_kernel<<<1, 1, 0, c->stream>>>(q_g, ctl, ls, max_iters_per_level, trace_dev, trace_cap);
                 }
+            return HGMM_OK;
+        };
+        // The host stays ONE BATCH AHEAD of the device: batch k + 1 is enqueued before the host waits for batch k's
+        // verdict (an asynchronous copy of {done, iterations} into pinned memory + an event), so the device never idles
+        // at a batch boundary (round 2: enqueue, copy, synchronise, enqueue -- 30-40 us of idle device per batch, a
+        // quarter of C4's build).  The price: when a level stops, the batch enqueued ahead runs as skipped launches
+        // (~1 us each).  No batch is enqueued beyond the level's iteration budget.
+        int it = 0;
+        {
+            TreeCtl* hp = nullptr;
+            rc = tree_host_ctl(c, &hp);
+            int enq = 0, slot = 0;
+            auto enqueue_batch = [&](int s) -> int {
+                const int cnt = std::min(batch, max_iters_per_level - enq);
+                for (int b = 0; b < cnt; ++b) {
+                    const int r = enqueue_iteration();
+                    if (r != HGMM_OK) return r;
+                }
+                enq += cnt;
+                if (hipMemcpyAsync(&hp[s], ctl, sizeof(TreeCtl), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                    hipEventRecord(c->tree_ev[s], c->stream) != hipSuccess)
+                    return fail(c, HGMM_ERR_HIP, "tree build: device error: %s", hipGetErrorString(hipGetLastError()));
+                return HGMM_OK;
+            };
+            if (rc == HGMM_OK) rc = enqueue_batch(slot);
+            while (rc == HGMM_OK) {
+                const bool ahead = enq < max_iters_per_level;
+                if (ahead) rc = enqueue_batch(slot ^ 1);
+                if (rc != HGMM_OK) break;
+                if (hipEventSynchronize(c->tree_ev[slot]) != hipSuccess) {
+                    rc = fail(c, HGMM_ERR_HIP, "tree build: device error: %s", hipGetErrorString(hipGetLastError()));
+                    break;
+                }
+                it = hp[slot].it;
+                if (hp[slot].done != 0) break;
+                if (!ahead) {                      // cannot happen (the budget's last iteration sets done); never spin
+                    rc = fail(c, HGMM_ERR_STATE, "tree build: level %d did not stop within its budget", l);
+                    break;
+                }
+                slot ^= 1;
             }
-            if (rc != HGMM_OK) break;
-            TreeCtl h;
-            if (hipMemcpyAsync(&h, ctl, sizeof h, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                hipStreamSynchronize(c->stream) != hipSuccess) {
-                rc = fail(c, HGMM_ERR_HIP, "tree build: device error: %s", hipGetErrorString(hipGetLastError()));
-                break;
-            }
-            it = h.it;
-            done = h.done != 0;
         }
-        if (rc == HGMM_OK && q_trace_out && q_len < q_capacity) {
-            const int take = std::min(std::min(it, trace_cap), q_capacity - q_len);
-            if (take > 0 && hipMemcpy(q_trace_out + q_len, trace_dev, sizeof(double) * take, hipMemcpyDeviceToHost) != hipSuccess)
-                rc = fail(c, HGMM_ERR_HIP, "tree build: q trace download failed");
-        }
-        q_len += it;
+        level_iters[l] = it;
         if (rc != HGMM_OK) break;
+        q_len += it;
         if (iters_per_level_out) iters_per_level_out[l] = it;
         if (l + 1 < L) {
             // partition for the next level
@@ -1713,6 +1762,17 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
         if (pi_out) e = hipMemcpyAsync(pi_out, d_pi, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess && mu_out) e = hipMemcpyAsync(mu_out, d_mu, sizeof(double) * 3 * T, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess && cov_out) e = hipMemcpyAsync(cov_out, d_cov, sizeof(double) * 9 * T, hipMemcpyDeviceToHost, c->stream);
+        if (q_trace_out) {                                          // the levels' q traces, back to back
+            int at = 0;
+            for (int l = 0; l < L && e == hipSuccess; ++l) {
+                const int take = std::min(std::min(level_iters[l], trace_cap), q_capacity - at);
+                if (take > 0)
+                    e = hipMemcpyAsync(q_trace_out + at, trace_base + (size_t)l * trace_cap, sizeof(double) * take,
+                                       hipMemcpyDeviceToHost, c->stream);
+                at += level_iters[l];
+                if (at >= q_capacity) break;
+            }
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) rc = fail(c, HGMM_ERR_HIP, "tree build: download failed: %s", hipGetErrorString(e));
     } else {
