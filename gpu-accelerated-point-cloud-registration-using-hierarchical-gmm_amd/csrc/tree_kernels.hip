@@ -218,6 +218,40 @@ __device__ __forceinline__ void exp_t11_4(const double (&yin)[4], double (&out)[
 #pragma unroll
     for (int k = 0; k < 4; ++k) out[k] = __hiloint2double(__double2hiint(q[k]) + mh[k], __double2loint(q[k]));
 }
+// The same exp in three stages, so that a caller can put the table look-ups of MANY values in flight before the first
+// one is needed (the one-block form above takes the table values as inputs of its asm block: the block cannot start
+// before every look-up has returned, and the polynomial does not overlap the LDS latency):
+//   exp_t11_head   clamp, n = round(y 2048 / ln 2), r = y - n ln2 / 2048, REQUEST T = 2^((n mod 2048) / 2048)
+//   exp_t11_poly4  p = e^r - 1 for four values (one asm block, inputs r only)
+//   exp_t11_tail   2^(n div 2048) * fma(T, p, T)
+struct ExpHead { double r, T; int mh; };
+template <bool NONPOS>
+__device__ __forceinline__ ExpHead exp_t11_head(double yin, const double* __restrict__ tab) {
+    constexpr double MAGIC = 6755399441055744.0, INV = 2954.6394437405972;
+    constexpr double C_HI = 6.93147180369123816490e-01 / 2048.0, C_LO = 1.90821492927058770002e-10 / 2048.0;
+    const double y = NONPOS ? fmax(yin, -708.0) : fmax(fmin(yin, 0.0), -708.0);
+    const double t = fma(y, INV, MAGIC);
+    const double nf = t - MAGIC;
+    ExpHead h;
+    h.r = fma(nf, -C_LO, fma(nf, -C_HI, y));
+    const int n = __double2loint(t);
+    h.T = tab[n & (EXP_TAB2_N - 1)];
+    h.mh = (int)((unsigned int)(n & ~(EXP_TAB2_N - 1)) << (20 - EXP_TAB2_BITS));
+    return h;
+}
+__device__ __forceinline__ void exp_t11_poly4(double r0, double r1, double r2, double r3, double (&p)[4]) {
+    asm("v_fma_f64 %0, %4, %8, 0.5\n\tv_fma_f64 %1, %5, %8, 0.5\n\tv_fma_f64 %2, %6, %8, 0.5\n\t"
+        "v_fma_f64 %3, %7, %8, 0.5\n\t"
+        "v_fma_f64 %0, %0, %4, 1.0\n\tv_fma_f64 %1, %1, %5, 1.0\n\tv_fma_f64 %2, %2, %6, 1.0\n\t"
+        "v_fma_f64 %3, %3, %7, 1.0\n\t"
+        "v_mul_f64 %0, %0, %4\n\tv_mul_f64 %1, %1, %5\n\tv_mul_f64 %2, %2, %6\n\tv_mul_f64 %3, %3, %7"
+        : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3])
+        : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(1.0 / 6.0));
+}
+__device__ __forceinline__ double exp_t11_tail(const ExpHead& h, double p) {
+    const double q = fma(h.T, p, h.T);
+    return __hiloint2double(__double2hiint(q) + h.mh, __double2loint(q));
+}
 __device__ __forceinline__ void exp_tab2_load(double* __restrict__ tab_lds, const double* __restrict__ tab_g) {
     for (int e = threadIdx.x; e < EXP_TAB2_N; e += blockDim.x) tab_lds[e] = tab_g[e];
 }
@@ -861,49 +895,77 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
 // quarter of the serial work per wave, a bounding box of 64 instead of 512 points for the reach test, and no split
 // of the level's nodes over gridDim.y -- hence no partial-sum buffer and no finish pass at levels 2 and 3.
 constexpr int LLS_PTS = 64;
+constexpr int LLS_PF = 4;                 // node tiles whose parameters are requested together
+// The kernel is a chain of memory round trips (~1.5 us each on this chip), not arithmetic, so they are taken side by
+// side wherever the addresses allow it: the stop flag, the points and the first four tiles' node parameters are all
+// requested before anything is waited for; the level's nodes are walked four 256-node tiles per round trip; and the
+// workgroup's share of q is a plain store -- a one-workgroup kernel behind this one (tree_qsum_kernel) adds the shares
+// and applies the stop rule (an arrival counter costs two more dependent trips per workgroup: measured 14-15 us for an
+// 8-node level with it, whether the counters were one, 65 adjacent or 65 spread over 260 KB).
 __global__ __launch_bounds__(CH) void tree_loglik_small_kernel(const double* __restrict__ xs, int64_t n, int64_t n_pad,
                                                                const double* __restrict__ prep, int64_t lb,
                                                                int n_level_nodes, double* __restrict__ block_q,
-                                                               unsigned int* __restrict__ ticket,
-                                                               double* __restrict__ q_out, const int* __restrict__ done,
-                                                               TreeStop stop, const int* __restrict__ flags,
+                                                               const int* __restrict__ done,
+                                                               const int* __restrict__ flags,
                                                                unsigned long long* __restrict__ pair_count) {
-    if (done && *done) return;
     __shared__ double tile[LL_TILE + 16][10];              // (+16: the tile is padded with weightless entries to 16 k)
     __shared__ double exp_tab[EXP_TAB_N];
     __shared__ double tot_sh[CH / 64][LLS_PTS];
     __shared__ int wcnt[CH / 64];
-    exp_tab_load(exp_tab);
-    const bool use_chol = !(flags && (*flags & 1));        // kernel-uniform
     const int w = wave_in_block(), lane = lane_id();
     const int64_t i_first = (int64_t)blockIdx.x * LLS_PTS;
     const int64_t i = i_first + lane;
     const bool active = i < n;
-    const double c0 = xs[i_first], c1 = xs[n_pad + i_first], c2 = xs[2 * n_pad + i_first];   // (i_first < n: grid = ceil(n / 64))
-    double x0 = 0.0, x1 = 0.0, x2 = 0.0;                    // inactive lanes sit on the origin
-    if (active) { x0 = xs[i] - c0; x1 = xs[n_pad + i] - c1; x2 = xs[2 * n_pad + i] - c2; }
+    const int64_t i_ld = active ? i : i_first;             // (i_first < n: grid = ceil(n / 64))
+    // ---- everything whose address is known up front, requested together ----
+    const int stop_flag = done ? *done : 0;
+    const int fl = flags ? *flags : 0;
+    const double c0 = xs[i_first], c1 = xs[n_pad + i_first], c2 = xs[2 * n_pad + i_first];
+    const double p0 = xs[i_ld], p1 = xs[n_pad + i_ld], p2 = xs[2 * n_pad + i_ld];
+    double nd[LLS_PF][11];                                 // wL, kappa, mu[3], six form entries of this thread's nodes
+    auto request = [&](int base4, bool chol) {
+#pragma unroll
+        for (int t = 0; t < LLS_PF; ++t) {
+            int node = base4 + t * LL_TILE + (int)threadIdx.x;
+            node = node < n_level_nodes ? node : n_level_nodes - 1;          // (clamped, not branched on)
+            const double* pr = prep + PREP_N * (lb + node);
+            const int fo = chol ? PREP_R : 0;
+            nd[t][0] = pr[10]; nd[t][1] = pr[PREP_KAPPA]; nd[t][2] = pr[6]; nd[t][3] = pr[7]; nd[t][4] = pr[8];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) nd[t][5 + e] = pr[fo + e];
+        }
+    };
+    // (the form is not known before `fl` is back: the first request asks for the triangular entries, the common case, and
+    //  is repeated in the symmetric form if the flag says so)
+    request(0, true);
+    exp_tab_load(exp_tab);
+    if (stop_flag) return;
+    const bool use_chol = !(fl & 1);                       // kernel-uniform
+    if (!use_chol) request(0, false);
+    const double x0 = p0 - c0, x1 = p1 - c1, x2 = p2 - c2;  // inactive lanes sit on the origin (i_ld = i_first)
     // bounding box of the 64 points (every wave forms the same one: no exchange needed)
     const double lo0 = -wave_max_f64(-x0), lo1 = -wave_max_f64(-x1), lo2 = -wave_max_f64(-x2);
     const double hi0 = wave_max_f64(x0), hi1 = wave_max_f64(x1), hi2 = wave_max_f64(x2);
     double tot = 0.0;
     int entered = 0;
-    for (int base = 0; base < n_level_nodes; base += LL_TILE) {
-        const int node = base + (int)threadIdx.x;
-        bool live = false;
-        double v[10];
+    for (int base4 = 0; base4 < n_level_nodes; base4 += LLS_PF * LL_TILE) {
+        if (base4 > 0) request(base4, use_chol);
 #pragma unroll
-        for (int e = 0; e < 10; ++e) v[e] = 0.0;
-        if (node < n_level_nodes) {
-            const double* pr = prep + PREP_N * (lb + node);
-            const double wL = pr[10], kap = pr[PREP_KAPPA], u0 = pr[6], u1 = pr[7], u2 = pr[8];
-            const int fo = use_chol ? PREP_R : 0;
-            const double f0 = pr[fo], f1 = pr[fo + 1], f2 = pr[fo + 2], f3 = pr[fo + 3], f4 = pr[fo + 4], f5 = pr[fo + 5];
-            if (wL != 0.0) {
-                const double m0 = u0 - c0, m1 = u1 - c1, m2 = u2 - c2;
+        for (int t = 0; t < LLS_PF; ++t) {
+            const int base = base4 + t * LL_TILE;
+            if (base >= n_level_nodes) break;               // workgroup-uniform
+            const int node = base + (int)threadIdx.x;
+            bool live = false;
+            double v[10];
+#pragma unroll
+            for (int e = 0; e < 10; ++e) v[e] = 0.0;
+            if (node < n_level_nodes && nd[t][0] != 0.0) {
+                const double m0 = nd[t][2] - c0, m1 = nd[t][3] - c1, m2 = nd[t][4] - c2;
                 const double g0 = fmax(fmax(lo0 - m0, m0 - hi0), 0.0), g1 = fmax(fmax(lo1 - m1, m1 - hi1), 0.0),
                              g2 = fmax(fmax(lo2 - m2, m2 - hi2), 0.0);
-                live = !(kap * (g0 * g0 + g1 * g1 + g2 * g2) > LL_CULL);
+                live = !(nd[t][1] * (g0 * g0 + g1 * g1 + g2 * g2) > LL_CULL);
                 if (live) {
+                    const double f0 = nd[t][5], f1 = nd[t][6], f2 = nd[t][7], f3 = nd[t][8], f4 = nd[t][9], f5 = nd[t][10];
                     if (use_chol) {
                         v[0] = f0; v[1] = f1; v[2] = f2; v[3] = f3; v[4] = f4; v[5] = f5;
                         v[6] = -fma(f2, m2, fma(f1, m1, f0 * m0));
@@ -913,52 +975,52 @@ __global__ __launch_bounds__(CH) void tree_loglik_small_kernel(const double* __r
                         v[0] = -0.5 * f0; v[1] = -0.5 * f1; v[2] = -0.5 * f2; v[3] = -0.5 * f3; v[4] = -0.5 * f4; v[5] = -0.5 * f5;
                         v[6] = m0; v[7] = m1; v[8] = m2;
                     }
-                    v[9] = wL;
+                    v[9] = nd[t][0];
                 }
             }
-        }
-        const unsigned long long mask = __ballot(live);
-        const int before = __popcll(mask & ((1ull << lane) - 1ull));
-        if (lane == 0) wcnt[w] = __popcll(mask);
-        __syncthreads();                                   // also: every wave is done with the previous tile
-        int off = 0, cnt = 0;
+            const unsigned long long mask = __ballot(live);
+            const int before = __popcll(mask & ((1ull << lane) - 1ull));
+            if (lane == 0) wcnt[w] = __popcll(mask);
+            __syncthreads();                               // also: every wave is done with the previous tile (and exp_tab is in)
+            int off = 0, cnt = 0;
 #pragma unroll
-        for (int ww = 0; ww < CH / 64; ++ww) {
-            const int t = wcnt[ww];
-            if (ww < w) off += t;
-            cnt += t;
-        }
-        if (live) {
-            double* dst = tile[off + before];
-#pragma unroll
-            for (int e = 0; e < 10; ++e) dst[e] = v[e];
-        }
-        const int cnt16 = (cnt + 15) & ~15;
-        if ((int)threadIdx.x < (cnt16 - cnt) * 10) (&tile[cnt][0])[threadIdx.x] = 0.0;      // weightless padding
-        __syncthreads();
-        entered += cnt;
-        for (int k0 = w; k0 < cnt16; k0 += 16) {           // this wave's entries k0, k0 + 4, k0 + 8, k0 + 12
-            double yv[4], wl[4];
-            bool need = false;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double* t = tile[k0 + 4 * q];
-                wl[q] = t[9];
-                if (use_chol) {
-                    const double z0 = fma(t[2], x2, fma(t[1], x1, fma(t[0], x0, t[6])));
-                    const double z1 = fma(t[4], x2, fma(t[3], x1, t[7]));
-                    const double z2 = fma(t[5], x2, t[8]);
-                    yv[q] = -fma(z2, z2, fma(z1, z1, z0 * z0));
-                } else {
-                    yv[q] = sym3_quad(t[0], t[1], t[2], t[3], t[4], t[5], x0 - t[6], x1 - t[7], x2 - t[8]);
-                }
-                need = need || (wl[q] != 0.0 && yv[q] > LL_SKIP);
+            for (int ww = 0; ww < CH / 64; ++ww) {
+                const int c = wcnt[ww];
+                if (ww < w) off += c;
+                cnt += c;
             }
-            if (__any(need)) {
-                double e[4];
-                exp_nonpos4(yv, e, exp_tab);
+            if (live) {
+                double* dst = tile[off + before];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) tot = fma(wl[q], e[q], tot);
+                for (int e = 0; e < 10; ++e) dst[e] = v[e];
+            }
+            const int cnt16 = (cnt + 15) & ~15;
+            if ((int)threadIdx.x < (cnt16 - cnt) * 10) (&tile[cnt][0])[threadIdx.x] = 0.0;      // weightless padding
+            __syncthreads();
+            entered += cnt;
+            for (int k0 = w; k0 < cnt16; k0 += 16) {       // this wave's entries k0, k0 + 4, k0 + 8, k0 + 12
+                double yv[4], wl[4];
+                bool need = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double* te = tile[k0 + 4 * q];
+                    wl[q] = te[9];
+                    if (use_chol) {
+                        const double z0 = fma(te[2], x2, fma(te[1], x1, fma(te[0], x0, te[6])));
+                        const double z1 = fma(te[4], x2, fma(te[3], x1, te[7]));
+                        const double z2 = fma(te[5], x2, te[8]);
+                        yv[q] = -fma(z2, z2, fma(z1, z1, z0 * z0));
+                    } else {
+                        yv[q] = sym3_quad(te[0], te[1], te[2], te[3], te[4], te[5], x0 - te[6], x1 - te[7], x2 - te[8]);
+                    }
+                    need = need || (wl[q] != 0.0 && yv[q] > LL_SKIP);
+                }
+                if (__any(need)) {
+                    double e[4];
+                    exp_nonpos4(yv, e, exp_tab);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tot = fma(wl[q], e[q], tot);
+                }
             }
         }
     }
@@ -968,13 +1030,31 @@ __global__ __launch_bounds__(CH) void tree_loglik_small_kernel(const double* __r
     }
     tot_sh[w][lane] = tot;
     __syncthreads();
-    double t = 0.0;
     if (w == 0) {
         const double all = ((tot_sh[0][lane] + tot_sh[1][lane]) + tot_sh[2][lane]) + tot_sh[3][lane];
         const double lq = active ? log(fmax(all, TREE_EPS)) : 0.0;
-        t = wave_sum_f64(lq);
+        const double t = wave_sum_f64(lq);
+        if (lane == 0) block_q[blockIdx.x] = t;
     }
-    store_block_q(t, block_q, (int)gridDim.x, ticket, q_out, stop);
+}
+
+// q = the sum of the workgroups' shares (fixed order) + the level's stop rule; one workgroup
+__global__ __launch_bounds__(CH) void tree_qsum_kernel(const double* __restrict__ block_q, int nb,
+                                                       double* __restrict__ q_out, const int* __restrict__ done,
+                                                       TreeStop stop) {
+    __shared__ double sh_fin[4];
+    const int stop_flag = done ? *done : 0;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nb; i += CH) acc += block_q[i];      // (requested before the flag is looked at)
+    if (stop_flag) return;
+    acc = wave_sum_f64(acc);
+    if (lane_id() == 0) sh_fin[wave_in_block()] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double q = sh_fin[0] + sh_fin[1] + sh_fin[2] + sh_fin[3];
+        *q_out = q;
+        if (stop.ctl) tree_ctl_update(q, stop);
+    }
 }
 
 __global__ __launch_bounds__(CH) void tree_loglik_finish_kernel(const double* __restrict__ partial, int64_t n,
@@ -1668,11 +1748,11 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     tree_loglik_kernel<PTS><<<dim3(llblocks, chunks), CH, 0, c->stream>>>(                                 \
         xs_cur, n, n_pad, d_prep, lb, n_level, per_chunk, ll_partial, block_q, q_ticket, q_dev, &ctl->done, \
         chunks > 1 ? no_stop : stop, flags_ptr(c), pairs_ptr(c))
-                    if (ll_small)
+                    if (ll_small) {
                         tree_loglik_small_kernel<<<nblk(n, LLS_PTS), CH, 0, c->stream>>>(
-                            xs_cur, n, n_pad, d_prep, lb, n_level, block_q, q_ticket, q_dev, &ctl->done, stop, flags_ptr(c),
-                            pairs_ptr(c));
-                    else if (ll_pts == 4)
+                            xs_cur, n, n_pad, d_prep, lb, n_level, block_q, &ctl->done, flags_ptr(c), pairs_ptr(c));
+                        tree_qsum_kernel<<<1, CH, 0, c->stream>>>(block_q, (int)nblk(n, LLS_PTS), q_dev, &ctl->done, stop);
+                    } else if (ll_pts == 4)
                         tree_loglik_kernel<4, true><<<dim3(llblocks, chunks), CH, 0, c->stream>>>(
                             xs_cur, n, n_pad, d_prep, lb, n_level, per_chunk, ll_partial, block_q, q_ticket, q_dev, &ctl->done,
                             chunks > 1 ? no_stop : stop, flags_ptr(c), pairs_ptr(c), c->exp_tab2.as<double>());
@@ -2417,18 +2497,46 @@ __device__ __forceinline__ void full_fused_body(
                 if (pb != pa) G[(size_t)pb * LDG + jc[c]] = wE[c] * e[1];
             }
         };
+        // four (point, component) pairs per step, the exponentials in three stages: the four table look-ups are in flight
+        // while the polynomials are evaluated (see exp_t11_head; eight per step needs 3 registers more than there are)
+        auto eval4s = [&](const int (&pt)[4], auto c_of) {
+            ExpHead hd[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c_of(k);
+                const double a0 = X[pt[k]], a1 = X[FT_P + pt[k]], a2 = X[2 * FT_P + pt[k]];
+                double y;
+                if (CHOL) {
+                    const double z0 = fma(s02[c], a2, fma(s01[c], a1, fma(s00[c], a0, m0[c])));
+                    const double z1 = fma(s12[c], a2, fma(s11[c], a1, m1[c]));
+                    const double z2 = fma(s22[c], a2, m2[c]);
+                    y = -fma(z2, z2, fma(z1, z1, z0 * z0));
+                } else {
+                    y = sym3_quad(s00[c], s01[c], s02[c], s11[c], s12[c], s22[c], a0 - m0[c], a1 - m1[c], a2 - m2[c]);
+                }
+                hd[k] = exp_t11_head<CHOL>(y, EXPT);
+            }
+            double pa[4];
+            exp_t11_poly4(hd[0].r, hd[1].r, hd[2].r, hd[3].r, pa);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c_of(k);
+                const double e = exp_t11_tail(hd[k], pa[k]);
+                if ((CPL == 2 && c == 0) || jc[c] < J16) G[(size_t)pt[k] * LDG + jc[c]] = wE[c] * e;
+            }
+        };
         const bool full2 = CPL == 2 && !tail_wave && (w * 64 + FT_BLOCK < J16);     // wave-uniform
         if (full2) {
 #pragma unroll 2
             for (int p0 = 0; p0 < FT_P; p0 += 2) {
                 const int pt[4] = {p0, p0, p0 + 1, p0 + 1};
-                eval4(pt, [](int k) { return k & 1; });
+                eval4s(pt, [](int k) { return k & 1; });
             }
         } else {
 #pragma unroll 2
             for (int p0 = 0; p0 < FT_P; p0 += 4) {
                 const int pt[4] = {p0, p0 + 1, p0 + 2, p0 + 3};
-                eval4(pt, [](int) { return 0; });
+                eval4s(pt, [](int) { return 0; });
             }
             if (tail_wave) {                                              // (tail_pts is workgroup-uniform)
                 if (tail_pts >= 4) {
