@@ -445,12 +445,15 @@ __global__ __launch_bounds__(CH) void tree_estep_kernel(
     const double* __restrict__ xs, int64_t n_pad, const double* __restrict__ prep,
     const int* __restrict__ chunk_desc, const int* __restrict__ n_chunks, int64_t parent_level_first,
     int level, double* __restrict__ partials, int* __restrict__ cur_sorted, const int* __restrict__ done) {
-    if (done && *done) return;            // the level converged in an earlier iteration of this batch
+    // (the stop flag, the chunk count and this chunk's descriptor are requested together -- the descriptor table is
+    //  allocated for the whole grid, so the read is safe before the count is known: one trip to memory instead of three)
     const int c = blockIdx.x;
-    if (c >= *n_chunks) return;
+    const int stop_flag = done ? *done : 0;        // the level converged in an earlier iteration of this batch
+    const int chunks_now = *n_chunks;
+    const int p = chunk_desc[3 * c + 0], begin = chunk_desc[3 * c + 1], end = chunk_desc[3 * c + 2];
     __shared__ double exp_tab[EXP_TAB_N];
     exp_tab_load(exp_tab);                         // (synchronised below, once the points' loads are on their way)
-    const int p = chunk_desc[3 * c + 0], begin = chunk_desc[3 * c + 1], end = chunk_desc[3 * c + 2];
+    if (stop_flag || c >= chunks_now) return;
     // node id of the parent: level 0 -> pseudo-parent -1; child(j) = 8 (j + 1)
     const int64_t parent_node = (level == 0) ? -1 : parent_level_first + p;
     const int64_t j0 = 8 * (parent_node + 1);
@@ -575,11 +578,12 @@ __global__ __launch_bounds__(64) void tree_moments_kernel(const double* __restri
                                                           int fuse, int64_t lb, double n_points_total, double ld,
                                                           double* pi, double* mu, double* cov, double* prep,
                                                           int* __restrict__ flags, const int* __restrict__ done) {
-    if (done && *done) return;
     const int cl = blockIdx.x;            // level-local child index
     if (cl >= n_level_nodes) return;
     const int p = cl >> 3, k = cl & 7;
+    const int stop_flag = done ? *done : 0;                   // (requested together with the chunk range)
     const int c0 = chunk_first[p], c1 = chunk_first[p + 1];
+    if (stop_flag) return;
     double acc[NMOM];
 #pragma unroll
     for (int m = 0; m < NMOM; ++m) acc[m] = 0.0;
@@ -1639,8 +1643,11 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     //  these launches are chains of memory round trips, not arithmetic)
     int ll_pts = n >= 400000 ? 4 : 2;
     if (const char* e = std::getenv("HGMM_TREE_LL_PTS")) ll_pts = atoi(e) >= 4 ? 4 : (atoi(e) >= 2 ? 2 : 1);
-    // small clouds: the 64-point / node-split form of the log-likelihood (tree_loglik_small_kernel)
-    bool ll_small = (int64_t)nblk(n, CH * 2) < 2 * (int64_t)c->cus;
+    // The 64-point / node-split form of the log-likelihood (tree_loglik_small_kernel) is OPT-IN (HGMM_TREE_LL_SMALL=1):
+    // measured on C4 it loses at every level -- 16.9 / 17.7 / 20.2 / 49 us per iteration (kernel + its sum kernel)
+    // against 8.9 / 14.8 / 19.1 / 22.4 for the 512-point form (+ finish pass): eight times as many workgroups each read
+    // the level's whole node table for the reach test (629 x 360 KB at level 3).  Kept for the record and the tests.
+    bool ll_small = false;
     if (const char* e = std::getenv("HGMM_TREE_LL_SMALL")) ll_small = e[0] == '1';
     if (ll_pts == 4 && !ll_small) HGMM_TRY(ensure_exp_tab2(c));
     int batch_iters = 8;                      // iterations enqueued per host synchronisation (1/2/4/8/16: 6.8/6.3/5.6/5.1/5.3 ms @C4)
