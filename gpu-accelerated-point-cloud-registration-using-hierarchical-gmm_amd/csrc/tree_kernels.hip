@@ -2722,6 +2722,285 @@ __global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
         full_fused_body<CPL, true>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds, exp2_tab);
 }
 
+// ------------------------------------------------------------------------------------------
+// The same one-pass E-step with SIXTEEN waves per workgroup (1024 threads, one component per lane).
+// The 8-wave kernel above sits at 58 % of the issue floor of its own formulation because two waves per SIMD in lock-step
+// cannot cover each other's LDS round trips (profiles/r03/fullcov_accounting.md).  The tile of g values allows one
+// workgroup per CU whatever its size -- so the workgroup is made larger: four waves per SIMD, each lane ONE component
+// (its 10 parameters in 20 registers instead of 40), 3-4 instead of 6-7 accumulator tiles per wave, the kernel inside the
+// 128 registers that 16 waves per CU leave to a wave.  Same LDS layout, same phases, same arithmetic per pair:
+//   A  wave w < wf = J16 / 64: components 64 w + lane, 16 points (four staged 4-evaluation steps); a tail of <= 32
+//      components is dealt over the waves behind the full ones exactly as in the 8-wave kernel (J = 800: waves 12-15,
+//      two points per lane); every SIMD (waves w, w + 4, w + 8, w + 12) carries 50 of the tile's 200 wave-evaluations
+//   B  wave w = point w (a full wave per row: 2 values per lane and 128-column step)
+//   C  wave w = 16-component tiles w, w + 16, w + 32, w + 48
+// ------------------------------------------------------------------------------------------
+constexpr int F16_WAVES = 16;
+constexpr int F16_BLOCK = F16_WAVES * 64;
+template <bool CHOL>
+__device__ __forceinline__ void full_fused16_body(
+    const double* __restrict__ xs, int64_t n, int64_t n_pad, const double* __restrict__ prep, int J16,
+    int* __restrict__ label_out, double* __restrict__ block_q, double* __restrict__ partials /*[grid][J16][NMOM]*/,
+    int want_stats, long long* __restrict__ dbg, double* lds, const double* __restrict__ exp2_tab) {
+    long long tA = 0, tB = 0, tC = 0, tW = 0, tm = 0;
+#define FT_TICK(acc) do { if (dbg) { const long long now_ = clock64(); acc += now_ - tm; tm = now_; } } while (0)
+    const int LDG = ft_ldg(J16);
+    double* G = lds;                              // [FT_P][LDG]
+    double* F = G + (size_t)FT_P * LDG;           // [16 features][FT_LDF]
+    double* INV = F + 16 * FT_LDF;                // [FT_P]
+    double* TOT = INV + FT_P;                     // [2][FT_P]
+    double* WL = TOT + 2 * FT_P;                  // [J16]
+    double* XS = WL + J16;                        // [2][3][FT_P] relative to the origin
+    double* XA = XS + 2 * 3 * FT_P;               // [2][3][FT_P] as given
+    double* EXPT = XA + 2 * 3 * FT_P;             // [2048]
+    const int w = wave_in_block(), lane = lane_id();
+    const int tid = (int)threadIdx.x;
+    exp_tab2_load(EXPT, exp2_tab);
+
+    const int wf = J16 / 64, rem = J16 % 64;
+    const bool tail_exists = rem > 0 && rem <= 32;
+    const int free_w = F16_WAVES - wf;
+    const int nw = tail_exists ? (free_w >= 8 ? 8 : (free_w >= 4 ? 4 : (free_w >= 2 ? 2 : 1))) : 0;
+    const bool tail_wave = tail_exists && w >= wf && w < wf + nw;        // wave-uniform
+    const int tail_pts = tail_exists ? FT_P / (2 * nw) : 0;              // points per half-wave: 8, 4, 2 or 1
+    const int tail_p0 = tail_wave ? (w - wf) * 2 * tail_pts + (lane >> 5) * tail_pts : 0;
+    const int jc = tail_wave ? 64 * wf + (lane & 31) : tid;              // this lane's component (>= J16: none)
+    const bool has = jc < J16;
+    const double o0 = xs[0], o1 = xs[n_pad], o2 = xs[2 * n_pad];
+    double s00 = 0.0, s01 = 0.0, s02 = 0.0, s11 = 0.0, s12 = 0.0, s22 = 0.0, m0 = 0.0, m1 = 0.0, m2 = 0.0, wE = 0.0;
+    if (has) {
+        const double* pr = prep + PREP_N * jc;
+        const double u0 = pr[6] - o0, u1 = pr[7] - o1, u2 = pr[8] - o2;
+        if (CHOL) {
+            s00 = pr[PREP_R]; s01 = pr[PREP_R + 1]; s02 = pr[PREP_R + 2];
+            s11 = pr[PREP_R + 3]; s12 = pr[PREP_R + 4]; s22 = pr[PREP_R + 5];
+            m0 = -fma(s02, u2, fma(s01, u1, s00 * u0));
+            m1 = -fma(s12, u2, s11 * u1);
+            m2 = -(s22 * u2);
+        } else {
+            s00 = -0.5 * pr[0]; s01 = -0.5 * pr[1]; s02 = -0.5 * pr[2];
+            s11 = -0.5 * pr[3]; s12 = -0.5 * pr[4]; s22 = -0.5 * pr[5];
+            m0 = u0; m1 = u1; m2 = u2;
+        }
+        wE = pr[9];
+    }
+    int my_small = 0;
+    for (int j = tid; j < J16; j += F16_BLOCK) {
+        const double wl = prep[PREP_N * j + 10], we = prep[PREP_N * j + 9];
+        WL[j] = (wl != 0.0) ? 1.0 : 0.0;
+        if (wl == 0.0 && we != 0.0) my_small = 1;
+    }
+    for (int e = tid; e < FT_P * LDG; e += F16_BLOCK) G[e] = 0.0;
+    const bool any_small = __syncthreads_or(my_small) != 0;
+    const int ntiles = J16 / 16;
+    constexpr int MAXT = FT_MAX_J16 / 16 / F16_WAVES;                     // 4
+    double acc[MAXT][3];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t][0] = acc[t][1] = acc[t][2] = 0.0;
+    const int a_idx = lane & 15, b_idx = lane >> 4;
+
+    const int64_t tiles = (n + FT_P - 1) / FT_P;
+    const int64_t per = (tiles + gridDim.x - 1) / gridDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * per;
+    const int64_t t1 = (t0 + per < tiles) ? t0 + per : tiles;
+    constexpr int LQ_WAVE = F16_WAVES - 1;       // the last wave never has a full block of components: room for the logs
+    double lq = 0.0;
+
+    const int st_d = tid / FT_P, st_p = tid % FT_P;
+    const double st_o = (tid < 3 * FT_P) ? xs[(size_t)st_d * n_pad] : 0.0;
+    auto stage = [&](int64_t tile, int buf) {
+        if (tid < 3 * FT_P) {
+            int64_t i = tile * FT_P + st_p;
+            i = i < n ? i : n - 1;
+            const double v = xs[(size_t)st_d * n_pad + i];
+            XA[(buf * 3 + st_d) * FT_P + st_p] = v;
+            XS[(buf * 3 + st_d) * FT_P + st_p] = v - st_o;
+        }
+    };
+    auto tile_loglik = [&](int par) {
+        const double tv = (lane < FT_P) ? TOT[par * FT_P + lane] : -1.0;
+        double term = (tv >= 0.0) ? log(fmax(tv, TREE_EPS)) : 0.0;
+        term = wave_sum_f64(term);
+        lq += term;
+    };
+    if (t0 < t1) stage(t0, 0);
+    __syncthreads();
+    for (int64_t tile = t0; tile < t1; ++tile) {
+        const int64_t base = tile * FT_P;
+        const int buf = (int)((tile - t0) & 1);
+        const double* X = XS + buf * 3 * FT_P;
+        if (dbg) tm = clock64();
+        if (w == LQ_WAVE && tile > t0) tile_loglik(buf ^ 1);
+        // ---- phase A ----
+        auto expo = [&](int pt) -> double {
+            const double a0 = X[pt], a1 = X[FT_P + pt], a2 = X[2 * FT_P + pt];
+            if (CHOL) {
+                const double z0 = fma(s02, a2, fma(s01, a1, fma(s00, a0, m0)));
+                const double z1 = fma(s12, a2, fma(s11, a1, m1));
+                const double z2 = fma(s22, a2, m2);
+                return -fma(z2, z2, fma(z1, z1, z0 * z0));
+            }
+            return sym3_quad(s00, s01, s02, s11, s12, s22, a0 - m0, a1 - m1, a2 - m2);
+        };
+        auto eval4 = [&](int pa, int pb, int pc, int pd, int distinct) {
+            ExpHead hd[4];
+            const int pt[4] = {pa, pb, pc, pd};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hd[k] = exp_t11_head<CHOL>(expo(pt[k]), EXPT);
+            double pp[4];
+            exp_t11_poly4(hd[0].r, hd[1].r, hd[2].r, hd[3].r, pp);
+            if (has) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < distinct) G[(size_t)pt[k] * LDG + jc] = wE * exp_t11_tail(hd[k], pp[k]);
+            }
+        };
+        if (tail_wave) {                                                   // (tail_pts is workgroup-uniform)
+            if (tail_pts >= 4) {
+                for (int q0 = 0; q0 < tail_pts; q0 += 4) eval4(tail_p0 + q0, tail_p0 + q0 + 1, tail_p0 + q0 + 2, tail_p0 + q0 + 3, 4);
+            } else if (tail_pts == 2) {
+                eval4(tail_p0, tail_p0 + 1, tail_p0 + 1, tail_p0 + 1, 2);
+            } else {
+                eval4(tail_p0, tail_p0, tail_p0, tail_p0, 1);
+            }
+        } else if (w * 64 < J16) {                                         // a wave with (some) first components
+#pragma unroll 1
+            for (int q0 = 0; q0 < FT_P; q0 += 4) eval4(q0, q0 + 1, q0 + 2, q0 + 3, 4);
+        }
+        if (tile + 1 < t1) stage(tile + 1, buf ^ 1);
+        FT_TICK(tA);
+        __syncthreads();
+        FT_TICK(tW);
+        // ---- phase B: wave w = point w ----
+        {
+            const int p = w;
+            const double* Gp = G + (size_t)p * LDG;
+            const int J128 = (J16 + 127) & ~127;                       // the row is zero beyond J16
+            double den = 0.0, tot = 0.0, best = -1.0;
+            int jbest = 0;
+            for (int jb = 0; jb < J128; jb += 256) {                   // two 128-column steps at a time, loads first
+                const bool two = jb + 128 < J128;                      // workgroup-uniform
+                const double g0 = Gp[jb + lane], g1 = Gp[jb + 64 + lane];
+                const double g2 = two ? Gp[jb + 128 + lane] : 0.0, g3 = two ? Gp[jb + 192 + lane] : 0.0;
+                const double ma = fmax(g0, g1), mb = fmax(g2, g3);
+                den += (g0 + g1) + (g2 + g3);
+                jbest = (ma > best) ? jb : jbest;
+                best = fmax(best, ma);
+                jbest = (mb > best) ? jb + 128 : jbest;
+                best = fmax(best, mb);
+                if (any_small) {
+                    const int j0 = jb + lane;
+                    tot = fma(g0, (j0 < J16) ? WL[j0] : 0.0, tot);
+                    tot = fma(g1, (j0 + 64 < J16) ? WL[j0 + 64] : 0.0, tot);
+                    tot = fma(g2, (j0 + 128 < J16) ? WL[j0 + 128] : 0.0, tot);
+                    tot = fma(g3, (j0 + 192 < J16) ? WL[j0 + 192] : 0.0, tot);
+                }
+            }
+            // the lane's first column holding its maximum: the first of the step's two values equal to it
+            const int am = jbest + lane + ((Gp[jbest + lane] == best) ? 0 : 64);
+            const double den_w = wave_sum_f64(den);
+            const double bm_w = wave_max_f64(best);
+            const int am_w = wave_reduce_i((best == bm_w) ? am : 0x7fffffff, OpMinI());
+            const double tot_w = any_small ? wave_sum_f64(tot) : den_w;
+            const double inv = 1.0 / den_w;
+            if (lane == 0) {
+                const bool live = base + p < n;
+                const bool good = den_w > TREE_EPS;
+                INV[p] = (live && good) ? inv : 0.0;
+                TOT[buf * FT_P + p] = live ? tot_w : -1.0;
+                if (live) label_out[base + p] = good ? am_w : 0;
+            }
+            if (lane < 16) {
+                const double* A = XA + buf * 3 * FT_P;
+                const double x0 = A[p], x1 = A[FT_P + p], x2 = A[2 * FT_P + p];
+                double f = 0.0;
+                switch (lane) {
+                    case 0: f = 1.0; break;
+                    case 1: f = x0; break;
+                    case 2: f = x1; break;
+                    case 3: f = x2; break;
+                    case 4: f = x0 * x0; break;
+                    case 5: f = x0 * x1; break;
+                    case 6: f = x0 * x2; break;
+                    case 7: f = x1 * x1; break;
+                    case 8: f = x1 * x2; break;
+                    case 9: f = x2 * x2; break;
+                    default: f = 0.0;
+                }
+                F[lane * FT_LDF + p] = f;
+            }
+        }
+        FT_TICK(tB);
+        __syncthreads();
+        FT_TICK(tW);
+        // ---- phase C: wave w = component tiles w, w + 16, ... ----
+        // (four points at a time in the OUTER loop: one set of feature fragments -- 3 doubles -- is live instead of 12;
+        //  the next four points' A operands are requested before the current ones are consumed)
+        if (want_stats) {
+            double araw[2][MAXT];
+            auto load_a = [&](int s, double (&dst)[MAXT]) {
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) {
+                    const int ct = w + t * F16_WAVES;
+                    dst[t] = (ct < ntiles) ? G[(size_t)(4 * s + b_idx) * LDG + 16 * ct + a_idx] : 0.0;
+                }
+            };
+            load_a(0, araw[0]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (s + 1 < 4) load_a(s + 1, araw[(s + 1) & 1]);
+                const double inv_s = INV[4 * s + b_idx];
+                const double b0 = F[(lane & 3) * FT_LDF + 4 * s + b_idx], b1 = F[(4 + (lane & 3)) * FT_LDF + 4 * s + b_idx],
+                             b2 = F[(8 + (lane & 3)) * FT_LDF + 4 * s + b_idx];
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) {
+                    const int ct = w + t * F16_WAVES;                      // wave-uniform
+                    if (ct < ntiles) {
+                        double a = araw[s & 1][t] * inv_s;
+                        if (a < TREE_EPS) a = 0.0;
+                        acc[t][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b0, acc[t][0], 0, 0, 0);
+                        acc[t][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b1, acc[t][1], 0, 0, 0);
+                        acc[t][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b2, acc[t][2], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        FT_TICK(tC);
+        __syncthreads();
+        FT_TICK(tW);
+    }
+    if (w == LQ_WAVE && t0 < t1) tile_loglik((int)((t1 - 1 - t0) & 1));
+    if (dbg && lane == 0 && blockIdx.x == 7) {
+        dbg[w * 4 + 0] = tA; dbg[w * 4 + 1] = tB; dbg[w * 4 + 2] = tC; dbg[w * 4 + 3] = tW;
+    }
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int ct = w + t * F16_WAVES;
+        if (ct < ntiles) {
+            const int comp = 16 * ct + 4 * ((lane >> 2) & 3) + (lane >> 4);
+#pragma unroll
+            for (int fb = 0; fb < 3; ++fb) {
+                const int feat = 4 * fb + (lane & 3);
+                if (feat < NMOM) partials[((size_t)blockIdx.x * J16 + comp) * NMOM + feat] = acc[t][fb];
+            }
+        }
+    }
+    if (w == LQ_WAVE && lane == 0) block_q[blockIdx.x] = lq;
+#undef FT_TICK
+}
+
+__global__ __launch_bounds__(F16_BLOCK) void full_fused16_kernel(
+    const double* __restrict__ xs, int64_t n, int64_t n_pad, const double* __restrict__ prep, int J16,
+    int* __restrict__ label_out, double* __restrict__ block_q, double* __restrict__ partials /*[grid][J16][NMOM]*/,
+    int want_stats, const int* __restrict__ flags, const double* __restrict__ exp2_tab,
+    long long* __restrict__ dbg = nullptr) {
+    extern __shared__ double lds[];
+    if (flags && (*flags & 1))
+        full_fused16_body<false>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds, exp2_tab);
+    else
+        full_fused16_body<true>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds, exp2_tab);
+}
+
 // one wave per component: fixed-order sum over the workgroups' partials
 __global__ __launch_bounds__(64) void full_reduce_kernel(const double* __restrict__ partials, int nblocks,
                                                          int J, int J16, double* __restrict__ mom) {
@@ -2801,9 +3080,29 @@ static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_hos
     double* q_dev = block_q + nblk(c->n, CH) + c->cus;
     const size_t lds = ft_lds_bytes(J16);
     HGMM_TRY(ensure_exp_tab2(c));
+    // 16 waves per workgroup (full_fused16_kernel) unless HGMM_FULLCOV_WAVES=8 asks for the 8-wave kernel
+    bool waves16 = true;
+    if (const char* e = std::getenv("HGMM_FULLCOV_WAVES")) waves16 = atoi(e) != 8;
     {
         ProfScope prof(c, HGMM_K_FULL_FUSED);
-        if (J16 <= FT_BLOCK) {
+        if (waves16) {
+            HGMM_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&full_fused16_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            long long* dbg = nullptr;
+            if (std::getenv("HGMM_FT_DEBUG")) { HGMM_HIP(c, hipMalloc(&dbg, 16 * 4 * 8)); }
+            full_fused16_kernel<<<grid, F16_BLOCK, lds, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
+                                                                    c->t_prep.as<double>(), J16, labels, block_q,
+                                                                    c->t_partials.as<double>(), want_stats ? 1 : 0,
+                                                                    flags_ptr(c), c->exp_tab2.as<double>(), dbg);
+            if (dbg) {
+                long long h[64];
+                HGMM_HIP(c, hipStreamSynchronize(c->stream));
+                HGMM_HIP(c, hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost));
+                for (int w = 0; w < 16; ++w)
+                    fprintf(stderr, "wave %d: A %lld  B %lld  C %lld  wait %lld cycles\n", w, h[4 * w], h[4 * w + 1], h[4 * w + 2], h[4 * w + 3]);
+                (void)hipFree(dbg);
+            }
+        } else if (J16 <= FT_BLOCK) {
             HGMM_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&full_fused_kernel<1>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             full_fused_kernel<1><<<grid, FT_BLOCK, lds, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
