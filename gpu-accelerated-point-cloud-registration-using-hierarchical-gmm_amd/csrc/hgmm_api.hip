@@ -363,7 +363,7 @@ extern "C" int hgmm_destroy(hgmm_ctx* c) {
                       &c->t_parent, &c->t_current, &c->t_perm, &c->t_seg, &c->t_chunks, &c->t_partials,
                       &c->t_q, &c->tgt_soa64, &c->comm_buf, &c->t_xs3, &c->t_llp, &c->t_qtrace, &c->f_cm, &c->f_cs, &c->f_ca, &c->f_lpn2,
                       &c->km_closest, &c->km_block, &c->km_centres, &c->km_ids, &c->km_rand, &c->km_labels,
-                      &c->km_mind2, &c->km_partial, &c->km_out, &c->gt_buf, &c->t_momq, &c->t_flags, &c->exp_tab2, &c->t_tickets, &c->x_rel64};
+                      &c->km_mind2, &c->km_partial, &c->km_out, &c->gt_buf, &c->t_momq, &c->t_flags, &c->exp_tab2, &c->t_tickets};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -445,7 +445,6 @@ extern "C" int hgmm_set_points_f32(hgmm_ctx* c, const float* xyz, int64_t n) {
     HGMM_HIP(c, hipGetLastError());
     HGMM_HIP(c, hipStreamSynchronize(c->stream));
     c->have_f32 = c->have_f64 = true;
-    c->x_rel_valid = false;
     return HGMM_OK;
 }
 
@@ -461,7 +460,6 @@ extern "C" int hgmm_set_points_f64(hgmm_ctx* c, const double* xyz, int64_t n) {
     HGMM_HIP(c, hipGetLastError());
     HGMM_HIP(c, hipStreamSynchronize(c->stream));
     c->have_f32 = c->have_f64 = true;
-    c->x_rel_valid = false;
     return HGMM_OK;
 }
 

@@ -61,8 +61,6 @@ struct hgmm_ctx {
     hgmm::DevBuf x_aos;               // float [n,3]  (flat EM; wave-uniform scalar loads)
     hgmm::DevBuf x_soa64;             // double [3][n_pad] (HGMM; lanes across points)
     bool have_f32 = false, have_f64 = false;
-    hgmm::DevBuf x_rel64;             // double [3][n_pad]: x_soa64 minus its first point (full-covariance kernels' scalar loads)
-    bool x_rel_valid = false;
     int64_t n_pad = 0;
 
     // ---- flat EM ----------------------------------------------------------------

@@ -2340,8 +2340,7 @@ template <int CPL, bool CHOL>
 __device__ __forceinline__ void full_fused_body(
     const double* __restrict__ xs, int64_t n, int64_t n_pad, const double* __restrict__ prep, int J16,
     int* __restrict__ label_out, double* __restrict__ block_q, double* __restrict__ partials /*[grid][J16][NMOM]*/,
-    int want_stats, long long* __restrict__ dbg, double* lds, const double* __restrict__ exp2_tab,
-    const double* __restrict__ xrel) {
+    int want_stats, long long* __restrict__ dbg, double* lds, const double* __restrict__ exp2_tab) {
     long long tA = 0, tB = 0, tC = 0, tW = 0, tm = 0;
 #define FT_TICK(acc) do { if (dbg) { const long long now_ = clock64(); acc += now_ - tm; tm = now_; } } while (0)
     const int LDG = ft_ldg(J16);
@@ -2507,17 +2506,12 @@ __device__ __forceinline__ void full_fused_body(
         };
         // four (point, component) pairs per step, the exponentials in three stages: the four table look-ups are in flight
         // while the polynomials are evaluated (see exp_t11_head; eight per step needs 3 registers more than there are)
-        // (main path: the tile's coordinates come through the SCALAR cache from the origin-relative copy of the cloud --
-        //  wave-uniform addresses, s_load, SGPR operands of the fmas.  Reading them as LDS broadcasts cost 3 of the 5 LDS
-        //  instructions per evaluation, and phase A turned out to be bound by the LDS pipe, not by the VALU: it took the
-        //  same 6.9 k cycles per tile with two and with four waves per SIMD.)
         auto eval4s = [&](const int (&pt)[4], auto c_of) {
             ExpHead hd[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int c = c_of(k);
-                const int64_t ip = (base + pt[k] < n) ? base + pt[k] : n - 1;          // wave-uniform
-                const double a0 = xrel[ip], a1 = xrel[n_pad + ip], a2 = xrel[2 * n_pad + ip];
+                const double a0 = X[pt[k]], a1 = X[FT_P + pt[k]], a2 = X[2 * FT_P + pt[k]];
                 double y;
                 if (CHOL) {
                     const double z0 = fma(s02[c], a2, fma(s01[c], a1, fma(s00[c], a0, m0[c])));
@@ -2720,12 +2714,12 @@ __global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
     const double* __restrict__ xs, int64_t n, int64_t n_pad, const double* __restrict__ prep, int J16,
     int* __restrict__ label_out, double* __restrict__ block_q, double* __restrict__ partials /*[grid][J16][NMOM]*/,
     int want_stats, const int* __restrict__ flags, const double* __restrict__ exp2_tab,
-    const double* __restrict__ xrel, long long* __restrict__ dbg = nullptr) {
+    long long* __restrict__ dbg = nullptr) {
     extern __shared__ double lds[];
     if (flags && (*flags & 1))                     // kernel-uniform: some Sigma^-1 failed the Cholesky test
-        full_fused_body<CPL, false>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds, exp2_tab, xrel);
+        full_fused_body<CPL, false>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds, exp2_tab);
     else
-        full_fused_body<CPL, true>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds, exp2_tab, xrel);
+        full_fused_body<CPL, true>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds, exp2_tab);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2747,8 +2741,7 @@ template <bool CHOL>
 __device__ __forceinline__ void full_fused16_body(
     const double* __restrict__ xs, int64_t n, int64_t n_pad, const double* __restrict__ prep, int J16,
     int* __restrict__ label_out, double* __restrict__ block_q, double* __restrict__ partials /*[grid][J16][NMOM]*/,
-    int want_stats, long long* __restrict__ dbg, double* lds, const double* __restrict__ exp2_tab,
-    const double* __restrict__ xrel) {
+    int want_stats, long long* __restrict__ dbg, double* lds, const double* __restrict__ exp2_tab) {
     long long tA = 0, tB = 0, tC = 0, tW = 0, tm = 0;
 #define FT_TICK(acc) do { if (dbg) { const long long now_ = clock64(); acc += now_ - tm; tm = now_; } } while (0)
     const int LDG = ft_ldg(J16);
@@ -2839,14 +2832,8 @@ __device__ __forceinline__ void full_fused16_body(
         if (dbg) tm = clock64();
         if (w == LQ_WAVE && tile > t0) tile_loglik(buf ^ 1);
         // ---- phase A ----
-        auto expo = [&](int pt, bool uniform) -> double {
-            double a0, a1, a2;
-            if (uniform) {                                     // scalar loads from the origin-relative copy of the cloud
-                const int64_t ip = (base + pt < n) ? base + pt : n - 1;
-                a0 = xrel[ip]; a1 = xrel[n_pad + ip]; a2 = xrel[2 * n_pad + ip];
-            } else {
-                a0 = X[pt]; a1 = X[FT_P + pt]; a2 = X[2 * FT_P + pt];
-            }
+        auto expo = [&](int pt) -> double {
+            const double a0 = X[pt], a1 = X[FT_P + pt], a2 = X[2 * FT_P + pt];
             if (CHOL) {
                 const double z0 = fma(s02, a2, fma(s01, a1, fma(s00, a0, m0)));
                 const double z1 = fma(s12, a2, fma(s11, a1, m1));
@@ -2855,11 +2842,11 @@ __device__ __forceinline__ void full_fused16_body(
             }
             return sym3_quad(s00, s01, s02, s11, s12, s22, a0 - m0, a1 - m1, a2 - m2);
         };
-        auto eval4 = [&](int pa, int pb, int pc, int pd, int distinct, bool uniform) {
+        auto eval4 = [&](int pa, int pb, int pc, int pd, int distinct) {
             ExpHead hd[4];
             const int pt[4] = {pa, pb, pc, pd};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) hd[k] = exp_t11_head<CHOL>(expo(pt[k], uniform), EXPT);
+            for (int k = 0; k < 4; ++k) hd[k] = exp_t11_head<CHOL>(expo(pt[k]), EXPT);
             double pp[4];
             exp_t11_poly4(hd[0].r, hd[1].r, hd[2].r, hd[3].r, pp);
             if (has) {
@@ -2870,16 +2857,15 @@ __device__ __forceinline__ void full_fused16_body(
         };
         if (tail_wave) {                                                   // (tail_pts is workgroup-uniform)
             if (tail_pts >= 4) {
-                for (int q0 = 0; q0 < tail_pts; q0 += 4)
-                    eval4(tail_p0 + q0, tail_p0 + q0 + 1, tail_p0 + q0 + 2, tail_p0 + q0 + 3, 4, false);
+                for (int q0 = 0; q0 < tail_pts; q0 += 4) eval4(tail_p0 + q0, tail_p0 + q0 + 1, tail_p0 + q0 + 2, tail_p0 + q0 + 3, 4);
             } else if (tail_pts == 2) {
-                eval4(tail_p0, tail_p0 + 1, tail_p0 + 1, tail_p0 + 1, 2, false);
+                eval4(tail_p0, tail_p0 + 1, tail_p0 + 1, tail_p0 + 1, 2);
             } else {
-                eval4(tail_p0, tail_p0, tail_p0, tail_p0, 1, false);
+                eval4(tail_p0, tail_p0, tail_p0, tail_p0, 1);
             }
         } else if (w * 64 < J16) {                                         // a wave with (some) first components
 #pragma unroll 1
-            for (int q0 = 0; q0 < FT_P; q0 += 4) eval4(q0, q0 + 1, q0 + 2, q0 + 3, 4, true);
+            for (int q0 = 0; q0 < FT_P; q0 += 4) eval4(q0, q0 + 1, q0 + 2, q0 + 3, 4);
         }
         if (tile + 1 < t1) stage(tile + 1, buf ^ 1);
         FT_TICK(tA);
@@ -3007,12 +2993,12 @@ __global__ __launch_bounds__(F16_BLOCK) void full_fused16_kernel(
     const double* __restrict__ xs, int64_t n, int64_t n_pad, const double* __restrict__ prep, int J16,
     int* __restrict__ label_out, double* __restrict__ block_q, double* __restrict__ partials /*[grid][J16][NMOM]*/,
     int want_stats, const int* __restrict__ flags, const double* __restrict__ exp2_tab,
-    const double* __restrict__ xrel, long long* __restrict__ dbg = nullptr) {
+    long long* __restrict__ dbg = nullptr) {
     extern __shared__ double lds[];
     if (flags && (*flags & 1))
-        full_fused16_body<false>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds, exp2_tab, xrel);
+        full_fused16_body<false>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds, exp2_tab);
     else
-        full_fused16_body<true>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds, exp2_tab, xrel);
+        full_fused16_body<true>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds, exp2_tab);
 }
 
 // one wave per component: fixed-order sum over the workgroups' partials
@@ -3082,22 +3068,6 @@ static int fullcov_moments(hgmm_ctx* c, int J, int J16, int grid) {
     return HGMM_OK;
 }
 
-// the cloud relative to its first point (what the one-pass kernels' scalar loads read); rebuilt when the points change
-__global__ void full_rel_kernel(const double* __restrict__ xs, int64_t n_pad, double* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pad) return;
-#pragma unroll
-    for (int d = 0; d < 3; ++d) out[d * n_pad + i] = xs[d * n_pad + i] - xs[d * n_pad];
-}
-static int ensure_x_rel(hgmm_ctx* c) {
-    if (c->x_rel_valid && c->x_rel64.p) return HGMM_OK;
-    HGMM_TRY(ensure(c, c->x_rel64, sizeof(double) * 3 * (size_t)c->n_pad));
-    full_rel_kernel<<<nblk(c->n_pad, 256), 256, 0, c->stream>>>(c->x_soa64.as<double>(), c->n_pad, c->x_rel64.as<double>());
-    HGMM_HIP(c, hipGetLastError());
-    c->x_rel_valid = true;
-    return HGMM_OK;
-}
-
 // one-pass E-step (J16 <= FT_MAX_J16): denominators, arg-max, q and the statistics from ONE evaluation of the pdfs
 static bool fullcov_one_pass(int J16) {
     if (const char* e = std::getenv("HGMM_FULLCOV_TWO_PASS")) if (e[0] == '1') return false;
@@ -3110,10 +3080,11 @@ static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_hos
     double* q_dev = block_q + nblk(c->n, CH) + c->cus;
     const size_t lds = ft_lds_bytes(J16);
     HGMM_TRY(ensure_exp_tab2(c));
-    HGMM_TRY(ensure_x_rel(c));
-    // 16 waves per workgroup (full_fused16_kernel) unless HGMM_FULLCOV_WAVES=8 asks for the 8-wave kernel
-    bool waves16 = true;
-    if (const char* e = std::getenv("HGMM_FULLCOV_WAVES")) waves16 = atoi(e) != 8;
+    // The 16-wave form (full_fused16_kernel) is OPT-IN (HGMM_FULLCOV_WAVES=16): measured at C3 it is slower than the
+    // 8-wave kernel, 1.83 vs 1.76 ms -- phase A takes the same ~6.9 k cycles per tile with four waves per SIMD as with two
+    // (so it is not waiting on LDS round trips that more waves could cover), and the 128-register budget costs 16 spills.
+    bool waves16 = false;
+    if (const char* e = std::getenv("HGMM_FULLCOV_WAVES")) waves16 = atoi(e) == 16;
     {
         ProfScope prof(c, HGMM_K_FULL_FUSED);
         if (waves16) {
@@ -3124,7 +3095,7 @@ static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_hos
             full_fused16_kernel<<<grid, F16_BLOCK, lds, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
                                                                     c->t_prep.as<double>(), J16, labels, block_q,
                                                                     c->t_partials.as<double>(), want_stats ? 1 : 0,
-                                                                    flags_ptr(c), c->exp_tab2.as<double>(), c->x_rel64.as<double>(), dbg);
+                                                                    flags_ptr(c), c->exp_tab2.as<double>(), dbg);
             if (dbg) {
                 long long h[64];
                 HGMM_HIP(c, hipStreamSynchronize(c->stream));
@@ -3139,7 +3110,7 @@ static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_hos
             full_fused_kernel<1><<<grid, FT_BLOCK, lds, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
                                                                    c->t_prep.as<double>(), J16, labels, block_q,
                                                                    c->t_partials.as<double>(), want_stats ? 1 : 0,
-                                                                   flags_ptr(c), c->exp_tab2.as<double>(), c->x_rel64.as<double>());
+                                                                   flags_ptr(c), c->exp_tab2.as<double>());
         } else {
             HGMM_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&full_fused_kernel<2>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -3148,7 +3119,7 @@ static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_hos
             full_fused_kernel<2><<<grid, FT_BLOCK, lds, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
                                                                    c->t_prep.as<double>(), J16, labels, block_q,
                                                                    c->t_partials.as<double>(), want_stats ? 1 : 0,
-                                                                   flags_ptr(c), c->exp_tab2.as<double>(), c->x_rel64.as<double>(), dbg);
+                                                                   flags_ptr(c), c->exp_tab2.as<double>(), dbg);
             if (dbg) {
                 long long h[32];
                 HGMM_HIP(c, hipStreamSynchronize(c->stream));
