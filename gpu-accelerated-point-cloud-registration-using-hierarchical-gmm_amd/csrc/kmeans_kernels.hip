@@ -677,6 +677,16 @@ __global__ __launch_bounds__(KM_BLOCK) void kmeans_accum_lds_kernel(const double
     double* T = km_lds + (size_t)wave * tsz;              // this wave's sums
     double* S = km_lds + (size_t)4 * tsz + wave * 256;    // [64 points][4] staging of the current batch
     for (int e = lane; e < tsz; e += 64) T[e] = 0.0;
+    // Wave-level ordering contract, stated instead of assumed: lanes 0..3 read what OTHER lanes of this wave stored
+    // (the staging tile, the cleared table).  The hardware executes one wave's LDS operations in order, but the
+    // compiler may reorder accesses it cannot prove to alias; a wavefront-scope release / acquire fence pair plus the
+    // (free) wave barrier pins the order in the generated code.
+    auto wave_lds_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    wave_lds_sync();                                      // table cleared before the first ds_add
     const int64_t waves = (int64_t)gridDim.x * 4;
     const int64_t per = ((n + waves - 1) / waves + 63) / 64 * 64;
     const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
@@ -689,7 +699,9 @@ __global__ __launch_bounds__(KM_BLOCK) void kmeans_accum_lds_kernel(const double
         const int64_t ii = ok ? i : 0;
         const int lab = ok ? labels[ii] : 0;
         const double x = xs[ii], y = xs[n_pad + ii], z = xs[2 * n_pad + ii];
+        wave_lds_sync();                                  // the previous batch has been consumed
         S[lane * 4 + 0] = x; S[lane * 4 + 1] = y; S[lane * 4 + 2] = z; S[lane * 4 + 3] = 1.0;
+        wave_lds_sync();                                  // all 64 lanes' stores before lanes 0..3 read them
         const int cnt = (int)(end - base < 64 ? end - base : 64);
         if (lane < 4) {
             int t = 0;

@@ -73,7 +73,10 @@ __device__ __forceinline__ double sym3_quad(double s00, double s01, double s02, 
 //   same word), e^r - 1 = r (1 + r (1/2 + r (1/6 + r (1/24 + r/120)))): degree 5 is enough at that range
 //   (r^6/720 < 6e-19), the result is formed as fma(T, e^r - 1, T) and 2^m goes into the exponent field.
 // 16 VALU instructions per value; the degree-13 polynomial on |r| <= ln2/2 that this replaces took 21.
-// Arguments below -708 are clamped (result < 3.3e-308, i.e. nothing); NaN comes back as garbage-free NaN.
+// Arguments below -708 are clamped (result < 3.3e-308, i.e. nothing).  A NaN argument is NOT propagated: fmin(NaN, 0)
+// is 0, the result is exp(0) = 1 -- a point with a NaN coordinate therefore contributes weight x 1 per node to the
+// sums it takes part in instead of poisoning them with NaN (the reference propagates NaN into every moment of the
+// nodes the point touches; neither result means anything -- callers must not pass non-finite points).
 __device__ const double EXP2_TAB[128] = {
     0x1.0000000000000p+0, 0x1.0163da9fb3335p+0, 0x1.02c9a3e778061p+0, 0x1.04315e86e7f85p+0,
     0x1.059b0d3158574p+0, 0x1.0706b29ddf6dep+0, 0x1.0874518759bc8p+0, 0x1.09e3ecac6f383p+0,
