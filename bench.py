@@ -428,7 +428,8 @@ def materialised_iteration_leg(ctx, lr, inv, mu, w):
     (gmm_impl.py:125-138): log_ll, log_resp = e_step(X, inv_cov, means, weights); weights, means, cov = m_step(X,
     exp(log_resp)); inv_cov = 1 / (sqrt(cov + 1e-6) + eps) ON THE HOST -- every iteration uploads new parameters and
     downloads the M-step's results; the E-step does not wait for its kernel (hgmm_flat_estep_async), the M-step's
-    download is the one synchronisation per iteration."""
+    download is the one synchronisation per iteration.  The loop starts from the fit's initial parameters (two untimed
+    iterations, then eight timed ones): the state a caller's loop is in when it starts."""
     reps = 8
     for timed in (False, True):
         inv_k, mu_k, w_k = inv, mu, w
@@ -641,7 +642,8 @@ def rank_main(args):
         if world > 1:
             out["roofline"]["scope"] = "one launch on rank 0's GPU after the joint fit (the kernel is rank-local)"
     if rank == 0 and world == 1:
-        out["materialised_iteration"] = materialised_iteration_leg(ctx, lr, inv, mu, w)
+        # (from the INITIAL parameters, as a caller's own loop starts: inv_cov0 = 1 / sqrt(cov0), gmm_impl.py:122)
+        out["materialised_iteration"] = materialised_iteration_leg(ctx, lr, (1.0 / np.sqrt(cov0)).astype(np.float32), mu0, w0)
         # what a pure 16-byte store stream of the same size reaches on this chip (write ceiling)
         # (best pure-store pattern found, tools/fillbench.py: one workgroup per CU, grid-stride)
         ctx.util_fill(lr, 0.0, False, 0, 1)
