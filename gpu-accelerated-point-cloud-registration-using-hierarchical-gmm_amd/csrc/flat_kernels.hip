@@ -1368,10 +1368,17 @@ static int flat_setup(hgmm_ctx* c, int cov_type, int variant, int J) {
         HGMM_TRY(ensure(c, c->f_ca, sizeof(int) * (size_t)nchunks * c->n));
         HGMM_TRY(ensure(c, c->f_lpn2, sizeof(float) * (size_t)c->n));
     }
-    HGMM_TRY(ensure(c, c->f_mu, sizeof(float) * 3 * Jpad));
-    HGMM_TRY(ensure(c, c->f_cov, sizeof(float) * 3 * Jpad));
-    HGMM_TRY(ensure(c, c->f_inv, sizeof(float) * 3 * Jpad));
-    HGMM_TRY(ensure(c, c->f_w, sizeof(float) * Jpad));
+    // the four parameter arrays are slices of ONE allocation, [cov | mu | w | inv] with a stride of Jpad per row:
+    // what an E-step call uploads (mu, w, inv) and what an M-step call downloads (cov, mu, w) are each one contiguous
+    // range -- one DMA packet per call instead of three (API-granular calls are a chain of such packets)
+    HGMM_TRY(ensure(c, c->f_block, sizeof(float) * 10 * (size_t)Jpad));
+    {
+        float* blk = c->f_block.as<float>();
+        c->f_cov.p = blk;                  c->f_cov.cap = sizeof(float) * 3 * Jpad;
+        c->f_mu.p = blk + 3 * (size_t)Jpad; c->f_mu.cap = sizeof(float) * 3 * Jpad;
+        c->f_w.p = blk + 6 * (size_t)Jpad;  c->f_w.cap = sizeof(float) * Jpad;
+        c->f_inv.p = blk + 7 * (size_t)Jpad; c->f_inv.cap = sizeof(float) * 3 * Jpad;
+    }
     HGMM_TRY(ensure(c, c->f_pack, sizeof(float) * FLAT_NSTAT * Jpad));
     HGMM_TRY(ensure(c, c->f_hint, sizeof(float) * 3 * Jpad));
     // grid_for() never launches more than min(FLAT_MAX_BLOCKS, 4 workgroups per CU)
@@ -1420,10 +1427,21 @@ static int stage_h2d(hgmm_ctx* c, void* dev, const void* host, size_t bytes) {
 }
 
 static int flat_upload(hgmm_ctx* c, const float* mu, const float* inv_or_cov, bool is_cov, const float* w) {
-    const int J = c->flat.J;
-    HGMM_TRY(stage_h2d(c, c->f_mu.p, mu, sizeof(float) * 3 * J));
-    HGMM_TRY(stage_h2d(c, is_cov ? c->f_cov.p : c->f_inv.p, inv_or_cov, sizeof(float) * cov_elems(c->flat.cov_type, J)));
-    HGMM_TRY(stage_h2d(c, c->f_w.p, w, sizeof(float) * J));
+    const int J = c->flat.J, Jpad = c->flat.Jpad;
+    const size_t ce = cov_elems(c->flat.cov_type, J);
+    // an image of the device block's range [cov | mu | w] (is_cov) or [mu | w | inv] in the pinned ring, ONE copy
+    void* st = nullptr;
+    HGMM_TRY(stage_reserve(c, sizeof(float) * 7 * (size_t)Jpad, &st));
+    float* img = static_cast<float*>(st);
+    float* dev = is_cov ? c->f_cov.as<float>() : c->f_mu.as<float>();
+    float* i_cov = img, *i_mu = img + (is_cov ? 3 * (size_t)Jpad : 0), *i_w = i_mu + 3 * (size_t)Jpad,
+         * i_inv = i_w + Jpad;
+    std::memcpy(i_mu, mu, sizeof(float) * 3 * J);
+    std::memcpy(i_w, w, sizeof(float) * J);
+    std::memcpy(is_cov ? i_cov : i_inv, inv_or_cov, sizeof(float) * ce);
+    // extent actually needed: up to the end of the last array written
+    const size_t used = is_cov ? (size_t)(i_w - img) + J : (size_t)(i_inv - img) + ce;
+    HGMM_HIP(c, hipMemcpyAsync(dev, img, sizeof(float) * used, hipMemcpyHostToDevice, c->stream));
     return HGMM_OK;
 }
 
@@ -1885,18 +1903,19 @@ extern "C" int hgmm_flat_mstep(hgmm_ctx* c, int cov_type, int variant, int J, co
             c->f_ctl.as<int>() + 16, nullptr);
     HGMM_HIP(c, hipGetLastError());
     // results: three DMA packets into the pinned ring, ONE synchronisation, then plain memcpys
+    // results: [cov | mu | w] is one contiguous range of the parameter block: ONE DMA packet into the pinned ring, ONE
+    // synchronisation, then plain memcpys
     const size_t b_mu = sizeof(float) * 3 * J, b_cov = sizeof(float) * cov_elems(cov_type, J), b_w = sizeof(float) * J;
+    const size_t span = sizeof(float) * (6 * (size_t)f.Jpad + J);
     void* st = nullptr;
-    HGMM_TRY(stage_reserve(c, b_mu + b_cov + b_w, &st));
+    HGMM_TRY(stage_reserve(c, span, &st));
     char* h = static_cast<char*>(st);
-    HGMM_HIP(c, hipMemcpyAsync(h, c->f_mu.p, b_mu, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipMemcpyAsync(h + b_mu, c->f_cov.p, b_cov, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipMemcpyAsync(h + b_mu + b_cov, c->f_w.p, b_w, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, hipMemcpyAsync(h, c->f_cov.p, span, hipMemcpyDeviceToHost, c->stream));
     HGMM_HIP(c, hipStreamSynchronize(c->stream));
     c->h_stage_off = 0;                                    // the stream is idle: every region of the ring is free
-    std::memcpy(mu_out, h, b_mu);
-    std::memcpy(cov_out, h + b_mu, b_cov);
-    std::memcpy(w_out, h + b_mu + b_cov, b_w);
+    std::memcpy(cov_out, h, b_cov);
+    std::memcpy(mu_out, h + sizeof(float) * 3 * (size_t)f.Jpad, b_mu);
+    std::memcpy(w_out, h + sizeof(float) * 6 * (size_t)f.Jpad, b_w);
     return HGMM_OK;
 }
 

@@ -357,7 +357,7 @@ extern "C" int hgmm_destroy(hgmm_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     hostcomm_close(c);
-    DevBuf* bufs[] = {&c->x_aos, &c->x_soa64, &c->f_mu, &c->f_cov, &c->f_w, &c->f_inv, &c->f_pack,
+    DevBuf* bufs[] = {&c->x_aos, &c->x_soa64, &c->f_block, &c->f_pack,
                       &c->f_partials, &c->f_lpn_partials, &c->f_stats, &c->f_lls, &c->f_ctl, &c->f_hint,
                       &c->scratch, &c->t_pi, &c->t_mu, &c->t_cov, &c->t_prep, &c->t_cplx, &c->t_mom,
                       &c->t_parent, &c->t_current, &c->t_perm, &c->t_seg, &c->t_chunks, &c->t_partials,

@@ -65,7 +65,8 @@ struct hgmm_ctx {
 
     // ---- flat EM ----------------------------------------------------------------
     hgmm::FlatState flat;
-    hgmm::DevBuf f_mu, f_cov, f_w, f_inv;     // float model parameters (reference layout)
+    hgmm::DevBuf f_block;                     // float [10][Jpad]: the allocation behind the four arrays below
+    hgmm::DevBuf f_mu, f_cov, f_w, f_inv;     // float model parameters (reference layout): NON-OWNING slices of f_block
     hgmm::DevBuf f_pack;                      // float [7][Jpad] packed E-step params
     hgmm::DevBuf f_partials;                  // float [blocks][7][Jpad]
     hgmm::DevBuf f_lpn_partials;              // double [blocks]
