@@ -1529,9 +1529,20 @@ static bool launch_estep_rows(hgmm_ctx* c, int nv4, int nv1, int grid_r, bool cs
 // 0.543 / 0.556 / 0.538 ms against 0.589 / 0.564 / 0.551 for the round-1 shape).  Timing the candidates at first
 // use was tried and dropped: two launches after an idle moment run at other clocks than a stream of them, and picked
 // 176.  Per-row results do not depend on the grid; the mean log-normaliser's summation order does (last bits).
+// Grid of the materialising E-step.  The kernel sits where two limits meet (its header): one wave per SIMD issues one
+// VALU instruction per ~5 cycles whatever its ILP, and the HBM write path delivers less the more waves write at once --
+// so in a stream of E-steps 3/4 of the CUs with one workgroup each is the optimum (0.536 ms; 2 per CU: 0.565).  That
+// optimum is FRAGILE: right behind the HBM-read-bound M-step (the `e_step -> m_step` loop of a caller of the module
+// functions) the same launch takes 0.81 ms -- the chip comes out of a memory-bound kernel at a lower core clock and the
+// issue-bound side of the kernel pays for it -- while two workgroups per CU take 0.60 ms there
+// (tools/em_loop_probe.py, profiles/r03/em_loop_probe.log: 160 / 192 / 224 / 256 / 320 / 384 / 512 workgroups behind an
+// M-step: 0.94 / 0.81 / 0.74 / 0.69 / 0.59 / 0.60 / 0.60 ms; alone: 0.63 / 0.54 / 0.54 / 0.56 / 0.70 / 0.61 / 0.57).
+// The grid therefore follows what the context enqueued last: behind an M-step two workgroups per CU, otherwise 3/4.
 static int estep_rows_grid(hgmm_ctx* c, bool cshift) {
-    const int full = grid_for(c, (c->n + 3) / 4, env_int("HGMM_ESTEP_BPC", 1));
+    const bool after_mstep = c->flat.last_kernel == 2;
+    const int full = grid_for(c, (c->n + 3) / 4, env_int("HGMM_ESTEP_BPC", after_mstep ? 2 : 1));
     if (env_int("HGMM_ESTEP_GRID", 0) > 0) return std::min(full, env_int("HGMM_ESTEP_GRID", 0));
+    if (after_mstep) return full;
     return cshift ? std::min(full, std::max(1, c->cus * 3 / 4)) : full;
 }
 
@@ -1552,6 +1563,7 @@ static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argma
     if (rows > 1) {
         const bool cshift = env_flag("HGMM_ESTEP_CS", true) && !argmax;
         const int grid_r = estep_rows_grid(c, cshift);
+        c->flat.last_kernel = 1;
         ProfScope prof(c, HGMM_K_FLAT_ESTEP);
         if (launch_estep_rows(c, nv4, nv1, grid_r, cshift, log_resp, lpn, argmax)) {
             *grid_out = grid_r;
@@ -1574,6 +1586,7 @@ static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argma
 }
 
 static int launch_fused(hgmm_ctx* c, const int* done_flag, int* grid_out, int* valid_j) {
+    c->flat.last_kernel = 3;
     const FlatState& f = c->flat;
     if (!done_flag) done_flag = c->f_ctl.as<int>() + 16;        // always 0 (flat_setup)
     const int grid = grid_for(c, c->n, env_int("HGMM_FUSED_BPC", 2));
@@ -1891,6 +1904,7 @@ extern "C" int hgmm_flat_mstep(hgmm_ctx* c, int cov_type, int variant, int J, co
 #undef MSTEP_M
     }
     HGMM_HIP(c, hipGetLastError());
+    c->flat.last_kernel = 2;                               // (the next E-step's grid looks at this, estep_rows_grid)
     HGMM_TRY(launch_reduce(c, grid, valid_j, false, nullptr));
     if (f.chunked)
         flat_finalize_mb_kernel<<<(f.Jpad + 255) / 256, 256, 0, c->stream>>>(

@@ -36,6 +36,7 @@ struct FlatState {
     bool active = false;
     bool chunked = false;             // J > FLAT_MAX_J: 832-component chunks
     int nchunks = 1;
+    int last_kernel = 0;              // what this context enqueued last: 1 materialising E-step, 2 M-step from resp, 3 fused EM
 };
 
 struct HostComm;                           // hgmm_api.hip
