@@ -3337,13 +3337,26 @@ __global__ __launch_bounds__(CH) void tree_estep_generic_kernel(const double* __
             const double gq = g[k] * fix_scale;
             const double v[NMOM] = {gq, gq * u0, gq * u1, gq * u2, gq * u0 * u0, gq * u0 * u1, gq * u0 * u2,
                                     gq * u1 * u1, gq * u1 * u2, gq * u2 * u2};
-            unsigned long long* dst = (node < lds_nodes) ? tab + NW * node : momq + NW * node;
+            // (two typed paths instead of one pointer that may name LDS or HBM: the latter compiles to flat-address
+            //  atomics, 320 of them per lane; these are ds_add_u64 resp. global_atomic_add_x2)
+            if (node < lds_nodes) {
+                unsigned long long* dst = tab + NW * node;
 #pragma unroll
-            for (int m = 0; m < NMOM; ++m) {
-                const long long hi = __double2ll_rn(v[m]);
-                const long long lo = __double2ll_rn((v[m] - (double)hi) * 4294967296.0);     // exact remainder x 2^32
-                atomicAdd(dst + 2 * m, (unsigned long long)hi);
-                atomicAdd(dst + 2 * m + 1, (unsigned long long)lo);
+                for (int m = 0; m < NMOM; ++m) {
+                    const long long hi = __double2ll_rn(v[m]);
+                    const long long lo = __double2ll_rn((v[m] - (double)hi) * 4294967296.0);     // exact remainder x 2^32
+                    atomicAdd(dst + 2 * m, (unsigned long long)hi);
+                    atomicAdd(dst + 2 * m + 1, (unsigned long long)lo);
+                }
+            } else {
+                unsigned long long* dst = momq + NW * node;
+#pragma unroll
+                for (int m = 0; m < NMOM; ++m) {
+                    const long long hi = __double2ll_rn(v[m]);
+                    const long long lo = __double2ll_rn((v[m] - (double)hi) * 4294967296.0);
+                    atomicAdd(dst + 2 * m, (unsigned long long)hi);
+                    atomicAdd(dst + 2 * m + 1, (unsigned long long)lo);
+                }
             }
         }
     }
