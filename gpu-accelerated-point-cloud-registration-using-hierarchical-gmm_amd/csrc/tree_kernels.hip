@@ -893,177 +893,6 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
     store_block_q(t, block_q, (int)gridDim.x, ticket, q_out, stop);
 }
 
-// Level log-likelihood for SMALL clouds (fewer 512-point blocks than CUs: C4's 40 256 points are 79).  There the
-// kernel above is a single wave per SIMD walking the level's nodes one after the other -- its time is that wave's
-// serial chain (64 nodes at level 1: 15 us), whatever the chip could do in parallel.  Here a workgroup takes only 64
-// points and its four waves split the NODES: every wave holds the same 64 points (one per lane) and evaluates every
-// fourth entry of the compacted node tile, four entries at a time (one interleaved exp for the four); the four
-// partial sums of a point are added in wave order.  629 workgroups instead of 79 at C4 (2-3 waves per SIMD), a
-// quarter of the serial work per wave, a bounding box of 64 instead of 512 points for the reach test, and no split
-// of the level's nodes over gridDim.y -- hence no partial-sum buffer and no finish pass at levels 2 and 3.
-constexpr int LLS_PTS = 64;
-constexpr int LLS_PF = 4;                 // node tiles whose parameters are requested together
-// The kernel is a chain of memory round trips (~1.5 us each on this chip), not arithmetic, so they are taken side by
-// side wherever the addresses allow it: the stop flag, the points and the first four tiles' node parameters are all
-// requested before anything is waited for; the level's nodes are walked four 256-node tiles per round trip; and the
-// workgroup's share of q is a plain store -- a one-workgroup kernel behind this one (tree_qsum_kernel) adds the shares
-// and applies the stop rule (an arrival counter costs two more dependent trips per workgroup: measured 14-15 us for an
-// 8-node level with it, whether the counters were one, 65 adjacent or 65 spread over 260 KB).
-__global__ __launch_bounds__(CH) void tree_loglik_small_kernel(const double* __restrict__ xs, int64_t n, int64_t n_pad,
-                                                               const double* __restrict__ prep, int64_t lb,
-                                                               int n_level_nodes, double* __restrict__ block_q,
-                                                               const int* __restrict__ done,
-                                                               const int* __restrict__ flags,
-                                                               unsigned long long* __restrict__ pair_count) {
-    __shared__ double tile[LL_TILE + 16][10];              // (+16: the tile is padded with weightless entries to 16 k)
-    __shared__ double exp_tab[EXP_TAB_N];
-    __shared__ double tot_sh[CH / 64][LLS_PTS];
-    __shared__ int wcnt[CH / 64];
-    const int w = wave_in_block(), lane = lane_id();
-    const int64_t i_first = (int64_t)blockIdx.x * LLS_PTS;
-    const int64_t i = i_first + lane;
-    const bool active = i < n;
-    const int64_t i_ld = active ? i : i_first;             // (i_first < n: grid = ceil(n / 64))
-    // ---- everything whose address is known up front, requested together ----
-    const int stop_flag = done ? *done : 0;
-    const int fl = flags ? *flags : 0;
-    const double c0 = xs[i_first], c1 = xs[n_pad + i_first], c2 = xs[2 * n_pad + i_first];
-    const double p0 = xs[i_ld], p1 = xs[n_pad + i_ld], p2 = xs[2 * n_pad + i_ld];
-    double nd[LLS_PF][11];                                 // wL, kappa, mu[3], six form entries of this thread's nodes
-    auto request = [&](int base4, bool chol) {
-#pragma unroll
-        for (int t = 0; t < LLS_PF; ++t) {
-            int node = base4 + t * LL_TILE + (int)threadIdx.x;
-            node = node < n_level_nodes ? node : n_level_nodes - 1;          // (clamped, not branched on)
-            const double* pr = prep + PREP_N * (lb + node);
-            const int fo = chol ? PREP_R : 0;
-            nd[t][0] = pr[10]; nd[t][1] = pr[PREP_KAPPA]; nd[t][2] = pr[6]; nd[t][3] = pr[7]; nd[t][4] = pr[8];
-#pragma unroll
-            for (int e = 0; e < 6; ++e) nd[t][5 + e] = pr[fo + e];
-        }
-    };
-    // (the form is not known before `fl` is back: the first request asks for the triangular entries, the common case, and
-    //  is repeated in the symmetric form if the flag says so)
-    request(0, true);
-    exp_tab_load(exp_tab);
-    if (stop_flag) return;
-    const bool use_chol = !(fl & 1);                       // kernel-uniform
-    if (!use_chol) request(0, false);
-    const double x0 = p0 - c0, x1 = p1 - c1, x2 = p2 - c2;  // inactive lanes sit on the origin (i_ld = i_first)
-    // bounding box of the 64 points (every wave forms the same one: no exchange needed)
-    const double lo0 = -wave_max_f64(-x0), lo1 = -wave_max_f64(-x1), lo2 = -wave_max_f64(-x2);
-    const double hi0 = wave_max_f64(x0), hi1 = wave_max_f64(x1), hi2 = wave_max_f64(x2);
-    double tot = 0.0;
-    int entered = 0;
-    for (int base4 = 0; base4 < n_level_nodes; base4 += LLS_PF * LL_TILE) {
-        if (base4 > 0) request(base4, use_chol);
-#pragma unroll
-        for (int t = 0; t < LLS_PF; ++t) {
-            const int base = base4 + t * LL_TILE;
-            if (base >= n_level_nodes) break;               // workgroup-uniform
-            const int node = base + (int)threadIdx.x;
-            bool live = false;
-            double v[10];
-#pragma unroll
-            for (int e = 0; e < 10; ++e) v[e] = 0.0;
-            if (node < n_level_nodes && nd[t][0] != 0.0) {
-                const double m0 = nd[t][2] - c0, m1 = nd[t][3] - c1, m2 = nd[t][4] - c2;
-                const double g0 = fmax(fmax(lo0 - m0, m0 - hi0), 0.0), g1 = fmax(fmax(lo1 - m1, m1 - hi1), 0.0),
-                             g2 = fmax(fmax(lo2 - m2, m2 - hi2), 0.0);
-                live = !(nd[t][1] * (g0 * g0 + g1 * g1 + g2 * g2) > LL_CULL);
-                if (live) {
-                    const double f0 = nd[t][5], f1 = nd[t][6], f2 = nd[t][7], f3 = nd[t][8], f4 = nd[t][9], f5 = nd[t][10];
-                    if (use_chol) {
-                        v[0] = f0; v[1] = f1; v[2] = f2; v[3] = f3; v[4] = f4; v[5] = f5;
-                        v[6] = -fma(f2, m2, fma(f1, m1, f0 * m0));
-                        v[7] = -fma(f4, m2, f3 * m1);
-                        v[8] = -(f5 * m2);
-                    } else {
-                        v[0] = -0.5 * f0; v[1] = -0.5 * f1; v[2] = -0.5 * f2; v[3] = -0.5 * f3; v[4] = -0.5 * f4; v[5] = -0.5 * f5;
-                        v[6] = m0; v[7] = m1; v[8] = m2;
-                    }
-                    v[9] = nd[t][0];
-                }
-            }
-            const unsigned long long mask = __ballot(live);
-            const int before = __popcll(mask & ((1ull << lane) - 1ull));
-            if (lane == 0) wcnt[w] = __popcll(mask);
-            __syncthreads();                               // also: every wave is done with the previous tile (and exp_tab is in)
-            int off = 0, cnt = 0;
-#pragma unroll
-            for (int ww = 0; ww < CH / 64; ++ww) {
-                const int c = wcnt[ww];
-                if (ww < w) off += c;
-                cnt += c;
-            }
-            if (live) {
-                double* dst = tile[off + before];
-#pragma unroll
-                for (int e = 0; e < 10; ++e) dst[e] = v[e];
-            }
-            const int cnt16 = (cnt + 15) & ~15;
-            if ((int)threadIdx.x < (cnt16 - cnt) * 10) (&tile[cnt][0])[threadIdx.x] = 0.0;      // weightless padding
-            __syncthreads();
-            entered += cnt;
-            for (int k0 = w; k0 < cnt16; k0 += 16) {       // this wave's entries k0, k0 + 4, k0 + 8, k0 + 12
-                double yv[4], wl[4];
-                bool need = false;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const double* te = tile[k0 + 4 * q];
-                    wl[q] = te[9];
-                    if (use_chol) {
-                        const double z0 = fma(te[2], x2, fma(te[1], x1, fma(te[0], x0, te[6])));
-                        const double z1 = fma(te[4], x2, fma(te[3], x1, te[7]));
-                        const double z2 = fma(te[5], x2, te[8]);
-                        yv[q] = -fma(z2, z2, fma(z1, z1, z0 * z0));
-                    } else {
-                        yv[q] = sym3_quad(te[0], te[1], te[2], te[3], te[4], te[5], x0 - te[6], x1 - te[7], x2 - te[8]);
-                    }
-                    need = need || (wl[q] != 0.0 && yv[q] > LL_SKIP);
-                }
-                if (__any(need)) {
-                    double e[4];
-                    exp_nonpos4(yv, e, exp_tab);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) tot = fma(wl[q], e[q], tot);
-                }
-            }
-        }
-    }
-    if (pair_count && threadIdx.x == 0) {
-        const int64_t rest = n - i_first;
-        atomicAdd(pair_count, (unsigned long long)((rest < LLS_PTS ? rest : (int64_t)LLS_PTS) * entered));
-    }
-    tot_sh[w][lane] = tot;
-    __syncthreads();
-    if (w == 0) {
-        const double all = ((tot_sh[0][lane] + tot_sh[1][lane]) + tot_sh[2][lane]) + tot_sh[3][lane];
-        const double lq = active ? log(fmax(all, TREE_EPS)) : 0.0;
-        const double t = wave_sum_f64(lq);
-        if (lane == 0) block_q[blockIdx.x] = t;
-    }
-}
-
-// q = the sum of the workgroups' shares (fixed order) + the level's stop rule; one workgroup
-__global__ __launch_bounds__(CH) void tree_qsum_kernel(const double* __restrict__ block_q, int nb,
-                                                       double* __restrict__ q_out, const int* __restrict__ done,
-                                                       TreeStop stop) {
-    __shared__ double sh_fin[4];
-    const int stop_flag = done ? *done : 0;
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < nb; i += CH) acc += block_q[i];      // (requested before the flag is looked at)
-    if (stop_flag) return;
-    acc = wave_sum_f64(acc);
-    if (lane_id() == 0) sh_fin[wave_in_block()] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double q = sh_fin[0] + sh_fin[1] + sh_fin[2] + sh_fin[3];
-        *q_out = q;
-        if (stop.ctl) tree_ctl_update(q, stop);
-    }
-}
-
 __global__ __launch_bounds__(CH) void tree_loglik_finish_kernel(const double* __restrict__ partial, int64_t n,
                                                                 int64_t n_pad, int n_chunks,
                                                                 double* __restrict__ block_q,
@@ -1612,7 +1441,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     HGMM_TRY(ensure(c, c->t_seg, sizeof(int) * (2 * (8 * maxP + 2) + 2 * (maxP + 2) + 8)));
     HGMM_TRY(ensure(c, c->t_chunks, sizeof(int) * (size_t)(3 + 8 + 8) * max_chunks));
     HGMM_TRY(ensure(c, c->t_partials, sizeof(double) * (size_t)8 * NMOM * max_chunks));
-    HGMM_TRY(ensure(c, c->t_q, sizeof(double) * (nblk(n, LLS_PTS) + 8)));
+    HGMM_TRY(ensure(c, c->t_q, sizeof(double) * (nblk(n, CH) + 8)));
 
     double* d_pi = c->t_pi.as<double>();
     double* d_mu = c->t_mu.as<double>();
@@ -1634,7 +1463,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     int* chunk_off = hist + 8 * max_chunks;
     double* partials = c->t_partials.as<double>();
     double* block_q = c->t_q.as<double>();
-    double* q_dev = block_q + nblk(n, LLS_PTS);
+    double* q_dev = block_q + nblk(n, CH);
     unsigned int* q_ticket = tickets_ptr(c);                  // (zeroed by tree_alloc_nodes -> tree_flags; every launch leaves them zero)
     TreeCtl* ctl = reinterpret_cast<TreeCtl*>(q_dev + 2);
     const int trace_cap = std::min(max_iters_per_level, 1 << 20);
@@ -1646,13 +1475,11 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     //  these launches are chains of memory round trips, not arithmetic)
     int ll_pts = n >= 400000 ? 4 : 2;
     if (const char* e = std::getenv("HGMM_TREE_LL_PTS")) ll_pts = atoi(e) >= 4 ? 4 : (atoi(e) >= 2 ? 2 : 1);
-    // The 64-point / node-split form of the log-likelihood (tree_loglik_small_kernel) is OPT-IN (HGMM_TREE_LL_SMALL=1):
-    // measured on C4 it loses at every level -- 16.9 / 17.7 / 20.2 / 49 us per iteration (kernel + its sum kernel)
-    // against 8.9 / 14.8 / 19.1 / 22.4 for the 512-point form (+ finish pass): eight times as many workgroups each read
-    // the level's whole node table for the reach test (629 x 360 KB at level 3).  Kept for the record and the tests.
-    bool ll_small = false;
-    if (const char* e = std::getenv("HGMM_TREE_LL_SMALL")) ll_small = e[0] == '1';
-    if (ll_pts == 4 && !ll_small) HGMM_TRY(ensure_exp_tab2(c));
+    // (a 64-point / node-split form of the log-likelihood for small clouds -- four waves of a workgroup sharing 64 points and
+    //  splitting the nodes, no finish pass -- was built and measured in round 3 and lost at every C4 level: 16.9 / 17.7 /
+    //  20.2 / 49 us per iteration against 8.9 / 14.8 / 19.1 / 22.4 for this form: eight times as many workgroups each read
+    //  the level's whole node table for the reach test; removed again, commit 7d926ef)
+    if (ll_pts == 4) HGMM_TRY(ensure_exp_tab2(c));
     int batch_iters = 8;                      // iterations enqueued per host synchronisation (1/2/4/8/16: 6.8/6.3/5.6/5.1/5.3 ms @C4)
     if (const char* e = std::getenv("HGMM_TREE_BATCH")) batch_iters = std::max(1, std::min(64, atoi(e)));
 
@@ -1697,7 +1524,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
         const int pblocks = (int)nblk(n, CH);
         const int llblocks = (int)nblk(n, CH * ll_pts);        // log-likelihood grid: ll_pts points per thread
         int chunks = 1;
-        if (!ll_small && llblocks < 2 * c->cus && n_level > LL_TILE) {     // (N = 1e6: 977 workgroups are plenty -- no split, no finish pass)
+        if (llblocks < 2 * c->cus && n_level > LL_TILE) {     // (N = 1e6: 977 workgroups are plenty -- no split, no finish pass)
             chunks = (4 * c->cus + llblocks - 1) / llblocks;
             const int max_chunks_l = (n_level + LL_TILE - 1) / LL_TILE;
             if (chunks > max_chunks_l) chunks = max_chunks_l;
@@ -1758,11 +1585,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     tree_loglik_kernel<PTS><<<dim3(llblocks, chunks), CH, 0, c->stream>>>(                                 \
         xs_cur, n, n_pad, d_prep, lb, n_level, per_chunk, ll_partial, block_q, q_ticket, q_dev, &ctl->done, \
         chunks > 1 ? no_stop : stop, flags_ptr(c), pairs_ptr(c))
-                    if (ll_small) {
-                        tree_loglik_small_kernel<<<nblk(n, LLS_PTS), CH, 0, c->stream>>>(
-                            xs_cur, n, n_pad, d_prep, lb, n_level, block_q, &ctl->done, flags_ptr(c), pairs_ptr(c));
-                        tree_qsum_kernel<<<1, CH, 0, c->stream>>>(block_q, (int)nblk(n, LLS_PTS), q_dev, &ctl->done, stop);
-                    } else if (ll_pts == 4)
+                    if (ll_pts == 4)
                         tree_loglik_kernel<4, true><<<dim3(llblocks, chunks), CH, 0, c->stream>>>(
                             xs_cur, n, n_pad, d_prep, lb, n_level, per_chunk, ll_partial, block_q, q_ticket, q_dev, &ctl->done,
                             chunks > 1 ? no_stop : stop, flags_ptr(c), pairs_ptr(c), c->exp_tab2.as<double>());
@@ -2725,285 +2548,6 @@ __global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
         full_fused_body<CPL, true>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds, exp2_tab);
 }
 
-// ------------------------------------------------------------------------------------------
-// The same one-pass E-step with SIXTEEN waves per workgroup (1024 threads, one component per lane).
-// The 8-wave kernel above sits at 58 % of the issue floor of its own formulation because two waves per SIMD in lock-step
-// cannot cover each other's LDS round trips (profiles/r03/fullcov_accounting.md).  The tile of g values allows one
-// workgroup per CU whatever its size -- so the workgroup is made larger: four waves per SIMD, each lane ONE component
-// (its 10 parameters in 20 registers instead of 40), 3-4 instead of 6-7 accumulator tiles per wave, the kernel inside the
-// 128 registers that 16 waves per CU leave to a wave.  Same LDS layout, same phases, same arithmetic per pair:
-//   A  wave w < wf = J16 / 64: components 64 w + lane, 16 points (four staged 4-evaluation steps); a tail of <= 32
-//      components is dealt over the waves behind the full ones exactly as in the 8-wave kernel (J = 800: waves 12-15,
-//      two points per lane); every SIMD (waves w, w + 4, w + 8, w + 12) carries 50 of the tile's 200 wave-evaluations
-//   B  wave w = point w (a full wave per row: 2 values per lane and 128-column step)
-//   C  wave w = 16-component tiles w, w + 16, w + 32, w + 48
-// ------------------------------------------------------------------------------------------
-constexpr int F16_WAVES = 16;
-constexpr int F16_BLOCK = F16_WAVES * 64;
-template <bool CHOL>
-__device__ __forceinline__ void full_fused16_body(
-    const double* __restrict__ xs, int64_t n, int64_t n_pad, const double* __restrict__ prep, int J16,
-    int* __restrict__ label_out, double* __restrict__ block_q, double* __restrict__ partials /*[grid][J16][NMOM]*/,
-    int want_stats, long long* __restrict__ dbg, double* lds, const double* __restrict__ exp2_tab) {
-    long long tA = 0, tB = 0, tC = 0, tW = 0, tm = 0;
-#define FT_TICK(acc) do { if (dbg) { const long long now_ = clock64(); acc += now_ - tm; tm = now_; } } while (0)
-    const int LDG = ft_ldg(J16);
-    double* G = lds;                              // [FT_P][LDG]
-    double* F = G + (size_t)FT_P * LDG;           // [16 features][FT_LDF]
-    double* INV = F + 16 * FT_LDF;                // [FT_P]
-    double* TOT = INV + FT_P;                     // [2][FT_P]
-    double* WL = TOT + 2 * FT_P;                  // [J16]
-    double* XS = WL + J16;                        // [2][3][FT_P] relative to the origin
-    double* XA = XS + 2 * 3 * FT_P;               // [2][3][FT_P] as given
-    double* EXPT = XA + 2 * 3 * FT_P;             // [2048]
-    const int w = wave_in_block(), lane = lane_id();
-    const int tid = (int)threadIdx.x;
-    exp_tab2_load(EXPT, exp2_tab);
-
-    const int wf = J16 / 64, rem = J16 % 64;
-    const bool tail_exists = rem > 0 && rem <= 32;
-    const int free_w = F16_WAVES - wf;
-    const int nw = tail_exists ? (free_w >= 8 ? 8 : (free_w >= 4 ? 4 : (free_w >= 2 ? 2 : 1))) : 0;
-    const bool tail_wave = tail_exists && w >= wf && w < wf + nw;        // wave-uniform
-    const int tail_pts = tail_exists ? FT_P / (2 * nw) : 0;              // points per half-wave: 8, 4, 2 or 1
-    const int tail_p0 = tail_wave ? (w - wf) * 2 * tail_pts + (lane >> 5) * tail_pts : 0;
-    const int jc = tail_wave ? 64 * wf + (lane & 31) : tid;              // this lane's component (>= J16: none)
-    const bool has = jc < J16;
-    const double o0 = xs[0], o1 = xs[n_pad], o2 = xs[2 * n_pad];
-    double s00 = 0.0, s01 = 0.0, s02 = 0.0, s11 = 0.0, s12 = 0.0, s22 = 0.0, m0 = 0.0, m1 = 0.0, m2 = 0.0, wE = 0.0;
-    if (has) {
-        const double* pr = prep + PREP_N * jc;
-        const double u0 = pr[6] - o0, u1 = pr[7] - o1, u2 = pr[8] - o2;
-        if (CHOL) {
-            s00 = pr[PREP_R]; s01 = pr[PREP_R + 1]; s02 = pr[PREP_R + 2];
-            s11 = pr[PREP_R + 3]; s12 = pr[PREP_R + 4]; s22 = pr[PREP_R + 5];
-            m0 = -fma(s02, u2, fma(s01, u1, s00 * u0));
-            m1 = -fma(s12, u2, s11 * u1);
-            m2 = -(s22 * u2);
-        } else {
-            s00 = -0.5 * pr[0]; s01 = -0.5 * pr[1]; s02 = -0.5 * pr[2];
-            s11 = -0.5 * pr[3]; s12 = -0.5 * pr[4]; s22 = -0.5 * pr[5];
-            m0 = u0; m1 = u1; m2 = u2;
-        }
-        wE = pr[9];
-    }
-    int my_small = 0;
-    for (int j = tid; j < J16; j += F16_BLOCK) {
-        const double wl = prep[PREP_N * j + 10], we = prep[PREP_N * j + 9];
-        WL[j] = (wl != 0.0) ? 1.0 : 0.0;
-        if (wl == 0.0 && we != 0.0) my_small = 1;
-    }
-    for (int e = tid; e < FT_P * LDG; e += F16_BLOCK) G[e] = 0.0;
-    const bool any_small = __syncthreads_or(my_small) != 0;
-    const int ntiles = J16 / 16;
-    constexpr int MAXT = FT_MAX_J16 / 16 / F16_WAVES;                     // 4
-    double acc[MAXT][3];
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) acc[t][0] = acc[t][1] = acc[t][2] = 0.0;
-    const int a_idx = lane & 15, b_idx = lane >> 4;
-
-    const int64_t tiles = (n + FT_P - 1) / FT_P;
-    const int64_t per = (tiles + gridDim.x - 1) / gridDim.x;
-    const int64_t t0 = (int64_t)blockIdx.x * per;
-    const int64_t t1 = (t0 + per < tiles) ? t0 + per : tiles;
-    constexpr int LQ_WAVE = F16_WAVES - 1;       // the last wave never has a full block of components: room for the logs
-    double lq = 0.0;
-
-    const int st_d = tid / FT_P, st_p = tid % FT_P;
-    const double st_o = (tid < 3 * FT_P) ? xs[(size_t)st_d * n_pad] : 0.0;
-    auto stage = [&](int64_t tile, int buf) {
-        if (tid < 3 * FT_P) {
-            int64_t i = tile * FT_P + st_p;
-            i = i < n ? i : n - 1;
-            const double v = xs[(size_t)st_d * n_pad + i];
-            XA[(buf * 3 + st_d) * FT_P + st_p] = v;
-            XS[(buf * 3 + st_d) * FT_P + st_p] = v - st_o;
-        }
-    };
-    auto tile_loglik = [&](int par) {
-        const double tv = (lane < FT_P) ? TOT[par * FT_P + lane] : -1.0;
-        double term = (tv >= 0.0) ? log(fmax(tv, TREE_EPS)) : 0.0;
-        term = wave_sum_f64(term);
-        lq += term;
-    };
-    if (t0 < t1) stage(t0, 0);
-    __syncthreads();
-    for (int64_t tile = t0; tile < t1; ++tile) {
-        const int64_t base = tile * FT_P;
-        const int buf = (int)((tile - t0) & 1);
-        const double* X = XS + buf * 3 * FT_P;
-        if (dbg) tm = clock64();
-        if (w == LQ_WAVE && tile > t0) tile_loglik(buf ^ 1);
-        // ---- phase A ----
-        auto expo = [&](int pt) -> double {
-            const double a0 = X[pt], a1 = X[FT_P + pt], a2 = X[2 * FT_P + pt];
-            if (CHOL) {
-                const double z0 = fma(s02, a2, fma(s01, a1, fma(s00, a0, m0)));
-                const double z1 = fma(s12, a2, fma(s11, a1, m1));
-                const double z2 = fma(s22, a2, m2);
-                return -fma(z2, z2, fma(z1, z1, z0 * z0));
-            }
-            return sym3_quad(s00, s01, s02, s11, s12, s22, a0 - m0, a1 - m1, a2 - m2);
-        };
-        auto eval4 = [&](int pa, int pb, int pc, int pd, int distinct) {
-            ExpHead hd[4];
-            const int pt[4] = {pa, pb, pc, pd};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) hd[k] = exp_t11_head<CHOL>(expo(pt[k]), EXPT);
-            double pp[4];
-            exp_t11_poly4(hd[0].r, hd[1].r, hd[2].r, hd[3].r, pp);
-            if (has) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (k < distinct) G[(size_t)pt[k] * LDG + jc] = wE * exp_t11_tail(hd[k], pp[k]);
-            }
-        };
-        if (tail_wave) {                                                   // (tail_pts is workgroup-uniform)
-            if (tail_pts >= 4) {
-                for (int q0 = 0; q0 < tail_pts; q0 += 4) eval4(tail_p0 + q0, tail_p0 + q0 + 1, tail_p0 + q0 + 2, tail_p0 + q0 + 3, 4);
-            } else if (tail_pts == 2) {
-                eval4(tail_p0, tail_p0 + 1, tail_p0 + 1, tail_p0 + 1, 2);
-            } else {
-                eval4(tail_p0, tail_p0, tail_p0, tail_p0, 1);
-            }
-        } else if (w * 64 < J16) {                                         // a wave with (some) first components
-#pragma unroll 1
-            for (int q0 = 0; q0 < FT_P; q0 += 4) eval4(q0, q0 + 1, q0 + 2, q0 + 3, 4);
-        }
-        if (tile + 1 < t1) stage(tile + 1, buf ^ 1);
-        FT_TICK(tA);
-        __syncthreads();
-        FT_TICK(tW);
-        // ---- phase B: wave w = point w ----
-        {
-            const int p = w;
-            const double* Gp = G + (size_t)p * LDG;
-            const int J128 = (J16 + 127) & ~127;                       // the row is zero beyond J16
-            double den = 0.0, tot = 0.0, best = -1.0;
-            int jbest = 0;
-            for (int jb = 0; jb < J128; jb += 256) {                   // two 128-column steps at a time, loads first
-                const bool two = jb + 128 < J128;                      // workgroup-uniform
-                const double g0 = Gp[jb + lane], g1 = Gp[jb + 64 + lane];
-                const double g2 = two ? Gp[jb + 128 + lane] : 0.0, g3 = two ? Gp[jb + 192 + lane] : 0.0;
-                const double ma = fmax(g0, g1), mb = fmax(g2, g3);
-                den += (g0 + g1) + (g2 + g3);
-                jbest = (ma > best) ? jb : jbest;
-                best = fmax(best, ma);
-                jbest = (mb > best) ? jb + 128 : jbest;
-                best = fmax(best, mb);
-                if (any_small) {
-                    const int j0 = jb + lane;
-                    tot = fma(g0, (j0 < J16) ? WL[j0] : 0.0, tot);
-                    tot = fma(g1, (j0 + 64 < J16) ? WL[j0 + 64] : 0.0, tot);
-                    tot = fma(g2, (j0 + 128 < J16) ? WL[j0 + 128] : 0.0, tot);
-                    tot = fma(g3, (j0 + 192 < J16) ? WL[j0 + 192] : 0.0, tot);
-                }
-            }
-            // the lane's first column holding its maximum: the first of the step's two values equal to it
-            const int am = jbest + lane + ((Gp[jbest + lane] == best) ? 0 : 64);
-            const double den_w = wave_sum_f64(den);
-            const double bm_w = wave_max_f64(best);
-            const int am_w = wave_reduce_i((best == bm_w) ? am : 0x7fffffff, OpMinI());
-            const double tot_w = any_small ? wave_sum_f64(tot) : den_w;
-            const double inv = 1.0 / den_w;
-            if (lane == 0) {
-                const bool live = base + p < n;
-                const bool good = den_w > TREE_EPS;
-                INV[p] = (live && good) ? inv : 0.0;
-                TOT[buf * FT_P + p] = live ? tot_w : -1.0;
-                if (live) label_out[base + p] = good ? am_w : 0;
-            }
-            if (lane < 16) {
-                const double* A = XA + buf * 3 * FT_P;
-                const double x0 = A[p], x1 = A[FT_P + p], x2 = A[2 * FT_P + p];
-                double f = 0.0;
-                switch (lane) {
-                    case 0: f = 1.0; break;
-                    case 1: f = x0; break;
-                    case 2: f = x1; break;
-                    case 3: f = x2; break;
-                    case 4: f = x0 * x0; break;
-                    case 5: f = x0 * x1; break;
-                    case 6: f = x0 * x2; break;
-                    case 7: f = x1 * x1; break;
-                    case 8: f = x1 * x2; break;
-                    case 9: f = x2 * x2; break;
-                    default: f = 0.0;
-                }
-                F[lane * FT_LDF + p] = f;
-            }
-        }
-        FT_TICK(tB);
-        __syncthreads();
-        FT_TICK(tW);
-        // ---- phase C: wave w = component tiles w, w + 16, ... ----
-        // (four points at a time in the OUTER loop: one set of feature fragments -- 3 doubles -- is live instead of 12;
-        //  the next four points' A operands are requested before the current ones are consumed)
-        if (want_stats) {
-            double araw[2][MAXT];
-            auto load_a = [&](int s, double (&dst)[MAXT]) {
-#pragma unroll
-                for (int t = 0; t < MAXT; ++t) {
-                    const int ct = w + t * F16_WAVES;
-                    dst[t] = (ct < ntiles) ? G[(size_t)(4 * s + b_idx) * LDG + 16 * ct + a_idx] : 0.0;
-                }
-            };
-            load_a(0, araw[0]);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (s + 1 < 4) load_a(s + 1, araw[(s + 1) & 1]);
-                const double inv_s = INV[4 * s + b_idx];
-                const double b0 = F[(lane & 3) * FT_LDF + 4 * s + b_idx], b1 = F[(4 + (lane & 3)) * FT_LDF + 4 * s + b_idx],
-                             b2 = F[(8 + (lane & 3)) * FT_LDF + 4 * s + b_idx];
-#pragma unroll
-                for (int t = 0; t < MAXT; ++t) {
-                    const int ct = w + t * F16_WAVES;                      // wave-uniform
-                    if (ct < ntiles) {
-                        double a = araw[s & 1][t] * inv_s;
-                        if (a < TREE_EPS) a = 0.0;
-                        acc[t][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b0, acc[t][0], 0, 0, 0);
-                        acc[t][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b1, acc[t][1], 0, 0, 0);
-                        acc[t][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b2, acc[t][2], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        FT_TICK(tC);
-        __syncthreads();
-        FT_TICK(tW);
-    }
-    if (w == LQ_WAVE && t0 < t1) tile_loglik((int)((t1 - 1 - t0) & 1));
-    if (dbg && lane == 0 && blockIdx.x == 7) {
-        dbg[w * 4 + 0] = tA; dbg[w * 4 + 1] = tB; dbg[w * 4 + 2] = tC; dbg[w * 4 + 3] = tW;
-    }
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-        const int ct = w + t * F16_WAVES;
-        if (ct < ntiles) {
-            const int comp = 16 * ct + 4 * ((lane >> 2) & 3) + (lane >> 4);
-#pragma unroll
-            for (int fb = 0; fb < 3; ++fb) {
-                const int feat = 4 * fb + (lane & 3);
-                if (feat < NMOM) partials[((size_t)blockIdx.x * J16 + comp) * NMOM + feat] = acc[t][fb];
-            }
-        }
-    }
-    if (w == LQ_WAVE && lane == 0) block_q[blockIdx.x] = lq;
-#undef FT_TICK
-}
-
-__global__ __launch_bounds__(F16_BLOCK) void full_fused16_kernel(
-    const double* __restrict__ xs, int64_t n, int64_t n_pad, const double* __restrict__ prep, int J16,
-    int* __restrict__ label_out, double* __restrict__ block_q, double* __restrict__ partials /*[grid][J16][NMOM]*/,
-    int want_stats, const int* __restrict__ flags, const double* __restrict__ exp2_tab,
-    long long* __restrict__ dbg = nullptr) {
-    extern __shared__ double lds[];
-    if (flags && (*flags & 1))
-        full_fused16_body<false>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds, exp2_tab);
-    else
-        full_fused16_body<true>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds, exp2_tab);
-}
-
 // one wave per component: fixed-order sum over the workgroups' partials
 __global__ __launch_bounds__(64) void full_reduce_kernel(const double* __restrict__ partials, int nblocks,
                                                          int J, int J16, double* __restrict__ mom) {
@@ -3083,31 +2627,12 @@ static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_hos
     double* q_dev = block_q + nblk(c->n, CH) + c->cus;
     const size_t lds = ft_lds_bytes(J16);
     HGMM_TRY(ensure_exp_tab2(c));
-    // The 16-wave form (full_fused16_kernel) is OPT-IN (HGMM_FULLCOV_WAVES=16): measured at C3 it is slower than the
-    // 8-wave kernel, 1.83 vs 1.76 ms -- phase A takes the same ~6.9 k cycles per tile with four waves per SIMD as with two
-    // (so it is not waiting on LDS round trips that more waves could cover), and the 128-register budget costs 16 spills.
-    bool waves16 = false;
-    if (const char* e = std::getenv("HGMM_FULLCOV_WAVES")) waves16 = atoi(e) == 16;
+    // (a 16-wave form of this kernel -- 1024 threads, one component per lane, 128 registers -- was built and measured in
+    //  round 3: 1.83 vs 1.76 ms, phase A no shorter with four waves per SIMD than with two; removed again, commit b7f6218,
+    //  profiles/r03/fullcov_accounting.md)
     {
         ProfScope prof(c, HGMM_K_FULL_FUSED);
-        if (waves16) {
-            HGMM_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&full_fused16_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            long long* dbg = nullptr;
-            if (std::getenv("HGMM_FT_DEBUG")) { HGMM_HIP(c, hipMalloc(&dbg, 16 * 4 * 8)); }
-            full_fused16_kernel<<<grid, F16_BLOCK, lds, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
-                                                                    c->t_prep.as<double>(), J16, labels, block_q,
-                                                                    c->t_partials.as<double>(), want_stats ? 1 : 0,
-                                                                    flags_ptr(c), c->exp_tab2.as<double>(), dbg);
-            if (dbg) {
-                long long h[64];
-                HGMM_HIP(c, hipStreamSynchronize(c->stream));
-                HGMM_HIP(c, hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost));
-                for (int w = 0; w < 16; ++w)
-                    fprintf(stderr, "wave %d: A %lld  B %lld  C %lld  wait %lld cycles\n", w, h[4 * w], h[4 * w + 1], h[4 * w + 2], h[4 * w + 3]);
-                (void)hipFree(dbg);
-            }
-        } else if (J16 <= FT_BLOCK) {
+        if (J16 <= FT_BLOCK) {
             HGMM_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&full_fused_kernel<1>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             full_fused_kernel<1><<<grid, FT_BLOCK, lds, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,

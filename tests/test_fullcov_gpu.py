@@ -64,25 +64,6 @@ def test_fullcov_component_layouts_vs_oracle(ctx, bunny, J):
     np.testing.assert_allclose(cov, o_cov, rtol=1e-6, atol=1e-14)
 
 
-@pytest.mark.parametrize("J", [100, 800, 990])
-def test_fullcov_sixteen_wave_kernel_matches(ctx, bunny, monkeypatch, J):
-    """The 16-wave form of the one-pass kernel (HGMM_FULLCOV_WAVES=16, opt-in: measured slower than the default 8-wave
-    form) on the same inputs: same iteration trace and hard assignments as the oracle, statistics equal to rounding."""
-    P = bunny[::13][:3000].astype(np.float64)
-    idx = np.random.RandomState(J).choice(len(P), J, replace=False)
-    ctx.set_points(P)
-    a = ctx.fullcov_fit(J, 1.0, 1e-4, P[idx], 0.0005, 4)
-    monkeypatch.setenv("HGMM_FULLCOV_WAVES", "16")
-    b = ctx.fullcov_fit(J, 1.0, 1e-4, P[idx], 0.0005, 4)
-    monkeypatch.delenv("HGMM_FULLCOV_WAVES")
-    o = hgmm_tree.build_flat_fullcov(P, J, 1.0, 1e-4, idx, 0.0005, max_iters=4)
-    for got in (a, b):
-        np.testing.assert_allclose(got[4], o[3], rtol=1e-9, atol=1e-6)
-        assert np.array_equal(got[3], o[4])
-        np.testing.assert_allclose(got[2], o[2], rtol=1e-6, atol=1e-14)
-    np.testing.assert_allclose(a[2], b[2], rtol=1e-9, atol=1e-16)
-
-
 def test_fullcov_estep_moments_layout(ctx, bunny):
     """hgmm_fullcov_estep: the 10-float statistics expanded to the reference's m0/m1/m2 layout."""
     P = bunny[::16].astype(np.float64)

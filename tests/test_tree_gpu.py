@@ -572,26 +572,3 @@ def test_symmetric_form_fallback_and_pair_counter(ctx, bunny, monkeypatch):
     cov8[5] = np.identity(3) * 1e-3
     ctx.tree_set_nodes(1, pi8, mu8, cov8)
     assert ctx.tree_stats()[1] == 0
-
-
-def test_loglik_kernel_variants_agree(ctx, bunny, monkeypatch):
-    """Small clouds take the 64-point / node-split log-likelihood kernel, large ones the 512- or 1024-point form with the
-    level's nodes split over a second grid dimension + a finish pass.  Both forms on the same small cloud: identical
-    iteration counts and assignments, q equal to rounding, both equal to the oracle."""
-    P = bunny[::5].astype(np.float64)
-    L = 4
-    T = hgmm_tree.n_total(L)
-    idx = np.random.RandomState(72).randint(T, size=T)
-    out = {}
-    for small in ("1", "0"):
-        monkeypatch.setenv("HGMM_TREE_LL_SMALL", small)
-        out[small] = build(ctx, P, L, 80.0, 1e-4, idx, 0.00034)
-    monkeypatch.delenv("HGMM_TREE_LL_SMALL")
-    a, b = out["1"], out["0"]
-    assert list(a[4]) == list(b[4]) and np.array_equal(a[3], b[3])
-    np.testing.assert_allclose(a[5], b[5], rtol=1e-12, atol=1e-9)
-    np.testing.assert_allclose(a[2], b[2], rtol=1e-9, atol=1e-16)
-    o_pi, o_mu, o_cov, tr = hgmm_tree.build_tree(P, L, 80.0, 1e-4, idx, 0.00034)
-    assert list(a[4]) == list(tr.iters_per_level)
-    np.testing.assert_allclose(a[5], tr.q, rtol=1e-9, atol=1e-6)
-    assert np.array_equal(a[3], tr.current_idx_per_level[-1])
