@@ -26,7 +26,7 @@ CASES = st.tuples(
 )
 
 
-@settings(max_examples=30, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(case=CASES)
 def test_random_shapes(ctx, case):
     N, J, (variant, cov_type), scale, seed = case
@@ -54,4 +54,6 @@ def test_random_shapes(ctx, case):
     stats, sum_lpn, n = ctx.flat_stats(inv, mu, w, cov_type, variant)
     assert n == N
     np.testing.assert_allclose(stats[:, 0], o_r.sum(0), rtol=2e-4, atol=1e-5)
-    np.testing.assert_allclose(sum_lpn, o_lpn.sum(), rtol=2e-5, atol=1e-3)
+    # (the per-component constant log|inv| + log w lives in the packed table as float32: with few components every
+    #  point inherits the SAME rounding of it -- up to ulp(30) / 2 = 1.9e-6 per point, added coherently over the cloud)
+    np.testing.assert_allclose(sum_lpn, o_lpn.sum(), rtol=2e-5, atol=1e-3 + 2e-6 * N)
