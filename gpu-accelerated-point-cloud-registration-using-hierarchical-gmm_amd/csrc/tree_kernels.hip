@@ -36,16 +36,19 @@ namespace hgmm {
 
 constexpr double TREE_EPS = 1.0e-15;                 // hgmm_cupy_cpu_working.py:29
 constexpr double TWO_PI_POW_1_5 = 15.749609945722419; // (2 pi)^(3/2)
-constexpr int PREP_N = 20;   // i00 i01 i02 i11 i12 i22 | mu0 mu1 mu2 | wE | wL | complexity | r00 r01 r02 r11 r12 r22 | kappa | -
+constexpr int PREP_N = 20;   // i00 i01 i02 i11 i12 i22 | mu0 mu1 mu2 | wE | wL | complexity | r00 r01 r02 r11 r12 r22 | kappa | kappa'
 // [12..17] R: upper-triangular factor of Sigma^-1 / 2 (R^T R = Sigma^-1 / 2), so that the exponent of the pdf is
 //          -(x-mu)^T Sigma^-1 (x-mu) / 2 = -|R (x - mu)|^2 : 9 fma/mul for a point given in coordinates where R mu is
 //          precomputed, against 14 for the symmetric form (tree_loglik_kernel, full_fused_kernel).
 // [18]     kappa = 1 / (2 lambda_max(Sigma)): the exponent is <= -kappa |x - mu|^2 for every x -- a whole node can be
 //          rejected for a whole box of points once kappa dist(box, mu)^2 passes the underflow threshold.
+// [19]     kappa' = lambda_max(Sigma^-1) / 2 (an upper bound of it): the exponent is >= -kappa' |x - mu|^2 for every x -- with
+//          the farthest corner of a box of points that is a LOWER bound of the node's pdf over the box (the relative
+//          reach test of tree_loglik_kernel); -1 where no bound is known.
 // A node whose Sigma^-1 is not numerically positive definite although det >= eps (cannot happen for a covariance
 // estimated from moments; a caller-supplied table may hold anything) raises bit 0 of the context's tree flags and the
 // consumers fall back to the symmetric form.
-constexpr int PREP_R = 12, PREP_KAPPA = 18;
+constexpr int PREP_R = 12, PREP_KAPPA = 18, PREP_KAPPA2 = 19;
 constexpr int CH = 256;      // points per chunk = threads per workgroup
 constexpr int NMOM = 10;     // m0, m1[3], m2 unique[6] (xx xy xz yy yz zz)
 
@@ -316,6 +319,7 @@ __device__ __forceinline__ void prep_node(double p, double m0, double m1, double
                        c02 * (c10 * c21 - c11 * c20);
 #pragma unroll
     for (int e = PREP_R; e < PREP_N; ++e) o[e] = 0.0;
+    o[PREP_KAPPA2] = -1.0;
     if (det < TREE_EPS) {           // gaussianPdf returns 0 (hgmm_cupy_cpu_working.py:65-67)
         o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = 0.0;
         o[9] = 0.0;
@@ -347,6 +351,8 @@ __device__ __forceinline__ void prep_node(double p, double m0, double m1, double
             o[PREP_R + 3] = r11; o[PREP_R + 4] = r12; o[PREP_R + 5] = r22;
             const double lmax = sym3_max_eig_upper(c00, c01, c02, c11, c12, c22);
             o[PREP_KAPPA] = (lmax > 0.0 && lmax == lmax && lmax < 1.0e300) ? 0.5 / lmax : 0.0;
+            const double imax = sym3_max_eig_upper(o[0], o[1], o[2], o[3], o[4], o[5]);
+            o[PREP_KAPPA2] = (imax > 0.0 && imax == imax && imax < 1.0e300) ? 0.5 * imax : -1.0;
         } else if (flags) {
             atomicOr(flags, 1);
         }
@@ -709,6 +715,8 @@ __device__ __forceinline__ void store_block_q(double value, double* __restrict__
 //   pair_count (optional): += (points of this workgroup) x (nodes that entered its tiles) -- the pairs actually evaluated.
 constexpr double LL_SKIP = -750.0;       // exp(y) == 0 in float64 below this exponent (denormals end at -745.13)
 constexpr double LL_CULL = 751.0;        // a node is out of reach when kappa dist^2 exceeds this (margin over LL_SKIP)
+constexpr double LL_REL_DROP = 46.1;     // ln(1e20) + margin: see the relative reach test in tree_loglik_kernel
+constexpr int LL_REL_MIN_NODES = 512;    // levels with fewer nodes skip the extra pass (measured: nothing to drop there)
 template <int PTS, bool BIGTAB = false>
 __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restrict__ xs, int64_t n,
                                                          int64_t n_pad, const double* __restrict__ prep,
@@ -721,14 +729,15 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
                                                          const int* __restrict__ flags,
                                                          unsigned long long* __restrict__ pair_count,
                                                          const double* __restrict__ exp2_tab = nullptr) {
-    if (done && *done) return;
+    const int stop_flag = done ? *done : 0;                // (looked at below, once the other requests are on their way)
     __shared__ double tile[LL_TILE][10];
     __shared__ double shq[CH / 64];
     __shared__ double exp_tab[BIGTAB ? EXP_TAB2_N : EXP_TAB_N];
     __shared__ double shbox[CH / 64][6];
     __shared__ int wcnt[CH / 64];
+    __shared__ double shl[CH / 64];
     if (BIGTAB) exp_tab2_load(exp_tab, exp2_tab); else exp_tab_load(exp_tab);   // (the tile loop's first barrier covers it)
-    const bool use_chol = !(flags && (*flags & 1));        // kernel-uniform
+    const int fl = flags ? *flags : 0;
     const int w = wave_in_block(), lane = lane_id();
     // origin: the workgroup's first point
     const int64_t i_first = (int64_t)blockIdx.x * PTS * CH;
@@ -738,13 +747,23 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
     bool active[PTS];
     double x0[PTS], x1[PTS], x2[PTS], tot[PTS];
     double lo0 = 0.0, lo1 = 0.0, lo2 = 0.0, hi0 = 0.0, hi1 = 0.0, hi2 = 0.0;    // the origin itself is in the box
+    // (the stop flag, the form flag, the origin and the points are requested together: the launches of a small cloud are
+    //  chains of trips to memory, ~1.5 us each, and every trip taken side by side instead of in turn is that much less)
+    double r0[PTS], r1[PTS], r2[PTS];
 #pragma unroll
     for (int p = 0; p < PTS; ++p) {
         i[p] = i_first + (int64_t)p * CH + threadIdx.x;
         active[p] = i[p] < n;
+        const int64_t il = active[p] ? i[p] : i_c;
+        r0[p] = xs[il]; r1[p] = xs[n_pad + il]; r2[p] = xs[2 * n_pad + il];
+    }
+    if (stop_flag) return;
+    const bool use_chol = !(fl & 1);                       // kernel-uniform
+#pragma unroll
+    for (int p = 0; p < PTS; ++p) {
         x0[p] = x1[p] = x2[p] = tot[p] = 0.0;              // inactive slots sit on the origin
         if (active[p]) {
-            x0[p] = xs[i[p]] - c0; x1[p] = xs[n_pad + i[p]] - c1; x2[p] = xs[2 * n_pad + i[p]] - c2;
+            x0[p] = r0[p] - c0; x1[p] = r1[p] - c1; x2[p] = r2[p] - c2;
         }
         lo0 = fmin(lo0, x0[p]); hi0 = fmax(hi0, x0[p]);
         lo1 = fmin(lo1, x1[p]); hi1 = fmax(hi1, x1[p]);
@@ -764,6 +783,45 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
     hi0 = fmax(fmax(shbox[0][3], shbox[1][3]), fmax(shbox[2][3], shbox[3][3]));
     hi1 = fmax(fmax(shbox[0][4], shbox[1][4]), fmax(shbox[2][4], shbox[3][4]));
     hi2 = fmax(fmax(shbox[0][5], shbox[1][5]), fmax(shbox[2][5], shbox[3][5]));
+
+    // ---- relative reach: a lower bound of log(sum_j w_j pdf_j(x)) that holds for EVERY point of the workgroup ----
+    // For node j and any x in the box: log(w_j pdf_j(x)) >= log w_j - kappa'_j D_j^2 with D_j the distance from the mean
+    // to the farthest corner; the largest of these over the level's nodes, lref, bounds every point's sum from below.
+    // A node whose UPPER bound over the box, log w_j - kappa_j dist(box, mu_j)^2, is below lref - ln(1e20 n_nodes)
+    // cannot contribute more than 1e-20 of any point's sum even together with every other node dropped this way:
+    // four orders of magnitude below half an ulp of the sum, i.e. below what the ORDER of the additions already
+    // decides.  (The absolute test alone keeps a node until its pdf underflows, 38 sigma away; this one lets go of it
+    // ~10 sigma beyond the box.)  Every workgroup -- also the ones that take a chunk of the nodes -- looks at ALL of
+    // the level's nodes here, so that every chunk uses the same lref.
+    double lref = -INFINITY;
+    const double rel_margin = LL_REL_DROP + log((double)n_level_nodes);
+    // Only in the large-cloud instantiation: the pass costs a few microseconds per launch, which the 40 256-point
+    // build (3.2 -> 3.45 ms with it) does not get back -- its launches are chains of latencies, not pdf evaluations;
+    // at 10^6 points it takes the evaluated pairs from 22 % to 18 % of the reference's (5.19 -> 5.04 ms per build).
+    if (BIGTAB && n_level_nodes >= LL_REL_MIN_NODES && !(fl & 2)) {
+        double best = -INFINITY;
+        for (int n0 = (int)threadIdx.x; n0 < n_level_nodes; n0 += 4 * CH) {
+            double wl[4], k2[4], u0[4], u1[4], u2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                  // (all twenty loads of the round in flight together)
+                const int nd = n0 + q * CH < n_level_nodes ? n0 + q * CH : n_level_nodes - 1;
+                const double* pr = prep + PREP_N * (lb + nd);
+                wl[q] = pr[10]; k2[q] = pr[PREP_KAPPA2]; u0[q] = pr[6]; u1[q] = pr[7]; u2[q] = pr[8];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (n0 + q * CH < n_level_nodes && wl[q] > 0.0 && k2[q] >= 0.0) {
+                    const double m0 = u0[q] - c0, m1 = u1[q] - c1, m2 = u2[q] - c2;
+                    const double f0 = fmax(m0 - lo0, hi0 - m0), f1 = fmax(m1 - lo1, hi1 - m1), f2 = fmax(m2 - lo2, hi2 - m2);
+                    best = fmax(best, log(wl[q]) - k2[q] * (f0 * f0 + f1 * f1 + f2 * f2));
+                }
+            }
+        }
+        best = wave_max_f64(best);
+        if (lane == 0) shl[w] = best;
+        __syncthreads();
+        lref = fmax(fmax(shl[0], shl[1]), fmax(shl[2], shl[3]));
+    }
 
     const int node_begin = blockIdx.y * nodes_per_chunk;
     const int node_end = (node_begin + nodes_per_chunk < n_level_nodes) ? node_begin + nodes_per_chunk : n_level_nodes;
@@ -787,7 +845,7 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
                 const double g0 = fmax(fmax(lo0 - m0, m0 - hi0), 0.0), g1 = fmax(fmax(lo1 - m1, m1 - hi1), 0.0),
                              g2 = fmax(fmax(lo2 - m2, m2 - hi2), 0.0);
                 const double d2 = g0 * g0 + g1 * g1 + g2 * g2;                      // squared distance box <-> mean
-                live = !(kap * d2 > LL_CULL);
+                live = !(kap * d2 > LL_CULL) && !(log(wL) - kap * d2 < lref - rel_margin);
                 if (live) {
                     if (use_chol) {
                         const double r00 = f0, r01 = f1, r02 = f2, r11 = f3, r12 = f4, r22 = f5;
@@ -1371,8 +1429,11 @@ static int tree_flags(hgmm_ctx* c, bool reset) {
     if (reset) {
         HGMM_HIP(c, hipMemsetAsync(c->t_flags.p, 0, TREE_FLAGS_BYTES, c->stream));
         // HGMM_TREE_NO_CHOL=1: take the symmetric-form fallback everywhere (lets the tests hold both forms to the oracle)
-        if (const char* e = std::getenv("HGMM_TREE_NO_CHOL"))
-            if (e[0] == '1') HGMM_HIP(c, hipMemsetAsync(c->t_flags.p, 1, 1, c->stream));
+        // HGMM_TREE_NO_REL=1: absolute reach test only (bit 1; for A/B timing of the relative test)
+        int preset = 0;
+        if (const char* e = std::getenv("HGMM_TREE_NO_CHOL")) preset |= (e[0] == '1') ? 1 : 0;
+        if (const char* e = std::getenv("HGMM_TREE_NO_REL")) preset |= (e[0] == '1') ? 2 : 0;
+        if (preset) HGMM_HIP(c, hipMemsetAsync(c->t_flags.p, preset, 1, c->stream));
     }
     return HGMM_OK;
 }
@@ -1480,7 +1541,12 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     //  20.2 / 49 us per iteration against 8.9 / 14.8 / 19.1 / 22.4 for this form: eight times as many workgroups each read
     //  the level's whole node table for the reach test; removed again, commit 7d926ef)
     if (ll_pts == 4) HGMM_TRY(ensure_exp_tab2(c));
-    int batch_iters = 8;                      // iterations enqueued per host synchronisation (1/2/4/8/16: 6.8/6.3/5.6/5.1/5.3 ms @C4)
+    // iterations enqueued per batch.  Round 2 (host waits at every batch boundary): 1/2/4/8/16 -> 6.8/6.3/5.6/5.1/5.3 ms @C4.
+    // With the host one batch ahead (below) a level that stops at iteration k still has (ceil(k / B) + 1) B - k
+    // iterations enqueued behind the stop (46 over C4's four levels at B = 8, 22 at B = 4) -- but each of those is three
+    // launches that return at their first load, and a batch boundary (control-word copy + event) costs more than it
+    // saves: 2/4/8 -> 3.67/3.60/3.46 ms @C4, 5.12/5.07/5.02 @1M on one box.
+    int batch_iters = 8;
     if (const char* e = std::getenv("HGMM_TREE_BATCH")) batch_iters = std::max(1, std::min(64, atoi(e)));
 
     HGMM_HIP(c, hipMemcpyAsync(c->scratch.p, init_mu, sizeof(double) * 3 * T, hipMemcpyHostToDevice, c->stream));

@@ -533,7 +533,8 @@ def test_symmetric_form_fallback_and_pair_counter(ctx, bunny, monkeypatch):
     """The level log-likelihood and the one-pass full-covariance kernel evaluate the exponent in a triangular form
     (R^T R = Sigma^-1 / 2) and fall back to the symmetric form when a node's Sigma^-1 fails the Cholesky test.
     Both forms are held to the oracle: the fallback is forced with HGMM_TREE_NO_CHOL=1.  Also hgmm_tree_stats: the
-    pdf evaluations really done never exceed the reference's N x 8^(l+1) per iteration, and skipping is exact."""
+    pdf evaluations really done never exceed the reference's N x 8^(l+1) per iteration (what is skipped is exactly 0 in
+    float64 here; clouds of >= 4e5 points also drop what stays below 1e-20 of every point's sum: test_tree_1M_...)."""
     P = bunny[::8].astype(np.float64)
     L = 3
     T = hgmm_tree.n_total(L)
