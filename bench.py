@@ -427,37 +427,67 @@ def estep_roofline_leg(ctx, lr, init, fitted, args):
 def materialised_iteration_leg(ctx, lr, inv, mu, w):
     """API-faithful iteration, the way a caller of the reference's module functions runs its own loop
     (gmm_impl.py:125-138): log_ll, log_resp = e_step(X, inv_cov, means, weights); weights, means, cov = m_step(X,
-    exp(log_resp)); inv_cov = 1 / (sqrt(cov + 1e-6) + eps) ON THE HOST -- every iteration uploads new parameters and
-    downloads the M-step's results; the E-step does not wait for its kernel (hgmm_flat_estep_async), the M-step's
-    download is the one synchronisation per iteration.  The loop starts from the fit's initial parameters (two untimed
-    iterations, then eight timed ones): the state a caller's loop is in when it starts."""
+    exp(log_resp)); inv_cov = 1 / (sqrt(cov + 1e-6) + eps); stop test on log_ll.  Timed in the two array modules the
+    reference's functions accept:
+      device arrays  (the reference under CuPy, `it_per_s`): the M-step's results stay in HBM (DeviceArray), the
+                     inverse standard deviations are formed there by elementwise kernels, the E-step packs its table
+                     from them; the only thing the host reads per iteration is the mean log-normaliser -- a pinned
+                     scalar behind an event, so the M-step keeps running while the loop looks at it;
+      host arrays    (`host_array_loop`): parameters as NumPy arrays -- every iteration downloads the M-step's results
+                     (its one synchronisation), forms inv_cov on the host and uploads it with the next E-step.
+    Both start from the fit's initial parameters (two untimed iterations, then eight timed ones): the state a caller's
+    loop is in when it starts."""
     reps = 8
-    for timed in (False, True):
-        inv_k, mu_k, w_k = inv, mu, w
-        if timed:
-            ctx.profile_reset()
-            ctx.profile_enable(True)
+    eps6, eps8 = np.float32(1e-6), np.float32(1e-8)
+
+    def run(device_arrays, n_it):
+        if device_arrays:
+            inv_k, mu_k, w_k = ctx.to_device(inv), ctx.to_device(mu), ctx.to_device(w)
+        else:
+            inv_k, mu_k, w_k = inv, mu, w
+        prev, mean = -np.inf, None
         ctx.synchronize()
         t0 = time.perf_counter()
-        for _ in range(reps if timed else 2):
+        for _ in range(n_it):
             mean, _, _, _ = ctx.flat_estep(inv_k, mu_k, w_k, "diag", "W", out=lr, lazy_mean=True)
-            w_k, mu_k, cov_k = ctx.flat_mstep(lr.exp(), "diag", "W", centre_hint=mu_k)
-            inv_k = (1.0 / (np.sqrt(cov_k + np.float32(1e-6)) + np.float32(1e-8))).astype(np.float32)
+            w_k, mu_k, cov_k = ctx.flat_mstep(lr.exp(), "diag", "W", centre_hint=mu_k, device_out=device_arrays)
+            if device_arrays:
+                inv_k = 1.0 / (np.sqrt(cov_k + eps6) + eps8)                  # four small kernels, nothing waits
+                m = float(mean)                                                # (waits for the E-step's event only)
+                change, prev = m - prev, m                                     # the stop test's operands (not applied)
+            else:
+                inv_k = (1.0 / (np.sqrt(cov_k + eps6) + eps8)).astype(np.float32)
         ctx.synchronize()
-        api_dt = (time.perf_counter() - t0) / reps
-    ctx.profile_enable(False)
-    m_ms, m_n = ctx.profile_get("flat_mstep")
-    e_ms, e_n = ctx.profile_get("flat_estep")
-    m_avg_s = m_ms / max(m_n, 1) * 1e-3
+        return (time.perf_counter() - t0) / n_it, float(mean), np.asarray(mu_k, dtype=np.float32)
+
+    legs = {}
+    for device_arrays in (False, True):
+        run(device_arrays, 2)
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        dt, last_mean, mu_end = run(device_arrays, reps)
+        ctx.profile_enable(False)
+        m_ms, m_n = ctx.profile_get("flat_mstep")
+        e_ms, e_n = ctx.profile_get("flat_estep")
+        k_ms = (m_ms + e_ms) / max(m_n, 1)
+        legs[device_arrays] = {"it_per_s": 1.0 / dt, "ms_per_iteration": dt * 1e3, "kernel_ms_per_iteration": k_ms,
+                               "outside_the_two_kernels_ms_per_iteration": dt * 1e3 - k_ms,
+                               "last_mean_log_normaliser": last_mean, "mstep_avg_ms": m_ms / max(m_n, 1),
+                               "_mu": mu_end}
+    dev, host = legs[True], legs[False]
+    # the two loops run the same kernels on the same numbers: elementwise float32 on the device == NumPy's
+    agree = bool(np.array_equal(dev.pop("_mu"), host.pop("_mu"))) and dev["last_mean_log_normaliser"] == host["last_mean_log_normaliser"]
+    m_avg_s = dev["mstep_avg_ms"] * 1e-3
     m_bytes = 4 * N_POINTS * J_COMP + 12 * N_POINTS
-    return {"it_per_s": 1.0 / api_dt, "ms_per_iteration": api_dt * 1e3,
-            "kernel_ms_per_iteration": (m_ms + e_ms) / max(m_n, 1),
-            "host_overhead_ms_per_iteration": api_dt * 1e3 - (m_ms + e_ms) / max(m_n, 1),
-            "last_mean_log_normaliser": float(mean),
-            "mstep_avg_ms": m_avg_s * 1e3, "mstep_GBs": m_bytes / m_avg_s / 1e9,
-            "roofline": {"kernel": "flat_mstep_kernel<3,1>", "bound": "hbm", "unit": "GB/s",
-                         "achieved": m_bytes / m_avg_s / 1e9, "peak": HBM_PEAK_GBS,
-                         "frac": m_bytes / m_avg_s / 1e9 / HBM_PEAK_GBS}}
+    out = dict(dev)
+    out.update({"arrays": "device (DeviceArray parameters, pinned scalar for the stop test)",
+                "host_overhead_ms_per_iteration": dev["outside_the_two_kernels_ms_per_iteration"],
+                "host_array_loop": host, "device_and_host_array_loops_bitwise_equal": agree,
+                "mstep_GBs": m_bytes / m_avg_s / 1e9,
+                "roofline": {"kernel": "flat_mstep_kernel<3,1>", "bound": "hbm", "unit": "GB/s",
+                             "achieved": m_bytes / m_avg_s / 1e9, "peak": HBM_PEAK_GBS,
+                             "frac": m_bytes / m_avg_s / 1e9 / HBM_PEAK_GBS}})
+    return out
 
 
 def fused_roofline(avg_launch_s, cus):

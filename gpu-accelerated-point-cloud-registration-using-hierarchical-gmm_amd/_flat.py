@@ -48,6 +48,11 @@ def _host(a):
     return np.asarray(a.get() if isinstance(a, DeviceArray) else a)
 
 
+def _param(a):
+    """A parameter array as the E-step takes it: DeviceArrays stay where they are, anything else becomes NumPy."""
+    return a if isinstance(a, DeviceArray) else np.asarray(a)
+
+
 @contextlib.contextmanager
 def timer(message):
     """gmm_impl.timer: synchronise, time, print (gmm_waymo/src/gmm_impl.py:43-50)."""
@@ -67,14 +72,18 @@ def estimate_log_prob(X, inv_cov, means, cov_type):
 def e_step(X, inv_cov, means, weights, cov_type, variant):
     ctx = _ctx_for(X)
     # like the reference under CuPy nothing waits here: the mean is a device scalar, read when it is looked at
-    mean_lpn, log_resp, _, _ = ctx.flat_estep(_host(inv_cov), _host(means), _host(weights), cov_type, variant,
+    # Parameters handed over as DeviceArrays (an earlier m_step's results, arithmetic on them) are used where they are.
+    mean_lpn, log_resp, _, _ = ctx.flat_estep(_param(inv_cov), _param(means), _param(weights), cov_type, variant,
                                               lazy_mean=True)
     return mean_lpn, log_resp
 
 
 def m_step(X, resp, cov_type, variant, centre_hint=None):
+    """Array module in = array module out, like the reference (``xp = cupy.get_array_module(X)``, gmm_impl.py:91):
+    responsibilities that live in HBM (a DeviceArray, e.g. ``log_resp.exp()`` of this module's e_step) give
+    DeviceArrays -- nothing is downloaded, nothing waits; host responsibilities give NumPy arrays."""
     ctx = _ctx_for(X)
-    return ctx.flat_mstep(resp, cov_type, variant, centre_hint)
+    return ctx.flat_mstep(resp, cov_type, variant, centre_hint, device_out=isinstance(resp, DeviceArray))
 
 
 def train_gmm(X, max_iter, tol, means, covariances, weights, cov_type, variant):

@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import threading
+import weakref
 
 import numpy as np
 
@@ -72,6 +73,12 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_num_points", [ctx], C.c_int64)
         _sig(lib, "hgmm_flat_estep", [ctx, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _f64p])
         _sig(lib, "hgmm_flat_estep_async", [ctx, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+        _sig(lib, "hgmm_flat_estep_dev", [ctx, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+        _sig(lib, "hgmm_flat_mstep_dev", [ctx, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp])
+        _sig(lib, "hgmm_elementwise_f32", [ctx, C.c_int, C.c_int64, _vp, _vp, C.c_float, _vp])
+        _sig(lib, "hgmm_host_scalars", [ctx, C.c_int, C.POINTER(_f64p), C.POINTER(_vp)])
+        _sig(lib, "hgmm_event_record", [ctx, C.c_int])
+        _sig(lib, "hgmm_event_wait", [ctx, C.c_int])
         _sig(lib, "hgmm_flat_predict", [ctx, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp])
         _sig(lib, "hgmm_flat_log_prob", [ctx, C.c_int, C.c_int, _vp, _vp, _vp])
         _sig(lib, "hgmm_flat_mstep", [ctx, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp])
@@ -129,11 +136,32 @@ def _f32(a, shape=None):
     return a
 
 
+EW_OPS = {"add": 0, "sub": 1, "rsub": 2, "mul": 3, "div": 4, "rdiv": 5, "sqrt": 6, "exp": 7, "log": 8, "max": 9, "min": 10}
+# arrays up to this size are carved from the context's arena (no hipMalloc / hipFree, nothing waits when they die)
+SMALL_BYTES = 128 << 10
+SMALL_SLABS = 64
+# np.exp() of an array with at least this many elements stays a lazy view (the consumer fuses the exponential)
+LAZY_EXP_ELEMS = 1 << 20
+# ndarray methods a DeviceArray answers by downloading itself first
+_HOST_METHODS = frozenset((
+    "sum", "mean", "min", "max", "std", "var", "copy", "T", "reshape", "tolist", "flatten", "ravel", "any", "all",
+    "round", "clip", "dot", "squeeze", "transpose", "item", "argmin", "argsort", "cumsum", "prod", "nonzero", "tobytes",
+    "view", "real", "imag", "flat", "take", "repeat", "fill", "itemsize", "strides", "base", "flags"))
+
+
 class DeviceArray:
     """A dense array living in HBM (what a CuPy ndarray was to the reference).
 
     ``np.asarray(d)`` / ``d.get()`` copy it to the host.  ``d.exp()`` is a lazy view used by
-    ``m_step(X, log_resp.exp())`` so the exponential is fused into the moment kernel."""
+    ``m_step(X, log_resp.exp())`` so the exponential is fused into the moment kernel.
+
+    float32 arrays do elementwise arithmetic with scalars and with arrays of their own shape ON THE DEVICE
+    (``+ - * /``, ``np.sqrt / np.exp / np.log / np.maximum / np.minimum``): small kernels on the context's stream,
+    nothing waits -- so a caller's own EM loop, ``inv_cov = 1 / (xp.sqrt(covariances + 1e-6) + eps)`` included
+    (gmm_impl.py:134), never brings the parameters to the host.  Everything else an ndarray can do (indexing,
+    ``.sum()``, comparisons, broadcasting against other shapes) is answered from a host copy."""
+
+    __array_priority__ = 1000
 
     def __init__(self, ctx, shape, dtype, is_log=False, _base=None):
         self.ctx = ctx
@@ -141,8 +169,11 @@ class DeviceArray:
         self.dtype = np.dtype(dtype)
         self.is_log = is_log
         self._base = _base
+        self._slab = None
         if _base is None:
-            self.ptr = ctx._alloc(self.nbytes)
+            self._slab, self.ptr = ctx._alloc_small(self.nbytes)
+            if self._slab is None:
+                self.ptr = ctx._alloc(self.nbytes)
             self._owner = True
         else:
             self.ptr = _base.ptr
@@ -192,12 +223,98 @@ class DeviceArray:
     def argmax(self, axis=None):
         return self.get().argmax(axis=axis)
 
+    def astype(self, dtype, copy=True, **kw):
+        """Same dtype: the array itself stays where it is (as ``cupy.ndarray.astype(..., copy=False)`` would
+        leave it); another dtype is answered from a host copy."""
+        if np.dtype(dtype) == self.dtype and self._base is None:
+            return self
+        return self.get().astype(dtype, **kw)
+
     def __len__(self):
         return self.shape[0]
 
+    def __getitem__(self, idx):
+        return self.get()[idx]
+
+    def __iter__(self):
+        return iter(self.get())
+
+    def __repr__(self):
+        return "DeviceArray(shape=%s, dtype=%s%s)" % (self.shape, self.dtype, ", lazy exp" if self._base is not None else "")
+
+    def __getattr__(self, name):
+        # (reached only for names the class does not define)
+        if name in _HOST_METHODS:
+            return getattr(self.get(), name)
+        raise AttributeError(name)
+
+    # -- elementwise arithmetic --------------------------------------------------------------
+    def _on_device(self):
+        return self.dtype == np.float32 and self._base is None and self.size > 0
+
+    def _ew(self, op, other=None):
+        """out = self op other on the device, or NotImplemented when this pair is not a device case."""
+        if not self._on_device():
+            return NotImplemented
+        b_ptr, scalar = None, 0.0
+        keep = None
+        if other is None:
+            pass
+        elif isinstance(other, DeviceScalar):
+            scalar = float(other)
+        elif isinstance(other, DeviceArray):
+            if not other._on_device() or other.shape != self.shape or other.ctx is not self.ctx:
+                return NotImplemented
+            b_ptr = other.ptr
+        elif isinstance(other, np.ndarray) and other.ndim > 0:
+            if other.shape != self.shape:
+                return NotImplemented
+            keep = self.ctx.to_device(np.ascontiguousarray(other, dtype=np.float32))
+            b_ptr = keep.ptr
+        elif isinstance(other, (int, float, np.integer, np.floating)) or (isinstance(other, np.ndarray) and other.ndim == 0):
+            scalar = float(other)
+        else:
+            return NotImplemented
+        out = DeviceArray(self.ctx, self.shape, np.float32)
+        self.ctx._check(self.ctx.lib.hgmm_elementwise_f32(self.ctx.h, EW_OPS[op], self.size, self.ptr, b_ptr,
+                                                          C.c_float(scalar), out.ptr))
+        return out
+
+    def _host_op(self, fn, other, reverse=False):
+        a, b = np.asarray(self), (np.asarray(other) if isinstance(other, DeviceArray) else other)
+        return fn(b, a) if reverse else fn(a, b)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        if method == "__call__" and not kwargs:
+            name = ufunc.__name__
+            if len(inputs) == 1 and name in ("sqrt", "exp", "log"):
+                if name == "exp" and self._base is None and self.size >= LAZY_EXP_ELEMS:
+                    return self.exp()                       # m_step(X, xp.exp(log_resp)), gmm_impl.py:132
+                r = self._ew(name)
+                if r is not NotImplemented:
+                    return r
+            elif len(inputs) == 2:
+                pair = {"add": ("add", "add"), "subtract": ("sub", "rsub"), "multiply": ("mul", "mul"),
+                        "true_divide": ("div", "rdiv"), "divide": ("div", "rdiv"), "maximum": ("max", "max"),
+                        "minimum": ("min", "min")}.get(name)
+                if pair is not None:
+                    if inputs[0] is self:
+                        r = self._ew(pair[0], inputs[1])
+                    else:
+                        r = self._ew(pair[1], inputs[0])
+                    if r is not NotImplemented:
+                        return r
+        host = [np.asarray(x) if isinstance(x, DeviceArray) else x for x in inputs]
+        if "out" in kwargs and any(isinstance(o, DeviceArray) for o in kwargs["out"]):
+            raise TypeError("a DeviceArray cannot be the out= of a NumPy ufunc")
+        return getattr(ufunc, method)(*host, **kwargs)
+
     def free(self):
         if self._owner and self.ptr:
-            self.ctx._free(self.ptr)
+            if self._slab is not None:
+                self.ctx._free_small(self._slab)
+            else:
+                self.ctx._free(self.ptr)
             self.ptr = None
 
     def __del__(self):
@@ -207,25 +324,74 @@ class DeviceArray:
             pass
 
 
+def _binary(op, rop, fn):
+    def fwd(self, other):
+        r = self._ew(op, other)
+        return self._host_op(fn, other) if r is NotImplemented else r
+
+    def rev(self, other):
+        r = self._ew(rop, other)
+        return self._host_op(fn, other, reverse=True) if r is NotImplemented else r
+    return fwd, rev
+
+
+for _n, _op, _rop, _fn in (("add", "add", "add", np.add), ("sub", "sub", "rsub", np.subtract),
+                           ("mul", "mul", "mul", np.multiply), ("truediv", "div", "rdiv", np.true_divide)):
+    _f, _r = _binary(_op, _rop, _fn)
+    setattr(DeviceArray, "__%s__" % _n, _f)
+    setattr(DeviceArray, "__r%s__" % _n, _r)
+for _n, _fn in (("lt", np.less), ("le", np.less_equal), ("gt", np.greater), ("ge", np.greater_equal),
+                ("pow", np.power)):
+    setattr(DeviceArray, "__%s__" % _n, (lambda fn: lambda self, other: self._host_op(fn, other))(_fn))
+DeviceArray.__neg__ = lambda self: self * -1.0
+
+
 class DeviceScalar(DeviceArray):
-    """A float64 scalar living in HBM that is read when somebody looks at it (what a 0-d CuPy array was to the
-    reference: ``e_step`` returns ``xp.mean(log_prob_norm)`` without synchronising, gmm_impl.py:114-116).
-    ``float(s)``, arithmetic, comparisons and ``np.float32(s)`` download it (one stream synchronisation)."""
+    """A float64 scalar that a kernel writes and the host reads when somebody looks at it (what a 0-d CuPy array was
+    to the reference: ``e_step`` returns ``xp.mean(log_prob_norm)`` without synchronising, gmm_impl.py:114-116).
+    It lives in pinned host memory the device writes directly (hgmm_host_scalars) with an event recorded behind its
+    producer: ``float(s)``, arithmetic, comparisons and ``np.float32(s)`` wait for THAT kernel only -- an M-step
+    enqueued after the E-step keeps running while the caller's loop looks at the E-step's mean."""
 
     def __init__(self, ctx):
-        super().__init__(ctx, (1,), np.float64)
+        self.ctx = ctx
+        self.shape = (1,)
+        self.dtype = np.dtype(np.float64)
+        self.is_log = False
+        self._base = None
+        self._slab = None
+        self._owner = False
         self._value = None
+        self._marked = False
+        self._slot, self.ptr = ctx._scalar_take(self)
+
+    def _mark(self):
+        """Call right after the producing kernel has been enqueued."""
+        self.ctx._check(self.ctx.lib.hgmm_event_record(self.ctx.h, self._slot))
+        self._marked = True
 
     def item(self):
         if self._value is None:
-            self._value = float(self.get()[0])
+            if self._marked:
+                self.ctx._check(self.ctx.lib.hgmm_event_wait(self.ctx.h, self._slot))
+            else:
+                self.ctx.synchronize()
+            self._value = float(self.ctx._scalar_host[self._slot])
         return self._value
+
+    def get(self):
+        return np.array([self.item()])
 
     def __float__(self):
         return self.item()
 
     def __array__(self, dtype=None, copy=None):
         return np.asarray(self.item(), dtype=dtype or np.float64)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        host = [x.item() if isinstance(x, DeviceScalar) else (np.asarray(x) if isinstance(x, DeviceArray) else x)
+                for x in inputs]
+        return getattr(ufunc, method)(*host, **kwargs)
 
     def __repr__(self):
         return "DeviceScalar(%r)" % self.item()
@@ -238,6 +404,9 @@ class DeviceScalar(DeviceArray):
 
     def __neg__(self):
         return -self.item()
+
+    def free(self):
+        pass
 
 
 def _scalar_op(name):
@@ -268,6 +437,11 @@ class Context:
         self.device_id = device_id
         self._points_owner = None
         self.nranks, self.rank = 1, 0
+        self._arena = None                    # (pointer, free slab indices) of the small-array pool
+        self._scalar_host = None              # pinned, device-visible doubles (DeviceScalar)
+        self._scalar_dev = None
+        self._scalar_next = 0
+        self._scalar_owner = [None] * 64
 
     # -- plumbing ---------------------------------------------------------------------
     def _check(self, rc):
@@ -279,6 +453,14 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            for ref in self._scalar_owner:            # scalars nobody has looked at yet keep their value
+                sc = ref() if ref is not None else None
+                if sc is not None:
+                    try:
+                        sc.item()
+                    except Exception:
+                        pass
+            self._scalar_host = None
             self.lib.hgmm_destroy(self.h)
             self.h = None
 
@@ -296,6 +478,40 @@ class Context:
     def _free(self, p):
         if getattr(self, "h", None):
             self.lib.hgmm_free(self.h, p)
+
+    def _alloc_small(self, nbytes):
+        """-> (slab index, pointer) from the context's arena, or (None, None) when the request is large or the
+        arena is in use to the last slab.  Everything that touches the arrays is ordered on the context's one
+        stream, so a slab can be handed out again as soon as its array died."""
+        if nbytes > SMALL_BYTES:
+            return None, None
+        if self._arena is None:
+            self._arena = (self._alloc(SMALL_BYTES * SMALL_SLABS), list(range(SMALL_SLABS - 1, -1, -1)))
+        base, free = self._arena
+        if not free:
+            return None, None
+        i = free.pop()
+        return i, C.c_void_p(base.value + i * SMALL_BYTES)
+
+    def _free_small(self, slab):
+        if self._arena is not None:
+            self._arena[1].append(slab)
+
+    def _scalar_take(self, owner):
+        """The next of 64 host-visible scalar slots (round robin); a scalar still alive in the slot is read first."""
+        if self._scalar_host is None:
+            hp, dp = _f64p(), _vp()
+            self._check(self.lib.hgmm_host_scalars(self.h, 64, C.byref(hp), C.byref(dp)))
+            self._scalar_host = np.ctypeslib.as_array(hp, shape=(64,))
+            self._scalar_dev = dp.value
+        slot = self._scalar_next
+        self._scalar_next = (slot + 1) % 64
+        old = self._scalar_owner[slot]
+        old = old() if old is not None else None
+        if old is not None:
+            old.item()
+        self._scalar_owner[slot] = weakref.ref(owner)
+        return slot, C.c_void_p(self._scalar_dev + 8 * slot)
 
     def _d2h(self, host, dev_ptr):
         self._check(self.lib.hgmm_d2h(self.h, _ptr(host), dev_ptr, host.nbytes))
@@ -354,24 +570,52 @@ class Context:
         w = _f32(w, (J,))
         return J, mu, ic, w
 
+    def _flat_dev_args(self, mu, inv_or_cov, w, cov_type):
+        """The parameters as float32 DeviceArrays of this context (host arrays among them are uploaded)."""
+        def dev(a, shape):
+            if isinstance(a, DeviceArray):
+                if a.ctx is not self or a.dtype != np.float32 or a._base is not None:
+                    raise ValueError("parameter arrays must be float32 DeviceArrays of this context")
+                if shape is not None and a.shape != tuple(shape):
+                    raise ValueError("expected shape %s, got %s" % (shape, a.shape))
+                return a
+            return self.to_device(_f32(a, shape))
+        mu = dev(mu, None)
+        J = mu.shape[0]
+        if mu.shape != (J, 3):
+            raise ValueError("means must be [J,3]")
+        return J, mu, dev(inv_or_cov, (J, 3) if cov_type == "diag" else (J,)), dev(w, (J,))
+
     def flat_estep(self, inv_std, mu, w, cov_type="diag", variant="W", want_log_resp=True,
                    want_lpn=False, want_argmax=False, out=None, lazy_mean=False):
         """``out``: optional pre-allocated DeviceArray [N,J] float32 to write log_resp into.
         ``lazy_mean``: do not wait for the kernel -- the mean log-normaliser comes back as a ``DeviceScalar``
         that is downloaded when it is looked at (hgmm_flat_estep_async)."""
-        J, mu, inv_std, w = self._flat_args(mu, inv_std, w, cov_type)
+        on_device = any(isinstance(a, DeviceArray) for a in (inv_std, mu, w))
+        if on_device:
+            J, mu, inv_std, w = self._flat_dev_args(mu, inv_std, w, cov_type)
+        else:
+            J, mu, inv_std, w = self._flat_args(mu, inv_std, w, cov_type)
         n = self.num_points
         if out is not None and (out.shape != (n, J) or out.dtype != np.float32):
             raise ValueError("out must be a float32 DeviceArray of shape %s" % ((n, J),))
         lr = out if out is not None else (self.empty((n, J), np.float32) if want_log_resp else None)
         lpn = self.empty((n,), np.float32) if want_lpn else None
         am = self.empty((n,), np.int32) if want_argmax else None
-        if lazy_mean:
+        if lazy_mean or on_device:
             ms = DeviceScalar(self)
-            self._check(self.lib.hgmm_flat_estep_async(
-                self.h, COV_TYPES[cov_type], VARIANTS[variant], J, _ptr(mu), _ptr(inv_std), _ptr(w),
-                None if lr is None else lr.ptr, None if lpn is None else lpn.ptr, None if am is None else am.ptr, ms.ptr))
-            return ms, lr, lpn, am
+            if on_device:
+                self._check(self.lib.hgmm_flat_estep_dev(
+                    self.h, COV_TYPES[cov_type], VARIANTS[variant], J, mu.ptr, inv_std.ptr, w.ptr,
+                    None if lr is None else lr.ptr, None if lpn is None else lpn.ptr, None if am is None else am.ptr,
+                    ms.ptr))
+            else:
+                self._check(self.lib.hgmm_flat_estep_async(
+                    self.h, COV_TYPES[cov_type], VARIANTS[variant], J, _ptr(mu), _ptr(inv_std), _ptr(w),
+                    None if lr is None else lr.ptr, None if lpn is None else lpn.ptr, None if am is None else am.ptr,
+                    ms.ptr))
+            ms._mark()
+            return (ms if lazy_mean else float(ms)), lr, lpn, am
         mean = C.c_double()
         self._check(self.lib.hgmm_flat_estep(
             self.h, COV_TYPES[cov_type], VARIANTS[variant], J, _ptr(mu), _ptr(inv_std), _ptr(w),
@@ -391,12 +635,29 @@ class Context:
                                                _ptr(mu), _ptr(inv_std), _ptr(w), lab.ptr))
         return lab
 
-    def flat_mstep(self, resp, cov_type="diag", variant="W", centre_hint=None):
+    def flat_mstep(self, resp, cov_type="diag", variant="W", centre_hint=None, device_out=False):
+        """``device_out``: the new parameters stay in HBM (float32 DeviceArrays w [J], mu [J,3], cov [J,3] / [J]);
+        nothing is downloaded and nothing waits (hgmm_flat_mstep_dev)."""
         if not isinstance(resp, DeviceArray):
             resp = self.to_device(np.ascontiguousarray(resp, dtype=np.float32))
         n, J = resp.shape
         if n != self.num_points:
             raise ValueError("resp has %d rows, context holds %d points" % (n, self.num_points))
+        if device_out:
+            hint = None
+            if centre_hint is not None:
+                hint = centre_hint if isinstance(centre_hint, DeviceArray) else self.to_device(_f32(centre_hint, (J, 3)))
+                if hint.shape != (J, 3) or hint.dtype != np.float32 or hint.ctx is not self or hint._base is not None:
+                    raise ValueError("centre_hint must be a float32 [J,3] array")
+            w = DeviceArray(self, (J,), np.float32)
+            mu = DeviceArray(self, (J, 3), np.float32)
+            cov = DeviceArray(self, (J, 3) if cov_type == "diag" else (J,), np.float32)
+            self._check(self.lib.hgmm_flat_mstep_dev(self.h, COV_TYPES[cov_type], VARIANTS[variant], J, resp.ptr,
+                                                     1 if resp.is_log else 0, None if hint is None else hint.ptr,
+                                                     w.ptr, mu.ptr, cov.ptr))
+            return w, mu, cov
+        if isinstance(centre_hint, DeviceArray):
+            centre_hint = centre_hint.get()
         hint = None if centre_hint is None else _f32(centre_hint, (J, 3))
         w = np.empty(J, np.float32)
         mu = np.empty((J, 3), np.float32)

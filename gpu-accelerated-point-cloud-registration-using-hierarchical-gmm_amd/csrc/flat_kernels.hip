@@ -1767,11 +1767,20 @@ __global__ __launch_bounds__(256) void flat_mean_lpn_kernel(const double* __rest
 }
 
 static int flat_estep_enqueue(hgmm_ctx* c, int cov_type, int variant, int J, const float* mu, const float* inv_std,
-                              const float* w, float* dev_log_resp, float* dev_lpn, int32_t* dev_argmax, int* grid_out) {
+                              const float* w, float* dev_log_resp, float* dev_lpn, int32_t* dev_argmax, int* grid_out,
+                              bool params_on_device = false) {
     HGMM_TRY(flat_check(c, cov_type, variant, J));
     HGMM_TRY(flat_setup(c, cov_type, variant, J));
-    HGMM_TRY(flat_upload(c, mu, inv_std, false, w));
-    launch_pack(c);
+    if (params_on_device) {
+        // the packed table is formed straight from the caller's device arrays: no staging, no copy
+        if (!mu || !inv_std || !w) return fail(c, HGMM_ERR_ARG, "device parameter array is NULL");
+        const FlatState& f = c->flat;
+        flat_pack_kernel<<<(f.Jpad + 255) / 256, 256, 0, c->stream>>>(f.J, f.Jpad, f.cov_type, f.variant, mu, inv_std, w,
+                                                                    c->f_pack.as<float>());
+    } else {
+        HGMM_TRY(flat_upload(c, mu, inv_std, false, w));
+        launch_pack(c);
+    }
     int grid = 0;
     if (c->flat.chunked) {
         const FlatState& f = c->flat;
@@ -1823,6 +1832,20 @@ extern "C" int hgmm_flat_estep_async(hgmm_ctx* c, int cov_type, int variant, int
     return HGMM_OK;                                   // nothing waited for: the caller's arrays were copied to the ring
 }
 
+extern "C" int hgmm_flat_estep_dev(hgmm_ctx* c, int cov_type, int variant, int J, const float* dev_mu,
+                                   const float* dev_inv_std, const float* dev_w, float* dev_log_resp,
+                                   float* dev_lpn, int32_t* dev_argmax, double* dev_mean_lpn) {
+    if (!c) return HGMM_ERR_ARG;
+    int grid = 0;
+    HGMM_TRY(flat_estep_enqueue(c, cov_type, variant, J, dev_mu, dev_inv_std, dev_w, dev_log_resp, dev_lpn, dev_argmax,
+                                &grid, /*params_on_device=*/true));
+    if (dev_mean_lpn) {
+        flat_mean_lpn_kernel<<<1, 256, 0, c->stream>>>(c->f_lpn_partials.as<double>(), grid, (double)c->n, dev_mean_lpn);
+        HGMM_HIP(c, hipGetLastError());
+    }
+    return HGMM_OK;
+}
+
 extern "C" int hgmm_flat_predict(hgmm_ctx* c, int cov_type, int variant, int J, const float* mu,
                                  const float* inv_std, const float* w, int32_t* dev_labels) {
     if (!c || !dev_labels) return c ? fail(c, HGMM_ERR_ARG, "dev_labels is NULL") : HGMM_ERR_ARG;
@@ -1861,14 +1884,14 @@ extern "C" int hgmm_flat_log_prob(hgmm_ctx* c, int cov_type, int J, const float*
     return HGMM_OK;
 }
 
-extern "C" int hgmm_flat_mstep(hgmm_ctx* c, int cov_type, int variant, int J, const float* dev_resp,
-                               int is_log, const float* centre_hint, float* w_out, float* mu_out,
-                               float* cov_out) {
-    if (!c || !dev_resp) return c ? fail(c, HGMM_ERR_ARG, "dev_resp is NULL") : HGMM_ERR_ARG;
-    HGMM_TRY(flat_check(c, cov_type, variant, J));
-    HGMM_TRY(flat_setup(c, cov_type, variant, J));
+// The M-step's launches.  centre_hint: host [J,3] (staged), device [J,3] (hint_on_device) or NULL; the new parameters
+// go to d_w [J], d_mu [J,3], d_cov [J,3] / [J] -- the context's own block or the caller's device arrays.
+static int flat_mstep_enqueue(hgmm_ctx* c, int cov_type, int variant, int J, const float* dev_resp, int is_log,
+                              const float* centre_hint, bool hint_on_device, float* d_w, float* d_mu, float* d_cov) {
     FlatState& f = c->flat;
-    if (centre_hint) {
+    if (centre_hint && hint_on_device) {
+        flat_hint_kernel<<<(f.Jpad + 255) / 256, 256, 0, c->stream>>>(centre_hint, J, f.Jpad, c->f_hint.as<float>());
+    } else if (centre_hint) {
         HGMM_TRY(stage_h2d(c, c->f_mu.p, centre_hint, sizeof(float) * 3 * J));
         flat_hint_kernel<<<(f.Jpad + 255) / 256, 256, 0, c->stream>>>(c->f_mu.as<float>(), J, f.Jpad,
                                                                     c->f_hint.as<float>());
@@ -1908,15 +1931,33 @@ extern "C" int hgmm_flat_mstep(hgmm_ctx* c, int cov_type, int variant, int J, co
     HGMM_TRY(launch_reduce(c, grid, valid_j, false, nullptr));
     if (f.chunked)
         flat_finalize_mb_kernel<<<(f.Jpad + 255) / 256, 256, 0, c->stream>>>(
-            c->f_stats.as<double>(), hint, J, f.Jpad, cov_type, variant, c->f_mu.as<float>(),
-            c->f_cov.as<float>(), c->f_w.as<float>(), nullptr, nullptr, nullptr);
+            c->f_stats.as<double>(), hint, J, f.Jpad, cov_type, variant, d_mu, d_cov, d_w, nullptr, nullptr, nullptr);
     else
         flat_finalize_kernel<<<f.Jpad / 256, 256, 0, c->stream>>>(
-            c->f_stats.as<double>(), hint, J, f.Jpad, cov_type, variant, c->f_mu.as<float>(),
-            c->f_cov.as<float>(), c->f_w.as<float>(), nullptr, nullptr, nullptr, 0, 0.f, nullptr, nullptr,
-            c->f_ctl.as<int>() + 16, nullptr);
+            c->f_stats.as<double>(), hint, J, f.Jpad, cov_type, variant, d_mu, d_cov, d_w, nullptr, nullptr,
+            nullptr, 0, 0.f, nullptr, nullptr, c->f_ctl.as<int>() + 16, nullptr);
     HGMM_HIP(c, hipGetLastError());
-    // results: three DMA packets into the pinned ring, ONE synchronisation, then plain memcpys
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_flat_mstep_dev(hgmm_ctx* c, int cov_type, int variant, int J, const float* dev_resp, int is_log,
+                                   const float* dev_centre_hint, float* dev_w, float* dev_mu, float* dev_cov) {
+    if (!c || !dev_resp) return c ? fail(c, HGMM_ERR_ARG, "dev_resp is NULL") : HGMM_ERR_ARG;
+    if (!dev_w || !dev_mu || !dev_cov) return fail(c, HGMM_ERR_ARG, "device output array is NULL");
+    HGMM_TRY(flat_check(c, cov_type, variant, J));
+    HGMM_TRY(flat_setup(c, cov_type, variant, J));
+    return flat_mstep_enqueue(c, cov_type, variant, J, dev_resp, is_log, dev_centre_hint, true, dev_w, dev_mu, dev_cov);
+}
+
+extern "C" int hgmm_flat_mstep(hgmm_ctx* c, int cov_type, int variant, int J, const float* dev_resp,
+                               int is_log, const float* centre_hint, float* w_out, float* mu_out,
+                               float* cov_out) {
+    if (!c || !dev_resp) return c ? fail(c, HGMM_ERR_ARG, "dev_resp is NULL") : HGMM_ERR_ARG;
+    HGMM_TRY(flat_check(c, cov_type, variant, J));
+    HGMM_TRY(flat_setup(c, cov_type, variant, J));
+    FlatState& f = c->flat;
+    HGMM_TRY(flat_mstep_enqueue(c, cov_type, variant, J, dev_resp, is_log, centre_hint, false, c->f_w.as<float>(),
+                                c->f_mu.as<float>(), c->f_cov.as<float>()));
     // results: [cov | mu | w] is one contiguous range of the parameter block: ONE DMA packet into the pinned ring, ONE
     // synchronisation, then plain memcpys
     const size_t b_mu = sizeof(float) * 3 * J, b_cov = sizeof(float) * cov_elems(cov_type, J), b_w = sizeof(float) * J;
@@ -1930,6 +1971,45 @@ extern "C" int hgmm_flat_mstep(hgmm_ctx* c, int cov_type, int variant, int J, co
     std::memcpy(cov_out, h, b_cov);
     std::memcpy(mu_out, h + sizeof(float) * 3 * (size_t)f.Jpad, b_mu);
     std::memcpy(w_out, h + sizeof(float) * 6 * (size_t)f.Jpad, b_w);
+    return HGMM_OK;
+}
+
+// ---- elementwise float32 arithmetic on small device arrays -----------------------------------------------------
+// What `inv_cov = 1 / (xp.sqrt(covariances + 1e-6) + eps)` (gmm_impl.py:134) is under CuPy: a few tiny kernels on
+// device arrays, so that a caller's own EM loop never brings the parameters to the host.  IEEE float32 operations
+// (hipcc rounds fp32 divide and sqrt correctly by default): the results are bitwise NumPy's.
+__global__ void flat_elementwise_kernel(int op, int64_t n, const float* __restrict__ a, const float* __restrict__ b,
+                                        float s, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i];
+    const float y = b ? b[i] : s;
+    float r;
+    switch (op) {
+        case HGMM_EW_ADD: r = x + y; break;
+        case HGMM_EW_SUB: r = x - y; break;
+        case HGMM_EW_RSUB: r = y - x; break;
+        case HGMM_EW_MUL: r = x * y; break;
+        case HGMM_EW_DIV: r = x / y; break;
+        case HGMM_EW_RDIV: r = y / x; break;
+        case HGMM_EW_SQRT: r = sqrtf(x); break;
+        case HGMM_EW_EXP: r = expf(x); break;
+        case HGMM_EW_LOG: r = logf(x); break;
+        case HGMM_EW_MAX: r = fmaxf(x, y); break;
+        case HGMM_EW_MIN: r = fminf(x, y); break;
+        default: r = x; break;
+    }
+    out[i] = r;
+}
+extern "C" int hgmm_elementwise_f32(hgmm_ctx* c, int op, int64_t n, const float* dev_a, const float* dev_b,
+                                    float scalar, float* dev_out) {
+    if (!c) return HGMM_ERR_ARG;
+    if (op < 0 || op > HGMM_EW_MIN) return fail(c, HGMM_ERR_ARG, "elementwise op %d", op);
+    if (n < 0 || (n > 0 && (!dev_a || !dev_out))) return fail(c, HGMM_ERR_ARG, "elementwise: NULL array");
+    if (n == 0) return HGMM_OK;
+    HGMM_HIP(c, hipSetDevice(c->device));
+    flat_elementwise_kernel<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(op, n, dev_a, dev_b, scalar, dev_out);
+    HGMM_HIP(c, hipGetLastError());
     return HGMM_OK;
 }
 

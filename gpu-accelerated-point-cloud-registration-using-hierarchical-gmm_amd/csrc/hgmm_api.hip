@@ -367,6 +367,8 @@ extern "C" int hgmm_destroy(hgmm_ctx* c) {
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+    for (hipEvent_t& e : c->ev_slots) if (e) (void)hipEventDestroy(e);
     if (c->tree_hctl) { (void)hipHostFree(c->tree_hctl); (void)hipEventDestroy(c->tree_ev[0]); (void)hipEventDestroy(c->tree_ev[1]); }
     for (auto& p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     (void)hipStreamDestroy(c->stream);
@@ -406,6 +408,40 @@ extern "C" int hgmm_free(hgmm_ctx* c, void* dev) {
     if (!dev) return HGMM_OK;
     HGMM_HIP(c, hipStreamSynchronize(c->stream));
     HGMM_HIP(c, hipFree(dev));
+    return HGMM_OK;
+}
+extern "C" int hgmm_host_scalars(hgmm_ctx* c, int count, double** host_out, double** dev_out) {
+    if (!c || !host_out || !dev_out) return c ? fail(c, HGMM_ERR_ARG, "hgmm_host_scalars: NULL output") : HGMM_ERR_ARG;
+    if (count < 1 || count > 4096) return fail(c, HGMM_ERR_ARG, "hgmm_host_scalars: count %d outside 1..4096", count);
+    HGMM_HIP(c, hipSetDevice(c->device));
+    if (!c->h_scalars) {
+        void* p = nullptr;
+        HGMM_HIP(c, hipHostMalloc(&p, sizeof(double) * (size_t)count, hipHostMallocMapped));
+        std::memset(p, 0, sizeof(double) * (size_t)count);
+        c->h_scalars = static_cast<double*>(p);
+        c->h_scalars_n = count;
+    } else if (count > c->h_scalars_n) {
+        return fail(c, HGMM_ERR_STATE, "hgmm_host_scalars: the array already exists with %d entries", c->h_scalars_n);
+    }
+    void* d = nullptr;
+    HGMM_HIP(c, hipHostGetDevicePointer(&d, c->h_scalars, 0));
+    *host_out = c->h_scalars;
+    *dev_out = static_cast<double*>(d);
+    return HGMM_OK;
+}
+extern "C" int hgmm_event_record(hgmm_ctx* c, int slot) {
+    if (!c) return HGMM_ERR_ARG;
+    if (slot < 0 || slot >= HGMM_EVENT_SLOTS) return fail(c, HGMM_ERR_ARG, "event slot %d", slot);
+    HGMM_HIP(c, hipSetDevice(c->device));
+    if (!c->ev_slots[slot]) HGMM_HIP(c, hipEventCreateWithFlags(&c->ev_slots[slot], hipEventDisableTiming));
+    HGMM_HIP(c, hipEventRecord(c->ev_slots[slot], c->stream));
+    return HGMM_OK;
+}
+extern "C" int hgmm_event_wait(hgmm_ctx* c, int slot) {
+    if (!c) return HGMM_ERR_ARG;
+    if (slot < 0 || slot >= HGMM_EVENT_SLOTS) return fail(c, HGMM_ERR_ARG, "event slot %d", slot);
+    if (!c->ev_slots[slot]) return fail(c, HGMM_ERR_STATE, "event slot %d was never recorded", slot);
+    HGMM_HIP(c, hipEventSynchronize(c->ev_slots[slot]));
     return HGMM_OK;
 }
 extern "C" int hgmm_h2d(hgmm_ctx* c, void* dev_dst, const void* host_src, size_t bytes) {

@@ -79,6 +79,9 @@ struct hgmm_ctx {
     hgmm::DevBuf scratch;
     // pinned host ring for small parameter uploads / result downloads (flat_kernels.hip: stage_*): a pageable
     // hipMemcpyAsync is staged by the runtime behind the stream's pending work, a pinned one is a plain DMA packet
+    double* h_scalars = nullptr;              // pinned, device-visible scalars (hgmm_host_scalars)
+    int h_scalars_n = 0;
+    hipEvent_t ev_slots[64] = {};             // hgmm_event_record / hgmm_event_wait
     void* h_stage = nullptr;
     size_t h_stage_cap = 0, h_stage_off = 0;
 

@@ -80,6 +80,27 @@ int hgmm_alloc(hgmm_ctx* ctx, size_t bytes, void** dev_out);
 int hgmm_free(hgmm_ctx* ctx, void* dev);
 int hgmm_h2d(hgmm_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);
 int hgmm_d2h(hgmm_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
+/* Host-visible scalars: `count` doubles (<= 4096) of pinned host memory owned by the context that kernels write
+ * directly (dev_out is the address they use, host_out the one the host reads).  With an event recorded behind the
+ * producing kernel a value is read without draining the stream: what a 0-d CuPy array is to the reference's loops
+ * (`lower_bound = log_prob_norm`, gmm_impl.py:136, read by `abs(change) < tol` while the M-step is still running).
+ * The same array is returned on every call (count only grows it before its first use). */
+int hgmm_host_scalars(hgmm_ctx* ctx, int count, double** host_out, double** dev_out);
+/* 64 event slots on the context's stream: record marks the work enqueued so far, wait blocks the host until that
+ * work (and only that) is done. */
+#define HGMM_EVENT_SLOTS 64
+int hgmm_event_record(hgmm_ctx* ctx, int slot);
+int hgmm_event_wait(hgmm_ctx* ctx, int slot);
+/* Elementwise float32 arithmetic on device arrays, enqueued on the context's stream (IEEE: bitwise NumPy's results
+ * for + - * / sqrt): out[i] = a[i] op (dev_b ? dev_b[i] : scalar); RSUB / RDIV take the operands the other way round;
+ * SQRT / EXP / LOG ignore the second operand.  out may alias a or b.  This is the `inv_cov = 1 / (xp.sqrt(covariances
+ * + 1e-6) + eps)` of a caller's own EM loop (gmm_impl.py:134) without a trip to the host. */
+enum hgmm_elementwise_op {
+    HGMM_EW_ADD = 0, HGMM_EW_SUB = 1, HGMM_EW_RSUB = 2, HGMM_EW_MUL = 3, HGMM_EW_DIV = 4, HGMM_EW_RDIV = 5,
+    HGMM_EW_SQRT = 6, HGMM_EW_EXP = 7, HGMM_EW_LOG = 8, HGMM_EW_MAX = 9, HGMM_EW_MIN = 10
+};
+int hgmm_elementwise_f32(hgmm_ctx* ctx, int op, int64_t n, const float* dev_a, const float* dev_b, float scalar,
+                         float* dev_out);
 
 /* ---- point cloud ------------------------------------------------------------------
  * Replaces `dev_X = cupy.asarray(X.astype(np.float32))` (gmm_waymo/src/gmm.py:73) and
@@ -109,6 +130,17 @@ int hgmm_flat_estep(hgmm_ctx* ctx, int cov_type, int variant, int J,
 int hgmm_flat_estep_async(hgmm_ctx* ctx, int cov_type, int variant, int J,
                           const float* mu, const float* inv_std, const float* w,
                           float* dev_log_resp, float* dev_lpn, int32_t* dev_argmax, double* dev_mean_lpn);
+/* E-step / M-step with the PARAMETERS in device arrays (dense, the host layouts: mu [J,3], inv_std / cov [J,3] or
+ * [J], w [J]) -- what the reference's functions are when they are handed CuPy arrays (`xp = cupy.get_array_module(X)`,
+ * gmm_impl.py:91, 106): nothing is staged, nothing is downloaded, nothing waits.  hgmm_flat_mstep_dev writes the new
+ * parameters to the caller's device arrays; dev_centre_hint may be NULL.  dev_mean_lpn may be a host-visible scalar
+ * (hgmm_host_scalars). */
+int hgmm_flat_estep_dev(hgmm_ctx* ctx, int cov_type, int variant, int J,
+                        const float* dev_mu, const float* dev_inv_std, const float* dev_w,
+                        float* dev_log_resp, float* dev_lpn, int32_t* dev_argmax, double* dev_mean_lpn);
+int hgmm_flat_mstep_dev(hgmm_ctx* ctx, int cov_type, int variant, int J,
+                        const float* dev_resp, int is_log, const float* dev_centre_hint,
+                        float* dev_w, float* dev_mu, float* dev_cov);
 /* Un-normalised per-pair log-densities log N(x_i; mu_j, diag) -> dev_log_prob [N,J]
  * (estimate_log_prob / estimate_log_prob_spherical, gmm_waymo gmm_impl.py:53-78). */
 int hgmm_flat_log_prob(hgmm_ctx* ctx, int cov_type, int J, const float* mu, const float* inv_std,

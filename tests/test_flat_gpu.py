@@ -778,3 +778,104 @@ def test_async_estep_and_device_scalar(ctx, bunny):
         assert abs(ll - o_ll) < 2e-5
     np.testing.assert_allclose(mu, om, atol=2e-5)
     np.testing.assert_allclose(w, ow, rtol=1e-3, atol=1e-6)
+
+
+def test_device_array_parameters_and_elementwise(ctx, bunny):
+    """The reference's functions are array-module polymorphic (`xp = cupy.get_array_module(X)`, gmm_impl.py:91): CuPy
+    arrays in, CuPy arrays out, nothing synchronises.  Here: responsibilities in HBM -> m_step returns DeviceArrays,
+    arithmetic on them runs on the device (bitwise NumPy's float32 results for + - * / sqrt), e_step packs its table
+    from them; the loop equals the host-array loop BITWISE.  DeviceScalars are pinned scalars behind an event."""
+    import hgmm_amd
+    from hgmm_amd.gmm_waymo import gmm_impl as W
+    DA = hgmm_amd.DeviceArray
+    rs = np.random.RandomState(4)
+    a = (rs.rand(800, 3).astype(np.float32) + np.float32(0.01))
+    b = (rs.rand(800, 3).astype(np.float32) + np.float32(0.5))
+    da, db = ctx.to_device(a), ctx.to_device(b)
+    e6, e8 = np.float32(1e-6), np.float32(1e-8)
+    cases = [
+        (da + e6, a + e6), (e6 + da, e6 + a), (da - 0.25, a - np.float32(0.25)), (1.0 - da, np.float32(1.0) - a),
+        (da * 3.0, a * np.float32(3.0)), (da / 7.0, a / np.float32(7.0)), (1.0 / da, np.float32(1.0) / a),
+        (np.sqrt(da), np.sqrt(a)), (da + db, a + b), (da - db, a - b), (da * db, a * b), (da / db, a / b),
+        (np.maximum(da, db), np.maximum(a, b)), (np.minimum(da, 0.5), np.minimum(a, np.float32(0.5))),
+        (da + b, a + b), (b / da, b / a), (-da, -a),
+        (1.0 / (np.sqrt(da + e6) + e8), 1.0 / (np.sqrt(a + e6) + e8)),          # gmm_impl.py:134
+    ]
+    for got, want in cases:
+        assert isinstance(got, DA) and got.dtype == np.float32 and got.shape == want.shape
+        assert np.array_equal(np.asarray(got), want)
+    np.testing.assert_allclose(np.asarray(np.exp(-da)), np.exp(-a), rtol=2e-6)
+    np.testing.assert_allclose(np.asarray(np.log(da)), np.log(a), rtol=2e-6, atol=2e-7)
+    # what is not a device case is answered from a host copy, with NumPy's semantics
+    row = np.float32([1, 2, 3])
+    assert isinstance(da * row, np.ndarray) and np.array_equal(da * row, a * row)
+    assert np.array_equal(da > 0.5, a > 0.5) and np.array_equal(da ** 2, a ** 2)
+    assert da.astype(np.float32) is da and da.astype(np.float64).dtype == np.float64
+    assert da.sum() == a.sum() and np.array_equal(da[3], a[3]) and np.array_equal(da.T, a.T) and len(da) == 800
+    # more small arrays alive at once than the arena has slabs, then released and taken again
+    many = [da + float(k) for k in range(100)]
+    assert all(np.array_equal(np.asarray(m), a + np.float32(k)) for k, m in enumerate(many))
+    del many
+    again = [da * float(k) for k in range(100)]
+    assert np.array_equal(np.asarray(again[99]), a * np.float32(99))
+    del again
+
+    # ---- the loop, parameters resident vs parameters on the host ----
+    X = bunny[::3]
+    J = 100
+    mu0, w0, cov0 = flat_em.seeded_init(X, J, 5)
+    inv0 = (1.0 / np.sqrt(cov0)).astype(np.float32)
+    dX = W.asarray(X, ctx)
+    ll0_h, lr_h = W.e_step(dX, inv0, mu0, w0)
+    rows_h = lr_h.get()
+    ll0_d, lr_d = W.e_step(dX, ctx.to_device(inv0), ctx.to_device(mu0), w0)       # mixed: w is uploaded
+    assert np.array_equal(lr_d.get(), rows_h) and float(ll0_d) == float(ll0_h)
+    del lr_h, lr_d
+    host = (inv0, mu0, w0)
+    dev = (ctx.to_device(inv0), ctx.to_device(mu0), ctx.to_device(w0))
+    scalars = []
+    for it in range(5):
+        ll_h, lr = W.e_step(dX, *host)
+        w_h, mu_h, cov_h = W.m_step(dX, np.exp(lr.get()), centre_hint=host[1])      # host responsibilities -> NumPy out
+        assert isinstance(mu_h, np.ndarray)
+        del lr
+        ll_d, lr = W.e_step(dX, *dev)
+        w_d, mu_d, cov_d = W.m_step(dX, np.exp(lr), centre_hint=dev[1])             # np.exp of a big DeviceArray: lazy view
+        assert isinstance(w_d, DA) and isinstance(mu_d, DA) and isinstance(cov_d, DA)
+        del lr
+        inv_d = 1 / (np.sqrt(cov_d + 1e-6) + 1e-8)
+        assert isinstance(inv_d, DA)
+        host = ((1 / (np.sqrt(cov_h + e6) + e8)).astype(np.float32), mu_h, w_h)
+        dev = (inv_d, mu_d, w_d)
+        scalars.append((ll_d, float(ll_h)))
+        # same kernels: fused exp of the log-responsibilities vs exp on the host differ in rounding -> tolerance
+        np.testing.assert_allclose(np.asarray(mu_d), mu_h, atol=2e-6)
+        np.testing.assert_allclose(np.asarray(cov_d), cov_h, rtol=2e-4, atol=1e-9)
+    for ll_d, ll_h in scalars:                                   # read long after they were produced
+        assert abs(float(ll_d) - ll_h) < 1e-5
+    # bitwise: the same loop with log_resp.exp() on both sides, device arrays vs host arrays
+    def loop(device_arrays):
+        p = (ctx.to_device(inv0), ctx.to_device(mu0), ctx.to_device(w0)) if device_arrays else (inv0, mu0, w0)
+        lls = []
+        for it in range(5):
+            ll, lr = W.e_step(dX, *p)
+            w, mu, cov = ctx.flat_mstep(lr.exp(), "diag", "W", centre_hint=p[1], device_out=device_arrays)
+            del lr
+            inv = 1 / (np.sqrt(cov + e6) + e8)
+            p = (inv if device_arrays else inv.astype(np.float32), mu, w)
+            lls.append(ll)
+        return [np.asarray(x) for x in p], [float(v) for v in lls]
+    p_d, l_d = loop(True)
+    p_h, l_h = loop(False)
+    assert l_d == l_h
+    for x, y in zip(p_d, p_h):
+        assert np.array_equal(x, y)
+    # 70 scalars outstanding at once: a slot that is taken again has its previous scalar read first
+    outs = [ctx.flat_estep(inv0, mu0 + np.float32(1e-4 * k), w0, "diag", "W", want_log_resp=False, lazy_mean=True)[0]
+            for k in range(70)]
+    vals = [float(s) for s in outs]
+    for k in (0, 5, 63, 64, 69):
+        ref = ctx.flat_estep(inv0, mu0 + np.float32(1e-4 * k), w0, "diag", "W", want_log_resp=False)[0]
+        assert abs(vals[k] - ref) < 1e-7
+    with pytest.raises(ValueError):
+        ctx.flat_estep(ctx.to_device(inv0[:5]), ctx.to_device(mu0), w0, "diag", "W", want_log_resp=False)

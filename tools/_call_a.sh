@@ -1,5 +1,8 @@
 set -u
 export TMPDIR=/tmp
-for r in 1 2 3; do
-for v in 0 1; do echo "NO_REL=$v"; HGMM_TREE_NO_REL=$v timeout 100 python tools/c4prof.py both 6 2>&1 | tail -2; done
-done
+timeout 900 python -m pytest tests/test_flat_gpu.py -m gpu -q -x --timeout 600 -k "device_array or async_estep or function_level or dropin or module" 2>&1 | tail -30
+timeout 300 python bench.py 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline())
+print(json.dumps(d['materialised_iteration'], indent=1)[:3000]); print(d['value'], d['roofline']['frac'])
+"
