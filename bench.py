@@ -402,6 +402,16 @@ def estep_roofline_leg(ctx, lr, init, fitted, args):
     ctx.profile_enable(False)
     e_ms, e_n = ctx.profile_get("flat_estep")
     avg_s = e_ms / e_n * 1e-3
+    # the same launches as a STREAM nobody waits for (hgmm_flat_estep_async): no idle moment between two launches
+    for timed in (False, True):
+        ctx.profile_reset()
+        ctx.profile_enable(timed)
+        for _ in range(args.estep_reps):
+            ctx.flat_estep(inv, mu, w, "diag", "W", out=lr, lazy_mean=True)
+        ctx.synchronize()
+    ctx.profile_enable(False)
+    s_ms, s_n = ctx.profile_get("flat_estep")
+    stream_s = s_ms / max(s_n, 1) * 1e-3
     alg_bytes = 12 * N_POINTS + 4 * N_POINTS * J_COMP + 4 * N_POINTS + 28 * J_COMP
     achieved = alg_bytes / avg_s / 1e9
     traffic, traffic_source = None, None
@@ -418,7 +428,12 @@ def estep_roofline_leg(ctx, lr, init, fitted, args):
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": e_n,
-            "steady_state_rule": "40 untimed launches (15 of them the cold ones below) precede the timed ones",
+            "steady_state_rule": "40 untimed launches (15 of them the cold ones below) precede the timed ones; every "
+                                 "launch is a blocking hgmm_flat_estep call (the host reads the mean, ~25 us idle)",
+            "unsynchronised_stream_avg_ms": stream_s * 1e3,
+            "unsynchronised_stream_frac": alg_bytes / stream_s / 1e9 / HBM_PEAK_GBS if stream_s else None,
+            "unsynchronised_stream_rule": "the same launches enqueued back to back (hgmm_flat_estep_async), nothing "
+                                          "waits in between: the chip runs at its sustained clocks",
             "first_launch_ms": cold[0], "cold_avg_ms": cold_avg, "cold_max_ms": float(np.max(cold)),
             "cold_frac": alg_bytes / (cold_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "cold_rule": "15 launches timed one by one (hipEvents) straight after a 50-iteration fused fit"}

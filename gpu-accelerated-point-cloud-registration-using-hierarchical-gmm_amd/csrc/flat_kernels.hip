@@ -1411,7 +1411,7 @@ static int stage_reserve(hgmm_ctx* c, size_t bytes, void** out) {
     bytes = (bytes + 255) & ~(size_t)255;
     if (bytes > c->h_stage_cap) return fail(c, HGMM_ERR_ARG, "staging request of %zu bytes", bytes);
     if (c->h_stage_off + bytes > c->h_stage_cap) {
-        HGMM_HIP(c, hipStreamSynchronize(c->stream));         // every earlier region has been consumed
+        HGMM_HIP(c, ctx_stream_sync(c));         // every earlier region has been consumed
         c->h_stage_off = 0;
     }
     *out = static_cast<char*>(c->h_stage) + c->h_stage_off;
@@ -1537,9 +1537,13 @@ static bool launch_estep_rows(hgmm_ctx* c, int nv4, int nv1, int grid_r, bool cs
 // issue-bound side of the kernel pays for it -- while two workgroups per CU take 0.60 ms there
 // (tools/em_loop_probe.py, profiles/r03/em_loop_probe.log: 160 / 192 / 224 / 256 / 320 / 384 / 512 workgroups behind an
 // M-step: 0.94 / 0.81 / 0.74 / 0.69 / 0.59 / 0.60 / 0.60 ms; alone: 0.63 / 0.54 / 0.54 / 0.56 / 0.70 / 0.61 / 0.57).
-// The grid therefore follows what the context enqueued last: behind an M-step two workgroups per CU, otherwise 3/4.
+// The same holds for a STREAM of E-steps that nobody waits for (hgmm_flat_estep_async / _dev back to back): 0.70 ms at
+// 192 workgroups, 0.62 at 512 -- the 0.54 of the 3/4 grid needs the ~25 us of idle time a blocking call leaves behind
+// every launch (tools/em_loop_probe2.py, profiles/r03/em_loop_probe2.log).
+// The grid therefore follows what the context did last: behind an M-step, or behind an E-step the host has not
+// waited for, two workgroups per CU; after an idle moment 3/4 of the CUs.
 static int estep_rows_grid(hgmm_ctx* c, bool cshift) {
-    const bool after_mstep = c->flat.last_kernel == 2;
+    const bool after_mstep = c->flat.last_kernel == 2 || (c->flat.last_kernel == 1 && !c->flat.idle_since_launch);
     const int full = grid_for(c, (c->n + 3) / 4, env_int("HGMM_ESTEP_BPC", after_mstep ? 2 : 1));
     if (env_int("HGMM_ESTEP_GRID", 0) > 0) return std::min(full, env_int("HGMM_ESTEP_GRID", 0));
     if (after_mstep) return full;
@@ -1564,6 +1568,7 @@ static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argma
         const bool cshift = env_flag("HGMM_ESTEP_CS", true) && !argmax;
         const int grid_r = estep_rows_grid(c, cshift);
         c->flat.last_kernel = 1;
+        c->flat.idle_since_launch = false;
         ProfScope prof(c, HGMM_K_FLAT_ESTEP);
         if (launch_estep_rows(c, nv4, nv1, grid_r, cshift, log_resp, lpn, argmax)) {
             *grid_out = grid_r;
@@ -1811,7 +1816,7 @@ extern "C" int hgmm_flat_estep(hgmm_ctx* c, int cov_type, int variant, int J, co
         std::vector<double> h(grid);
         HGMM_HIP(c, hipMemcpyAsync(h.data(), c->f_lpn_partials.p, sizeof(double) * grid,
                                    hipMemcpyDeviceToHost, c->stream));
-        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+        HGMM_HIP(c, ctx_stream_sync(c));
         double t = 0.0;
         for (double v : h) t += v;
         *mean_lpn_out = t / (double)c->n;
@@ -1867,7 +1872,7 @@ extern "C" int hgmm_flat_log_prob(hgmm_ctx* c, int cov_type, int J, const float*
     HGMM_TRY(flat_setup(c, cov_type, HGMM_VARIANT_G, J));
     std::vector<float> ones((size_t)J, 1.0f);
     HGMM_TRY(flat_upload(c, mu, inv_std, false, ones.data()));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));   // `ones` is pageable host memory
+    HGMM_HIP(c, ctx_stream_sync(c));   // `ones` is pageable host memory
     launch_pack(c);
     int grid = 0;
     if (c->flat.chunked) {
@@ -1928,6 +1933,7 @@ static int flat_mstep_enqueue(hgmm_ctx* c, int cov_type, int variant, int J, con
     }
     HGMM_HIP(c, hipGetLastError());
     c->flat.last_kernel = 2;                               // (the next E-step's grid looks at this, estep_rows_grid)
+    c->flat.idle_since_launch = false;
     HGMM_TRY(launch_reduce(c, grid, valid_j, false, nullptr));
     if (f.chunked)
         flat_finalize_mb_kernel<<<(f.Jpad + 255) / 256, 256, 0, c->stream>>>(
@@ -1966,7 +1972,7 @@ extern "C" int hgmm_flat_mstep(hgmm_ctx* c, int cov_type, int variant, int J, co
     HGMM_TRY(stage_reserve(c, span, &st));
     char* h = static_cast<char*>(st);
     HGMM_HIP(c, hipMemcpyAsync(h, c->f_cov.p, span, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     c->h_stage_off = 0;                                    // the stream is idle: every region of the ring is free
     std::memcpy(cov_out, h, b_cov);
     std::memcpy(mu_out, h + sizeof(float) * 3 * (size_t)f.Jpad, b_mu);
@@ -2059,7 +2065,7 @@ extern "C" int hgmm_flat_train_end(hgmm_ctx* c, float* mu, float* cov, float* w,
     if (cov) HGMM_HIP(c, hipMemcpyAsync(cov, c->f_cov.p, sizeof(float) * cov_elems(f.cov_type, J), hipMemcpyDeviceToHost, c->stream));
     if (w) HGMM_HIP(c, hipMemcpyAsync(w, c->f_w.p, sizeof(float) * J, hipMemcpyDeviceToHost, c->stream));
     if (inv_std_out) HGMM_HIP(c, hipMemcpyAsync(inv_std_out, c->f_inv.p, sizeof(float) * cov_elems(f.cov_type, J), hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     const int n_it = ctl[1];
     if (lls_out && n_it > 0) {
         const int cnt = n_it < f.lls_cap ? n_it : f.lls_cap;
@@ -2102,7 +2108,7 @@ extern "C" int hgmm_flat_stats(hgmm_ctx* c, int cov_type, int variant, int J, co
     const FlatState& f = c->flat;
     std::vector<double> h((size_t)FLAT_NSTAT * f.Jpad + 2);
     HGMM_HIP(c, hipMemcpyAsync(h.data(), c->f_stats.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     if (stats_out)
         for (int j = 0; j < J; ++j)
             for (int s = 0; s < FLAT_NSTAT; ++s) stats_out[(size_t)j * FLAT_NSTAT + s] = h[(size_t)s * f.Jpad + j];

@@ -99,7 +99,7 @@ extern "C" int hgmm_gauss_transform(hgmm_ctx* c, const double* centres, int n_ce
     HGMM_HIP(c, hipGetLastError());
     std::vector<double> part(part_doubles);
     HGMM_HIP(c, hipMemcpyAsync(part.data(), d_part, sizeof(double) * part_doubles, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     const size_t row = (size_t)n_weights * n_points;
     for (size_t e = 0; e < row; ++e) {
         double s = 0.0;

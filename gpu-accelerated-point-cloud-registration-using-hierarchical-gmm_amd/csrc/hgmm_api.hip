@@ -23,7 +23,7 @@ static std::mutex g_mu;
 int ensure(hgmm_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes <= b.cap && b.p) return HGMM_OK;
     if (b.p) {
-        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+        HGMM_HIP(c, ctx_stream_sync(c));
         HGMM_HIP(c, hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -52,7 +52,7 @@ ProfScope::~ProfScope() {
 
 int profile_collect(hgmm_ctx* c) {
     if (c->events_used == 0) return HGMM_OK;
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     for (size_t i = 0; i < c->events_used; ++i) {
         float ms = 0.f;
         EventPair& p = c->events[i];
@@ -113,7 +113,7 @@ static int hostcomm_allreduce_dev(hgmm_ctx* c, double* dev, size_t n, int op) {
         const size_t cnt = std::min(HOSTCOMM_SLOT, n - off);
         double* mine = h->data + (size_t)c->rank * HOSTCOMM_SLOT;
         HGMM_HIP(c, hipMemcpyAsync(mine, dev + off, sizeof(double) * cnt, hipMemcpyDeviceToHost, c->stream));
-        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+        HGMM_HIP(c, ctx_stream_sync(c));
         HGMM_TRY(hostcomm_barrier(c));
         h->tmp.resize(cnt);
         if (op == 2) {                                      // the words are int64: exact sums
@@ -135,7 +135,7 @@ static int hostcomm_allreduce_dev(hgmm_ctx* c, double* dev, size_t n, int op) {
         }
         HGMM_TRY(hostcomm_barrier(c));                     // everybody has read the slots
         HGMM_HIP(c, hipMemcpyAsync(dev + off, h->tmp.data(), sizeof(double) * cnt, hipMemcpyHostToDevice, c->stream));
-        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+        HGMM_HIP(c, ctx_stream_sync(c));
     }
     return HGMM_OK;
 }
@@ -354,7 +354,7 @@ extern "C" int hgmm_create(int device_id, hgmm_ctx** out) {
 extern "C" int hgmm_destroy(hgmm_ctx* c) {
     if (!c) return HGMM_OK;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)ctx_stream_sync(c);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     hostcomm_close(c);
     DevBuf* bufs[] = {&c->x_aos, &c->x_soa64, &c->f_block, &c->f_pack,
@@ -393,7 +393,7 @@ extern "C" int hgmm_device_info(hgmm_ctx* c, char* name, int name_len, int* comp
 
 extern "C" int hgmm_synchronize(hgmm_ctx* c) {
     if (!c) return HGMM_ERR_ARG;
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     return HGMM_OK;
 }
 
@@ -406,7 +406,7 @@ extern "C" int hgmm_alloc(hgmm_ctx* c, size_t bytes, void** dev_out) {
 extern "C" int hgmm_free(hgmm_ctx* c, void* dev) {
     if (!c) return HGMM_ERR_ARG;
     if (!dev) return HGMM_OK;
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     HGMM_HIP(c, hipFree(dev));
     return HGMM_OK;
 }
@@ -447,13 +447,13 @@ extern "C" int hgmm_event_wait(hgmm_ctx* c, int slot) {
 extern "C" int hgmm_h2d(hgmm_ctx* c, void* dev_dst, const void* host_src, size_t bytes) {
     if (!c) return HGMM_ERR_ARG;
     HGMM_HIP(c, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, c->stream));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     return HGMM_OK;
 }
 extern "C" int hgmm_d2h(hgmm_ctx* c, void* host_dst, const void* dev_src, size_t bytes) {
     if (!c) return HGMM_ERR_ARG;
     HGMM_HIP(c, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     return HGMM_OK;
 }
 
@@ -479,7 +479,7 @@ extern "C" int hgmm_set_points_f32(hgmm_ctx* c, const float* xyz, int64_t n) {
     aos_to_soa64_f32<<<(unsigned)((c->n_pad + 255) / 256), 256, 0, c->stream>>>(
         c->x_aos.as<float>(), n, c->n_pad, c->x_soa64.as<double>());
     HGMM_HIP(c, hipGetLastError());
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     c->have_f32 = c->have_f64 = true;
     return HGMM_OK;
 }
@@ -494,7 +494,7 @@ extern "C" int hgmm_set_points_f64(hgmm_ctx* c, const double* xyz, int64_t n) {
     f64_to_f32<<<(unsigned)((3 * n + 255) / 256), 256, 0, c->stream>>>(c->scratch.as<double>(), 3 * n,
                                                                       c->x_aos.as<float>());
     HGMM_HIP(c, hipGetLastError());
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     c->have_f32 = c->have_f64 = true;
     return HGMM_OK;
 }
@@ -584,14 +584,14 @@ extern "C" int hgmm_comm_init_host(hgmm_ctx* c, int nranks, int rank, const char
 extern "C" int hgmm_comm_destroy(hgmm_ctx* c) {
     if (!c) return HGMM_ERR_ARG;
     if (c->hcomm) {
-        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+        HGMM_HIP(c, ctx_stream_sync(c));
         (void)hostcomm_barrier(c);                          // nobody unlinks while a peer still reduces
         hostcomm_close(c);
         c->nranks = 1;
         c->rank = 0;
     }
     if (c->comm) {
-        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+        HGMM_HIP(c, ctx_stream_sync(c));
         HGMM_NCCL(c, ncclCommDestroy(c->comm));
         c->comm = nullptr;
         c->nranks = 1;
@@ -611,7 +611,7 @@ extern "C" int hgmm_comm_allreduce_f64(hgmm_ctx* c, double* host_inout, int n, i
         HGMM_NCCL(c, ncclAllReduce(c->comm_buf.p, c->comm_buf.p, (size_t)n, ncclDouble,
                                    op == 1 ? ncclMax : ncclSum, c->comm, c->stream));
     HGMM_HIP(c, hipMemcpyAsync(host_inout, c->comm_buf.p, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     return HGMM_OK;
 }
 

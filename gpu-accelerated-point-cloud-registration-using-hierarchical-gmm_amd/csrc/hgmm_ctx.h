@@ -37,6 +37,7 @@ struct FlatState {
     bool chunked = false;             // J > FLAT_MAX_J: 832-component chunks
     int nchunks = 1;
     int last_kernel = 0;              // what this context enqueued last: 1 materialising E-step, 2 M-step from resp, 3 fused EM
+    bool idle_since_launch = true;    // the host has drained the stream since the last of these launches (ctx_stream_sync)
 };
 
 struct HostComm;                           // hgmm_api.hip
@@ -77,11 +78,11 @@ struct hgmm_ctx {
     hgmm::DevBuf f_hint;                      // float [3][Jpad] centre hint for m-step
     hgmm::DevBuf f_cm, f_cs, f_ca, f_lpn2;    // chunked path: per-chunk (max, sum, arg-max) [C][n], lpn2 [n]
     hgmm::DevBuf scratch;
-    // pinned host ring for small parameter uploads / result downloads (flat_kernels.hip: stage_*): a pageable
-    // hipMemcpyAsync is staged by the runtime behind the stream's pending work, a pinned one is a plain DMA packet
     double* h_scalars = nullptr;              // pinned, device-visible scalars (hgmm_host_scalars)
     int h_scalars_n = 0;
     hipEvent_t ev_slots[64] = {};             // hgmm_event_record / hgmm_event_wait
+    // pinned host ring for small parameter uploads / result downloads (flat_kernels.hip: stage_*): a pageable
+    // hipMemcpyAsync is staged by the runtime behind the stream's pending work, a pinned one is a plain DMA packet
     void* h_stage = nullptr;
     size_t h_stage_cap = 0, h_stage_off = 0;
 
@@ -139,6 +140,15 @@ struct hgmm_ctx {
     double prof_ms[HGMM_K_COUNT] = {0};
     int64_t prof_n[HGMM_K_COUNT] = {0};
 };
+
+// Every wait for the context's stream goes through here: the E-step's grid policy (flat_kernels.hip, estep_rows_grid)
+// wants to know whether the chip has been idle since the last bandwidth-bound launch.
+inline hipError_t ctx_stream_sync(hgmm_ctx* c) {
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    c->flat.idle_since_launch = true;
+    return e;
+}
+
 
 namespace hgmm {
 

@@ -937,7 +937,7 @@ extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const 
     if (ids_out) HGMM_HIP(c, hipMemcpyAsync(ids_out, ids, sizeof(int64_t) * k, hipMemcpyDeviceToHost, c->stream));
     if (centers_out)
         HGMM_HIP(c, hipMemcpyAsync(centers_out, centres, sizeof(double) * 3 * k, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     return HGMM_OK;
 }
 
@@ -1027,7 +1027,7 @@ extern "C" int hgmm_kmeans_step(hgmm_ctx* c, int k, const double* centers, int r
     std::vector<double> tail(2);
     if (sums_out) HGMM_HIP(c, hipMemcpyAsync(sums_out, L.out, sizeof(double) * 4 * k, hipMemcpyDeviceToHost, c->stream));
     HGMM_HIP(c, hipMemcpyAsync(tail.data(), L.out + 4 * (size_t)k, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     if (inertia_out) *inertia_out = tail[0];
     if (n_changed_out) *n_changed_out = (int64_t)tail[1];
     return HGMM_OK;
@@ -1060,7 +1060,7 @@ extern "C" int hgmm_kmeans_lloyd(hgmm_ctx* c, int k, double* centers_inout, int 
         }
         HGMM_HIP(c, hipGetLastError());
         HGMM_HIP(c, hipMemcpyAsync(&h, L.ctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
-        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+        HGMM_HIP(c, ctx_stream_sync(c));
     }
     HGMM_HIP(c, hipMemcpyAsync(centers_inout, L.c3, sizeof(double) * 3 * k, hipMemcpyDeviceToHost, c->stream));
     if (h.needs_host) {
@@ -1069,10 +1069,10 @@ extern "C" int hgmm_kmeans_lloyd(hgmm_ctx* c, int k, double* centers_inout, int 
         if (sums_out)
             HGMM_HIP(c, hipMemcpyAsync(sums_out, L.out, sizeof(double) * 4 * k, hipMemcpyDeviceToHost, c->stream));
         HGMM_HIP(c, hipMemcpyAsync(tail.data(), L.out + 4 * (size_t)k, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
-        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+        HGMM_HIP(c, ctx_stream_sync(c));
         if (n_changed_out) *n_changed_out = (int64_t)tail[1];
     }
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     if (n_iter_out) *n_iter_out = h.it;
     if (strict_out) *strict_out = h.strict;
     if (needs_host_out) *needs_host_out = h.needs_host;
@@ -1087,6 +1087,6 @@ extern "C" int hgmm_kmeans_labels(hgmm_ctx* c, int32_t* labels_out, double* min_
         HGMM_HIP(c, hipMemcpyAsync(labels_out, c->km_labels.p, sizeof(int32_t) * c->n, hipMemcpyDeviceToHost, c->stream));
     if (min_dist2_out)
         HGMM_HIP(c, hipMemcpyAsync(min_dist2_out, c->km_mind2.p, sizeof(double) * c->n, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     return HGMM_OK;
 }

@@ -1450,7 +1450,7 @@ static int ensure_exp_tab2(hgmm_ctx* c) {
     std::vector<double> h(EXP_TAB2_N);
     for (int j = 0; j < EXP_TAB2_N; ++j) h[j] = (double)exp2l((long double)j / (long double)EXP_TAB2_N);
     HGMM_HIP(c, hipMemcpyAsync(c->exp_tab2.p, h.data(), sizeof(double) * EXP_TAB2_N, hipMemcpyHostToDevice, c->stream));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));              // `h` is pageable host memory
+    HGMM_HIP(c, ctx_stream_sync(c));              // `h` is pageable host memory
     return HGMM_OK;
 }
 
@@ -1752,10 +1752,10 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                 if (at >= q_capacity) break;
             }
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = ctx_stream_sync(c);
         if (e != hipSuccess) rc = fail(c, HGMM_ERR_HIP, "tree build: download failed: %s", hipGetErrorString(e));
     } else {
-        (void)hipStreamSynchronize(c->stream);
+        (void)ctx_stream_sync(c);
     }
     cleanup();
     if (q_len_out) *q_len_out = q_len < q_capacity ? q_len : q_capacity;
@@ -1773,7 +1773,7 @@ extern "C" int hgmm_tree_set_nodes(hgmm_ctx* c, int L, const double* pi, const d
     HGMM_HIP(c, hipMemcpyAsync(c->t_mu.p, mu, sizeof(double) * 3 * T, hipMemcpyHostToDevice, c->stream));
     HGMM_HIP(c, hipMemcpyAsync(c->t_cov.p, cov, sizeof(double) * 9 * T, hipMemcpyHostToDevice, c->stream));
     HGMM_TRY(tree_prep(c, 0, T));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     double m2max = 0.0;
     for (int64_t j = 0; j < T; ++j) {
         const double v = mu[3 * j] * mu[3 * j] + mu[3 * j + 1] * mu[3 * j + 1] + mu[3 * j + 2] * mu[3 * j + 2];
@@ -1799,7 +1799,7 @@ extern "C" int hgmm_tree_set_target(hgmm_ctx* c, const double* xyz, int64_t n) {
     }
     c->tgt_rmax = std::sqrt(r2max);
     HGMM_HIP(c, hipMemcpyAsync(c->tgt_soa64.p, soa.data(), sizeof(double) * soa.size(), hipMemcpyHostToDevice, c->stream));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     c->tgt_n = n;
     c->tgt_pad = n_pad;
     return HGMM_OK;
@@ -1822,7 +1822,7 @@ static int reg_estep_fixed(hgmm_ctx* c, const double* rot, const double* t, doub
     if (c->tree.mu_rmax < 0.0) {                                  // tree built on the device: means not seen by the host
         std::vector<double> mu((size_t)3 * T);
         HGMM_HIP(c, hipMemcpyAsync(mu.data(), c->t_mu.p, sizeof(double) * 3 * T, hipMemcpyDeviceToHost, c->stream));
-        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+        HGMM_HIP(c, ctx_stream_sync(c));
         double m2 = 0.0;
         for (int64_t j = 0; j < T; ++j) {
             const double v = mu[3 * j] * mu[3 * j] + mu[3 * j + 1] * mu[3 * j + 1] + mu[3 * j + 2] * mu[3 * j + 2];
@@ -1892,7 +1892,7 @@ extern "C" int hgmm_tree_reg_estep(hgmm_ctx* c, const double* rot, const double*
     if (m0_out) HGMM_HIP(c, hipMemcpyAsync(m0_out, e0, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
     if (m1_out) HGMM_HIP(c, hipMemcpyAsync(m1_out, e1, sizeof(double) * 3 * T, hipMemcpyDeviceToHost, c->stream));
     if (m2_out) HGMM_HIP(c, hipMemcpyAsync(m2_out, e2, sizeof(double) * 9 * T, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     return HGMM_OK;
 }
 
@@ -1909,7 +1909,7 @@ extern "C" int hgmm_tree_reg_normal(hgmm_ctx* c, const double* rot, const double
     HGMM_HIP(c, hipGetLastError());
     c->tree.momq_dirty = false;                                   // the kernel zeroed the [T][4] words it consumed
     HGMM_HIP(c, hipMemcpyAsync(out28, c->scratch.p, sizeof(double) * 28, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     return HGMM_OK;
 }
 
@@ -2042,7 +2042,7 @@ extern "C" int hgmm_tree_node_complexity(hgmm_ctx* c, double* cplx_out) {
     tree_copy_cplx_kernel<<<nblk(T, 256), 256, 0, c->stream>>>(c->t_prep.as<double>(), T, c->t_cplx.as<double>());
     HGMM_HIP(c, hipGetLastError());
     HGMM_HIP(c, hipMemcpyAsync(cplx_out, c->t_cplx.p, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     return HGMM_OK;
 }
 
@@ -2716,7 +2716,7 @@ static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_hos
                                                                    flags_ptr(c), c->exp_tab2.as<double>(), dbg);
             if (dbg) {
                 long long h[32];
-                HGMM_HIP(c, hipStreamSynchronize(c->stream));
+                HGMM_HIP(c, ctx_stream_sync(c));
                 HGMM_HIP(c, hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost));
                 for (int w = 0; w < 8; ++w)
                     fprintf(stderr, "wave %d: A %lld  B %lld  C %lld  wait %lld cycles\n", w, h[4 * w], h[4 * w + 1], h[4 * w + 2], h[4 * w + 3]);
@@ -2734,7 +2734,7 @@ static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_hos
     }
     if (q_host) {
         HGMM_HIP(c, hipMemcpyAsync(q_host, q_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+        HGMM_HIP(c, ctx_stream_sync(c));
     }
     return HGMM_OK;
 }
@@ -2753,7 +2753,7 @@ static int fullcov_pass(hgmm_ctx* c, int J, int* labels, double* q_host) {
     if (c->comm_on()) HGMM_TRY(allreduce_f64_dev(c, q_dev, 1));
     if (q_host) {
         HGMM_HIP(c, hipMemcpyAsync(q_host, q_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HGMM_HIP(c, hipStreamSynchronize(c->stream));
+        HGMM_HIP(c, ctx_stream_sync(c));
     }
     return HGMM_OK;
 }
@@ -2809,7 +2809,7 @@ extern "C" int hgmm_fullcov_fit(hgmm_ctx* c, int J, double ls, double ld, const 
     if (pi_out) HGMM_HIP(c, hipMemcpyAsync(pi_out, d_pi, sizeof(double) * J, hipMemcpyDeviceToHost, c->stream));
     if (mu_out) HGMM_HIP(c, hipMemcpyAsync(mu_out, d_mu, sizeof(double) * 3 * J, hipMemcpyDeviceToHost, c->stream));
     if (cov_out) HGMM_HIP(c, hipMemcpyAsync(cov_out, d_cov, sizeof(double) * 9 * J, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     if (q_len_out) *q_len_out = q_len < q_capacity ? q_len : q_capacity;
     return HGMM_OK;
 }
@@ -2849,7 +2849,7 @@ extern "C" int hgmm_fullcov_estep(hgmm_ctx* c, int J, const double* pi, const do
     if (m1_out) HGMM_HIP(c, hipMemcpyAsync(m1_out, e1, sizeof(double) * 3 * J, hipMemcpyDeviceToHost, c->stream));
     if (m2_out) HGMM_HIP(c, hipMemcpyAsync(m2_out, e2, sizeof(double) * 9 * J, hipMemcpyDeviceToHost, c->stream));
     if (labels_out) HGMM_HIP(c, hipMemcpyAsync(labels_out, lab, sizeof(int) * c->n, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     if (q_out) *q_out = q;
     return HGMM_OK;
 }
@@ -3029,7 +3029,7 @@ extern "C" int hgmm_tree_estep(hgmm_ctx* c, int64_t T, const double* pi, const d
     tree_rmax_kernel<<<nblk(c->n, 256), 256, 0, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad, mq + 2 * NMOM * T);
     unsigned long long r2bits = 0;
     HGMM_HIP(c, hipMemcpyAsync(&r2bits, mq + 2 * NMOM * T, sizeof r2bits, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     double r2 = 0.0;
     memcpy(&r2, &r2bits, sizeof r2);
     double m2max = 0.0;
@@ -3070,7 +3070,7 @@ extern "C" int hgmm_tree_estep(hgmm_ctx* c, int64_t T, const double* pi, const d
     if (m1_out) HGMM_HIP(c, hipMemcpyAsync(m1_out, e1, sizeof(double) * 3 * T, hipMemcpyDeviceToHost, c->stream));
     if (m2_out) HGMM_HIP(c, hipMemcpyAsync(m2_out, e2, sizeof(double) * 9 * T, hipMemcpyDeviceToHost, c->stream));
     if (current_idx_out) HGMM_HIP(c, hipMemcpyAsync(current_idx_out, cur, sizeof(int) * c->n, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     return HGMM_OK;
 }
 
@@ -3099,7 +3099,7 @@ extern "C" int hgmm_tree_mstep(hgmm_ctx* c, int64_t T, const double* m0, const d
     HGMM_HIP(c, hipMemcpyAsync(pi_inout, c->t_pi.p, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
     HGMM_HIP(c, hipMemcpyAsync(mu_inout, c->t_mu.p, sizeof(double) * 3 * T, hipMemcpyDeviceToHost, c->stream));
     HGMM_HIP(c, hipMemcpyAsync(cov_inout, c->t_cov.p, sizeof(double) * 9 * T, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     return HGMM_OK;
 }
 
@@ -3127,7 +3127,7 @@ extern "C" int hgmm_tree_loglik(hgmm_ctx* c, int64_t T, const double* pi, const 
     HGMM_HIP(c, hipGetLastError());
     if (c->comm_on()) HGMM_TRY(allreduce_f64_dev(c, q_dev, 1));
     HGMM_HIP(c, hipMemcpyAsync(q_out, q_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     return HGMM_OK;
 }
 
@@ -3137,7 +3137,7 @@ extern "C" int hgmm_tree_stats(hgmm_ctx* c, unsigned long long* pairs_out, int* 
     HGMM_TRY(tree_flags(c, false));
     unsigned char h[64];
     HGMM_HIP(c, hipMemcpyAsync(h, c->t_flags.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipStreamSynchronize(c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
     if (flags_out) memcpy(flags_out, h, sizeof(int));
     if (pairs_out) memcpy(pairs_out, h + 16, sizeof(unsigned long long));
     return HGMM_OK;
