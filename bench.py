@@ -333,9 +333,9 @@ def tree_1m_leg(ctx):
                          "frac": executed * instr_per_pair / (ll_ms * 1e-3) / lane_rate if ll_ms else None,
                          "algorithmic_TFLOPs": flop / (ll_ms * 1e-3) / 1e12 if ll_ms else None,
                          "algorithmic_frac_of_fp64_peak": flop / (ll_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TF if ll_ms else None,
-                         "note": "frac counts only pdfs that were evaluated (skipped: nodes with pi < eps, nodes whose pdf is "
-                                 "exactly 0 in float64 for a whole workgroup, nodes that together stay below 1e-20 of "
-                                 "every point's sum); algorithmic_* prices all N x 8^(l+1) pairs "
+                         "note": "frac counts only pdfs that were evaluated (nodes with pi < eps and nodes whose pdf is "
+                                 "exactly 0 in float64 for a whole workgroup are skipped: q is bitwise the full sum's); "
+                                 "algorithmic_* prices all N x 8^(l+1) pairs "
                                  "of the reference's loop at 25 flops and is NOT a utilisation figure",
                          "flags": flags}}
 

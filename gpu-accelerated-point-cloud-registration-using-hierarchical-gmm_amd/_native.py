@@ -341,9 +341,11 @@ for _n, _op, _rop, _fn in (("add", "add", "add", np.add), ("sub", "sub", "rsub",
     setattr(DeviceArray, "__%s__" % _n, _f)
     setattr(DeviceArray, "__r%s__" % _n, _r)
 for _n, _fn in (("lt", np.less), ("le", np.less_equal), ("gt", np.greater), ("ge", np.greater_equal),
-                ("pow", np.power)):
+                ("eq", np.equal), ("ne", np.not_equal), ("pow", np.power)):
     setattr(DeviceArray, "__%s__" % _n, (lambda fn: lambda self, other: self._host_op(fn, other))(_fn))
 DeviceArray.__neg__ = lambda self: self * -1.0
+DeviceArray.__abs__ = lambda self: np.abs(np.asarray(self))
+DeviceArray.__hash__ = lambda self: id(self)
 
 
 class DeviceScalar(DeviceArray):
@@ -461,6 +463,9 @@ class Context:
                     except Exception:
                         pass
             self._scalar_host = None
+            if self._arena is not None:               # (arrays carved from it die with the context)
+                self.lib.hgmm_free(self.h, self._arena[0])
+                self._arena = None
             self.lib.hgmm_destroy(self.h)
             self.h = None
 

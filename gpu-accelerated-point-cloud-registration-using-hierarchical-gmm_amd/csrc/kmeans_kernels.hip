@@ -276,6 +276,13 @@ __global__ __launch_bounds__(KM_BLOCK) void kmpp_update_kernel(const double* __r
 // is a trip through the fabric, and a CU keeps only so many of them in flight.  The two-level layout keeps the
 // lines on its critical path to ~120 (all part16 rows) + 2 per draw + the 64 lines of the block a draw lands in;
 // a flat per-block table (3907 sums per row at N = 1M) cost twice the time.
+// Round 3: step and tail as ONE launch per centre (kmpp_fused_kernel: every workgroup of the pass runs the previous
+// centre's tail for itself first, 245 times the same arithmetic on the same numbers) -- 16.3 -> 12.8 us per centre,
+// 13.1 -> 10.2 ms for k = 800 at N = 1M.  Where the 12 us of a launch go (HGMM_KMPP_DEBUG=1, thread 0's clock): first
+// round of loads + the candidates' totals 2.0, arg-min 1.3, prefix scan of the winner's row 1.1, group search 0.6, the
+// group's 16 block sums 0.9, the block's points 0.9, hand-over 0.5 -- then the pass itself, whose operands are in
+// registers by then: 4.6 us of fp64 issue (1M points x 8 candidates x 8 instructions, 16 waves on each CU) and 2 us
+// until the last wave of the workgroup is through.  The two-launch form stays for clouds beyond 16.7 M points.
 // Fixed summation orders throughout, hence the same seeds run to run; the four-kernel form (kmpp_pick / eval /
 // select / update) is kept as the readable statement of the same algorithm and is used by nothing else.
 // ------------------------------------------------------------------------------------------
@@ -357,28 +364,63 @@ __global__ __launch_bounds__(KM_STEP_BLOCK) void kmpp_step_kernel(const double* 
 // centre, the first kernel's sums `g0` / `bsum0`); `closest` lacks the fold of centre `pend` (-1: it is current),
 // applied on the fly inside the blocks the draws land in.
 constexpr int KM_TAIL_LDS_GROUPS = 4096;                 // group-prefix table kept in LDS up to this many groups
+// HGMM_KMPP_DEBUG=1: thread 0 of workgroups 0 and 128 adds the time since its kernel started (100 MHz ticks) at nine
+// points of kmpp_fused_kernel into dbg[wg slot][9] (tools/kmpp_prof.py prints the averages per centre)
+__device__ __forceinline__ void km_stamp(unsigned long long* dbg, int k, unsigned long long t0) {
+    if (dbg && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 128))
+        atomicAdd(dbg + (blockIdx.x ? 16 : 0) + k, (unsigned long long)wall_clock64() - t0);
+}
+struct KmTailShared {                                    // the tail's LDS (declared by the kernel that runs the body)
+    double wsum[KM_MAX_TRIALS][16];
+    double wave_tot[16];
+    double seg_end[1024];
+    double pre_sh[KM_TAIL_LDS_GROUPS];                   // inclusive prefix of the group sums (global `gprefix` beyond)
+    double total_sh;
+    int best_sh;
+};
+// The candidates of centre c and their potentials live in buffer c & 1 (`cand_in` / `part` are the ones being judged,
+// `cand_out` the ones being drawn): kmpp_fused_kernel has every workgroup run this body while others already write
+// the next potentials.  `writer`: this workgroup stores the results to memory (always, in the one-workgroup kernel);
+// `sh_cand` (LDS [T][3], may be null) receives the drawn candidates' coordinates for the code that follows in the
+// same workgroup; (pcx, pcy, pcz) = the accepted centre's coordinates in every thread (select).
 template <int TMAX>
-__global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restrict__ xs, int64_t n, int64_t n_pad,
-                                                         const double* __restrict__ closest,
-                                                         const double* __restrict__ part,
-                                                         const double* __restrict__ part16, int G,
-                                                         const double* __restrict__ bsum0,
-                                                         const double* __restrict__ g0, int B, int T, int j,
-                                                         int select, int draw, const double* __restrict__ rand_c,
-                                                         int64_t* __restrict__ cand, double* __restrict__ cand_xyz,
-                                                         double* __restrict__ centres,
-                                                         int64_t* __restrict__ ids, double* __restrict__ gprefix) {
-    __shared__ double wsum[KM_MAX_TRIALS][16];
-    __shared__ double wave_tot[16];
-    __shared__ double seg_end[1024];
-    __shared__ double pre_sh[KM_TAIL_LDS_GROUPS];       // inclusive prefix of the group sums (global `gprefix` beyond)
-    __shared__ double total_sh;
-    __shared__ int best_sh;
+__device__ __forceinline__ void kmpp_tail_body(const double* __restrict__ xs, int64_t n, int64_t n_pad,
+                                               const double* closest,
+                                               const double* __restrict__ part,
+                                               const double* __restrict__ part16, int G,
+                                               const double* __restrict__ bsum0,
+                                               const double* __restrict__ g0, int B, int T, int j,
+                                               int select, int draw, const double* __restrict__ rand_c,
+                                               const int64_t* cand_in, const double* cand_xyz_in,
+                                               int64_t* cand_out, double* cand_xyz_out,
+                                               double* __restrict__ centres,
+                                               int64_t* __restrict__ ids, double* gprefix, bool writer,
+                                               double* sh_cand, double& pcx, double& pcy, double& pcz,
+                                               KmTailShared& ts, unsigned long long* dbg = nullptr,
+                                               unsigned long long t_start = 0, double* pre_pts = nullptr,
+                                               int64_t pre_i0 = 0) {
+    auto& wsum = ts.wsum;
+    auto& wave_tot = ts.wave_tot;
+    auto& seg_end = ts.seg_end;
+    auto& pre_sh = ts.pre_sh;
+    double& total_sh = ts.total_sh;
+    int& best_sh = ts.best_sh;
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
     const bool in_lds = G <= KM_TAIL_LDS_GROUPS;
     const int seg = (G + 1023) / 1024;                      // groups per thread in the prefix scan (1 up to N = 4M)
     const int g_lo = tid * seg, g_hi = min(G, g_lo + seg);
     double loc = 0.0;                                       // the thread's run of the winner's group sums
+    // Everything whose ADDRESS is known now is requested now, next to the first round of loads, instead of one trip
+    // each further down the chain: this wave's uniform, and every candidate's id and coordinates (lane t holds
+    // candidate t; the winner's are picked out of the registers once it is known).
+    const double u_rand = draw ? rand_c[wave < T ? wave : T - 1] : 0.0;
+    const int tl = lane < T ? lane : 0;
+    int64_t my_cand = 0;
+    double my_cx = 0.0, my_cy = 0.0, my_cz = 0.0;
+    if (select) {
+        my_cand = cand_in[tl];
+        my_cx = cand_xyz_in[3 * tl]; my_cy = cand_xyz_in[3 * tl + 1]; my_cz = cand_xyz_in[3 * tl + 2];
+    }
     if (select) {
         double acc[TMAX];
 #pragma unroll
@@ -393,13 +435,26 @@ __global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restric
 #pragma unroll
             for (int t = 0; t < TMAX; ++t) acc[t] += (t < T) ? v[t] : 0.0;
         }
+        // (kmpp_fused_kernel: the caller's 16 point values are requested HERE, behind the loads the chain waits for --
+        //  the counter of outstanding loads retires in order, so requested first they would hold the chain up)
+        if (pre_pts) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                pre_pts[q] = xs[pre_i0 + q]; pre_pts[4 + q] = xs[n_pad + pre_i0 + q];
+                pre_pts[8 + q] = xs[2 * n_pad + pre_i0 + q]; pre_pts[12 + q] = closest[pre_i0 + q];
+            }
+        }
+        // (a wave none of whose threads owns a group -- 12 of the 16 at N = 1M -- has nothing to add up: eight fp64
+        //  wave reductions by every wave of the workgroup were a microsecond of this chain)
+        const bool wave_has_groups = wave * 64 * seg < G;
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) {
             if (t < T) {
-                const double w = wave_sum_f64(acc[t]);
+                const double w = wave_has_groups ? wave_sum_f64(acc[t]) : 0.0;
                 if (lane == 0) wsum[t][wave] = w;
             }
         }
+        km_stamp(dbg, 1, t_start);
         __syncthreads();
         if (tid < 64) {
             // lanes 0..T-1 add up their candidate's 16 wave totals (fixed order); first minimum wins (np.argmin)
@@ -416,6 +471,7 @@ __global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restric
             if (tid == 0) best_sh = best;
         }
         __syncthreads();
+        km_stamp(dbg, 2, t_start);
         const int best = best_sh;
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) if (t == best) loc = acc[t];
@@ -423,12 +479,13 @@ __global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restric
         for (int g = g_lo; g < g_hi; ++g) loc += g0[g];
     }
     int64_t win = 0;
-    double pcx = 0.0, pcy = 0.0, pcz = 0.0;
+    pcx = 0.0; pcy = 0.0; pcz = 0.0;
     const int best = select ? best_sh : 0;
     if (select) {
-        win = cand[best];
-        pcx = cand_xyz[3 * best]; pcy = cand_xyz[3 * best + 1]; pcz = cand_xyz[3 * best + 2];
-        if (tid == 0) {
+        const int bl = __builtin_amdgcn_readfirstlane(best);
+        win = (int64_t)__double_as_longlong(readlane_f64(__longlong_as_double((long long)my_cand), bl));
+        pcx = readlane_f64(my_cx, bl); pcy = readlane_f64(my_cy, bl); pcz = readlane_f64(my_cz, bl);
+        if (tid == 0 && writer) {
             ids[j] = win;
             centres[3 * j + 0] = pcx; centres[3 * j + 1] = pcy; centres[3 * j + 2] = pcz;
         }
@@ -437,7 +494,7 @@ __global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restric
     const double* gs = select ? part16 + (size_t)best * G : g0;      // group sums of the winner
     const double* bs = select ? part + (size_t)best * B : bsum0;     // its block sums
     const int pend = select ? j : -1;                       // centre whose fold `closest` is still missing
-    const double incl = wave_scan_f64(loc);
+    const double incl = (wave * 64 * seg < G) ? wave_scan_f64(loc) : 0.0;     // (loc = 0 in a wave without groups)
     if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();                                        // (also: everybody has read cand[best] before it is overwritten)
     double off = 0.0;
@@ -456,8 +513,9 @@ __global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restric
     if (!in_lds) __threadfence();
     __syncthreads();
     const double pot = total_sh;
-    if (wave >= T) return;
-    const double v = rand_c[wave] * pot;
+    km_stamp(dbg, 3, t_start);
+    if (wave >= T) return;                               // (no barrier of this body follows)
+    const double v = u_rand * pot;
     const volatile double* gp = gprefix;                 // written by other waves of this workgroup
     auto pre = [&](int g) -> double { return in_lds ? pre_sh[g] : gp[g]; };
     // first thread segment whose end >= v = number of segment ends below v (the ends never decrease): the wave
@@ -470,7 +528,10 @@ __global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restric
     lo = min(G, lo * seg);
     while (lo < hi && !(pre(lo) >= v)) ++lo;
     if (lo == hi && hi < G) lo = hi;                     // rounding at the segment's end
+    km_stamp(dbg, 4, t_start);
     int64_t found = n - 1;                               // np.clip(..., n - 1)
+    bool have_xyz = false;                               // (wave-uniform) the drawn point's coordinates are in registers
+    double fdx = 0.0, fdy = 0.0, fdz = 0.0;
     if (lo < G) {
         // the block inside group `lo`: running sum of its 16 block sums in the order the step kernel added them
         const double gbase = lo > 0 ? pre(lo - 1) : 0.0;
@@ -484,21 +545,27 @@ __global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restric
             run += readlane_f64(mine, q);
             if (blk < 0 && bfirst + q < B && gbase + run >= v) { blk = bfirst + q; break; }
         }
+        km_stamp(dbg, 5, t_start);
         if (blk < 0) {                                   // rounding at the group's end: first element after it
             const int64_t nxt = (int64_t)min(B, bfirst + KM_GROUP) * KM_BLOCK;
             found = nxt < n ? nxt : n - 1;
         } else {
             const double base = gbase + before;
             const int64_t e0 = (int64_t)blk * KM_BLOCK + 4 * lane;
-            double c[4];
+            // the block's 4 x 4 values per lane in ONE round of loads (the padding up to n_pad exists in both arrays and
+            // is masked below; written with a test per element this was four dependent trips), and the coordinates
+            // double as the drawn point's: no further trip for them
+            double c[4], cv[4], xv[4], yv[4], zv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                cv[q] = closest[e0 + q]; xv[q] = xs[e0 + q]; yv[q] = xs[n_pad + e0 + q]; zv[q] = xs[2 * n_pad + e0 + q];
+            }
             double s = 0.0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                double val = 0.0;
-                if (e0 + q < n) {
-                    val = closest[e0 + q];
-                    if (pend >= 0) val = fmin(val, dist2(xs[e0 + q], xs[n_pad + e0 + q], xs[2 * n_pad + e0 + q], pcx, pcy, pcz));
-                }
+                double val = cv[q];
+                if (pend >= 0) val = fmin(val, dist2(xv[q], yv[q], zv[q], pcx, pcy, pcz));
+                if (!(e0 + q < n)) val = 0.0;
                 s += val;
                 c[q] = s;
             }
@@ -512,6 +579,11 @@ __global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restric
                 const int l = __ffsll((long long)hit) - 1;
                 const int q = __builtin_amdgcn_readlane(first_q, l);
                 found = (int64_t)blk * KM_BLOCK + 4 * l + q;
+                const double sx = q == 0 ? xv[0] : q == 1 ? xv[1] : q == 2 ? xv[2] : xv[3];
+                const double sy = q == 0 ? yv[0] : q == 1 ? yv[1] : q == 2 ? yv[2] : yv[3];
+                const double sz = q == 0 ? zv[0] : q == 1 ? zv[1] : q == 2 ? zv[2] : zv[3];
+                fdx = readlane_f64(sx, l); fdy = readlane_f64(sy, l); fdz = readlane_f64(sz, l);
+                have_xyz = true;
             } else {
                 // rounding at the block's end: the threshold falls on the first element after it
                 const int64_t nxt = (int64_t)(blk + 1) * KM_BLOCK;
@@ -519,8 +591,109 @@ __global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restric
             }
         }
     }
-    if (lane < 3) cand_xyz[3 * wave + lane] = xs[(size_t)lane * n_pad + found];     // for the next step + tail
-    if (lane == 0) cand[wave] = found;
+    km_stamp(dbg, 6, t_start);
+    if (!have_xyz) { fdx = xs[found]; fdy = xs[n_pad + found]; fdz = xs[2 * n_pad + found]; }   // (the rounding cases)
+    if (lane < 3) {                                      // for the next step + tail
+        const double v3 = lane == 0 ? fdx : lane == 1 ? fdy : fdz;
+        if (writer) cand_xyz_out[3 * wave + lane] = v3;
+        if (sh_cand) sh_cand[3 * wave + lane] = v3;
+    }
+    if (lane == 0 && writer) cand_out[wave] = found;
+}
+
+template <int TMAX>
+__global__ __launch_bounds__(1024) void kmpp_tail_kernel(const double* __restrict__ xs, int64_t n, int64_t n_pad,
+                                                         const double* __restrict__ closest,
+                                                         const double* __restrict__ part,
+                                                         const double* __restrict__ part16, int G,
+                                                         const double* __restrict__ bsum0,
+                                                         const double* __restrict__ g0, int B, int T, int j,
+                                                         int select, int draw, const double* __restrict__ rand_c,
+                                                         const int64_t* cand_in, const double* cand_xyz_in,
+                                                         int64_t* cand_out, double* cand_xyz_out,
+                                                         double* __restrict__ centres,
+                                                         int64_t* __restrict__ ids, double* __restrict__ gprefix) {
+    __shared__ KmTailShared ts;
+    double pcx, pcy, pcz;
+    kmpp_tail_body<TMAX>(xs, n, n_pad, closest, part, part16, G, bsum0, g0, B, T, j, select, draw, rand_c, cand_in,
+                         cand_xyz_in, cand_out, cand_xyz_out, centres, ids, gprefix, true, nullptr, pcx, pcy, pcz, ts);
+}
+
+// ONE launch per centre: every workgroup of the pass over the points first runs the tail of the PREVIOUS centre for
+// itself -- accept centre j - 1 among its candidates (potentials in buffer (j - 1) & 1), draw the candidates of centre
+// j -- and then its share of the pass: fold centre j - 1 into `closest`, potentials of the new candidates into buffer
+// j & 1.  The tail is a chain of ~5 dependent trips to memory (~6 us); run by one workgroup in a launch of its own it
+// was 8.5 of the 16.4 us per centre.  Here the workgroup's points are requested BEFORE the chain starts, so the pass's
+// 32 MB stream rides under it, and the launch boundary between tail and pass is gone.  All workgroups compute the
+// same draws (same code on the same numbers: the only memory they read that others write meanwhile is `closest`,
+// where a value is either before or after the fold of centre j - 1 -- and the draw applies that fold on the fly,
+// min(min(c, d), d) = min(c, d)); workgroup 0 records them.  Needs the group-prefix table in LDS (G <= 4096 groups
+// = 16.7 M points); larger clouds take the two-launch form.
+template <int TMAX>
+__global__ __launch_bounds__(KM_STEP_BLOCK) void kmpp_fused_kernel(const double* __restrict__ xs, int64_t n, int64_t n_pad,
+                                                                   double* closest,
+                                                                   const double* __restrict__ part_prev,
+                                                                   const double* __restrict__ part16_prev,
+                                                                   double* __restrict__ part_next,
+                                                                   double* __restrict__ part16_next, int G, int B, int T,
+                                                                   int j, const double* __restrict__ rand_c,
+                                                                   const int64_t* cand_prev, const double* cand_xyz_prev,
+                                                                   int64_t* cand_next, double* cand_xyz_next,
+                                                                   double* __restrict__ centres,
+                                                                   int64_t* __restrict__ ids,
+                                                                   unsigned long long* dbg) {
+    const unsigned long long t_start = dbg ? (unsigned long long)wall_clock64() : 0ull;
+    static_assert(KM_STEP_BLOCK == 1024, "the tail body is written for 1024 threads");
+    __shared__ double shg[KM_MAX_TRIALS][KM_GROUP];
+    __shared__ double sh_cand[3 * KM_MAX_TRIALS];
+    __shared__ KmTailShared ts;
+    const int lane = lane_id();
+    const int64_t blk = (int64_t)blockIdx.x * KM_GROUP + wave_in_block();     // 256-point block of this wave
+    const bool have = blk < B;
+    const int64_t i0 = (have ? blk : 0) * KM_BLOCK + 4 * lane;                 // n_pad is a multiple of 256
+    // the pass's operands do not depend on the tail: requested inside its first round of loads (see there)
+    double pts[16];
+    double fx, fy, fz;
+    kmpp_tail_body<TMAX>(xs, n, n_pad, closest, part_prev, part16_prev, G, nullptr, nullptr, B, T, j - 1, 1, 1, rand_c,
+                         cand_prev, cand_xyz_prev, cand_next, cand_xyz_next, centres, ids, nullptr, blockIdx.x == 0,
+                         sh_cand, fx, fy, fz, ts, dbg, t_start, pts, i0);
+    __syncthreads();                                         // sh_cand
+    km_stamp(dbg, 7, t_start);
+    double x[4], y[4], z[4], cl[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { x[q] = pts[q]; y[q] = pts[4 + q]; z[q] = pts[8 + q]; cl[q] = pts[12 + q]; }
+    if (have) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double d = dist2(x[q], y[q], z[q], fx, fy, fz);
+            if (i0 + q < n && d < cl[q]) { cl[q] = d; closest[i0 + q] = d; }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (!have || !(i0 + q < n)) cl[q] = 0.0;      // padding contributes min(0, d) = 0
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        if (t < T) {
+            const double cx = sh_cand[3 * t], cy = sh_cand[3 * t + 1], cz = sh_cand[3 * t + 2];
+            double sacc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sacc += fmin(cl[q], dist2(x[q], y[q], z[q], cx, cy, cz));
+            const double w = wave_sum_f64(sacc);
+            if (lane == 0) {
+                if (have) part_next[(size_t)t * B + blk] = w;
+                shg[t][wave_in_block()] = have ? w : 0.0;
+            }
+        }
+    }
+    km_stamp(dbg, 9, t_start);
+    __syncthreads();
+    if ((int)threadIdx.x < T) {
+        double s2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < KM_GROUP; ++q) s2 += shg[threadIdx.x][q];
+        part16_next[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s2;
+    }
+    km_stamp(dbg, 8, t_start);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -876,18 +1049,19 @@ extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const 
     const int B = (int)km_nblk(n, KM_BLOCK);
     HGMM_TRY(ensure(c, c->km_closest, sizeof(double) * n_pad));
     const int G = (B + KM_GROUP - 1) / KM_GROUP;
-    HGMM_TRY(ensure(c, c->km_block, sizeof(double) * ((size_t)2 * B + (size_t)(B + G) * KM_MAX_TRIALS + 2 * (size_t)G + 8)));
-    HGMM_TRY(ensure(c, c->km_centres, sizeof(double) * (7 * (size_t)k + 3 * KM_MAX_TRIALS)));
-    HGMM_TRY(ensure(c, c->km_ids, sizeof(int64_t) * ((size_t)k + KM_MAX_TRIALS)));
+    // (potentials and candidates are double-buffered by centre parity: kmpp_fused_kernel)
+    HGMM_TRY(ensure(c, c->km_block, sizeof(double) * ((size_t)2 * B + 2 * (size_t)(B + G) * KM_MAX_TRIALS + 2 * (size_t)G + 8)));
+    HGMM_TRY(ensure(c, c->km_centres, sizeof(double) * (7 * (size_t)k + 2 * 3 * KM_MAX_TRIALS)));
+    HGMM_TRY(ensure(c, c->km_ids, sizeof(int64_t) * ((size_t)k + 2 * KM_MAX_TRIALS)));
     HGMM_TRY(ensure(c, c->km_rand, sizeof(double) * (size_t)std::max(1, (k - 1) * n_trials)));
     const double* xs = c->x_soa64.as<double>();
     double* closest = c->km_closest.as<double>();
     double* bsum = c->km_block.as<double>();
     double* bprefix = bsum + B;
-    double* part = bprefix + B;
-    double* pot = part + (size_t)B * KM_MAX_TRIALS;
-    double* part16 = pot + 8;
-    double* g0 = part16 + (size_t)G * KM_MAX_TRIALS;
+    double* part = bprefix + B;                               // [2][KM_MAX_TRIALS][B]
+    double* pot = part + 2 * (size_t)B * KM_MAX_TRIALS;
+    double* part16 = pot + 8;                                 // [2][KM_MAX_TRIALS][G]
+    double* g0 = part16 + 2 * (size_t)G * KM_MAX_TRIALS;
     double* gprefix = g0 + G;
     double* centres = c->km_centres.as<double>();
     int64_t* ids = c->km_ids.as<int64_t>();
@@ -906,30 +1080,74 @@ extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const 
             kmpp_update_kernel<<<B, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, centres, j, closest, bsum);
         }
     } else if (k > 1) {
-        // two launches per centre: the pass over the points (fold of the previous centre + candidate potentials),
-        // then one workgroup that names the winner and draws the next centre's candidates
-        double* cand_xyz = centres + 7 * (size_t)k;             // [T][3], behind the centre tables
+        // The candidates of centre j, their coordinates and their potentials live in buffer j & 1.
+        double* cand_xyz = centres + 7 * (size_t)k;             // [2][T][3], behind the centre tables
         const bool t8 = n_trials <= 8;
+        auto cand_b = [&](int j) { return cand + (size_t)(j & 1) * KM_MAX_TRIALS; };
+        auto xyz_b = [&](int j) { return cand_xyz + (size_t)(j & 1) * 3 * KM_MAX_TRIALS; };
+        auto part_b = [&](int j) { return part + (size_t)(j & 1) * B * KM_MAX_TRIALS; };
+        auto part16_b = [&](int j) { return part16 + (size_t)(j & 1) * G * KM_MAX_TRIALS; };
+        // tail(jj): accept centre jj among its candidates (select) and / or draw the candidates of centre jj + 1 (draw)
         auto tail = [&](int jj, int select, int draw, const double* rnd) {
             if (t8)
-                kmpp_tail_kernel<8><<<1, 1024, 0, c->stream>>>(xs, n, n_pad, closest, part, part16, G, bsum, g0, B, n_trials, jj,
-                                                               select, draw, rnd, cand, cand_xyz, centres, ids, gprefix);
+                kmpp_tail_kernel<8><<<1, 1024, 0, c->stream>>>(xs, n, n_pad, closest, part_b(jj), part16_b(jj), G, bsum, g0, B,
+                                                               n_trials, jj, select, draw, rnd, cand_b(jj), xyz_b(jj),
+                                                               cand_b(jj + 1), xyz_b(jj + 1), centres, ids, gprefix);
             else
-                kmpp_tail_kernel<KM_MAX_TRIALS><<<1, 1024, 0, c->stream>>>(xs, n, n_pad, closest, part, part16, G, bsum, g0, B,
-                                                                           n_trials, jj, select, draw, rnd, cand, cand_xyz,
-                                                                           centres, ids, gprefix);
+                kmpp_tail_kernel<KM_MAX_TRIALS><<<1, 1024, 0, c->stream>>>(xs, n, n_pad, closest, part_b(jj), part16_b(jj), G, bsum,
+                                                                           g0, B, n_trials, jj, select, draw, rnd, cand_b(jj),
+                                                                           xyz_b(jj), cand_b(jj + 1), xyz_b(jj + 1), centres,
+                                                                           ids, gprefix);
+        };
+        auto step = [&](int j, int fold) {
+            if (t8)
+                kmpp_step_kernel<8><<<G, KM_STEP_BLOCK, 0, c->stream>>>(xs, n, n_pad, closest, centres, fold, xyz_b(j), n_trials,
+                                                                        part_b(j), B, part16_b(j));
+            else
+                kmpp_step_kernel<KM_MAX_TRIALS><<<G, KM_STEP_BLOCK, 0, c->stream>>>(xs, n, n_pad, closest, centres, fold, xyz_b(j),
+                                                                                    n_trials, part_b(j), B, part16_b(j));
         };
         kmpp_group_kernel<<<km_nblk(G, 256), 256, 0, c->stream>>>(bsum, B, G, g0);
         tail(0, 0, 1, rand_dev);
-        for (int j = 1; j < k; ++j) {
-            const int fold = j >= 2 ? j - 1 : -1;
-            if (t8)
-                kmpp_step_kernel<8><<<G, KM_STEP_BLOCK, 0, c->stream>>>(xs, n, n_pad, closest, centres, fold, cand_xyz, n_trials,
-                                                                        part, B, part16);
-            else
-                kmpp_step_kernel<KM_MAX_TRIALS><<<G, KM_STEP_BLOCK, 0, c->stream>>>(xs, n, n_pad, closest, centres, fold, cand_xyz,
-                                                                                    n_trials, part, B, part16);
-            tail(j, 1, j + 1 < k ? 1 : 0, rand_dev + (size_t)j * n_trials);
+        if (G <= KM_TAIL_LDS_GROUPS && !std::getenv("HGMM_KMPP_TWO_LAUNCHES")) {
+            // one launch per centre (kmpp_fused_kernel): pass of centre 1, then for every further centre the tail of
+            // the previous one inside the pass's own launch, and the last centre's tail on its own
+            step(1, -1);
+            unsigned long long* dbg = nullptr;
+            if (std::getenv("HGMM_KMPP_DEBUG")) {
+                HGMM_TRY(ensure(c, c->scratch, 32 * sizeof(unsigned long long)));
+                dbg = c->scratch.as<unsigned long long>();
+                HGMM_HIP(c, hipMemsetAsync(dbg, 0, 32 * sizeof(unsigned long long), c->stream));
+            }
+            for (int j = 2; j < k; ++j) {
+                const double* rnd = rand_dev + (size_t)(j - 1) * n_trials;
+                if (t8)
+                    kmpp_fused_kernel<8><<<G, KM_STEP_BLOCK, 0, c->stream>>>(
+                        xs, n, n_pad, closest, part_b(j - 1), part16_b(j - 1), part_b(j), part16_b(j), G, B, n_trials, j, rnd,
+                        cand_b(j - 1), xyz_b(j - 1), cand_b(j), xyz_b(j), centres, ids, dbg);
+                else
+                    kmpp_fused_kernel<KM_MAX_TRIALS><<<G, KM_STEP_BLOCK, 0, c->stream>>>(
+                        xs, n, n_pad, closest, part_b(j - 1), part16_b(j - 1), part_b(j), part16_b(j), G, B, n_trials, j, rnd,
+                        cand_b(j - 1), xyz_b(j - 1), cand_b(j), xyz_b(j), centres, ids, dbg);
+            }
+            if (dbg) {
+                unsigned long long h[32];
+                HGMM_HIP(c, hipMemcpyAsync(h, dbg, sizeof h, hipMemcpyDeviceToHost, c->stream));
+                HGMM_HIP(c, ctx_stream_sync(c));
+                for (int wg = 0; wg < 2; ++wg) {
+                    fprintf(stderr, "kmpp_fused_kernel workgroup %3d, us since kernel start (mean of %d launches):", wg ? 128 : 0, k - 2);
+                    for (int q : {1, 2, 3, 4, 5, 6, 7, 9, 8}) fprintf(stderr, " s%d %.2f", q, h[16 * wg + q] * 0.01 / std::max(1, k - 2));
+                    fprintf(stderr, "\n");
+                }
+            }
+            tail(k - 1, 1, 0, nullptr);
+        } else {
+            // two launches per centre: the pass over the points (fold of the previous centre + candidate potentials),
+            // then one workgroup that names the winner and draws the next centre's candidates
+            for (int j = 1; j < k; ++j) {
+                step(j, j >= 2 ? j - 1 : -1);
+                tail(j, 1, j + 1 < k ? 1 : 0, rand_dev + (size_t)j * n_trials);
+            }
         }
     }
     (void)pot;

@@ -795,10 +795,11 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
     // the level's nodes here, so that every chunk uses the same lref.
     double lref = -INFINITY;
     const double rel_margin = LL_REL_DROP + log((double)n_level_nodes);
-    // Only in the large-cloud instantiation: the pass costs a few microseconds per launch, which the 40 256-point
-    // build (3.2 -> 3.45 ms with it) does not get back -- its launches are chains of latencies, not pdf evaluations;
-    // at 10^6 points it takes the evaluated pairs from 22 % to 18 % of the reference's (5.19 -> 5.04 ms per build).
-    if (BIGTAB && n_level_nodes >= LL_REL_MIN_NODES && !(fl & 2)) {
+    // OPT-IN (HGMM_TREE_REL=1 -> bit 1 of the flags) and only in the large-cloud instantiation.  Measured: at 10^6
+    // points it takes the evaluated pairs from 22 % to 18 % of the reference's, 5.19 -> 5.04 ms per build -- 3 %, for
+    // which the default does not give up "q is bitwise the full sum's"; the 40 256-point build loses 0.2 ms to the
+    // extra pass (its launches are chains of latencies, and a converged bunny tree has 26 / 44 / 34 live nodes per level).
+    if (BIGTAB && n_level_nodes >= LL_REL_MIN_NODES && (fl & 2)) {
         double best = -INFINITY;
         for (int n0 = (int)threadIdx.x; n0 < n_level_nodes; n0 += 4 * CH) {
             double wl[4], k2[4], u0[4], u1[4], u2[4];
@@ -1429,10 +1430,12 @@ static int tree_flags(hgmm_ctx* c, bool reset) {
     if (reset) {
         HGMM_HIP(c, hipMemsetAsync(c->t_flags.p, 0, TREE_FLAGS_BYTES, c->stream));
         // HGMM_TREE_NO_CHOL=1: take the symmetric-form fallback everywhere (lets the tests hold both forms to the oracle)
-        // HGMM_TREE_NO_REL=1: absolute reach test only (bit 1; for A/B timing of the relative test)
+        // HGMM_TREE_REL=1: add the RELATIVE reach test of tree_loglik_kernel (bit 1).  Off by default: what the absolute
+        // test skips is exactly 0 in float64 (q and the stop rule are bitwise those of the full sum), what the relative
+        // test drops is "only" below 1e-20 of every point's sum.
         int preset = 0;
         if (const char* e = std::getenv("HGMM_TREE_NO_CHOL")) preset |= (e[0] == '1') ? 1 : 0;
-        if (const char* e = std::getenv("HGMM_TREE_NO_REL")) preset |= (e[0] == '1') ? 2 : 0;
+        if (const char* e = std::getenv("HGMM_TREE_REL")) preset |= (e[0] == '1') ? 2 : 0;
         if (preset) HGMM_HIP(c, hipMemsetAsync(c->t_flags.p, preset, 1, c->stream));
     }
     return HGMM_OK;

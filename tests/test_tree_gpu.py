@@ -497,7 +497,7 @@ def _label_checksum(cur):
     return int((cur * pos).sum(dtype=np.uint64)), int((cur * cur * pos).sum(dtype=np.uint64))
 
 
-def test_tree_1M_matches_oracle_fixture(ctx):
+def test_tree_1M_matches_oracle_fixture(ctx, monkeypatch):
     """The size bench.py's `tree_1M` leg times (uniform cloud N = 1e6, L = 4, 4 iterations per level) against
     oracle.hgmm_tree.build_tree run on the SAME million points (tools/gen_oracle_fixtures.py --only tree1m):
     q trace, parameters, the node populations of every level, a checksum over all 10^6 leaf assignments per
@@ -527,6 +527,18 @@ def test_tree_1M_matches_oracle_fixture(ctx):
         assert abs(s - g["pi"][hgmm_tree.level(l):hgmm_tree.level(l + 1)].sum()) < 1e-12
     again = build(ctx, P, L, float(g["ls"]), float(g["ld"]), idx, float(g["sig2"]), max_iters=k)
     assert np.array_equal(again[5], q) and np.array_equal(again[3], leaf) and np.array_equal(again[2], cov)
+    pairs_abs = ctx.tree_stats()[0]
+    # test_tree_1M_relative_reach_opt_in: HGMM_TREE_REL=1 also drops nodes that together stay below 1e-20 of every
+    # point's sum -- fewer pdf evaluations, the same tree, q within the bound (1e-20 per point is far below 1 ulp of q)
+    monkeypatch.setenv("HGMM_TREE_REL", "1")
+    rel = build(ctx, P, L, float(g["ls"]), float(g["ld"]), idx, float(g["sig2"]), max_iters=k)
+    pairs_rel, flags = ctx.tree_stats()
+    monkeypatch.delenv("HGMM_TREE_REL")
+    assert flags == 2 and pairs_rel < pairs_abs
+    assert np.array_equal(rel[3], leaf) and np.array_equal(rel[2], cov)          # the E/M steps do not see the test
+    np.testing.assert_allclose(rel[5], q, rtol=1e-14, atol=0)
+    print("evaluated pairs: absolute reach test %d, with the relative test %d (%.1f %%)"
+          % (pairs_abs, pairs_rel, 100.0 * pairs_rel / pairs_abs))
 
 
 def test_symmetric_form_fallback_and_pair_counter(ctx, bunny, monkeypatch):
@@ -534,7 +546,7 @@ def test_symmetric_form_fallback_and_pair_counter(ctx, bunny, monkeypatch):
     (R^T R = Sigma^-1 / 2) and fall back to the symmetric form when a node's Sigma^-1 fails the Cholesky test.
     Both forms are held to the oracle: the fallback is forced with HGMM_TREE_NO_CHOL=1.  Also hgmm_tree_stats: the
     pdf evaluations really done never exceed the reference's N x 8^(l+1) per iteration (what is skipped is exactly 0 in
-    float64 here; clouds of >= 4e5 points also drop what stays below 1e-20 of every point's sum: test_tree_1M_...)."""
+    float64; the opt-in relative test, HGMM_TREE_REL=1, is held to the fixture in test_tree_1M_relative_reach_opt_in)."""
     P = bunny[::8].astype(np.float64)
     L = 3
     T = hgmm_tree.n_total(L)
