@@ -409,6 +409,9 @@ __device__ __forceinline__ void kmpp_tail_body(const double* __restrict__ xs, in
     const bool in_lds = G <= KM_TAIL_LDS_GROUPS;
     const int seg = (G + 1023) / 1024;                      // groups per thread in the prefix scan (1 up to N = 4M)
     const int g_lo = tid * seg, g_hi = min(G, g_lo + seg);
+    // waves 0 .. nwg-1 own groups; the totals of the others are exact zeros, and x + 0.0 == x: leaving them out of the
+    // fixed-order sums below changes no bit and takes up to 12 dependent LDS reads out of two steps of the chain
+    const int nwg = min(16, (G + 64 * seg - 1) / (64 * seg));
     double loc = 0.0;                                       // the thread's run of the winner's group sums
     // Everything whose ADDRESS is known now is requested now, next to the first round of loads, instead of one trip
     // each further down the chain: this wave's uniform, and every candidate's id and coordinates (lane t holds
@@ -460,7 +463,7 @@ __device__ __forceinline__ void kmpp_tail_body(const double* __restrict__ xs, in
             // lanes 0..T-1 add up their candidate's 16 wave totals (fixed order); first minimum wins (np.argmin)
             double p = 0.0;
             if (tid < T)
-                for (int w = 0; w < 16; ++w) p += wsum[tid][w];
+                for (int w = 0; w < nwg; ++w) p += wsum[tid][w];
             int best = 0;
             double best_pot = readlane_f64(p, 0);
 #pragma unroll
@@ -498,7 +501,7 @@ __device__ __forceinline__ void kmpp_tail_body(const double* __restrict__ xs, in
     if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();                                        // (also: everybody has read cand[best] before it is overwritten)
     double off = 0.0;
-    for (int w = 0; w < wave; ++w) off += wave_tot[w];
+    for (int w = 0; w < min(wave, nwg); ++w) off += wave_tot[w];
     if (seg == 1) {
         if (g_lo < g_hi) pre_sh[g_lo] = off + incl;
     } else {
