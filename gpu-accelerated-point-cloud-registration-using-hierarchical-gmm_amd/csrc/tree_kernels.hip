@@ -985,15 +985,24 @@ __global__ void tree_ctl_kernel(const double* __restrict__ q_dev, TreeCtl* __res
     tree_ctl_update(*q_dev, TreeStop{ctl, ls, max_iters, trace, trace_cap});
 }
 
-__global__ __launch_bounds__(256) void tree_sum_kernel(const double* __restrict__ v, int n, double* out) {
+// (`done`: skip when the loop this launch belongs to has stopped; `stop`: apply the loop's stop rule to the sum)
+__global__ __launch_bounds__(256) void tree_sum_kernel(const double* __restrict__ v, int n, double* out,
+                                                       const int* __restrict__ done = nullptr,
+                                                       TreeStop stop = TreeStop{nullptr, 0.0, 0, nullptr, 0}) {
     // single workgroup, fixed order
+    const int stop_flag = done ? *done : 0;                // (requested together with the shares)
     __shared__ double sh[4];
     double acc = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) acc += v[i];
+    if (stop_flag) return;
     acc = wave_sum_f64(acc);
     if (lane_id() == 0) sh[wave_in_block()] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) *out = sh[0] + sh[1] + sh[2] + sh[3];
+    if (threadIdx.x == 0) {
+        const double q = sh[0] + sh[1] + sh[2] + sh[3];
+        *out = q;
+        if (stop.ctl) tree_ctl_update(q, stop);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2609,8 +2618,9 @@ __global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
     const double* __restrict__ xs, int64_t n, int64_t n_pad, const double* __restrict__ prep, int J16,
     int* __restrict__ label_out, double* __restrict__ block_q, double* __restrict__ partials /*[grid][J16][NMOM]*/,
     int want_stats, const int* __restrict__ flags, const double* __restrict__ exp2_tab,
-    long long* __restrict__ dbg = nullptr) {
+    long long* __restrict__ dbg = nullptr, const int* __restrict__ done = nullptr) {
     extern __shared__ double lds[];
+    if (done && *done) return;                     // the loop stopped in an earlier iteration of this batch
     if (flags && (*flags & 1))                     // kernel-uniform: some Sigma^-1 failed the Cholesky test
         full_fused_body<CPL, false>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds, exp2_tab);
     else
@@ -2619,9 +2629,11 @@ __global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
 
 // one wave per component: fixed-order sum over the workgroups' partials
 __global__ __launch_bounds__(64) void full_reduce_kernel(const double* __restrict__ partials, int nblocks,
-                                                         int J, int J16, double* __restrict__ mom) {
+                                                         int J, int J16, double* __restrict__ mom,
+                                                         const int* __restrict__ done = nullptr) {
     const int j = blockIdx.x;
     if (j >= J) return;
+    if (done && *done) return;
     double acc[NMOM];
 #pragma unroll
     for (int m = 0; m < NMOM; ++m) acc[m] = 0.0;
@@ -2689,7 +2701,10 @@ static bool fullcov_one_pass(int J16) {
     if (const char* e = std::getenv("HGMM_FULLCOV_TWO_PASS")) if (e[0] == '1') return false;
     return J16 <= FT_MAX_J16;
 }
-static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_host, bool want_stats = true) {
+// `ctl` (device): the launches look at ctl->done first and the sum of q applies the stop rule `stop` -- for a loop whose
+// iterations are enqueued ahead of the host's knowledge (hgmm_fullcov_fit); then nothing is copied to the host here.
+static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_host, bool want_stats = true,
+                         const int* done = nullptr, TreeStop stop = TreeStop{nullptr, 0.0, 0, nullptr, 0}) {
     const int64_t tiles = (c->n + FT_P - 1) / FT_P;
     const int grid = (int)std::min<int64_t>(tiles, c->cus);             // 100+ KB of LDS: one workgroup per CU
     double* block_q = c->t_q.as<double>();
@@ -2707,7 +2722,7 @@ static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_hos
             full_fused_kernel<1><<<grid, FT_BLOCK, lds, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
                                                                    c->t_prep.as<double>(), J16, labels, block_q,
                                                                    c->t_partials.as<double>(), want_stats ? 1 : 0,
-                                                                   flags_ptr(c), c->exp_tab2.as<double>());
+                                                                   flags_ptr(c), c->exp_tab2.as<double>(), nullptr, done);
         } else {
             HGMM_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&full_fused_kernel<2>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2716,7 +2731,7 @@ static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_hos
             full_fused_kernel<2><<<grid, FT_BLOCK, lds, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
                                                                    c->t_prep.as<double>(), J16, labels, block_q,
                                                                    c->t_partials.as<double>(), want_stats ? 1 : 0,
-                                                                   flags_ptr(c), c->exp_tab2.as<double>(), dbg);
+                                                                   flags_ptr(c), c->exp_tab2.as<double>(), dbg, done);
             if (dbg) {
                 long long h[32];
                 HGMM_HIP(c, ctx_stream_sync(c));
@@ -2728,8 +2743,11 @@ static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_hos
         }
     }
     HGMM_HIP(c, hipGetLastError());
-    tree_sum_kernel<<<1, 256, 0, c->stream>>>(block_q, grid, q_dev);
-    full_reduce_kernel<<<J, 64, 0, c->stream>>>(c->t_partials.as<double>(), grid, J, J16, c->t_mom.as<double>());
+    // (the statistics before the sum: the sum may set the stop flag, and a loop that stops still wants THIS launch's q --
+    //  its statistics are not needed any more, but the reduction has looked at the flag before it is raised)
+    if (want_stats)
+        full_reduce_kernel<<<J, 64, 0, c->stream>>>(c->t_partials.as<double>(), grid, J, J16, c->t_mom.as<double>(), done);
+    tree_sum_kernel<<<1, 256, 0, c->stream>>>(block_q, grid, q_dev, done, stop);
     HGMM_HIP(c, hipGetLastError());
     if (c->comm_on()) {
         HGMM_TRY(allreduce_f64_dev(c, c->t_mom.as<double>(), (size_t)NMOM * J));
@@ -2792,6 +2810,59 @@ extern "C" int hgmm_fullcov_fit(hgmm_ctx* c, int J, double ls, double ld, const 
     int* lab_nxt = lab_b;
     double prev_q = 0.0;
     int it = 0, q_len = 0;
+    if (one_pass && !c->comm_on() && !std::getenv("HGMM_FULLCOV_SYNC")) {
+        // The stop rule on the device, the host one batch of iterations ahead (the scheme of hgmm_tree_build): the
+        // launches of an iteration look at ctl->done first, the sum of q applies |q - prev_q| < ls / the budget, and the
+        // host reads {done, iterations} through a pinned copy + an event while the next batch is already queued.
+        // (Waiting for q after every iteration left the device idle for ~0.1 ms per 1.7 ms iteration at N = 1e6.)
+        double* q_dev = c->t_q.as<double>() + nblk(c->n, CH) + c->cus;
+        TreeCtl* ctl = reinterpret_cast<TreeCtl*>(q_dev + 2);
+        const int trace_cap = std::min(max_iters, 1 << 20);
+        HGMM_TRY(ensure(c, c->t_qtrace, sizeof(double) * (size_t)trace_cap));
+        double* trace_dev = c->t_qtrace.as<double>();
+        HGMM_HIP(c, hipMemsetAsync(ctl, 0, sizeof(TreeCtl), c->stream));
+        const TreeStop stop{ctl, ls, max_iters, trace_dev, trace_cap};
+        TreeCtl* hp = nullptr;
+        HGMM_TRY(tree_host_ctl(c, &hp));
+        const int batch = 4;
+        int enq = 0, slot = 0, rc = HGMM_OK;
+        auto enqueue_batch = [&](int s) -> int {
+            const int cnt = std::min(batch, max_iters - enq);
+            for (int b = 0; b < cnt; ++b) {
+                const int k = enq + b;                         // iteration k: labels into buffer (k + 1) & 1
+                tree_mstep_kernel<<<nblk(J, 256), 256, 0, c->stream>>>(c->t_mom.as<double>(), 0, J, n_total, ld, d_pi, d_mu,
+                                                                       d_cov, d_prep, flags_ptr(c), &ctl->done);
+                const int r = fullcov_fused(c, J, J16, ((k + 1) & 1) ? lab_b : lab_a, nullptr, k + 1 < max_iters,
+                                            &ctl->done, stop);
+                if (r != HGMM_OK) return r;
+            }
+            enq += cnt;
+            if (hipMemcpyAsync(&hp[s], ctl, sizeof(TreeCtl), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipEventRecord(c->tree_ev[s], c->stream) != hipSuccess)
+                return fail(c, HGMM_ERR_HIP, "full-covariance fit: device error: %s", hipGetErrorString(hipGetLastError()));
+            return HGMM_OK;
+        };
+        rc = enqueue_batch(slot);
+        while (rc == HGMM_OK) {
+            const bool ahead = enq < max_iters;
+            if (ahead) rc = enqueue_batch(slot ^ 1);
+            if (rc != HGMM_OK) break;
+            if (hipEventSynchronize(c->tree_ev[slot]) != hipSuccess) {
+                rc = fail(c, HGMM_ERR_HIP, "full-covariance fit: device error: %s", hipGetErrorString(hipGetLastError()));
+                break;
+            }
+            it = hp[slot].it;
+            if (hp[slot].done != 0) break;
+            if (!ahead) { rc = fail(c, HGMM_ERR_STATE, "full-covariance fit did not stop within its budget"); break; }
+            slot ^= 1;
+        }
+        HGMM_TRY(rc);
+        q_len = it;
+        lab_cur = ((it - 1) & 1) ? lab_b : lab_a;              // the arg-max of the E-step whose statistics the last M-step took
+        if (q_trace_out && q_len > 0)
+            HGMM_HIP(c, hipMemcpyAsync(q_trace_out, trace_dev, sizeof(double) * std::min(std::min(q_len, q_capacity), trace_cap),
+                                       hipMemcpyDeviceToHost, c->stream));
+    } else
     while (true) {
         if (!one_pass) HGMM_TRY(fullcov_moments(c, J, J16, grid));                    // E (moments)
         tree_mstep_kernel<<<nblk(J, 256), 256, 0, c->stream>>>(c->t_mom.as<double>(), 0, J, n_total, ld, d_pi, d_mu,
