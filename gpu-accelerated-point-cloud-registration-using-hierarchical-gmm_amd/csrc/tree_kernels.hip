@@ -630,15 +630,21 @@ constexpr int LL_TILE = 256;
 // shares -- in the same fixed order as tree_sum_kernel -- so that no separate reduction launch is
 // needed (the result does not depend on which workgroup happens to be last).
 struct TreeCtl { int done; int it; double prev_q; };
-struct TreeStop { TreeCtl* ctl; double ls; int max_iters; double* trace; int trace_cap; };   // ctl == nullptr: not here
+// host_word (may be null): a word of pinned HOST memory that receives (done << 32 | iterations) after every update, so
+// that the host can follow the loop without a copy, an event or a synchronisation (hgmm_tree_build)
+struct TreeStop { TreeCtl* ctl; double ls; int max_iters; double* trace; int trace_cap; unsigned long long* host_word = nullptr; };   // ctl == nullptr: not here
 // the stop rule of one tree level (see tree_ctl_kernel); one thread
 __device__ __forceinline__ void tree_ctl_update(double q, const TreeStop& st) {
     TreeCtl* ctl = st.ctl;
     const int it = ctl->it;
     if (it < st.trace_cap) st.trace[it] = q;
     ctl->it = it + 1;
-    if (fabs(q - ctl->prev_q) < st.ls || it + 1 >= st.max_iters) ctl->done = 1;
+    const int stop_now = (fabs(q - ctl->prev_q) < st.ls || it + 1 >= st.max_iters) ? 1 : 0;
+    if (stop_now) ctl->done = 1;
     ctl->prev_q = q;
+    if (st.host_word)
+        __hip_atomic_store(st.host_word, ((unsigned long long)stop_now << 32) | (unsigned long long)(unsigned)(it + 1),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // (With `stop.ctl` set the workgroup that finishes last also applies the level's stop rule -- every other workgroup
 //  of the launch has passed its own look at the flag by then -- which saves the one-thread launch per iteration.)
@@ -980,9 +986,10 @@ __global__ __launch_bounds__(CH) void tree_loglik_finish_kernel(const double* __
 // prev_q sits behind it.  Lets the host enqueue several iterations per synchronisation: the kernels of
 // an iteration that comes after the stop return at once.
 __global__ void tree_ctl_kernel(const double* __restrict__ q_dev, TreeCtl* __restrict__ ctl, double ls,
-                                int max_iters, double* __restrict__ trace, int trace_cap) {
+                                int max_iters, double* __restrict__ trace, int trace_cap,
+                                unsigned long long* host_word = nullptr) {
     if (ctl->done) return;
-    tree_ctl_update(*q_dev, TreeStop{ctl, ls, max_iters, trace, trace_cap});
+    tree_ctl_update(*q_dev, TreeStop{ctl, ls, max_iters, trace, trace_cap, host_word});
 }
 
 // (`done`: skip when the loop this launch belongs to has stopped; `stop`: apply the loop's stop rule to the sum)
@@ -1469,7 +1476,9 @@ static int ensure_exp_tab2(hgmm_ctx* c) {
 // pinned {done, iterations} slots + events for the build's look-ahead batches
 static int tree_host_ctl(hgmm_ctx* c, TreeCtl** out) {
     if (!c->tree_hctl) {
-        HGMM_HIP(c, hipHostMalloc(&c->tree_hctl, 256, hipHostMallocDefault));
+        // (coherent = fine-grained: a system-scope store of a running kernel is visible to the polling host at once)
+        HGMM_HIP(c, hipHostMalloc(&c->tree_hctl, 256, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(c->tree_hctl, 0, 256);
         HGMM_HIP(c, hipEventCreateWithFlags(&c->tree_ev[0], hipEventDisableTiming));
         HGMM_HIP(c, hipEventCreateWithFlags(&c->tree_ev[1], hipEventDisableTiming));
     }
@@ -1560,6 +1569,21 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     // saves: 2/4/8 -> 3.67/3.60/3.46 ms @C4, 5.12/5.07/5.02 @1M on one box.
     int batch_iters = 8;
     if (const char* e = std::getenv("HGMM_TREE_BATCH")) batch_iters = std::max(1, std::min(64, atoi(e)));
+    // single GPU: progress word in pinned host memory, polled (see the level loop); HGMM_TREE_AHEAD=0 -> the batch scheme
+    // (C4, one box: batch scheme 3.16-3.6 ms; 1 / 2 / 3 / 4 / 6 iterations ahead: 3.39 / 2.88 / 3.0 / 2.94 / 2.97 ms -- with one
+    //  the device waits for the host after every iteration; the host needs ~10 us to enqueue what the device runs in ~25)
+    int ahead_iters = 2;
+    if (const char* e = std::getenv("HGMM_TREE_AHEAD")) ahead_iters = std::max(0, std::min(64, atoi(e)));
+    unsigned long long* host_word = nullptr;                   // host address / device address of the same pinned word
+    unsigned long long* host_word_dev = nullptr;
+    if (!c->comm_on() && ahead_iters > 0) {
+        TreeCtl* hp0 = nullptr;
+        HGMM_TRY(tree_host_ctl(c, &hp0));
+        host_word = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(hp0) + 64);
+        void* dp = nullptr;
+        HGMM_HIP(c, hipHostGetDevicePointer(&dp, host_word, 0));
+        host_word_dev = static_cast<unsigned long long*>(dp);
+    }
 
     HGMM_HIP(c, hipMemcpyAsync(c->scratch.p, init_mu, sizeof(double) * 3 * T, hipMemcpyHostToDevice, c->stream));
     tree_init_nodes_kernel<<<nblk(T, 256), 256, 0, c->stream>>>(c->scratch.as<double>(), sig2, T, d_pi, d_mu, d_cov);
@@ -1658,7 +1682,8 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                     // ... and, on a single GPU, applies the level's stop rule (with a communicator q is all-reduced
                     // first and tree_ctl_kernel does it)
                     const TreeStop no_stop{nullptr, 0.0, 0, nullptr, 0};
-                    const TreeStop stop = c->comm_on() ? no_stop : TreeStop{ctl, ls, max_iters_per_level, trace_dev, trace_cap};
+                    const TreeStop stop = c->comm_on() ? no_stop
+                                                       : TreeStop{ctl, ls, max_iters_per_level, trace_dev, trace_cap, host_word_dev};
 #define LL_LAUNCH(PTS)                                                                                     \
     tree_loglik_kernel<PTS><<<dim3(llblocks, chunks), CH, 0, c->stream>>>(                                 \
         xs_cur, n, n_pad, d_prep, lb, n_level, per_chunk, ll_partial, block_q, q_ticket, q_dev, &ctl->done, \
@@ -1687,7 +1712,37 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
         // quarter of C4's build).  The price: when a level stops, the batch enqueued ahead runs as skipped launches
         // (~1 us each).  No batch is enqueued beyond the level's iteration budget.
         int it = 0;
-        {
+        if (host_word) {
+            // Single GPU: the stop rule's last thread also stores (done << 32 | iterations) into a word of pinned HOST
+            // memory, and the host keeps `ahead` iterations enqueued beyond the last one it has seen finished -- no copy, no
+            // event, no synchronisation inside a level, and at most `ahead` iterations of skipped launches behind a stop
+            // (the batch scheme below: 46 of them over C4's four levels, ~0.25 ms of a 3.1 ms build, plus a control-word
+            // copy per batch).  The word is reset here: every launch that could write it belongs to this level.
+            __atomic_store_n(host_word, 0ull, __ATOMIC_RELAXED);
+            int enq = 0;
+            unsigned spins = 0;
+            while (rc == HGMM_OK) {
+                const unsigned long long w = __atomic_load_n(host_word, __ATOMIC_RELAXED);
+                it = (int)(w & 0xffffffffull);
+                if (w >> 32) break;                                           // the level has stopped after `it` iterations
+                if (enq < max_iters_per_level && enq - it < ahead_iters) {
+                    rc = enqueue_iteration();
+                    ++enq;
+                    spins = 0;
+                    continue;
+                }
+                if (enq >= max_iters_per_level && it >= enq) {                // cannot happen (the budget's last iteration stops)
+                    rc = fail(c, HGMM_ERR_STATE, "tree build: level %d did not stop within its budget", l);
+                    break;
+                }
+                __builtin_ia32_pause();
+                if ((++spins & 0x3fff) == 0) {                                // every ~16k polls: is the device still alive?
+                    const hipError_t qe = hipStreamQuery(c->stream);
+                    if (qe != hipSuccess && qe != hipErrorNotReady)
+                        rc = fail(c, HGMM_ERR_HIP, "tree build: device error: %s", hipGetErrorString(qe));
+                }
+            }
+        } else {
             TreeCtl* hp = nullptr;
             rc = tree_host_ctl(c, &hp);
             int enq = 0, slot = 0;
