@@ -48,6 +48,7 @@ struct TreeState {
     bool nodes_ready = false;
     double mu_rmax = -1.0;            // largest |mu_j| of the node table (< 0: not known on the host yet)
     bool momq_dirty = true;           // the fixed-point moment words hold sums nobody has cleared yet
+    unsigned long long reg_seq = 0;   // sequence number of the last registration system handed over in pinned memory
 };
 
 }  // namespace hgmm

@@ -1336,7 +1336,10 @@ __global__ void tree_reg_expand_kernel(const double* __restrict__ cm, const doub
 __global__ __launch_bounds__(256) void tree_reg_normal_kernel(unsigned long long* __restrict__ momq /*[T][4]*/,
                                                               double d_ext, double inv_scale,
                                                               const double* __restrict__ prep, int64_t T,
-                                                              double* __restrict__ out) {
+                                                              double* __restrict__ out,
+                                                              double* host_out = nullptr,
+                                                              unsigned long long* host_seq = nullptr,
+                                                              unsigned long long seq = 0) {
     double acc[28];
 #pragma unroll
     for (int k = 0; k < 28; ++k) acc[k] = 0.0;
@@ -1394,7 +1397,20 @@ __global__ __launch_bounds__(256) void tree_reg_normal_kernel(unsigned long long
         if (lane_id() == 0) sh[wave_in_block()][k] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 28) out[threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    // host_out / host_seq: coherent pinned HOST memory -- the 28 numbers, then (behind a system-scope release) the
+    // sequence number the host is polling for: the registration loop's one hand-over per iteration without a copy
+    // packet and a stream synchronisation
+    if (threadIdx.x < 64) {                                  // wave 0
+        if (threadIdx.x < 28) {
+            const double v = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+            out[threadIdx.x] = v;
+            if (host_out) host_out[threadIdx.x] = v;
+        }
+        if (host_out) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // expand the 10 unique moments into the reference layout m0[T], m1[T,3], m2[T,3,3]
@@ -1477,8 +1493,10 @@ static int ensure_exp_tab2(hgmm_ctx* c) {
 static int tree_host_ctl(hgmm_ctx* c, TreeCtl** out) {
     if (!c->tree_hctl) {
         // (coherent = fine-grained: a system-scope store of a running kernel is visible to the polling host at once)
-        HGMM_HIP(c, hipHostMalloc(&c->tree_hctl, 256, hipHostMallocMapped | hipHostMallocCoherent));
-        std::memset(c->tree_hctl, 0, 256);
+        // layout: [0, 32) two control-word slots of the batch scheme, [64] the polled progress word of the tree build,
+        // [128] sequence number + [256, 480) the 28 numbers of the registration loop's hand-over
+        HGMM_HIP(c, hipHostMalloc(&c->tree_hctl, 1024, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(c->tree_hctl, 0, 1024);
         HGMM_HIP(c, hipEventCreateWithFlags(&c->tree_ev[0], hipEventDisableTiming));
         HGMM_HIP(c, hipEventCreateWithFlags(&c->tree_ev[1], hipEventDisableTiming));
     }
@@ -1971,12 +1989,32 @@ extern "C" int hgmm_tree_reg_normal(hgmm_ctx* c, const double* rot, const double
     HGMM_TRY(reg_estep_fixed<4>(c, rot, t, scale, lambda_c, &D, &F));
     const int64_t T = c->tree.T;
     HGMM_TRY(ensure(c, c->scratch, sizeof(double) * 32));
+    // The 28 numbers come back through coherent pinned memory: the kernel stores them there and then a sequence
+    // number the host polls (a D2H copy packet + a stream synchronisation cost ~20 us of every ~60 us iteration).
+    TreeCtl* hp = nullptr;
+    HGMM_TRY(tree_host_ctl(c, &hp));
+    char* hbase = reinterpret_cast<char*>(hp);
+    unsigned long long* h_seq = reinterpret_cast<unsigned long long*>(hbase + 128);
+    double* h_out = reinterpret_cast<double*>(hbase + 256);
+    void *d_seq = nullptr, *d_out = nullptr;
+    HGMM_HIP(c, hipHostGetDevicePointer(&d_seq, h_seq, 0));
+    HGMM_HIP(c, hipHostGetDevicePointer(&d_out, h_out, 0));
+    const unsigned long long seq = ++c->tree.reg_seq;
     tree_reg_normal_kernel<<<1, 256, 0, c->stream>>>(c->t_momq.as<unsigned long long>(), D, std::ldexp(1.0, -F),
-                                                    c->t_prep.as<double>(), T, c->scratch.as<double>());
+                                                    c->t_prep.as<double>(), T, c->scratch.as<double>(),
+                                                    static_cast<double*>(d_out), static_cast<unsigned long long*>(d_seq), seq);
     HGMM_HIP(c, hipGetLastError());
     c->tree.momq_dirty = false;                                   // the kernel zeroed the [T][4] words it consumed
-    HGMM_HIP(c, hipMemcpyAsync(out28, c->scratch.p, sizeof(double) * 28, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, ctx_stream_sync(c));
+    unsigned spins = 0;
+    while (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) != seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0x3fff) == 0) {                            // is the device still alive?  has the stream drained?
+            const hipError_t qe = hipStreamQuery(c->stream);
+            if (qe != hipSuccess && qe != hipErrorNotReady)
+                return fail(c, HGMM_ERR_HIP, "registration: device error: %s", hipGetErrorString(qe));
+        }
+    }
+    std::memcpy(out28, h_out, sizeof(double) * 28);
     return HGMM_OK;
 }
 
