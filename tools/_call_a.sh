@@ -1,11 +1,19 @@
 set -u
-export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_tree_gpu.py tests/test_dropin_gpu.py tests/test_integration_snippet_gpu.py -m gpu -q -x --timeout 600 2>&1 | tail -3
-timeout 300 python bench.py 2>/dev/null > gpurun_out/bench_try.json; python -c "
-import json
-d=json.loads(open('gpurun_out/bench_try.json').readline())
-print('reg',json.dumps(d['registration']))
-print('hgmm',d['hgmm']['build_ms'],'t1M',d['tree_1M']['build_ms'], 'fullcov', d['fullcov']['ms_per_iteration'], d['fullcov'].get('marginal_ms_per_iteration'))
-k=d['kmeans_init'] if 'kmeans_init' in d else d['kmeans']; print('kmeans', k['fit_ms_warm'], k['seeding_ms_warm'], k['bun000_k100_fit_ms'])
-print('value', d['value'], d['roofline']['frac'], d['materialised_iteration']['it_per_s'])
-"
+python - <<'PY'
+import os, sys
+import numpy as np
+sys.path.insert(0, '.')
+import hgmm_amd
+ctx = hgmm_amd.Context(0)
+for n, k, trials in ((60000, 1200, None), (4000, 50, 16), (4000, 50, 1), (70000, 3, 3), (1100000, 64, 5)):
+    X = np.random.RandomState(n).rand(n, 3); ctx.set_points(X - X.mean(0))
+    t = trials or (2 + int(np.log(k))); rand = np.random.RandomState(1).uniform(size=(k - 1, t))
+    os.environ.pop("HGMM_KMPP_TWO_LAUNCHES", None)
+    a = ctx.kmeans_plusplus(k, 7 % n, rand)
+    os.environ["HGMM_KMPP_TWO_LAUNCHES"] = "1"
+    b = ctx.kmeans_plusplus(k, 7 % n, rand)
+    os.environ["HGMM_KMPP_UNFUSED"] = "1"
+    c = ctx.kmeans_plusplus(k, 7 % n, rand)
+    os.environ.pop("HGMM_KMPP_UNFUSED")
+    print(n, k, t, "fused==two-launch", np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), "==four-kernel form", np.array_equal(a[0], c[0]))
+PY
