@@ -97,4 +97,4 @@ def train_gmm(X, max_iter, tol, means, covariances, weights, cov_type, variant):
 
 def predict(X, inv_cov, means, weights, cov_type, variant):
     ctx = _ctx_for(X)
-    return ctx.flat_predict(_host(inv_cov), _host(means), _host(weights), cov_type, variant).get().astype(np.int64)
+    return ctx.flat_predict(_param(inv_cov), _param(means), _param(weights), cov_type, variant).get().astype(np.int64)

@@ -75,6 +75,7 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_flat_estep_async", [ctx, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
         _sig(lib, "hgmm_flat_estep_dev", [ctx, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
         _sig(lib, "hgmm_flat_mstep_dev", [ctx, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp])
+        _sig(lib, "hgmm_flat_predict_dev", [ctx, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp])
         _sig(lib, "hgmm_elementwise_f32", [ctx, C.c_int, C.c_int64, _vp, _vp, C.c_float, _vp])
         _sig(lib, "hgmm_host_scalars", [ctx, C.c_int, C.POINTER(_f64p), C.POINTER(_vp)])
         _sig(lib, "hgmm_event_record", [ctx, C.c_int])
@@ -634,6 +635,12 @@ class Context:
         return out
 
     def flat_predict(self, inv_std, mu, w, cov_type="diag", variant="W"):
+        if any(isinstance(a, DeviceArray) for a in (inv_std, mu, w)):
+            J, mu, inv_std, w = self._flat_dev_args(mu, inv_std, w, cov_type)
+            lab = self.empty((self.num_points,), np.int32)
+            self._check(self.lib.hgmm_flat_predict_dev(self.h, COV_TYPES[cov_type], VARIANTS[variant], J,
+                                                       mu.ptr, inv_std.ptr, w.ptr, lab.ptr))
+            return lab
         J, mu, inv_std, w = self._flat_args(mu, inv_std, w, cov_type)
         lab = self.empty((self.num_points,), np.int32)
         self._check(self.lib.hgmm_flat_predict(self.h, COV_TYPES[cov_type], VARIANTS[variant], J,

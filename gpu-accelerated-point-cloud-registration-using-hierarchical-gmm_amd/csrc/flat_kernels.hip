@@ -1864,6 +1864,21 @@ extern "C" int hgmm_flat_predict(hgmm_ctx* c, int cov_type, int variant, int J, 
     return HGMM_OK;
 }
 
+extern "C" int hgmm_flat_predict_dev(hgmm_ctx* c, int cov_type, int variant, int J, const float* dev_mu,
+                                     const float* dev_inv_std, const float* dev_w, int32_t* dev_labels) {
+    if (!c || !dev_labels) return c ? fail(c, HGMM_ERR_ARG, "dev_labels is NULL") : HGMM_ERR_ARG;
+    if (!dev_mu || !dev_inv_std || !dev_w) return fail(c, HGMM_ERR_ARG, "device parameter array is NULL");
+    HGMM_TRY(flat_check(c, cov_type, variant, J));
+    HGMM_TRY(flat_setup(c, cov_type, variant, J));
+    const FlatState& f = c->flat;
+    flat_pack_kernel<<<(f.Jpad + 255) / 256, 256, 0, c->stream>>>(f.J, f.Jpad, f.cov_type, f.variant, dev_mu, dev_inv_std,
+                                                                dev_w, c->f_pack.as<float>());
+    int grid = 0;
+    if (c->flat.chunked) return chunk_normalisers(c, true, nullptr, dev_labels, false, nullptr);
+    HGMM_TRY(launch_estep<false>(c, nullptr, nullptr, dev_labels, &grid));
+    return HGMM_OK;
+}
+
 extern "C" int hgmm_flat_log_prob(hgmm_ctx* c, int cov_type, int J, const float* mu, const float* inv_std,
                                   float* dev_log_prob) {
     if (!c || !dev_log_prob) return c ? fail(c, HGMM_ERR_ARG, "dev_log_prob is NULL") : HGMM_ERR_ARG;

@@ -141,6 +141,9 @@ int hgmm_flat_estep_dev(hgmm_ctx* ctx, int cov_type, int variant, int J,
 int hgmm_flat_mstep_dev(hgmm_ctx* ctx, int cov_type, int variant, int J,
                         const float* dev_resp, int is_log, const float* dev_centre_hint,
                         float* dev_w, float* dev_mu, float* dev_cov);
+int hgmm_flat_predict_dev(hgmm_ctx* ctx, int cov_type, int variant, int J,
+                          const float* dev_mu, const float* dev_inv_std, const float* dev_w,
+                          int32_t* dev_labels);
 /* Un-normalised per-pair log-densities log N(x_i; mu_j, diag) -> dev_log_prob [N,J]
  * (estimate_log_prob / estimate_log_prob_spherical, gmm_waymo gmm_impl.py:53-78). */
 int hgmm_flat_log_prob(hgmm_ctx* ctx, int cov_type, int J, const float* mu, const float* inv_std,

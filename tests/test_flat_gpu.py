@@ -879,3 +879,7 @@ def test_device_array_parameters_and_elementwise(ctx, bunny):
         assert abs(vals[k] - ref) < 1e-7
     with pytest.raises(ValueError):
         ctx.flat_estep(ctx.to_device(inv0[:5]), ctx.to_device(mu0), w0, "diag", "W", want_log_resp=False)
+    # predict with the parameters where they are == predict with host copies of them
+    lab_d = W.predict(dX, *[ctx.to_device(x) for x in p_h])
+    lab_h = W.predict(dX, *p_h)
+    assert lab_d.dtype == np.int64 and np.array_equal(lab_d, lab_h)
