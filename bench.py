@@ -515,6 +515,36 @@ def materialised_iteration_leg(ctx, lr, inv, mu, w):
     return out
 
 
+def predict_leg(ctx, fitted):
+    """predict(X, inv_cov, means, weights) (gmm_impl.py:147-155) on the C3 frame: labels[N] only, parameters in device
+    arrays, one call per frame the way run_gmm_waymo_gpu.py:32-61 predicts every frame."""
+    inv, mu, w = fitted
+    p = (ctx.to_device(inv), ctx.to_device(mu), ctx.to_device(w))
+    for _ in range(3):
+        lab = ctx.flat_predict(*p)
+    ctx.synchronize()
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        lab = ctx.flat_predict(*p)
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    ctx.profile_enable(False)
+    k_ms, k_n = ctx.profile_get("flat_estep")
+    k_s = k_ms / max(k_n, 1) * 1e-3
+    flop = 12.0 * N_POINTS * J_COMP                 # per pair and axis: x - mu, (x - mu) g, c -= ((x - mu) g)(x - mu)
+    del lab
+    return {"workload": "predict() on the 1M-point frame, J=800 (labels only; parameters in device arrays)",
+            "ms_per_frame": dt * 1e3, "kernel_ms": k_s * 1e3, "points_per_s": N_POINTS / dt,
+            "roofline": {"kernel": "flat_predict_rows_kernel<3,1>", "bound": "valu", "unit": "TFLOP/s",
+                         "flop_per_pair": 12, "achieved": flop / k_s / 1e12, "peak": FP32_VECTOR_PEAK_TF,
+                         "frac": flop / k_s / 1e12 / FP32_VECTOR_PEAK_TF,
+                         "note": "the arg-max (row maximum, index search, two wave reductions) is as many issue slots "
+                                 "again as the quadratic forms and is not counted as flops"}}
+
+
 def fused_roofline(avg_launch_s, cus):
     """VALU accounting of flat_fused_pk_kernel<13> from the code object (tools/isa_count.py)."""
     out = {"kernel": "flat_fused_pk_kernel<13> (constant-shift loop)", "bound": "valu", "unit": "TFLOP/s",
@@ -700,6 +730,7 @@ def rank_main(args):
     if rank == 0 and world == 1:
         # (from the INITIAL parameters, as a caller's own loop starts: inv_cov0 = 1 / sqrt(cov0), gmm_impl.py:122)
         out["materialised_iteration"] = materialised_iteration_leg(ctx, lr, (1.0 / np.sqrt(cov0)).astype(np.float32), mu0, w0)
+        out["predict"] = predict_leg(ctx, (inv, mu, w))
         # what a pure 16-byte store stream of the same size reaches on this chip (write ceiling)
         # (best pure-store pattern found, tools/fillbench.py: one workgroup per CU, grid-stride)
         ctx.util_fill(lr, 0.0, False, 0, 1)

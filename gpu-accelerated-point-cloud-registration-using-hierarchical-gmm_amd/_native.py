@@ -141,6 +141,8 @@ EW_OPS = {"add": 0, "sub": 1, "rsub": 2, "mul": 3, "div": 4, "rdiv": 5, "sqrt": 
 # arrays up to this size are carved from the context's arena (no hipMalloc / hipFree, nothing waits when they die)
 SMALL_BYTES = 128 << 10
 SMALL_SLABS = 64
+# dead arrays kept for reuse by the next array of the same size, in total at most this much memory (of 288 GB)
+FREED_CAP_BYTES = 16 << 30
 # np.exp() of an array with at least this many elements stays a lazy view (the consumer fuses the exponential)
 LAZY_EXP_ELEMS = 1 << 20
 # ndarray methods a DeviceArray answers by downloading itself first
@@ -315,7 +317,7 @@ class DeviceArray:
             if self._slab is not None:
                 self.ctx._free_small(self._slab)
             else:
-                self.ctx._free(self.ptr)
+                self.ctx._free(self.ptr, self.nbytes)
             self.ptr = None
 
     def __del__(self):
@@ -441,6 +443,8 @@ class Context:
         self._points_owner = None
         self.nranks, self.rank = 1, 0
         self._arena = None                    # (pointer, free slab indices) of the small-array pool
+        self._freed = {}                      # size -> pointers of dead arrays kept for reuse (_free)
+        self._freed_bytes = 0
         self._scalar_host = None              # pinned, device-visible doubles (DeviceScalar)
         self._scalar_dev = None
         self._scalar_next = 0
@@ -467,6 +471,10 @@ class Context:
             if self._arena is not None:               # (arrays carved from it die with the context)
                 self.lib.hgmm_free(self.h, self._arena[0])
                 self._arena = None
+            for lst in self._freed.values():
+                for ptr in lst:
+                    self.lib.hgmm_free(self.h, ptr)
+            self._freed, self._freed_bytes = {}, 0
             self.lib.hgmm_destroy(self.h)
             self.h = None
 
@@ -477,13 +485,30 @@ class Context:
             pass
 
     def _alloc(self, nbytes):
+        nbytes = int(max(nbytes, 4))
+        cached = self._freed.get(nbytes)
+        if cached:                                   # an array of exactly this size died earlier: take its memory
+            self._freed_bytes -= nbytes
+            return cached.pop()
         p = _vp()
-        self._check(self.lib.hgmm_alloc(self.h, int(max(nbytes, 4)), C.byref(p)))
+        self._check(self.lib.hgmm_alloc(self.h, nbytes, C.byref(p)))
         return p
 
-    def _free(self, p):
-        if getattr(self, "h", None):
-            self.lib.hgmm_free(self.h, p)
+    def _free(self, p, nbytes=None):
+        """Arrays that die are kept for the next array of the same size (a caller's loop allocates the same shapes
+        over and over: labels per frame, log_resp per iteration) -- up to FREED_CAP_BYTES; hipFree beyond that.  Everything
+        that touches the memory is ordered on the context's one stream, so handing it out again needs no waiting,
+        while hgmm_free has to drain the stream first."""
+        if not getattr(self, "h", None):
+            return
+        if nbytes is not None:
+            nbytes = int(max(nbytes, 4))
+            lst = self._freed.setdefault(nbytes, [])
+            if self._freed_bytes + nbytes <= FREED_CAP_BYTES and len(lst) < 4:
+                lst.append(p)
+                self._freed_bytes += nbytes
+                return
+        self.lib.hgmm_free(self.h, p)
 
     def _alloc_small(self, nbytes):
         """-> (slab index, pointer) from the context's arena, or (None, None) when the request is large or the

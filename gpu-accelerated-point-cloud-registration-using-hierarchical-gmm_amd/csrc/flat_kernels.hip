@@ -520,6 +520,121 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_rows_pk_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// predict(): arg-max_j of the weighted log-probabilities, nothing else (gmm_impl.py:147-155).  Same lane <-> component
+// layout and the same packed arithmetic as flat_estep_rows_pk_kernel (so the values compared are the ones e_step's own
+// arg-max sees), four rows in flight per wave -- and no exponentials, no normaliser, no N x J traffic: per row the
+// quadratic forms (9 packed instructions per pair of components), the row maximum (one 4-wide DPP reduction for the
+// four rows) and the smallest index that attains it (indices ride as negated floats through the same 4-wide max
+// reduction: a second compare-and-select pass instead of an index carried through the first).
+// (The single-row kernel this replaces for predict ran 0.33 ms per 10^6 x 800 frame; its row maximum, index search
+//  and two 6-step wave reductions were one dependent chain per row.)
+// ------------------------------------------------------------------------------------------
+template <int NV4, int NV1>
+__global__ __launch_bounds__(BLOCK) void flat_predict_rows_kernel(
+    const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int J, int Jpad,
+    int32_t* __restrict__ labels) {
+    using L = Layout<NV4, NV1>;
+    constexpr int K = L::K;
+    constexpr int KP = 2 * NV4 + NV1 / 2;          // pairs
+    constexpr bool ODD = (NV1 & 1) != 0;           // trailing single = component K - 1
+    constexpr int ROWS = 4;
+    const int lane = lane_id();
+    f2 mu0[KP + 1], mu1[KP + 1], mu2[KP + 1], g0[KP + 1], g1[KP + 1], g2[KP + 1], cc[KP + 1];
+    float mu0s = 0.f, mu1s = 0.f, mu2s = 0.f, g0s = 0.f, g1s = 0.f, g2s = 0.f, cs = NEG_INF;
+    auto ld = [&](int row, int j) { return pack[row * Jpad + j]; };
+#pragma unroll
+    for (int p = 0; p < KP; ++p) {
+        const int ja = L::j_of(2 * p, lane), jb = L::j_of(2 * p + 1, lane);
+        mu0[p] = f2{ld(PK_MU + 0, ja), ld(PK_MU + 0, jb)};
+        mu1[p] = f2{ld(PK_MU + 1, ja), ld(PK_MU + 1, jb)};
+        mu2[p] = f2{ld(PK_MU + 2, ja), ld(PK_MU + 2, jb)};
+        g0[p] = f2{ld(PK_G + 0, ja), ld(PK_G + 0, jb)};
+        g1[p] = f2{ld(PK_G + 1, ja), ld(PK_G + 1, jb)};
+        g2[p] = f2{ld(PK_G + 2, ja), ld(PK_G + 2, jb)};
+        cc[p] = f2{ld(PK_C, ja), ld(PK_C, jb)};
+    }
+    if (ODD) {
+        const int j = L::j_of(K - 1, lane);
+        mu0s = ld(PK_MU + 0, j); mu1s = ld(PK_MU + 1, j); mu2s = ld(PK_MU + 2, j);
+        g0s = ld(PK_G + 0, j); g1s = ld(PK_G + 1, j); g2s = ld(PK_G + 2, j);
+        cs = ld(PK_C, j);
+    }
+    float njf[K];                                  // -(index): the smallest index is the largest of these
+#pragma unroll
+    for (int k = 0; k < K; ++k) njf[k] = -(float)L::j_of(k, lane);
+
+    const int64_t nw = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    const int64_t gw = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
+    const int64_t ngroups = (n + ROWS - 1) / ROWS;
+    float x[ROWS][3];
+    auto load_group = [&](int64_t g, float (&dst)[ROWS][3]) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            int64_t row = g * ROWS + r;
+            row = row < n ? row : n - 1;
+            const float* xp = X + 3 * row;
+            dst[r][0] = xp[0]; dst[r][1] = xp[1]; dst[r][2] = xp[2];
+        }
+    };
+    if (gw < ngroups) load_group(gw, x);
+    for (int64_t g = gw; g < ngroups; g += nw) {
+        float nx[ROWS][3];
+        load_group((g + nw < ngroups) ? g + nw : g, nx);          // prefetch (scalar loads)
+        f2 wl[ROWS][KP + 1];
+        float wls[ROWS];
+        float m[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const f2 X0 = f2{x[r][0], x[r][0]}, X1 = f2{x[r][1], x[r][1]}, X2 = f2{x[r][2], x[r][2]};
+            float mm = NEG_INF;
+#pragma unroll
+            for (int p = 0; p < KP; ++p) {
+                const f2 d0 = X0 - mu0[p], d1 = X1 - mu1[p], d2 = X2 - mu2[p];
+                f2 a = cc[p] - (d0 * g0[p]) * d0;
+                a = a - (d1 * g1[p]) * d1;
+                a = a - (d2 * g2[p]) * d2;
+                wl[r][p] = a;
+                mm = fmaxf(mm, fmaxf(a.x, a.y));
+            }
+            wls[r] = NEG_INF;
+            if (ODD) {
+                const float d0 = x[r][0] - mu0s, d1 = x[r][1] - mu1s, d2 = x[r][2] - mu2s;
+                float a = fmaf(-(d0 * g0s), d0, cs);
+                a = fmaf(-(d1 * g1s), d1, a);
+                a = fmaf(-(d2 * g2s), d2, a);
+                wls[r] = a;
+                mm = fmaxf(mm, a);
+            }
+            m[r] = mm;
+        }
+        wave_max4_dpp(m);
+        float b[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            float best = NEG_INF;                                  // descending k: the last hit is the lane's smallest index
+#pragma unroll
+            for (int k = K - 1; k >= 0; --k) {
+                const float val = (ODD && k == K - 1) ? wls[r] : ((k & 1) ? wl[r][k >> 1].y : wl[r][k >> 1].x);
+                best = (val == m[r]) ? njf[k] : best;
+            }
+            b[r] = best;
+        }
+        wave_max4_dpp(b);
+        if (lane < ROWS) {
+            const int64_t row = g * ROWS + lane;
+            const float mb = lane == 0 ? m[0] : lane == 1 ? m[1] : lane == 2 ? m[2] : m[3];
+            const float bb = lane == 0 ? b[0] : lane == 1 ? b[1] : lane == 2 ? b[2] : b[3];
+            // every component at -inf (zero weights) or NaN everywhere: index 0, like argmax of a constant row
+            int lab = (mb == NEG_INF || !(bb > NEG_INF)) ? 0 : (int)(-bb);
+            if (lab >= J) lab = 0;
+            if (row < n) labels[row] = lab;
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { x[r][0] = nx[r][0]; x[r][1] = nx[r][1]; x[r][2] = nx[r][2]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // fused E+M: sufficient statistics without the N x J round trip
 //   s0_j = sum_i r_ij,  a_jd = sum_i r_ij (x_id - mu_jd),  b_jd = sum_i r_ij (x_id - mu_jd)^2
 // ------------------------------------------------------------------------------------------
@@ -1521,6 +1636,36 @@ static bool launch_estep_rows(hgmm_ctx* c, int nv4, int nv1, int grid_r, bool cs
     return true;
 }
 
+// predict(): the four-rows-in-flight arg-max kernel for the layouts it is instantiated for (the others take the general kernel)
+static bool predict_rows_layout(int nv4, int nv1) {
+    if (env_flag("HGMM_PREDICT_SINGLE_ROW", false)) return false;
+    return (nv4 == 3 && nv1 <= 2) || (nv4 == 4 && nv1 == 0) || (nv4 == 2 && nv1 <= 2) || (nv4 == 1 && nv1 <= 2) ||
+           (nv4 == 0 && (nv1 == 1 || nv1 == 2));
+}
+static bool launch_predict_rows(hgmm_ctx* c, int nv4, int nv1, int32_t* labels) {
+    const FlatState& f = c->flat;
+    // (one frame of 10^6 x 800: 0.38 / 0.26 / 0.26 / 0.24 ms with 1 / 2 / 3 / 4 workgroups per CU; the single-row kernel 0.36)
+    const int grid = grid_for(c, (c->n + 3) / 4, env_int("HGMM_PREDICT_BPC", 4));
+    const float* X = c->x_aos.as<float>();
+    const float* pk = c->f_pack.as<float>();
+#define PRED_R(A, B) flat_predict_rows_kernel<A, B><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, labels)
+    if (nv4 == 3 && nv1 == 1) PRED_R(3, 1);
+    else if (nv4 == 3 && nv1 == 0) PRED_R(3, 0);
+    else if (nv4 == 3 && nv1 == 2) PRED_R(3, 2);
+    else if (nv4 == 4 && nv1 == 0) PRED_R(4, 0);
+    else if (nv4 == 2 && nv1 == 0) PRED_R(2, 0);
+    else if (nv4 == 2 && nv1 == 1) PRED_R(2, 1);
+    else if (nv4 == 2 && nv1 == 2) PRED_R(2, 2);
+    else if (nv4 == 1 && nv1 == 0) PRED_R(1, 0);
+    else if (nv4 == 1 && nv1 == 1) PRED_R(1, 1);
+    else if (nv4 == 1 && nv1 == 2) PRED_R(1, 2);
+    else if (nv4 == 0 && nv1 == 1) PRED_R(0, 1);
+    else if (nv4 == 0 && nv1 == 2) PRED_R(0, 2);
+    else return false;
+#undef PRED_R
+    return true;
+}
+
 // Number of workgroups of the materialising E-step.  The kernel sits where two limits meet: with one wave per SIMD
 // its arithmetic is issue-bound, and the HBM write path delivers LESS the more waves write at once (fillbench) --
 // so there is a best grid and it is sharp: constant-shift loop 0.559 / 0.543 / 0.559 / 0.580 / 0.616 ms at 184 / 192 /
@@ -1562,6 +1707,12 @@ static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argma
     pick_layout(f.J, &nv4, &nv1);
     const bool nt = NORMALISE && env_flag("HGMM_ESTEP_NT", true);
     const int rr = env_int("HGMM_ESTEP_RR", 0);
+    if (!NORMALISE && !log_resp && !lpn && argmax && predict_rows_layout(nv4, nv1)) {      // predict(): labels only
+        ProfScope prof(c, HGMM_K_FLAT_ESTEP);
+        (void)launch_predict_rows(c, nv4, nv1, argmax);
+        HGMM_HIP(c, hipGetLastError());
+        return HGMM_OK;
+    }
     // Materialising path: 4 rows in flight per wave, at most ONE workgroup per CU (see the kernel's header)
     const int rows = (NORMALISE && log_resp) ? env_int("HGMM_ESTEP_ROWS", 4) : 1;
     if (rows > 1) {

@@ -883,3 +883,44 @@ def test_device_array_parameters_and_elementwise(ctx, bunny):
     lab_d = W.predict(dX, *[ctx.to_device(x) for x in p_h])
     lab_h = W.predict(dX, *p_h)
     assert lab_d.dtype == np.int64 and np.array_equal(lab_d, lab_h)
+
+
+def test_predict_four_row_kernel_and_array_reuse(ctx, monkeypatch):
+    """predict() runs on its own arg-max kernel (four rows in flight per wave, packed arithmetic, no exponentials);
+    the single-row kernel it replaced is kept for layouts it is not instantiated for: both give the same labels on
+    every layout / flavour, and the labels are the oracle's up to near-ties.  Also: a DeviceArray that dies hands its
+    memory to the next one of the same size (no hipMalloc / hipFree / synchronisation per call in a caller's loop)."""
+    rs = np.random.RandomState(5)
+    for J, ct, var, n in ((100, "diag", "G", 50001), (257, "spherical", "W", 50001), (64, "diag", "W", 3), (1000, "diag", "W", 20011),
+                          (513, "diag", "G", 7777), (7, "spherical", "W", 50001), (800, "diag", "W", 30000), (1024, "diag", "W", 4097)):
+        Xs = rs.rand(n, 3).astype(np.float32)
+        ctx.set_points(Xs)
+        mu = rs.rand(J, 3).astype(np.float32)
+        w = rs.rand(J).astype(np.float32)
+        w /= w.sum()
+        inv = (1.0 / (0.02 + 0.1 * rs.rand(*((J, 3) if ct == "diag" else (J,))))).astype(np.float32)
+        monkeypatch.setenv("HGMM_PREDICT_SINGLE_ROW", "1")
+        a = ctx.flat_predict(inv, mu, w, ct, var).get()
+        monkeypatch.delenv("HGMM_PREDICT_SINGLE_ROW")
+        b = ctx.flat_predict(inv, mu, w, ct, var).get()
+        assert np.array_equal(a, b), (J, ct, var)
+        o = flat_em.predict(Xs.astype(np.float64), inv.astype(np.float64), mu.astype(np.float64), w.astype(np.float64), ct, var)
+        diff = np.nonzero(b != o)[0]
+        if len(diff):                                  # float32 vs float64 near-ties only
+            lp = (flat_em._log_gauss(Xs[diff].astype(np.float64), inv.astype(np.float64), mu.astype(np.float64), ct)
+                  + flat_em._log_weights(w.astype(np.float64), var))
+            r = np.arange(len(diff))
+            assert np.all(np.abs(lp[r, b[diff]] - lp[r, o[diff]]) < 1e-4), (J, ct, var)
+    # zero weights everywhere: index 0, like the arg-max of a constant row
+    ctx.set_points(rs.rand(1000, 3).astype(np.float32))
+    z = ctx.flat_predict(np.ones((8, 3), np.float32), rs.rand(8, 3).astype(np.float32), np.zeros(8, np.float32), "diag", "G").get()
+    assert (z == 0).all()
+    # array reuse: same size -> same memory, another size -> other memory
+    a1 = ctx.empty((1 << 20,), np.float32)
+    p1 = a1.ptr.value
+    del a1
+    a2 = ctx.empty((1 << 20,), np.float32)
+    a3 = ctx.empty((1 << 20,), np.float32)
+    assert a2.ptr.value == p1 and a3.ptr.value != p1
+    a4 = ctx.empty(((1 << 20) + 1,), np.float32)
+    assert a4.ptr.value not in (a2.ptr.value, a3.ptr.value)
