@@ -251,12 +251,24 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_kernel(
             }
             if (lane == slot) keep_lpn = lpn;
         } else if (log_resp) {
-            // raw weighted log-probabilities (estimate_log_prob + log weights), natural log
+            // raw weighted log-probabilities (estimate_log_prob + log weights), natural log; the vector slots as
+            // 16-byte stores like the normalised path (written one float at a time this call ran at 3.6 TB/s)
             float* out = log_resp + row * (int64_t)J;
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const int j = L::j_of(k, lane);
-                if (j < J) out[j] = wl[k] * LN2;
+            for (int v = 0; v < NV4; ++v) {
+                const int jb = (v * 64 + lane) * 4;
+                if (jb + 3 < J)
+                    store_f4<NT>(out + jb, wl[4 * v + 0] * LN2, wl[4 * v + 1] * LN2, wl[4 * v + 2] * LN2, wl[4 * v + 3] * LN2);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (jb + e < J) out[jb + e] = wl[4 * v + e] * LN2;
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < NV1; ++v) {
+                const int j = 256 * NV4 + v * 64 + lane;
+                if (j < J) out[j] = wl[4 * NV4 + v] * LN2;
             }
         }
         if (argmax_out) {
