@@ -446,6 +446,50 @@ __global__ void tree_chunks_kernel(const int* __restrict__ seg_start, int P, int
 }
 
 // ------------------------------------------------------------------------------------------
+// The level's stop rule WITHOUT a reduction tail: every workgroup of the NEXT launch in the stream (the next
+// iteration's E-step, or the one-workgroup tree_close_kernel behind a level's last budgeted iteration) adds up the
+// previous iteration's shares of q for itself -- same fixed order everywhere, so the same q and the same verdict -- and
+// workgroup 0 records it (trace, iteration count, stop flag, the host's progress word).  The log-likelihood kernels
+// just store their shares: no ticket, no atomic, no last-workgroup pass (store_block_q's chain of a drained store, two
+// arrival counters and a read-back was ~3 us at the end of every C4 iteration), and the build path is free of atomics.
+// State is double-buffered by launch parity (launch e reads slot (e - 1) & 1 and writes slot e & 1): a workgroup that
+// starts late must not read what workgroup 0 of its own launch has just written.
+// ------------------------------------------------------------------------------------------
+struct TreeLoopState { int it; int pad; double prev_q; };
+struct TreeFollow {                      // q_blocks == nullptr: nothing to follow (a level's first iteration)
+    const double* q_blocks; int nb;
+    const TreeLoopState* prev; TreeLoopState* next;
+    int* done; double ls; int max_iters; double* trace; int trace_cap; unsigned long long* host_word;
+};
+// true: the level has stopped -- this launch has nothing to do.  Called by all threads of a CH-thread workgroup.
+__device__ __forceinline__ bool tree_follow(const TreeFollow& f, int stop_flag, double* sh4) {
+    const double prev_q = f.prev->prev_q;                 // (requested together with the shares)
+    const int it = f.prev->it;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < f.nb; i += CH) acc += f.q_blocks[i];
+    if (stop_flag) return true;                           // kernel-uniform
+    acc = wave_sum_f64(acc);                              // (the order of store_block_q's last workgroup / tree_sum_kernel)
+    if (lane_id() == 0) sh4[wave_in_block()] = acc;
+    __syncthreads();
+    const double q = sh4[0] + sh4[1] + sh4[2] + sh4[3];
+    const bool stop_now = fabs(q - prev_q) < f.ls || it + 1 >= f.max_iters;      // (hgmm_gpu.py:532; prev_q starts at 0)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (it < f.trace_cap) f.trace[it] = q;
+        f.next->it = it + 1;
+        f.next->prev_q = q;
+        if (stop_now) *f.done = 1;
+        if (f.host_word)
+            __hip_atomic_store(f.host_word, ((unsigned long long)(stop_now ? 1 : 0) << 32) | (unsigned long long)(unsigned)(it + 1),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return stop_now;
+}
+__global__ __launch_bounds__(CH) void tree_close_kernel(TreeFollow f) {
+    __shared__ double sh4[4];
+    (void)tree_follow(f, *f.done, sh4);
+}
+
+// ------------------------------------------------------------------------------------------
 // E-step of one tree level
 // ------------------------------------------------------------------------------------------
 constexpr int ES_LD = 66;            // LDS row stride (doubles) of the moment contraction's operands: conflict-free fragment reads
@@ -453,7 +497,8 @@ typedef double double4_es __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(CH) void tree_estep_kernel(
     const double* __restrict__ xs, int64_t n_pad, const double* __restrict__ prep,
     const int* __restrict__ chunk_desc, const int* __restrict__ n_chunks, int64_t parent_level_first,
-    int level, double* __restrict__ partials, int* __restrict__ cur_sorted, const int* __restrict__ done) {
+    int level, double* __restrict__ partials, int* __restrict__ cur_sorted, const int* __restrict__ done,
+    TreeFollow follow = TreeFollow{nullptr, 0, nullptr, nullptr, nullptr, 0.0, 0, nullptr, 0, nullptr}) {
     // (the stop flag, the chunk count and this chunk's descriptor are requested together -- the descriptor table is
     //  allocated for the whole grid, so the read is safe before the count is known: one trip to memory instead of three)
     const int c = blockIdx.x;
@@ -461,8 +506,14 @@ __global__ __launch_bounds__(CH) void tree_estep_kernel(
     const int chunks_now = *n_chunks;
     const int p = chunk_desc[3 * c + 0], begin = chunk_desc[3 * c + 1], end = chunk_desc[3 * c + 2];
     __shared__ double exp_tab[EXP_TAB_N];
+    __shared__ double sh_follow[4];
     exp_tab_load(exp_tab);                         // (synchronised below, once the points' loads are on their way)
-    if (stop_flag || c >= chunks_now) return;
+    if (c >= chunks_now) return;                   // (workgroup 0 always owns a chunk)
+    if (follow.q_blocks) {
+        if (tree_follow(follow, stop_flag, sh_follow)) return;       // the previous iteration's q stopped the level
+    } else if (stop_flag) {
+        return;
+    }
     // node id of the parent: level 0 -> pseudo-parent -1; child(j) = 8 (j + 1)
     const int64_t parent_node = (level == 0) ? -1 : parent_level_first + p;
     const int64_t j0 = 8 * (parent_node + 1);
@@ -1564,8 +1615,9 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     double* partials = c->t_partials.as<double>();
     double* block_q = c->t_q.as<double>();
     double* q_dev = block_q + nblk(n, CH);
-    unsigned int* q_ticket = tickets_ptr(c);                  // (zeroed by tree_alloc_nodes -> tree_flags; every launch leaves them zero)
+    unsigned int* q_ticket_buf = tickets_ptr(c);              // (zeroed by tree_alloc_nodes -> tree_flags; every launch leaves them zero)
     TreeCtl* ctl = reinterpret_cast<TreeCtl*>(q_dev + 2);
+    TreeLoopState* loop_state = reinterpret_cast<TreeLoopState*>(q_dev + 4);     // two slots (tree_follow), right behind ctl
     const int trace_cap = std::min(max_iters_per_level, 1 << 20);
     HGMM_TRY(ensure(c, c->t_qtrace, sizeof(double) * (size_t)trace_cap * L));     // one segment per level, read back at the end
     double* trace_base = c->t_qtrace.as<double>();
@@ -1592,6 +1644,9 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     //  the device waits for the host after every iteration; the host needs ~10 us to enqueue what the device runs in ~25)
     int ahead_iters = 2;
     if (const char* e = std::getenv("HGMM_TREE_AHEAD")) ahead_iters = std::max(0, std::min(64, atoi(e)));
+    // the stop rule inside the next launch (tree_follow) instead of a ticketed tail of the log-likelihood: needs the
+    // polled scheme with >= 2 iterations ahead (the verdict on iteration e is reached by launch e + 1)
+    const bool use_follow = !c->comm_on() && ahead_iters >= 2 && !std::getenv("HGMM_TREE_TICKETS");
     unsigned long long* host_word = nullptr;                   // host address / device address of the same pinned word
     unsigned long long* host_word_dev = nullptr;
     if (!c->comm_on() && ahead_iters > 0) {
@@ -1663,7 +1718,8 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
         // enqueued iterations cannot be predicated, so they run out of place: rank-local moments / q stay where
         // the (skipped) kernels left them, the reduced copies are rebuilt identically, the M-step and the stop
         // rule read the copies -- surplus iterations are idempotent and no per-iteration host round trip is needed.
-        HGMM_HIP(c, hipMemsetAsync(ctl, 0, sizeof(TreeCtl), c->stream));
+        // (ctl and the two loop-state slots of tree_follow behind it: 48 contiguous bytes)
+        HGMM_HIP(c, hipMemsetAsync(ctl, 0, sizeof(TreeCtl) + 2 * sizeof(TreeLoopState), c->stream));
         const int batch = batch_iters;
         double* mom_g = nullptr;
         double* q_g = q_dev;
@@ -1675,13 +1731,25 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
         }
         // One EM iteration of the level, enqueued (every kernel looks at ctl->done first and returns at once when the level
         // has stopped).
-        auto enqueue_iteration = [&]() -> int {
+        // follow mode (single GPU, polled look-ahead): launch e of the E-step adds up the shares of q that iteration e - 1
+        // left behind and applies the stop rule itself (tree_follow); the log-likelihood kernels only store their shares
+        const int q_shares = chunks > 1 ? pblocks : llblocks;
+        auto follow_of = [&](int e) {
+            return TreeFollow{block_q, q_shares, loop_state + ((e - 1) & 1), loop_state + (e & 1), &ctl->done, ls,
+                              max_iters_per_level, trace_dev, trace_cap, host_word_dev};
+        };
+        auto enqueue_iteration = [&](int e) -> int {
             int rc = HGMM_OK;
                 {
                     ProfScope prof(c, HGMM_K_TREE_ESTEP);
-                    tree_estep_kernel<<<grid_chunks, CH, 0, c->stream>>>(xs_cur, n_pad, d_prep, chunk_desc,
-                                                                        n_chunks_dev, parent_first, l, partials, cur,
-                                                                        &ctl->done);
+                    if (use_follow && e >= 1)
+                        tree_estep_kernel<<<grid_chunks, CH, 0, c->stream>>>(xs_cur, n_pad, d_prep, chunk_desc,
+                                                                            n_chunks_dev, parent_first, l, partials, cur,
+                                                                            &ctl->done, follow_of(e));
+                    else
+                        tree_estep_kernel<<<grid_chunks, CH, 0, c->stream>>>(xs_cur, n_pad, d_prep, chunk_desc,
+                                                                            n_chunks_dev, parent_first, l, partials, cur,
+                                                                            &ctl->done);
                 }
                 // single GPU: reduction, M-step and preparation of a node in one launch; with a
                 // communicator the all-reduce of the moments sits between reduction and M-step
@@ -1700,8 +1768,10 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                     // ... and, on a single GPU, applies the level's stop rule (with a communicator q is all-reduced
                     // first and tree_ctl_kernel does it)
                     const TreeStop no_stop{nullptr, 0.0, 0, nullptr, 0};
-                    const TreeStop stop = c->comm_on() ? no_stop
-                                                       : TreeStop{ctl, ls, max_iters_per_level, trace_dev, trace_cap, host_word_dev};
+                    const TreeStop stop = (c->comm_on() || use_follow)
+                                              ? no_stop
+                                              : TreeStop{ctl, ls, max_iters_per_level, trace_dev, trace_cap, host_word_dev};
+                    unsigned int* q_ticket = use_follow ? nullptr : q_ticket_buf;     // follow mode: plain stores of the shares
 #define LL_LAUNCH(PTS)                                                                                     \
     tree_loglik_kernel<PTS><<<dim3(llblocks, chunks), CH, 0, c->stream>>>(                                 \
         xs_cur, n, n_pad, d_prep, lb, n_level, per_chunk, ll_partial, block_q, q_ticket, q_dev, &ctl->done, \
@@ -1744,8 +1814,13 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                 it = (int)(w & 0xffffffffull);
                 if (w >> 32) break;                                           // the level has stopped after `it` iterations
                 if (enq < max_iters_per_level && enq - it < ahead_iters) {
-                    rc = enqueue_iteration();
+                    rc = enqueue_iteration(enq);
                     ++enq;
+                    if (use_follow && rc == HGMM_OK && enq == max_iters_per_level) {
+                        // nobody follows the budget's last iteration: one workgroup accounts for its q
+                        tree_close_kernel<<<1, CH, 0, c->stream>>>(follow_of(enq));
+                        if (hipGetLastError() != hipSuccess) rc = fail(c, HGMM_ERR_HIP, "tree build: launch failed");
+                    }
                     spins = 0;
                     continue;
                 }
@@ -1767,7 +1842,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
             auto enqueue_batch = [&](int s) -> int {
                 const int cnt = std::min(batch, max_iters_per_level - enq);
                 for (int b = 0; b < cnt; ++b) {
-                    const int r = enqueue_iteration();
+                    const int r = enqueue_iteration(enq + b);
                     if (r != HGMM_OK) return r;
                 }
                 enq += cnt;

@@ -585,3 +585,27 @@ def test_symmetric_form_fallback_and_pair_counter(ctx, bunny, monkeypatch):
     cov8[5] = np.identity(3) * 1e-3
     ctx.tree_set_nodes(1, pi8, mu8, cov8)
     assert ctx.tree_stats()[1] == 0
+
+
+@pytest.mark.parametrize("L,max_iters", [(2, 1000), (4, 1000), (3, 1), (3, 2), (2, 7)])
+def test_stop_rule_in_the_next_launch_equals_the_ticketed_tail(ctx, bunny, monkeypatch, L, max_iters):
+    """On one GPU the level's stop rule runs inside the NEXT launch of the stream (every workgroup of the next E-step adds
+    up the previous iteration's shares of q for itself, tree_follow; a one-workgroup closing kernel behind the budget's
+    last iteration) -- no ticket, no atomic on the build path.  HGMM_TREE_TICKETS=1 keeps the last-workgroup form
+    (what a communicator uses); HGMM_TREE_AHEAD=0 the batch scheme.  All three: the same tree, bit for bit."""
+    P = bunny.astype(np.float64)
+    T = hgmm_tree.n_total(L)
+    idx = np.random.RandomState(72).randint(T, size=T)
+    a = build(ctx, P, L, 80.0, 1e-4, idx, 0.00034, max_iters)
+    monkeypatch.setenv("HGMM_TREE_TICKETS", "1")
+    b = build(ctx, P, L, 80.0, 1e-4, idx, 0.00034, max_iters)
+    monkeypatch.delenv("HGMM_TREE_TICKETS")
+    monkeypatch.setenv("HGMM_TREE_AHEAD", "0")
+    c = build(ctx, P, L, 80.0, 1e-4, idx, 0.00034, max_iters)
+    monkeypatch.delenv("HGMM_TREE_AHEAD")
+    for other in (b, c):
+        assert list(a[4]) == list(other[4])
+        for x, y in zip((a[0], a[1], a[2], a[3], a[5]), (other[0], other[1], other[2], other[3], other[5])):
+            assert np.array_equal(x, y)
+    if max_iters < 1000:
+        assert list(a[4]) == [max_iters] * L
