@@ -744,7 +744,10 @@ class Context:
         return stats, s.value, n.value
 
     # -- HGMM ---------------------------------------------------------------------------
-    def tree_build(self, L, ls, ld, init_mu, sig2, max_iters_per_level=1000, q_capacity=None):
+    def tree_build(self, L, ls, ld, init_mu, sig2, max_iters_per_level=1000, q_capacity=None, want_leaf=True):
+        """``want_leaf=False``: the node tables only, like the reference's buildGMMTree (hgmm_gpu.py:466-548 returns the
+        nodes; its currentIdx stays on the device) -- the N-long leaf assignment is neither un-sorted nor downloaded
+        (4 MB per million points through pageable memory: 0.4 ms)."""
         T = 8 * (8 ** L - 1) // 7
         init_mu = np.ascontiguousarray(init_mu, dtype=np.float64)
         if init_mu.shape != (T, 3):
@@ -753,7 +756,7 @@ class Context:
         pi = np.empty(T)
         mu = np.empty((T, 3))
         cov = np.empty((T, 3, 3))
-        leaf = np.empty(n, np.int32)
+        leaf = np.empty(n, np.int32) if want_leaf else None
         iters = np.zeros(L, np.int32)
         qcap = int(q_capacity or L * max_iters_per_level)
         q = np.zeros(qcap)

@@ -1529,7 +1529,7 @@ static size_t cov_elems(int cov_type, int J) { return cov_type == HGMM_COV_DIAG 
 // that queues behind the kernels already on the stream -- so hgmm_flat_estep_enqueue returns while its kernel
 // runs and the next call's host work overlaps it.  A region is reused only after a stream synchronisation.
 constexpr size_t STAGE_BYTES = 4u << 20;
-static int stage_reserve(hgmm_ctx* c, size_t bytes, void** out) {
+int stage_reserve(hgmm_ctx* c, size_t bytes, void** out) {            // (declared in hgmm_ctx.h: the tree build's downloads use it too)
     if (!c->h_stage) {
         HGMM_HIP(c, hipHostMalloc(&c->h_stage, STAGE_BYTES, hipHostMallocDefault));
         c->h_stage_cap = STAGE_BYTES;

@@ -142,6 +142,12 @@ struct hgmm_ctx {
     int64_t prof_n[HGMM_K_COUNT] = {0};
 };
 
+namespace hgmm {
+// a region of the context's pinned staging ring (flat_kernels.hip); reused only after a stream synchronisation
+int stage_reserve(hgmm_ctx* c, size_t bytes, void** out);
+constexpr size_t STAGE_RING_BYTES = 4u << 20;
+}  // namespace hgmm
+
 // Every wait for the context's stream goes through here: the E-step's grid policy (flat_kernels.hip, estep_rows_grid)
 // wants to know whether the chip has been idle since the last bandwidth-bound launch.
 inline hipError_t ctx_stream_sync(hgmm_ctx* c) {

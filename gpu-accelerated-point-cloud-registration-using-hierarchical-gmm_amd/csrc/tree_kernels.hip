@@ -1897,23 +1897,41 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     if (rc == HGMM_OK) {
         // the per-iteration M-steps skip the 'complexity' ratio (registration only): all nodes at once, now
         tree_complexity_kernel<<<nblk(T, 256), 256, 0, c->stream>>>(d_cov, 0, T, d_prep);
+        // The node tables and the q traces come back through the context's pinned ring: every copy is a DMA packet that
+        // queues at once, ONE synchronisation, then plain memcpys.  (Copied straight into the caller's pageable arrays
+        // each of the 3 + L copies blocked the host for ~20 us while the runtime staged it: 5 % of a C4 build.)  Tables
+        // too large for the ring (L >= 5) are copied directly.
         hipError_t e = hipSuccess;
-        if (pi_out) e = hipMemcpyAsync(pi_out, d_pi, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess && mu_out) e = hipMemcpyAsync(mu_out, d_mu, sizeof(double) * 3 * T, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess && cov_out) e = hipMemcpyAsync(cov_out, d_cov, sizeof(double) * 9 * T, hipMemcpyDeviceToHost, c->stream);
+        struct Pending { void* dst; const void* src; size_t bytes; };
+        std::vector<Pending> pending;
+        size_t staged = 0;
+        auto download = [&](void* dst, const void* dev_src, size_t bytes) {
+            if (e != hipSuccess || !dst || bytes == 0) return;
+            void* st = nullptr;
+            if (staged + bytes + 256 <= STAGE_RING_BYTES / 2 && stage_reserve(c, bytes, &st) == HGMM_OK) {
+                staged += (bytes + 255) & ~(size_t)255;
+                e = hipMemcpyAsync(st, dev_src, bytes, hipMemcpyDeviceToHost, c->stream);
+                pending.push_back({dst, st, bytes});
+            } else {
+                e = hipMemcpyAsync(dst, dev_src, bytes, hipMemcpyDeviceToHost, c->stream);
+            }
+        };
+        download(pi_out, d_pi, sizeof(double) * T);
+        download(mu_out, d_mu, sizeof(double) * 3 * T);
+        download(cov_out, d_cov, sizeof(double) * 9 * T);
         if (q_trace_out) {                                          // the levels' q traces, back to back
             int at = 0;
             for (int l = 0; l < L && e == hipSuccess; ++l) {
                 const int take = std::min(std::min(level_iters[l], trace_cap), q_capacity - at);
-                if (take > 0)
-                    e = hipMemcpyAsync(q_trace_out + at, trace_base + (size_t)l * trace_cap, sizeof(double) * take,
-                                       hipMemcpyDeviceToHost, c->stream);
+                if (take > 0) download(q_trace_out + at, trace_base + (size_t)l * trace_cap, sizeof(double) * take);
                 at += level_iters[l];
                 if (at >= q_capacity) break;
             }
         }
         if (e == hipSuccess) e = ctx_stream_sync(c);
         if (e != hipSuccess) rc = fail(c, HGMM_ERR_HIP, "tree build: download failed: %s", hipGetErrorString(e));
+        else
+            for (const Pending& pd : pending) std::memcpy(pd.dst, pd.src, pd.bytes);
     } else {
         (void)ctx_stream_sync(c);
     }

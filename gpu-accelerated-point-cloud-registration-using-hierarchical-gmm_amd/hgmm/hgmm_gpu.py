@@ -64,7 +64,7 @@ def buildGMMTree(points, maxTreeLevel, ls, ld, sig2=0.004, seed=72, init_idx=Non
         init_idx = rs.randint(T, size=T)
     ctx.set_points(P)
     pi, mu, cov, leaf, iters, q = ctx.tree_build(maxTreeLevel, ls, ld, P[np.asarray(init_idx)], sig2,
-                                                 max_iters_per_level)
+                                                 max_iters_per_level, want_leaf=bool(return_trace))
     if return_trace:
         return pi, mu, cov, {"leaf_idx": leaf, "iters_per_level": iters, "q_trace": q}
     return pi, mu, cov

@@ -13,6 +13,9 @@ import hgmm_amd  # noqa: E402
 
 what = sys.argv[1] if len(sys.argv) > 1 else "both"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+# C4PROF_LEAF=1: also un-sort and download the N-long leaf assignment (bench.py's build_ms is the node tables only,
+# what the reference's buildGMMTree returns)
+LEAF = os.environ.get("C4PROF_LEAF", "0") == "1"
 ctx = hgmm_amd.Context(0)
 L, T = 4, 4680
 if what in ("c4", "both"):
@@ -24,7 +27,7 @@ if what in ("c4", "both"):
     ts = []
     for _ in range(reps):
         t0 = time.perf_counter()
-        out = ctx.tree_build(L, 80.0, 1e-4, P[idx], 0.00034, 1000)
+        out = ctx.tree_build(L, 80.0, 1e-4, P[idx], 0.00034, 1000, want_leaf=LEAF)
         ts.append(time.perf_counter() - t0)
     print("C4 build ms", [round(t * 1e3, 3) for t in ts], "iterations", list(out[4]), flush=True)
 if what in ("tree1m", "both"):
@@ -35,7 +38,7 @@ if what in ("tree1m", "both"):
     ts = []
     for _ in range(reps):
         t0 = time.perf_counter()
-        out = ctx.tree_build(L, 80.0, 1e-4, P[idx], 0.01, 4)
+        out = ctx.tree_build(L, 80.0, 1e-4, P[idx], 0.01, 4, want_leaf=LEAF)
         ts.append(time.perf_counter() - t0)
     pi = out[0]
     print("tree_1M build ms", [round(t * 1e3, 3) for t in ts], "dead nodes per level",
