@@ -494,6 +494,11 @@ __global__ __launch_bounds__(CH) void tree_close_kernel(TreeFollow f) {
 // ------------------------------------------------------------------------------------------
 constexpr int ES_LD = 66;            // LDS row stride (doubles) of the moment contraction's operands: conflict-free fragment reads
 typedef double double4_es __attribute__((ext_vector_type(4)));
+// HALF: the wave's 64 points go through the LDS transpose 32 at a time (18 rows x 34 instead of x 66 doubles per wave:
+// 23 KB of LDS per workgroup instead of 42) -- same products, same order of accumulation, so the same sums bit for bit.
+// A million-point level is 3907 chunks = 15 workgroups per CU, of which the LDS admitted 3 at a time: the launch was
+// five rounds of one latency chain each.  Small clouds (less than one workgroup per CU) keep the one-pass form.
+template <bool HALF>
 __global__ __launch_bounds__(CH) void tree_estep_kernel(
     const double* __restrict__ xs, int64_t n_pad, const double* __restrict__ prep,
     const int* __restrict__ chunk_desc, const int* __restrict__ n_chunks, int64_t parent_level_first,
@@ -566,27 +571,35 @@ __global__ __launch_bounds__(CH) void tree_estep_kernel(
     // 16 v_mfma_f64_16x16x4_f64 walk the wave's 64 points four at a time.  (Round 2 took 80 DPP wave reductions here,
     // ~1400 dependent fp64 instructions per wave -- a third of this latency-bound kernel's time at C4.)  Rows 8..15 of
     // the A operand and columns 10..15 of B alias rows that exist: their products land in accumulator entries nobody reads.
+    constexpr int LD = HALF ? ES_LD / 2 + 1 : ES_LD;          // 34 / 66: the same bank pattern (stride = 4 mod 64 dwords)
+    constexpr int PASS_PTS = HALF ? 32 : 64;
     __shared__ double sh[CH / 64][8 * NMOM];
-    __shared__ double GS[CH / 64][8][ES_LD];
-    __shared__ double FS[CH / 64][NMOM][ES_LD];
+    __shared__ double GS[CH / 64][8][LD];
+    __shared__ double FS[CH / 64][NMOM][LD];
     const int w = wave_in_block();
     const int lane = lane_id();
     {
         const double f[NMOM] = {1.0, x0, x1, x2, x0 * x0, x0 * x1, x0 * x2, x1 * x1, x1 * x2, x2 * x2};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) GS[w][k][lane] = g[k];
-#pragma unroll
-        for (int m = 0; m < NMOM; ++m) FS[w][m][lane] = f[m];
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's LDS writes have landed
-    __builtin_amdgcn_wave_barrier();
-    {
         const int a_idx = lane & 15, b_idx = lane >> 4;
         const double* ga = &GS[w][a_idx & 7][b_idx];
         const double* fb = &FS[w][a_idx < NMOM ? a_idx : NMOM - 1][b_idx];
         double4_es acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int st = 0; st < 16; ++st) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[4 * st], fb[4 * st], acc, 0, 0, 0);
+        for (int pass = 0; pass < 64 / PASS_PTS; ++pass) {
+            if (pass > 0) __builtin_amdgcn_wave_barrier();     // the previous pass's fragment reads are done (same wave, in order)
+            if (lane / PASS_PTS == pass) {
+                const int col = lane % PASS_PTS;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) GS[w][k][col] = g[k];
+#pragma unroll
+                for (int m = 0; m < NMOM; ++m) FS[w][m][col] = f[m];
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): this wave's LDS writes have landed
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int st = 0; st < PASS_PTS / 4; ++st)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[4 * st], fb[4 * st], acc, 0, 0, 0);
+        }
         // D layout (f64 16x16x4): row (child) = (lane >> 4) + 4 r, column (feature) = lane & 15
         if (a_idx < NMOM) {
             sh[w][b_idx * NMOM + a_idx] = acc[0];
@@ -1632,6 +1645,10 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     //  20.2 / 49 us per iteration against 8.9 / 14.8 / 19.1 / 22.4 for this form: eight times as many workgroups each read
     //  the level's whole node table for the reach test; removed again, commit 7d926ef)
     if (ll_pts == 4) HGMM_TRY(ensure_exp_tab2(c));
+    // the E-step's LDS transpose in two passes (half the LDS, twice the resident workgroups) once a level has more chunks
+    // than the chip holds at a time
+    bool estep_half = n / CH > (int64_t)3 * c->cus;
+    if (const char* e = std::getenv("HGMM_TREE_ESTEP_HALF")) estep_half = e[0] == '1';
     // iterations enqueued per batch.  Round 2 (host waits at every batch boundary): 1/2/4/8/16 -> 6.8/6.3/5.6/5.1/5.3 ms @C4.
     // With the host one batch ahead (below) a level that stops at iteration k still has (ceil(k / B) + 1) B - k
     // iterations enqueued behind the stop (46 over C4's four levels at B = 8, 22 at B = 4) -- but each of those is three
@@ -1742,14 +1759,17 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
             int rc = HGMM_OK;
                 {
                     ProfScope prof(c, HGMM_K_TREE_ESTEP);
-                    if (use_follow && e >= 1)
-                        tree_estep_kernel<<<grid_chunks, CH, 0, c->stream>>>(xs_cur, n_pad, d_prep, chunk_desc,
-                                                                            n_chunks_dev, parent_first, l, partials, cur,
-                                                                            &ctl->done, follow_of(e));
+                    const TreeFollow fol = (use_follow && e >= 1)
+                                               ? follow_of(e)
+                                               : TreeFollow{nullptr, 0, nullptr, nullptr, nullptr, 0.0, 0, nullptr, 0, nullptr};
+                    if (estep_half)
+                        tree_estep_kernel<true><<<grid_chunks, CH, 0, c->stream>>>(xs_cur, n_pad, d_prep, chunk_desc,
+                                                                                  n_chunks_dev, parent_first, l, partials, cur,
+                                                                                  &ctl->done, fol);
                     else
-                        tree_estep_kernel<<<grid_chunks, CH, 0, c->stream>>>(xs_cur, n_pad, d_prep, chunk_desc,
-                                                                            n_chunks_dev, parent_first, l, partials, cur,
-                                                                            &ctl->done);
+                        tree_estep_kernel<false><<<grid_chunks, CH, 0, c->stream>>>(xs_cur, n_pad, d_prep, chunk_desc,
+                                                                                   n_chunks_dev, parent_first, l, partials, cur,
+                                                                                   &ctl->done, fol);
                 }
                 // single GPU: reduction, M-step and preparation of a node in one launch; with a
                 // communicator the all-reduce of the moments sits between reduction and M-step
