@@ -68,6 +68,7 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_free", [ctx, _vp])
         _sig(lib, "hgmm_h2d", [ctx, _vp, _vp, C.c_size_t])
         _sig(lib, "hgmm_d2h", [ctx, _vp, _vp, C.c_size_t])
+        _sig(lib, "hgmm_d2d", [ctx, _vp, _vp, C.c_size_t])
         _sig(lib, "hgmm_set_points_f32", [ctx, _vp, C.c_int64])
         _sig(lib, "hgmm_set_points_f64", [ctx, _vp, C.c_int64])
         _sig(lib, "hgmm_num_points", [ctx], C.c_int64)
@@ -114,6 +115,7 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_comm_init_rank", [ctx, C.c_int, C.c_int, _vp])
         _sig(lib, "hgmm_comm_destroy", [ctx])
         _sig(lib, "hgmm_comm_init_host", [ctx, C.c_int, C.c_int, C.c_char_p])
+        _sig(lib, "hgmm_comm_init_ipc", [ctx, C.c_int, C.c_int, C.c_char_p])
         _sig(lib, "hgmm_comm_allreduce_f64", [ctx, _vp, C.c_int, C.c_int])
         _sig(lib, "hgmm_profile_enable", [ctx, C.c_int])
         _sig(lib, "hgmm_profile_reset", [ctx])
@@ -141,7 +143,8 @@ EW_OPS = {"add": 0, "sub": 1, "rsub": 2, "mul": 3, "div": 4, "rdiv": 5, "sqrt": 
 # arrays up to this size are carved from the context's arena (no hipMalloc / hipFree, nothing waits when they die)
 SMALL_BYTES = 128 << 10
 SMALL_SLABS = 64
-# dead arrays kept for reuse by the next array of the same size, in total at most this much memory (of 288 GB)
+# dead arrays kept for reuse by the next array of the same size, in total at most this much memory (and at most 1/16
+# of the device's: Context._freed_cap; an allocation that fails releases them and is tried again, Context._alloc)
 FREED_CAP_BYTES = 16 << 30
 # np.exp() of an array with at least this many elements stays a lazy view (the consumer fuses the exponential)
 LAZY_EXP_ELEMS = 1 << 20
@@ -149,7 +152,9 @@ LAZY_EXP_ELEMS = 1 << 20
 _HOST_METHODS = frozenset((
     "sum", "mean", "min", "max", "std", "var", "copy", "T", "reshape", "tolist", "flatten", "ravel", "any", "all",
     "round", "clip", "dot", "squeeze", "transpose", "item", "argmin", "argsort", "cumsum", "prod", "nonzero", "tobytes",
-    "view", "real", "imag", "flat", "take", "repeat", "fill", "itemsize", "strides", "base", "flags"))
+    "real", "imag", "take", "repeat", "itemsize", "strides", "base", "flags"))
+# ... and the ones that would silently modify (or alias) that throw-away copy: refused
+_HOST_MUTATORS = frozenset(("fill", "flat", "view", "sort", "put", "itemset", "resize", "setflags", "partition"))
 
 
 class DeviceArray:
@@ -230,7 +235,11 @@ class DeviceArray:
         """Same dtype: the array itself stays where it is (as ``cupy.ndarray.astype(..., copy=False)`` would
         leave it); another dtype is answered from a host copy."""
         if np.dtype(dtype) == self.dtype and self._base is None:
-            return self
+            if not copy:
+                return self
+            dup = DeviceArray(self.ctx, self.shape, self.dtype)      # copy=True (the default): a fresh array, as NumPy / CuPy give
+            self.ctx._d2d(dup.ptr, self.ptr, self.nbytes)
+            return dup
         return self.get().astype(dtype, **kw)
 
     def __len__(self):
@@ -247,6 +256,8 @@ class DeviceArray:
 
     def __getattr__(self, name):
         # (reached only for names the class does not define)
+        if name in _HOST_MUTATORS:
+            raise TypeError("DeviceArray.%s would act on a throw-away host copy; use .get() for a host array" % name)
         if name in _HOST_METHODS:
             return getattr(self.get(), name)
         raise AttributeError(name)
@@ -414,15 +425,39 @@ class DeviceScalar(DeviceArray):
         pass
 
 
+_SCALAR_OPS = {
+    "__add__": lambda a, b: a + b, "__radd__": lambda a, b: b + a, "__sub__": lambda a, b: a - b,
+    "__rsub__": lambda a, b: b - a, "__mul__": lambda a, b: a * b, "__rmul__": lambda a, b: b * a,
+    "__truediv__": lambda a, b: a / b, "__rtruediv__": lambda a, b: b / a,
+    "__lt__": lambda a, b: a < b, "__le__": lambda a, b: a <= b, "__gt__": lambda a, b: a > b,
+    "__ge__": lambda a, b: a >= b, "__eq__": lambda a, b: a == b, "__ne__": lambda a, b: a != b}
+# a DeviceArray operand answers through ITS operator with the roles swapped (its device kernels take a scalar)
+_SCALAR_SWAP = {"__add__": "__radd__", "__radd__": "__add__", "__sub__": "__rsub__", "__rsub__": "__sub__",
+                "__mul__": "__rmul__", "__rmul__": "__mul__", "__truediv__": "__rtruediv__",
+                "__rtruediv__": "__truediv__", "__lt__": "__gt__", "__le__": "__ge__", "__gt__": "__lt__",
+                "__ge__": "__le__", "__eq__": "__eq__", "__ne__": "__ne__"}
+
+
 def _scalar_op(name):
+    """Operators of a DeviceScalar.  The value takes part as a NumPy float32 scalar -- what ``xp.mean(log_prob_norm)``
+    of a float32 array is in the reference (gmm_impl.py:114-116), so ``abs(change) < tol`` of a caller's loop rounds
+    as it does there; ``float(s)`` keeps the kernel's float64.  Operands that are not numbers: arrays take the array
+    path, anything else gets Python's NotImplemented protocol (``s == None`` is False, ``s in [None, 1.0]`` works)."""
+    fn = _SCALAR_OPS[name]
+
     def f(self, other):
-        return getattr(self.item(), name)(float(other))
+        if isinstance(other, DeviceScalar):
+            return fn(np.float32(self.item()), np.float32(other.item()))
+        if isinstance(other, DeviceArray):
+            return getattr(other, _SCALAR_SWAP[name])(float(np.float32(self.item())))
+        if isinstance(other, (bool, int, float, np.generic, np.ndarray)):
+            return fn(np.float32(self.item()), other)
+        return NotImplemented
     f.__name__ = name
     return f
 
 
-for _n in ("__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", "__truediv__", "__rtruediv__",
-           "__lt__", "__le__", "__gt__", "__ge__", "__eq__", "__ne__"):
+for _n in _SCALAR_OPS:
     setattr(DeviceScalar, _n, _scalar_op(_n))
 DeviceScalar.__hash__ = lambda self: id(self)
 
@@ -445,6 +480,7 @@ class Context:
         self._arena = None                    # (pointer, free slab indices) of the small-array pool
         self._freed = {}                      # size -> pointers of dead arrays kept for reuse (_free)
         self._freed_bytes = 0
+        self._freed_cap_bytes = None
         self._scalar_host = None              # pinned, device-visible doubles (DeviceScalar)
         self._scalar_dev = None
         self._scalar_next = 0
@@ -491,8 +527,28 @@ class Context:
             self._freed_bytes -= nbytes
             return cached.pop()
         p = _vp()
-        self._check(self.lib.hgmm_alloc(self.h, nbytes, C.byref(p)))
+        rc = self.lib.hgmm_alloc(self.h, nbytes, C.byref(p))
+        if rc != 0 and self._freed_bytes:
+            self.trim()                              # out of memory with dead arrays still cached: release them, once more
+            rc = self.lib.hgmm_alloc(self.h, nbytes, C.byref(p))
+        self._check(rc)
         return p
+
+    def trim(self):
+        """Give the memory of dead arrays (kept for reuse, see _free) back to the device."""
+        for lst in self._freed.values():
+            for ptr in lst:
+                self.lib.hgmm_free(self.h, ptr)
+        self._freed, self._freed_bytes = {}, 0
+
+    def _freed_cap(self):
+        """Dead arrays are kept up to 1/16 of the device's memory (18 GB of an MI355X's 288), FREED_CAP_BYTES at most."""
+        if self._freed_cap_bytes is None:
+            try:
+                self._freed_cap_bytes = min(FREED_CAP_BYTES, self.device_info()["hbm_bytes"] // 16)
+            except HgmmError:
+                self._freed_cap_bytes = FREED_CAP_BYTES
+        return self._freed_cap_bytes
 
     def _free(self, p, nbytes=None):
         """Arrays that die are kept for the next array of the same size (a caller's loop allocates the same shapes
@@ -504,7 +560,7 @@ class Context:
         if nbytes is not None:
             nbytes = int(max(nbytes, 4))
             lst = self._freed.setdefault(nbytes, [])
-            if self._freed_bytes + nbytes <= FREED_CAP_BYTES and len(lst) < 4:
+            if self._freed_bytes + nbytes <= self._freed_cap() and len(lst) < 4:
                 lst.append(p)
                 self._freed_bytes += nbytes
                 return
@@ -546,6 +602,9 @@ class Context:
 
     def _d2h(self, host, dev_ptr):
         self._check(self.lib.hgmm_d2h(self.h, _ptr(host), dev_ptr, host.nbytes))
+
+    def _d2d(self, dst_ptr, src_ptr, nbytes):
+        self._check(self.lib.hgmm_d2d(self.h, dst_ptr, src_ptr, int(nbytes)))
 
     def synchronize(self):
         self._check(self.lib.hgmm_synchronize(self.h))
@@ -604,13 +663,12 @@ class Context:
     def _flat_dev_args(self, mu, inv_or_cov, w, cov_type):
         """The parameters as float32 DeviceArrays of this context (host arrays among them are uploaded)."""
         def dev(a, shape):
-            if isinstance(a, DeviceArray):
-                if a.ctx is not self or a.dtype != np.float32 or a._base is not None:
-                    raise ValueError("parameter arrays must be float32 DeviceArrays of this context")
+            if isinstance(a, DeviceArray) and a.ctx is self and a.dtype == np.float32 and a._base is None:
                 if shape is not None and a.shape != tuple(shape):
                     raise ValueError("expected shape %s, got %s" % (shape, a.shape))
                 return a
-            return self.to_device(_f32(a, shape))
+            # anything else -- host arrays, float64 / lazy-view / foreign-context DeviceArrays -- goes through the host
+            return self.to_device(_f32(np.asarray(a), shape))
         mu = dev(mu, None)
         J = mu.shape[0]
         if mu.shape != (J, 3):
@@ -967,6 +1025,12 @@ class Context:
     def comm_init_host(self, nranks, rank, name: str):
         """Host shared-memory communicator (tests on a single-GPU box; see include/hgmm.h)."""
         self._check(self.lib.hgmm_comm_init_host(self.h, int(nranks), int(rank), name.encode()))
+        self.nranks, self.rank = int(nranks), int(rank)
+
+    def comm_init_ipc(self, nranks, rank, name: str):
+        """One-shot peer exchange over mapped peer memory (hipIpc; the ranks are processes of one node, see
+        include/hgmm.h): every all-reduce is one kernel per rank, all ranks end with bitwise the same sums."""
+        self._check(self.lib.hgmm_comm_init_ipc(self.h, int(nranks), int(rank), name.encode()))
         self.nranks, self.rank = int(nranks), int(rank)
 
     def comm_destroy(self):

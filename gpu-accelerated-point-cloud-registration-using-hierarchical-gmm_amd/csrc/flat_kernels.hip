@@ -532,6 +532,105 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_rows_pk_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// estimate_log_prob (gmm_impl.py:53-78): the un-normalised table, natural log.  The materialising E-step's layout, four
+// rows in flight and packed arithmetic with everything but the quadratic forms taken out: no maximum, no exponential,
+// no wave reduction -- 10 packed instructions per pair of components and row (9 for the form, one for log2 -> ln),
+// then the same 16-byte non-temporal stores.  (Round 3 ran this call on the single-row kernel: 0.69 ms per
+// 10^6 x 800 table = 4.7 TB/s while e_step, which does strictly more work on the same bytes, ran at 5.9.)
+// ------------------------------------------------------------------------------------------
+template <int NV4, int NV1>
+__global__ __launch_bounds__(BLOCK) void flat_logprob_rows_pk_kernel(
+    const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int J, int Jpad,
+    float* __restrict__ log_prob) {
+    using L = Layout<NV4, NV1>;
+    constexpr int K = L::K;
+    constexpr int KP = 2 * NV4 + NV1 / 2;          // pairs
+    constexpr bool ODD = (NV1 & 1) != 0;           // trailing single = component K - 1
+    constexpr int ROWS = 4;
+    const int lane = lane_id();
+    f2 mu0[KP + 1], mu1[KP + 1], mu2[KP + 1], g0[KP + 1], g1[KP + 1], g2[KP + 1], cc[KP + 1];
+    float mu0s = 0.f, mu1s = 0.f, mu2s = 0.f, g0s = 0.f, g1s = 0.f, g2s = 0.f, cs = NEG_INF;
+    auto ld = [&](int row, int j) { return pack[row * Jpad + j]; };
+    // the table is kept in the log2 domain (pack_values); here the NATURAL log is the output, so the factor ln 2 is
+    // folded into the lane's copy of (g, c) once instead of costing an instruction per pair and row
+    const f2 LNV = f2{LN2, LN2};
+#pragma unroll
+    for (int p = 0; p < KP; ++p) {
+        const int ja = L::j_of(2 * p, lane), jb = L::j_of(2 * p + 1, lane);
+        mu0[p] = f2{ld(PK_MU + 0, ja), ld(PK_MU + 0, jb)};
+        mu1[p] = f2{ld(PK_MU + 1, ja), ld(PK_MU + 1, jb)};
+        mu2[p] = f2{ld(PK_MU + 2, ja), ld(PK_MU + 2, jb)};
+        g0[p] = f2{ld(PK_G + 0, ja), ld(PK_G + 0, jb)} * LNV;
+        g1[p] = f2{ld(PK_G + 1, ja), ld(PK_G + 1, jb)} * LNV;
+        g2[p] = f2{ld(PK_G + 2, ja), ld(PK_G + 2, jb)} * LNV;
+        cc[p] = f2{ld(PK_C, ja), ld(PK_C, jb)} * LNV;
+    }
+    if (ODD) {
+        const int j = L::j_of(K - 1, lane);
+        mu0s = ld(PK_MU + 0, j); mu1s = ld(PK_MU + 1, j); mu2s = ld(PK_MU + 2, j);
+        g0s = ld(PK_G + 0, j) * LN2; g1s = ld(PK_G + 1, j) * LN2; g2s = ld(PK_G + 2, j) * LN2;
+        cs = ld(PK_C, j) * LN2;
+    }
+    const int64_t nw = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    const int64_t gw = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
+    const int64_t ngroups = (n + ROWS - 1) / ROWS;
+    float x[ROWS][3];
+    auto load_group = [&](int64_t g, float (&dst)[ROWS][3]) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            int64_t row = g * ROWS + r;
+            row = row < n ? row : n - 1;
+            const float* xp = X + 3 * row;
+            dst[r][0] = xp[0]; dst[r][1] = xp[1]; dst[r][2] = xp[2];
+        }
+    };
+    if (gw < ngroups) load_group(gw, x);
+    for (int64_t g = gw; g < ngroups; g += nw) {
+        float nx[ROWS][3];
+        load_group((g + nw < ngroups) ? g + nw : g, nx);          // prefetch (scalar loads)
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int64_t row = g * ROWS + r;
+            const f2 X0 = f2{x[r][0], x[r][0]}, X1 = f2{x[r][1], x[r][1]}, X2 = f2{x[r][2], x[r][2]};
+            f2 wl[KP + 1];
+#pragma unroll
+            for (int p = 0; p < KP; ++p) {
+                const f2 d0 = X0 - mu0[p], d1 = X1 - mu1[p], d2 = X2 - mu2[p];
+                f2 a = cc[p] - (d0 * g0[p]) * d0;
+                a = a - (d1 * g1[p]) * d1;
+                a = a - (d2 * g2[p]) * d2;
+                wl[p] = a;
+            }
+            float wls = NEG_INF;
+            if (ODD) {
+                const float d0 = x[r][0] - mu0s, d1 = x[r][1] - mu1s, d2 = x[r][2] - mu2s;
+                float a = fmaf(-(d0 * g0s), d0, cs);
+                a = fmaf(-(d1 * g1s), d1, a);
+                a = fmaf(-(d2 * g2s), d2, a);
+                wls = a;
+            }
+            if (row < n) {                                          // wave-uniform
+                float* out = log_prob + row * (int64_t)J;
+#pragma unroll
+                for (int v = 0; v < NV4; ++v) {
+                    const int jb = (v * 64 + lane) * 4;
+                    if (jb < J) store_f4<true>(out + jb, wl[2 * v].x, wl[2 * v].y, wl[2 * v + 1].x, wl[2 * v + 1].y);
+                }
+#pragma unroll
+                for (int v = 0; v < NV1; ++v) {
+                    const int j = 256 * NV4 + v * 64 + lane;
+                    const int k = 4 * NV4 + v;
+                    const float val = (ODD && k == K - 1) ? wls : ((k & 1) ? wl[k >> 1].y : wl[k >> 1].x);
+                    if (j < J) store_f1<true>(out + j, val);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { x[r][0] = nx[r][0]; x[r][1] = nx[r][1]; x[r][2] = nx[r][2]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // predict(): arg-max_j of the weighted log-probabilities, nothing else (gmm_impl.py:147-155).  Same lane <-> component
 // layout and the same packed arithmetic as flat_estep_rows_pk_kernel (so the values compared are the ones e_step's own
 // arg-max sees), four rows in flight per wave -- and no exponentials, no normaliser, no N x J traffic: per row the
@@ -1648,6 +1747,33 @@ static bool launch_estep_rows(hgmm_ctx* c, int nv4, int nv1, int grid_r, bool cs
     return true;
 }
 
+// estimate_log_prob on the four-rows-in-flight kernel (the layouts the materialising E-step is instantiated for); false: not instantiated
+static bool launch_logprob_rows(hgmm_ctx* c, int nv4, int nv1, float* log_prob) {
+    const FlatState& f = c->flat;
+    if (env_flag("HGMM_LOGPROB_SINGLE_ROW", false)) return false;
+    // grid: the store stream is all this kernel has to wait for -- one workgroup per CU by default (tools/estep_sweep.py)
+    int grid = grid_for(c, (c->n + 3) / 4, env_int("HGMM_LOGPROB_BPC", 1));
+    if (env_int("HGMM_LOGPROB_GRID", 0) > 0) grid = std::min(grid_for(c, (c->n + 3) / 4, 4), env_int("HGMM_LOGPROB_GRID", 0));
+    const float* X = c->x_aos.as<float>();
+    const float* pk = c->f_pack.as<float>();
+#define LOGP_R(A, B) flat_logprob_rows_pk_kernel<A, B><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, log_prob)
+    if (nv4 == 3 && nv1 == 1) LOGP_R(3, 1);
+    else if (nv4 == 3 && nv1 == 0) LOGP_R(3, 0);
+    else if (nv4 == 3 && nv1 == 2) LOGP_R(3, 2);
+    else if (nv4 == 4 && nv1 == 0) LOGP_R(4, 0);
+    else if (nv4 == 2 && nv1 == 0) LOGP_R(2, 0);
+    else if (nv4 == 2 && nv1 == 1) LOGP_R(2, 1);
+    else if (nv4 == 2 && nv1 == 2) LOGP_R(2, 2);
+    else if (nv4 == 1 && nv1 == 0) LOGP_R(1, 0);
+    else if (nv4 == 1 && nv1 == 1) LOGP_R(1, 1);
+    else if (nv4 == 1 && nv1 == 2) LOGP_R(1, 2);
+    else if (nv4 == 0 && nv1 == 1) LOGP_R(0, 1);
+    else if (nv4 == 0 && nv1 == 2) LOGP_R(0, 2);
+    else return false;
+#undef LOGP_R
+    return true;
+}
+
 // predict(): the four-rows-in-flight arg-max kernel for the layouts it is instantiated for (the others take the general kernel)
 static bool predict_rows_layout(int nv4, int nv1) {
     if (env_flag("HGMM_PREDICT_SINGLE_ROW", false)) return false;
@@ -1724,6 +1850,15 @@ static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argma
         (void)launch_predict_rows(c, nv4, nv1, argmax);
         HGMM_HIP(c, hipGetLastError());
         return HGMM_OK;
+    }
+    if (!NORMALISE && log_resp && !lpn && !argmax) {                                        // estimate_log_prob: the raw table
+        ProfScope prof(c, HGMM_K_FLAT_ESTEP);
+        if (launch_logprob_rows(c, nv4, nv1, log_resp)) {
+            c->flat.last_kernel = 1;
+            c->flat.idle_since_launch = false;
+            HGMM_HIP(c, hipGetLastError());
+            return HGMM_OK;
+        }
     }
     // Materialising path: 4 rows in flight per wave, at most ONE workgroup per CU (see the kernel's header)
     const int rows = (NORMALISE && log_resp) ? env_int("HGMM_ESTEP_ROWS", 4) : 1;

@@ -149,6 +149,155 @@ static void hostcomm_close(hgmm_ctx* c) {
     c->hcomm = nullptr;
 }
 
+// ---- one-shot peer exchange (hgmm_comm_init_ipc) ------------------------------------------------
+// The sufficient-statistics all-reduce is 57 KB per EM iteration of 0.38 ms: latency is all that matters, and the
+// topology is a full xGMI mesh.  So no ring and no tree: every rank WRITES its slice straight into a slot it owns in
+// every peer's exchange buffer and every rank adds the R slices it received, in rank order -- one kernel per rank and
+// collective, one trip over the links, bitwise the same sum on all ranks.
+//
+// Exchange buffer of a rank (uncached device memory, exported with hipIpcGetMemHandle, mapped by all peers):
+//   flags [2][IPC_MAX_RANKS][IPC_MAX_CHUNKS] uint64   sequence number of the last collective whose piece has landed
+//   slots [2][IPC_MAX_RANKS][IPC_SLOT]       double   the pieces; index = (parity of the sequence number, writer)
+// Double buffering by parity is enough: rank A can only write collective k + 2 into B's parity-(k & 1) slots after it
+// has consumed k + 1, i.e. after it has seen B's flags of k + 1 -- and B released those from a kernel that its stream
+// started after B's kernel of collective k (the reader of those slots) had finished.
+constexpr int IPC_MAX_RANKS = 8;
+constexpr int IPC_CHUNK = 512;                         // doubles per workgroup: two per thread, 4 KB
+constexpr size_t IPC_SLOT = (size_t)1 << 16;           // doubles per slot (512 KB); larger payloads go in pieces
+constexpr int IPC_MAX_CHUNKS = (int)(IPC_SLOT / IPC_CHUNK);
+constexpr size_t IPC_FLAG_BYTES = sizeof(unsigned long long) * 2 * IPC_MAX_RANKS * IPC_MAX_CHUNKS;
+constexpr size_t IPC_BUF_BYTES = IPC_FLAG_BYTES + sizeof(double) * 2 * IPC_MAX_RANKS * IPC_SLOT;
+constexpr double IPC_TIMEOUT_S = 20.0;
+
+struct IpcShm {
+    std::atomic<int> ready;
+    std::atomic<int> count;
+    std::atomic<int> generation;
+    std::atomic<int> failed;                     // some rank could not map a peer: nobody keeps the communicator
+    int nranks;
+    hipIpcMemHandle_t handle[IPC_MAX_RANKS];
+    int device[IPC_MAX_RANKS];
+    int pid[IPC_MAX_RANKS];
+};
+struct IpcPeers {
+    unsigned long long* flags[IPC_MAX_RANKS];
+    double* slots[IPC_MAX_RANKS];
+};
+struct IpcComm {
+    IpcShm* shm = nullptr;
+    size_t shm_bytes = 0;
+    std::string name;
+    bool owner = false;
+    void* local = nullptr;                       // this rank's exchange buffer
+    void* mapped[IPC_MAX_RANKS] = {};            // every rank's buffer as this process sees it (mapped[rank] == local)
+    IpcPeers peers = {};
+    unsigned long long seq = 0;                  // collectives issued so far (the same number on every rank)
+    bool in_step = false;                        // initialised together with the peers: teardown meets them in a barrier
+    unsigned* err_host = nullptr;
+    unsigned* err_dev = nullptr;
+    long long timeout_ticks = 0;
+};
+
+static int ipc_barrier(hgmm_ctx* c) {
+    IpcShm* s = c->icomm->shm;
+    const int gen = s->generation.load(std::memory_order_acquire);
+    if (s->count.fetch_add(1, std::memory_order_acq_rel) + 1 == s->nranks) {
+        s->count.store(0, std::memory_order_relaxed);
+        s->generation.store(gen + 1, std::memory_order_release);
+        return HGMM_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    while (s->generation.load(std::memory_order_acquire) == gen) {
+        sched_yield();
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(HOSTCOMM_TIMEOUT_S))
+            return fail(c, HGMM_ERR_STATE, "peer exchange: barrier timed out (a peer rank is gone?)");
+    }
+    return HGMM_OK;
+}
+
+__device__ __forceinline__ double ipc_combine(double a, double b, int op) {
+    if (op == 1) return b > a ? b : a;
+    if (op == 2) return __longlong_as_double(__double_as_longlong(a) + __double_as_longlong(b));   // exact int64 sum
+    return a + b;
+}
+
+// One collective: blockIdx.x = piece of IPC_CHUNK values.  op: 0 sum, 1 max (float64), 2 sum of int64 words.
+__global__ __launch_bounds__(256) void ipc_allreduce_kernel(IpcPeers pp, int R, int rank, const double* __restrict__ src,
+                                                            double* __restrict__ dst, int n, int op,
+                                                            unsigned long long seq, unsigned* err, long long timeout_ticks) {
+    const int c = blockIdx.x, t = threadIdx.x;
+    const int i0 = c * IPC_CHUNK + 2 * t;
+    const int parity = (int)(seq & 1);
+    const double v0 = i0 < n ? src[i0] : 0.0, v1 = i0 + 1 < n ? src[i0 + 1] : 0.0;
+    // 1. this rank's piece into the slot it owns in every buffer (its own included: one code path, one summation order)
+    const size_t mine = ((size_t)parity * IPC_MAX_RANKS + rank) * IPC_SLOT + i0;
+    for (int p = 0; p < R; ++p) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<d2*>(pp.slots[p] + mine) = d2{v0, v1};
+    }
+    __threadfence_system();                      // the piece has left for every peer ...
+    __syncthreads();
+    if (t < R) {
+        // 2. ... before its flag does (release, system scope)
+        __hip_atomic_store(pp.flags[t] + ((size_t)parity * IPC_MAX_RANKS + rank) * IPC_MAX_CHUNKS + c, seq,
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // 3. the same piece of peer t, in MY buffer
+        const unsigned long long* f = pp.flags[rank] + ((size_t)parity * IPC_MAX_RANKS + t) * IPC_MAX_CHUNKS + c;
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > timeout_ticks) {             // never hang the GPU: raise the error word, go on
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");     // system scope: the pieces behind the flags
+    // 4. the R slices in rank order
+    double a0 = 0.0, a1 = 0.0;
+    for (int p = 0; p < R; ++p) {
+        const unsigned long long* q = reinterpret_cast<const unsigned long long*>(
+            pp.slots[rank] + ((size_t)parity * IPC_MAX_RANKS + p) * IPC_SLOT + i0);
+        const double w0 = __longlong_as_double((long long)__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        const double w1 = __longlong_as_double((long long)__hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        a0 = p == 0 ? w0 : ipc_combine(a0, w0, op);
+        a1 = p == 0 ? w1 : ipc_combine(a1, w1, op);
+    }
+    if (i0 < n) dst[i0] = a0;
+    if (i0 + 1 < n) dst[i0 + 1] = a1;
+}
+
+static int ipc_allreduce(hgmm_ctx* c, const double* src, double* dst, size_t n, int op) {
+    IpcComm* ic = c->icomm;
+    for (size_t off = 0; off < n; off += IPC_SLOT) {
+        const int cnt = (int)std::min(IPC_SLOT, n - off);
+        const unsigned long long seq = ++ic->seq;
+        ipc_allreduce_kernel<<<(cnt + IPC_CHUNK - 1) / IPC_CHUNK, 256, 0, c->stream>>>(
+            ic->peers, c->nranks, c->rank, src + off, dst + off, cnt, op, seq, ic->err_dev, ic->timeout_ticks);
+    }
+    HGMM_HIP(c, hipGetLastError());
+    return HGMM_OK;
+}
+
+static void ipc_close(hgmm_ctx* c) {
+    IpcComm* ic = c->icomm;
+    if (!ic) return;
+    for (int p = 0; p < IPC_MAX_RANKS; ++p)
+        if (ic->mapped[p] && ic->mapped[p] != ic->local) (void)hipIpcCloseMemHandle(ic->mapped[p]);
+    if (ic->shm) {
+        // nobody frees its buffer while a peer still has it mapped
+        if (ic->in_step) (void)ipc_barrier(c);
+        munmap(ic->shm, ic->shm_bytes);
+    }
+    if (ic->local) (void)hipFree(ic->local);
+    if (ic->err_host) (void)hipHostFree(ic->err_host);
+    if (ic->owner) shm_unlink(ic->name.c_str());
+    c->icomm_err = nullptr;
+    delete ic;
+    c->icomm = nullptr;
+}
+
 int allreduce_f64_dev(hgmm_ctx* c, double* dev, size_t n) {
     if (!c->comm_on()) return HGMM_OK;
     ProfScope prof(c, HGMM_K_ALLREDUCE);
@@ -156,6 +305,7 @@ int allreduce_f64_dev(hgmm_ctx* c, double* dev, size_t n) {
         HGMM_NCCL(c, ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, c->comm, c->stream));
         return HGMM_OK;
     }
+    if (c->icomm) return ipc_allreduce(c, dev, dev, n, 0);
     if (c->hcomm) return hostcomm_allreduce_dev(c, dev, n, 0);
     return HGMM_OK;
 }
@@ -167,6 +317,7 @@ int allreduce_i64_dev(hgmm_ctx* c, long long* dev, size_t n) {
         HGMM_NCCL(c, ncclAllReduce(dev, dev, n, ncclInt64, ncclSum, c->comm, c->stream));
         return HGMM_OK;
     }
+    if (c->icomm) return ipc_allreduce(c, reinterpret_cast<double*>(dev), reinterpret_cast<double*>(dev), n, 2);
     return hostcomm_allreduce_dev(c, reinterpret_cast<double*>(dev), n, 2);
 }
 
@@ -182,6 +333,7 @@ int allreduce_f64_oop(hgmm_ctx* c, const double* src, double* dst, size_t n) {
         HGMM_NCCL(c, ncclAllReduce(src, dst, n, ncclDouble, ncclSum, c->comm, c->stream));
         return HGMM_OK;
     }
+    if (c->icomm) return ipc_allreduce(c, src, dst, n, 0);
     if (src != dst) HGMM_HIP(c, hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
     return hostcomm_allreduce_dev(c, dst, n, 0);
 }
@@ -357,6 +509,7 @@ extern "C" int hgmm_destroy(hgmm_ctx* c) {
     (void)ctx_stream_sync(c);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     hostcomm_close(c);
+    ipc_close(c);
     DevBuf* bufs[] = {&c->x_aos, &c->x_soa64, &c->f_block, &c->f_pack,
                       &c->f_partials, &c->f_lpn_partials, &c->f_stats, &c->f_lls, &c->f_ctl, &c->f_hint,
                       &c->scratch, &c->t_pi, &c->t_mu, &c->t_cov, &c->t_prep, &c->t_cplx, &c->t_mom,
@@ -454,6 +607,14 @@ extern "C" int hgmm_d2h(hgmm_ctx* c, void* host_dst, const void* dev_src, size_t
     if (!c) return HGMM_ERR_ARG;
     HGMM_HIP(c, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, c->stream));
     HGMM_HIP(c, ctx_stream_sync(c));
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_d2d(hgmm_ctx* c, void* dev_dst, const void* dev_src, size_t bytes) {
+    if (!c) return HGMM_ERR_ARG;
+    if (bytes == 0) return HGMM_OK;
+    if (!dev_dst || !dev_src) return fail(c, HGMM_ERR_ARG, "hgmm_d2d: NULL pointer");
+    HGMM_HIP(c, hipMemcpyAsync(dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice, c->stream));
     return HGMM_OK;
 }
 
@@ -581,6 +742,113 @@ extern "C" int hgmm_comm_init_host(hgmm_ctx* c, int nranks, int rank, const char
     return hostcomm_barrier(c);
 }
 
+extern "C" int hgmm_comm_init_ipc(hgmm_ctx* c, int nranks, int rank, const char* name) {
+    if (!c || !name || !name[0]) return c ? fail(c, HGMM_ERR_ARG, "peer exchange: name is empty") : HGMM_ERR_ARG;
+    if (nranks < 1 || nranks > IPC_MAX_RANKS || rank < 0 || rank >= nranks)
+        return fail(c, HGMM_ERR_ARG, "peer exchange: bad rank %d / %d (at most %d ranks: one node)", rank, nranks, IPC_MAX_RANKS);
+    if (c->comm_on()) return fail(c, HGMM_ERR_STATE, "communicator already attached");
+    HGMM_HIP(c, hipSetDevice(c->device));
+    IpcComm* ic = new IpcComm;
+    c->icomm = ic;
+    c->nranks = nranks;
+    c->rank = rank;
+    auto bail = [&](int code, const char* what, const char* detail) {
+        ipc_close(c);                                       // (in_step is false: no barrier, the peers are not in step)
+        c->nranks = 1;
+        c->rank = 0;
+        return fail(c, code, "peer exchange: %s%s%s", what, detail[0] ? ": " : "", detail);
+    };
+    // exchange buffer: device memory that peers write while kernels here read it -> uncached (fine-grained as second choice)
+    hipError_t e = hipExtMallocWithFlags(&ic->local, IPC_BUF_BYTES, hipDeviceMallocUncached);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&ic->local, IPC_BUF_BYTES, hipDeviceMallocFinegrained); }
+    if (e != hipSuccess) { ic->local = nullptr; return bail(HGMM_ERR_HIP, "no uncached device memory", hipGetErrorString(e)); }
+    e = hipMemset(ic->local, 0, IPC_FLAG_BYTES);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    void* eh = nullptr;
+    if (e == hipSuccess) e = hipHostMalloc(&eh, 64, hipHostMallocMapped);
+    if (e != hipSuccess) return bail(HGMM_ERR_HIP, "setup failed", hipGetErrorString(e));
+    ic->err_host = static_cast<unsigned*>(eh);
+    *ic->err_host = 0;
+    void* ed = nullptr;
+    if ((e = hipHostGetDevicePointer(&ed, eh, 0)) != hipSuccess) return bail(HGMM_ERR_HIP, "setup failed", hipGetErrorString(e));
+    ic->err_dev = static_cast<unsigned*>(ed);
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
+    ic->timeout_ticks = (long long)(IPC_TIMEOUT_S * 1000.0 * (double)khz);
+    hipIpcMemHandle_t mine;
+    if ((e = hipIpcGetMemHandle(&mine, ic->local)) != hipSuccess)
+        return bail(HGMM_ERR_HIP, "hipIpcGetMemHandle", hipGetErrorString(e));
+    // the handles meet in a POSIX shared-memory object
+    ic->name = std::string("/") + name;
+    ic->shm_bytes = sizeof(IpcShm);
+    ic->owner = rank == 0;
+    int fd = -1;
+    if (rank == 0) {
+        shm_unlink(ic->name.c_str());
+        fd = shm_open(ic->name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd >= 0 && ftruncate(fd, (off_t)ic->shm_bytes) != 0) { close(fd); fd = -1; }
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (fd < 0) {
+            fd = shm_open(ic->name.c_str(), O_RDWR, 0600);
+            struct stat st;
+            if (fd >= 0 && (fstat(fd, &st) != 0 || (size_t)st.st_size < ic->shm_bytes)) { close(fd); fd = -1; }
+            if (fd < 0) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(HOSTCOMM_TIMEOUT_S)) break;
+                usleep(1000);
+            }
+        }
+    }
+    if (fd < 0) return bail(HGMM_ERR_STATE, "cannot open shared memory", name);
+    void* p = mmap(nullptr, ic->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return bail(HGMM_ERR_STATE, "mmap failed", "");
+    ic->shm = static_cast<IpcShm*>(p);
+    if (rank == 0) {
+        ic->shm->count.store(0);
+        ic->shm->generation.store(0);
+        ic->shm->failed.store(0);
+        ic->shm->nranks = nranks;
+        ic->shm->ready.store(1, std::memory_order_release);
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (ic->shm->ready.load(std::memory_order_acquire) != 1) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(HOSTCOMM_TIMEOUT_S))
+                return bail(HGMM_ERR_STATE, "rank 0 never initialised", name);
+            usleep(1000);
+        }
+        if (ic->shm->nranks != nranks) return bail(HGMM_ERR_ARG, "world size mismatch", "");
+    }
+    ic->shm->handle[rank] = mine;
+    ic->shm->device[rank] = c->device;
+    ic->shm->pid[rank] = (int)getpid();
+    if (ipc_barrier(c) != HGMM_OK) return bail(HGMM_ERR_STATE, "a peer rank never published its buffer", "");
+    for (int r = 0; r < nranks; ++r) {
+        if (r == rank) { ic->mapped[r] = ic->local; continue; }
+        if (ic->shm->pid[r] == (int)getpid()) return bail(HGMM_ERR_ARG, "two ranks in one process", "");
+        void* q = nullptr;
+        e = hipIpcOpenMemHandle(&q, ic->shm->handle[r], hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            char msg[160];
+            snprintf(msg, sizeof msg, "%s (rank %d on device %d -> rank %d on device %d)", hipGetErrorString(e), rank, c->device,
+                     r, ic->shm->device[r]);
+            ic->shm->failed.store(1, std::memory_order_release);
+            (void)ipc_barrier(c);                            // the peers are waiting in the barrier below, and look at `failed`
+            return bail(HGMM_ERR_HIP, "hipIpcOpenMemHandle", msg);
+        }
+        ic->mapped[r] = q;
+    }
+    for (int r = 0; r < nranks; ++r) {
+        ic->peers.flags[r] = static_cast<unsigned long long*>(ic->mapped[r]);
+        ic->peers.slots[r] = reinterpret_cast<double*>(static_cast<char*>(ic->mapped[r]) + IPC_FLAG_BYTES);
+    }
+    if (ipc_barrier(c) != HGMM_OK) return bail(HGMM_ERR_STATE, "a peer rank never finished mapping", "");
+    if (ic->shm->failed.load(std::memory_order_acquire)) return bail(HGMM_ERR_STATE, "a peer rank could not map the buffers", "");
+    c->icomm_err = ic->err_host;                             // every rank has every buffer mapped
+    ic->in_step = true;
+    return HGMM_OK;
+}
+
 extern "C" int hgmm_comm_destroy(hgmm_ctx* c) {
     if (!c) return HGMM_ERR_ARG;
     if (c->hcomm) {
@@ -589,6 +857,13 @@ extern "C" int hgmm_comm_destroy(hgmm_ctx* c) {
         hostcomm_close(c);
         c->nranks = 1;
         c->rank = 0;
+    }
+    if (c->icomm) {
+        const hipError_t e = ctx_stream_sync(c);
+        ipc_close(c);                                       // (barrier inside: nobody unmaps while a peer still exchanges)
+        c->nranks = 1;
+        c->rank = 0;
+        if (e != hipSuccess) return fail(c, HGMM_ERR_HIP, "peer exchange: %s", hipGetErrorString(e));
     }
     if (c->comm) {
         HGMM_HIP(c, ctx_stream_sync(c));
@@ -605,7 +880,9 @@ extern "C" int hgmm_comm_allreduce_f64(hgmm_ctx* c, double* host_inout, int n, i
     if (!c->comm_on()) return HGMM_OK;   // single rank: identity
     HGMM_TRY(ensure(c, c->comm_buf, sizeof(double) * (size_t)n));
     HGMM_HIP(c, hipMemcpyAsync(c->comm_buf.p, host_inout, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-    if (c->hcomm)
+    if (c->icomm)
+        HGMM_TRY(ipc_allreduce(c, c->comm_buf.as<double>(), c->comm_buf.as<double>(), (size_t)n, op == 1 ? 1 : 0));
+    else if (c->hcomm)
         HGMM_TRY(hostcomm_allreduce_dev(c, c->comm_buf.as<double>(), (size_t)n, op));
     else
         HGMM_NCCL(c, ncclAllReduce(c->comm_buf.p, c->comm_buf.p, (size_t)n, ncclDouble,

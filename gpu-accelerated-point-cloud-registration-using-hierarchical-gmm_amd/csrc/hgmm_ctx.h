@@ -41,6 +41,7 @@ struct FlatState {
 };
 
 struct HostComm;                           // hgmm_api.hip
+struct IpcComm;                            // hgmm_api.hip: one-shot peer-to-peer exchange over mapped peer memory
 
 struct TreeState {
     int L = 0;
@@ -130,9 +131,11 @@ struct hgmm_ctx {
     // ---- multi-GPU --------------------------------------------------------------
     ncclComm_t comm = nullptr;                // RCCL over xGMI (one GPU per rank)
     hgmm::HostComm* hcomm = nullptr;          // host shared-memory communicator (tests: ranks may share a GPU)
+    hgmm::IpcComm* icomm = nullptr;           // one-shot exchange: every rank writes its slice into every peer's buffer (xGMI)
+    volatile unsigned* icomm_err = nullptr;   // pinned host word an exchange kernel raises when a peer never arrived
     int nranks = 1, rank = 0;
     hgmm::DevBuf comm_buf;
-    bool comm_on() const { return comm != nullptr || hcomm != nullptr; }
+    bool comm_on() const { return comm != nullptr || hcomm != nullptr || icomm != nullptr; }
 
     // ---- profiling --------------------------------------------------------------
     bool profiling = false;
@@ -153,6 +156,9 @@ constexpr size_t STAGE_RING_BYTES = 4u << 20;
 inline hipError_t ctx_stream_sync(hgmm_ctx* c) {
     const hipError_t e = hipStreamSynchronize(c->stream);
     c->flat.idle_since_launch = true;
+    // an exchange kernel that waited in vain for a peer's slice has produced garbage: every result read after this
+    // synchronisation would be wrong, so the wait itself fails (hipErrorLaunchTimeOut -> HGMM_ERR_HIP at the call site)
+    if (e == hipSuccess && c->icomm_err && *c->icomm_err) return hipErrorLaunchTimeOut;
     return e;
 }
 

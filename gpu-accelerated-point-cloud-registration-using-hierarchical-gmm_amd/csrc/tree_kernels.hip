@@ -1812,6 +1812,10 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                     if (rc != HGMM_OK) return rc;
                     tree_ctl_kernel<<<1, 1, 0, c->stream>>>(q_g, ctl, ls, max_iters_per_level, trace_dev, trace_cap);
                 }
+            // a launch the runtime rejected (LDS / grid limits of another chip) would leave the progress word untouched
+            // for ever: the loops below must hear about it here
+            const hipError_t le = hipGetLastError();
+            if (le != hipSuccess) return fail(c, HGMM_ERR_HIP, "tree build: kernel launch failed: %s", hipGetErrorString(le));
             return HGMM_OK;
         };
         // The host stays ONE BATCH AHEAD of the device: batch k + 1 is enqueued before the host waits for batch k's
@@ -1853,6 +1857,11 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                     const hipError_t qe = hipStreamQuery(c->stream);
                     if (qe != hipSuccess && qe != hipErrorNotReady)
                         rc = fail(c, HGMM_ERR_HIP, "tree build: device error: %s", hipGetErrorString(qe));
+                    else if (qe == hipSuccess && __atomic_load_n(host_word, __ATOMIC_ACQUIRE) == w)
+                        // the stream is idle -- everything enqueued has run -- and the word has not moved: nothing is left
+                        // that could move it (the old batch scheme ended in the same error here)
+                        rc = fail(c, HGMM_ERR_STATE, "tree build: level %d made no progress (%d iterations enqueued, %d seen)",
+                                  l, enq, it);
                 }
             }
         } else {
@@ -2125,6 +2134,9 @@ extern "C" int hgmm_tree_reg_normal(hgmm_ctx* c, const double* rot, const double
             const hipError_t qe = hipStreamQuery(c->stream);
             if (qe != hipSuccess && qe != hipErrorNotReady)
                 return fail(c, HGMM_ERR_HIP, "registration: device error: %s", hipGetErrorString(qe));
+            // idle stream and still no sequence number: the kernel that writes it never ran
+            if (qe == hipSuccess && __atomic_load_n(h_seq, __ATOMIC_ACQUIRE) != seq)
+                return fail(c, HGMM_ERR_STATE, "registration: the normal-equation kernel did not report (sequence %llu)", seq);
         }
     }
     std::memcpy(out28, h_out, sizeof(double) * 28);

@@ -76,12 +76,18 @@ def exchange_bytes_tcp(rank: int, world: int, payload: bytes | None, addr: str, 
                         if _recv_exact(conn, len(_MAGIC)) != _MAGIC:
                             continue                      # not one of ours
                         conn.sendall(_MAGIC + struct.pack("<I", len(payload)) + payload)
-                        # a rank counts as served only once it has CONFIRMED the payload: a client that times out
-                        # or resets while reading retries, and must still find the listener
-                        if _recv_exact(conn, len(_ACK)) == _ACK:
-                            served += 1
                     except (ConnectionError, socket.timeout, OSError):
-                        continue
+                        continue                          # it did not get the payload: it retries, the listener stays
+                    # The payload is out.  The client confirms it and returns at once, without ever retrying after its
+                    # ACK -- so a lost ACK or a connection closed behind a full send is a served rank too (counting only
+                    # ACKs left rank 0 waiting out its timeout for a rank that already held the id); only an explicit
+                    # non-ACK reply means "not taken".
+                    try:
+                        reply = _recv_exact(conn, len(_ACK))
+                    except (ConnectionError, socket.timeout, OSError):
+                        reply = _ACK
+                    if reply == _ACK:
+                        served += 1
         finally:
             srv.close()
         return payload
@@ -138,10 +144,20 @@ def allgather_bytes_tcp(rank: int, world: int, payload: bytes, port_offset: int 
         return [payload]
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = int(os.environ.get("MASTER_PORT", "29500")) + port_offset
+    offsets = tuple(o - PORT_OFFSETS[0] for o in PORT_OFFSETS)       # the same fall-back ladder as the id exchange
     if rank == 0:
-        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        srv.bind((addr, port))
+        srv = None
+        for off in offsets:
+            s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                s.bind((addr, port + off))
+                srv = s
+                break
+            except OSError:
+                s.close()
+        if srv is None:
+            raise OSError("all-gather: no free port among %s" % [port + o for o in offsets])
         srv.listen(world)
         srv.settimeout(timeout)
         got = {0: payload}
@@ -158,6 +174,9 @@ def allgather_bytes_tcp(rank: int, world: int, payload: bytes, port_offset: int 
                         conn.close()
                         continue
                     r, n = struct.unpack("<II", _recv_exact(conn, 8))
+                    if not (0 < r < world) or n > (1 << 20):          # not a rank of this job
+                        conn.close()
+                        continue
                     got[r] = _recv_exact(conn, n)
                     conns.append(conn)
                 except (ConnectionError, socket.timeout, OSError):
@@ -171,23 +190,28 @@ def allgather_bytes_tcp(rank: int, world: int, payload: bytes, port_offset: int 
             for conn in conns:
                 conn.close()
             srv.close()
+    if not (0 < rank < world):
+        raise ValueError("all-gather: rank %d outside 0..%d" % (rank, world - 1))
     deadline = time.time() + timeout
     while True:
-        try:
-            with socket.create_connection((addr, port), timeout=5.0) as s:
-                s.settimeout(timeout)
-                s.sendall(_MAGIC + struct.pack("<II", rank, len(payload)) + payload)
-                blob = _recv_exact(s, struct.unpack("<I", _recv_exact(s, 4))[0])
-                out, off = [], 0
-                while off < len(blob):
-                    n = struct.unpack("<I", blob[off:off + 4])[0]
-                    out.append(blob[off + 4:off + 4 + n])
-                    off += 4 + n
-                return out
-        except (ConnectionError, socket.timeout, OSError):
-            if time.time() > deadline:
-                raise TimeoutError("all-gather: rank 0 not reachable on %s:%d" % (addr, port))
-            time.sleep(0.05)
+        for off in offsets:
+            try:
+                with socket.create_connection((addr, port + off), timeout=5.0) as s:
+                    s.settimeout(timeout)
+                    s.sendall(_MAGIC + struct.pack("<II", rank, len(payload)) + payload)
+                    blob = _recv_exact(s, struct.unpack("<I", _recv_exact(s, 4))[0])
+                    out, at = [], 0
+                    while at < len(blob):
+                        n = struct.unpack("<I", blob[at:at + 4])[0]
+                        out.append(blob[at + 4:at + 4 + n])
+                        at += 4 + n
+                    if len(out) == world:
+                        return out
+            except (ConnectionError, socket.timeout, OSError, struct.error):
+                continue
+        if time.time() > deadline:
+            raise TimeoutError("all-gather: rank 0 not reachable on %s ports %s" % (addr, [port + o for o in offsets]))
+        time.sleep(0.05)
 
 
 def attach_communicator(ctx, rank: int | None = None, world: int | None = None, transport: str = "tcp",

@@ -80,6 +80,8 @@ int hgmm_alloc(hgmm_ctx* ctx, size_t bytes, void** dev_out);
 int hgmm_free(hgmm_ctx* ctx, void* dev);
 int hgmm_h2d(hgmm_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);
 int hgmm_d2h(hgmm_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
+/* device -> device on the context's stream, nothing waits (cupy.ndarray.copy() / astype(copy=True)) */
+int hgmm_d2d(hgmm_ctx* ctx, void* dev_dst, const void* dev_src, size_t bytes);
 /* Host-visible scalars: `count` doubles (<= 4096) of pinned host memory owned by the context that kernels write
  * directly (dev_out is the address they use, host_out the one the host reads).  With an event recorded behind the
  * producing kernel a value is read without draining the stream: what a 0-d CuPy array is to the reference's loops
@@ -317,6 +319,16 @@ int hgmm_comm_destroy(hgmm_ctx* ctx);
  * all-reduce goes device -> host -> summed in rank order -> device.  For exercising the N > 1 path on a
  * single-GPU box; not a performance path.                                                          */
 int hgmm_comm_init_host(hgmm_ctx* ctx, int nranks, int rank, const char* name);
+/* One-shot exchange backend behind the same all-reduce call sites (the message is 57 KB, latency is
+ * everything): the ranks are processes of ONE node, one GPU each.  Every rank owns an exchange buffer in uncached
+ * device memory, exported with hipIpcGetMemHandle and mapped by all peers (the handles meet in the POSIX shared-memory
+ * object `name`).  An all-reduce is ONE kernel per rank: each workgroup writes its 4 KB piece of the rank's slice
+ * into the slot this rank owns in EVERY peer's buffer (plain stores over xGMI), releases a sequence flag per piece and
+ * peer, waits for the same piece of every peer in its own buffer and adds the slices up in RANK ORDER -- so all ranks
+ * hold bitwise the same sum, with no ring, no tree and no proxy thread.  Slots are double-buffered by the parity of
+ * the collective's sequence number (stream order makes that enough).  A peer that never arrives raises an error word
+ * after ~20 s instead of hanging the GPU: the next synchronising call fails.  Two ranks may share one GPU (tests). */
+int hgmm_comm_init_ipc(hgmm_ctx* ctx, int nranks, int rank, const char* name);
 int hgmm_comm_allreduce_f64(hgmm_ctx* ctx, double* host_inout, int n, int op /*0 sum,1 max*/);
 
 /* ---- profiling (hipEvent pairs around the hot kernels, on the context's stream) ---- */

@@ -339,6 +339,84 @@ def test_c3_sampled_rows_at_20_iteration_parameters(ctx, variant, cov_type):
         assert ((part[:, -1] - part[:, -2]) < RESP_TOL).all()
 
 
+def _label_checksum(lab):
+    lab = np.asarray(lab).astype(np.uint64)
+    pos = np.arange(1, len(lab) + 1, dtype=np.uint64)
+    return int((lab * pos).sum(dtype=np.uint64)), int((lab * lab * pos).sum(dtype=np.uint64))
+
+
+@pytest.mark.parametrize("variant,cov_type", FLAVOURS)
+def test_c3_training_matches_oracle_fixture(ctx, variant, cov_type):
+    """BASELINE config 3 -- the configuration bench.py's headline `value` is timed on -- against the ORACLE at full
+    size: tests/golden/flat_uniform1M_J800_oracle.npz holds oracle.flat_em's float64 EM (tools/gen_oracle_fixtures.py
+    --only flat1m: the oracle's op sequence over 16384-row blocks, asserted equal to oracle.flat_em.train) on the
+    bench frame, 3 iterations, every flavour.  Held to it: (i) the fused training loop (flat_fused_pk_kernel ->
+    flat_reduce_kernel -> flat_finalize_kernel over ~500 workgroup partials) -- lls, mu, w, cov, inv_std with the
+    tolerances of test_train_small; (ii) the same three iterations through the materialised e_step -> m_step loop;
+    (iii) predict at the oracle's final parameters: ALL 10^6 labels equal the oracle's except on rows whose two
+    largest responsibilities are closer than 1e-5 (north_star's near-tie rule) -- checked exactly through a
+    position-weighted checksum over the other rows, the population per component, and 20 000 sampled labels."""
+    g = load_golden("flat_uniform1M_J800_oracle.npz")
+    k = "%s_%s_" % (variant, cov_type)
+    N, J, iters = int(g["N"]), int(g["J"]), int(g["iters"])
+    X = np.random.RandomState(int(g["cloud_seed"])).rand(N, 3).astype(np.float32)
+    idx = np.random.RandomState(int(g["init_seed"])).choice(N, J, replace=False)
+    assert np.array_equal(idx, g["init_idx"])
+    mu0 = X[idx].copy()
+    w0 = (np.ones(J) / J).astype(np.float32)
+    cov0 = (0.1 * np.ones((J, 3) if cov_type == "diag" else (J,))).astype(np.float32)
+    ctx.set_points(X)
+
+    def check_fit(tag, inv, mu, w, cov, lls):
+        d_ll = np.abs(np.asarray(lls, dtype=np.float64) - g[k + "lls"]).max()
+        d_mu = np.abs(mu - g[k + "mu"]).max()
+        print("C3 fit %s/%s %s: max|dlls| %.3g max|dmu| %.3g max rel dw %.3g max rel dcov %.3g"
+              % (variant, cov_type, tag, d_ll, d_mu, np.abs(w / g[k + "w"] - 1).max(), np.abs(cov / g[k + "cov"] - 1).max()))
+        assert len(lls) == iters and d_ll <= 2e-5
+        assert d_mu <= 5e-6
+        np.testing.assert_allclose(w, g[k + "w"], rtol=1e-5, atol=1e-10)
+        np.testing.assert_allclose(cov, g[k + "cov"], rtol=1e-4, atol=1e-9)
+        np.testing.assert_allclose(inv, g[k + "inv"], rtol=1e-4)
+        assert abs(float(w.astype(np.float64).sum()) - float(g[k + "w"].sum())) < 1e-5
+
+    # (i) the device-resident loop: the kernel bench.py's `value` times
+    inv, mu, w, cov, lls, _ = ctx.flat_train(iters, 0.0, mu0, cov0, w0, cov_type, variant)
+    check_fit("fused", inv, mu, w, cov, lls)
+    # (ii) the materialised loop of a caller of the module functions: e_step -> m_step(exp(log_resp)) -> inv_cov
+    inv_m = flat_em.inv_std_from_cov(cov0, variant, initial=True).astype(np.float32)
+    mu_m, w_m, cov_m, lls_m = mu0, w0, cov0, []
+    lr = None
+    for _ in range(iters):
+        mean, lr, _, _ = ctx.flat_estep(inv_m, mu_m, w_m, cov_type, variant, out=lr)
+        lls_m.append(mean)
+        w_m, mu_m, cov_m = ctx.flat_mstep(lr.exp(), cov_type, variant, centre_hint=mu_m)
+        inv_m = flat_em.inv_std_from_cov(cov_m, variant).astype(np.float32)
+    del lr
+    check_fit("materialised", inv_m, mu_m, w_m, cov_m, lls_m)
+    # (iii) hard labels of ALL points at the float32 roundings of the oracle's final parameters
+    f32 = lambda a: np.asarray(a, dtype=np.float32)
+    lab = ctx.flat_predict(f32(g[k + "inv"]), f32(g[k + "mu"]), f32(g[k + "w"]), cov_type, variant).get()
+    assert lab.min() >= 0 and lab.max() < J
+    near = g[k + "near_rows"]
+    clear = np.ones(N, dtype=bool)
+    clear[near] = False
+    got = np.array(_label_checksum(np.where(clear, lab, 0)), dtype=np.uint64)
+    assert np.array_equal(got, g[k + "checksum_clear"]), "a hard label differs on a row that is not near a tie"
+    flips_near = int((lab[near] != g[k + "near_labels"]).sum())
+    sample = g["sample"]
+    flips = lab[sample] != g[k + "labels_sample"]
+    assert (g[k + "gap_sample"][flips] < RESP_TOL).all()
+    pop = np.bincount(lab, minlength=J)
+    assert np.abs(pop - g[k + "population"]).sum() <= 2 * flips_near
+    print("C3 labels %s/%s: %d of %d near-tie rows (top-2 gap < 1e-5) differ, every other of the 10^6 rows is equal"
+          % (variant, cov_type, flips_near, len(near)))
+    # the arg-max of the materialising E-step (row-maximum loop) sees the same values
+    _, _, _, am = ctx.flat_estep(f32(g[k + "inv"]), f32(g[k + "mu"]), f32(g[k + "w"]), cov_type, variant,
+                                 want_log_resp=False, want_argmax=True)
+    am = am.get()
+    assert np.array_equal(np.array(_label_checksum(np.where(clear, am, 0)), dtype=np.uint64), g[k + "checksum_clear"])
+
+
 def test_profiler_reports_kernel_time(ctx):
     X = np.random.RandomState(1).rand(20000, 3).astype(np.float32)
     ctx.set_points(X)

@@ -61,11 +61,23 @@ def _run_all(ctx, lo, hi):
     return out
 
 
-def _worker(rank, name, q, rccl_port=None):
+def _worker(rank, name, q, rccl_port=None, backend="host"):
+    try:
+        _worker_body(rank, name, q, rccl_port, backend)
+    except BaseException as e:                              # the parent must not wait out its timeout for a dead rank
+        import traceback
+        q.put((rank, "rank %d failed: %r\n%s" % (rank, e, traceback.format_exc()), None))
+        raise
+
+
+def _worker_body(rank, name, q, rccl_port, backend):
     import hgmm_amd
     if rccl_port is None:
         ctx = hgmm_amd.Context(0)
-        ctx.comm_init_host(2, rank, name)
+        if backend == "ipc":
+            ctx.comm_init_ipc(2, rank, name)
+        else:
+            ctx.comm_init_host(2, rank, name)
     else:
         from hgmm_amd import parallel
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(rccl_port), RANK=str(rank), LOCAL_RANK=str(rank),
@@ -81,6 +93,68 @@ def _worker(rank, name, q, rccl_port=None):
 
 def test_two_ranks_on_one_gpu_match_the_single_context_fit():
     _two_ranks_match_single_context(None)
+
+
+def test_two_ranks_on_one_gpu_peer_exchange_backend():
+    """The one-shot peer exchange (hgmm_comm_init_ipc: every rank writes its slice into every peer's mapped buffer, one
+    kernel per all-reduce) behind the same call sites: two processes that share the box's GPU map each other's
+    exchange buffers through hipIpc handles.  Same fits, same iteration counts, bitwise equal models on both ranks."""
+    _two_ranks_match_single_context(None, backend="ipc")
+
+
+def test_peer_exchange_collectives_two_ranks_one_gpu():
+    """The exchange kernel by itself: sum / max of float64 and payloads larger than one slot (pieces), many collectives
+    in a row (slot parity, flag sequence), both ranks bitwise equal and equal to the host's sum in rank order."""
+    name = "hgmm_ipc_%d" % os.getpid()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_ipc_collectives_worker, args=(r, name, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in procs)
+    assert not any(isinstance(v, str) for v in got.values()), got
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for a, b in zip(got[0], got[1]):
+        assert np.array_equal(a, b)
+    exp = _ipc_collectives_expected()
+    assert len(exp) == len(got[0])
+    for a, e in zip(got[0], exp):
+        assert np.array_equal(a, e)
+
+
+def _ipc_payloads(rank):
+    rs = np.random.RandomState(40 + rank)
+    return [rs.randn(n) * 10.0 ** rs.randint(-3, 4) for n in (1, 7, 511, 512, 513, 7170, 65536, 65537, 150001)]
+
+
+def _ipc_collectives_expected():
+    a, b = _ipc_payloads(0), _ipc_payloads(1)
+    out = []
+    for rep in range(3):
+        for x, y in zip(a, b):
+            out.append((x + rep) + (y + rep))
+            out.append(np.maximum(x + rep, y + rep))
+    return out
+
+
+def _ipc_collectives_worker(rank, name, q):
+    try:
+        import hgmm_amd
+        ctx = hgmm_amd.Context(0)
+        ctx.comm_init_ipc(2, rank, name)
+        out = []
+        for rep in range(3):
+            for x in _ipc_payloads(rank):
+                out.append(ctx.allreduce(x + rep))
+                out.append(ctx.allreduce(x + rep, op="max"))
+        ctx.comm_destroy()
+        ctx.close()
+        q.put((rank, out))
+    except BaseException as e:
+        q.put((rank, "rank %d failed: %r" % (rank, e)))
+        raise
 
 
 def test_rccl_two_ranks_two_gpus():
@@ -99,17 +173,18 @@ def test_rccl_two_ranks_two_gpus():
     _two_ranks_match_single_context(port)
 
 
-def _two_ranks_match_single_context(rccl_port):
+def _two_ranks_match_single_context(rccl_port, backend="host"):
     import hgmm_amd
-    name = "hgmm_test_%d" % os.getpid()
+    name = "hgmm_test_%s_%d" % (backend, os.getpid())
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    procs = [mpc.Process(target=_worker, args=(r, name, q, rccl_port)) for r in range(2)]
+    procs = [mpc.Process(target=_worker, args=(r, name, q, rccl_port, backend)) for r in range(2)]
     for p in procs:
         p.start()
     got = {}
     for _ in procs:
         rank, res, total = q.get(timeout=300)
+        assert total is not None, res
         got[rank] = res
         assert total == N_ALL
     for p in procs:
@@ -148,6 +223,6 @@ def _two_ranks_match_single_context(rccl_port):
         np.testing.assert_allclose(centres, rc, rtol=0, atol=1e-12)
         np.testing.assert_allclose(inertia, ri, rtol=1e-10)
     # both ranks hold identical models
-    for key in ("flat_W", "tree", "full"):
+    for key in ("flat_W", "flat_G", "tree", "full") if backend == "ipc" else ("flat_W", "tree", "full"):
         for a, b in zip(got[0][key][:3], got[1][key][:3]):
             assert np.array_equal(a, b)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Full-size oracle fixtures for the sizes bench.py prints numbers for (task 1).
 
-    python tools/gen_oracle_fixtures.py [--only c4|tree1m|fullcov1m]
+    python tools/gen_oracle_fixtures.py [--only c4|tree1m|fullcov1m|flat1m]
 
 Unlike tools/gen_golden.py (which runs the REFERENCE and needs /root/reference) this script runs the
 committed NumPy oracle (oracle/hgmm_tree.py, itself pinned to reference-generated fixtures by
@@ -21,6 +21,17 @@ compare against stored results instead of properties:
              (oracle.build_flat_fullcov's op sequence applied to 8192-point chunks: the N x J matrix does not
               fit host memory in one piece) -> tests/golden/fullcov_uniform1M_J800_oracle.npz
 
+  flat1m     the HEADLINE leg of bench.py (BASELINE configs[2]): the same cloud, flat diag / spherical EM with
+             J = 800, 3 iterations, all three flavours the reference has, oracle.flat_em's op sequence in float64
+             applied to 16384-point chunks (the E-step / M-step split over row blocks; the chunked driver is
+             asserted equal to oracle.flat_em.train on a size the oracle takes in one piece)
+             -> tests/golden/flat_uniform1M_J800_oracle.npz
+               (per flavour: lls[3], mu, w, cov, inv_std after 3 iterations; hard labels of ALL points at the
+                float32 roundings of those parameters: population, position-weighted checksum over the rows
+                whose two largest responsibilities are at least 1e-5 apart -- north_star's near-tie rule; three
+                iterations from cov = 0.1 leave the responsibilities of a uniform cloud flat, 2-3 % of the rows are
+                that close to a tie --, those rows themselves with their labels, 20 000 sampled labels + gaps)
+
 Fixtures hold inputs (seeds / constants) and outputs only.
 """
 import argparse
@@ -35,6 +46,7 @@ sys.path.insert(0, ROOT)
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 from oracle import hgmm_tree  # noqa: E402
+from oracle import flat_em  # noqa: E402
 
 
 def gen_c4():
@@ -156,6 +168,106 @@ def gen_fullcov1m():
     print("wrote %s: q %s, %.0f s" % (path, qs, dt))
 
 
+def flat_m_from_sums(n, s0, s1, s2, cov_type, variant):
+    """oracle.flat_em.m_step (gmm_waymo gmm_impl.py:81-103 / gmmreg_gpu gmm_impl.py:46-52) with the three products
+    resp.T @ 1, resp.T @ X, resp.T @ (X * X) handed in as sums over row blocks."""
+    EPS = flat_em.EPS
+    if variant == "W":
+        nk = s0 + EPS
+        mu = s1 / nk[:, None]
+        ex2 = s2 / nk[:, None]
+        cov = ex2 - 2 * (mu * s1 / nk[:, None]) + mu ** 2 + flat_em.REG_COVAR
+        if cov_type == "spherical":
+            cov = np.mean(cov, axis=1)
+        return nk / n, mu, cov
+    mu = s1 / (s0[:, None] + EPS)
+    ex2 = s2 / (s0[:, None] + EPS)
+    return s0 / n, mu, np.clip(ex2 - mu ** 2, 0.0, None)
+
+
+def flat_chunked(X, iters, mu, cov, w, cov_type, variant, chunk=16384):
+    """oracle.flat_em.train (gmm_impl.py:118-145 / 63-85; tol = 0) with the N x J tables formed per row block."""
+    n, J = len(X), len(mu)
+    inv = flat_em.inv_std_from_cov(cov, variant, initial=True)
+    lls = []
+    for _ in range(iters):
+        s0, s1, s2, lsum = np.zeros(J), np.zeros((J, 3)), np.zeros((J, 3)), 0.0
+        for s in range(0, n, chunk):
+            x = X[s:s + chunk]
+            _, log_resp, lpn, _ = flat_em.e_step_full(x, inv, mu, w, cov_type, variant)
+            r = np.exp(log_resp)
+            lsum += lpn.sum()
+            s0 += r.sum(axis=0)
+            s1 += r.T @ x
+            s2 += r.T @ (x * x)
+        lls.append(lsum / n)
+        w, mu, cov = flat_m_from_sums(n, s0, s1, s2, cov_type, variant)
+        inv = flat_em.inv_std_from_cov(cov, variant)
+    return inv, mu, w, cov, np.array(lls)
+
+
+def flat_labels_chunked(X, inv, mu, w, cov_type, variant, chunk=16384):
+    """oracle.flat_em.predict over row blocks + the gap between the two largest responsibilities of every row."""
+    lab = np.zeros(len(X), dtype=np.int64)
+    gap = np.zeros(len(X))
+    for s in range(0, len(X), chunk):
+        _, log_resp, _, am = flat_em.e_step_full(X[s:s + chunk], inv, mu, w, cov_type, variant)
+        part = np.partition(np.exp(log_resp), -2, axis=1)
+        lab[s:s + chunk] = am
+        gap[s:s + chunk] = part[:, -1] - part[:, -2]
+    return lab, gap
+
+
+FLAT_FLAVOURS = (("W", "diag"), ("W", "spherical"), ("G", "diag"))
+
+
+def gen_flat1m():
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    # the chunked driver == the oracle on a size the oracle takes in one piece
+    Xs = f64(np.random.RandomState(0).rand(5000, 3).astype(np.float32))
+    for variant, cov_type in FLAT_FLAVOURS:
+        mu0, w0, cov0 = flat_em.seeded_init(Xs.astype(np.float32), 40, 3, cov_type)
+        a = flat_em.train(Xs, 4, 0.0, f64(mu0), f64(cov0), f64(w0), cov_type, variant)
+        b = flat_chunked(Xs, 4, f64(mu0), f64(cov0), f64(w0), cov_type, variant, chunk=512)
+        assert np.allclose(a[4], b[4], rtol=1e-13, atol=0) and np.allclose(a[1], b[1], rtol=1e-11, atol=1e-14)
+        assert np.allclose(a[2], b[2], rtol=1e-11) and np.allclose(a[3], b[3], rtol=1e-9, atol=1e-15)
+        assert np.array_equal(flat_labels_chunked(Xs, a[0], a[1], a[2], cov_type, variant, 512)[0],
+                              flat_em.predict(Xs, a[0], a[1], a[2], cov_type, variant))
+    N, J, iters = 1_000_000, 800, 3
+    X32 = np.random.RandomState(0).rand(N, 3).astype(np.float32)            # bench.synth_frame(0)
+    X = f64(X32)
+    idx = np.random.RandomState(100).choice(N, J, replace=False)            # bench.synth_init: seed 100 + frame
+    sample = np.sort(np.random.RandomState(13).choice(N, 20000, replace=False))
+    out = {"N": N, "J": J, "iters": iters, "cloud_seed": 0, "init_seed": 100, "init_idx": idx.astype(np.int32),
+           "cov0": np.float32(0.1), "sample": sample.astype(np.int32), "tie_gap": 1e-5}
+    t00 = time.time()
+    for variant, cov_type in FLAT_FLAVOURS:
+        t0 = time.time()
+        mu0 = f64(X32[idx])
+        w0 = f64((np.ones(J) / J).astype(np.float32))
+        cov0 = f64((0.1 * np.ones((J, 3) if cov_type == "diag" else (J,))).astype(np.float32))
+        inv, mu, w, cov, lls = flat_chunked(X, iters, mu0, cov0, w0, cov_type, variant)
+        # hard labels at the float32 roundings of the final parameters: the inputs a float32 engine can be given exactly
+        inv32, mu32, w32 = (np.asarray(a, dtype=np.float32) for a in (inv, mu, w))
+        lab, gap = flat_labels_chunked(X, f64(inv32), f64(mu32), f64(w32), cov_type, variant)
+        near = np.flatnonzero(gap < out["tie_gap"])
+        clear = np.ones(N, dtype=bool)
+        clear[near] = False
+        k = "%s_%s_" % (variant, cov_type)
+        out.update({k + "lls": lls, k + "mu": mu, k + "w": w, k + "cov": cov, k + "inv": inv,
+                    k + "population": np.bincount(lab, minlength=J).astype(np.int32),
+                    k + "checksum_clear": np.array(label_checksum(np.where(clear, lab, 0)), dtype=np.uint64),
+                    k + "near_rows": near.astype(np.int32), k + "near_labels": lab[near].astype(np.int16),
+                    k + "labels_sample": lab[sample].astype(np.int16),
+                    k + "gap_sample": gap[sample].astype(np.float32)})
+        print("flat1m %s/%s: lls %s, %d rows within %.0e of a tie, %.0f s"
+              % (variant, cov_type, lls, len(near), out["tie_gap"], time.time() - t0), flush=True)
+    out["oracle_seconds"] = time.time() - t00
+    path = os.path.join(GOLD, "flat_uniform1M_J800_oracle.npz")
+    np.savez_compressed(path, **out)
+    print("wrote %s, %.0f s" % (path, out["oracle_seconds"]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -166,6 +278,8 @@ def main():
         gen_tree1m()
     if a.only in ("", "fullcov1m"):
         gen_fullcov1m()
+    if a.only in ("", "flat1m"):
+        gen_flat1m()
 
 
 if __name__ == "__main__":
