@@ -130,31 +130,27 @@ def launch_ranks(n, argv, script=None, extra_env=None, timeout=None):
 
 
 def self_launch(args, argv):
-    # (the ranks are told who started them: under this launcher a rank that cannot get an RCCL communicator exits and
-    #  everybody is restarted on the fallback; under an external launcher the ranks fall back in place)
-    rc = launch_ranks(args.gpus, argv, extra_env={"HGMM_BENCH_LAUNCHER": "self"})
-    if rc == RCCL_INIT_FAILED and not os.environ.get("HGMM_BENCH_HOSTCOMM"):
-        # RCCL could not build a communicator on this node: measure with the library's host shared-memory
-        # all-reduce instead (every rank on its own GPU; statistics go device -> shared memory -> device)
-        sys.stderr.write("bench: RCCL communicator unavailable, re-running with the host shared-memory all-reduce\n")
-        rc = launch_ranks(args.gpus, argv, extra_env={"HGMM_BENCH_HOSTCOMM": "hgmm_bench_%d" % os.getpid(),
-                                                      "HGMM_BENCH_FALLBACK": "1"})
-    return rc
+    # (a backend that cannot be set up on every rank is replaced IN PLACE by the next one, collectively -- rank_main /
+    #  choose_collective; rounds 1-3 restarted the ranks instead, which an external launcher cannot do)
+    return launch_ranks(args.gpus, argv, extra_env={"HGMM_BENCH_LAUNCHER": "self"})
 
 
 # ------------------------------------------------------------------------------------------------
 # legs that run on rank 0 at N = 1
 # ------------------------------------------------------------------------------------------------
-def cpu_baseline_main(sample_n=200_000, iters=10):
-    """NumPy oracle (fp32, reference op sequence) on a bounded sample of the workload."""
+def cpu_baseline_main(sample_n=200_000, sample_iters=5, full_iters=3):
+    """NumPy oracle (fp32, reference op sequence) on this box's host cores: the FULL 1M x 800 frame, `full_iters`
+    iterations in one piece like the reference (train_gmm materialises its N x J temporaries, ~20 GB at this size) --
+    when the host has the memory; beside it (and instead of it on a small host) a 200 k-point sample scaled linearly."""
     from oracle import flat_em
-    X = synth_frame(0)[:sample_n]
-    mu, w, cov = init_params(synth_frame(0))
-    flat_em.train(X[:2000], 1, 0.0, mu, cov, w, "diag", "W")          # warm BLAS / pages
+    frame = synth_frame(0)
+    mu, w, cov = init_params(frame)
+    flat_em.train(frame[:2000], 1, 0.0, mu, cov, w, "diag", "W")          # warm BLAS / pages
+    X = frame[:sample_n]
     t0 = time.perf_counter()
-    flat_em.train(X, iters, 0.0, mu, cov, w, "diag", "W")
-    dt = time.perf_counter() - t0
-    it_per_s_sample = iters / dt
+    flat_em.train(X, sample_iters, 0.0, mu, cov, w, "diag", "W")
+    dt_s = time.perf_counter() - t0
+    it_per_s_sample = sample_iters / dt_s
     blas_threads = None
     try:                                   # threads the GEMMs actually ran on (elementwise passes are 1 thread)
         from threadpoolctl import threadpool_info
@@ -162,16 +158,42 @@ def cpu_baseline_main(sample_n=200_000, iters=10):
         blas_threads = max([p.get("num_threads", 1) for p in pools] or [1])
     except Exception:
         pass
-    return {
-        "value": it_per_s_sample * sample_n / N_POINTS,
-        "unit": "EM it/s per 1M-pt x 800-comp frame (extrapolated linearly in N from the sample)",
+    extrapolated = it_per_s_sample * sample_n / N_POINTS
+    out = {
+        "unit": "EM it/s per 1M-pt x 800-comp frame",
         "cores": blas_threads or os.cpu_count(),
         "host_cpu_count": os.cpu_count(),
         "kind": "port",
-        "sample": "oracle/flat_em.train (NumPy fp32, same op sequence as reference train_gmm), N=%d of the "
-                  "1M-point frame, J=800, %d iterations, %.1f s" % (sample_n, iters, dt),
-        "it_per_s_on_sample": it_per_s_sample,
+        "extrapolated_from_sample": {"value": extrapolated, "it_per_s_on_sample": it_per_s_sample,
+                                     "sample": "N=%d of the frame, %d iterations, %.1f s; scaled linearly in N"
+                                               % (sample_n, sample_iters, dt_s)},
     }
+    avail_gb = None
+    try:
+        import psutil
+        avail_gb = psutil.virtual_memory().available / 2 ** 30
+    except Exception:
+        pass
+    need_gb = 10 * 4.0 * len(frame) * J_COMP / 2 ** 30              # ~10 live N x J float32 temporaries at the peak
+    # (the budget: a few iterations of (sample time per iteration x N / sample_n) must stay within ~40 s)
+    est_full_s = full_iters * dt_s / sample_iters * len(frame) / sample_n
+    if avail_gb is not None and avail_gb > need_gb + 8 and est_full_s < 60 and not os.environ.get("HGMM_BENCH_CPU_SAMPLE_ONLY"):
+        t0 = time.perf_counter()
+        flat_em.train(frame, full_iters, 0.0, mu, cov, w, "diag", "W")
+        dt = time.perf_counter() - t0
+        out["value"] = full_iters / dt
+        out["sample"] = ("oracle/flat_em.train (NumPy fp32, same op sequence as reference train_gmm) on the WHOLE 1M-point "
+                         "frame, J=800, %d iterations in one piece, %.1f s" % (full_iters, dt))
+    else:
+        out["value"] = extrapolated
+        out["unit"] += " (extrapolated linearly in N from the sample)"
+        out["sample"] = ("oracle/flat_em.train (NumPy fp32, same op sequence as reference train_gmm), N=%d of the 1M-point "
+                         "frame, J=800, %d iterations, %.1f s -- the whole frame was not timed: %s"
+                         % (sample_n, sample_iters, dt_s,
+                            "host memory %.0f GB available, ~%.0f GB needed" % (avail_gb or -1, need_gb + 8)
+                            if not (avail_gb is not None and avail_gb > need_gb + 8) else
+                            "estimated %.0f s exceed the bench's CPU budget" % est_full_s))
+    return out
 
 
 def bunny_leg(ctx):
@@ -453,10 +475,20 @@ def estep_roofline_leg(ctx, lr, init, fitted, args):
         except Exception:
             traffic = None
     cold_avg = float(np.mean(cold))
+    # headline: the mean over the three call patterns the kernel was timed in (equal weights) -- blocking calls, an
+    # unwaited-for stream, the launches right behind a fit; each pattern's own figure stays beside it
+    pattern_ms = [avg_s * 1e3, stream_s * 1e3, cold_avg] if stream_s else [avg_s * 1e3, cold_avg]
+    mean_s = float(np.mean(pattern_ms)) * 1e-3
+    blocking = achieved
+    achieved = alg_bytes / mean_s / 1e9
     return {"kernel": "materialising E-step (flat_estep kernel, log_resp[N,J] written once)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_s * 1e3, "launches": e_n,
+            "rule": "achieved = algorithmic bytes / mean launch duration over the call patterns below (hipEvents), equal weights",
+            "patterns_ms": {"blocking_calls": avg_s * 1e3, "unsynchronised_stream": stream_s * 1e3,
+                            "right_behind_a_fit": cold_avg},
+            "blocking_calls_frac": blocking / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": mean_s * 1e3, "launches": e_n + s_n + len(cold),
             "steady_state_rule": "40 untimed launches (15 of them the cold ones below) precede the timed ones; every "
                                  "launch is a blocking hgmm_flat_estep call (the host reads the mean, ~25 us idle)",
             "unsynchronised_stream_avg_ms": stream_s * 1e3,
@@ -534,6 +566,33 @@ def materialised_iteration_leg(ctx, lr, inv, mu, w):
     return out
 
 
+def log_prob_leg(ctx, fitted):
+    """estimate_log_prob(X, inv_cov, means) (gmm_impl.py:53-78) on the C3 frame: the un-normalised N x J table.  The same
+    bytes as e_step's output, no exponential, no reduction: the kernel is as close to a pure store stream as this path
+    gets (four rows in flight per wave, 16-byte non-temporal stores)."""
+    inv, mu, w = fitted
+    out = None
+    for _ in range(5):
+        out = None
+        out = ctx.flat_log_prob(inv, mu, "diag")
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    reps = 20
+    for _ in range(reps):
+        out = None                                      # (the dead table's memory is handed to the next one)
+        out = ctx.flat_log_prob(inv, mu, "diag")
+    ctx.profile_enable(False)
+    k_ms, k_n = ctx.profile_get("flat_estep")
+    del out
+    k_s = k_ms / max(k_n, 1) * 1e-3
+    alg = 12 * N_POINTS + 4 * N_POINTS * J_COMP + 28 * J_COMP
+    return {"workload": "estimate_log_prob() on the 1M-point frame, J=800 (log N(x_i; mu_j, diag) for all pairs)",
+            "kernel_ms": k_s * 1e3, "launches": k_n,
+            "roofline": {"kernel": "flat_logprob_rows_pk_kernel<3,1>", "bound": "hbm", "unit": "GB/s",
+                         "algorithmic_bytes_per_launch": alg, "achieved": alg / k_s / 1e9, "peak": HBM_PEAK_GBS,
+                         "frac": alg / k_s / 1e9 / HBM_PEAK_GBS}}
+
+
 def predict_leg(ctx, fitted):
     """predict(X, inv_cov, means, weights) (gmm_impl.py:147-155) on the C3 frame: labels[N] only, parameters in device
     arrays, one call per frame the way run_gmm_waymo_gpu.py:32-61 predicts every frame."""
@@ -594,68 +653,78 @@ def fused_roofline(avg_launch_s, cus):
 
 
 # ------------------------------------------------------------------------------------------------
-def rank_main(args):
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    args.gpus = world
+COLLECTIVES = {
+    "rccl": "RCCL ncclAllReduce(sum, float64) on the kernel stream",
+    "ipc": "one-shot peer exchange over mapped peer memory (hipIpc, xGMI): one kernel per all-reduce, every rank "
+           "writes its slice into every peer's buffer, slices summed in rank order",
+    "host": "host shared memory (device -> shm -> device)",
+}
+# what a rank moves on to when a backend cannot be set up on every rank (decided collectively, see choose_collective)
+FALLBACK_ORDER = {"auto": ["rccl", "ipc", "host"], "rccl": ["rccl", "ipc", "host"], "ipc": ["ipc", "host"], "host": ["host"]}
+ATTACH_TIMEOUT_S = float(os.environ.get("HGMM_BENCH_ATTACH_TIMEOUT", "180"))
 
-    import hgmm_amd
-    # HGMM_BENCH_HOSTCOMM=<name>: all-reduce through the library's host shared-memory backend instead of RCCL.
-    #   + HGMM_BENCH_DEVICE=<id>  rehearsal of the N > 1 flow on a single-GPU box (all ranks on one device;
-    #                             a flow check, not a measurement)
-    #   + HGMM_BENCH_FALLBACK=1   set by the launcher after RCCL failed to initialise (ranks on their own GPUs)
-    hostcomm = os.environ.get("HGMM_BENCH_HOSTCOMM")
-    fallback = bool(os.environ.get("HGMM_BENCH_FALLBACK"))
-    rehearsal = bool(hostcomm) and not fallback
-    device = int(os.environ.get("HGMM_BENCH_DEVICE", local_rank)) if rehearsal else local_rank
-    ctx = hgmm_amd.Context(device)
-    info = ctx.device_info()
-    collective = None
-    if world > 1 and hostcomm:
-        ctx.comm_init_host(world, rank, hostcomm)
-        collective = "host shared memory (device -> shm -> device)"
-    elif world > 1:
-        from hgmm_amd import parallel
-        err = None
+
+def _run_with_timeout(fn, seconds):
+    """fn() in a daemon thread -> None, or the exception / a TimeoutError.  (A collective set-up call can block for ever
+    when a peer rank failed in it: the thread is then abandoned and the backend counts as unavailable.)"""
+    import threading
+    box = {}
+
+    def work():
         try:
-            parallel.attach_communicator(ctx, rank, world, transport="tcp")
-        except Exception as e:
-            err = e
-            sys.stderr.write("rank %d: RCCL communicator could not be created: %s\n" % (rank, e))
-        # Communicator creation can fail on SOME ranks only: the backend is chosen collectively.  Every rank reports
-        # (ok flag, hostname, rank 0 adds a job-unique token) over a plain TCP all-gather before anybody decides.
-        token = ("%08x" % (int.from_bytes(os.urandom(4), "little"))) if rank == 0 else ""
-        mine = ("%d|%s|%s" % (0 if err else 1, socket.gethostname(), token)).encode()
-        reports = [r.decode().split("|") for r in parallel.allgather_bytes_tcp(rank, world, mine)]
-        all_ok = all(r[0] == "1" for r in reports)
-        if all_ok:
-            collective = "RCCL ncclAllReduce(sum, float64) on the kernel stream"
-        else:
-            if os.environ.get("HGMM_BENCH_LAUNCHER") == "self":
-                sys.exit(RCCL_INIT_FAILED)               # the launcher restarts every rank on the fallback
-            # started by an external launcher: nobody can restart the group, so every rank moves to the library's
-            # host shared-memory all-reduce in place -- possible only when all ranks share one host
-            hosts = sorted(set(r[1] for r in reports))
-            if len(hosts) > 1:
-                sys.stderr.write("rank %d: no RCCL communicator and the ranks span %s: the host shared-memory "
-                                 "fallback needs one host\n" % (rank, hosts))
-                sys.exit(RCCL_INIT_FAILED)
-            if not err:
-                ctx.comm_destroy()                        # this rank's communicator is useless without the others
-            ctx.comm_init_host(world, rank, "hgmm_bench_fb_%s" % reports[0][2])
-            collective = "host shared memory (device -> shm -> device)"
-            fallback = True
+            fn()
+        except BaseException as e:          # noqa: BLE001 -- reported, not swallowed
+            box["err"] = e
+        box["done"] = True
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(seconds)
+    if not box.get("done"):
+        return TimeoutError("no answer within %.0f s" % seconds)
+    return box.get("err")
 
-    frame = synth_frame(rank)
-    mu0, w0, cov0 = init_params(synth_frame(0) if rank else frame)
-    ctx.set_points(frame)
+
+def attach_collective(ctx, kind, rank, world, token):
+    from hgmm_amd import parallel
+    if kind == "rccl":
+        return _run_with_timeout(lambda: parallel.attach_communicator(ctx, rank, world, transport="tcp"), ATTACH_TIMEOUT_S)
+    if kind == "ipc":
+        return _run_with_timeout(lambda: ctx.comm_init_ipc(world, rank, "hgmm_bench_ipc_%s" % token), ATTACH_TIMEOUT_S)
+    return _run_with_timeout(lambda: ctx.comm_init_host(world, rank, "hgmm_bench_host_%s" % token), ATTACH_TIMEOUT_S)
+
+
+def choose_collective(ctx, rank, world, order, token, hosts, round0=1):
+    """Attach the first backend of `order` that EVERY rank can set up: after each attempt the ranks all-gather their ok
+    flags over plain TCP, so a failure on some ranks only cannot leave the ranks on different backends.
+    -> (kind or None, [(kind, error text), ...] of the attempts that failed somewhere)."""
+    from hgmm_amd import parallel
+    failed = []
+    for i, kind in enumerate(order):
+        if kind != "rccl" and len(hosts) > 1:
+            failed.append((kind, "the ranks span %s: this backend needs one host" % hosts))
+            continue
+        err = attach_collective(ctx, kind, rank, world, token)
+        if err is not None:
+            sys.stderr.write("rank %d: %s backend could not be set up: %r\n" % (rank, kind, err))
+        flags = parallel.allgather_bytes_tcp(rank, world, b"0" if err is not None else b"1", port_offset=137 + 10 * (round0 + i))
+        if all(f == b"1" for f in flags):
+            return kind, failed
+        failed.append((kind, repr(err) if err is not None else "failed on another rank"))
+        if err is None:
+            # this rank's communicator is useless without the others (the call may wait for peers that are gone)
+            _run_with_timeout(ctx.comm_destroy, 30.0)
+    return None, failed
+
+
+def timed_fit(ctx, args, world, init):
+    """The timed region: W warm-up steps, then blocks of exactly K fused EM iterations, each bracketed by barrier +
+    stream synchronisation, MAX over ranks; one more block under the hipEvent profiler; the fitted model."""
+    mu0, cov0, w0 = init
 
     def barrier():
         ctx.synchronize()
         ctx.allreduce([0.0])
 
-    # ---- timed region: blocks of K fused EM iterations ---------------------------------------------
     K, W = args.steps, args.warmup
     cap = W + K * (MAX_BLOCKS + 2) + 8
     ctx.flat_train_begin(0.0, mu0, cov0, w0, "diag", "W", lls_capacity=cap)
@@ -677,11 +746,10 @@ def rank_main(args):
     barrier()
     ctx.profile_enable(False)
     fused_ms, fused_n = ctx.profile_get("flat_fused")
-    ar_ms, ar_n = ctx.profile_get("allreduce") if world > 1 else (0.0, 0)
+    ar_ms, ar_n = ctx.profile_get("allreduce") if (world > 1 or args._world1_comm) else (0.0, 0)
     inv, mu, w, cov, lls, conv, n_it = ctx.flat_train_end()
     assert n_it == W + K * (len(blocks) + 1), (n_it, W, K, len(blocks))
     assert np.isfinite(lls).all()
-
     # every rank must hold the same model after the joint fit: checksum of (mu, cov, w, inv) as raw 32-bit words
     # (exact in float64), all-reduced with max and with min -- equal on all ranks iff max == min
     words = np.concatenate([np.ascontiguousarray(a).view(np.uint32).ravel() for a in (mu, cov, w, inv)]).astype(np.float64)
@@ -689,16 +757,115 @@ def rank_main(args):
     hi = ctx.allreduce(sums, op="max")
     lo = -ctx.allreduce(-sums, op="max")
     consistent = bool(np.array_equal(hi, lo))
-    if not consistent:
-        sys.stderr.write("rank %d: model checksums differ across ranks: max %s min %s\n" % (rank, hi, lo))
     barrier()
+    return {"blocks": blocks, "fused_ms": fused_ms, "fused_n": fused_n, "ar_ms": ar_ms, "ar_n": ar_n,
+            "model": (inv, mu, w, cov), "lls": lls, "consistent": consistent, "checksum": [float(v) for v in hi],
+            "checksum_lo": [float(v) for v in lo]}
+
+
+def collective_world1_leg(ctx, args, init, base_it_per_s):
+    """What the all-reduce call itself costs on the stream, before any link is crossed: the fused loop with a
+    communicator of ONE rank attached -- RCCL (ncclAllReduce of 57 KB in place) and the one-shot peer exchange (its
+    kernel writes the slice into this rank's own slot and reads it back).  `allreduce_us` = hipEvent time around the
+    call per iteration; `it_per_s` against `it_per_s_no_communicator` also shows what the enqueue costs the host."""
+    out = {"payload_bytes": 8 * (7 * 1024 + 2), "it_per_s_no_communicator": base_it_per_s}
+    a2 = argparse.Namespace(**vars(args))
+    a2.min_time = min(args.min_time, 0.3)
+    a2._world1_comm = True
+    for kind in ("rccl", "ipc"):
+        try:
+            if kind == "rccl":
+                ctx.comm_init(1, 0, type(ctx).comm_unique_id())
+            else:
+                ctx.comm_init_ipc(1, 0, "hgmm_bench_w1_%d" % os.getpid())
+            try:
+                r = timed_fit(ctx, a2, 1, init)
+            finally:
+                ctx.comm_destroy()
+            med = float(np.median(r["blocks"]))
+            out[kind] = {"allreduce_us": 1e3 * r["ar_ms"] / max(r["ar_n"], 1), "launches": r["ar_n"],
+                         "it_per_s": args.steps / med, "ms_per_step": 1e3 * med / args.steps,
+                         "fused_kernel_avg_ms": r["fused_ms"] / max(r["fused_n"], 1)}
+        except Exception as e:                                  # a side leg must not lose the headline line
+            out[kind] = {"error": repr(e)}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def rank_main(args):
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    args.gpus = world
+    args._world1_comm = False
+
+    import hgmm_amd
+    # HGMM_BENCH_DEVICE=<id>: rehearsal of the N > 1 flow on a single-GPU box -- all ranks on one device, joined by the
+    #   host shared-memory backend (HGMM_BENCH_HOSTCOMM=<name>, or --collective host) or by the peer exchange
+    #   (--collective ipc; RCCL does not accept two ranks on one device).  A flow check, not a measurement.
+    hostcomm = os.environ.get("HGMM_BENCH_HOSTCOMM")
+    requested = "host" if hostcomm else args.collective
+    rehearsal = "HGMM_BENCH_DEVICE" in os.environ and world > 1
+    device = int(os.environ["HGMM_BENCH_DEVICE"]) if rehearsal else local_rank
+    ctx = hgmm_amd.Context(device)
+    info = ctx.device_info()
+    kind, failed_kinds, token, hosts = None, [], "", [socket.gethostname()]
     if world > 1:
-        ctx.comm_destroy()                     # the legs below run on rank 0 alone
+        from hgmm_amd import parallel
+        # round 0: everybody is there; a job-unique token (names of the shared-memory objects) and the hosts
+        mine = ("%s|%s" % (socket.gethostname(), ("%08x" % int.from_bytes(os.urandom(4), "little")) if rank == 0 else "")).encode()
+        reports = [r.decode().split("|") for r in parallel.allgather_bytes_tcp(rank, world, mine)]
+        token = hostcomm or reports[0][1]
+        hosts = sorted(set(r[0] for r in reports))
+        order = FALLBACK_ORDER[requested]
+        if rehearsal:
+            order = [k for k in order if k != "rccl"]
+        kind, failed_kinds = choose_collective(ctx, rank, world, order, token, hosts)
+        if kind is None:
+            sys.stderr.write("rank %d: no all-reduce backend could be set up on all ranks: %s\n" % (rank, failed_kinds))
+            sys.exit(RCCL_INIT_FAILED)
+    fallback = bool(failed_kinds) and not rehearsal
+
+    frame = synth_frame(rank)
+    mu0, w0, cov0 = init_params(synth_frame(0) if rank else frame)
+    ctx.set_points(frame)
+
+    K, W = args.steps, args.warmup
+    fit = timed_fit(ctx, args, world, (mu0, cov0, w0))
+    blocks, consistent = fit["blocks"], fit["consistent"]
+    inv, mu, w, cov = fit["model"]
+    lls = fit["lls"]
+    fused_ms, fused_n, ar_ms, ar_n = fit["fused_ms"], fit["fused_n"], fit["ar_ms"], fit["ar_n"]
+    if not consistent:
+        sys.stderr.write("rank %d: model checksums differ across ranks: max %s min %s\n" % (rank, fit["checksum"], fit["checksum_lo"]))
+    # --collective auto: the same joint fit once more over the one-shot peer exchange, reported beside the RCCL figure
+    second = None
+    if world > 1 and requested == "auto" and kind == "rccl" and len(hosts) == 1:
+        _run_with_timeout(ctx.comm_destroy, 60.0)
+        k2, failed2 = choose_collective(ctx, rank, world, ["ipc"], token, hosts, round0=8)
+        if k2 == "ipc":
+            f2 = timed_fit(ctx, args, world, (mu0, cov0, w0))
+            med2 = float(np.median(f2["blocks"]))
+            same = all(np.array_equal(a, b) for a, b in zip(f2["model"], fit["model"]))
+            second = {"collective": COLLECTIVES["ipc"], "value": world * K / med2, "ms_per_step": 1e3 * med2 / K,
+                      "allreduce_us": 1e3 * f2["ar_ms"] / max(f2["ar_n"], 1),
+                      "identical_model_on_all_ranks": f2["consistent"],
+                      "model_bitwise_equal_to_the_rccl_fit": bool(same),
+                      "max_abs_dmu_vs_the_rccl_fit": float(np.abs(f2["model"][1] - fit["model"][1]).max()),
+                      "blocks": len(f2["blocks"]),
+                      "note": "same frames, same initial parameters, same K-step blocks as `value`; only the all-reduce "
+                              "behind the statistics differs (sums in rank order instead of RCCL's reduction order)"}
+            consistent = consistent and f2["consistent"]
+        else:
+            second = {"collective": COLLECTIVES["ipc"], "error": "could not be set up on every rank: %s" % (failed2,)}
+    if world > 1:
+        _run_with_timeout(ctx.comm_destroy, 60.0)            # the legs below run on rank 0 alone
 
     out = None
     if rank == 0:
         med = float(np.median(blocks))
         fused_avg_ms = fused_ms / max(fused_n, 1)
+        collective = COLLECTIVES.get(kind)
         out = {
             "metric": "EM iterations/sec (N points x J components); E-step achieved HBM GB/s",
             "value": world * K / med,
@@ -713,18 +880,17 @@ def rank_main(args):
                                    "(7J+2) f64 sufficient statistics per iteration",
                        "points_per_gpu": N_POINTS, "components": J_COMP, "cov_type": "diag",
                        "device": info["name"], "compute_units": info["compute_units"],
-                       **({"collective": collective} if collective else {}),
-                       **({"rehearsal": "all ranks on ONE device, host shared-memory all-reduce -- flow check, "
-                                        "not a measurement"} if rehearsal else {}),
-                       **({"fallback": "RCCL communicator could not be created on this node; statistics "
-                                       "all-reduced through host shared memory"} if fallback else {})},
+                       **({"collective": collective, "collective_requested": requested} if collective else {}),
+                       **({"rehearsal": "all ranks on ONE device -- flow check, not a measurement"} if rehearsal else {}),
+                       **({"fallback": "backend(s) that could not be set up on every rank of this node: %s"
+                                       % "; ".join("%s (%s)" % fk for fk in failed_kinds)} if fallback else {})},
             "timing": {"blocks": len(blocks), "steps_per_block": K, "timed_s": float(sum(blocks)),
                        "median_block_ms": med * 1e3, "first_block_it_per_s": world * K / blocks[0],
                        "min_block_it_per_s": world * K / max(blocks), "max_block_it_per_s": world * K / min(blocks),
                        "rule": "value = world x K / median block; every block = K steps between barrier+sync pairs, "
                                "MAX over ranks"},
             "it_per_s_per_gpu": K / med,
-            "rank_consistency": {"identical_model_on_all_ranks": consistent, "checksum": [float(v) for v in hi],
+            "rank_consistency": {"identical_model_on_all_ranks": fit["consistent"], "checksum": fit["checksum"],
                                  "rule": "sum of the raw 32-bit words of (mu, cov, w, inv_std), plain and position-"
                                          "weighted, all-reduced with max and min over the ranks"},
             "fused_kernel": {"avg_ms": fused_avg_ms, "launches": fused_n,
@@ -735,6 +901,8 @@ def rank_main(args):
             out["allreduce_us"] = 1e3 * ar_ms / max(ar_n, 1)
             out["allreduce_payload_bytes"] = 8 * (7 * 1024 + 2)        # 7 statistics x Jpad(=1024) + sum lpn + n
             out["allreduce_launches"] = ar_n
+            if second is not None:
+                out["peer_exchange"] = second
         if fused_avg_ms:
             out["roofline_fused"] = fused_roofline(fused_avg_ms * 1e-3, info["compute_units"])
         if not consistent:
@@ -750,6 +918,7 @@ def rank_main(args):
         # (from the INITIAL parameters, as a caller's own loop starts: inv_cov0 = 1 / sqrt(cov0), gmm_impl.py:122)
         out["materialised_iteration"] = materialised_iteration_leg(ctx, lr, (1.0 / np.sqrt(cov0)).astype(np.float32), mu0, w0)
         out["predict"] = predict_leg(ctx, (inv, mu, w))
+        out["estimate_log_prob"] = log_prob_leg(ctx, (inv, mu, w))
         # what a pure 16-byte store stream of the same size reaches on this chip (write ceiling)
         # (best pure-store pattern found, tools/fillbench.py: one workgroup per CU, grid-stride)
         ctx.util_fill(lr, 0.0, False, 0, 1)
@@ -779,6 +948,12 @@ def rank_main(args):
                 out[name] = leg(ctx)
             except Exception as e:                                    # a side leg must not lose the headline line
                 out[name] = {"error": repr(e)}
+    if rank == 0 and world == 1 and "collective" not in args.skip:
+        try:
+            ctx.set_points(frame)
+            out["collective_world1"] = collective_world1_leg(ctx, args, (mu0, cov0, w0), out["it_per_s_per_gpu"])
+        except Exception as e:
+            out["collective_world1"] = {"error": repr(e)}
     if rank == 0:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_main()
@@ -803,6 +978,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--estep-reps", type=int, default=30)
     ap.add_argument("--skip", default="", help="comma-separated side legs to skip (bunny,hgmm,tree_1M,fullcov,...)")
+    ap.add_argument("--collective", default="auto", choices=sorted(FALLBACK_ORDER),
+                    help="N > 1: the all-reduce behind the sufficient statistics.  auto (default): `value` over RCCL "
+                         "and the same fit once more over the one-shot peer exchange (`peer_exchange`); rccl / ipc / "
+                         "host: that backend only.  A backend that cannot be set up on every rank is replaced by the "
+                         "next of rccl -> ipc -> host, collectively, and the line says so (config.fallback)")
     args = ap.parse_args()
     args.skip = set(s for s in args.skip.split(",") if s)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

@@ -1751,11 +1751,19 @@ static bool launch_estep_rows(hgmm_ctx* c, int nv4, int nv1, int grid_r, bool cs
 static bool launch_logprob_rows(hgmm_ctx* c, int nv4, int nv1, float* log_prob) {
     const FlatState& f = c->flat;
     if (env_flag("HGMM_LOGPROB_SINGLE_ROW", false)) return false;
-    // grid: the store stream is all this kernel has to wait for -- one workgroup per CU by default (tools/estep_sweep.py)
-    int grid = grid_for(c, (c->n + 3) / 4, env_int("HGMM_LOGPROB_BPC", 1));
-    if (env_int("HGMM_LOGPROB_GRID", 0) > 0) grid = std::min(grid_for(c, (c->n + 3) / 4, 4), env_int("HGMM_LOGPROB_GRID", 0));
+    const bool have = (nv4 >= 1 && nv4 <= 3 && nv1 <= 2) || (nv4 == 4 && nv1 == 0) || (nv4 == 0 && (nv1 == 1 || nv1 == 2));
+    if (!have) return false;
+    // Grid: with no reduction and no exponential left, the store stream is all this kernel waits for, and unlike the
+    // E-step (issue-bound at one wave per SIMD, best at 3/4 of the CUs) it keeps gaining with more waves in flight:
+    // 0.545 / 0.566 / 0.559 / 0.536 / 0.520 / 0.516 ms at 128 / 192 / 256 / 512 / 768 / 1024 workgroups
+    // (tools/logprob_sweep.py, N = 1e6, J = 800) -- four workgroups per CU.
+    const int64_t groups = (c->n + 3) / 4;
+    int64_t g64 = (int64_t)c->cus * std::max(1, std::min(16, env_int("HGMM_LOGPROB_BPC", 4)));
+    if (env_int("HGMM_LOGPROB_GRID", 0) > 0) g64 = env_int("HGMM_LOGPROB_GRID", 0);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(g64, (groups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
     const float* X = c->x_aos.as<float>();
     const float* pk = c->f_pack.as<float>();
+    ProfScope prof(c, HGMM_K_FLAT_ESTEP);
 #define LOGP_R(A, B) flat_logprob_rows_pk_kernel<A, B><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, log_prob)
     if (nv4 == 3 && nv1 == 1) LOGP_R(3, 1);
     else if (nv4 == 3 && nv1 == 0) LOGP_R(3, 0);
@@ -1852,7 +1860,6 @@ static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argma
         return HGMM_OK;
     }
     if (!NORMALISE && log_resp && !lpn && !argmax) {                                        // estimate_log_prob: the raw table
-        ProfScope prof(c, HGMM_K_FLAT_ESTEP);
         if (launch_logprob_rows(c, nv4, nv1, log_resp)) {
             c->flat.last_kernel = 1;
             c->flat.idle_since_launch = false;

@@ -17,9 +17,19 @@ from test_bench_flow_cpu import FakeContext  # noqa: E402
 class Ctx(FakeContext):
     def comm_init(self, world, rank, uid):
         broken = sys.argv[-1]
-        if broken == "RCCL_BROKEN" or (broken == "RCCL_BROKEN_ON_RANK_1" and rank == 1):
+        if broken in ("RCCL_BROKEN", "RCCL_AND_IPC_BROKEN") or (broken == "RCCL_BROKEN_ON_RANK_1" and rank == 1):
             raise hgmm_amd.HgmmError("ncclCommInitRank failed (test)")
+        if broken == "RCCL_HANGS_ON_RANK_0":
+            if rank == 1:
+                raise hgmm_amd.HgmmError("ncclCommInitRank failed (test)")
+            import time
+            time.sleep(3600)                                  # the healthy rank waits for its peer inside the collective call
         super().comm_init(world, rank, uid)
+
+    def comm_init_ipc(self, world, rank, name):
+        if sys.argv[-1] == "RCCL_AND_IPC_BROKEN":
+            raise hgmm_amd.HgmmError("hipIpcOpenMemHandle failed (test)")
+        super().comm_init_ipc(world, rank, name)
 
 
 if "FAIL_RANK_1" in sys.argv[-1] and os.environ.get("RANK") == "1":

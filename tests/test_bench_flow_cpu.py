@@ -41,6 +41,9 @@ class FakeContext:
     def comm_init_host(self, world, rank, name):
         self.world, self.rank, self.hostcomm = world, rank, name
 
+    def comm_init_ipc(self, world, rank, name):
+        self.world, self.rank, self.ipc = world, rank, name
+
     def comm_destroy(self):
         pass
 
@@ -71,6 +74,7 @@ class FakeContext:
 
     def flat_train_begin(self, tol, mu, cov, w, cov_type, variant, lls_capacity):
         self.J = len(mu)
+        self.n_it = 0
 
     def flat_train_step(self, iters):
         self.n_it += iters
@@ -154,8 +158,12 @@ def test_bench_two_rank_flow():
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0 and "cold_frac" in d["roofline"]
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
     assert d["rank_consistency"]["identical_model_on_all_ranks"] is True
-    assert "workload" in d["config"] and "RCCL" in d["config"]["collective"]
+    assert "workload" in d["config"] and "RCCL" in d["config"]["collective"] and d["config"]["collective_requested"] == "auto"
     assert d["allreduce_us"] == 500.0 and d["timing"]["blocks"] >= 3 and d["timing"]["steps_per_block"] == 3
+    # --collective auto: the same joint fit once more over the one-shot peer exchange, beside the RCCL headline
+    px = d["peer_exchange"]
+    assert "peer exchange" in px["collective"] and px["value"] > 0 and px["identical_model_on_all_ranks"] is True
+    assert px["model_bitwise_equal_to_the_rccl_fit"] is True
     assert "torch" not in open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                             "bench.py")).read().split('"""', 2)[2].replace("torch.distributed.run", "")
 
@@ -198,23 +206,34 @@ def test_self_launch_reports_a_failing_rank():
 
 def test_ranks_of_an_external_launcher_fall_back_in_place_when_rccl_is_unavailable():
     """Started by something that is not bench.py's own launcher (torchrun in the driver's N > 1 runs): no restart is
-    possible, every rank switches to the host shared-memory all-reduce and the line is still produced."""
+    possible, every rank moves on to the next backend -- the one-shot peer exchange -- and the line is still produced."""
     r = _run_launcher(2, "plain", ["--skip", "RCCL_BROKEN"])
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0
-    assert "fallback" in d["config"] and "host shared memory" in d["config"]["collective"]
+    assert "rccl" in d["config"]["fallback"] and "peer exchange" in d["config"]["collective"]
+    assert "peer_exchange" not in d                           # the headline already ran on it
 
 
-def test_self_launch_retries_on_the_host_backend_when_rccl_is_unavailable():
-    r = _run_launcher(2, "self", ["--skip", "RCCL_BROKEN"])
+def test_fallback_chain_ends_on_the_host_backend():
+    """Neither RCCL nor the peer exchange: host shared memory, under bench.py's own launcher as under an external one."""
+    for mode in ("self", "plain"):
+        r = _run_launcher(2, mode, ["--skip", "RCCL_AND_IPC_BROKEN"])
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        assert "rccl" in d["config"]["fallback"] and "ipc" in d["config"]["fallback"]
+        assert "host shared memory" in d["config"]["collective"]
+
+
+def test_explicit_collective_is_used_alone():
+    r = _run_launcher(2, "plain", ["--collective", "ipc"])
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
-    assert len(lines) == 1, r.stdout
-    d = json.loads(lines[0])
-    assert "fallback" in d["config"] and "host shared memory" in d["config"]["collective"]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert "peer exchange" in d["config"]["collective"] and "fallback" not in d["config"] and "peer_exchange" not in d
 
 
 def test_partial_rccl_failure_is_agreed_on_collectively():
@@ -225,5 +244,18 @@ def test_partial_rccl_failure_is_agreed_on_collectively():
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert "fallback" in d["config"] and "host shared memory" in d["config"]["collective"]
+    assert "fallback" in d["config"] and "peer exchange" in d["config"]["collective"]
     assert d["rank_consistency"]["identical_model_on_all_ranks"] is True
+
+
+def test_a_hanging_backend_setup_times_out_and_falls_back():
+    """a rank that blocks inside the collective communicator set-up (its peer failed there) must not wait
+    for ever: the attempt is abandoned after HGMM_BENCH_ATTACH_TIMEOUT and the agreement round moves everybody on."""
+    os.environ["HGMM_BENCH_ATTACH_TIMEOUT"] = "3"
+    try:
+        r = _run_launcher(2, "plain", ["--skip", "RCCL_HANGS_ON_RANK_0"])
+    finally:
+        os.environ.pop("HGMM_BENCH_ATTACH_TIMEOUT", None)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert "rccl" in d["config"]["fallback"] and "peer exchange" in d["config"]["collective"]

@@ -833,6 +833,22 @@ def test_async_estep_and_device_scalar(ctx, bunny):
     assert abs(float(mean_a) - mean_b) < 1e-7 and abs(mean_a - mean_b) < 1e-7 and np.float32(mean_a) == np.float32(mean_b)
     assert np.array_equal(lr_a.get(), lr_b.get())
     assert abs(lpn_a.get().astype(np.float64).mean() - float(mean_a)) < 1e-5
+    # operators: the value takes part as a NumPy float32 scalar (what xp.mean of a float32 array is in the reference);
+    # non-numbers get Python's protocol instead of a TypeError, arrays take the array path
+    v32 = np.float32(float(mean_a))
+    assert (mean_a == None) is False and (mean_a != None) is True and (mean_a in [None, 1.0]) is False   # noqa: E711
+    assert mean_a == mean_a and mean_a in [None, mean_a] and not (mean_a < mean_a)
+    assert isinstance(mean_a - 1.0, np.float32) and mean_a - 1.0 == v32 - np.float32(1.0) and 2.0 * mean_a == v32 * np.float32(2.0)
+    assert abs(mean_a - (-np.inf)) == np.inf                                  # `change = lower_bound - prev`, gmm_impl.py:137-139
+    assert np.array_equal(mean_a * np.ones(3, np.float32), v32 * np.ones(3, np.float32))
+    assert np.array_equal(np.ones(3, np.float32) * mean_a, v32 * np.ones(3, np.float32))
+    dev3 = ctx.to_device(np.float32([1.0, 2.0, 3.0]))
+    for prod in (mean_a * dev3, dev3 * mean_a, dev3 + mean_a, mean_a - dev3):
+        assert isinstance(prod, hgmm_amd.DeviceArray)
+    assert np.array_equal(np.asarray(dev3 * mean_a), np.float32([1.0, 2.0, 3.0]) * v32)
+    assert np.array_equal(np.asarray(mean_a - dev3), v32 - np.float32([1.0, 2.0, 3.0]))
+    with pytest.raises(TypeError):
+        mean_a + "x"
     # many un-synchronised calls in a row wrap the staging ring (it synchronises before reusing a region)
     last = None
     for k in range(400):
@@ -888,7 +904,11 @@ def test_device_array_parameters_and_elementwise(ctx, bunny):
     row = np.float32([1, 2, 3])
     assert isinstance(da * row, np.ndarray) and np.array_equal(da * row, a * row)
     assert np.array_equal(da > 0.5, a > 0.5) and np.array_equal(da ** 2, a ** 2)
-    assert da.astype(np.float32) is da and da.astype(np.float64).dtype == np.float64
+    assert da.astype(np.float32, copy=False) is da and da.astype(np.float64).dtype == np.float64
+    dup = da.astype(np.float32)                                   # copy=True (NumPy's / CuPy's default): a fresh device array
+    assert isinstance(dup, DA) and dup is not da and dup.ptr.value != da.ptr.value and np.array_equal(np.asarray(dup), a)
+    with pytest.raises(TypeError):
+        da.fill(0)                                                # would act on a throw-away host copy
     assert da.sum() == a.sum() and np.array_equal(da[3], a[3]) and np.array_equal(da.T, a.T) and len(da) == 800
     # more small arrays alive at once than the arena has slabs, then released and taken again
     many = [da + float(k) for k in range(100)]

@@ -16,7 +16,7 @@ inv, mu, w, cov, lls, _ = ctx.flat_train(10, 0.0, mu0, cov0, w0, "diag", "W")
 alg = 12 * N + 4 * N * J + 28 * J
 cus = ctx.device_info()["compute_units"]
 cfgs = [("single-row kernel (round 3)", {"HGMM_LOGPROB_SINGLE_ROW": "1"})]
-for g in (128, 160, 176, 192, 208, 224, 256, 320, 384, 512, 768, 1024):
+for g in (192, 256, 512, 768, 1024, 1280, 1536, 2048, 3072, 4096):
     cfgs.append(("rows=4 grid=%d" % g, {"HGMM_LOGPROB_GRID": str(g)}))
 res = {k: [] for k, _ in cfgs}
 keys = ("HGMM_LOGPROB_SINGLE_ROW", "HGMM_LOGPROB_GRID", "HGMM_LOGPROB_BPC")
