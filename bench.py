@@ -792,7 +792,38 @@ def collective_world1_leg(ctx, args, init, base_it_per_s):
 
 
 # ------------------------------------------------------------------------------------------------
+class _StdoutGuard:
+    """stdout must carry ONE JSON line and nothing else -- and libraries print there (RCCL's version banner at the first
+    communicator, five lines through C stdio that surface when the process exits, i.e. BEHIND the JSON line).  While
+    the bench runs, file descriptor 1 points at stderr; restore() flushes C stdio into it and puts the real stdout back
+    for the one line."""
+
+    def __init__(self):
+        self.saved = None
+        try:
+            if sys.stdout.fileno() == 1:
+                sys.stdout.flush()
+                self.saved = os.dup(1)
+                os.dup2(2, 1)
+        except (OSError, ValueError, AttributeError):        # stdout replaced by an in-memory stream (tests)
+            self.saved = None
+
+    def restore(self):
+        if self.saved is None:
+            return
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        self.saved = None
+
+
 def rank_main(args):
+    guard = _StdoutGuard()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -961,8 +992,10 @@ def rank_main(args):
                 out["cpu_baseline"]["scope"] = "timed on rank 0's host cores after the joint fit (other ranks idle)"
         else:
             out["cpu_baseline"] = None
+        guard.restore()
         print(json.dumps(out))
         sys.stdout.flush()
+        guard = _StdoutGuard()                 # whatever the teardown prints goes to stderr again
     ctx.close()
     if not consistent:
         sys.exit(3)

@@ -711,9 +711,11 @@ class Context:
             None if lr is None else lr.ptr, None if lpn is None else lpn.ptr, None if am is None else am.ptr, C.byref(mean)))
         return mean.value, lr, lpn, am
 
-    def flat_log_prob(self, inv_std, mu, cov_type="diag"):
+    def flat_log_prob(self, inv_std, mu, cov_type="diag", out=None):
         J, mu, inv_std, _ = self._flat_args(mu, inv_std, np.ones(len(mu), np.float32), cov_type)
-        out = self.empty((self.num_points, J), np.float32)
+        if out is not None and (out.shape != (self.num_points, J) or out.dtype != np.float32):
+            raise ValueError("out must be a float32 DeviceArray of shape %s" % ((self.num_points, J),))
+        out = out if out is not None else self.empty((self.num_points, J), np.float32)
         self._check(self.lib.hgmm_flat_log_prob(self.h, COV_TYPES[cov_type], J, _ptr(mu), _ptr(inv_std), out.ptr))
         return out
 

@@ -306,6 +306,43 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// Store pacing.  The HBM write path of this chip delivers LESS the more stores are waiting for it: a grid that offers
+// the 3200-byte rows faster than memory drains them falls from ~6.0 to ~5.3 TB/s (tools/logprob_sweep.py: the raw-table
+// kernel, which has nothing to do but store, ran 0.60 ms at every grid from 128 to 4096 workgroups -- and 0.536 ms once
+// every wave idled ~1000 cycles behind each group of rows).  The E-step kernel had found the same sweet spot by
+// accident: at exactly 3/4 of the CUs its arithmetic happened to offer the rows at the drain rate -- at one core clock;
+// behind a memory-bound kernel or in an unwaited-for stream the clock differs and the optimum moved (estep_rows_grid).
+// So the rate is made explicit: every wave issues its i-th group of rows no earlier than t0 + i * period on the
+// constant-rate wall clock (100 MHz), period chosen on the host so that all waves together offer the target rate.
+// Enough waves are launched for the arithmetic to keep up at any clock; the clock then no longer matters.
+// ------------------------------------------------------------------------------------------
+struct StorePacer {
+    unsigned long long next;
+    unsigned period16, frac;           // period in 1/16 ticks of the wall clock; 0 = no pacing
+    // wave `gw` of `nw`: the waves' schedules are staggered evenly over one period -- started in phase, all of them would
+    // store at the same moments, a burst per period
+    __device__ __forceinline__ StorePacer(int p16, long long gw, long long nw) : next(0), period16((unsigned)p16), frac(0) {
+        if (period16) next = wall_clock64() + (unsigned long long)(((unsigned long long)period16 * (unsigned long long)gw / (unsigned long long)nw) >> 4);
+    }
+    // call right before a group's stores
+    __device__ __forceinline__ void wait() {
+        if (!period16) return;
+        unsigned long long now = wall_clock64();
+        while (now < next) {
+            __builtin_amdgcn_s_sleep(1);
+            now = wall_clock64();
+        }
+        // a wave that has fallen behind by more than a period (its arithmetic could not keep up: low clocks, a late
+        // start) is re-anchored instead of catching up in a burst -- bursts are what the write path punishes
+        const unsigned period = period16 >> 4;
+        if (now > next + period) next = now;
+        frac += period16;
+        next += frac >> 4;
+        frac &= 15u;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
 // materialising E-step, ROWS consecutive rows in flight per wave, components paired into float2.
 // No accumulators live in this kernel (parameters 7K + ROWS*K values), so the independent max / sum
 // reduction chains of several rows interleave inside ONE wave; that lets the kernel run with few
@@ -326,7 +363,7 @@ template <int NV4, int NV1, int ROWS, bool NT>
 __global__ __launch_bounds__(BLOCK) void flat_estep_rows_pk_kernel(
     const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int J, int Jpad,
     float* __restrict__ log_resp, float* __restrict__ lpn_out, int32_t* __restrict__ argmax_out,
-    double* __restrict__ lpn_partials, int allow_const_shift) {
+    double* __restrict__ lpn_partials, int allow_const_shift, int pace) {
     using L = Layout<NV4, NV1>;
     constexpr int K = L::K;
     constexpr int KP = 2 * NV4 + NV1 / 2;          // pairs
@@ -391,6 +428,7 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_rows_pk_kernel(
         cs -= m0;
     }
     const float eps_scale = __builtin_amdgcn_exp2f(-m0);
+    StorePacer pacer(pace, gw, nw);
     if (gw < ngroups) load_group(gw, x);
     for (int64_t g = gw; g < ngroups; g += nw) {
         float nx[ROWS][3];
@@ -459,6 +497,7 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_rows_pk_kernel(
         }
         float keep_lpn = 0.f;
         int keep_arg = 0;
+        pacer.wait();
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
             const int64_t row = g * ROWS + r;
@@ -538,10 +577,10 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_rows_pk_kernel(
 // then the same 16-byte non-temporal stores.  (Round 3 ran this call on the single-row kernel: 0.69 ms per
 // 10^6 x 800 table = 4.7 TB/s while e_step, which does strictly more work on the same bytes, ran at 5.9.)
 // ------------------------------------------------------------------------------------------
-template <int NV4, int NV1>
+template <int NV4, int NV1, bool LATE>
 __global__ __launch_bounds__(BLOCK) void flat_logprob_rows_pk_kernel(
     const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int J, int Jpad,
-    float* __restrict__ log_prob) {
+    float* __restrict__ log_prob, int pace) {
     using L = Layout<NV4, NV1>;
     constexpr int K = L::K;
     constexpr int KP = 2 * NV4 + NV1 / 2;          // pairs
@@ -584,46 +623,60 @@ __global__ __launch_bounds__(BLOCK) void flat_logprob_rows_pk_kernel(
             dst[r][0] = xp[0]; dst[r][1] = xp[1]; dst[r][2] = xp[2];
         }
     };
+    StorePacer pacer(pace, gw, nw);
     if (gw < ngroups) load_group(gw, x);
     for (int64_t g = gw; g < ngroups; g += nw) {
         float nx[ROWS][3];
         load_group((g + nw < ngroups) ? g + nw : g, nx);          // prefetch (scalar loads)
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            const int64_t row = g * ROWS + r;
+        f2 wl[ROWS][KP + 1];
+        float wls[ROWS];
+        auto compute = [&](int r) {
             const f2 X0 = f2{x[r][0], x[r][0]}, X1 = f2{x[r][1], x[r][1]}, X2 = f2{x[r][2], x[r][2]};
-            f2 wl[KP + 1];
 #pragma unroll
             for (int p = 0; p < KP; ++p) {
                 const f2 d0 = X0 - mu0[p], d1 = X1 - mu1[p], d2 = X2 - mu2[p];
                 f2 a = cc[p] - (d0 * g0[p]) * d0;
                 a = a - (d1 * g1[p]) * d1;
                 a = a - (d2 * g2[p]) * d2;
-                wl[p] = a;
+                wl[r][p] = a;
             }
-            float wls = NEG_INF;
+            wls[r] = NEG_INF;
             if (ODD) {
                 const float d0 = x[r][0] - mu0s, d1 = x[r][1] - mu1s, d2 = x[r][2] - mu2s;
                 float a = fmaf(-(d0 * g0s), d0, cs);
                 a = fmaf(-(d1 * g1s), d1, a);
                 a = fmaf(-(d2 * g2s), d2, a);
-                wls = a;
+                wls[r] = a;
             }
+        };
+        auto store = [&](int r) {
+            const int64_t row = g * ROWS + r;
             if (row < n) {                                          // wave-uniform
                 float* out = log_prob + row * (int64_t)J;
 #pragma unroll
                 for (int v = 0; v < NV4; ++v) {
                     const int jb = (v * 64 + lane) * 4;
-                    if (jb < J) store_f4<true>(out + jb, wl[2 * v].x, wl[2 * v].y, wl[2 * v + 1].x, wl[2 * v + 1].y);
+                    if (jb < J) store_f4<true>(out + jb, wl[r][2 * v].x, wl[r][2 * v].y, wl[r][2 * v + 1].x, wl[r][2 * v + 1].y);
                 }
 #pragma unroll
                 for (int v = 0; v < NV1; ++v) {
                     const int j = 256 * NV4 + v * 64 + lane;
                     const int k = 4 * NV4 + v;
-                    const float val = (ODD && k == K - 1) ? wls : ((k & 1) ? wl[k >> 1].y : wl[k >> 1].x);
+                    const float val = (ODD && k == K - 1) ? wls[r] : ((k & 1) ? wl[r][k >> 1].y : wl[r][k >> 1].x);
                     if (j < J) store_f1<true>(out + j, val);
                 }
             }
+        };
+        if (LATE) {             // the four rows' forms first, then one 12.8 KB run of stores (the E-step's pattern)
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) compute(r);
+            asm volatile("" ::: "memory");
+            pacer.wait();
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) store(r);
+        } else {
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) { compute(r); store(r); }
         }
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) { x[r][0] = nx[r][0]; x[r][1] = nx[r][1]; x[r][2] = nx[r][2]; }
@@ -1096,6 +1149,9 @@ __global__ __launch_bounds__(BLOCK) void flat_mstep_kernel(
             v[4 * NV4 + s] = (j < J) ? in[j] : fill;
         }
     };
+    // (Round 4, measured and dropped: two rows ahead instead of one -- three buffers in rotation, loop unrolled by three --
+    //  0.547 ms against 0.531; a StorePacer in front of every row load, 0.55 - 0.56 ms at every target rate.  Neither more
+    //  nor fewer loads in flight move the read side: profiles/r04/mstep_pace.log, mstep_prefetch2.log.)
     float cur[K], nxt[K];
     if (cnt > 0) load_row(base, cur);
     for (int64_t it = 0; it < cnt; ++it) {
@@ -1720,16 +1776,33 @@ static bool env_flag(const char* name, bool dflt) {
         }                                                                                      \
     } while (0)
 
+constexpr int ESTEP_TARGET_GBS = 6600;      // offered store rate of the paced N x J writers (materialising E-step, estimate_log_prob)
+
+// StorePacer period (1/16 ticks of the 100 MHz wall clock) per group of 4 rows: all `grid` x 4 waves together offer
+// `target_gbs` GB/s of J-float rows.  0 = no pacing.
+static int store_pace16(hgmm_ctx* c, int grid, int J, double target_gbs) {
+    if (target_gbs <= 0.0) return 0;
+    int khz = c->wall_khz;
+    if (khz <= 0) {
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
+        c->wall_khz = khz;
+    }
+    const double bytes_per_group = 4.0 * 4.0 * (double)J;
+    const double seconds = bytes_per_group * (double)grid * WAVES_PER_BLOCK / (target_gbs * 1e9);
+    const double p16 = seconds * (double)khz * 1e3 * 16.0;
+    return p16 < 1.0 ? 0 : (p16 > 2e9 ? 2000000000 : (int)(p16 + 0.5));
+}
+
 // the 4-rows-per-wave materialising kernel for one (layout, grid, log-sum-exp variant); false: layout not instantiated
 static bool launch_estep_rows(hgmm_ctx* c, int nv4, int nv1, int grid_r, bool cshift, float* log_resp, float* lpn,
-                              int32_t* argmax) {
+                              int32_t* argmax, int pace) {
     const FlatState& f = c->flat;
     const float* X = c->x_aos.as<float>();
     const float* pk = c->f_pack.as<float>();
     double* lp = c->f_lpn_partials.as<double>();
 #define ESTEP_R(A, B)                                                                              \
     flat_estep_rows_pk_kernel<A, B, 4, true><<<grid_r, BLOCK, 0, c->stream>>>(                      \
-        X, pk, c->n, f.J, f.Jpad, log_resp, lpn, argmax, lp, cshift ? 1 : 0)
+        X, pk, c->n, f.J, f.Jpad, log_resp, lpn, argmax, lp, cshift ? 1 : 0, pace)
     if (nv4 == 3 && nv1 == 1) ESTEP_R(3, 1);
     else if (nv4 == 3 && nv1 == 0) ESTEP_R(3, 0);
     else if (nv4 == 3 && nv1 == 2) ESTEP_R(3, 2);
@@ -1753,18 +1826,23 @@ static bool launch_logprob_rows(hgmm_ctx* c, int nv4, int nv1, float* log_prob) 
     if (env_flag("HGMM_LOGPROB_SINGLE_ROW", false)) return false;
     const bool have = (nv4 >= 1 && nv4 <= 3 && nv1 <= 2) || (nv4 == 4 && nv1 == 0) || (nv4 == 0 && (nv1 == 1 || nv1 == 2));
     if (!have) return false;
-    // Grid: with no reduction and no exponential left, the store stream is all this kernel waits for, and unlike the
-    // E-step (issue-bound at one wave per SIMD, best at 3/4 of the CUs) it keeps gaining with more waves in flight:
-    // 0.545 / 0.566 / 0.559 / 0.536 / 0.520 / 0.516 ms at 128 / 192 / 256 / 512 / 768 / 1024 workgroups
-    // (tools/logprob_sweep.py, N = 1e6, J = 800) -- four workgroups per CU.
+    // Grid: with no reduction and no exponential left, the store stream is all this kernel waits for.  Un-paced it ran
+    // 0.60 ms at every grid from 128 to 4096 workgroups on the box where the E-step took 0.54 (tools/logprob_sweep.py):
+    // the write path was over-subscribed.  Paced like the E-step (StorePacer), two workgroups per CU: 0.506 ms.
     const int64_t groups = (c->n + 3) / 4;
-    int64_t g64 = (int64_t)c->cus * std::max(1, std::min(16, env_int("HGMM_LOGPROB_BPC", 4)));
+    int64_t g64 = (int64_t)c->cus * std::max(1, std::min(2, env_int("HGMM_LOGPROB_BPC", 2)));
     if (env_int("HGMM_LOGPROB_GRID", 0) > 0) g64 = env_int("HGMM_LOGPROB_GRID", 0);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(g64, (groups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
     const float* X = c->x_aos.as<float>();
     const float* pk = c->f_pack.as<float>();
     ProfScope prof(c, HGMM_K_FLAT_ESTEP);
-#define LOGP_R(A, B) flat_logprob_rows_pk_kernel<A, B><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, log_prob)
+    const bool late = env_flag("HGMM_LOGPROB_LATE", true);
+    const int pace = store_pace16(c, grid, f.J, (double)env_int("HGMM_LOGPROB_TARGET_GBS", ESTEP_TARGET_GBS));
+#define LOGP_R(A, B)                                                                                                 \
+    do {                                                                                                             \
+        if (late) flat_logprob_rows_pk_kernel<A, B, true><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, log_prob, pace);  \
+        else flat_logprob_rows_pk_kernel<A, B, false><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, log_prob, pace);      \
+    } while (0)
     if (nv4 == 3 && nv1 == 1) LOGP_R(3, 1);
     else if (nv4 == 3 && nv1 == 0) LOGP_R(3, 0);
     else if (nv4 == 3 && nv1 == 2) LOGP_R(3, 2);
@@ -1871,11 +1949,19 @@ static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argma
     const int rows = (NORMALISE && log_resp) ? env_int("HGMM_ESTEP_ROWS", 4) : 1;
     if (rows > 1) {
         const bool cshift = env_flag("HGMM_ESTEP_CS", true) && !argmax;
-        const int grid_r = estep_rows_grid(c, cshift);
+        // Paced stores (StorePacer): two workgroups per CU -- all resident at once, which the pacer's period assumes, and
+        // enough waves for the arithmetic to keep up at any core clock -- offering the rows at ESTEP_TARGET_GBS.  The
+        // write path takes an evenly paced, phase-staggered 6.8 TB/s of these rows in every call pattern and collapses to
+        // ~5.3 at 7.0 - 7.4 (tools/pace_sweep.py, profiles/r04/pace_sweep.log): the default stays 3 % below the knee.  HGMM_ESTEP_TARGET_GBS=0: the un-paced
+        // launch with round 3's grid policy (estep_rows_grid).
+        const double target = (double)env_int("HGMM_ESTEP_TARGET_GBS", ESTEP_TARGET_GBS);
+        const int grid_r = target > 0.0 ? grid_for(c, (c->n + 3) / 4, std::min(2, env_int("HGMM_ESTEP_BPC", 2)))
+                                        : estep_rows_grid(c, cshift);
+        const int pace = store_pace16(c, grid_r, f.J, target);
         c->flat.last_kernel = 1;
         c->flat.idle_since_launch = false;
         ProfScope prof(c, HGMM_K_FLAT_ESTEP);
-        if (launch_estep_rows(c, nv4, nv1, grid_r, cshift, log_resp, lpn, argmax)) {
+        if (launch_estep_rows(c, nv4, nv1, grid_r, cshift, log_resp, lpn, argmax, pace)) {
             *grid_out = grid_r;
             HGMM_HIP(c, hipGetLastError());
             return HGMM_OK;

@@ -57,6 +57,7 @@ struct TreeState {
 struct hgmm_ctx {
     int device = 0;
     int cus = 256;
+    int wall_khz = 0;                 // rate of wall_clock64() on this device (StorePacer, flat_kernels.hip)
     hipStream_t stream = nullptr;
     std::string err;
 

@@ -15,29 +15,33 @@ ctx.set_points(X)
 inv, mu, w, cov, lls, _ = ctx.flat_train(10, 0.0, mu0, cov0, w0, "diag", "W")
 alg = 12 * N + 4 * N * J + 28 * J
 cus = ctx.device_info()["compute_units"]
-cfgs = [("single-row kernel (round 3)", {"HGMM_LOGPROB_SINGLE_ROW": "1"})]
-for g in (192, 256, 512, 768, 1024, 1280, 1536, 2048, 3072, 4096):
-    cfgs.append(("rows=4 grid=%d" % g, {"HGMM_LOGPROB_GRID": str(g)}))
+lr = ctx.empty((N, J), np.float32)
+cfgs = [("e_step (blocking calls, its own grid policy)", None),
+        ("single-row kernel (round 3)", {"HGMM_LOGPROB_SINGLE_ROW": "1"})]
+for pace in (0, 1, 2, 3, 4):
+    for g in (96, 128, 192, 256, 512):
+        cfgs.append(("rows=4 pace=%d grid=%d" % (pace, g), {"HGMM_LOGPROB_GRID": str(g), "HGMM_LOGPROB_PACE": str(pace)}))
 res = {k: [] for k, _ in cfgs}
-keys = ("HGMM_LOGPROB_SINGLE_ROW", "HGMM_LOGPROB_GRID", "HGMM_LOGPROB_BPC")
-out = None
+keys = ("HGMM_LOGPROB_SINGLE_ROW", "HGMM_LOGPROB_GRID", "HGMM_LOGPROB_BPC", "HGMM_LOGPROB_LATE", "HGMM_LOGPROB_PACE")
 for rnd in range(3):
     for name, env in cfgs:
         for k in keys:
             os.environ.pop(k, None)
-        os.environ.update(env)
+        if env is None:
+            call = lambda: ctx.flat_estep(inv, mu, w, "diag", "W", out=lr)
+        else:
+            os.environ.update(env)
+            call = lambda: ctx.flat_log_prob(inv, mu, "diag", out=lr)
         for _ in range(3):
-            out = None
-            out = ctx.flat_log_prob(inv, mu, "diag")
+            call()
         ctx.profile_reset(); ctx.profile_enable(True)
         for _ in range(12):
-            out = None
-            out = ctx.flat_log_prob(inv, mu, "diag")
+            call()
         ctx.profile_enable(False)
         ms, n = ctx.profile_get("flat_estep")
         res[name].append(ms / n)
 print("estimate_log_prob, N = %d, J = %d, %d CUs; algorithmic bytes %.4f GB" % (N, J, cus, alg / 1e9))
 for name, _ in cfgs:
     v = np.array(res[name])
-    print("%-28s median %.4f ms  (%.0f GB/s, %.1f%% of 8 TB/s)   rounds %s"
+    print("%-46s median %.4f ms  (%.0f GB/s, %.1f%% of 8 TB/s)   rounds %s"
           % (name, np.median(v), alg / np.median(v) / 1e6, alg / np.median(v) / 1e6 / 80, np.round(v, 4)))
