@@ -16,19 +16,38 @@ from ._native import Context, DeviceArray, default_context
 
 
 class DevicePoints:
-    """A point cloud resident in HBM on one context (what ``cupy.asarray(X)`` was to the
-    reference, gmm_waymo/src/gmm.py:73).  Pass it wherever the API takes ``X``."""
+    """A point cloud resident in HBM on one context (what ``cupy.asarray(X)`` was to the reference,
+    gmm_waymo/src/gmm.py:73).  Pass it wherever the API takes ``X``.  Any number of them may be alive on a context
+    (hgmm_points_*: each owns its device copy; using one binds it -- a pointer swap, nothing is uploaded again)."""
 
     def __init__(self, X, ctx: Context | None = None):
         self.ctx = ctx or default_context()
         X = np.asarray(X)
+        if X.ndim != 2 or X.shape[1] != 3:
+            raise ValueError("points must have shape [N,3], got %s" % (X.shape,))
         self.shape = X.shape
         self.dtype = np.dtype(np.float32)
-        self.ctx.set_points(X)
-        self.ctx._points_owner = self
+        self._h = self.ctx.points_create(X)
 
     def __len__(self):
         return self.shape[0]
+
+    def bind(self):
+        if self._h is None:
+            raise RuntimeError("this DevicePoints has been freed")
+        self.ctx.points_bind(self._h)
+        return self.ctx
+
+    def free(self):
+        if self._h is not None:
+            h, self._h = self._h, None
+            self.ctx.points_destroy(h)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def asarray(X, ctx: Context | None = None):
@@ -36,12 +55,13 @@ def asarray(X, ctx: Context | None = None):
 
 
 def _ctx_for(X) -> Context:
-    """Returns the context holding X, uploading host arrays first."""
+    """Returns the context holding X as its bound cloud: resident clouds are bound (nothing moves), host arrays are
+    uploaded into the context's own cloud (like handing NumPy to the reference: a copy per call)."""
     if isinstance(X, DevicePoints):
-        if getattr(X.ctx, "_points_owner", None) is not X:
-            raise RuntimeError("this DevicePoints was superseded by a later upload on its context")
-        return X.ctx
-    return DevicePoints(X).ctx
+        return X.bind()
+    ctx = default_context()
+    ctx.set_points(X)
+    return ctx
 
 
 def _host(a):
@@ -96,5 +116,9 @@ def train_gmm(X, max_iter, tol, means, covariances, weights, cov_type, variant):
 
 
 def predict(X, inv_cov, means, weights, cov_type, variant):
+    """Array module in = array module out (``xp.argmax``, gmm_impl.py:147-155): a resident cloud gives the labels as a
+    DeviceArray (int32 in HBM; nothing is downloaded, nothing waits -- the reference's caller does the
+    ``cupy.asnumpy``, run_gmm_static.py:49), a host array gives NumPy int64 like the reference under NumPy."""
     ctx = _ctx_for(X)
-    return ctx.flat_predict(_param(inv_cov), _param(means), _param(weights), cov_type, variant).get().astype(np.int64)
+    lab = ctx.flat_predict(_param(inv_cov), _param(means), _param(weights), cov_type, variant)
+    return lab if isinstance(X, DevicePoints) else lab.get().astype(np.int64)

@@ -72,6 +72,11 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_set_points_f32", [ctx, _vp, C.c_int64])
         _sig(lib, "hgmm_set_points_f64", [ctx, _vp, C.c_int64])
         _sig(lib, "hgmm_num_points", [ctx], C.c_int64)
+        _sig(lib, "hgmm_points_create_f32", [ctx, _vp, C.c_int64, C.POINTER(_vp)])
+        _sig(lib, "hgmm_points_create_f64", [ctx, _vp, C.c_int64, C.POINTER(_vp)])
+        _sig(lib, "hgmm_points_bind", [ctx, _vp])
+        _sig(lib, "hgmm_points_destroy", [ctx, _vp])
+        _sig(lib, "hgmm_points_count", [_vp], C.c_int64)
         _sig(lib, "hgmm_flat_estep", [ctx, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _f64p])
         _sig(lib, "hgmm_flat_estep_async", [ctx, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
         _sig(lib, "hgmm_flat_estep_dev", [ctx, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
@@ -475,7 +480,6 @@ class Context:
                             % (device_id, rc, msg.decode() if msg else "?"))
         self.h = h
         self.device_id = device_id
-        self._points_owner = None
         self.nranks, self.rank = 1, 0
         self._arena = None                    # (pointer, free slab indices) of the small-array pool
         self._freed = {}                      # size -> pointers of dead arrays kept for reuse (_free)
@@ -640,14 +644,38 @@ class Context:
             Xc = np.ascontiguousarray(X, dtype=np.float32)
             self._check(self.lib.hgmm_set_points_f32(self.h, _ptr(Xc), Xc.shape[0]))
         self.n = Xc.shape[0]
-        # every upload replaces the resident cloud: a DevicePoints handle taken before it is stale
-        # from now on (DevicePoints.__init__ claims ownership again right after its own upload)
-        self._points_owner = None
+        # (this is the context's OWN cloud and becomes the bound one; clouds held through points_create handles --
+        #  DevicePoints -- stay resident and are re-bound when they are used)
         return self
 
     @property
     def num_points(self):
         return int(self.lib.hgmm_num_points(self.h))
+
+    # several resident clouds (hgmm_points_*): a handle owns its device copy, bind is a pointer swap
+    def points_create(self, X):
+        """Upload [N,3] points into a handle of their own (float64 input keeps full precision for the HGMM / KMeans
+        kernels).  -> opaque handle for points_bind / points_destroy; the context's bound cloud does not change."""
+        X = np.asarray(X)
+        if X.ndim != 2 or X.shape[1] != 3:
+            raise ValueError("points must have shape [N,3], got %s" % (X.shape,))
+        h = _vp()
+        if X.dtype == np.float64:
+            Xc = np.ascontiguousarray(X)
+            self._check(self.lib.hgmm_points_create_f64(self.h, _ptr(Xc), Xc.shape[0], C.byref(h)))
+        else:
+            Xc = np.ascontiguousarray(X, dtype=np.float32)
+            self._check(self.lib.hgmm_points_create_f32(self.h, _ptr(Xc), Xc.shape[0], C.byref(h)))
+        return h
+
+    def points_bind(self, handle):
+        """Every following call works on this cloud (None: the cloud of the last set_points)."""
+        self._check(self.lib.hgmm_points_bind(self.h, handle))
+        self.n = self.num_points
+
+    def points_destroy(self, handle):
+        if getattr(self, "h", None) and handle:
+            self._check(self.lib.hgmm_points_destroy(self.h, handle))
 
     # -- flat EM ----------------------------------------------------------------------
     @staticmethod

@@ -510,7 +510,8 @@ extern "C" int hgmm_destroy(hgmm_ctx* c) {
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     hostcomm_close(c);
     ipc_close(c);
-    DevBuf* bufs[] = {&c->x_aos, &c->x_soa64, &c->f_block, &c->f_pack,
+    // (x_aos / x_soa64 are views; handles a caller still holds are the caller's to destroy -- before the context)
+    DevBuf* bufs[] = {&c->own_points.x_aos, &c->own_points.x_soa64, &c->f_block, &c->f_pack,
                       &c->f_partials, &c->f_lpn_partials, &c->f_stats, &c->f_lls, &c->f_ctl, &c->f_hint,
                       &c->scratch, &c->t_pi, &c->t_mu, &c->t_cov, &c->t_prep, &c->t_cplx, &c->t_mom,
                       &c->t_parent, &c->t_current, &c->t_perm, &c->t_seg, &c->t_chunks, &c->t_partials,
@@ -620,45 +621,122 @@ extern "C" int hgmm_d2d(hgmm_ctx* c, void* dev_dst, const void* dev_src, size_t 
 
 extern "C" int64_t hgmm_num_points(const hgmm_ctx* c) { return c ? c->n : 0; }
 
-static int upload_common(hgmm_ctx* c, int64_t n) {
-    if (n <= 0) return fail(c, HGMM_ERR_ARG, "number of points must be positive");
-    HGMM_HIP(c, hipSetDevice(c->device));
-    c->n = n;
-    c->n_pad = (n + 255) / 256 * 256;
+// the cloud `p` becomes the one every kernel of the context works on
+static void bind_points(hgmm_ctx* c, hgmm_points* p) {
+    c->bound = p;
+    c->x_aos = p ? p->x_aos : DevBuf();
+    c->x_soa64 = p ? p->x_soa64 : DevBuf();
+    c->n = p ? p->n : 0;
+    c->n_pad = p ? p->n_pad : 0;
+    c->have_f32 = c->have_f64 = p != nullptr && p->n > 0;
     c->flat.active = false;
     c->tree.nodes_ready = false;
     c->km_labels_n = -1;              // labels / distances of the previous cloud are void
-    HGMM_TRY(ensure(c, c->x_aos, sizeof(float) * 3 * (size_t)n));
-    HGMM_TRY(ensure(c, c->x_soa64, sizeof(double) * 3 * (size_t)c->n_pad));
+}
+
+static int points_alloc(hgmm_ctx* c, hgmm_points* p, int64_t n) {
+    if (n <= 0) return fail(c, HGMM_ERR_ARG, "number of points must be positive");
+    HGMM_HIP(c, hipSetDevice(c->device));
+    p->ctx = c;
+    p->n = n;
+    p->n_pad = (n + 255) / 256 * 256;
+    HGMM_TRY(ensure(c, p->x_aos, sizeof(float) * 3 * (size_t)n));
+    HGMM_TRY(ensure(c, p->x_soa64, sizeof(double) * 3 * (size_t)p->n_pad));
+    return HGMM_OK;
+}
+
+static int points_upload_f32(hgmm_ctx* c, hgmm_points* p, const float* xyz, int64_t n) {
+    HGMM_TRY(points_alloc(c, p, n));
+    HGMM_HIP(c, hipMemcpyAsync(p->x_aos.p, xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    aos_to_soa64_f32<<<(unsigned)((p->n_pad + 255) / 256), 256, 0, c->stream>>>(
+        p->x_aos.as<float>(), n, p->n_pad, p->x_soa64.as<double>());
+    HGMM_HIP(c, hipGetLastError());
+    HGMM_HIP(c, ctx_stream_sync(c));
+    return HGMM_OK;
+}
+
+static int points_upload_f64(hgmm_ctx* c, hgmm_points* p, const double* xyz, int64_t n) {
+    HGMM_TRY(points_alloc(c, p, n));
+    HGMM_TRY(ensure(c, c->scratch, sizeof(double) * 3 * (size_t)n));
+    HGMM_HIP(c, hipMemcpyAsync(c->scratch.p, xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    aos_to_soa64_f64<<<(unsigned)((p->n_pad + 255) / 256), 256, 0, c->stream>>>(
+        c->scratch.as<double>(), n, p->n_pad, p->x_soa64.as<double>());
+    f64_to_f32<<<(unsigned)((3 * n + 255) / 256), 256, 0, c->stream>>>(c->scratch.as<double>(), 3 * n,
+                                                                      p->x_aos.as<float>());
+    HGMM_HIP(c, hipGetLastError());
+    HGMM_HIP(c, ctx_stream_sync(c));
     return HGMM_OK;
 }
 
 extern "C" int hgmm_set_points_f32(hgmm_ctx* c, const float* xyz, int64_t n) {
     if (!c || !xyz) return c ? fail(c, HGMM_ERR_ARG, "xyz is NULL") : HGMM_ERR_ARG;
-    HGMM_TRY(upload_common(c, n));
-    HGMM_HIP(c, hipMemcpyAsync(c->x_aos.p, xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    aos_to_soa64_f32<<<(unsigned)((c->n_pad + 255) / 256), 256, 0, c->stream>>>(
-        c->x_aos.as<float>(), n, c->n_pad, c->x_soa64.as<double>());
-    HGMM_HIP(c, hipGetLastError());
-    HGMM_HIP(c, ctx_stream_sync(c));
-    c->have_f32 = c->have_f64 = true;
+    bind_points(c, nullptr);                       // (a failed upload leaves nothing bound)
+    HGMM_TRY(points_upload_f32(c, &c->own_points, xyz, n));
+    bind_points(c, &c->own_points);
     return HGMM_OK;
 }
 
 extern "C" int hgmm_set_points_f64(hgmm_ctx* c, const double* xyz, int64_t n) {
     if (!c || !xyz) return c ? fail(c, HGMM_ERR_ARG, "xyz is NULL") : HGMM_ERR_ARG;
-    HGMM_TRY(upload_common(c, n));
-    HGMM_TRY(ensure(c, c->scratch, sizeof(double) * 3 * (size_t)n));
-    HGMM_HIP(c, hipMemcpyAsync(c->scratch.p, xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    aos_to_soa64_f64<<<(unsigned)((c->n_pad + 255) / 256), 256, 0, c->stream>>>(
-        c->scratch.as<double>(), n, c->n_pad, c->x_soa64.as<double>());
-    f64_to_f32<<<(unsigned)((3 * n + 255) / 256), 256, 0, c->stream>>>(c->scratch.as<double>(), 3 * n,
-                                                                      c->x_aos.as<float>());
-    HGMM_HIP(c, hipGetLastError());
-    HGMM_HIP(c, ctx_stream_sync(c));
-    c->have_f32 = c->have_f64 = true;
+    bind_points(c, nullptr);
+    HGMM_TRY(points_upload_f64(c, &c->own_points, xyz, n));
+    bind_points(c, &c->own_points);
     return HGMM_OK;
 }
+
+extern "C" int hgmm_points_create_f32(hgmm_ctx* c, const float* xyz, int64_t n, hgmm_points** out) {
+    if (!c || !xyz || !out) return c ? fail(c, HGMM_ERR_ARG, "hgmm_points_create: NULL argument") : HGMM_ERR_ARG;
+    *out = nullptr;
+    hgmm_points* p = new hgmm_points();
+    const int rc = points_upload_f32(c, p, xyz, n);
+    if (rc != HGMM_OK) {
+        if (p->x_aos.p) (void)hipFree(p->x_aos.p);
+        if (p->x_soa64.p) (void)hipFree(p->x_soa64.p);
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_points_create_f64(hgmm_ctx* c, const double* xyz, int64_t n, hgmm_points** out) {
+    if (!c || !xyz || !out) return c ? fail(c, HGMM_ERR_ARG, "hgmm_points_create: NULL argument") : HGMM_ERR_ARG;
+    *out = nullptr;
+    hgmm_points* p = new hgmm_points();
+    const int rc = points_upload_f64(c, p, xyz, n);
+    if (rc != HGMM_OK) {
+        if (p->x_aos.p) (void)hipFree(p->x_aos.p);
+        if (p->x_soa64.p) (void)hipFree(p->x_soa64.p);
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_points_bind(hgmm_ctx* c, hgmm_points* p) {
+    if (!c) return HGMM_ERR_ARG;
+    if (!p) p = c->own_points.n > 0 ? &c->own_points : nullptr;      // NULL: back to the cloud of hgmm_set_points_*
+    if (p && p->ctx != c) return fail(c, HGMM_ERR_ARG, "hgmm_points_bind: the cloud belongs to another context");
+    if (p == c->bound) return HGMM_OK;             // (kernels already enqueued keep the pointers they were launched with)
+    bind_points(c, p);
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_points_destroy(hgmm_ctx* c, hgmm_points* p) {
+    if (!c) return HGMM_ERR_ARG;
+    if (!p) return HGMM_OK;
+    if (p->ctx != c || p == &c->own_points) return fail(c, HGMM_ERR_ARG, "hgmm_points_destroy: not a cloud created on this context");
+    if (c->bound == p) bind_points(c, nullptr);
+    HGMM_HIP(c, hipSetDevice(c->device));
+    HGMM_HIP(c, ctx_stream_sync(c));               // kernels that read it may still be running
+    if (p->x_aos.p) HGMM_HIP(c, hipFree(p->x_aos.p));
+    if (p->x_soa64.p) HGMM_HIP(c, hipFree(p->x_soa64.p));
+    delete p;
+    return HGMM_OK;
+}
+
+extern "C" int64_t hgmm_points_count(const hgmm_points* p) { return p ? p->n : 0; }
 
 // ---- RCCL -----------------------------------------------------------------------------------
 extern "C" int hgmm_comm_unique_id(void* id128_out) {

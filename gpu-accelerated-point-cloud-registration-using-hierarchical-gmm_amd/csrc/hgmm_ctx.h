@@ -54,6 +54,14 @@ struct TreeState {
 
 }  // namespace hgmm
 
+// A point cloud resident in HBM that outlives the calls made on it (hgmm_points_create_*): the float32 row-major copy the
+// flat EM reads and the float64 structure-of-arrays copy of the HGMM / KMeans kernels.  Any number per context.
+struct hgmm_points {
+    hgmm_ctx* ctx = nullptr;
+    int64_t n = 0, n_pad = 0;
+    hgmm::DevBuf x_aos, x_soa64;
+};
+
 struct hgmm_ctx {
     int device = 0;
     int cus = 256;
@@ -63,8 +71,12 @@ struct hgmm_ctx {
 
     // ---- points -----------------------------------------------------------------
     int64_t n = 0;                    // local points
+    // x_aos / x_soa64 are VIEWS of the cloud the kernels work on: the context's own one (own_points, hgmm_set_points_*) or
+    // a caller-held handle (hgmm_points_bind); the memory belongs to whoever `bound` names
     hgmm::DevBuf x_aos;               // float [n,3]  (flat EM; wave-uniform scalar loads)
     hgmm::DevBuf x_soa64;             // double [3][n_pad] (HGMM; lanes across points)
+    hgmm_points own_points;           // the one-cloud shortcut's storage
+    hgmm_points* bound = nullptr;     // nullptr: nothing resident yet
     bool have_f32 = false, have_f64 = false;
     int64_t n_pad = 0;
 

@@ -15,7 +15,7 @@ import warnings
 import numpy as np
 
 from . import gmm_impl
-from .gmm_impl import train_gmm, init_gmm_params, timer, predict, asarray  # noqa: F401
+from .gmm_impl import train_gmm, init_gmm_params, timer, predict, asarray, DevicePoints  # noqa: F401
 
 
 class Feature(abc.ABC):
@@ -55,9 +55,16 @@ class GMM_GPU_Base:
     def fit(self, X, init=None):
         """``init`` = optional explicit ``(means, weights, covs)`` (the reference always draws
         them with the host RNG; tests and benchmarks pass them in)."""
-        X = np.asarray(X)
-        means, weights, covs = init if init is not None else self._init_params(X)
-        dev_X = asarray(X.astype(np.float32))
+        if isinstance(X, DevicePoints):                   # already resident (hgmm_amd.asarray): no upload
+            if init is None:
+                raise TypeError("fit(DevicePoints) needs init=(means, weights, covs): the reference's initialiser "
+                                "samples from the HOST array (gmm_impl.py:26-41)")
+            means, weights, covs = init
+            dev_X = X
+        else:
+            X = np.asarray(X)
+            means, weights, covs = init if init is not None else self._init_params(X)
+            dev_X = asarray(X.astype(np.float32))
         with timer(self._label):
             inv, mu, w, cov, lls = train_gmm(dev_X, self.max_iter, self.tol,
                                              np.asarray(means, np.float32), np.asarray(covs, np.float32),
@@ -69,7 +76,11 @@ class GMM_GPU_Base:
         return self
 
     def predict(self, X):
-        X = np.asarray(X).astype(np.float32)
+        """Host array in -> NumPy int64 labels; a resident cloud (DevicePoints) in -> the labels as a DeviceArray,
+        nothing downloaded (the reference returns the CuPy array and its caller does ``cupy.asnumpy``,
+        run_gmm_waymo_gpu.py:52-55)."""
+        if not isinstance(X, DevicePoints):
+            X = np.asarray(X).astype(np.float32)
         return predict(X, self.inv_covs, self.means_, self.weights_, cov_type=self.cov_type)
 
 

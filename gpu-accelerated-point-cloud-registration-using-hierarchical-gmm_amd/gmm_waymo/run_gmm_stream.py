@@ -6,11 +6,13 @@ per-frame labels and the frames/second the reference plots in its FPS chart (REA
     python -m hgmm_amd.gmm_waymo.run_gmm_stream frame1.pcd frame2.pcd ... [--components 50]
 """
 import argparse
+import collections
 import time
 
 import numpy as np
 
 from .gmm import GMM_GPU
+from .gmm_impl import asarray
 from ..pointcloud_io import read_point_cloud, voxel_down_sample
 
 
@@ -23,6 +25,9 @@ def run_stream(frames, n_components=50, max_iter=50, cov_type='spherical', fit_e
     gmm.init()
     gmm._clf._verbose = verbose
     labels, fit_s, models = [], [], []
+    # every frame is uploaded ONCE and stays resident (like the reference's CuPy frames, waymoutils.py: the H2D copy per
+    # frame) for the refit and the predict that use it; the last `fit_every` frames are kept in HBM
+    resident = collections.deque(maxlen=max(int(fit_every), 1))
     np.random.seed(seed)
     t0 = time.perf_counter()
     n = 0
@@ -30,11 +35,15 @@ def run_stream(frames, n_components=50, max_iter=50, cov_type='spherical', fit_e
         pts = np.asarray(pts)
         if voxel_size:
             pts = voxel_down_sample(pts, voxel_size)
+        dev = asarray(pts.astype(np.float32))
+        resident.append(dev)
         if i % fit_every == 0:
             t1 = time.perf_counter()
-            models.append(tuple(np.array(a) for a in gmm.compute(pts)))
+            clf = gmm._clf
+            clf.fit(dev, init=clf._init_params(pts))               # (the initialiser samples from the host array)
+            models.append(tuple(np.array(a) for a in (clf.means_, clf.weights_, clf.covariances_, clf.inv_covs)))
             fit_s.append(time.perf_counter() - t1)
-        labels.append(gmm.predict(pts))
+        labels.append(np.asarray(gmm.predict(dev)).astype(np.int64))    # = cupy.asnumpy(gmm_idxs), run_gmm_waymo_gpu.py:55
         n += 1
     dt = time.perf_counter() - t0
     return {"labels": labels, "fps": n / dt if dt > 0 else float("inf"), "fit_s": fit_s, "frames": n,

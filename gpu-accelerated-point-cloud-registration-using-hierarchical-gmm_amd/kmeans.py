@@ -164,8 +164,7 @@ class KMeans:
         else:
             mean, var, Xc = column_mean_var(X)
         tol_abs = 0.0 if self.tol == 0 else float(np.mean(var) * self.tol)
-        ctx.set_points(Xc)
-        ctx._points_owner = None                      # supersedes any DevicePoints on this context
+        ctx.set_points(Xc)                            # (the context's own cloud; DevicePoints handles stay valid)
         if isinstance(self.init, str):
             rs = _random_state(self.random_state)
             self.init_indices_, centres = self._seed(ctx, n, rs)

@@ -110,6 +110,18 @@ int hgmm_elementwise_f32(hgmm_ctx* ctx, int op, int64_t n, const float* dev_a, c
 int hgmm_set_points_f32(hgmm_ctx* ctx, const float* xyz, int64_t n);
 int hgmm_set_points_f64(hgmm_ctx* ctx, const double* xyz, int64_t n);
 int64_t hgmm_num_points(const hgmm_ctx* ctx);
+/* Several resident clouds per context -- what any number of `cupy.asarray(frame)` arrays are to the reference (the H2D
+ * copy of every frame in gmm_waymo/src/waymoutils.py, `dev_X` in gmm.py:73): a handle owns its device copy (float32
+ * rows + float64 structure of arrays, like hgmm_set_points_*), hgmm_points_bind makes it the cloud every following
+ * call of the context works on -- a pointer swap: nothing is copied, nothing waits, kernels already enqueued keep the
+ * cloud they were launched on.  bind(ctx, NULL) goes back to the cloud of hgmm_set_points_* (the one-cloud shortcut,
+ * which stays).  Destroying the bound handle leaves nothing bound.  Handles must be destroyed before their context. */
+typedef struct hgmm_points hgmm_points;
+int hgmm_points_create_f32(hgmm_ctx* ctx, const float* xyz, int64_t n, hgmm_points** out);
+int hgmm_points_create_f64(hgmm_ctx* ctx, const double* xyz, int64_t n, hgmm_points** out);
+int hgmm_points_bind(hgmm_ctx* ctx, hgmm_points* points);
+int hgmm_points_destroy(hgmm_ctx* ctx, hgmm_points* points);
+int64_t hgmm_points_count(const hgmm_points* points);
 
 /* ---- flat GMM EM (diag / spherical) ------------------------------------------------
  * hgmm_flat_estep   <- e_step()            gmm_waymo gmm_impl.py:105-116, gmmreg_gpu gmm_impl.py:55-61

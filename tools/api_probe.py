@@ -51,6 +51,19 @@ timeit("flat_mstep(lr.exp()) host outputs", lambda: ctx.flat_mstep(lr.exp(), cen
 timeit("flat_stats", lambda: ctx.flat_stats(inv, mu, w), 6, "flat_fused")
 timeit("flat_train 20 iterations (upload, loop, download)", lambda: ctx.flat_train(20, 0.0, mu0, cov0, w0, "diag", "W"), 3, "flat_fused")
 del lr
+# ---- module-level functions on a resident cloud (DevicePoints): array module in = array module out
+from hgmm_amd.gmm_waymo import gmm_impl as W
+hgmm_amd.set_default_context(ctx)
+dX = W.asarray(X)
+d_inv, d_mu, d_w = ctx.to_device(inv), ctx.to_device(mu), ctx.to_device(w)
+timeit("W.predict(DevicePoints, device params) -> DeviceArray labels", lambda: W.predict(dX, d_inv, d_mu, d_w), 10, "flat_estep")
+timeit("W.predict(DevicePoints, host params)   -> DeviceArray labels", lambda: W.predict(dX, inv, mu, w), 10, "flat_estep")
+timeit("W.predict(host X [1M,3], host params)  -> NumPy int64 (upload + download)", lambda: W.predict(X, inv, mu, w), 5, "flat_estep")
+timeit("W.e_step(DevicePoints, device params) (lazy mean)", lambda: W.e_step(dX, d_inv, d_mu, d_w), 6, "flat_estep")
+other = W.asarray(X[::2])
+timeit("re-binding between two resident clouds + predict each", lambda: (W.predict(dX, d_inv, d_mu, d_w), W.predict(other, d_inv, d_mu, d_w)), 10, "flat_estep")
+other.free(); dX.free()
+ctx.set_points(X)
 # ---- bunny-sized module-level API
 B = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "bun000_xyz.npy"))
 from hgmm_amd.gmm_waymo.gmm import GMM_GPU
