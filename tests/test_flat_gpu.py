@@ -773,6 +773,7 @@ def test_several_resident_clouds_per_context(ctx, bunny):
     assert ctx.num_points == len(clouds[0])
     assert np.array_equal(np.asarray(W.predict(devs[2], inv0, mu0, w0)), np.asarray(W.predict(clouds[2], inv0, mu0, w0)))
     # freeing the bound cloud leaves nothing bound; the others live on; a freed handle says so
+    devs[2].bind()
     devs[2].free()
     with pytest.raises(hgmm_amd.HgmmError):
         ctx.flat_predict(inv0, mu0, w0)
