@@ -32,23 +32,6 @@
 #include <cstring>
 #include <vector>
 
-#include <type_traits>
-#include <utility>
-
-namespace hgmm {
-
-// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-}  // namespace hgmm
-
 namespace hgmm {
 
 constexpr double TREE_EPS = 1.0e-15;                 // hgmm_cupy_cpu_working.py:29
@@ -2862,356 +2845,6 @@ __global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
         full_fused_body<CPL, true>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds, exp2_tab);
 }
 
-// ------------------------------------------------------------------------------------------
-// The same one-pass E-step with FOUR-wave workgroups on 8-point tiles, two workgroups per CU (round 4).
-//
-// full_fused_kernel's 117 KB tile leaves room for ONE 8-wave workgroup per CU: the two waves of a SIMD belong to the
-// same workgroup, run through the same three barriers per tile in lock-step, and the phases' latencies (phase B is a
-// chain of LDS round trips and wave reductions) are exposed on every SIMD at once -- the kernel sits at 58 % of the
-// issue floor of its own formulation (profiles/r03/fullcov_accounting.md).  Here a tile is 8 points (58 KB of g at
-// J = 800, 76 KB of LDS per workgroup with the exp table), a workgroup is 4 waves = one per SIMD, and TWO workgroups
-// share a CU: the two waves of a SIMD now belong to different workgroups at different places of their tiles, so one
-// workgroup's phase B / C barriers hide under the other's phase A.  Same arithmetic per (point, component) pair, same
-// phases, same summation order inside a tile; a lane carries up to 4 components (J16 <= 1024 over 256 lanes) and a
-// wave up to 16 of the 16-component statistics tiles -- the register budget of one wave per SIMD and workgroup (256)
-// is what makes that possible.  Template parameters: waves per workgroup, points per tile (= 2 x waves: phase B gives
-// every half-wave one point), component slots per lane, statistics tiles per wave.
-// ------------------------------------------------------------------------------------------
-template <int WAVES, int P>
-__host__ __device__ inline size_t ftg_lds_doubles(int J16) {
-    // (WL is a byte per component here -- 6 KB less than full_fused_kernel's doubles: two of these workgroups must fit 160 KB)
-    return (size_t)P * ft_ldg(J16) + 16 * (P + 2) + 3 * P + (J16 + 7) / 8 + 4 * 3 * P + EXP_TAB2_N;
-}
-
-template <int WAVES, int P, int CPL, int MAXT, bool CHOL>
-__device__ __forceinline__ void full_fused_body_g(
-    const double* __restrict__ xs, int64_t n, int64_t n_pad, const double* __restrict__ prep, int J16,
-    int* __restrict__ label_out, double* __restrict__ block_q, double* __restrict__ partials /*[grid][J16][NMOM]*/,
-    int want_stats, long long* __restrict__ dbg, double* lds, const double* __restrict__ exp2_tab) {
-    static_assert(P == 2 * WAVES && P % 4 == 0, "phase B gives every half-wave one point; phases A / C work in fours");
-    constexpr int BLOCK = WAVES * 64;
-    constexpr int LDF = P + 2;                    // feature rows: P points + 2 (conflict-free B-fragment reads)
-    constexpr int KS = P / 4;                     // 4-point steps of the matrix instruction
-    long long tA = 0, tB = 0, tC = 0, tW = 0, tm = 0;
-#define FTG_TICK(acc) do { if (dbg) { const long long now_ = clock64(); acc += now_ - tm; tm = now_; } } while (0)
-    const int LDG = ft_ldg(J16);
-    double* G = lds;                              // [P][LDG]
-    double* F = G + (size_t)P * LDG;              // [16 features][LDF]
-    double* INV = F + 16 * LDF;                   // [P] 1 / denominator (0: dead point)
-    double* TOT = INV + P;                        // [2][P] sum over the components with pi >= eps (-1: dead point), by tile parity
-    unsigned char* WL = reinterpret_cast<unsigned char*>(TOT + 2 * P);   // [J16] 1 where pi_j >= eps (the component counts towards q)
-    double* XS = TOT + 2 * P + (J16 + 7) / 8;     // [2][3][P] the tile's coordinates relative to the origin, double-buffered
-    double* XA = XS + 2 * 3 * P;                  // [2][3][P] ... and as given (the statistics' features)
-    double* EXPT = XA + 2 * 3 * P;                // [2048] 2^(j/2048)
-    const int w = wave_in_block(), lane = lane_id();
-    const int tid = (int)threadIdx.x;
-    exp_tab2_load(EXPT, exp2_tab);                // (the barrier behind the WL / G initialisation covers it)
-
-    // this lane's components: slot c < CPL - 1 = tid + c BLOCK (always present: J16 > (CPL - 1) BLOCK); the LAST slot holds
-    // the R = J16 - (CPL - 1) BLOCK remaining components: waves below w_r have a full 64, and when the wave behind them has
-    // at most 32 left, those are a TAIL BLOCK of 32 components x P points dealt out over `nw` of the waves without a full
-    // last slot -- each holds the same 32 components in both half-waves and evaluates them for P / (2 nw) points per
-    // half-wave (full_fused_kernel's scheme, see there)
-    const int R = J16 - (CPL - 1) * BLOCK;
-    const int w_r = R / 64, rem = R % 64;
-    const bool tail_exists = rem > 0 && rem <= 32 && w_r < WAVES;
-    const int free_w = WAVES - w_r;                                      // waves without a full last slot
-    int nw = 0;
-    if (tail_exists) {
-        nw = 1;
-        while (2 * nw <= free_w && 4 * nw <= P) nw *= 2;                 // a power of two, P / (2 nw) >= 1 point per half-wave
-    }
-    const bool tail_wave = tail_exists && w >= w_r && w < w_r + nw;      // wave-uniform
-    const int tail_pts = tail_exists ? P / (2 * nw) : 0;
-    const int tail_p0 = tail_wave ? (w - w_r) * 2 * tail_pts + (lane >> 5) * tail_pts : 0;
-    // wave-uniform: the wave evaluates its last slot for every point (a partly filled one too: lanes past J16 have wE = 0
-    // and do not store)
-    const bool full_last = !tail_wave && (w * 64 + (CPL - 1) * BLOCK < J16);
-    int jc[CPL];
-#pragma unroll
-    for (int c = 0; c < CPL - 1; ++c) jc[c] = tid + c * BLOCK;
-    jc[CPL - 1] = tail_wave ? (CPL - 1) * BLOCK + 64 * w_r + (lane & 31) : tid + (CPL - 1) * BLOCK;
-    const double o0 = xs[0], o1 = xs[n_pad], o2 = xs[2 * n_pad];
-    // CHOL: s* = R, m* = -R (mu - o);   !CHOL: s* = -Sigma^-1 / 2, m* = mu - o
-    double s00[CPL], s01[CPL], s02[CPL], s11[CPL], s12[CPL], s22[CPL], m0[CPL], m1[CPL], m2[CPL], wE[CPL];
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-        const int j = jc[c];
-        wE[c] = 0.0;
-        s00[c] = s01[c] = s02[c] = s11[c] = s12[c] = s22[c] = m0[c] = m1[c] = m2[c] = 0.0;
-        if (j < J16) {
-            const double* pr = prep + PREP_N * j;
-            const double u0 = pr[6] - o0, u1 = pr[7] - o1, u2 = pr[8] - o2;
-            if (CHOL) {
-                s00[c] = pr[PREP_R]; s01[c] = pr[PREP_R + 1]; s02[c] = pr[PREP_R + 2];
-                s11[c] = pr[PREP_R + 3]; s12[c] = pr[PREP_R + 4]; s22[c] = pr[PREP_R + 5];
-                m0[c] = -fma(s02[c], u2, fma(s01[c], u1, s00[c] * u0));
-                m1[c] = -fma(s12[c], u2, s11[c] * u1);
-                m2[c] = -(s22[c] * u2);
-            } else {
-                s00[c] = -0.5 * pr[0]; s01[c] = -0.5 * pr[1]; s02[c] = -0.5 * pr[2];
-                s11[c] = -0.5 * pr[3]; s12[c] = -0.5 * pr[4]; s22[c] = -0.5 * pr[5];
-                m0[c] = u0; m1[c] = u1; m2[c] = u2;
-            }
-            wE[c] = pr[9];
-        }
-    }
-    int my_small = 0;
-    for (int j = tid; j < J16; j += BLOCK) {
-        const double wl = prep[PREP_N * j + 10], we = prep[PREP_N * j + 9];
-        WL[j] = (wl != 0.0) ? 1 : 0;
-        if (wl == 0.0 && we != 0.0) my_small = 1;
-    }
-    for (int e = tid; e < P * LDG; e += BLOCK) G[e] = 0.0;              // phase B reads whole 128-column steps
-    const bool any_small = __syncthreads_or(my_small) != 0;
-    const int ntiles = J16 / 16;
-    double acc[MAXT][3];                          // per statistics tile: three 4-feature blocks
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) acc[t][0] = acc[t][1] = acc[t][2] = 0.0;
-    const int a_idx = lane & 15, b_idx = lane >> 4;
-
-    const int64_t tiles = (n + P - 1) / P;
-    const int64_t per = (tiles + gridDim.x - 1) / gridDim.x;
-    const int64_t t0 = (int64_t)blockIdx.x * per;
-    const int64_t t1 = (t0 + per < tiles) ? t0 + per : tiles;
-    constexpr int LQ_WAVE = 1;
-    double lq = 0.0;                              // wave LQ_WAVE: sum of the workgroup's log-likelihood terms
-
-    const int st_d = tid / P, st_p = tid % P;                            // the staging threads' (coordinate, point)
-    const double st_o = (tid < 3 * P) ? xs[(size_t)st_d * n_pad] : 0.0;
-    auto stage = [&](int64_t tile, int buf) {
-        if (tid < 3 * P) {
-            int64_t i = tile * P + st_p;
-            i = i < n ? i : n - 1;
-            const double v = xs[(size_t)st_d * n_pad + i];
-            XA[(buf * 3 + st_d) * P + st_p] = v;
-            XS[(buf * 3 + st_d) * P + st_p] = v - st_o;
-        }
-    };
-    auto tile_loglik = [&](int par) {
-        const double tv = (lane < P) ? TOT[par * P + lane] : -1.0;
-        double term = (tv >= 0.0) ? log(fmax(tv, TREE_EPS)) : 0.0;
-        term = wave_sum_f64(term);
-        lq += term;
-    };
-    if (t0 < t1) stage(t0, 0);
-    __syncthreads();
-    for (int64_t tile = t0; tile < t1; ++tile) {
-        const int64_t base = tile * P;
-        const int buf = (int)((tile - t0) & 1);
-        const double* X = XS + buf * 3 * P;
-        if (dbg) tm = clock64();
-        if (w == LQ_WAVE && tile > t0) tile_loglik(buf ^ 1);
-        // ---- phase A ------------------------------------------------------------------------------------------------
-        // one (point, component slot) pair's exponent
-        auto quad = [&](int pt, auto ctag) -> double {
-            constexpr int c = decltype(ctag)::value;
-            const double a0 = X[pt], a1 = X[P + pt], a2 = X[2 * P + pt];
-            if (CHOL) {
-                const double z0 = fma(s02[c], a2, fma(s01[c], a1, fma(s00[c], a0, m0[c])));
-                const double z1 = fma(s12[c], a2, fma(s11[c], a1, m1[c]));
-                const double z2 = fma(s22[c], a2, m2[c]);
-                return -fma(z2, z2, fma(z1, z1, z0 * z0));
-            }
-            return sym3_quad(s00[c], s01[c], s02[c], s11[c], s12[c], s22[c], a0 - m0[c], a1 - m1[c], a2 - m2[c]);
-        };
-        // four points x NC component slots = NC steps of four pairs (pair q of the block: point q / NC, slot q % NC); the
-        // exponentials in three stages like full_fused_kernel's (table look-ups in flight under the polynomials)
-        auto block4 = [&](int p0, auto nctag) {
-            constexpr int NC = decltype(nctag)::value;
-            static_for<NC>([&](auto gtag) {
-                constexpr int g = decltype(gtag)::value;
-                ExpHead hd[4];
-                static_for<4>([&](auto ktag) {
-                    constexpr int k = decltype(ktag)::value;
-                    constexpr int q = 4 * g + k;
-                    hd[k] = exp_t11_head<CHOL>(quad(p0 + q / NC, std::integral_constant<int, q % NC>{}), EXPT);
-                });
-                double pa[4];
-                exp_t11_poly4(hd[0].r, hd[1].r, hd[2].r, hd[3].r, pa);
-                static_for<4>([&](auto ktag) {
-                    constexpr int k = decltype(ktag)::value;
-                    constexpr int q = 4 * g + k;
-                    constexpr int c = q % NC;
-                    const double e = exp_t11_tail(hd[k], pa[k]);
-                    if (c < CPL - 1 || jc[c] < J16) G[(size_t)(p0 + q / NC) * LDG + jc[c]] = wE[c] * e;
-                });
-            });
-        };
-        if (full_last) {
-#pragma unroll 1
-            for (int p0 = 0; p0 < P; p0 += 4) block4(p0, std::integral_constant<int, CPL>{});
-        } else {
-            if constexpr (CPL > 1) {
-#pragma unroll 1
-                for (int p0 = 0; p0 < P; p0 += 4) block4(p0, std::integral_constant<int, CPL - 1>{});
-            }
-            if (tail_wave) {
-                // the tail block's share of this half-wave: `tail_pts` points of the 32 components in the last slot
-                constexpr int c = CPL - 1;
-                const int np = tail_pts;
-                const int pbeg = tail_p0;
-                for (int p0 = 0; p0 < np; p0 += 4) {
-                    double y[4], e[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int pt = pbeg + ((p0 + k < np) ? p0 + k : np - 1);
-                        y[k] = quad(pt, std::integral_constant<int, c>{});
-                    }
-                    exp_t11_4<CHOL>(y, e, EXPT);
-                    if (jc[c] < J16) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (p0 + k < np) G[(size_t)(pbeg + p0 + k) * LDG + jc[c]] = wE[c] * e[k];
-                    }
-                }
-            }
-        }
-        if (tile + 1 < t1) stage(tile + 1, buf ^ 1);
-        FTG_TICK(tA);
-        __syncthreads();
-        FTG_TICK(tW);
-        // ---- phase B: half-wave h of wave w owns point 2 w + h (see full_fused_kernel) ------------------------------
-        {
-            const int h = lane >> 5, sub = lane & 31;
-            const int p = w * 2 + h;
-            const double* Gp = G + (size_t)p * LDG;
-            const int J128 = (J16 + 127) & ~127;
-            double den = 0.0, tot = 0.0, best = -1.0;
-            int jbest = 0;
-            for (int jb = 0; jb < J128; jb += 128) {
-                double gv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) gv[u] = Gp[jb + 32 * u + sub];
-                const double m4 = fmax(fmax(gv[0], gv[1]), fmax(gv[2], gv[3]));
-                den += (gv[0] + gv[1]) + (gv[2] + gv[3]);
-                jbest = (m4 > best) ? jb : jbest;
-                best = fmax(best, m4);
-                if (any_small) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int j = jb + 32 * u + sub;
-                        tot += (j < J16 && WL[j]) ? gv[u] : 0.0;
-                    }
-                }
-            }
-            int am;
-            {
-                const double g0 = Gp[jbest + sub], g1 = Gp[jbest + 32 + sub], g2 = Gp[jbest + 64 + sub];
-                am = jbest + sub + ((g0 == best) ? 0 : ((g1 == best) ? 32 : ((g2 == best) ? 64 : 96)));
-            }
-            double den0, den1, bm0, bm1;
-            halfwave_sum_f64(den, den0, den1);
-            halfwave_max_f64(best, bm0, bm1);
-            const double den_h = h ? den1 : den0, bm_h = h ? bm1 : bm0;
-            int c0, c1;
-            halfwave_min_i32((best == bm_h) ? am : 0x7fffffff, c0, c1);
-            double tot_h = den_h;
-            if (any_small) {
-                double t0s, t1s;
-                halfwave_sum_f64(tot, t0s, t1s);
-                tot_h = h ? t1s : t0s;
-            }
-            const double inv = 1.0 / den_h;
-            if (sub == 0) {
-                const bool live = base + p < n;
-                const bool good = den_h > TREE_EPS;
-                INV[p] = (live && good) ? inv : 0.0;
-                TOT[buf * P + p] = live ? tot_h : -1.0;
-                if (live) label_out[base + p] = good ? (h ? c1 : c0) : 0;
-            }
-            if (sub < 16) {
-                const double* A = XA + buf * 3 * P;
-                const double x0 = A[p], x1 = A[P + p], x2 = A[2 * P + p];
-                double f = 0.0;
-                switch (sub) {
-                    case 0: f = 1.0; break;
-                    case 1: f = x0; break;
-                    case 2: f = x1; break;
-                    case 3: f = x2; break;
-                    case 4: f = x0 * x0; break;
-                    case 5: f = x0 * x1; break;
-                    case 6: f = x0 * x2; break;
-                    case 7: f = x1 * x1; break;
-                    case 8: f = x1 * x2; break;
-                    case 9: f = x2 * x2; break;
-                    default: f = 0.0;
-                }
-                F[sub * LDF + p] = f;
-            }
-        }
-        FTG_TICK(tB);
-        __syncthreads();
-        FTG_TICK(tW);
-        // ---- phase C: statistics on the matrix cores (v_mfma_f64_4x4x4_4b_f64, layout: full_fused_kernel) ------------
-        if (want_stats) {
-            double bfrag[3][KS], ifrag[KS];
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                ifrag[s] = INV[4 * s + b_idx];
-#pragma unroll
-                for (int fb = 0; fb < 3; ++fb) bfrag[fb][s] = F[(4 * fb + (lane & 3)) * LDF + 4 * s + b_idx];
-            }
-            double araw[2][KS];
-            auto load_a = [&](int ct, double (&dst)[KS]) {
-#pragma unroll
-                for (int s = 0; s < KS; ++s) dst[s] = G[(size_t)(4 * s + b_idx) * LDG + 16 * ct + a_idx];
-            };
-            if (w < ntiles) load_a(w, araw[0]);
-#pragma unroll
-            for (int t = 0; t < MAXT; ++t) {
-                const int ct = w + t * WAVES;                          // wave-uniform
-                if (ct < ntiles) {
-                    if (t + 1 < MAXT && ct + WAVES < ntiles) load_a(ct + WAVES, araw[(t + 1) & 1]);
-#pragma unroll
-                    for (int s = 0; s < KS; ++s) {
-                        double a = araw[t & 1][s] * ifrag[s];
-                        if (a < TREE_EPS) a = 0.0;
-#pragma unroll
-                        for (int fb = 0; fb < 3; ++fb)
-                            acc[t][fb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bfrag[fb][s], acc[t][fb], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        FTG_TICK(tC);
-        __syncthreads();                                               // G is overwritten by the next tile
-        FTG_TICK(tW);
-    }
-    if (w == LQ_WAVE && t0 < t1) tile_loglik((int)((t1 - 1 - t0) & 1));
-    if (dbg && lane == 0 && blockIdx.x == 7) {
-        dbg[w * 4 + 0] = tA; dbg[w * 4 + 1] = tB; dbg[w * 4 + 2] = tC; dbg[w * 4 + 3] = tW;
-    }
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-        const int ct = w + t * WAVES;
-        if (ct < ntiles) {
-            const int comp = 16 * ct + 4 * ((lane >> 2) & 3) + (lane >> 4);
-#pragma unroll
-            for (int fb = 0; fb < 3; ++fb) {
-                const int feat = 4 * fb + (lane & 3);
-                if (feat < NMOM) partials[((size_t)blockIdx.x * J16 + comp) * NMOM + feat] = acc[t][fb];
-            }
-        }
-    }
-    if (w == LQ_WAVE && lane == 0) block_q[blockIdx.x] = lq;
-#undef FTG_TICK
-}
-
-template <int WAVES, int P, int CPL, int MAXT>
-__global__ __launch_bounds__(WAVES * 64, 2) void full_fused_g_kernel(
-    const double* __restrict__ xs, int64_t n, int64_t n_pad, const double* __restrict__ prep, int J16,
-    int* __restrict__ label_out, double* __restrict__ block_q, double* __restrict__ partials,
-    int want_stats, const int* __restrict__ flags, const double* __restrict__ exp2_tab,
-    long long* __restrict__ dbg = nullptr, const int* __restrict__ done = nullptr) {
-    extern __shared__ double lds[];
-    if (done && *done) return;
-    if (flags && (*flags & 1))
-        full_fused_body_g<WAVES, P, CPL, MAXT, false>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds, exp2_tab);
-    else
-        full_fused_body_g<WAVES, P, CPL, MAXT, true>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds, exp2_tab);
-}
-
 // one wave per component: fixed-order sum over the workgroups' partials
 __global__ __launch_bounds__(64) void full_reduce_kernel(const double* __restrict__ partials, int nblocks,
                                                          int J, int J16, double* __restrict__ mom,
@@ -3286,10 +2919,6 @@ static bool fullcov_one_pass(int J16) {
     if (const char* e = std::getenv("HGMM_FULLCOV_TWO_PASS")) if (e[0] == '1') return false;
     return J16 <= FT_MAX_J16;
 }
-static bool fullcov_four_waves() {
-    if (const char* e = std::getenv("HGMM_FULLCOV_WAVES")) return e[0] == '4';
-    return false;
-}
 // `ctl` (device): the launches look at ctl->done first and the sum of q applies the stop rule `stop` -- for a loop whose
 // iterations are enqueued ahead of the host's knowledge (hgmm_fullcov_fit); then nothing is copied to the host here.
 static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_host, bool want_stats = true,
@@ -3302,41 +2931,12 @@ static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_hos
     HGMM_TRY(ensure_exp_tab2(c));
     // (a 16-wave form of this kernel -- 1024 threads, one component per lane, 128 registers -- was built and measured in
     //  round 3: 1.83 vs 1.76 ms, phase A no shorter with four waves per SIMD than with two; removed again, commit b7f6218,
-    //  profiles/r03/fullcov_accounting.md)
-    int grid4 = 0;
-    if (fullcov_four_waves()) {
-        // four-wave workgroups on 8-point tiles, two per CU (full_fused_g_kernel)
-        const int64_t tiles8 = (c->n + 7) / 8;
-        grid4 = (int)std::min<int64_t>(tiles8, (int64_t)c->cus * 2);
-        const size_t lds4 = sizeof(double) * ftg_lds_doubles<4, 8>(J16);
-        long long* dbg = nullptr;
-        if (std::getenv("HGMM_FT_DEBUG")) { HGMM_HIP(c, hipMalloc(&dbg, 8 * 4 * 8)); }
-        {
-            ProfScope prof(c, HGMM_K_FULL_FUSED);
-#define FTG_LAUNCH(CPLV, MAXTV)                                                                                         \
-    do {                                                                                                                \
-        HGMM_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&full_fused_g_kernel<4, 8, CPLV, MAXTV>),         \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4));                        \
-        full_fused_g_kernel<4, 8, CPLV, MAXTV><<<grid4, 256, lds4, c->stream>>>(                                        \
-            c->x_soa64.as<double>(), c->n, c->n_pad, c->t_prep.as<double>(), J16, labels, block_q,                      \
-            c->t_partials.as<double>(), want_stats ? 1 : 0, flags_ptr(c), c->exp_tab2.as<double>(), dbg, done);         \
-    } while (0)
-            if (J16 <= 256) FTG_LAUNCH(1, 4);
-            else if (J16 <= 512) FTG_LAUNCH(2, 8);
-            else if (J16 <= 768) FTG_LAUNCH(3, 12);
-            else if (J16 <= 832) FTG_LAUNCH(4, 13);
-            else FTG_LAUNCH(4, 16);
-#undef FTG_LAUNCH
-        }
-        if (dbg) {
-            long long h[32];
-            HGMM_HIP(c, ctx_stream_sync(c));
-            HGMM_HIP(c, hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost));
-            for (int w = 0; w < 4; ++w)
-                fprintf(stderr, "wave %d: A %lld  B %lld  C %lld  wait %lld cycles\n", w, h[4 * w], h[4 * w + 1], h[4 * w + 2], h[4 * w + 3]);
-            (void)hipFree(dbg);
-        }
-    } else {
+    //  profiles/r03/fullcov_accounting.md.  Round 4: four-wave workgroups on 8-point tiles, TWO workgroups per CU so that
+    //  the two waves of a SIMD run out of step -- up to 4 components per lane, 13 statistics tiles per wave: parity green,
+    //  2.04 ms against 1.73; it needs 281 registers where two waves per SIMD leave 256 (40 spilled), phase B is a latency
+    //  chain per TILE, not per point (3.5 k cycles per 8-point tile against 3.2 k per 16-point tile), phase C 6.1 k per
+    //  8 points against 4.5 k per 16; removed again, commit 875bec9, profiles/r04/fullcov_accounting_r04.md)
+    {
         ProfScope prof(c, HGMM_K_FULL_FUSED);
         if (J16 <= FT_BLOCK) {
             HGMM_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&full_fused_kernel<1>),
@@ -3367,10 +2967,9 @@ static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_hos
     HGMM_HIP(c, hipGetLastError());
     // (the statistics before the sum: the sum may set the stop flag, and a loop that stops still wants THIS launch's q --
     //  its statistics are not needed any more, but the reduction has looked at the flag before it is raised)
-    const int nparts = grid4 ? grid4 : grid;
     if (want_stats)
-        full_reduce_kernel<<<J, 64, 0, c->stream>>>(c->t_partials.as<double>(), nparts, J, J16, c->t_mom.as<double>(), done);
-    tree_sum_kernel<<<1, 256, 0, c->stream>>>(block_q, nparts, q_dev, done, stop);
+        full_reduce_kernel<<<J, 64, 0, c->stream>>>(c->t_partials.as<double>(), grid, J, J16, c->t_mom.as<double>(), done);
+    tree_sum_kernel<<<1, 256, 0, c->stream>>>(block_q, grid, q_dev, done, stop);
     HGMM_HIP(c, hipGetLastError());
     if (c->comm_on()) {
         HGMM_TRY(allreduce_f64_dev(c, c->t_mom.as<double>(), (size_t)NMOM * J));
