@@ -12,7 +12,9 @@ ctx = hgmm_amd.Context(0)
 
 
 def timeit(label, fn, reps=10, kernel=None):
-    for _ in range(2):
+    # (the first series of calls of a kind carries one-time costs -- code objects, buffers, queues: 8 ms spread over the
+    #  first M-step series when it had two warm-up calls -- so every line gets four untimed calls first)
+    for _ in range(4):
         fn()
     ctx.synchronize()
     if kernel:
