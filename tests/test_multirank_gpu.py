@@ -139,10 +139,10 @@ def _ipc_collectives_expected():
     return out
 
 
-def _ipc_collectives_worker(rank, name, q):
+def _ipc_collectives_worker(rank, name, q, device=0):
     try:
         import hgmm_amd
-        ctx = hgmm_amd.Context(0)
+        ctx = hgmm_amd.Context(device)
         ctx.comm_init_ipc(2, rank, name)
         out = []
         for rep in range(3):
@@ -171,6 +171,32 @@ def test_rccl_two_ranks_two_gpus():
     port = s.getsockname()[1]
     s.close()
     _two_ranks_match_single_context(port)
+
+
+def test_peer_exchange_two_ranks_two_gpus():
+    """The one-shot peer exchange ACROSS two GPUs (each rank maps the other's exchange buffer over xGMI / PCIe through
+    its hipIpc handle): the collectives by themselves, bitwise equal on both ranks and equal to the host's sums.  Needs
+    two GPUs (the driver's multi-GPU node; a 1-GPU box skips)."""
+    import ctypes
+    import hgmm_amd
+    cnt = ctypes.c_int(0)
+    hgmm_amd.load_library().hgmm_device_count(ctypes.byref(cnt))
+    if cnt.value < 2:
+        pytest.skip("needs >= 2 GPUs (found %d)" % cnt.value)
+    name = "hgmm_ipc2_%d" % os.getpid()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_ipc_collectives_worker, args=(r, name, q, r)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in procs)
+    assert not any(isinstance(v, str) for v in got.values()), got
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    exp = _ipc_collectives_expected()
+    for a, b, e in zip(got[0], got[1], exp):
+        assert np.array_equal(a, b) and np.array_equal(a, e)
 
 
 def _two_ranks_match_single_context(rccl_port, backend="host"):
