@@ -874,8 +874,14 @@ def rank_main(args):
     if world > 1 and requested == "auto" and kind == "rccl" and len(hosts) == 1:
         _run_with_timeout(ctx.comm_destroy, 60.0)
         k2, failed2 = choose_collective(ctx, rank, world, ["ipc"], token, hosts, round0=8)
+        f2 = None
         if k2 == "ipc":
-            f2 = timed_fit(ctx, args, world, (mu0, cov0, w0))
+            try:                                    # a side leg on hardware it has never seen must not lose the headline line
+                f2 = timed_fit(ctx, args, world, (mu0, cov0, w0))
+            except Exception as e:                  # (a peer's slice that never arrives fails every rank alike, after ~20 s)
+                sys.stderr.write("rank %d: the peer-exchange leg failed: %r\n" % (rank, e))
+                second = {"collective": COLLECTIVES["ipc"], "error": "the joint fit failed: %r" % (e,)}
+        if f2 is not None:
             med2 = float(np.median(f2["blocks"]))
             same = all(np.array_equal(a, b) for a, b in zip(f2["model"], fit["model"]))
             second = {"collective": COLLECTIVES["ipc"], "value": world * K / med2, "ms_per_step": 1e3 * med2 / K,
@@ -887,7 +893,7 @@ def rank_main(args):
                       "note": "same frames, same initial parameters, same K-step blocks as `value`; only the all-reduce "
                               "behind the statistics differs (sums in rank order instead of RCCL's reduction order)"}
             consistent = consistent and f2["consistent"]
-        else:
+        elif second is None:
             second = {"collective": COLLECTIVES["ipc"], "error": "could not be set up on every rank: %s" % (failed2,)}
     if world > 1:
         _run_with_timeout(ctx.comm_destroy, 60.0)            # the legs below run on rank 0 alone

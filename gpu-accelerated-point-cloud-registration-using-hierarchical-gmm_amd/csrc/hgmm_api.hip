@@ -11,6 +11,7 @@
 #include <atomic>
 #include <chrono>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -244,7 +245,10 @@ __global__ __launch_bounds__(256) void ipc_allreduce_kernel(IpcPeers pp, int R, 
         // 3. the same piece of peer t, in MY buffer
         const unsigned long long* f = pp.flags[rank] + ((size_t)parity * IPC_MAX_RANKS + t) * IPC_MAX_CHUNKS + c;
         const long long t0 = wall_clock64();
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+        // (once the error word is up -- an earlier collective waited in vain -- nobody waits again: the collectives
+        //  enqueued behind it drain at once instead of sitting out the timeout one after the other)
+        const bool broken = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+        while (!broken && __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
             __builtin_amdgcn_s_sleep(2);
             if (wall_clock64() - t0 > timeout_ticks) {             // never hang the GPU: raise the error word, go on
                 __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -852,7 +856,9 @@ extern "C" int hgmm_comm_init_ipc(hgmm_ctx* c, int nranks, int rank, const char*
     ic->err_dev = static_cast<unsigned*>(ed);
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
-    ic->timeout_ticks = (long long)(IPC_TIMEOUT_S * 1000.0 * (double)khz);
+    double timeout_s = IPC_TIMEOUT_S;
+    if (const char* e = std::getenv("HGMM_IPC_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0 && v < 600.0) timeout_s = v; }
+    ic->timeout_ticks = (long long)(timeout_s * 1000.0 * (double)khz);
     hipIpcMemHandle_t mine;
     if ((e = hipIpcGetMemHandle(&mine, ic->local)) != hipSuccess)
         return bail(HGMM_ERR_HIP, "hipIpcGetMemHandle", hipGetErrorString(e));

@@ -124,6 +124,48 @@ def test_peer_exchange_collectives_two_ranks_one_gpu():
         assert np.array_equal(a, e)
 
 
+def test_peer_exchange_missing_peer_raises_instead_of_hanging():
+    """A peer that never joins a collective must not hang the GPU: the exchange kernel gives up after its timeout
+    (HGMM_IPC_TIMEOUT_S, 20 s by default; 2 s here), raises the context's error word, and the call that waits for the
+    result fails; collectives already enqueued behind it drain at once."""
+    import time
+    name = "hgmm_ipc_to_%d" % os.getpid()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_ipc_timeout_worker, args=(r, name, q)) for r in range(2)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert got[1] == "idle"
+    assert got[0].startswith("raised:") and ("peer exchange" in got[0] or "hipErrorLaunchTimeOut" in got[0] or "timed out" in got[0].lower()), got[0]
+    assert time.time() - t0 < 100
+
+
+def _ipc_timeout_worker(rank, name, q):
+    os.environ["HGMM_IPC_TIMEOUT_S"] = "2"
+    import time
+    import hgmm_amd
+    ctx = hgmm_amd.Context(0)
+    ctx.comm_init_ipc(2, rank, name)
+    if rank == 1:
+        time.sleep(12)                                     # never takes part in the collective
+        q.put((rank, "idle"))
+        q.close(); q.join_thread()                         # (the queue's feeder thread must have sent it before _exit)
+        os._exit(0)                                        # (no orderly teardown with a peer that has given up)
+    try:
+        t0 = time.time()
+        ctx.allreduce(np.arange(5000.0))
+        ctx.allreduce(np.arange(5000.0))                   # behind a failed collective: must not sit out another timeout
+        q.put((rank, "no error after %.1f s" % (time.time() - t0)))
+    except hgmm_amd.HgmmError as e:
+        q.put((rank, "raised: %s (%.1f s)" % (e, time.time() - t0)))
+    q.close(); q.join_thread()
+    os._exit(0)
+
+
 def _ipc_payloads(rank):
     rs = np.random.RandomState(40 + rank)
     return [rs.randn(n) * 10.0 ** rs.randint(-3, 4) for n in (1, 7, 511, 512, 513, 7170, 65536, 65537, 150001)]
