@@ -51,6 +51,19 @@ def test_random_shapes(ctx, case):
     if flips.any():
         part = np.partition(o_r[flips], -2, axis=1)
         assert ((part[:, -1] - part[:, -2]) < 1e-5).all()
+    # the other loop of the materialising kernel (no arg-max asked: constant-shift log-sum-exp) and predict's own kernel
+    mean2, lr2, lpn2, _ = ctx.flat_estep(inv, mu, w, cov_type, variant, want_lpn=True)
+    assert np.abs(np.exp(lr2.get().astype(np.float64)) - o_r).max() <= 1e-5
+    np.testing.assert_allclose(lpn2.get(), o_lpn, rtol=2e-5, atol=2e-5)
+    assert abs(mean2 - o_mean) <= 2e-5 * max(1.0, abs(o_mean))
+    flips = ctx.flat_predict(inv, mu, w, cov_type, variant).get() != o_am
+    if flips.any():
+        part = np.partition(o_r[flips], -2, axis=1)
+        assert ((part[:, -1] - part[:, -2]) < 1e-5).all()
+    # estimate_log_prob: the raw table (four rows in flight, paced stores; ragged N, every component layout)
+    lp = ctx.flat_log_prob(inv, mu, cov_type).get()
+    o_lp = (flat_em.log_gauss_diag if cov_type == "diag" else flat_em.log_gauss_spherical)(f64(X), f64(inv), f64(mu))
+    np.testing.assert_allclose(lp, o_lp, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(o_lp).max()) * 1e-2))
     stats, sum_lpn, n = ctx.flat_stats(inv, mu, w, cov_type, variant)
     assert n == N
     np.testing.assert_allclose(stats[:, 0], o_r.sum(0), rtol=2e-4, atol=1e-5)
