@@ -481,6 +481,7 @@ class Context:
         self.h = h
         self.device_id = device_id
         self.nranks, self.rank = 1, 0
+        self._points_handles = set()          # clouds created through points_create and not destroyed yet
         self._arena = None                    # (pointer, free slab indices) of the small-array pool
         self._freed = {}                      # size -> pointers of dead arrays kept for reuse (_free)
         self._freed_bytes = 0
@@ -508,6 +509,9 @@ class Context:
                     except Exception:
                         pass
             self._scalar_host = None
+            for hv in list(self._points_handles):     # resident clouds nobody freed: they must go before the context
+                self.lib.hgmm_points_destroy(self.h, _vp(hv))
+            self._points_handles.clear()
             if self._arena is not None:               # (arrays carved from it die with the context)
                 self.lib.hgmm_free(self.h, self._arena[0])
                 self._arena = None
@@ -663,9 +667,12 @@ class Context:
         if X.dtype == np.float64:
             Xc = np.ascontiguousarray(X)
             self._check(self.lib.hgmm_points_create_f64(self.h, _ptr(Xc), Xc.shape[0], C.byref(h)))
+            self._points_handles.add(h.value)
+            return h
         else:
             Xc = np.ascontiguousarray(X, dtype=np.float32)
             self._check(self.lib.hgmm_points_create_f32(self.h, _ptr(Xc), Xc.shape[0], C.byref(h)))
+        self._points_handles.add(h.value)
         return h
 
     def points_bind(self, handle):
@@ -674,7 +681,8 @@ class Context:
         self.n = self.num_points
 
     def points_destroy(self, handle):
-        if getattr(self, "h", None) and handle:
+        if getattr(self, "h", None) and handle and handle.value in self._points_handles:
+            self._points_handles.discard(handle.value)
             self._check(self.lib.hgmm_points_destroy(self.h, handle))
 
     # -- flat EM ----------------------------------------------------------------------
