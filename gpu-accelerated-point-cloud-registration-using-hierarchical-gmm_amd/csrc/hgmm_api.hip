@@ -935,6 +935,7 @@ extern "C" int hgmm_comm_init_ipc(hgmm_ctx* c, int nranks, int rank, const char*
 
 extern "C" int hgmm_comm_destroy(hgmm_ctx* c) {
     if (!c) return HGMM_ERR_ARG;
+    HGMM_HIP(c, hipSetDevice(c->device));                  // (the current device is per THREAD: a caller may tear down from another one)
     if (c->hcomm) {
         HGMM_HIP(c, ctx_stream_sync(c));
         (void)hostcomm_barrier(c);                          // nobody unlinks while a peer still reduces
