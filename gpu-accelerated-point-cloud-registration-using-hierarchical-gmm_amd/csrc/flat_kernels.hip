@@ -315,6 +315,9 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_kernel(
 // So the rate is made explicit: every wave issues its i-th group of rows no earlier than t0 + i * period on the
 // constant-rate wall clock (100 MHz), period chosen on the host so that all waves together offer the target rate.
 // Enough waves are launched for the arithmetic to keep up at any clock; the clock then no longer matters.
+// (The single-row kernel that serves the layouts without 16-byte stores -- J not a multiple of 4 -- is not paced: it is
+//  bound by its per-row reduction chain, not by the write path, and reaches 6.0 - 6.2 TB/s un-paced; paced at the same
+//  target it measured 2 - 3 % slower: J = 801 / 515 / 1001 at N = 1e6: 0.529 / 0.348 / 0.648 ms against 0.541 / 0.360 / 0.666.)
 // ------------------------------------------------------------------------------------------
 struct StorePacer {
     unsigned long long next;
