@@ -953,6 +953,7 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
         }
         __syncthreads();
         entered += cnt;
+        if (fl & 4) cnt = 0;                               // HGMM_TREE_LL_NOEVAL (measurement aid)
         for (int k = 0; k < cnt; ++k) {
             // (node parameters through the LDS tile: reading them with wave-uniform scalar loads
             //  instead was measured 60 % slower for the C4 build, 8.6 vs 5.2 ms)
@@ -1532,6 +1533,10 @@ static int tree_flags(hgmm_ctx* c, bool reset) {
         int preset = 0;
         if (const char* e = std::getenv("HGMM_TREE_NO_CHOL")) preset |= (e[0] == '1') ? 1 : 0;
         if (const char* e = std::getenv("HGMM_TREE_REL")) preset |= (e[0] == '1') ? 2 : 0;
+        // HGMM_TREE_LL_NOEVAL=1 (measurement aid, WRONG q): the log-likelihood kernels build their node tiles -- loads,
+        // reach tests, compaction, barriers -- and skip the pdf evaluations: what is left of their time is everything a
+        // precomputed per-chunk node list could save at most (profiles/r04/tree_loglik_split.log)
+        if (const char* e = std::getenv("HGMM_TREE_LL_NOEVAL")) preset |= (e[0] == '1') ? 4 : 0;
         if (preset) HGMM_HIP(c, hipMemsetAsync(c->t_flags.p, preset, 1, c->stream));
     }
     return HGMM_OK;
