@@ -1779,7 +1779,74 @@ static bool env_flag(const char* name, bool dflt) {
         }                                                                                      \
     } while (0)
 
-constexpr int ESTEP_TARGET_GBS = 6600;      // offered store rate of the paced N x J writers (materialising E-step, estimate_log_prob)
+// Offered store rate of the paced N x J writers (materialising E-step, estimate_log_prob), GB/s.  The knee of the write
+// path sat at 6.8 - 7.0 TB/s on every box of round 4, but it is a property of the memory system's state (refresh rate
+// with temperature, the stacks of the particular chip), and past it the kernel does not degrade gracefully -- it drops
+// to ~5.3 TB/s; the knee is soft besides: at 6700 one launch in three already ran 3 - 18 % long in bursts, at 6600 the
+// 150 launches of a bench run stayed within 488 - 506 us of their 487 (profiles/r04).  So the rate starts at 6600 and is
+// CONTROLLED, downwards only: a paced launch that runs more than 6 % longer than its
+// target explains counts as a strike, three strikes in a row lower the target by 2 % (never below PACE_FLOOR_GBS).  The
+// evidence comes from event pairs around the last few launches that are queried -- never waited for -- at the next
+// launch, so the stream is not disturbed.  Launches that are not store-bound by construction (the row-maximum loop,
+// small tables) neither adapt nor are they judged.  HGMM_ESTEP_TARGET_GBS=<n> fixes the rate (0: un-paced), HGMM_ESTEP_ADAPT=0
+// keeps the initial one.
+constexpr int ESTEP_TARGET_GBS = 6600;
+constexpr double PACE_FLOOR_GBS = 5800.0;
+constexpr double PACE_STRIKE_RATIO = 1.06;
+constexpr double PACE_STEP = 0.98;
+constexpr double PACE_MIN_BYTES = 256.0 * 1024 * 1024;
+
+// the rate the next paced launch of J-float rows offers
+static double pace_target(hgmm_ctx* c, int J) {
+    const int fixed = env_int("HGMM_ESTEP_TARGET_GBS", -1);
+    if (fixed >= 0) return (double)fixed;
+    PaceCtl& p = c->pace;
+    if (p.target <= 0.0 || p.J != J) { p.target = (double)env_int("HGMM_PACE_START", ESTEP_TARGET_GBS); p.strikes = 0; p.J = J; }
+    return p.target;
+}
+// look at the launches that have finished since the last call (no waiting)
+static void pace_poll(hgmm_ctx* c) {
+    PaceCtl& p = c->pace;
+    while (p.tail != p.head) {
+        const unsigned s = p.tail % PaceCtl::RING;
+        if (hipEventQuery(p.ev[s][1]) != hipSuccess) { (void)hipGetLastError(); break; }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.ev[s][0], p.ev[s][1]) == hipSuccess && p.tgt_at[s] == p.target) {
+            const double ideal_ms = p.bytes_at[s] / (p.tgt_at[s] * 1e9) * 1e3;
+            if ((double)ms > PACE_STRIKE_RATIO * ideal_ms) {
+                if (++p.strikes >= 3) {
+                    p.target = std::max(PACE_FLOOR_GBS, p.target * PACE_STEP);
+                    p.strikes = 0;
+                    p.steps_down++;
+                }
+            } else {
+                p.strikes = 0;
+            }
+        }
+        p.tail++;
+    }
+}
+// bracket a paced launch: begin() before the kernel, end() behind it; false: this launch is not observed
+static bool pace_observe_begin(hgmm_ctx* c, double target, double bytes) {
+    PaceCtl& p = c->pace;
+    if (env_int("HGMM_ESTEP_TARGET_GBS", -1) >= 0 || !env_flag("HGMM_ESTEP_ADAPT", true)) return false;
+    if (bytes < PACE_MIN_BYTES || target <= 0.0) return false;
+    if (!p.have_events) {
+        for (auto& pr : p.ev)
+            if (hipEventCreate(&pr[0]) != hipSuccess || hipEventCreate(&pr[1]) != hipSuccess) return false;
+        p.have_events = true;
+    }
+    pace_poll(c);
+    if (p.head - p.tail >= (unsigned)PaceCtl::RING) return false;          // every pair is still in flight
+    const unsigned s = p.head % PaceCtl::RING;
+    p.tgt_at[s] = target;
+    p.bytes_at[s] = bytes;
+    return hipEventRecord(p.ev[s][0], c->stream) == hipSuccess;
+}
+static void pace_observe_end(hgmm_ctx* c) {
+    PaceCtl& p = c->pace;
+    if (hipEventRecord(p.ev[p.head % PaceCtl::RING][1], c->stream) == hipSuccess) p.head++;
+}
 
 // StorePacer period (1/16 ticks of the 100 MHz wall clock) per group of 4 rows: all `grid` x 4 waves together offer
 // `target_gbs` GB/s of J-float rows.  0 = no pacing.
@@ -1840,7 +1907,9 @@ static bool launch_logprob_rows(hgmm_ctx* c, int nv4, int nv1, float* log_prob) 
     const float* pk = c->f_pack.as<float>();
     ProfScope prof(c, HGMM_K_FLAT_ESTEP);
     const bool late = env_flag("HGMM_LOGPROB_LATE", true);
-    const int pace = store_pace16(c, grid, f.J, (double)env_int("HGMM_LOGPROB_TARGET_GBS", ESTEP_TARGET_GBS));
+    // (the raw table follows the rate the E-step's controller has settled on for this row length)
+    const int lp_fixed = env_int("HGMM_LOGPROB_TARGET_GBS", -1);
+    const int pace = store_pace16(c, grid, f.J, lp_fixed >= 0 ? (double)lp_fixed : pace_target(c, f.J));
 #define LOGP_R(A, B)                                                                                                 \
     do {                                                                                                             \
         if (late) flat_logprob_rows_pk_kernel<A, B, true><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, log_prob, pace);  \
@@ -1953,18 +2022,25 @@ static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argma
     if (rows > 1) {
         const bool cshift = env_flag("HGMM_ESTEP_CS", true) && !argmax;
         // Paced stores (StorePacer): two workgroups per CU -- all resident at once, which the pacer's period assumes, and
-        // enough waves for the arithmetic to keep up at any core clock -- offering the rows at ESTEP_TARGET_GBS.  The
-        // write path takes an evenly paced, phase-staggered 6.8 TB/s of these rows in every call pattern and collapses to
-        // ~5.3 at 7.0 - 7.4 (tools/pace_sweep.py, profiles/r04/pace_sweep.log): the default stays 3 % below the knee.  HGMM_ESTEP_TARGET_GBS=0: the un-paced
-        // launch with round 3's grid policy (estep_rows_grid).
-        const double target = (double)env_int("HGMM_ESTEP_TARGET_GBS", ESTEP_TARGET_GBS);
+        // enough waves for the arithmetic to keep up at any core clock -- offering the rows at the controlled target
+        // rate (ESTEP_TARGET_GBS above).  The write path takes an evenly paced, phase-staggered 6.8 TB/s of these rows in
+        // every call pattern and collapses to ~5.3 at 7.0 - 7.4 (tools/pace_sweep.py, profiles/r04/pace_sweep.log).
+        // HGMM_ESTEP_TARGET_GBS=0: the un-paced launch with round 3's grid policy (estep_rows_grid).
+        const double target = pace_target(c, f.J);
         const int grid_r = target > 0.0 ? grid_for(c, (c->n + 3) / 4, std::min(2, env_int("HGMM_ESTEP_BPC", 2)))
                                         : estep_rows_grid(c, cshift);
         const int pace = store_pace16(c, grid_r, f.J, target);
         c->flat.last_kernel = 1;
         c->flat.idle_since_launch = false;
-        ProfScope prof(c, HGMM_K_FLAT_ESTEP);
-        if (launch_estep_rows(c, nv4, nv1, grid_r, cshift, log_resp, lpn, argmax, pace)) {
+        // (only the constant-shift loop is store-bound by construction: the row-maximum loop is not judged)
+        const bool observed = cshift && pace_observe_begin(c, target, 4.0 * (double)c->n * (double)f.J);
+        bool launched;
+        {
+            ProfScope prof(c, HGMM_K_FLAT_ESTEP);
+            launched = launch_estep_rows(c, nv4, nv1, grid_r, cshift, log_resp, lpn, argmax, pace);
+        }
+        if (launched) {
+            if (observed) pace_observe_end(c);
             *grid_out = grid_r;
             HGMM_HIP(c, hipGetLastError());
             return HGMM_OK;
@@ -2242,6 +2318,15 @@ extern "C" int hgmm_flat_estep_dev(hgmm_ctx* c, int cov_type, int variant, int J
         flat_mean_lpn_kernel<<<1, 256, 0, c->stream>>>(c->f_lpn_partials.as<double>(), grid, (double)c->n, dev_mean_lpn);
         HGMM_HIP(c, hipGetLastError());
     }
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_pace_info(hgmm_ctx* c, double* target_gbs_out, int* steps_down_out) {
+    if (!c) return HGMM_ERR_ARG;
+    pace_poll(c);
+    const int fixed = env_int("HGMM_ESTEP_TARGET_GBS", -1);
+    if (target_gbs_out) *target_gbs_out = fixed >= 0 ? (double)fixed : (c->pace.target > 0.0 ? c->pace.target : (double)ESTEP_TARGET_GBS);
+    if (steps_down_out) *steps_down_out = c->pace.steps_down;
     return HGMM_OK;
 }
 

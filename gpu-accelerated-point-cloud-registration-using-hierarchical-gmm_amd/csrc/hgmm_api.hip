@@ -527,6 +527,8 @@ extern "C" int hgmm_destroy(hgmm_ctx* c) {
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     for (hipEvent_t& e : c->ev_slots) if (e) (void)hipEventDestroy(e);
+    if (c->pace.have_events)
+        for (auto& pr : c->pace.ev) { (void)hipEventDestroy(pr[0]); (void)hipEventDestroy(pr[1]); }
     if (c->tree_hctl) { (void)hipHostFree(c->tree_hctl); (void)hipEventDestroy(c->tree_ev[0]); (void)hipEventDestroy(c->tree_ev[1]); }
     for (auto& p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     (void)hipStreamDestroy(c->stream);

@@ -40,6 +40,20 @@ struct FlatState {
     bool idle_since_launch = true;    // the host has drained the stream since the last of these launches (ctx_stream_sync)
 };
 
+// Online control of the store pacer's target rate (flat_kernels.hip, pace_target / pace_observe): the last few paced
+// E-step launches are bracketed by event pairs that are looked at -- never waited for -- when the next one is launched.
+struct PaceCtl {
+    static constexpr int RING = 4;
+    double target = 0.0;               // GB/s offered by the next paced launch; 0: not initialised
+    int strikes = 0;                   // consecutive launches that ran longer than their target explains
+    int J = 0;                         // the row length the state belongs to (another J starts over)
+    int steps_down = 0;                // how often the target was lowered (reported by hgmm_pace_info)
+    hipEvent_t ev[RING][2] = {};
+    double tgt_at[RING] = {}, bytes_at[RING] = {};
+    unsigned head = 0, tail = 0;
+    bool have_events = false;
+};
+
 struct HostComm;                           // hgmm_api.hip
 struct IpcComm;                            // hgmm_api.hip: one-shot peer-to-peer exchange over mapped peer memory
 
@@ -82,6 +96,7 @@ struct hgmm_ctx {
 
     // ---- flat EM ----------------------------------------------------------------
     hgmm::FlatState flat;
+    hgmm::PaceCtl pace;
     hgmm::DevBuf f_block;                     // float [10][Jpad]: the allocation behind the four arrays below
     hgmm::DevBuf f_mu, f_cov, f_w, f_inv;     // float model parameters (reference layout): NON-OWNING slices of f_block
     hgmm::DevBuf f_pack;                      // float [7][Jpad] packed E-step params
