@@ -417,6 +417,59 @@ def test_c3_training_matches_oracle_fixture(ctx, variant, cov_type):
     assert np.array_equal(np.array(_label_checksum(np.where(clear, am, 0)), dtype=np.uint64), g[k + "checksum_clear"])
 
 
+def test_store_pacer_controller_backs_off(monkeypatch):
+    """The materialising E-step offers its rows at a controlled rate (StorePacer / PaceCtl, csrc/flat_kernels.hip): a
+    context started far above the write path's knee (HGMM_PACE_START=7800) must walk down -- launches that run > 6 %
+    longer than the rate explains are strikes, three in a row lower it by 2 % -- without ever waiting for its evidence,
+    and the table it writes is the same whatever the rate; a fixed rate (HGMM_ESTEP_TARGET_GBS) switches the controller
+    off; small tables are not judged."""
+    import hgmm_amd
+    N, J = 1_000_000, 800
+    X = np.random.RandomState(0).rand(N, 3).astype(np.float32)
+    idx = np.random.RandomState(100).choice(N, J, replace=False)
+    mu, w = X[idx].copy(), (np.ones(J) / J).astype(np.float32)
+    inv = (1 / np.sqrt(0.01 * np.ones((J, 3)))).astype(np.float32)
+    rows = np.arange(0, N, 20011)
+    monkeypatch.setenv("HGMM_PACE_START", "7800")
+    c = hgmm_amd.Context(0)
+    try:
+        c.set_points(X)
+        lr = c.empty((N, J), np.float32)
+        mean0 = c.flat_estep(inv, mu, w, out=lr)[0]
+        ref = lr.get()[rows].copy()
+        assert c.pace_info() == (7800.0, 0)
+        for _ in range(20):
+            c.flat_estep(inv, mu, w, out=lr, lazy_mean=True)            # nobody waits: the evidence is only ever queried
+        c.synchronize()                                                  # (... so launches enqueued far ahead mostly go unobserved)
+        for _ in range(40):
+            mean1 = c.flat_estep(inv, mu, w, out=lr)[0]
+        target, steps = c.pace_info()
+        print("store pacer: 7800 -> %.0f GB/s after %d steps down in 61 launches" % (target, steps))
+        assert steps >= 2 and 5800.0 <= target < 7800.0 * 0.98 ** 2 + 1.0
+        assert np.array_equal(lr.get()[rows], ref) and mean1 == mean0           # the rate does not touch the values
+        # a small table (4 MB) is neither paced down nor judged
+        c.set_points(X[:5000])
+        small = c.empty((5000, J), np.float32)
+        for _ in range(8):
+            c.flat_estep(inv, mu, w, out=small)
+        assert c.pace_info() == (target, steps)
+        del small, lr
+    finally:
+        c.close()
+    monkeypatch.delenv("HGMM_PACE_START")
+    monkeypatch.setenv("HGMM_ESTEP_TARGET_GBS", "6000")
+    c = hgmm_amd.Context(0)
+    try:
+        c.set_points(X)
+        lr = c.empty((N, J), np.float32)
+        for _ in range(12):
+            c.flat_estep(inv, mu, w, out=lr)
+        assert c.pace_info() == (6000.0, 0)
+        assert np.array_equal(lr.get()[rows], ref)
+    finally:
+        c.close()
+
+
 def test_profiler_reports_kernel_time(ctx):
     X = np.random.RandomState(1).rand(20000, 3).astype(np.float32)
     ctx.set_points(X)
