@@ -259,3 +259,23 @@ def test_a_hanging_backend_setup_times_out_and_falls_back():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][0])
     assert "rccl" in d["config"]["fallback"] and "peer exchange" in d["config"]["collective"]
+
+
+def test_stdout_carries_the_json_line_only():
+    """bench.py's stdout guard: whatever libraries print to file descriptor 1 while the bench runs (RCCL's version
+    banner through C stdio, flushed at exit) lands on stderr; the restored stdout carries the one line."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, os, ctypes; sys.path.insert(0, %r); import bench\n"
+            "libc = ctypes.CDLL(None)\n"
+            "g = bench._StdoutGuard()\n"
+            "libc.puts(b'banner through C stdio (buffered until exit)')\n"
+            "os.write(1, b'raw write to fd 1\\n')\n"
+            "g.restore()\n"
+            "print('{\"the\": \"line\"}'); sys.stdout.flush()\n"
+            "g2 = bench._StdoutGuard()\n"
+            "libc.puts(b'teardown chatter')\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip() == '{"the": "line"}', r.stdout
+    assert "banner through C stdio" in r.stderr and "raw write to fd 1" in r.stderr and "teardown chatter" in r.stderr
