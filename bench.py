@@ -980,6 +980,22 @@ def rank_main(args):
         ctx.profile_enable(False)
         f_ms, f_n = ctx.profile_get("util_fill")
         out["roofline"]["row_pitch_store_ceiling_GBs"] = 4 * N_POINTS * J_COMP / (f_ms / f_n * 1e-3) / 1e9
+        # ... and what a pure store stream reaches when it is OFFERED at a fixed rate like the E-step's rows (fillbench mode 6:
+        # the E-step's store pattern without its arithmetic, released by the same StorePacer): the best of three rates around
+        # the knee -- the ceiling the paced kernel is up against (un-paced the same stream collapses to ~5.5 TB/s)
+        best = 0.0
+        for rate in (6600.0, 6800.0, 7000.0):
+            for _ in range(3):
+                ctx.util_fill(lr, rate, True, 6, 2)
+            ctx.profile_reset()
+            ctx.profile_enable(True)
+            for _ in range(10):
+                ctx.util_fill(lr, rate, True, 6, 2)
+            ctx.profile_enable(False)
+            f_ms, f_n = ctx.profile_get("util_fill")
+            best = max(best, 4 * N_POINTS * J_COMP / (f_ms / f_n * 1e-3) / 1e9)
+        out["roofline"]["paced_store_stream_ceiling_GBs"] = best
+        out["roofline"]["frac_of_paced_store_ceiling"] = out["roofline"]["achieved"] / best
         lr.free()
         for name, leg in (("bunny", bunny_leg), ("hgmm", hgmm_leg), ("tree_1M", tree_1m_leg), ("fullcov", fullcov_leg),
                           ("kmeans_init", kmeans_leg), ("registration", registration_leg)):

@@ -1,6 +1,7 @@
 // Context lifecycle, device memory, point upload, RCCL attachment and the hipEvent profiler
 // behind the C ABI of include/hgmm.h.
 #include "hgmm_ctx.h"
+#include "wave_ops.h"
 
 #include <fcntl.h>
 #include <sched.h>
@@ -363,6 +364,28 @@ __global__ void f64_to_f32(const double* __restrict__ in, int64_t n, float* __re
 // wave writes 1 KiB adjacent to its neighbours').  MODE 1: each workgroup owns one contiguous
 // region and streams through it (the E-step's pattern: every wave a private sequential stream).
 // MODE 2: like 0 with four independent 16-byte stores per thread per step.
+// MODE 6 (paced): the E-step's store pattern without its arithmetic -- every wave writes runs of `run4` float4 (12.8 KB at
+// J = 800: four rows), runs dealt round-robin over the waves, each run released by a StorePacer whose period makes all
+// waves together offer `pace16`'s rate: what the write path takes when it is offered exactly that much.
+template <bool NT>
+__global__ __launch_bounds__(256) void util_fill_paced_kernel(float* __restrict__ p, int64_t n4, int run4, int pace16) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 one = {1.f, 1.f, 1.f, 1.f};
+    f4* q = reinterpret_cast<f4*>(p);
+    const int64_t nw = (int64_t)gridDim.x * 4, gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int64_t nruns = (n4 + run4 - 1) / run4;
+    StorePacer pacer(pace16, gw, nw);
+    for (int64_t r = gw; r < nruns; r += nw) {
+        const int64_t lo = r * run4, hi = (lo + run4 < n4) ? lo + run4 : n4;
+        pacer.wait();
+        for (int64_t i = lo + lane; i < hi; i += 64) {
+            if (NT) __builtin_nontemporal_store(one, q + i);
+            else q[i] = one;
+        }
+    }
+}
+
 template <bool NT, int MODE>
 __global__ __launch_bounds__(256) void util_fill_kernel(float* __restrict__ p, int64_t n4, float v) {
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -434,6 +457,21 @@ extern "C" int hgmm_util_fill_f32(hgmm_ctx* c, float* dev, int64_t n, float valu
         if (mode == 0) { if (nt) FILL(true, 0); else FILL(false, 0); }
         else if (mode == 1) { if (nt) FILL(true, 1); else FILL(false, 1); }
         else if (mode == 2) { if (nt) FILL(true, 2); else FILL(false, 2); }
+        else if (mode == 6) {       // paced runs: value = offered GB/s (0: un-paced), grid = cus * gmul workgroups of 4 waves
+            const int run4 = 800;                                   // 12.8 KB: four rows of J = 800
+            int khz = c->wall_khz;
+            if (khz <= 0) {
+                if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
+                c->wall_khz = khz;
+            }
+            int pace16 = 0;
+            if (value > 0.f) {
+                const double seconds = 16.0 * run4 * (double)grid * 4.0 / ((double)value * 1e9);
+                pace16 = (int)(seconds * (double)khz * 1e3 * 16.0 + 0.5);
+            }
+            if (nt) util_fill_paced_kernel<true><<<grid, 256, 0, c->stream>>>(dev, n4, run4, pace16);
+            else util_fill_paced_kernel<false><<<grid, 256, 0, c->stream>>>(dev, n4, run4, pace16);
+        }
         else if (mode == 4) {       // mode 3's chunks written by a whole 256-thread workgroup
             if (nt) util_fill_kernel<true, 3><<<grid, 256, 0, c->stream>>>(dev, n4, value);
             else util_fill_kernel<false, 3><<<grid, 256, 0, c->stream>>>(dev, n4, value);

@@ -182,4 +182,31 @@ __device__ __forceinline__ int wave_in_block() {
     return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 }
 
+// Per-wave store schedule on the constant-rate wall clock (flat_kernels.hip, "Store pacing", explains why).
+struct StorePacer {
+    unsigned long long next;
+    unsigned period16, frac;           // period in 1/16 ticks of the wall clock; 0 = no pacing
+    // wave `gw` of `nw`: the waves' schedules are staggered evenly over one period -- started in phase, all of them would
+    // store at the same moments, a burst per period
+    __device__ __forceinline__ StorePacer(int p16, long long gw, long long nw) : next(0), period16((unsigned)p16), frac(0) {
+        if (period16) next = wall_clock64() + (unsigned long long)(((unsigned long long)period16 * (unsigned long long)gw / (unsigned long long)nw) >> 4);
+    }
+    // call right before a group's stores
+    __device__ __forceinline__ void wait() {
+        if (!period16) return;
+        unsigned long long now = wall_clock64();
+        while (now < next) {
+            __builtin_amdgcn_s_sleep(1);
+            now = wall_clock64();
+        }
+        // a wave that has fallen behind by more than a period (its arithmetic could not keep up: low clocks, a late
+        // start) is re-anchored instead of catching up in a burst -- bursts are what the write path punishes
+        const unsigned period = period16 >> 4;
+        if (now > next + period) next = now;
+        frac += period16;
+        next += frac >> 4;
+        frac &= 15u;
+    }
+};
+
 }  // namespace hgmm
