@@ -475,7 +475,7 @@ def estep_roofline_leg(ctx, lr, init, fitted, args):
         except Exception:
             traffic = None
     cold_avg = float(np.mean(cold))
-    pace = getattr(ctx, "pace_info", lambda: (None, None))()
+    pace = getattr(ctx, "pace_info", lambda: (None, None, None))()
     # headline: the mean over the three call patterns the kernel was timed in (equal weights) -- blocking calls, an
     # unwaited-for stream, the launches right behind a fit; each pattern's own figure stays beside it
     pattern_ms = [avg_s * 1e3, stream_s * 1e3, cold_avg] if stream_s else [avg_s * 1e3, cold_avg]
@@ -489,9 +489,10 @@ def estep_roofline_leg(ctx, lr, init, fitted, args):
             "patterns_ms": {"blocking_calls": avg_s * 1e3, "unsynchronised_stream": stream_s * 1e3,
                             "right_behind_a_fit": cold_avg},
             "blocking_calls_frac": blocking / HBM_PEAK_GBS,
-            "store_pacer": {"offered_GBs": pace[0], "controller_steps_down": pace[1],
-                            "rule": "rows offered at this rate (wall-clock schedule per wave); starts at 6600 and backs off 2 % "
-                                    "after three launches in a row that ran > 6 % longer than the rate explains"},
+            "store_pacer": {"offered_GBs": pace[0], "controller_steps_down": pace[1], "controller_probes_held": pace[2],
+                            "rule": "rows offered at this rate (wall-clock schedule per wave); starts at 6600, backs off 2 % after "
+                                    "three launches in a row that ran > 6 % longer than the rate explains, probes 2 % upwards "
+                                    "after 24 clean launches (one long launch takes a probe back and caps the rate)"},
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": mean_s * 1e3, "launches": e_n + s_n + len(cold),
             "steady_state_rule": "40 untimed launches (15 of them the cold ones below) precede the timed ones; every "
                                  "launch is a blocking hgmm_flat_estep call (the host reads the mean, ~25 us idle)",

@@ -1760,7 +1760,7 @@ static bool env_flag(const char* name, bool dflt) {
 // with temperature, the stacks of the particular chip), and past it the kernel does not degrade gracefully -- it drops
 // to ~5.3 TB/s; the knee is soft besides: at 6700 one launch in three already ran 3 - 18 % long in bursts, at 6600 the
 // 150 launches of a bench run stayed within 488 - 506 us of their 487 (profiles/r04).  So the rate starts at 6600 and is
-// CONTROLLED, downwards only: a paced launch that runs more than 6 % longer than its
+// CONTROLLED: a paced launch that runs more than 6 % longer than its
 // target explains counts as a strike, three strikes in a row lower the target by 2 % (never below PACE_FLOOR_GBS).  The
 // evidence comes from event pairs around the last few launches that are queried -- never waited for -- at the next
 // launch, so the stream is not disturbed.  Launches that are not store-bound by construction (the row-maximum loop,
@@ -1771,32 +1771,69 @@ constexpr double PACE_FLOOR_GBS = 5800.0;
 constexpr double PACE_STRIKE_RATIO = 1.06;
 constexpr double PACE_STEP = 0.98;
 constexpr double PACE_MIN_BYTES = 256.0 * 1024 * 1024;
+// ... and upwards, carefully: the knee sat at 7.0 TB/s on one box and at 7.6 on another (profiles/r04/paced_fill_lease*.log).
+// After PACE_PROBE_AFTER clean launches in a row the rate is raised by 2 % on probation: three clean launches keep it, the
+// first long one takes it back, remembers the rate as a ceiling and doubles the wait before the next probe.
+constexpr int PACE_PROBE_AFTER = 24, PACE_PROBE_AFTER_MAX = 4096;
+constexpr double PACE_PROBE_STEP = 1.02;
+constexpr double PACE_CEILING_GBS = 7600.0;
 
 // the rate the next paced launch of J-float rows offers
 static double pace_target(hgmm_ctx* c, int J) {
     const int fixed = env_int("HGMM_ESTEP_TARGET_GBS", -1);
     if (fixed >= 0) return (double)fixed;
     PaceCtl& p = c->pace;
-    if (p.target <= 0.0 || p.J != J) { p.target = (double)env_int("HGMM_PACE_START", ESTEP_TARGET_GBS); p.strikes = 0; p.J = J; }
+    if (p.target <= 0.0 || p.J != J) {
+        p.target = (double)env_int("HGMM_PACE_START", ESTEP_TARGET_GBS);
+        p.strikes = p.clean = p.probe_seen = 0;
+        p.probe_after = PACE_PROBE_AFTER;
+        p.probe_base = 0.0;
+        p.ceiling = 1e30;
+        p.J = J;
+    }
     return p.target;
 }
 // look at the launches that have finished since the last call (no waiting)
 static void pace_poll(hgmm_ctx* c) {
     PaceCtl& p = c->pace;
+    const bool probing_allowed = env_flag("HGMM_ESTEP_PROBE", true);
     while (p.tail != p.head) {
         const unsigned s = p.tail % PaceCtl::RING;
         if (hipEventQuery(p.ev[s][1]) != hipSuccess) { (void)hipGetLastError(); break; }
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.ev[s][0], p.ev[s][1]) == hipSuccess && p.tgt_at[s] == p.target) {
             const double ideal_ms = p.bytes_at[s] / (p.tgt_at[s] * 1e9) * 1e3;
-            if ((double)ms > PACE_STRIKE_RATIO * ideal_ms) {
+            const bool slow = (double)ms > PACE_STRIKE_RATIO * ideal_ms;
+            if (p.probe_base > 0.0) {
+                // a probe is running: ONE long launch ends it (the memory system has said no), three clean ones accept it
+                if (slow) {
+                    p.ceiling = p.target;
+                    p.target = p.probe_base;
+                    p.probe_base = 0.0;
+                    p.probe_after = std::min(PACE_PROBE_AFTER_MAX, 2 * p.probe_after);
+                    p.clean = 0;
+                    p.strikes = 0;
+                } else if (++p.probe_seen >= 3) {
+                    p.probe_base = 0.0;
+                    p.steps_up++;
+                    p.clean = 0;
+                }
+            } else if (slow) {
+                p.clean = 0;
                 if (++p.strikes >= 3) {
+                    p.ceiling = std::min(p.ceiling, p.target);
                     p.target = std::max(PACE_FLOOR_GBS, p.target * PACE_STEP);
                     p.strikes = 0;
                     p.steps_down++;
                 }
             } else {
                 p.strikes = 0;
+                const double up = p.target * PACE_PROBE_STEP;
+                if (probing_allowed && ++p.clean >= p.probe_after && up < p.ceiling * 0.995 && up <= PACE_CEILING_GBS) {
+                    p.probe_base = p.target;
+                    p.target = up;
+                    p.probe_seen = 0;
+                }
             }
         }
         p.tail++;
@@ -2297,12 +2334,13 @@ extern "C" int hgmm_flat_estep_dev(hgmm_ctx* c, int cov_type, int variant, int J
     return HGMM_OK;
 }
 
-extern "C" int hgmm_pace_info(hgmm_ctx* c, double* target_gbs_out, int* steps_down_out) {
+extern "C" int hgmm_pace_info(hgmm_ctx* c, double* target_gbs_out, int* steps_down_out, int* steps_up_out) {
     if (!c) return HGMM_ERR_ARG;
     pace_poll(c);
     const int fixed = env_int("HGMM_ESTEP_TARGET_GBS", -1);
     if (target_gbs_out) *target_gbs_out = fixed >= 0 ? (double)fixed : (c->pace.target > 0.0 ? c->pace.target : (double)ESTEP_TARGET_GBS);
     if (steps_down_out) *steps_down_out = c->pace.steps_down;
+    if (steps_up_out) *steps_up_out = c->pace.steps_up;
     return HGMM_OK;
 }
 

@@ -48,6 +48,12 @@ struct PaceCtl {
     int strikes = 0;                   // consecutive launches that ran longer than their target explains
     int J = 0;                         // the row length the state belongs to (another J starts over)
     int steps_down = 0;                // how often the target was lowered (reported by hgmm_pace_info)
+    int steps_up = 0;                  // probes upwards that held
+    // probing upwards: after `probe_after` clean launches in a row the next ones are offered 2 % more; three clean ones
+    // make that the new target, a single long one ends the probe, caps the rate below it and doubles `probe_after`
+    double ceiling = 1e30;             // a rate that was seen to congest: never probed again
+    double probe_base = 0.0;           // > 0: a probe is running, this is the rate to fall back to
+    int clean = 0, probe_after = 0, probe_seen = 0;
     hipEvent_t ev[RING][2] = {};
     double tgt_at[RING] = {}, bytes_at[RING] = {};
     unsigned head = 0, tail = 0;

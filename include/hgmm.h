@@ -159,10 +159,12 @@ int hgmm_flat_predict_dev(hgmm_ctx* ctx, int cov_type, int variant, int J,
                           const float* dev_mu, const float* dev_inv_std, const float* dev_w,
                           int32_t* dev_labels);
 /* The store pacer of the two N x J writers (hgmm_flat_estep*, hgmm_flat_log_prob): *target_gbs_out = the rate the next
- * paced launch offers its rows at (GB/s; 0 = un-paced), *steps_down_out = how often the context's controller has lowered
- * it since the context was created (it starts just below the write path's congestion knee and backs off, 2 % at a time,
- * when three launches in a row run more than 6 % longer than the target explains).  Measurement aid, no reference counterpart. */
-int hgmm_pace_info(hgmm_ctx* ctx, double* target_gbs_out, int* steps_down_out);
+ * paced launch offers its rows at (GB/s; 0 = un-paced), *steps_down_out / *steps_up_out = how often the context's
+ * controller has lowered it / raised it for good since the context was created.  The rate starts just below the write
+ * path's congestion knee; three launches in a row that run more than 6 % longer than the rate explains lower it by 2 %;
+ * after a run of clean launches it is raised by 2 % on probation (one long launch takes that back and caps the rate).
+ * Measurement aid, no reference counterpart. */
+int hgmm_pace_info(hgmm_ctx* ctx, double* target_gbs_out, int* steps_down_out, int* steps_up_out);
 /* Un-normalised per-pair log-densities log N(x_i; mu_j, diag) -> dev_log_prob [N,J]
  * (estimate_log_prob / estimate_log_prob_spherical, gmm_waymo gmm_impl.py:53-78). */
 int hgmm_flat_log_prob(hgmm_ctx* ctx, int cov_type, int J, const float* mu, const float* inv_std,

@@ -422,7 +422,8 @@ def test_store_pacer_controller_backs_off(monkeypatch):
     context started far above the write path's knee (HGMM_PACE_START=7800) must walk down -- launches that run > 6 %
     longer than the rate explains are strikes, three in a row lower it by 2 % -- without ever waiting for its evidence,
     and the table it writes is the same whatever the rate; a fixed rate (HGMM_ESTEP_TARGET_GBS) switches the controller
-    off; small tables are not judged."""
+    off; small tables are not judged.  (Probing upwards -- 2 % on probation after 24 clean launches -- cannot happen above
+    PACE_CEILING_GBS = 7600, so `ups` stays 0 here.)"""
     import hgmm_amd
     N, J = 1_000_000, 800
     X = np.random.RandomState(0).rand(N, 3).astype(np.float32)
@@ -437,22 +438,22 @@ def test_store_pacer_controller_backs_off(monkeypatch):
         lr = c.empty((N, J), np.float32)
         mean0 = c.flat_estep(inv, mu, w, out=lr)[0]
         ref = lr.get()[rows].copy()
-        assert c.pace_info() == (7800.0, 0)
+        assert c.pace_info() == (7800.0, 0, 0)
         for _ in range(20):
             c.flat_estep(inv, mu, w, out=lr, lazy_mean=True)            # nobody waits: the evidence is only ever queried
         c.synchronize()                                                  # (... so launches enqueued far ahead mostly go unobserved)
         for _ in range(40):
             mean1 = c.flat_estep(inv, mu, w, out=lr)[0]
-        target, steps = c.pace_info()
+        target, steps, ups = c.pace_info()
         print("store pacer: 7800 -> %.0f GB/s after %d steps down in 61 launches" % (target, steps))
-        assert steps >= 2 and 5800.0 <= target < 7800.0 * 0.98 ** 2 + 1.0
+        assert steps >= 2 and ups == 0 and 5800.0 <= target < 7800.0 * 0.98 ** 2 + 1.0
         assert np.array_equal(lr.get()[rows], ref) and mean1 == mean0           # the rate does not touch the values
         # a small table (4 MB) is neither paced down nor judged
         c.set_points(X[:5000])
         small = c.empty((5000, J), np.float32)
         for _ in range(8):
             c.flat_estep(inv, mu, w, out=small)
-        assert c.pace_info() == (target, steps)
+        assert c.pace_info() == (target, steps, ups)
         del small, lr
     finally:
         c.close()
@@ -464,7 +465,7 @@ def test_store_pacer_controller_backs_off(monkeypatch):
         lr = c.empty((N, J), np.float32)
         for _ in range(12):
             c.flat_estep(inv, mu, w, out=lr)
-        assert c.pace_info() == (6000.0, 0)
+        assert c.pace_info() == (6000.0, 0, 0)
         assert np.array_equal(lr.get()[rows], ref)
     finally:
         c.close()

@@ -34,6 +34,6 @@ for start in (None, "7600"):
             pat = "behind m_step"
         ctx.profile_enable(False)
         ms, n = ctx.profile_get("flat_estep")
-        print("  block %d (%-13s): kernel %.4f ms   pacer now at %.0f GB/s after %d steps down" % ((blk, pat, ms / n) + ctx.pace_info()), flush=True)
+        print("  block %d (%-13s): kernel %.4f ms   pacer now at %.0f GB/s after %d steps down, %d probes held" % ((blk, pat, ms / n) + ctx.pace_info()), flush=True)
     del lr
     ctx.close()
