@@ -1130,7 +1130,8 @@ __global__ __launch_bounds__(BLOCK) void flat_mstep_kernel(
     };
     // (Round 4, measured and dropped: two rows ahead instead of one -- three buffers in rotation, loop unrolled by three --
     //  0.547 ms against 0.531; a StorePacer in front of every row load, 0.55 - 0.56 ms at every target rate.  Neither more
-    //  nor fewer loads in flight move the read side: profiles/r04/mstep_pace.log, mstep_prefetch2.log.)
+    //  nor fewer loads in flight move the read side: profiles/r04/mstep_pace.log, mstep_prefetch2.log.  Non-temporal
+    //  loads: 0.563 against 0.513 ms in a stream of M-steps.)
     float cur[K], nxt[K];
     if (cnt > 0) load_row(base, cur);
     for (int64_t it = 0; it < cnt; ++it) {
