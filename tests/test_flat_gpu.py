@@ -417,6 +417,36 @@ def test_c3_training_matches_oracle_fixture(ctx, variant, cov_type):
     assert np.array_equal(np.array(_label_checksum(np.where(clear, am, 0)), dtype=np.uint64), g[k + "checksum_clear"])
 
 
+def test_c3_training_20_iterations_match_oracle_fixture(ctx):
+    """The headline configuration once more, where the fit has left its initial parameters far behind: 20 fused EM
+    iterations on the bench frame (flavour W / diag) against oracle.flat_em's float64 loop on the SAME million points
+    (tests/golden/flat_uniform1M_J800_oracle_20it.npz, tools/gen_oracle_fixtures.py --only flat1m_long): the whole
+    log-likelihood trace and the final model."""
+    g = load_golden("flat_uniform1M_J800_oracle_20it.npz")
+    N, J, iters = int(g["N"]), int(g["J"]), int(g["iters"])
+    X = np.random.RandomState(int(g["cloud_seed"])).rand(N, 3).astype(np.float32)
+    idx = np.random.RandomState(int(g["init_seed"])).choice(N, J, replace=False)
+    assert np.array_equal(idx, g["init_idx"])
+    mu0 = X[idx].copy()
+    w0 = (np.ones(J) / J).astype(np.float32)
+    cov0 = (0.1 * np.ones((J, 3))).astype(np.float32)
+    ctx.set_points(X)
+    inv, mu, w, cov, lls, _ = ctx.flat_train(iters, 0.0, mu0, cov0, w0, "diag", "W")
+    d_ll = np.abs(np.asarray(lls, dtype=np.float64) - g["lls"]).max()
+    live = g["w"] > 1e-5
+    d_mu = np.abs(mu - g["mu"])[live].max()
+    print("C3 20 iterations: max|dlls| %.3g (trace %.4f .. %.4f), max|dmu| %.3g, max rel dw %.3g, max rel dcov %.3g, live %d"
+          % (d_ll, g["lls"][0], g["lls"][-1], d_mu, np.abs(w / g["w"] - 1)[live].max(), np.abs(cov / g["cov"] - 1)[live].max(),
+             int(live.sum())))
+    # (measured: 5e-7 / 4e-7 / 5e-6 / 9e-6 -- the bounds leave a factor of ten)
+    assert len(lls) == iters and d_ll <= 5e-6
+    assert np.abs(mu - mu0).max() > 1e-2                          # the fit has moved
+    assert d_mu <= 5e-6
+    np.testing.assert_allclose(w[live], g["w"][live], rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(cov[live], g["cov"][live], rtol=2e-4, atol=1e-9)
+    np.testing.assert_allclose(inv[live], g["inv"][live], rtol=1e-4)
+
+
 def test_store_pacer_controller_backs_off(monkeypatch):
     """The materialising E-step offers its rows at a controlled rate (StorePacer / PaceCtl, csrc/flat_kernels.hip): a
     context started far above the write path's knee (HGMM_PACE_START=7800) must walk down -- launches that run > 6 %

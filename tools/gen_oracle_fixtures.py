@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Full-size oracle fixtures for the sizes bench.py prints numbers for (task 1).
 
-    python tools/gen_oracle_fixtures.py [--only c4|tree1m|fullcov1m|flat1m]
+    python tools/gen_oracle_fixtures.py [--only c4|tree1m|fullcov1m|flat1m|flat1m_long]
 
 Unlike tools/gen_golden.py (which runs the REFERENCE and needs /root/reference) this script runs the
 committed NumPy oracle (oracle/hgmm_tree.py, itself pinned to reference-generated fixtures by
@@ -268,6 +268,23 @@ def gen_flat1m():
     print("wrote %s, %.0f s" % (path, out["oracle_seconds"]))
 
 
+def gen_flat1m_long():
+    """The same frame and initial parameters, flavour W / diag, 20 iterations: where the fit has left its initial
+    parameters far behind (the trajectory the timed region of bench.py runs through)
+    -> tests/golden/flat_uniform1M_J800_oracle_20it.npz (lls[20], mu, w, cov, inv_std)."""
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    N, J, iters = 1_000_000, 800, 20
+    X32 = np.random.RandomState(0).rand(N, 3).astype(np.float32)
+    idx = np.random.RandomState(100).choice(N, J, replace=False)
+    t0 = time.time()
+    inv, mu, w, cov, lls = flat_chunked(f64(X32), iters, f64(X32[idx]), f64((0.1 * np.ones((J, 3))).astype(np.float32)),
+                                        f64((np.ones(J) / J).astype(np.float32)), "diag", "W")
+    path = os.path.join(GOLD, "flat_uniform1M_J800_oracle_20it.npz")
+    np.savez_compressed(path, N=N, J=J, iters=iters, cloud_seed=0, init_seed=100, init_idx=idx.astype(np.int32),
+                        lls=lls, mu=mu, w=w, cov=cov, inv=inv, oracle_seconds=time.time() - t0)
+    print("wrote %s: lls %s ... %s, %.0f s" % (path, lls[:3], lls[-3:], time.time() - t0))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -280,6 +297,8 @@ def main():
         gen_fullcov1m()
     if a.only in ("", "flat1m"):
         gen_flat1m()
+    if a.only in ("", "flat1m_long"):
+        gen_flat1m_long()
 
 
 if __name__ == "__main__":
