@@ -166,6 +166,61 @@ def _ipc_timeout_worker(rank, name, q):
     os._exit(0)
 
 
+@pytest.mark.parametrize("backend", ["ipc", "host"])
+def test_two_full_frames_joint_fit_matches_oracle_fixture(backend):
+    """BASELINE configs[4] in small, at the bench's frame size: two ranks with one 1M-point frame each (bench.synth_frame(0)
+    and (1), initial parameters from frame 0 as bench.py takes them) fit ONE mixture, all-reducing the 57 KB of
+    sufficient statistics per iteration -- against oracle.flat_em's float64 EM on the 2M points together
+    (tests/golden/flat_uniform2x1M_J800_oracle.npz, tools/gen_oracle_fixtures.py --only flat2x1m).  Both ranks must
+    hold the same model (bitwise under the peer exchange, whose sums are rank-ordered on every rank)."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flat_uniform2x1M_J800_oracle.npz"))
+    name = "hgmm_2x1m_%s_%d" % (backend, os.getpid())
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_joint_fit_worker, args=(r, name, q, backend)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in procs)
+    assert not any(isinstance(v, str) for v in got.values()), got
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        mu, w, cov, inv, lls = got[rank]
+        d_ll = np.abs(np.asarray(lls, dtype=np.float64) - g["lls"]).max()
+        d_mu = np.abs(mu - g["mu"]).max()
+        print("rank %d (%s): max|dlls| %.3g max|dmu| %.3g max rel dw %.3g max rel dcov %.3g"
+              % (rank, backend, d_ll, d_mu, np.abs(w / g["w"] - 1).max(), np.abs(cov / g["cov"] - 1).max()))
+        assert len(lls) == int(g["iters"]) and d_ll <= 2e-5 and d_mu <= 5e-6
+        np.testing.assert_allclose(w, g["w"], rtol=1e-5, atol=1e-10)
+        np.testing.assert_allclose(cov, g["cov"], rtol=1e-4, atol=1e-9)
+        np.testing.assert_allclose(inv, g["inv"], rtol=1e-4)
+    for a, b in zip(got[0], got[1]):
+        assert np.array_equal(a, b)
+
+
+def _joint_fit_worker(rank, name, q, backend):
+    try:
+        import hgmm_amd
+        N, J = 1_000_000, 800
+        frame0 = np.random.RandomState(0).rand(N, 3).astype(np.float32)
+        frame = frame0 if rank == 0 else np.random.RandomState(rank).rand(N, 3).astype(np.float32)
+        idx = np.random.RandomState(100).choice(N, J, replace=False)
+        mu0 = frame0[idx].copy()
+        w0 = (np.ones(J) / J).astype(np.float32)
+        cov0 = (0.1 * np.ones((J, 3))).astype(np.float32)
+        ctx = hgmm_amd.Context(0)
+        (ctx.comm_init_ipc if backend == "ipc" else ctx.comm_init_host)(2, rank, name)
+        ctx.set_points(frame)
+        inv, mu, w, cov, lls, _ = ctx.flat_train(3, 0.0, mu0, cov0, w0, "diag", "W")
+        ctx.comm_destroy()
+        ctx.close()
+        q.put((rank, (mu, w, cov, inv, np.asarray(lls))))
+    except BaseException as e:
+        q.put((rank, "rank %d failed: %r" % (rank, e)))
+        raise
+
+
 def _ipc_payloads(rank):
     rs = np.random.RandomState(40 + rank)
     return [rs.randn(n) * 10.0 ** rs.randint(-3, 4) for n in (1, 7, 511, 512, 513, 7170, 65536, 65537, 150001)]
