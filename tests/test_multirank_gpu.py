@@ -166,6 +166,15 @@ def _ipc_timeout_worker(rank, name, q):
     os._exit(0)
 
 
+def test_configs4_eight_frames_joint_fit_matches_oracle_fixture():
+    """BASELINE configs[4] ITSELF -- 8 frames x 1M points, J = 800, one frame per rank, one joint fit with an all-reduce of
+    the sufficient statistics per iteration -- with the 8 ranks sharing the box's ONE GPU (joined by the one-shot peer
+    exchange: each rank maps the seven other exchange buffers): the data path of the 8-GPU run at full size against
+    oracle.flat_em's float64 EM on the 8M points together (tests/golden/flat_uniform8x1M_J800_oracle.npz,
+    tools/gen_oracle_fixtures.py --only flat8x1m).  All eight ranks must end with bitwise the same model."""
+    _full_frames_joint_fit("ipc", 8)
+
+
 @pytest.mark.parametrize("backend", ["ipc", "host"])
 def test_two_full_frames_joint_fit_matches_oracle_fixture(backend):
     """BASELINE configs[4] in small, at the bench's frame size: two ranks with one 1M-point frame each (bench.synth_frame(0)
@@ -173,19 +182,24 @@ def test_two_full_frames_joint_fit_matches_oracle_fixture(backend):
     sufficient statistics per iteration -- against oracle.flat_em's float64 EM on the 2M points together
     (tests/golden/flat_uniform2x1M_J800_oracle.npz, tools/gen_oracle_fixtures.py --only flat2x1m).  Both ranks must
     hold the same model (bitwise under the peer exchange, whose sums are rank-ordered on every rank)."""
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flat_uniform2x1M_J800_oracle.npz"))
-    name = "hgmm_2x1m_%s_%d" % (backend, os.getpid())
+    _full_frames_joint_fit(backend, 2)
+
+
+def _full_frames_joint_fit(backend, world):
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flat_uniform%dx1M_J800_oracle.npz" % world))
+    assert int(g["frames"]) == world
+    name = "hgmm_%dx1m_%s_%d" % (world, backend, os.getpid())
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    procs = [mpc.Process(target=_joint_fit_worker, args=(r, name, q, backend)) for r in range(2)]
+    procs = [mpc.Process(target=_joint_fit_worker, args=(r, name, q, backend, world)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=240) for _ in procs)
+    got = dict(q.get(timeout=300) for _ in procs)
     assert not any(isinstance(v, str) for v in got.values()), got
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank in (0, 1):
+    for rank in range(world):
         mu, w, cov, inv, lls = got[rank]
         d_ll = np.abs(np.asarray(lls, dtype=np.float64) - g["lls"]).max()
         d_mu = np.abs(mu - g["mu"]).max()
@@ -195,11 +209,12 @@ def test_two_full_frames_joint_fit_matches_oracle_fixture(backend):
         np.testing.assert_allclose(w, g["w"], rtol=1e-5, atol=1e-10)
         np.testing.assert_allclose(cov, g["cov"], rtol=1e-4, atol=1e-9)
         np.testing.assert_allclose(inv, g["inv"], rtol=1e-4)
-    for a, b in zip(got[0], got[1]):
-        assert np.array_equal(a, b)
+    for rank in range(1, world):
+        for a, b in zip(got[0], got[rank]):
+            assert np.array_equal(a, b)
 
 
-def _joint_fit_worker(rank, name, q, backend):
+def _joint_fit_worker(rank, name, q, backend, world=2):
     try:
         import hgmm_amd
         N, J = 1_000_000, 800
@@ -210,7 +225,7 @@ def _joint_fit_worker(rank, name, q, backend):
         w0 = (np.ones(J) / J).astype(np.float32)
         cov0 = (0.1 * np.ones((J, 3))).astype(np.float32)
         ctx = hgmm_amd.Context(0)
-        (ctx.comm_init_ipc if backend == "ipc" else ctx.comm_init_host)(2, rank, name)
+        (ctx.comm_init_ipc if backend == "ipc" else ctx.comm_init_host)(world, rank, name)
         ctx.set_points(frame)
         inv, mu, w, cov, lls, _ = ctx.flat_train(3, 0.0, mu0, cov0, w0, "diag", "W")
         ctx.comm_destroy()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Full-size oracle fixtures for the sizes bench.py prints numbers for (task 1).
 
-    python tools/gen_oracle_fixtures.py [--only c4|tree1m|fullcov1m|flat1m|flat1m_long|flat2x1m]
+    python tools/gen_oracle_fixtures.py [--only c4|tree1m|fullcov1m|flat1m|flat1m_long|flat2x1m|flat8x1m]
 
 Unlike tools/gen_golden.py (which runs the REFERENCE and needs /root/reference) this script runs the
 committed NumPy oracle (oracle/hgmm_tree.py, itself pinned to reference-generated fixtures by
@@ -285,20 +285,21 @@ def gen_flat1m_long():
     print("wrote %s: lls %s ... %s, %.0f s" % (path, lls[:3], lls[-3:], time.time() - t0))
 
 
-def gen_flat2x1m():
-    """BASELINE configs[4] in small: TWO of its frames (bench.synth_frame(0), synth_frame(1): 1M uniform points each,
-    seeds = ranks) fitted jointly, initial parameters from frame 0 as bench.py takes them, flavour W / diag, 3
-    iterations -> tests/golden/flat_uniform2x1M_J800_oracle.npz: what two ranks with one frame each must reproduce."""
+def gen_flat2x1m(nframes=2):
+    """BASELINE configs[4]: `nframes` of its frames (bench.synth_frame(r): 1M uniform points each, seed = rank) fitted
+    jointly, initial parameters from frame 0 as bench.py takes them, flavour W / diag, 3 iterations
+    -> tests/golden/flat_uniform<nframes>x1M_J800_oracle.npz: what `nframes` ranks with one frame each must reproduce
+    (2 frames: configs[4] in small; 8 frames: configs[4] itself, the whole joint fit of the 8-GPU run)."""
     f64 = lambda a: np.asarray(a, dtype=np.float64)
     N, J, iters = 1_000_000, 800, 3
-    frames = [np.random.RandomState(r).rand(N, 3).astype(np.float32) for r in (0, 1)]
+    frames = [np.random.RandomState(r).rand(N, 3).astype(np.float32) for r in range(nframes)]
     idx = np.random.RandomState(100).choice(N, J, replace=False)
     t0 = time.time()
     inv, mu, w, cov, lls = flat_chunked(f64(np.concatenate(frames)), iters, f64(frames[0][idx]),
                                         f64((0.1 * np.ones((J, 3))).astype(np.float32)),
                                         f64((np.ones(J) / J).astype(np.float32)), "diag", "W")
-    path = os.path.join(GOLD, "flat_uniform2x1M_J800_oracle.npz")
-    np.savez_compressed(path, N_per_frame=N, frames=2, J=J, iters=iters, init_seed=100, init_idx=idx.astype(np.int32),
+    path = os.path.join(GOLD, "flat_uniform%dx1M_J800_oracle.npz" % nframes)
+    np.savez_compressed(path, N_per_frame=N, frames=nframes, J=J, iters=iters, init_seed=100, init_idx=idx.astype(np.int32),
                         lls=lls, mu=mu, w=w, cov=cov, inv=inv, oracle_seconds=time.time() - t0)
     print("wrote %s: lls %s, %.0f s" % (path, lls, time.time() - t0))
 
@@ -318,7 +319,9 @@ def main():
     if a.only in ("", "flat1m_long"):
         gen_flat1m_long()
     if a.only in ("", "flat2x1m"):
-        gen_flat2x1m()
+        gen_flat2x1m(2)
+    if a.only in ("", "flat8x1m"):
+        gen_flat2x1m(8)
 
 
 if __name__ == "__main__":
