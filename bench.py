@@ -843,6 +843,14 @@ def rank_main(args):
     requested = "host" if hostcomm else args.collective
     rehearsal = "HGMM_BENCH_DEVICE" in os.environ and world > 1
     device = int(os.environ["HGMM_BENCH_DEVICE"]) if rehearsal else local_rank
+    if not rehearsal:
+        # a launcher that narrows every rank's view to its own GPU (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank)
+        # leaves LOCAL_RANK beyond the device count: the rank's GPU is then the one it sees
+        for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            vis = [v for v in os.environ.get(var, "").split(",") if v.strip()]
+            if vis and len(vis) <= local_rank:
+                device = local_rank % len(vis)
+                break
     ctx = hgmm_amd.Context(device)
     info = ctx.device_info()
     kind, failed_kinds, token, hosts = None, [], "", [socket.gethostname()]
