@@ -1069,9 +1069,9 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_pk_kernel(
 // ------------------------------------------------------------------------------------------
 // M-step moments from a materialised responsibility matrix (m_step(X, resp))
 // ------------------------------------------------------------------------------------------
-template <int NV4, int NV1>
+template <int NV4, int NV1, bool ISLOG, bool NTLOAD>
 __global__ __launch_bounds__(BLOCK) void flat_mstep_kernel(
-    const float* __restrict__ X, const float* __restrict__ resp, int is_log,
+    const float* __restrict__ X, const float* __restrict__ resp,
     const float* __restrict__ hint /*[3][Jpad]*/, int64_t n, int J, int Jpad,
     float* __restrict__ partials, int64_t ld, int round_robin) {
     // resp / hint / partials point at this launch's first column; J = valid columns from there,
@@ -1112,37 +1112,34 @@ __global__ __launch_bounds__(BLOCK) void flat_mstep_kernel(
         }
     }
 
-    const float fill = is_log ? NEG_INF : 0.f;
+    constexpr bool is_log = ISLOG;
+    // Every load of the row loop is unconditional: a lane whose column is past J reads column 0 instead (its sums are
+    // zeroed on the way out), and the look-ahead past a wave's last row re-reads that row.  With conditional loads the
+    // compiler cannot count what is in flight and waits with vmcnt(0) -- behind the NEXT row's loads -- before touching the
+    // current row, which serialises each row's load and arithmetic (round 4: 0.526 -> 0.48 ms together with the
+    // non-temporal loads, which a pure read of the same matrix shows to be worth 6.5 -> 7.1 TB/s: profiles/r04/read_probe.log).
+    int off4[NV4 > 0 ? NV4 : 1], off1[NV1 > 0 ? NV1 : 1];
+#pragma unroll
+    for (int s = 0; s < NV4; ++s) { const int jb = (s * 64 + lane) * 4; off4[s] = (jb < J) ? jb : 0; }
+#pragma unroll
+    for (int s = 0; s < NV1; ++s) { const int j = 256 * NV4 + s * 64 + lane; off1[s] = (j < J) ? j : 0; }
     auto load_row = [&](int64_t row, float (&v)[K]) {
         const float* in = resp + row * ld;
 #pragma unroll
         for (int s = 0; s < NV4; ++s) {
-            const int jb = (s * 64 + lane) * 4;
-            float4 t = make_float4(fill, fill, fill, fill);
-            if (jb < J) t = *reinterpret_cast<const float4*>(in + jb);
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const f4v* q = reinterpret_cast<const f4v*>(in + off4[s]);
+            const f4v t = NTLOAD ? __builtin_nontemporal_load(q) : *q;
             v[s * 4 + 0] = t.x; v[s * 4 + 1] = t.y; v[s * 4 + 2] = t.z; v[s * 4 + 3] = t.w;
         }
 #pragma unroll
-        for (int s = 0; s < NV1; ++s) {
-            const int j = 256 * NV4 + s * 64 + lane;
-            v[4 * NV4 + s] = (j < J) ? in[j] : fill;
-        }
+        for (int s = 0; s < NV1; ++s) v[4 * NV4 + s] = NTLOAD ? __builtin_nontemporal_load(in + off1[s]) : in[off1[s]];
     };
-    // (Round 4, measured and dropped: two rows ahead instead of one -- three buffers in rotation, loop unrolled by three --
-    //  0.547 ms against 0.531; a StorePacer in front of every row load, 0.55 - 0.56 ms at every target rate.  Neither more
-    //  nor fewer loads in flight move the read side: profiles/r04/mstep_pace.log, mstep_prefetch2.log.  Non-temporal
-    //  loads: 0.563 against 0.513 ms in a stream of M-steps.)
-    float cur[K], nxt[K];
-    if (cnt > 0) load_row(base, cur);
-    for (int64_t it = 0; it < cnt; ++it) {
-        const int64_t row = base + it * stride;
-        if (it + 1 < cnt) load_row(row + stride, nxt);
-        const float* xp = X + 3 * row;
-        const float x0 = xp[0], x1 = xp[1], x2 = xp[2];
+    auto accumulate = [&](const float (&v)[K], float x0, float x1, float x2) {
         const f2 X0 = f2{x0, x0}, X1 = f2{x1, x1}, X2 = f2{x2, x2}, L2 = f2{LOG2E, LOG2E};
 #pragma unroll
         for (int p = 0; p < KP; ++p) {
-            f2 r = f2{cur[2 * p], cur[2 * p + 1]};
+            f2 r = f2{v[2 * p], v[2 * p + 1]};
             if (is_log) {
                 const f2 t = r * L2;
                 r = f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
@@ -1154,21 +1151,48 @@ __global__ __launch_bounds__(BLOCK) void flat_mstep_kernel(
             b0[p] += rd0 * d0; b1[p] += rd1 * d1; b2[p] += rd2 * d2;
         }
         if (ODD) {
-            const float r = is_log ? __builtin_amdgcn_exp2f(cur[K - 1] * LOG2E) : cur[K - 1];
+            const float r = is_log ? __builtin_amdgcn_exp2f(v[K - 1] * LOG2E) : v[K - 1];
             const float d0 = x0 - c0s, d1 = x1 - c1s, d2 = x2 - c2s;
             const float rd0 = r * d0, rd1 = r * d1, rd2 = r * d2;
             s0s += r;
             a0s += rd0; a1s += rd1; a2s += rd2;
             b0s = fmaf(rd0, d0, b0s); b1s = fmaf(rd1, d1, b1s); b2s = fmaf(rd2, d2, b2s);
         }
-#pragma unroll
-        for (int k = 0; k < K; ++k) cur[k] = nxt[k];
+    };
+    // Two row buffers used in turn (no register copies), rows in order, so the sums are those of the plain loop bit for
+    // bit.  (Round 4, measured and dropped: a StorePacer in front of every row load, 0.55 - 0.56 ms at every target
+    // rate: profiles/r04/mstep_pace.log.)
+    if (cnt > 0) {
+        float bufa[K], bufb[K];
+        load_row(base, bufa);
+        const float* xp = X + 3 * base;
+        float xa0 = xp[0], xa1 = xp[1], xa2 = xp[2];
+        int64_t it = 0;
+        for (; it + 2 <= cnt; it += 2) {
+            const int64_t rb = base + (it + 1) * stride;
+            __builtin_amdgcn_sched_barrier(0);
+            load_row(rb, bufb);
+            const float* xq = X + 3 * rb;
+            const float xb0 = xq[0], xb1 = xq[1], xb2 = xq[2];
+            __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks the loads to just before their use)
+            accumulate(bufa, xa0, xa1, xa2);
+            __builtin_amdgcn_sched_barrier(0);
+            const int64_t ra = base + ((it + 2 < cnt) ? it + 2 : cnt - 1) * stride;
+            load_row(ra, bufa);
+            const float* xr = X + 3 * ra;
+            xa0 = xr[0]; xa1 = xr[1]; xa2 = xr[2];
+            __builtin_amdgcn_sched_barrier(0);
+            accumulate(bufb, xb0, xb1, xb2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (it < cnt) accumulate(bufa, xa0, xa1, xa2);
     }
     __shared__ float sh[FLAT_NSTAT * L::CAP];
     const int w = wave_in_block();
     constexpr int ST = L::CAP;
     auto put = [&](int k, bool first, float v0, float v1, float v2, float v3, float v4, float v5, float v6) {
         float* q = sh + L::j_of(k, lane);
+        if (L::j_of(k, lane) >= J) v0 = v1 = v2 = v3 = v4 = v5 = v6 = 0.f;   // (that lane summed column 0's values)
         if (first) { q[0 * ST] = v0; q[1 * ST] = v1; q[2 * ST] = v2; q[3 * ST] = v3; q[4 * ST] = v4; q[5 * ST] = v5; q[6 * ST] = v6; }
         else { q[0 * ST] += v0; q[1 * ST] += v1; q[2 * ST] += v2; q[3 * ST] += v3; q[4 * ST] += v4; q[5 * ST] += v5; q[6 * ST] += v6; }
     };
@@ -2415,17 +2439,26 @@ static int flat_mstep_enqueue(hgmm_ctx* c, int cov_type, int variant, int J, con
     }
     int grid = grid_for(c, c->n, env_int("HGMM_MSTEP_BPC", 2));
     if (env_int("HGMM_MSTEP_GRID", 0) > 0) grid = std::min(grid_for(c, c->n, 4), env_int("HGMM_MSTEP_GRID", 0));
-    const int rr = env_int("HGMM_MSTEP_RR", 0);
+    const int rr = env_int("HGMM_MSTEP_RR", 1);     // rows dealt round-robin: 0.480 against 0.492 ms (profiles/r04/mstep_nt_rr_sweep.log)
     const float* X = c->x_aos.as<float>();
     float* part = c->f_partials.as<float>();
     const float* hint = c->f_hint.as<float>();
     int valid_j = 0;
+    const bool ntload = env_flag("HGMM_MSTEP_NT", true);
+#define MSTEP_LAUNCH(A, B, RESP, HINT, JV, PART)                                                               \
+    do {                                                                                                       \
+        if (is_log) {                                                                                          \
+            if (ntload) flat_mstep_kernel<A, B, true, true><<<grid, BLOCK, 0, c->stream>>>(X, RESP, HINT, c->n, JV, f.Jpad, PART, (int64_t)J, rr);  \
+            else flat_mstep_kernel<A, B, true, false><<<grid, BLOCK, 0, c->stream>>>(X, RESP, HINT, c->n, JV, f.Jpad, PART, (int64_t)J, rr);       \
+        } else {                                                                                               \
+            if (ntload) flat_mstep_kernel<A, B, false, true><<<grid, BLOCK, 0, c->stream>>>(X, RESP, HINT, c->n, JV, f.Jpad, PART, (int64_t)J, rr); \
+            else flat_mstep_kernel<A, B, false, false><<<grid, BLOCK, 0, c->stream>>>(X, RESP, HINT, c->n, JV, f.Jpad, PART, (int64_t)J, rr);      \
+        }                                                                                                      \
+    } while (0)
     if (f.chunked) {
         ProfScope prof(c, HGMM_K_FLAT_MSTEP);
         for (int ci = 0; ci < f.nchunks; ++ci)
-            flat_mstep_kernel<0, CH_SLOTS><<<grid, BLOCK, 0, c->stream>>>(
-                X, dev_resp + ci * CH_J, is_log, hint + ci * CH_J, c->n, chunk_valid(f, ci), f.Jpad,
-                part + ci * CH_J, (int64_t)J, rr);
+            MSTEP_LAUNCH(0, CH_SLOTS, dev_resp + ci * CH_J, hint + ci * CH_J, chunk_valid(f, ci), part + ci * CH_J);
         valid_j = f.nchunks * CH_J;
     } else {
         ProfScope prof(c, HGMM_K_FLAT_MSTEP);
@@ -2433,13 +2466,13 @@ static int flat_mstep_enqueue(hgmm_ctx* c, int cov_type, int variant, int J, con
         pick_layout(J, &nv4, &nv1);
 #define MSTEP_M(A, B)                                                                              \
     do {                                                                                           \
-        flat_mstep_kernel<A, B><<<grid, BLOCK, 0, c->stream>>>(X, dev_resp, is_log, hint, c->n, J,  \
-                                                              f.Jpad, part, (int64_t)J, rr);      \
+        MSTEP_LAUNCH(A, B, dev_resp, hint, J, part);                                               \
         valid_j = 256 * A + 64 * B;                                                                \
     } while (0)
         LAYOUT_DISPATCH(nv4, nv1, MSTEP_M);
 #undef MSTEP_M
     }
+#undef MSTEP_LAUNCH
     HGMM_HIP(c, hipGetLastError());
     c->flat.last_kernel = 2;                               // (the next E-step's grid looks at this, estep_rows_grid)
     c->flat.idle_since_launch = false;

@@ -386,6 +386,51 @@ __global__ __launch_bounds__(256) void util_fill_paced_kernel(float* __restrict_
     }
 }
 
+// MODE 7 (read probe): the M-step's access pattern without its arithmetic -- every wave READS runs of `run4` float4 (a
+// row of J = 800: 200 float4), `depth` runs requested before the first is consumed, runs contiguous per wave or dealt
+// round-robin; the sums keep the loads alive (one value per wave written at the end).  What the HBM read path delivers.
+template <int DEPTH, bool NT>
+__global__ __launch_bounds__(256) void util_read_kernel(const float* __restrict__ p, int64_t n4, int run4, int round_robin,
+                                                        float* __restrict__ sink) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4* q = reinterpret_cast<const f4*>(p);
+    const int64_t nw = (int64_t)gridDim.x * 4, gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int64_t nruns = n4 / run4;
+    const int64_t per = (nruns + nw - 1) / nw;
+    const int64_t r_lo = round_robin ? gw : gw * per, r_step = round_robin ? nw : 1;
+    const int64_t cnt = round_robin ? (gw < nruns ? (nruns - gw + nw - 1) / nw : 0)
+                                    : (r_lo < nruns ? (r_lo + per < nruns ? per : nruns - r_lo) : 0);
+    constexpr int SEG = 4;                                  // float4 per lane and run (run4 <= 256)
+    f4 buf[DEPTH][SEG];
+    auto load = [&](int64_t it, f4 (&dst)[SEG]) {
+        const int64_t r = r_lo + (it < cnt ? it : cnt - 1) * r_step;
+#pragma unroll
+        for (int s = 0; s < SEG; ++s) {
+            const int off = s * 64 + lane;
+            const f4* src = q + r * run4 + (off < run4 ? off : run4 - 1);
+            dst[s] = NT ? __builtin_nontemporal_load(src) : *src;
+        }
+    };
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (cnt > 0) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) load(d, buf[d]);
+        for (int64_t it = 0; it < cnt; it += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                if (it + d < cnt) {
+#pragma unroll
+                    for (int s = 0; s < SEG; ++s) acc += buf[d][s];
+                    load(it + d + DEPTH, buf[d]);
+                }
+            }
+        }
+    }
+    const float t = acc.x + acc.y + acc.z + acc.w;
+    if (t == 12345.678f) sink[gw] = t;                      // (never true for the probe's data: the loads stay, nothing is written)
+}
+
 template <bool NT, int MODE>
 __global__ __launch_bounds__(256) void util_fill_kernel(float* __restrict__ p, int64_t n4, float v) {
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -471,6 +516,14 @@ extern "C" int hgmm_util_fill_f32(hgmm_ctx* c, float* dev, int64_t n, float valu
             }
             if (nt) util_fill_paced_kernel<true><<<grid, 256, 0, c->stream>>>(dev, n4, run4, pace16);
             else util_fill_paced_kernel<false><<<grid, 256, 0, c->stream>>>(dev, n4, run4, pace16);
+        }
+        else if (mode == 7) {       // read probe: value = 10 * depth + round_robin (depth 1, 2, 3), grid = cus * gmul
+            const int depth = ((int)value) / 10, rr = ((int)value) % 10;
+            const int run4 = 200;
+#define RD(D) do { if (nt) util_read_kernel<D, true><<<grid, 256, 0, c->stream>>>(dev, n4, run4, rr, dev); \
+                   else util_read_kernel<D, false><<<grid, 256, 0, c->stream>>>(dev, n4, run4, rr, dev); } while (0)
+            if (depth <= 1) RD(1); else if (depth == 2) RD(2); else RD(3);
+#undef RD
         }
         else if (mode == 4) {       // mode 3's chunks written by a whole 256-thread workgroup
             if (nt) util_fill_kernel<true, 3><<<grid, 256, 0, c->stream>>>(dev, n4, value);

@@ -16,9 +16,12 @@ inv, mu, w, cov, lls, _ = ctx.flat_train(10, 0.0, mu0, cov0, w0, "diag", "W")
 lr = ctx.empty((N, J), np.float32)
 ctx.flat_estep(inv, mu, w, "diag", "W", out=lr)
 alg = 4 * N * J + 12 * N
-cfgs = [("no pacing, 2 wg/CU", {"HGMM_MSTEP_TARGET_GBS": "0", "HGMM_MSTEP_BPC": "2"}),
-        ("no pacing, 3 wg/CU", {"HGMM_MSTEP_TARGET_GBS": "0", "HGMM_MSTEP_BPC": "3"}),
-        ("no pacing, 4 wg/CU", {"HGMM_MSTEP_TARGET_GBS": "0", "HGMM_MSTEP_BPC": "4"})]
+cfgs = []
+for nt in ("0", "1"):
+    for rr in ("0", "1"):
+        for bpc in ("2", "3"):
+            cfgs.append(("%s loads, rows %s, %s wg/CU" % ("non-temporal" if nt == "1" else "plain", "round-robin" if rr == "1" else "contiguous", bpc),
+                         {"HGMM_MSTEP_NT": nt, "HGMM_MSTEP_RR": rr, "HGMM_MSTEP_BPC": bpc}))
 res = {c: [] for c, _ in cfgs}
 dmu = ctx.to_device(mu)
 for rnd in range(3):
@@ -34,4 +37,4 @@ for rnd in range(3):
         res[name].append(ms / n)
 for name, _ in cfgs:
     v = np.array(res[name])
-    print("%-28s median %.4f ms  (%.0f GB/s, %.1f%% of 8 TB/s)  rounds %s" % (name, np.median(v), alg / np.median(v) / 1e6, alg / np.median(v) / 1e6 / 80, np.round(v, 4)))
+    print("%-46s median %.4f ms  (%.0f GB/s, %.1f%% of 8 TB/s)  rounds %s" % (name, np.median(v), alg / np.median(v) / 1e6, alg / np.median(v) / 1e6 / 80, np.round(v, 4)))
