@@ -484,6 +484,45 @@ __device__ __forceinline__ bool tree_follow(const TreeFollow& f, int stop_flag, 
     }
     return stop_now;
 }
+// The same for a workgroup of ONE wave (tree_moments_kernel): lane t adds up what threads t, t + 64, t + 128, t + 192 of a
+// CH-thread workgroup would have -- four separate sums, reduced and combined exactly as above, so the same q bit for bit.
+struct TreeFollowLoads { double acc[CH / 64]; double prev_q; int it; };
+// (the loads first -- the caller puts its own requests behind them and only then asks for the verdict, so that the two
+//  chains of trips to memory run side by side)
+__device__ __forceinline__ TreeFollowLoads tree_follow_wave_load(const TreeFollow& f) {
+    TreeFollowLoads r;
+    r.prev_q = f.prev->prev_q;
+    r.it = f.prev->it;
+#pragma unroll
+    for (int w = 0; w < CH / 64; ++w) r.acc[w] = 0.0;
+    for (int i0 = threadIdx.x; i0 < f.nb; i0 += CH) {
+#pragma unroll
+        for (int w = 0; w < CH / 64; ++w)
+            if (i0 + 64 * w < f.nb) r.acc[w] += f.q_blocks[i0 + 64 * w];
+    }
+    return r;
+}
+__device__ __forceinline__ bool tree_follow_wave_verdict(const TreeFollow& f, TreeFollowLoads r, int stop_flag) {
+    if (stop_flag) return true;
+#pragma unroll
+    for (int w = 0; w < CH / 64; ++w) r.acc[w] = wave_sum_f64(r.acc[w]);
+    double q = r.acc[0];
+#pragma unroll
+    for (int w = 1; w < CH / 64; ++w) q += r.acc[w];
+    const double prev_q = r.prev_q;
+    const int it = r.it;
+    const bool stop_now = fabs(q - prev_q) < f.ls || it + 1 >= f.max_iters;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (it < f.trace_cap) f.trace[it] = q;
+        f.next->it = it + 1;
+        f.next->prev_q = q;
+        if (stop_now) *f.done = 1;
+        if (f.host_word)
+            __hip_atomic_store(f.host_word, ((unsigned long long)(stop_now ? 1 : 0) << 32) | (unsigned long long)(unsigned)(it + 1),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return stop_now;
+}
 __global__ __launch_bounds__(CH) void tree_close_kernel(TreeFollow f) {
     __shared__ double sh4[4];
     (void)tree_follow(f, *f.done, sh4);
@@ -498,20 +537,34 @@ typedef double double4_es __attribute__((ext_vector_type(4)));
 // 23 KB of LDS per workgroup instead of 42) -- same products, same order of accumulation, so the same sums bit for bit.
 // A million-point level is 3907 chunks = 15 workgroups per CU, of which the LDS admitted 3 at a time: the launch was
 // five rounds of one latency chain each.  Small clouds (less than one workgroup per CU) keep the one-pass form.
+struct TreeEstepArgs {
+    const double* xs; int64_t n_pad; const double* prep; const int* chunk_desc; const int* n_chunks;
+    int64_t parent_level_first; int level; double* partials; int* cur_sorted; const int* done;
+};
+// (c = the workgroup's chunk: blockIdx.x in tree_estep_kernel, an offset of it in tree_ll_estep_kernel)
+// LDS of one E-step workgroup, in doubles: exp table, tree_follow's four, the waves' [8][NMOM] sums, gamma rows, feature rows
 template <bool HALF>
-__global__ __launch_bounds__(CH) void tree_estep_kernel(
-    const double* __restrict__ xs, int64_t n_pad, const double* __restrict__ prep,
-    const int* __restrict__ chunk_desc, const int* __restrict__ n_chunks, int64_t parent_level_first,
-    int level, double* __restrict__ partials, int* __restrict__ cur_sorted, const int* __restrict__ done,
-    TreeFollow follow = TreeFollow{nullptr, 0, nullptr, nullptr, nullptr, 0.0, 0, nullptr, 0, nullptr}) {
+constexpr int tree_estep_lds() { return EXP_TAB_N + 4 + (CH / 64) * 8 * NMOM + (CH / 64) * (8 + NMOM) * (HALF ? ES_LD / 2 + 1 : ES_LD); }
+template <bool HALF>
+__device__ __forceinline__ void tree_estep_body(const int c, const TreeEstepArgs& a, const TreeFollow& follow,
+                                                double* __restrict__ smem) {
+    const double* __restrict__ xs = a.xs;
+    const int64_t n_pad = a.n_pad;
+    const double* __restrict__ prep = a.prep;
+    const int* __restrict__ chunk_desc = a.chunk_desc;
+    const int* __restrict__ n_chunks = a.n_chunks;
+    const int64_t parent_level_first = a.parent_level_first;
+    const int level = a.level;
+    double* __restrict__ partials = a.partials;
+    int* __restrict__ cur_sorted = a.cur_sorted;
+    const int* __restrict__ done = a.done;
     // (the stop flag, the chunk count and this chunk's descriptor are requested together -- the descriptor table is
     //  allocated for the whole grid, so the read is safe before the count is known: one trip to memory instead of three)
-    const int c = blockIdx.x;
     const int stop_flag = done ? *done : 0;        // the level converged in an earlier iteration of this batch
     const int chunks_now = *n_chunks;
     const int p = chunk_desc[3 * c + 0], begin = chunk_desc[3 * c + 1], end = chunk_desc[3 * c + 2];
-    __shared__ double exp_tab[EXP_TAB_N];
-    __shared__ double sh_follow[4];
+    double* exp_tab = smem;
+    double* sh_follow = smem + EXP_TAB_N;
     exp_tab_load(exp_tab);                         // (synchronised below, once the points' loads are on their way)
     if (c >= chunks_now) return;                   // (workgroup 0 always owns a chunk)
     if (follow.q_blocks) {
@@ -573,9 +626,9 @@ __global__ __launch_bounds__(CH) void tree_estep_kernel(
     // the A operand and columns 10..15 of B alias rows that exist: their products land in accumulator entries nobody reads.
     constexpr int LD = HALF ? ES_LD / 2 + 1 : ES_LD;          // 34 / 66: the same bank pattern (stride = 4 mod 64 dwords)
     constexpr int PASS_PTS = HALF ? 32 : 64;
-    __shared__ double sh[CH / 64][8 * NMOM];
-    __shared__ double GS[CH / 64][8][LD];
-    __shared__ double FS[CH / 64][NMOM][LD];
+    double (*sh)[8 * NMOM] = reinterpret_cast<double (*)[8 * NMOM]>(smem + EXP_TAB_N + 4);
+    double (*GS)[8][LD] = reinterpret_cast<double (*)[8][LD]>(smem + EXP_TAB_N + 4 + (CH / 64) * 8 * NMOM);
+    double (*FS)[NMOM][LD] = reinterpret_cast<double (*)[NMOM][LD]>(smem + EXP_TAB_N + 4 + (CH / 64) * 8 * NMOM + (CH / 64) * 8 * LD);
     const int w = wave_in_block();
     const int lane = lane_id();
     {
@@ -614,6 +667,17 @@ __global__ __launch_bounds__(CH) void tree_estep_kernel(
         partials[(size_t)c * (8 * NMOM) + threadIdx.x] = t;
     }
 }
+template <bool HALF>
+__global__ __launch_bounds__(CH) void tree_estep_kernel(
+    const double* __restrict__ xs, int64_t n_pad, const double* __restrict__ prep,
+    const int* __restrict__ chunk_desc, const int* __restrict__ n_chunks, int64_t parent_level_first,
+    int level, double* __restrict__ partials, int* __restrict__ cur_sorted, const int* __restrict__ done,
+    TreeFollow follow = TreeFollow{nullptr, 0, nullptr, nullptr, nullptr, 0.0, 0, nullptr, 0, nullptr}) {
+    __shared__ double smem[tree_estep_lds<HALF>()];
+    tree_estep_body<HALF>((int)blockIdx.x,
+                          TreeEstepArgs{xs, n_pad, prep, chunk_desc, n_chunks, parent_level_first, level, partials, cur_sorted, done},
+                          follow, smem);
+}
 
 // one wave per child node of the level: fixed-order sum of its parent's chunk partials
 // ML estimate of one node from its moments (mlEstimator, hgmm_cupy_cpu_working.py:109-119) followed by
@@ -650,13 +714,19 @@ __global__ __launch_bounds__(64) void tree_moments_kernel(const double* __restri
                                                           int n_level_nodes, double* __restrict__ mom,
                                                           int fuse, int64_t lb, double n_points_total, double ld,
                                                           double* pi, double* mu, double* cov, double* prep,
-                                                          int* __restrict__ flags, const int* __restrict__ done) {
+                                                          int* __restrict__ flags, const int* __restrict__ done,
+                                                          TreeFollow follow = TreeFollow{nullptr, 0, nullptr, nullptr, nullptr, 0.0,
+                                                                                         0, nullptr, 0, nullptr}) {
     const int cl = blockIdx.x;            // level-local child index
     if (cl >= n_level_nodes) return;
     const int p = cl >> 3, k = cl & 7;
     const int stop_flag = done ? *done : 0;                   // (requested together with the chunk range)
     const int c0 = chunk_first[p], c1 = chunk_first[p + 1];
-    if (stop_flag) return;
+    // (tree_ll_estep_kernel's launch order: this launch is the one that follows iteration e - 1's log-likelihood; if the
+    //  level turns out to have stopped, the partial moments read here are the speculative E-step's and go nowhere)
+    TreeFollowLoads fl;
+    if (follow.q_blocks) fl = tree_follow_wave_load(follow);
+    else if (stop_flag) return;
     double acc[NMOM];
 #pragma unroll
     for (int m = 0; m < NMOM; ++m) acc[m] = 0.0;
@@ -665,6 +735,7 @@ __global__ __launch_bounds__(64) void tree_moments_kernel(const double* __restri
 #pragma unroll
         for (int m = 0; m < NMOM; ++m) acc[m] += src[m];
     }
+    if (follow.q_blocks && tree_follow_wave_verdict(follow, fl, stop_flag)) return;
 #pragma unroll
     for (int m = 0; m < NMOM; ++m) acc[m] = wave_sum_f64(acc[m]);
     if (threadIdx.x == 0) {
@@ -726,7 +797,7 @@ constexpr int TICKET_GROUPS = 64;                        // counter 0 = top leve
 // ... and the counters sit 4 KB apart: device-scope atomics are executed at the memory side, one queue per channel --
 // 65 counters in three cache lines still queued behind each other (15.3 us for the 8-node level, unchanged).
 constexpr int TICKET_STRIDE = 1024;                      // unsigned ints between two counters
-__device__ __forceinline__ void store_block_q(double value, double* __restrict__ block_q, int nb,
+__device__ __forceinline__ void store_block_q(double value, double* __restrict__ block_q, const int bx, int nb,
                                               unsigned int* __restrict__ ticket, double* __restrict__ q_out,
                                               const TreeStop& stop) {
     __shared__ bool is_last;
@@ -734,10 +805,10 @@ __device__ __forceinline__ void store_block_q(double value, double* __restrict__
     if (threadIdx.x == 0) {
         is_last = false;
         if (ticket) {
-            __hip_atomic_store(block_q + blockIdx.x, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(block_q + bx, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the share has left this CU before the ticket does
             const int ng = nb < TICKET_GROUPS ? nb : TICKET_GROUPS;
-            const int g = (int)(blockIdx.x % (unsigned)ng);
+            const int g = (int)((unsigned)bx % (unsigned)ng);
             const unsigned int members = (unsigned int)((nb - g + ng - 1) / ng);
             unsigned int* mine = ticket + (size_t)(1 + g) * TICKET_STRIDE;
             if (__hip_atomic_fetch_add(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
@@ -745,7 +816,7 @@ __device__ __forceinline__ void store_block_q(double value, double* __restrict__
                 is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)(ng - 1);
             }
         } else {
-            block_q[blockIdx.x] = value;
+            block_q[bx] = value;
         }
     }
     __syncthreads();
@@ -787,30 +858,45 @@ constexpr double LL_SKIP = -750.0;       // exp(y) == 0 in float64 below this ex
 constexpr double LL_CULL = 751.0;        // a node is out of reach when kappa dist^2 exceeds this (margin over LL_SKIP)
 constexpr double LL_REL_DROP = 46.1;     // ln(1e20) + margin: see the relative reach test in tree_loglik_kernel
 constexpr int LL_REL_MIN_NODES = 512;    // levels with fewer nodes skip the extra pass (measured: nothing to drop there)
-template <int PTS, bool BIGTAB = false>
-__global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restrict__ xs, int64_t n,
-                                                         int64_t n_pad, const double* __restrict__ prep,
-                                                         int64_t lb, int n_level_nodes, int nodes_per_chunk,
-                                                         double* __restrict__ partial,
-                                                         double* __restrict__ block_q,
-                                                         unsigned int* __restrict__ ticket,
-                                                         double* __restrict__ q_out,
-                                                         const int* __restrict__ done, TreeStop stop,
-                                                         const int* __restrict__ flags,
-                                                         unsigned long long* __restrict__ pair_count,
-                                                         const double* __restrict__ exp2_tab = nullptr) {
+struct TreeLoglikArgs {
+    const double* xs; int64_t n; int64_t n_pad; const double* prep; int64_t lb; int n_level_nodes; int nodes_per_chunk;
+    double* partial; double* block_q; unsigned int* ticket; double* q_out; const int* done; TreeStop stop;
+    const int* flags; unsigned long long* pair_count; const double* exp2_tab;
+};
+// (bx, by) of a (gx, gy) grid: blockIdx / gridDim in tree_loglik_kernel, a slice of a 1-d grid in tree_ll_estep_kernel
+// LDS of one log-likelihood workgroup, in doubles: node tile, exp table, the waves' q / boxes / lref, the waves' counts (ints)
+template <bool BIGTAB>
+constexpr int tree_loglik_lds() { return LL_TILE * 10 + (BIGTAB ? EXP_TAB2_N : EXP_TAB_N) + (CH / 64) * (1 + 6 + 1) + (CH / 64) / 2; }
+template <int PTS, bool BIGTAB>
+__device__ __forceinline__ void tree_loglik_body(const int bx, const int by, const int gx, const int gy,
+                                                 const TreeLoglikArgs& a, double* __restrict__ smem) {
+    const double* __restrict__ xs = a.xs;
+    const int64_t n = a.n, n_pad = a.n_pad;
+    const double* __restrict__ prep = a.prep;
+    const int64_t lb = a.lb;
+    const int n_level_nodes = a.n_level_nodes, nodes_per_chunk = a.nodes_per_chunk;
+    double* __restrict__ partial = a.partial;
+    double* __restrict__ block_q = a.block_q;
+    unsigned int* __restrict__ ticket = a.ticket;
+    double* __restrict__ q_out = a.q_out;
+    const int* __restrict__ done = a.done;
+    const TreeStop& stop = a.stop;
+    const int* __restrict__ flags = a.flags;
+    unsigned long long* __restrict__ pair_count = a.pair_count;
+    const double* __restrict__ exp2_tab = a.exp2_tab;
     const int stop_flag = done ? *done : 0;                // (looked at below, once the other requests are on their way)
-    __shared__ double tile[LL_TILE][10];
-    __shared__ double shq[CH / 64];
-    __shared__ double exp_tab[BIGTAB ? EXP_TAB2_N : EXP_TAB_N];
-    __shared__ double shbox[CH / 64][6];
-    __shared__ int wcnt[CH / 64];
-    __shared__ double shl[CH / 64];
+    constexpr int TAB_N = BIGTAB ? EXP_TAB2_N : EXP_TAB_N;
+    double (*tile)[10] = reinterpret_cast<double (*)[10]>(smem);
+    double* exp_tab = smem + LL_TILE * 10;
+    double* shq = exp_tab + TAB_N;
+    double (*shbox)[6] = reinterpret_cast<double (*)[6]>(shq + CH / 64);
+    double* shl = shq + (CH / 64) * 7;
+    int* wcnt = reinterpret_cast<int*>(shl + CH / 64);
     if (BIGTAB) exp_tab2_load(exp_tab, exp2_tab); else exp_tab_load(exp_tab);   // (the tile loop's first barrier covers it)
     const int fl = flags ? *flags : 0;
     const int w = wave_in_block(), lane = lane_id();
     // origin: the workgroup's first point
-    const int64_t i_first = (int64_t)blockIdx.x * PTS * CH;
+    const int64_t i_first = (int64_t)bx * PTS * CH;
     const int64_t i_c = i_first < n ? i_first : n - 1;
     const double c0 = xs[i_c], c1 = xs[n_pad + i_c], c2 = xs[2 * n_pad + i_c];
     int64_t i[PTS];
@@ -894,7 +980,7 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
         lref = fmax(fmax(shl[0], shl[1]), fmax(shl[2], shl[3]));
     }
 
-    const int node_begin = blockIdx.y * nodes_per_chunk;
+    const int node_begin = by * nodes_per_chunk;
     const int node_end = (node_begin + nodes_per_chunk < n_level_nodes) ? node_begin + nodes_per_chunk : n_level_nodes;
     int entered = 0;                                       // nodes that made it into this workgroup's tiles
     for (int base = node_begin; base < node_end; base += LL_TILE) {
@@ -1005,10 +1091,10 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
         const int64_t pts = rest <= 0 ? 0 : (rest < (int64_t)PTS * CH ? rest : (int64_t)PTS * CH);
         atomicAdd(pair_count, (unsigned long long)(pts * entered));
     }
-    if (gridDim.y > 1) {
+    if (gy > 1) {
 #pragma unroll
         for (int p = 0; p < PTS; ++p)
-            if (active[p]) partial[(size_t)blockIdx.y * n_pad + i[p]] = tot[p];
+            if (active[p]) partial[(size_t)by * n_pad + i[p]] = tot[p];
         return;
     }
     double lq = 0.0;
@@ -1020,8 +1106,48 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
     __syncthreads();
     double t = 0.0;
     for (int ww = 0; ww < CH / 64; ++ww) t += shq[ww];
-    store_block_q(t, block_q, (int)gridDim.x, ticket, q_out, stop);
+    store_block_q(t, block_q, bx, gx, ticket, q_out, stop);
 }
+template <int PTS, bool BIGTAB = false>
+__global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restrict__ xs, int64_t n,
+                                                         int64_t n_pad, const double* __restrict__ prep,
+                                                         int64_t lb, int n_level_nodes, int nodes_per_chunk,
+                                                         double* __restrict__ partial,
+                                                         double* __restrict__ block_q,
+                                                         unsigned int* __restrict__ ticket,
+                                                         double* __restrict__ q_out,
+                                                         const int* __restrict__ done, TreeStop stop,
+                                                         const int* __restrict__ flags,
+                                                         unsigned long long* __restrict__ pair_count,
+                                                         const double* __restrict__ exp2_tab = nullptr) {
+    __shared__ double smem[tree_loglik_lds<BIGTAB>()];
+    tree_loglik_body<PTS, BIGTAB>((int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y,
+                                  TreeLoglikArgs{xs, n, n_pad, prep, lb, n_level_nodes, nodes_per_chunk, partial, block_q, ticket,
+                                                 q_out, done, stop, flags, pair_count, exp2_tab}, smem);
+}
+
+// One launch for two independent pieces of work on the same parameters (small clouds, single GPU): the level
+// log-likelihood of iteration e and -- on workgroups of their own, behind them in the grid -- the E-step of iteration
+// e + 1.  Both read the node parameters iteration e's M-step left; neither reads what the other writes.  The E-step is
+// speculative: whether iteration e + 1 exists is decided by the q this very launch produces (the next launch, the
+// moments kernel, adds it up and applies the stop rule, tree_follow_wave); if the level stops, the E-step's partial
+// moments are never read and its assignment sits in the OTHER of two buffers (iteration e's E-step wrote buffer e & 1).
+// What it buys: the E-step's chain of trips to memory (5 - 6 us at C4) runs beside the log-likelihood's instead of
+// behind it, and a level-iteration is two or three launches instead of three or four.
+template <int PTS>
+__global__ __launch_bounds__(CH) void tree_ll_estep_kernel(TreeLoglikArgs la, int gx, int gy, TreeEstepArgs ea) {
+    // (one LDS block for whichever of the two a workgroup turns out to be; the E-step in its two-pass form -- the same
+    //  sums bit for bit -- so that both need ~23 KB and the launch's workgroups are all resident at once)
+    constexpr int LDS = tree_loglik_lds<false>() > tree_estep_lds<true>() ? tree_loglik_lds<false>() : tree_estep_lds<true>();
+    __shared__ double smem[LDS];
+    const int nll = gx * gy;
+    const int b = (int)blockIdx.x;
+    if (b < nll)
+        tree_loglik_body<PTS, false>(b % gx, b / gx, gx, gy, la, smem);
+    else
+        tree_estep_body<true>(b - nll, ea, TreeFollow{nullptr, 0, nullptr, nullptr, nullptr, 0.0, 0, nullptr, 0, nullptr}, smem);
+}
+
 
 __global__ __launch_bounds__(CH) void tree_loglik_finish_kernel(const double* __restrict__ partial, int64_t n,
                                                                 int64_t n_pad, int n_chunks,
@@ -1043,7 +1169,7 @@ __global__ __launch_bounds__(CH) void tree_loglik_finish_kernel(const double* __
     __syncthreads();
     double t = 0.0;
     for (int w = 0; w < CH / 64; ++w) t += shq[w];
-    store_block_q(t, block_q, (int)gridDim.x, ticket, q_out, stop);
+    store_block_q(t, block_q, (int)blockIdx.x, (int)gridDim.x, ticket, q_out, stop);
 }
 
 // Device-side stop rule of one tree level (buildGMMTree, hgmm_cupy_cpu_working.py:149-157): record q,
@@ -1604,7 +1730,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     const int64_t max_chunks = n / CH + maxP + 8;
     // buffers
     HGMM_TRY(ensure(c, c->scratch, sizeof(double) * 3 * T));
-    HGMM_TRY(ensure(c, c->t_current, sizeof(int) * n_pad));
+    HGMM_TRY(ensure(c, c->t_current, sizeof(int) * 2 * n_pad));              // two assignments (tree_ll_estep_kernel)
     HGMM_TRY(ensure(c, c->t_perm, sizeof(int) * 2 * n_pad));                 // ping-pong
     HGMM_TRY(ensure(c, c->t_parent, sizeof(double) * 3 * n_pad));            // second coordinate buffer
     HGMM_TRY(ensure(c, c->t_seg, sizeof(int) * (2 * (8 * maxP + 2) + 2 * (maxP + 2) + 8)));
@@ -1669,6 +1795,11 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     // the stop rule inside the next launch (tree_follow) instead of a ticketed tail of the log-likelihood: needs the
     // polled scheme with >= 2 iterations ahead (the verdict on iteration e is reached by launch e + 1)
     const bool use_follow = !c->comm_on() && ahead_iters >= 2 && !std::getenv("HGMM_TREE_TICKETS");
+    // small clouds: iteration e + 1's (speculative) E-step rides in iteration e's log-likelihood launch and the moments
+    // kernel takes over the stop rule (tree_ll_estep_kernel); HGMM_TREE_OVERLAP=0 -> one launch each, as for large clouds
+    bool overlap = use_follow && ahead_iters > 0 && !estep_half && ll_pts != 4;
+    if (const char* e = std::getenv("HGMM_TREE_OVERLAP")) overlap = overlap && e[0] != '0';
+    int* curbuf[2] = {cur, overlap ? cur + n_pad : cur};
     unsigned long long* host_word = nullptr;                   // host address / device address of the same pinned word
     unsigned long long* host_word_dev = nullptr;
     if (!c->comm_on() && ahead_iters > 0) {
@@ -1762,11 +1893,11 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
         };
         auto enqueue_iteration = [&](int e) -> int {
             int rc = HGMM_OK;
-                {
+            const TreeFollow no_follow{nullptr, 0, nullptr, nullptr, nullptr, 0.0, 0, nullptr, 0, nullptr};
+            int* cur = curbuf[e & 1];                                      // (overlap: iteration e's assignment; else always the same)
+                if (!overlap || e == 0) {
                     ProfScope prof(c, HGMM_K_TREE_ESTEP);
-                    const TreeFollow fol = (use_follow && e >= 1)
-                                               ? follow_of(e)
-                                               : TreeFollow{nullptr, 0, nullptr, nullptr, nullptr, 0.0, 0, nullptr, 0, nullptr};
+                    const TreeFollow fol = (use_follow && e >= 1) ? follow_of(e) : no_follow;
                     if (estep_half)
                         tree_estep_kernel<true><<<grid_chunks, CH, 0, c->stream>>>(xs_cur, n_pad, d_prep, chunk_desc,
                                                                                   n_chunks_dev, parent_first, l, partials, cur,
@@ -1780,7 +1911,8 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                 // communicator the all-reduce of the moments sits between reduction and M-step
                 tree_moments_kernel<<<n_level, 64, 0, c->stream>>>(partials, chunk_first, n_level, d_mom + NMOM * lb,
                                                                    c->comm_on() ? 0 : 1, lb, n_total, ld, d_pi, d_mu, d_cov,
-                                                                   d_prep, flags_ptr(c), &ctl->done);
+                                                                   d_prep, flags_ptr(c), &ctl->done,
+                                                                   (overlap && e >= 1) ? follow_of(e) : no_follow);
                 if (c->comm_on()) {
                     rc = allreduce_f64_oop(c, d_mom + NMOM * lb, mom_g, (size_t)NMOM * n_level);
                     if (rc != HGMM_OK) return rc;
@@ -1801,7 +1933,15 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     tree_loglik_kernel<PTS><<<dim3(llblocks, chunks), CH, 0, c->stream>>>(                                 \
         xs_cur, n, n_pad, d_prep, lb, n_level, per_chunk, ll_partial, block_q, q_ticket, q_dev, &ctl->done, \
         chunks > 1 ? no_stop : stop, flags_ptr(c), pairs_ptr(c))
-                    if (ll_pts == 4)
+                    if (overlap && e + 1 < max_iters_per_level) {
+                        const TreeLoglikArgs la{xs_cur, n, n_pad, d_prep, lb, n_level, per_chunk, ll_partial, block_q, q_ticket,
+                                                q_dev, &ctl->done, no_stop, flags_ptr(c), pairs_ptr(c), nullptr};
+                        const TreeEstepArgs ea{xs_cur, n_pad, d_prep, chunk_desc, n_chunks_dev, parent_first, l, partials,
+                                               curbuf[(e + 1) & 1], &ctl->done};
+                        const unsigned g = (unsigned)(llblocks * chunks) + grid_chunks;
+                        if (ll_pts == 2) tree_ll_estep_kernel<2><<<g, CH, 0, c->stream>>>(la, llblocks, chunks, ea);
+                        else tree_ll_estep_kernel<1><<<g, CH, 0, c->stream>>>(la, llblocks, chunks, ea);
+                    } else if (ll_pts == 4)
                         tree_loglik_kernel<4, true><<<dim3(llblocks, chunks), CH, 0, c->stream>>>(
                             xs_cur, n, n_pad, d_prep, lb, n_level, per_chunk, ll_partial, block_q, q_ticket, q_dev, &ctl->done,
                             chunks > 1 ? no_stop : stop, flags_ptr(c), pairs_ptr(c), c->exp_tab2.as<double>());
@@ -1905,6 +2045,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
         }
         level_iters[l] = it;
         if (rc != HGMM_OK) break;
+        int* cur = curbuf[(it - 1) & 1];                       // the assignment of the last iteration that counted
         q_len += it;
         if (iters_per_level_out) iters_per_level_out[l] = it;
         if (l + 1 < L) {
