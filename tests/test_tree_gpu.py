@@ -603,7 +603,13 @@ def test_stop_rule_in_the_next_launch_equals_the_ticketed_tail(ctx, bunny, monke
     monkeypatch.setenv("HGMM_TREE_AHEAD", "0")
     c = build(ctx, P, L, 80.0, 1e-4, idx, 0.00034, max_iters)
     monkeypatch.delenv("HGMM_TREE_AHEAD")
-    for other in (b, c):
+    # round 4: for small clouds the default form also runs iteration e + 1's E-step (speculatively) inside iteration e's
+    # log-likelihood launch, the moments kernel applies the stop rule and the assignment is double-buffered
+    # (tree_ll_estep_kernel); HGMM_TREE_OVERLAP=0 is the one-launch-each form -- a fourth way to the same tree
+    monkeypatch.setenv("HGMM_TREE_OVERLAP", "0")
+    d = build(ctx, P, L, 80.0, 1e-4, idx, 0.00034, max_iters)
+    monkeypatch.delenv("HGMM_TREE_OVERLAP")
+    for other in (b, c, d):
         assert list(a[4]) == list(other[4])
         for x, y in zip((a[0], a[1], a[2], a[3], a[5]), (other[0], other[1], other[2], other[3], other[5])):
             assert np.array_equal(x, y)
