@@ -55,12 +55,12 @@ MIN_TIMED_S = 1.0            # timed blocks repeat until this much timed work ha
 MAX_BLOCKS = 400
 RCCL_INIT_FAILED = 17        # exit code of a rank whose RCCL communicator could not be created
 
-# fused EM kernel, USEFUL fp32 flops per (point, component) pair (fma = 2), DESIGN.md section 3:
-#   E: 3 sub + 3 mul + 3 fma = 12, exp 1, row sum 1;  M: r = e/S 1, s0 1, 3 mul + 3 add + 3 fma = 12  -> 28
-# The kernel also RE-computes the three (x - mu) subtractions in its M-phase (keeping them costs more registers than
-# it saves, profiles/r02/fused_isa_accounting.md): 3 executed-but-redundant flops per pair, reported separately.
+# fused EM kernel, fp32 flops per (point, component) pair (fma = 2), DESIGN.md section 3:
+#   E: 3 sub + 3 mul (squares) + 3 fma = 12, exp 1, row sum 1;  M: r = e/S 1, s0 1, first moments 3 fma, second moments 3 fma
+#   = 14  -> 28.  (Round 4's formulation executes exactly these; rounds 2-3 spent 3 mul + 3 add + 3 fma on the moments --
+#   the same 28 -- plus 3 re-computed subtractions.)
 FUSED_FLOP_PER_PAIR = 28
-FUSED_RECOMPUTED_FLOP_PER_PAIR = 3
+FUSED_RECOMPUTED_FLOP_PER_PAIR = 0
 
 
 def synth_frame(seed, n=None):
