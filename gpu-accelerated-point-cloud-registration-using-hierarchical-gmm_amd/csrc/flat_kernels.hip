@@ -1629,10 +1629,6 @@ __global__ void flat_ctl_kernel(const double* __restrict__ stats, int Jpad, floa
     ctl_update(stats, Jpad, lls, lls_cap, tol, ctl, ctl_f, ctl);
 }
 
-__global__ void flat_ctl_init_kernel(int* ctl, float* ctl_f) {
-    ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; ctl[3] = 0;
-    ctl_f[0] = -__builtin_huge_valf();
-}
 
 // hint table [3][Jpad] from host-layout mu [J,3]
 __global__ void flat_hint_kernel(const float* mu, int J, int Jpad, float* hint) {
@@ -2135,7 +2131,8 @@ static int launch_fused(hgmm_ctx* c, const int* done_flag, int* grid_out, int* v
     c->flat.last_kernel = 3;
     const FlatState& f = c->flat;
     if (!done_flag) done_flag = c->f_ctl.as<int>() + 16;        // always 0 (flat_setup)
-    const int grid = grid_for(c, c->n, env_int("HGMM_FUSED_BPC", 2));
+    int grid = grid_for(c, c->n, env_int("HGMM_FUSED_BPC", 2));
+    if (env_int("HGMM_FUSED_GRID", 0) > 0) grid = std::min(grid, env_int("HGMM_FUSED_GRID", 0));
     *grid_out = grid;
     const float* X = c->x_aos.as<float>();
     const float* pk = c->f_pack.as<float>();
@@ -2594,10 +2591,33 @@ extern "C" int hgmm_elementwise_f32(hgmm_ctx* c, int op, int64_t n, const float*
     return HGMM_OK;
 }
 
-__global__ void flat_inv_from_cov_kernel(const float* cov, float* inv, int n) {
-    // initial inv_std = 1/sqrt(cov)  (gmm_waymo gmm_impl.py:122, gmmreg_gpu gmm_impl.py:67)
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) inv[i] = 1.0f / sqrtf(cov[i]);
+
+// Everything a fit needs before its first iteration, in ONE launch: initial inv_std from the covariances, the packed
+// table from them, the loop's control words.  (Three launches before round 4; at the start of a call -- the stream has
+// been idle -- each of them came with ~13 us of launch latency: 40 us of a 620 us bun000 fit.)
+__global__ void flat_begin_kernel(int J, int Jpad, int cov_type, int variant, const float* __restrict__ mu,
+                                  const float* __restrict__ cov, const float* __restrict__ w, float* __restrict__ inv,
+                                  float* __restrict__ pack, int* __restrict__ ctl, float* __restrict__ ctl_f) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) {
+        ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; ctl[3] = 0;
+        ctl_f[0] = -__builtin_huge_valf();
+    }
+    if (j >= Jpad) return;
+    float m[3] = {0.f, 0.f, 0.f}, i[3] = {0.f, 0.f, 0.f}, wj = 0.f;
+    if (j < J) {
+        // initial inv_std = 1/sqrt(cov)  (gmm_waymo gmm_impl.py:122, gmmreg_gpu gmm_impl.py:67)
+        if (cov_type == HGMM_COV_DIAG) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { i[d] = 1.0f / sqrtf(cov[3 * j + d]); inv[3 * j + d] = i[d]; }
+        } else {
+            i[0] = i[1] = i[2] = 1.0f / sqrtf(cov[j]);
+            inv[j] = i[0];
+        }
+        m[0] = mu[3 * j + 0]; m[1] = mu[3 * j + 1]; m[2] = mu[3 * j + 2];
+        wj = w[j];
+    }
+    pack_values(j, j < J, Jpad, variant, m, i, wj, pack);
 }
 
 extern "C" int hgmm_flat_train_begin(hgmm_ctx* c, int cov_type, int variant, int J, float tol,
@@ -2611,12 +2631,11 @@ extern "C" int hgmm_flat_train_begin(hgmm_ctx* c, int cov_type, int variant, int
     FlatState& f = c->flat;
     f.tol = tol; f.lls_cap = lls_capacity; f.launched = 0; f.active = true;
     HGMM_TRY(flat_upload(c, mu, cov, true, w));
-    const int ne = (int)cov_elems(cov_type, J);
-    flat_inv_from_cov_kernel<<<(ne + 255) / 256, 256, 0, c->stream>>>(c->f_cov.as<float>(),
-                                                                     c->f_inv.as<float>(), ne);
-    launch_pack(c);
     int* ctl = c->f_ctl.as<int>();
-    flat_ctl_init_kernel<<<1, 1, 0, c->stream>>>(ctl, reinterpret_cast<float*>(ctl + 8));
+    flat_begin_kernel<<<(f.Jpad + 255) / 256, 256, 0, c->stream>>>(J, f.Jpad, cov_type, variant, c->f_mu.as<float>(),
+                                                                  c->f_cov.as<float>(), c->f_w.as<float>(),
+                                                                  c->f_inv.as<float>(), c->f_pack.as<float>(), ctl,
+                                                                  reinterpret_cast<float*>(ctl + 8));
     HGMM_HIP(c, hipGetLastError());
     return HGMM_OK;
 }
@@ -2633,18 +2652,52 @@ extern "C" int hgmm_flat_train_end(hgmm_ctx* c, float* mu, float* cov, float* w,
     if (!c) return HGMM_ERR_ARG;
     FlatState& f = c->flat;
     if (!f.active) return fail(c, HGMM_ERR_STATE, "hgmm_flat_train_end before hgmm_flat_train_begin");
+    // The results come back through the pinned ring: the whole parameter block [cov | mu | w | inv], the control words
+    // and the head of the lls trace are three DMA packets that queue behind the last iteration at once, ONE
+    // synchronisation, then plain memcpys.  (Copied straight into the caller's pageable arrays every one of the six
+    // copies was staged by the runtime and waited for in turn, ~17 us each: a fifth of a 20-iteration bun000 fit.)
     int ctl[4] = {0, 0, 0, 0};
-    HGMM_HIP(c, hipMemcpyAsync(ctl, c->f_ctl.p, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
     const int J = f.J;
-    if (mu) HGMM_HIP(c, hipMemcpyAsync(mu, c->f_mu.p, sizeof(float) * 3 * J, hipMemcpyDeviceToHost, c->stream));
-    if (cov) HGMM_HIP(c, hipMemcpyAsync(cov, c->f_cov.p, sizeof(float) * cov_elems(f.cov_type, J), hipMemcpyDeviceToHost, c->stream));
-    if (w) HGMM_HIP(c, hipMemcpyAsync(w, c->f_w.p, sizeof(float) * J, hipMemcpyDeviceToHost, c->stream));
-    if (inv_std_out) HGMM_HIP(c, hipMemcpyAsync(inv_std_out, c->f_inv.p, sizeof(float) * cov_elems(f.cov_type, J), hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, ctx_stream_sync(c));
-    const int n_it = ctl[1];
-    if (lls_out && n_it > 0) {
-        const int cnt = n_it < f.lls_cap ? n_it : f.lls_cap;
-        HGMM_HIP(c, hipMemcpy(lls_out, c->f_lls.p, sizeof(float) * cnt, hipMemcpyDeviceToHost));
+    const size_t ce = cov_elems(f.cov_type, J);
+    const size_t span = sizeof(float) * 10 * (size_t)f.Jpad;
+    const int eager = f.lls_cap < 16384 ? f.lls_cap : 16384;
+    int n_it = 0;
+    if (span + 512 + sizeof(float) * (size_t)eager <= STAGE_RING_BYTES / 2) {
+        void *s_blk = nullptr, *s_ctl = nullptr, *s_lls = nullptr;
+        HGMM_TRY(stage_reserve(c, span, &s_blk));
+        HGMM_TRY(stage_reserve(c, sizeof ctl, &s_ctl));
+        HGMM_TRY(stage_reserve(c, sizeof(float) * (size_t)eager, &s_lls));
+        HGMM_HIP(c, hipMemcpyAsync(s_blk, c->f_block.p, span, hipMemcpyDeviceToHost, c->stream));
+        HGMM_HIP(c, hipMemcpyAsync(s_ctl, c->f_ctl.p, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
+        HGMM_HIP(c, hipMemcpyAsync(s_lls, c->f_lls.p, sizeof(float) * (size_t)eager, hipMemcpyDeviceToHost, c->stream));
+        HGMM_HIP(c, ctx_stream_sync(c));
+        c->h_stage_off = 0;                                // the stream is idle: every region of the ring is free
+        std::memcpy(ctl, s_ctl, sizeof ctl);
+        const float* blk = static_cast<const float*>(s_blk);
+        if (cov) std::memcpy(cov, blk, sizeof(float) * ce);
+        if (mu) std::memcpy(mu, blk + 3 * (size_t)f.Jpad, sizeof(float) * 3 * J);
+        if (w) std::memcpy(w, blk + 6 * (size_t)f.Jpad, sizeof(float) * J);
+        if (inv_std_out) std::memcpy(inv_std_out, blk + 7 * (size_t)f.Jpad, sizeof(float) * ce);
+        n_it = ctl[1];
+        if (lls_out && n_it > 0) {
+            const int cnt = n_it < f.lls_cap ? n_it : f.lls_cap;
+            std::memcpy(lls_out, s_lls, sizeof(float) * (size_t)(cnt < eager ? cnt : eager));
+            if (cnt > eager)
+                HGMM_HIP(c, hipMemcpy(lls_out + eager, c->f_lls.as<float>() + eager, sizeof(float) * (size_t)(cnt - eager),
+                                      hipMemcpyDeviceToHost));
+        }
+    } else {                                               // (very large J: the block does not fit the ring)
+        HGMM_HIP(c, hipMemcpyAsync(ctl, c->f_ctl.p, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
+        if (mu) HGMM_HIP(c, hipMemcpyAsync(mu, c->f_mu.p, sizeof(float) * 3 * J, hipMemcpyDeviceToHost, c->stream));
+        if (cov) HGMM_HIP(c, hipMemcpyAsync(cov, c->f_cov.p, sizeof(float) * ce, hipMemcpyDeviceToHost, c->stream));
+        if (w) HGMM_HIP(c, hipMemcpyAsync(w, c->f_w.p, sizeof(float) * J, hipMemcpyDeviceToHost, c->stream));
+        if (inv_std_out) HGMM_HIP(c, hipMemcpyAsync(inv_std_out, c->f_inv.p, sizeof(float) * ce, hipMemcpyDeviceToHost, c->stream));
+        HGMM_HIP(c, ctx_stream_sync(c));
+        n_it = ctl[1];
+        if (lls_out && n_it > 0) {
+            const int cnt = n_it < f.lls_cap ? n_it : f.lls_cap;
+            HGMM_HIP(c, hipMemcpy(lls_out, c->f_lls.p, sizeof(float) * cnt, hipMemcpyDeviceToHost));
+        }
     }
     if (n_iter_out) *n_iter_out = n_it;
     if (converged_out) *converged_out = ctl[2];
