@@ -342,12 +342,14 @@ template <int NV4, int NV1, int ROWS, bool NT>
 __global__ __launch_bounds__(BLOCK) void flat_estep_rows_pk_kernel(
     const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int J, int Jpad,
     float* __restrict__ log_resp, float* __restrict__ lpn_out, int32_t* __restrict__ argmax_out,
-    double* __restrict__ lpn_partials, int allow_const_shift, int pace) {
+    double* __restrict__ lpn_partials, int allow_const_shift, int pace,
+    unsigned long long* __restrict__ stamp /*[2][gridDim.x] wall-clock start / end per workgroup, pinned host memory; may be null*/) {
     using L = Layout<NV4, NV1>;
     constexpr int K = L::K;
     constexpr int KP = 2 * NV4 + NV1 / 2;          // pairs
     constexpr bool ODD = (NV1 & 1) != 0;           // trailing single = component K - 1
     const int lane = lane_id();
+    if (stamp && threadIdx.x == 0) stamp[blockIdx.x] = wall_clock64();
     f2 mu0[KP + 1], mu1[KP + 1], mu2[KP + 1], g0[KP + 1], g1[KP + 1], g2[KP + 1], cc[KP + 1];
     float mu0s = 0.f, mu1s = 0.f, mu2s = 0.f, g0s = 0.f, g1s = 0.f, g2s = 0.f, cs = NEG_INF;
     auto ld = [&](int row, int j) { return pack[row * Jpad + j]; };
@@ -546,6 +548,11 @@ __global__ __launch_bounds__(BLOCK) void flat_estep_rows_pk_kernel(
             for (int i = 0; i < WAVES_PER_BLOCK; ++i) t += sh[i];
             lpn_partials[blockIdx.x] = t;
         }
+    }
+    if (stamp) {                                   // every wave's stores have been acknowledged, then the workgroup's end
+        __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
+        __syncthreads();
+        if (threadIdx.x == 0) stamp[gridDim.x + blockIdx.x] = wall_clock64();
     }
 }
 
@@ -1855,7 +1862,20 @@ static void pace_poll(hgmm_ctx* c) {
         const unsigned s = p.tail % PaceCtl::RING;
         if (hipEventQuery(p.ev[s][1]) != hipSuccess) { (void)hipGetLastError(); break; }
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, p.ev[s][0], p.ev[s][1]) == hipSuccess && p.tgt_at[s] == p.target) {
+        bool have_ms = false;
+        if (p.stamps && p.grid_at[s] > 0 && c->wall_khz > 0) {
+            // the launch is complete (its end event has passed): first workgroup start to last workgroup end
+            const unsigned long long* st = p.stamps + (size_t)s * 2 * PaceCtl::STAMP_WG;
+            unsigned long long t0 = ~0ull, t1 = 0ull;
+            for (int b = 0; b < p.grid_at[s]; ++b) {
+                t0 = st[b] < t0 ? st[b] : t0;
+                t1 = st[p.grid_at[s] + b] > t1 ? st[p.grid_at[s] + b] : t1;
+            }
+            if (t1 > t0) { ms = (float)((double)(t1 - t0) / (double)c->wall_khz); have_ms = true; }
+        } else {
+            have_ms = hipEventElapsedTime(&ms, p.ev[s][0], p.ev[s][1]) == hipSuccess;
+        }
+        if (have_ms && p.tgt_at[s] == p.target) {
             const double ideal_ms = p.bytes_at[s] / (p.tgt_at[s] * 1e9) * 1e3;
             const bool slow = (double)ms > PACE_STRIKE_RATIO * ideal_ms;
             if (p.probe_base > 0.0) {
@@ -1894,20 +1914,40 @@ static void pace_poll(hgmm_ctx* c) {
     }
 }
 // bracket a paced launch: begin() before the kernel, end() behind it; false: this launch is not observed
-static bool pace_observe_begin(hgmm_ctx* c, double target, double bytes) {
+// (*stamp_out: where this launch's workgroups leave their wall-clock stamps, null when the launch is judged by its events)
+static bool pace_observe_begin(hgmm_ctx* c, double target, double bytes, int grid, unsigned long long** stamp_out) {
     PaceCtl& p = c->pace;
+    *stamp_out = nullptr;
     if (env_int("HGMM_ESTEP_TARGET_GBS", -1) >= 0 || !env_flag("HGMM_ESTEP_ADAPT", true)) return false;
     if (bytes < PACE_MIN_BYTES || target <= 0.0) return false;
     if (!p.have_events) {
         for (auto& pr : p.ev)
             if (hipEventCreate(&pr[0]) != hipSuccess || hipEventCreate(&pr[1]) != hipSuccess) return false;
         p.have_events = true;
+        if (env_flag("HGMM_PACE_STAMPS", true)) {
+            void* h = nullptr;
+            void* d = nullptr;
+            const size_t bytes_st = sizeof(unsigned long long) * PaceCtl::RING * 2 * PaceCtl::STAMP_WG;
+            if (hipHostMalloc(&h, bytes_st, hipHostMallocDefault) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+                p.stamps = static_cast<unsigned long long*>(h);
+                p.stamps_dev = static_cast<unsigned long long*>(d);
+            } else {
+                if (h) (void)hipHostFree(h);
+                (void)hipGetLastError();
+            }
+        }
     }
     pace_poll(c);
     if (p.head - p.tail >= (unsigned)PaceCtl::RING) return false;          // every pair is still in flight
     const unsigned s = p.head % PaceCtl::RING;
     p.tgt_at[s] = target;
     p.bytes_at[s] = bytes;
+    p.grid_at[s] = 0;
+    if (p.stamps && grid <= PaceCtl::STAMP_WG) {
+        // the kernel writes start[b] at st[b] and end[b] at st[grid + b]: the slot is laid out for THIS grid
+        p.grid_at[s] = grid;
+        *stamp_out = p.stamps_dev + (size_t)s * 2 * PaceCtl::STAMP_WG;
+    }
     return hipEventRecord(p.ev[s][0], c->stream) == hipSuccess;
 }
 static void pace_observe_end(hgmm_ctx* c) {
@@ -1932,14 +1972,14 @@ static int store_pace16(hgmm_ctx* c, int grid, int J, double target_gbs) {
 
 // the 4-rows-per-wave materialising kernel for one (layout, grid, log-sum-exp variant); false: layout not instantiated
 static bool launch_estep_rows(hgmm_ctx* c, int nv4, int nv1, int grid_r, bool cshift, float* log_resp, float* lpn,
-                              int32_t* argmax, int pace) {
+                              int32_t* argmax, int pace, unsigned long long* stamp) {
     const FlatState& f = c->flat;
     const float* X = c->x_aos.as<float>();
     const float* pk = c->f_pack.as<float>();
     double* lp = c->f_lpn_partials.as<double>();
 #define ESTEP_R(A, B)                                                                              \
     flat_estep_rows_pk_kernel<A, B, 4, true><<<grid_r, BLOCK, 0, c->stream>>>(                      \
-        X, pk, c->n, f.J, f.Jpad, log_resp, lpn, argmax, lp, cshift ? 1 : 0, pace)
+        X, pk, c->n, f.J, f.Jpad, log_resp, lpn, argmax, lp, cshift ? 1 : 0, pace, stamp)
     if (nv4 == 3 && nv1 == 1) ESTEP_R(3, 1);
     else if (nv4 == 3 && nv1 == 0) ESTEP_R(3, 0);
     else if (nv4 == 3 && nv1 == 2) ESTEP_R(3, 2);
@@ -2100,11 +2140,12 @@ static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argma
         c->flat.last_kernel = 1;
         c->flat.idle_since_launch = false;
         // (only the constant-shift loop is store-bound by construction: the row-maximum loop is not judged)
-        const bool observed = cshift && pace_observe_begin(c, target, 4.0 * (double)c->n * (double)f.J);
+        unsigned long long* stamp = nullptr;
+        const bool observed = cshift && pace_observe_begin(c, target, 4.0 * (double)c->n * (double)f.J, grid_r, &stamp);
         bool launched;
         {
             ProfScope prof(c, HGMM_K_FLAT_ESTEP);
-            launched = launch_estep_rows(c, nv4, nv1, grid_r, cshift, log_resp, lpn, argmax, pace);
+            launched = launch_estep_rows(c, nv4, nv1, grid_r, cshift, log_resp, lpn, argmax, pace, observed ? stamp : nullptr);
         }
         if (launched) {
             if (observed) pace_observe_end(c);

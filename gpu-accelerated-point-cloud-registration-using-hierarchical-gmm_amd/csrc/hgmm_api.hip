@@ -620,6 +620,7 @@ extern "C" int hgmm_destroy(hgmm_ctx* c) {
     for (hipEvent_t& e : c->ev_slots) if (e) (void)hipEventDestroy(e);
     if (c->pace.have_events)
         for (auto& pr : c->pace.ev) { (void)hipEventDestroy(pr[0]); (void)hipEventDestroy(pr[1]); }
+    if (c->pace.stamps) (void)hipHostFree(c->pace.stamps);
     if (c->tree_hctl) { (void)hipHostFree(c->tree_hctl); (void)hipEventDestroy(c->tree_ev[0]); (void)hipEventDestroy(c->tree_ev[1]); }
     for (auto& p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     (void)hipStreamDestroy(c->stream);

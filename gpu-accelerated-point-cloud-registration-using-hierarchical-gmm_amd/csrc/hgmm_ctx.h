@@ -58,6 +58,14 @@ struct PaceCtl {
     double tgt_at[RING] = {}, bytes_at[RING] = {};
     unsigned head = 0, tail = 0;
     bool have_events = false;
+    // what a launch is judged by: wall-clock stamps the kernel's workgroups leave in pinned host memory -- [RING][2][STAMP_WG]:
+    // start and end per workgroup -- so that nothing the host, the queue or a profiler puts around the launch counts as
+    // the memory system's answer (the event pair only says WHEN the stamps are complete; it is the fall-back measure if
+    // the buffer could not be had)
+    static constexpr int STAMP_WG = 1024;
+    unsigned long long* stamps = nullptr;       // host address
+    unsigned long long* stamps_dev = nullptr;   // the same memory as the device sees it
+    int grid_at[RING] = {};
 };
 
 struct HostComm;                           // hgmm_api.hip
