@@ -2320,7 +2320,12 @@ static int enqueue_em_iteration(hgmm_ctx* c) {
     HGMM_TRY(launch_reduce(c, grid, valid_j, true, stop));
     // (reduction + finalisation in ONE launch -- the last workgroup to finish, found by a ticket, runs the
     //  M-step -- was measured no faster: 0.4253 vs 0.4254 ms per iteration at C3, 35 - 36 k vs 38 k it/s
-    //  on bun000 J = 100: the serial tail in one 256-thread workgroup costs what the launch saved)
+    //  on bun000 J = 100: the serial tail in one 256-thread workgroup costs what the launch saved.  Round 4 tried the form
+    //  WITHOUT a hand-over -- a workgroup owns 8 components, adds up their 7 statistics over all partial blocks in the
+    //  reduction kernel's own slices and orders (the same fit bit for bit) and runs their M-step: slower again, 0.3465 vs
+    //  0.3416 ms per iteration at C3 and 0.45 vs 0.385 ms per 20-iteration fit on bun000 J = 100 -- 100 workgroups reading
+    //  32-byte pieces of 512 partial blocks take longer than the 225 well-coalesced workgroups of the reduction kernel
+    //  plus a launch.)
     // the statistics were centred about the means the E-step used = rows PK_MU.. of pack
     flat_finalize_kernel<<<f.Jpad / 256, 256, 0, c->stream>>>(
         c->f_stats.as<double>(), c->f_pack.as<float>() + PK_MU * f.Jpad, f.J, f.Jpad, f.cov_type,
