@@ -2520,7 +2520,10 @@ static int flat_mstep_enqueue(hgmm_ctx* c, int cov_type, int variant, int J, con
     float* part = c->f_partials.as<float>();
     const float* hint = c->f_hint.as<float>();
     int valid_j = 0;
-    const bool ntload = env_flag("HGMM_MSTEP_NT", true);
+    // non-temporal loads: 6.1 -> 6.8 TB/s at J = 800, a gain or a tie for every row length that is a whole number of
+    // 16-byte pieces -- and a loss when rows straddle them (J = 513: 0.380 vs 0.351 ms, J = 37: 0.176 vs 0.142: a line shared by
+    // two rows is then fetched for each of them; profiles/r04/mstep_nt_by_J.log)
+    const bool ntload = env_flag("HGMM_MSTEP_NT", true) && J % 4 == 0;
 #define MSTEP_LAUNCH(A, B, RESP, HINT, JV, PART)                                                               \
     do {                                                                                                       \
         if (is_log) {                                                                                          \
