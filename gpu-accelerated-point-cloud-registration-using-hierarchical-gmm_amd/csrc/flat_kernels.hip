@@ -1426,6 +1426,7 @@ __global__ __launch_bounds__(BLOCK) void flat_chunk_write_kernel(
     P.load(pack, Jpad, lane);
     int64_t r0, r1;
     wave_row_range(n, r0, r1);
+    const bool nt_rows = (ld & 3) == 0;               // (rows of whole 16-byte pieces: see launch_estep)
     for (int64_t row = r0; row < r1; ++row) {
         const float* xp = X + 3 * row;
         const float x0 = xp[0], x1 = xp[1], x2 = xp[2];
@@ -1436,7 +1437,10 @@ __global__ __launch_bounds__(BLOCK) void flat_chunk_write_kernel(
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int j = k * 64 + lane;
-            if (j < jvalid) __builtin_nontemporal_store(fmaf(wl[k], LN2, -l), o + j);
+            if (j < jvalid) {
+                const float v = fmaf(wl[k], LN2, -l);
+                if (nt_rows) __builtin_nontemporal_store(v, o + j); else o[j] = v;
+            }
         }
     }
 }
@@ -2108,7 +2112,10 @@ static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argma
     double* lp = c->f_lpn_partials.as<double>();
     int nv4, nv1;
     pick_layout(f.J, &nv4, &nv1);
-    const bool nt = NORMALISE && env_flag("HGMM_ESTEP_NT", true);
+    // (single-row kernel) non-temporal stores only for rows that are whole 16-byte pieces: J = 513 wrote its table in 0.364 ms
+    // with them and in 0.251 ms without -- a line two rows share is written twice, each time in part
+    // (profiles/r04/estep_nt_by_J.log)
+    const bool nt = NORMALISE && env_flag("HGMM_ESTEP_NT", true) && f.J % 4 == 0;
     const int rr = env_int("HGMM_ESTEP_RR", 0);
     if (!NORMALISE && !log_resp && !lpn && argmax && predict_rows_layout(nv4, nv1)) {      // predict(): labels only
         ProfScope prof(c, HGMM_K_FLAT_ESTEP);
