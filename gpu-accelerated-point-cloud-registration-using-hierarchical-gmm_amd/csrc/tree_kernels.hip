@@ -913,6 +913,20 @@ __device__ __forceinline__ void tree_loglik_body(const int bx, const int by, con
         const int64_t il = active[p] ? i[p] : i_c;
         r0[p] = xs[il]; r1[p] = xs[n_pad + il]; r2[p] = xs[2 * n_pad + il];
     }
+    // Small clouds: the WEIGHTS of this thread's nodes in the first LL_WPRE tiles are requested with the points.  A level's
+    // dead nodes (pi < eps: 3370 of C4's 4096 level-3 slots) then cost 8 bytes each instead of the 17 parameters the tile
+    // loop asks for at once -- 70 KB per workgroup, 88 MB per launch of a kernel that lasts 15 us (C4: 2.32 -> 2.27 ms).
+    // (Also tried for these instantiations and dropped: two nodes per step of the evaluation loop, four exponentials
+    //  interleaved -- 2.29 ms: the loop is not what these launches wait for.)
+    constexpr int LL_WPRE = BIGTAB ? 0 : 2;
+    const int node_begin = by * nodes_per_chunk;
+    const int node_end = (node_begin + nodes_per_chunk < n_level_nodes) ? node_begin + nodes_per_chunk : n_level_nodes;
+    double wpre[LL_WPRE > 0 ? LL_WPRE : 1];
+#pragma unroll
+    for (int t = 0; t < LL_WPRE; ++t) {
+        const int nd = node_begin + t * LL_TILE + (int)threadIdx.x;
+        wpre[t] = nd < node_end ? prep[PREP_N * (lb + nd) + 10] : 0.0;
+    }
     if (stop_flag) return;
     const bool use_chol = !(fl & 1);                       // kernel-uniform
 #pragma unroll
@@ -980,8 +994,6 @@ __device__ __forceinline__ void tree_loglik_body(const int bx, const int by, con
         lref = fmax(fmax(shl[0], shl[1]), fmax(shl[2], shl[3]));
     }
 
-    const int node_begin = by * nodes_per_chunk;
-    const int node_end = (node_begin + nodes_per_chunk < n_level_nodes) ? node_begin + nodes_per_chunk : n_level_nodes;
     int entered = 0;                                       // nodes that made it into this workgroup's tiles
     for (int base = node_begin; base < node_end; base += LL_TILE) {
         // ---- this thread's node of the tile: weight, reach test, parameters in workgroup coordinates ----
@@ -990,7 +1002,12 @@ __device__ __forceinline__ void tree_loglik_body(const int bx, const int by, con
         double v[10];
 #pragma unroll
         for (int e = 0; e < 10; ++e) v[e] = 0.0;
-        if (node < node_end) {
+        bool known_dead = false;                            // (weight already here and zero: nothing else is requested)
+        if constexpr (LL_WPRE > 0) {
+            const int ti = (base - node_begin) / LL_TILE;
+            if (ti < LL_WPRE) known_dead = (ti == 0 ? wpre[0] : wpre[LL_WPRE - 1]) == 0.0;
+        }
+        if (node < node_end && !known_dead) {
             const double* pr = prep + PREP_N * (lb + node);
             // (every field requested at once: two dependent rounds of loads are two trips to memory in a kernel
             //  that lasts a handful of them)
