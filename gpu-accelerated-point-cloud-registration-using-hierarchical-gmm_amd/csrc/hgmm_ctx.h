@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <cstring>
 #include <vector>
 
 #include "../../include/hgmm.h"
@@ -191,6 +192,7 @@ namespace hgmm {
 // a region of the context's pinned staging ring (flat_kernels.hip); reused only after a stream synchronisation
 int stage_reserve(hgmm_ctx* c, size_t bytes, void** out);
 constexpr size_t STAGE_RING_BYTES = 4u << 20;
+
 }  // namespace hgmm
 
 // Every wait for the context's stream goes through here: the E-step's grid policy (flat_kernels.hip, estep_rows_grid)
@@ -206,6 +208,40 @@ inline hipError_t ctx_stream_sync(hgmm_ctx* c) {
 
 
 namespace hgmm {
+
+// Results of an API call on their way to the caller's (pageable) arrays: every add() enqueues ONE asynchronous DMA into
+// the pinned ring behind the kernels already on the stream (large arrays, or whatever no longer fits half the ring, go
+// straight to their destination), finish() synchronises once and hands the ring's regions out with plain memcpys.
+// (Copied straight into pageable memory each array is staged by the runtime and waited for in turn, ~17 us apiece.)
+struct StagedDownloads {
+    hgmm_ctx* c;
+    struct Pending { void* dst; const void* src; size_t bytes; };
+    std::vector<Pending> pending;
+    size_t staged = 0;
+    hipError_t e = hipSuccess;
+    explicit StagedDownloads(hgmm_ctx* ctx) : c(ctx) {}
+    void add(void* dst, const void* dev_src, size_t bytes) {
+        if (e != hipSuccess || !dst || bytes == 0) return;
+        void* st = nullptr;
+        if (bytes <= (256u << 10) && staged + bytes + 256 <= STAGE_RING_BYTES / 2 && stage_reserve(c, bytes, &st) == 0) {
+            staged += (bytes + 255) & ~(size_t)255;
+            e = hipMemcpyAsync(st, dev_src, bytes, hipMemcpyDeviceToHost, c->stream);
+            pending.push_back({dst, st, bytes});
+        } else {
+            e = hipMemcpyAsync(dst, dev_src, bytes, hipMemcpyDeviceToHost, c->stream);
+        }
+    }
+    // (hipSuccess, or the first error of a copy / of the synchronisation)
+    hipError_t finish() {
+        if (e == hipSuccess) e = ctx_stream_sync(c);
+        if (e == hipSuccess) {
+            for (const Pending& pd : pending) std::memcpy(pd.dst, pd.src, pd.bytes);
+            c->h_stage_off = 0;                            // the stream is idle: every region of the ring is free
+        }
+        pending.clear();
+        return e;
+    }
+};
 
 inline int fail(hgmm_ctx* c, int code, const char* fmt, ...) {
     char buf[512];

@@ -1155,10 +1155,10 @@ extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const 
     }
     (void)pot;
     HGMM_HIP(c, hipGetLastError());
-    if (ids_out) HGMM_HIP(c, hipMemcpyAsync(ids_out, ids, sizeof(int64_t) * k, hipMemcpyDeviceToHost, c->stream));
-    if (centers_out)
-        HGMM_HIP(c, hipMemcpyAsync(centers_out, centres, sizeof(double) * 3 * k, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, ctx_stream_sync(c));
+    StagedDownloads dl(c);
+    dl.add(ids_out, ids, sizeof(int64_t) * k);
+    dl.add(centers_out, centres, sizeof(double) * 3 * k);
+    HGMM_HIP(c, dl.finish());
     return HGMM_OK;
 }
 
@@ -1245,10 +1245,11 @@ extern "C" int hgmm_kmeans_step(hgmm_ctx* c, int k, const double* centers, int r
     HGMM_HIP(c, hipMemsetAsync(L.changed, 0, sizeof(unsigned long long), c->stream));
     HGMM_TRY(km_enqueue(c, k, L, nullptr));
     if (c->comm_on()) HGMM_TRY(allreduce_f64_dev(c, L.out, 4 * (size_t)k + 2));
-    std::vector<double> tail(2);
-    if (sums_out) HGMM_HIP(c, hipMemcpyAsync(sums_out, L.out, sizeof(double) * 4 * k, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, hipMemcpyAsync(tail.data(), L.out + 4 * (size_t)k, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
-    HGMM_HIP(c, ctx_stream_sync(c));
+    double tail[2] = {0.0, 0.0};
+    StagedDownloads dl(c);
+    dl.add(sums_out, L.out, sizeof(double) * 4 * k);
+    dl.add(tail, L.out + 4 * (size_t)k, sizeof tail);
+    HGMM_HIP(c, dl.finish());
     if (inertia_out) *inertia_out = tail[0];
     if (n_changed_out) *n_changed_out = (int64_t)tail[1];
     return HGMM_OK;
@@ -1283,17 +1284,18 @@ extern "C" int hgmm_kmeans_lloyd(hgmm_ctx* c, int k, double* centers_inout, int 
         HGMM_HIP(c, hipMemcpyAsync(&h, L.ctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
         HGMM_HIP(c, ctx_stream_sync(c));
     }
-    HGMM_HIP(c, hipMemcpyAsync(centers_inout, L.c3, sizeof(double) * 3 * k, hipMemcpyDeviceToHost, c->stream));
-    if (h.needs_host) {
-        // the iteration that met an empty cluster: its sums / counts / changed labels, centres untouched
-        std::vector<double> tail(2);
-        if (sums_out)
-            HGMM_HIP(c, hipMemcpyAsync(sums_out, L.out, sizeof(double) * 4 * k, hipMemcpyDeviceToHost, c->stream));
-        HGMM_HIP(c, hipMemcpyAsync(tail.data(), L.out + 4 * (size_t)k, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
-        HGMM_HIP(c, ctx_stream_sync(c));
-        if (n_changed_out) *n_changed_out = (int64_t)tail[1];
+    {
+        double tail[2] = {0.0, 0.0};
+        StagedDownloads dl(c);
+        dl.add(centers_inout, L.c3, sizeof(double) * 3 * k);
+        if (h.needs_host) {
+            // the iteration that met an empty cluster: its sums / counts / changed labels, centres untouched
+            dl.add(sums_out, L.out, sizeof(double) * 4 * k);
+            dl.add(tail, L.out + 4 * (size_t)k, sizeof tail);
+        }
+        HGMM_HIP(c, dl.finish());
+        if (h.needs_host && n_changed_out) *n_changed_out = (int64_t)tail[1];
     }
-    HGMM_HIP(c, ctx_stream_sync(c));
     if (n_iter_out) *n_iter_out = h.it;
     if (strict_out) *strict_out = h.strict;
     if (needs_host_out) *needs_host_out = h.needs_host;

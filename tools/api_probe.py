@@ -14,11 +14,16 @@ ctx = hgmm_amd.Context(0)
 def timeit(label, fn, reps=10, kernel=None):
     # (the first series of calls of a kind carries one-time costs -- code objects, buffers, queues: 8 ms spread over the
     #  first M-step series when it had two warm-up calls -- so every line gets four untimed calls first)
+    # (... and they run with the kernel timers already on: the first timed M-step of a process pays a one-time 8 ms in
+    #  the runtime when its event pairs are first read -- per call 0.52 - 0.55 ms with the timers off, on, and off again,
+    #  except for that one call; profiles/r04/README.md)
+    if kernel:
+        ctx.profile_reset(); ctx.profile_enable(True)
     for _ in range(4):
         fn()
     ctx.synchronize()
     if kernel:
-        ctx.profile_reset(); ctx.profile_enable(True)
+        ctx.profile_reset()
     t0 = time.perf_counter()
     for _ in range(reps):
         fn()
