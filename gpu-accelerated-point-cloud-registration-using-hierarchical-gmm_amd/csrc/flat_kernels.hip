@@ -1661,7 +1661,7 @@ static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static int grid_for(hgmm_ctx* c, int64_t n, int blocks_per_cu) {
     int64_t want = (n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;     // one row per wave at least
     if (blocks_per_cu < 1) blocks_per_cu = 1;
-    if (blocks_per_cu > 4) blocks_per_cu = 4;
+    if (blocks_per_cu > 8) blocks_per_cu = 8;
     int64_t cap = (int64_t)c->cus * blocks_per_cu;
     if (cap > FLAT_MAX_BLOCKS) cap = FLAT_MAX_BLOCKS;
     int64_t g = want < cap ? want : cap;
@@ -1707,8 +1707,8 @@ static int flat_setup(hgmm_ctx* c, int cov_type, int variant, int J) {
     }
     HGMM_TRY(ensure(c, c->f_pack, sizeof(float) * FLAT_NSTAT * Jpad));
     HGMM_TRY(ensure(c, c->f_hint, sizeof(float) * 3 * Jpad));
-    // grid_for() never launches more than min(FLAT_MAX_BLOCKS, 4 workgroups per CU)
-    const size_t max_blocks = std::min<size_t>(FLAT_MAX_BLOCKS, (size_t)c->cus * 4);
+    // grid_for() never launches more than min(FLAT_MAX_BLOCKS, 8 workgroups per CU)
+    const size_t max_blocks = std::min<size_t>(FLAT_MAX_BLOCKS, (size_t)c->cus * 8);
     HGMM_TRY(ensure(c, c->f_partials, sizeof(float) * max_blocks * FLAT_NSTAT * Jpad));
     HGMM_TRY(ensure(c, c->f_lpn_partials,
                     sizeof(double) * std::max<size_t>(FLAT_MAX_BLOCKS, (size_t)((c->n + 255) / 256))));
@@ -2179,14 +2179,29 @@ static int launch_fused(hgmm_ctx* c, const int* done_flag, int* grid_out, int* v
     c->flat.last_kernel = 3;
     const FlatState& f = c->flat;
     if (!done_flag) done_flag = c->f_ctl.as<int>() + 16;        // always 0 (flat_setup)
-    int grid = grid_for(c, c->n, env_int("HGMM_FUSED_BPC", 2));
+    const int ns = (f.J + 63) / 64;
+    // Grid.  Two workgroups per CU are the floor (a small cloud wants every CU busy: bun000 is fastest at 512 workgroups of
+    // 20 rows per wave, tools/bunny_grid.py); a large cloud takes more, as long as a wave keeps ~100 rows: J = 800 (254
+    // registers, two waves per SIMD resident either way) gains 1.6 % from 4 per CU -- a finer tail -- and small J, whose
+    // lanes hold few components and leave the register file empty, gain 10 - 28 % from 6 - 8 per CU: more resident waves
+    // hide the row's reduction chain (N = 1e6: J = 64 0.105 -> 0.075 ms per iteration, J = 100 0.117 -> 0.098, J = 400
+    // 0.227 -> 0.202; profiles/r04/fused_bpc_by_J.log).  More workgroups are more partials for the reduction to read:
+    // the iteration times above include it.  HGMM_FUSED_BPC=<n> fixes the number per CU.
+    int grid;
+    if (env_int("HGMM_FUSED_BPC", 0) > 0) {
+        grid = grid_for(c, c->n, env_int("HGMM_FUSED_BPC", 2));
+    } else {
+        const int bpc_max = ns <= 4 ? 8 : (ns <= 8 ? 6 : 4);
+        const int64_t by_rows = c->n / (WAVES_PER_BLOCK * 100);
+        const int64_t big = std::min<int64_t>(by_rows, std::min<int64_t>((int64_t)c->cus * bpc_max, FLAT_MAX_BLOCKS));
+        grid = (int)std::max<int64_t>(grid_for(c, c->n, 2), big);
+    }
     if (env_int("HGMM_FUSED_GRID", 0) > 0) grid = std::min(grid, env_int("HGMM_FUSED_GRID", 0));
     *grid_out = grid;
     const float* X = c->x_aos.as<float>();
     const float* pk = c->f_pack.as<float>();
     float* part = c->f_partials.as<float>();
     double* lp = c->f_lpn_partials.as<double>();
-    const int ns = (f.J + 63) / 64;
     // Design notes (measured on MI355X at N = 1e6, J = 800; see DESIGN.md section 6 for the list):
     //  * more rows in flight per wave lose: 1 row (249 VGPRs, 2 waves/SIMD) 0.544 ms, 2 rows
     //    (310 regs, 1 wave/SIMD) 0.677 ms, 4 rows (424 regs) 0.772 ms;

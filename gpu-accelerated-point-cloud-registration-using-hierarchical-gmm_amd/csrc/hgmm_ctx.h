@@ -18,7 +18,7 @@ constexpr float FLAT_EPS = 1e-8f;     // gmm_waymo gmm_impl.py:15 / gmmreg_gpu g
 constexpr int FLAT_NSTAT = 7;         // s0, a[3], b[3]
 constexpr int FLAT_MAX_J = 1024;      // single-pass kernels (all parameters of a lane in registers)
 constexpr int FLAT_MAX_J_CHUNKED = 16384;  // chunked path (832-component chunks)
-constexpr int FLAT_MAX_BLOCKS = 1024; // persistent grid upper bound (partials buffer)
+constexpr int FLAT_MAX_BLOCKS = 2048; // persistent grid upper bound (partials buffer)
 
 // A growable device buffer owned by the context.
 struct DevBuf {
