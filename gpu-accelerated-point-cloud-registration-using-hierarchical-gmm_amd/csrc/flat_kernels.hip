@@ -2052,7 +2052,8 @@ static bool predict_rows_layout(int nv4, int nv1) {
 static bool launch_predict_rows(hgmm_ctx* c, int nv4, int nv1, int32_t* labels) {
     const FlatState& f = c->flat;
     // (one frame of 10^6 x 800: 0.38 / 0.26 / 0.26 / 0.24 ms with 1 / 2 / 3 / 4 workgroups per CU; the single-row kernel 0.36)
-    const int grid = grid_for(c, (c->n + 3) / 4, env_int("HGMM_PREDICT_BPC", 4));
+    // (N = 1e6: 8 workgroups per CU beat 4 at every J -- 0.258 -> 0.235 ms at J = 800, 0.080 -> 0.072 at J = 100; profiles/r04/small_j_grids.log)
+    const int grid = grid_for(c, (c->n + 3) / 4, env_int("HGMM_PREDICT_BPC", c->n >= 400000 ? 8 : 4));
     const float* X = c->x_aos.as<float>();
     const float* pk = c->f_pack.as<float>();
 #define PRED_R(A, B) flat_predict_rows_kernel<A, B><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, labels)
@@ -2141,7 +2142,11 @@ static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argma
         // every call pattern and collapses to ~5.3 at 7.0 - 7.4 (tools/pace_sweep.py, profiles/r04/pace_sweep.log).
         // HGMM_ESTEP_TARGET_GBS=0: the un-paced launch with round 3's grid policy (estep_rows_grid).
         const double target = pace_target(c, f.J);
-        const int grid_r = target > 0.0 ? grid_for(c, (c->n + 3) / 4, std::min(2, env_int("HGMM_ESTEP_BPC", 2)))
+        // (few components per lane leave the register file empty: on a large cloud four workgroups per CU -- all
+        //  resident, as the pacer's period assumes -- hide more of the rows' reduction chains: J = 64 0.110 -> 0.082 ms at
+        //  N = 1e6; from J = 256 on two are as good or better, and more than fit at once break the pacing: profiles/r04/small_j_grids.log)
+        const int bpc_rows = (c->n >= 400000 && f.J <= 128) ? 4 : 2;
+        const int grid_r = target > 0.0 ? grid_for(c, (c->n + 3) / 4, std::min(bpc_rows, env_int("HGMM_ESTEP_BPC", bpc_rows)))
                                         : estep_rows_grid(c, cshift);
         const int pace = store_pace16(c, grid_r, f.J, target);
         c->flat.last_kernel = 1;
@@ -2535,7 +2540,11 @@ static int flat_mstep_enqueue(hgmm_ctx* c, int cov_type, int variant, int J, con
         flat_hint_const_kernel<<<(f.Jpad + 255) / 256, 256, 0, c->stream>>>(0.f, 0.f, 0.f, f.Jpad,
                                                                           c->f_hint.as<float>());
     }
-    int grid = grid_for(c, c->n, env_int("HGMM_MSTEP_BPC", 2));
+    // (workgroups per CU: two at J = 800 (three or four lose: mstep_nt_rr_sweep.log); short rows leave registers and
+    //  memory-level parallelism unused -- N = 1e6: J = 64 0.133 -> 0.061 ms with 8, J = 100 0.153 -> 0.082, J = 200 0.183 -> 0.131
+    //  with 4, J = 400 0.271 -> 0.257; from J = 512 on two again: profiles/r04/small_j_grids.log)
+    const int bpc_m = c->n >= 400000 ? (J <= 128 ? 8 : (J <= 448 ? 4 : 2)) : 2;
+    int grid = grid_for(c, c->n, env_int("HGMM_MSTEP_BPC", bpc_m));
     if (env_int("HGMM_MSTEP_GRID", 0) > 0) grid = std::min(grid_for(c, c->n, 4), env_int("HGMM_MSTEP_GRID", 0));
     const int rr = env_int("HGMM_MSTEP_RR", 1);     // rows dealt round-robin: 0.480 against 0.492 ms (profiles/r04/mstep_nt_rr_sweep.log)
     const float* X = c->x_aos.as<float>();
