@@ -2420,6 +2420,7 @@ static int flat_estep_enqueue(hgmm_ctx* c, int cov_type, int variant, int J, con
 extern "C" int hgmm_flat_estep(hgmm_ctx* c, int cov_type, int variant, int J, const float* mu,
                                const float* inv_std, const float* w, float* dev_log_resp,
                                float* dev_lpn, int32_t* dev_argmax, double* mean_lpn_out) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     int grid = 0;
     HGMM_TRY(flat_estep_enqueue(c, cov_type, variant, J, mu, inv_std, w, dev_log_resp, dev_lpn, dev_argmax, &grid));
@@ -2438,6 +2439,7 @@ extern "C" int hgmm_flat_estep(hgmm_ctx* c, int cov_type, int variant, int J, co
 extern "C" int hgmm_flat_estep_async(hgmm_ctx* c, int cov_type, int variant, int J, const float* mu,
                                      const float* inv_std, const float* w, float* dev_log_resp,
                                      float* dev_lpn, int32_t* dev_argmax, double* dev_mean_lpn) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     int grid = 0;
     HGMM_TRY(flat_estep_enqueue(c, cov_type, variant, J, mu, inv_std, w, dev_log_resp, dev_lpn, dev_argmax, &grid));
@@ -2451,6 +2453,7 @@ extern "C" int hgmm_flat_estep_async(hgmm_ctx* c, int cov_type, int variant, int
 extern "C" int hgmm_flat_estep_dev(hgmm_ctx* c, int cov_type, int variant, int J, const float* dev_mu,
                                    const float* dev_inv_std, const float* dev_w, float* dev_log_resp,
                                    float* dev_lpn, int32_t* dev_argmax, double* dev_mean_lpn) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     int grid = 0;
     HGMM_TRY(flat_estep_enqueue(c, cov_type, variant, J, dev_mu, dev_inv_std, dev_w, dev_log_resp, dev_lpn, dev_argmax,
@@ -2463,6 +2466,7 @@ extern "C" int hgmm_flat_estep_dev(hgmm_ctx* c, int cov_type, int variant, int J
 }
 
 extern "C" int hgmm_pace_info(hgmm_ctx* c, double* target_gbs_out, int* steps_down_out, int* steps_up_out) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     pace_poll(c);
     const int fixed = env_int("HGMM_ESTEP_TARGET_GBS", -1);
@@ -2474,6 +2478,7 @@ extern "C" int hgmm_pace_info(hgmm_ctx* c, double* target_gbs_out, int* steps_do
 
 extern "C" int hgmm_flat_predict(hgmm_ctx* c, int cov_type, int variant, int J, const float* mu,
                                  const float* inv_std, const float* w, int32_t* dev_labels) {
+    HGMM_ENTER(c);
     if (!c || !dev_labels) return c ? fail(c, HGMM_ERR_ARG, "dev_labels is NULL") : HGMM_ERR_ARG;
     HGMM_TRY(flat_check(c, cov_type, variant, J));
     HGMM_TRY(flat_setup(c, cov_type, variant, J));
@@ -2487,6 +2492,7 @@ extern "C" int hgmm_flat_predict(hgmm_ctx* c, int cov_type, int variant, int J, 
 
 extern "C" int hgmm_flat_predict_dev(hgmm_ctx* c, int cov_type, int variant, int J, const float* dev_mu,
                                      const float* dev_inv_std, const float* dev_w, int32_t* dev_labels) {
+    HGMM_ENTER(c);
     if (!c || !dev_labels) return c ? fail(c, HGMM_ERR_ARG, "dev_labels is NULL") : HGMM_ERR_ARG;
     if (!dev_mu || !dev_inv_std || !dev_w) return fail(c, HGMM_ERR_ARG, "device parameter array is NULL");
     HGMM_TRY(flat_check(c, cov_type, variant, J));
@@ -2502,6 +2508,7 @@ extern "C" int hgmm_flat_predict_dev(hgmm_ctx* c, int cov_type, int variant, int
 
 extern "C" int hgmm_flat_log_prob(hgmm_ctx* c, int cov_type, int J, const float* mu, const float* inv_std,
                                   float* dev_log_prob) {
+    HGMM_ENTER(c);
     if (!c || !dev_log_prob) return c ? fail(c, HGMM_ERR_ARG, "dev_log_prob is NULL") : HGMM_ERR_ARG;
     // weights = 1 under flavour G (log 1 = 0, no eps) gives the bare log-density
     HGMM_TRY(flat_check(c, cov_type, cov_type == HGMM_COV_DIAG ? HGMM_VARIANT_G : HGMM_VARIANT_W, J));
@@ -2600,6 +2607,7 @@ static int flat_mstep_enqueue(hgmm_ctx* c, int cov_type, int variant, int J, con
 
 extern "C" int hgmm_flat_mstep_dev(hgmm_ctx* c, int cov_type, int variant, int J, const float* dev_resp, int is_log,
                                    const float* dev_centre_hint, float* dev_w, float* dev_mu, float* dev_cov) {
+    HGMM_ENTER(c);
     if (!c || !dev_resp) return c ? fail(c, HGMM_ERR_ARG, "dev_resp is NULL") : HGMM_ERR_ARG;
     if (!dev_w || !dev_mu || !dev_cov) return fail(c, HGMM_ERR_ARG, "device output array is NULL");
     HGMM_TRY(flat_check(c, cov_type, variant, J));
@@ -2610,6 +2618,7 @@ extern "C" int hgmm_flat_mstep_dev(hgmm_ctx* c, int cov_type, int variant, int J
 extern "C" int hgmm_flat_mstep(hgmm_ctx* c, int cov_type, int variant, int J, const float* dev_resp,
                                int is_log, const float* centre_hint, float* w_out, float* mu_out,
                                float* cov_out) {
+    HGMM_ENTER(c);
     if (!c || !dev_resp) return c ? fail(c, HGMM_ERR_ARG, "dev_resp is NULL") : HGMM_ERR_ARG;
     HGMM_TRY(flat_check(c, cov_type, variant, J));
     HGMM_TRY(flat_setup(c, cov_type, variant, J));
@@ -2661,6 +2670,7 @@ __global__ void flat_elementwise_kernel(int op, int64_t n, const float* __restri
 }
 extern "C" int hgmm_elementwise_f32(hgmm_ctx* c, int op, int64_t n, const float* dev_a, const float* dev_b,
                                     float scalar, float* dev_out) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     if (op < 0 || op > HGMM_EW_MIN) return fail(c, HGMM_ERR_ARG, "elementwise op %d", op);
     if (n < 0 || (n > 0 && (!dev_a || !dev_out))) return fail(c, HGMM_ERR_ARG, "elementwise: NULL array");
@@ -2703,6 +2713,7 @@ __global__ void flat_begin_kernel(int J, int Jpad, int cov_type, int variant, co
 extern "C" int hgmm_flat_train_begin(hgmm_ctx* c, int cov_type, int variant, int J, float tol,
                                      const float* mu, const float* cov, const float* w,
                                      int lls_capacity) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     HGMM_TRY(flat_check(c, cov_type, variant, J));
     HGMM_TRY(flat_setup(c, cov_type, variant, J));
@@ -2721,6 +2732,7 @@ extern "C" int hgmm_flat_train_begin(hgmm_ctx* c, int cov_type, int variant, int
 }
 
 extern "C" int hgmm_flat_train_step(hgmm_ctx* c, int iters) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     if (!c->flat.active) return fail(c, HGMM_ERR_STATE, "hgmm_flat_train_step before hgmm_flat_train_begin");
     for (int i = 0; i < iters; ++i) HGMM_TRY(enqueue_em_iteration(c));
@@ -2729,6 +2741,7 @@ extern "C" int hgmm_flat_train_step(hgmm_ctx* c, int iters) {
 
 extern "C" int hgmm_flat_train_end(hgmm_ctx* c, float* mu, float* cov, float* w, float* inv_std_out,
                                    float* lls_out, int* n_iter_out, int* converged_out) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     FlatState& f = c->flat;
     if (!f.active) return fail(c, HGMM_ERR_STATE, "hgmm_flat_train_end before hgmm_flat_train_begin");
@@ -2788,6 +2801,7 @@ extern "C" int hgmm_flat_train_end(hgmm_ctx* c, float* mu, float* cov, float* w,
 extern "C" int hgmm_flat_train(hgmm_ctx* c, int cov_type, int variant, int J, int max_iter, float tol,
                                float* mu, float* cov, float* w, float* inv_std_out, float* lls_out,
                                int* n_iter_out, int* converged_out) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     if (max_iter < 0) return fail(c, HGMM_ERR_ARG, "max_iter < 0");
     HGMM_TRY(hgmm_flat_train_begin(c, cov_type, variant, J, tol, mu, cov, w, max_iter));
@@ -2798,6 +2812,7 @@ extern "C" int hgmm_flat_train(hgmm_ctx* c, int cov_type, int variant, int J, in
 extern "C" int hgmm_flat_stats(hgmm_ctx* c, int cov_type, int variant, int J, const float* mu,
                                const float* inv_std, const float* w, double* stats_out,
                                double* sum_lpn_out, double* n_points_out) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     HGMM_TRY(flat_check(c, cov_type, variant, J));
     HGMM_TRY(flat_setup(c, cov_type, variant, J));

@@ -489,6 +489,7 @@ __global__ __launch_bounds__(256) void util_fill_kernel(float* __restrict__ p, i
 using namespace hgmm;
 
 extern "C" int hgmm_util_fill_f32(hgmm_ctx* c, float* dev, int64_t n, float value, int nontemporal) {
+    HGMM_ENTER(c);
     if (!c || !dev || n < 4) return HGMM_ERR_ARG;
     const int64_t n4 = n / 4;
     // bits 8.. of `nontemporal` select the probe variant: mode = (flags >> 8) & 3, grid = cus * ((flags >> 16) or 8)
@@ -630,6 +631,7 @@ extern "C" int hgmm_destroy(hgmm_ctx* c) {
 
 extern "C" int hgmm_device_info(hgmm_ctx* c, char* name, int name_len, int* compute_units,
                                 int64_t* hbm_bytes) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     hipDeviceProp_t prop;
     HGMM_HIP(c, hipGetDeviceProperties(&prop, c->device));
@@ -644,18 +646,21 @@ extern "C" int hgmm_device_info(hgmm_ctx* c, char* name, int name_len, int* comp
 }
 
 extern "C" int hgmm_synchronize(hgmm_ctx* c) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     HGMM_HIP(c, ctx_stream_sync(c));
     return HGMM_OK;
 }
 
 extern "C" int hgmm_alloc(hgmm_ctx* c, size_t bytes, void** dev_out) {
+    HGMM_ENTER(c);
     if (!c || !dev_out) return HGMM_ERR_ARG;
     HGMM_HIP(c, hipSetDevice(c->device));
     HGMM_HIP(c, hipMalloc(dev_out, bytes ? bytes : 4));
     return HGMM_OK;
 }
 extern "C" int hgmm_free(hgmm_ctx* c, void* dev) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     if (!dev) return HGMM_OK;
     HGMM_HIP(c, ctx_stream_sync(c));
@@ -663,6 +668,7 @@ extern "C" int hgmm_free(hgmm_ctx* c, void* dev) {
     return HGMM_OK;
 }
 extern "C" int hgmm_host_scalars(hgmm_ctx* c, int count, double** host_out, double** dev_out) {
+    HGMM_ENTER(c);
     if (!c || !host_out || !dev_out) return c ? fail(c, HGMM_ERR_ARG, "hgmm_host_scalars: NULL output") : HGMM_ERR_ARG;
     if (count < 1 || count > 4096) return fail(c, HGMM_ERR_ARG, "hgmm_host_scalars: count %d outside 1..4096", count);
     HGMM_HIP(c, hipSetDevice(c->device));
@@ -682,6 +688,7 @@ extern "C" int hgmm_host_scalars(hgmm_ctx* c, int count, double** host_out, doub
     return HGMM_OK;
 }
 extern "C" int hgmm_event_record(hgmm_ctx* c, int slot) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     if (slot < 0 || slot >= HGMM_EVENT_SLOTS) return fail(c, HGMM_ERR_ARG, "event slot %d", slot);
     HGMM_HIP(c, hipSetDevice(c->device));
@@ -690,6 +697,7 @@ extern "C" int hgmm_event_record(hgmm_ctx* c, int slot) {
     return HGMM_OK;
 }
 extern "C" int hgmm_event_wait(hgmm_ctx* c, int slot) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     if (slot < 0 || slot >= HGMM_EVENT_SLOTS) return fail(c, HGMM_ERR_ARG, "event slot %d", slot);
     if (!c->ev_slots[slot]) return fail(c, HGMM_ERR_STATE, "event slot %d was never recorded", slot);
@@ -697,12 +705,14 @@ extern "C" int hgmm_event_wait(hgmm_ctx* c, int slot) {
     return HGMM_OK;
 }
 extern "C" int hgmm_h2d(hgmm_ctx* c, void* dev_dst, const void* host_src, size_t bytes) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     HGMM_HIP(c, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, c->stream));
     HGMM_HIP(c, ctx_stream_sync(c));
     return HGMM_OK;
 }
 extern "C" int hgmm_d2h(hgmm_ctx* c, void* host_dst, const void* dev_src, size_t bytes) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     HGMM_HIP(c, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, c->stream));
     HGMM_HIP(c, ctx_stream_sync(c));
@@ -710,6 +720,7 @@ extern "C" int hgmm_d2h(hgmm_ctx* c, void* host_dst, const void* dev_src, size_t
 }
 
 extern "C" int hgmm_d2d(hgmm_ctx* c, void* dev_dst, const void* dev_src, size_t bytes) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     if (bytes == 0) return HGMM_OK;
     if (!dev_dst || !dev_src) return fail(c, HGMM_ERR_ARG, "hgmm_d2d: NULL pointer");
@@ -767,6 +778,7 @@ static int points_upload_f64(hgmm_ctx* c, hgmm_points* p, const double* xyz, int
 }
 
 extern "C" int hgmm_set_points_f32(hgmm_ctx* c, const float* xyz, int64_t n) {
+    HGMM_ENTER(c);
     if (!c || !xyz) return c ? fail(c, HGMM_ERR_ARG, "xyz is NULL") : HGMM_ERR_ARG;
     bind_points(c, nullptr);                       // (a failed upload leaves nothing bound)
     HGMM_TRY(points_upload_f32(c, &c->own_points, xyz, n));
@@ -775,6 +787,7 @@ extern "C" int hgmm_set_points_f32(hgmm_ctx* c, const float* xyz, int64_t n) {
 }
 
 extern "C" int hgmm_set_points_f64(hgmm_ctx* c, const double* xyz, int64_t n) {
+    HGMM_ENTER(c);
     if (!c || !xyz) return c ? fail(c, HGMM_ERR_ARG, "xyz is NULL") : HGMM_ERR_ARG;
     bind_points(c, nullptr);
     HGMM_TRY(points_upload_f64(c, &c->own_points, xyz, n));
@@ -783,6 +796,7 @@ extern "C" int hgmm_set_points_f64(hgmm_ctx* c, const double* xyz, int64_t n) {
 }
 
 extern "C" int hgmm_points_create_f32(hgmm_ctx* c, const float* xyz, int64_t n, hgmm_points** out) {
+    HGMM_ENTER(c);
     if (!c || !xyz || !out) return c ? fail(c, HGMM_ERR_ARG, "hgmm_points_create: NULL argument") : HGMM_ERR_ARG;
     *out = nullptr;
     hgmm_points* p = new hgmm_points();
@@ -798,6 +812,7 @@ extern "C" int hgmm_points_create_f32(hgmm_ctx* c, const float* xyz, int64_t n, 
 }
 
 extern "C" int hgmm_points_create_f64(hgmm_ctx* c, const double* xyz, int64_t n, hgmm_points** out) {
+    HGMM_ENTER(c);
     if (!c || !xyz || !out) return c ? fail(c, HGMM_ERR_ARG, "hgmm_points_create: NULL argument") : HGMM_ERR_ARG;
     *out = nullptr;
     hgmm_points* p = new hgmm_points();
@@ -813,6 +828,7 @@ extern "C" int hgmm_points_create_f64(hgmm_ctx* c, const double* xyz, int64_t n,
 }
 
 extern "C" int hgmm_points_bind(hgmm_ctx* c, hgmm_points* p) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     if (!p) p = c->own_points.n > 0 ? &c->own_points : nullptr;      // NULL: back to the cloud of hgmm_set_points_*
     if (p && p->ctx != c) return fail(c, HGMM_ERR_ARG, "hgmm_points_bind: the cloud belongs to another context");
@@ -822,6 +838,7 @@ extern "C" int hgmm_points_bind(hgmm_ctx* c, hgmm_points* p) {
 }
 
 extern "C" int hgmm_points_destroy(hgmm_ctx* c, hgmm_points* p) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     if (!p) return HGMM_OK;
     if (p->ctx != c || p == &c->own_points) return fail(c, HGMM_ERR_ARG, "hgmm_points_destroy: not a cloud created on this context");
@@ -847,6 +864,7 @@ extern "C" int hgmm_comm_unique_id(void* id128_out) {
 }
 
 extern "C" int hgmm_comm_init_rank(hgmm_ctx* c, int nranks, int rank, const void* id128) {
+    HGMM_ENTER(c);
     if (!c || !id128) return HGMM_ERR_ARG;
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(c, HGMM_ERR_ARG, "bad rank %d / %d", rank, nranks);
     if (c->comm_on()) return fail(c, HGMM_ERR_STATE, "communicator already attached");
@@ -860,6 +878,7 @@ extern "C" int hgmm_comm_init_rank(hgmm_ctx* c, int nranks, int rank, const void
 }
 
 extern "C" int hgmm_comm_init_host(hgmm_ctx* c, int nranks, int rank, const char* name) {
+    HGMM_ENTER(c);
     if (!c || !name || !name[0]) return c ? fail(c, HGMM_ERR_ARG, "host communicator: name is empty") : HGMM_ERR_ARG;
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(c, HGMM_ERR_ARG, "bad rank %d / %d", rank, nranks);
     if (c->comm_on()) return fail(c, HGMM_ERR_STATE, "communicator already attached");
@@ -919,6 +938,7 @@ extern "C" int hgmm_comm_init_host(hgmm_ctx* c, int nranks, int rank, const char
 }
 
 extern "C" int hgmm_comm_init_ipc(hgmm_ctx* c, int nranks, int rank, const char* name) {
+    HGMM_ENTER(c);
     if (!c || !name || !name[0]) return c ? fail(c, HGMM_ERR_ARG, "peer exchange: name is empty") : HGMM_ERR_ARG;
     if (nranks < 1 || nranks > IPC_MAX_RANKS || rank < 0 || rank >= nranks)
         return fail(c, HGMM_ERR_ARG, "peer exchange: bad rank %d / %d (at most %d ranks: one node)", rank, nranks, IPC_MAX_RANKS);
@@ -1028,6 +1048,7 @@ extern "C" int hgmm_comm_init_ipc(hgmm_ctx* c, int nranks, int rank, const char*
 }
 
 extern "C" int hgmm_comm_destroy(hgmm_ctx* c) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     HGMM_HIP(c, hipSetDevice(c->device));                  // (the current device is per THREAD: a caller may tear down from another one)
     if (c->hcomm) {
@@ -1055,6 +1076,7 @@ extern "C" int hgmm_comm_destroy(hgmm_ctx* c) {
 }
 
 extern "C" int hgmm_comm_allreduce_f64(hgmm_ctx* c, double* host_inout, int n, int op) {
+    HGMM_ENTER(c);
     if (!c || !host_inout || n < 1) return HGMM_ERR_ARG;
     if (!c->comm_on()) return HGMM_OK;   // single rank: identity
     HGMM_TRY(ensure(c, c->comm_buf, sizeof(double) * (size_t)n));
@@ -1073,18 +1095,21 @@ extern "C" int hgmm_comm_allreduce_f64(hgmm_ctx* c, double* host_inout, int n, i
 
 // ---- profiling --------------------------------------------------------------------------------
 extern "C" int hgmm_profile_enable(hgmm_ctx* c, int on) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     if (!on) HGMM_TRY(profile_collect(c));
     c->profiling = on != 0;
     return HGMM_OK;
 }
 extern "C" int hgmm_profile_reset(hgmm_ctx* c) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     HGMM_TRY(profile_collect(c));
     for (int i = 0; i < HGMM_K_COUNT; ++i) { c->prof_ms[i] = 0.0; c->prof_n[i] = 0; }
     return HGMM_OK;
 }
 extern "C" int hgmm_profile_get(hgmm_ctx* c, int kernel_id, double* total_ms_out, int64_t* launches_out) {
+    HGMM_ENTER(c);
     if (!c || kernel_id < 0 || kernel_id >= HGMM_K_COUNT) return HGMM_ERR_ARG;
     HGMM_TRY(profile_collect(c));
     if (total_ms_out) *total_ms_out = c->prof_ms[kernel_id];

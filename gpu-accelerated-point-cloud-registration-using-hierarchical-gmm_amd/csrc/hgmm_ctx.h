@@ -233,11 +233,13 @@ struct StagedDownloads {
     }
     // (hipSuccess, or the first error of a copy / of the synchronisation)
     hipError_t finish() {
-        if (e == hipSuccess) e = ctx_stream_sync(c);
-        if (e == hipSuccess) {
+        // always drain the stream, also after a failed add(): copies enqueued before the failure may still be in flight
+        // into the caller's memory (a stack array in kmeans_kernels.hip), and the ring is only free once they are done
+        const hipError_t es = ctx_stream_sync(c);
+        if (e == hipSuccess) e = es;
+        if (e == hipSuccess)
             for (const Pending& pd : pending) std::memcpy(pd.dst, pd.src, pd.bytes);
-            c->h_stage_off = 0;                            // the stream is idle: every region of the ring is free
-        }
+        if (es == hipSuccess) c->h_stage_off = 0;          // the stream is idle: every region of the ring is free
         pending.clear();
         return e;
     }
@@ -267,6 +269,16 @@ inline int fail(hgmm_ctx* c, int code, const char* fmt, ...) {
         if (r_ != ncclSuccess)                                                           \
             return hgmm::fail((ctx), HGMM_ERR_RCCL, "%s failed: %s (%s:%d)", #call,      \
                               ncclGetErrorString(r_), __FILE__, __LINE__);               \
+    } while (0)
+
+// First statement of every extern "C" entry that takes a context: the current HIP device is a property of the calling
+// THREAD, so a caller that drives two contexts from one thread, or one context from several, gets the context's own
+// device for every allocation, event and launch the entry makes (include/hgmm.h: "distinct contexts may be driven from
+// distinct threads").  hipSetDevice on the device that is already current is a thread-local compare.
+#define HGMM_ENTER(ctx)                                                                  \
+    do {                                                                                 \
+        if (!(ctx)) return HGMM_ERR_ARG;                                                 \
+        HGMM_HIP((ctx), hipSetDevice((ctx)->device));                                    \
     } while (0)
 
 #define HGMM_TRY(expr)                   \

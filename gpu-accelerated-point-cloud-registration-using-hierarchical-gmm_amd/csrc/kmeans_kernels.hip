@@ -1040,6 +1040,7 @@ extern "C" int hgmm_kmeans_center_f64(const double* x, int64_t n, double* mean3,
 
 extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const double* rand_vals,
                                     int n_trials, int64_t* ids_out, double* centers_out) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     HGMM_TRY(km_check(c, k));
     if (k > c->n) return fail(c, HGMM_ERR_ARG, "kmeans++: k = %d exceeds the %lld points", k, (long long)c->n);
@@ -1236,6 +1237,7 @@ int km_enqueue(hgmm_ctx* c, int k, const KmLaunch& L, const int* done) {
 
 extern "C" int hgmm_kmeans_step(hgmm_ctx* c, int k, const double* centers, int reset_labels,
                                 double* sums_out, double* inertia_out, int64_t* n_changed_out) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     HGMM_TRY(km_check(c, k));
     if (!centers) return fail(c, HGMM_ERR_ARG, "kmeans: centers is NULL");
@@ -1258,6 +1260,7 @@ extern "C" int hgmm_kmeans_step(hgmm_ctx* c, int k, const double* centers, int r
 extern "C" int hgmm_kmeans_lloyd(hgmm_ctx* c, int k, double* centers_inout, int max_iter, double tol_abs,
                                  int reset_labels, int* n_iter_out, int* strict_out, int* needs_host_out,
                                  double* sums_out, int64_t* n_changed_out) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     HGMM_TRY(km_check(c, k));
     if (!centers_inout) return fail(c, HGMM_ERR_ARG, "kmeans: centers is NULL");
@@ -1303,6 +1306,7 @@ extern "C" int hgmm_kmeans_lloyd(hgmm_ctx* c, int k, double* centers_inout, int 
 }
 
 extern "C" int hgmm_kmeans_labels(hgmm_ctx* c, int32_t* labels_out, double* min_dist2_out) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     if (c->km_labels_n != c->n || c->n <= 0 || !c->km_labels.p)
         return fail(c, HGMM_ERR_STATE, "kmeans: no assignment on the device (call hgmm_kmeans_step first)");

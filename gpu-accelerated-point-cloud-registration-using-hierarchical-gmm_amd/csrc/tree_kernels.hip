@@ -1732,6 +1732,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                                double sig2, int max_iters_per_level, double* pi_out, double* mu_out,
                                double* cov_out, int32_t* leaf_idx_out, int32_t* iters_per_level_out,
                                double* q_trace_out, int q_capacity, int* q_len_out) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     if (!c->have_f64 || c->n <= 0) return fail(c, HGMM_ERR_STATE, "tree build: set points first");
     if (L < 1 || L > 6) return fail(c, HGMM_ERR_ARG, "tree levels L = %d outside 1..6", L);
@@ -2134,6 +2135,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
 }
 
 extern "C" int hgmm_tree_set_nodes(hgmm_ctx* c, int L, const double* pi, const double* mu, const double* cov) {
+    HGMM_ENTER(c);
     if (!c || !pi || !mu || !cov) return c ? fail(c, HGMM_ERR_ARG, "NULL node table") : HGMM_ERR_ARG;
     if (L < 1 || L > 6) return fail(c, HGMM_ERR_ARG, "tree levels L = %d outside 1..6", L);
     HGMM_HIP(c, hipSetDevice(c->device));
@@ -2155,6 +2157,7 @@ extern "C" int hgmm_tree_set_nodes(hgmm_ctx* c, int L, const double* pi, const d
 }
 
 extern "C" int hgmm_tree_set_target(hgmm_ctx* c, const double* xyz, int64_t n) {
+    HGMM_ENTER(c);
     if (!c || !xyz) return c ? fail(c, HGMM_ERR_ARG, "xyz is NULL") : HGMM_ERR_ARG;
     if (n <= 0) return fail(c, HGMM_ERR_ARG, "target must have at least one point");
     HGMM_HIP(c, hipSetDevice(c->device));
@@ -2245,6 +2248,7 @@ static int reg_estep_fixed(hgmm_ctx* c, const double* rot, const double* t, doub
 
 extern "C" int hgmm_tree_reg_estep(hgmm_ctx* c, const double* rot, const double* t, double scale,
                                    double lambda_c, double* m0_out, double* m1_out, double* m2_out) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     double D = 1.0;
     int F = 0;
@@ -2269,6 +2273,7 @@ extern "C" int hgmm_tree_reg_estep(hgmm_ctx* c, const double* rot, const double*
 
 extern "C" int hgmm_tree_reg_normal(hgmm_ctx* c, const double* rot, const double* t, double scale,
                                     double lambda_c, double* out28) {
+    HGMM_ENTER(c);
     if (!c || !out28) return c ? fail(c, HGMM_ERR_ARG, "out28 is NULL") : HGMM_ERR_ARG;
     double D = 1.0;
     int F = 0;
@@ -2394,6 +2399,7 @@ void twist_compose(const double (&x)[6], double* rot, double* t) {
 extern "C" int hgmm_tree_register(hgmm_ctx* c, double* rot, double* t, double scale, double lambda_c, int max_iter,
                                   double tol, double* q_prev_inout, int* iters_out, int* status_out,
                                   double* trace /*[max_iter][13] or NULL*/) {
+    HGMM_ENTER(c);
     if (!c || !rot || !t || !q_prev_inout || !iters_out || !status_out)
         return c ? fail(c, HGMM_ERR_ARG, "tree_register: NULL argument") : HGMM_ERR_ARG;
     *iters_out = 0;
@@ -2429,6 +2435,7 @@ extern "C" int hgmm_tree_register(hgmm_ctx* c, double* rot, double* t, double sc
 }
 
 extern "C" int hgmm_tree_node_complexity(hgmm_ctx* c, double* cplx_out) {
+    HGMM_ENTER(c);
     if (!c || !cplx_out) return c ? fail(c, HGMM_ERR_ARG, "cplx_out is NULL") : HGMM_ERR_ARG;
     if (!c->tree.nodes_ready) return fail(c, HGMM_ERR_STATE, "no tree");
     const int64_t T = c->tree.T;
@@ -3168,6 +3175,7 @@ static int fullcov_pass(hgmm_ctx* c, int J, int* labels, double* q_host) {
 extern "C" int hgmm_fullcov_fit(hgmm_ctx* c, int J, double ls, double ld, const double* init_mu, double sig2,
                                 int max_iters, double* pi_out, double* mu_out, double* cov_out,
                                 int32_t* labels_out, double* q_trace_out, int q_capacity, int* q_len_out) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     if (!c->have_f64 || c->n <= 0) return fail(c, HGMM_ERR_STATE, "full-covariance fit: set points first");
     if (J < 1 || J > 4096) return fail(c, HGMM_ERR_ARG, "J = %d outside 1..4096", J);
@@ -3280,6 +3288,7 @@ extern "C" int hgmm_fullcov_fit(hgmm_ctx* c, int J, double ls, double ld, const 
 extern "C" int hgmm_fullcov_estep(hgmm_ctx* c, int J, const double* pi, const double* mu, const double* cov,
                                   double* m0_out, double* m1_out, double* m2_out, int32_t* labels_out,
                                   double* q_out) {
+    HGMM_ENTER(c);
     if (!c || !pi || !mu || !cov) return c ? fail(c, HGMM_ERR_ARG, "NULL parameter table") : HGMM_ERR_ARG;
     if (!c->have_f64 || c->n <= 0) return fail(c, HGMM_ERR_STATE, "full-covariance E-step: set points first");
     if (J < 1 || J > 4096) return fail(c, HGMM_ERR_ARG, "J = %d outside 1..4096", J);
@@ -3477,6 +3486,7 @@ static int tree_upload_nodes(hgmm_ctx* c, int64_t T, const double* pi, const dou
 extern "C" int hgmm_tree_estep(hgmm_ctx* c, int64_t T, const double* pi, const double* mu, const double* cov,
                                const int32_t* parent_idx, double* m0_out, double* m1_out, double* m2_out,
                                int32_t* current_idx_out) {
+    HGMM_ENTER(c);
     if (!c || !pi || !mu || !cov || !parent_idx) return c ? fail(c, HGMM_ERR_ARG, "NULL argument") : HGMM_ERR_ARG;
     if (!c->have_f64 || c->n <= 0) return fail(c, HGMM_ERR_STATE, "tree E-step: set points first");
     if (T < 8) return fail(c, HGMM_ERR_ARG, "node table must hold at least 8 nodes");
@@ -3544,6 +3554,7 @@ extern "C" int hgmm_tree_estep(hgmm_ctx* c, int64_t T, const double* pi, const d
 extern "C" int hgmm_tree_mstep(hgmm_ctx* c, int64_t T, const double* m0, const double* m1, const double* m2,
                                int64_t j_begin, int64_t j_end, double n_points, double ld, double* pi_inout,
                                double* mu_inout, double* cov_inout) {
+    HGMM_ENTER(c);
     if (!c || !m0 || !m1 || !m2 || !pi_inout || !mu_inout || !cov_inout)
         return c ? fail(c, HGMM_ERR_ARG, "NULL argument") : HGMM_ERR_ARG;
     if (j_begin < 0 || j_end > T || j_begin >= j_end) return fail(c, HGMM_ERR_ARG, "bad node range");
@@ -3573,6 +3584,7 @@ extern "C" int hgmm_tree_mstep(hgmm_ctx* c, int64_t T, const double* m0, const d
 
 extern "C" int hgmm_tree_loglik(hgmm_ctx* c, int64_t T, const double* pi, const double* mu, const double* cov,
                                 int64_t j_begin, int64_t j_end, double* q_out) {
+    HGMM_ENTER(c);
     if (!c || !pi || !mu || !cov || !q_out) return c ? fail(c, HGMM_ERR_ARG, "NULL argument") : HGMM_ERR_ARG;
     if (!c->have_f64 || c->n <= 0) return fail(c, HGMM_ERR_STATE, "tree log-likelihood: set points first");
     if (j_begin < 0 || j_end > T || j_begin >= j_end) return fail(c, HGMM_ERR_ARG, "bad node range");
@@ -3600,6 +3612,7 @@ extern "C" int hgmm_tree_loglik(hgmm_ctx* c, int64_t T, const double* pi, const 
 }
 
 extern "C" int hgmm_tree_stats(hgmm_ctx* c, unsigned long long* pairs_out, int* flags_out) {
+    HGMM_ENTER(c);
     if (!c) return HGMM_ERR_ARG;
     HGMM_HIP(c, hipSetDevice(c->device));
     HGMM_TRY(tree_flags(c, false));
