@@ -13,7 +13,7 @@ The reference's scripts import its modules by their bare names (``from gmm impor
 ``import cost_functions as cf`` ...): ``hgmm_amd.install_dropin("gmm_waymo" | "gmmreg_gpu" | "hgmm")``
 registers this package's mirrors under those names, see INTEGRATION.md section 1.
 """
-from ._native import Context, DeviceArray, DeviceScalar, HgmmError, default_context, set_default_context, load_library  # noqa: F401
+from ._native import Context, DeviceArray, DeviceScalar, HgmmError, default_context, set_default_context, use_context, load_library  # noqa: F401
 from ._flat import DevicePoints, asarray  # noqa: F401
 
 from ._dropin import install_dropin, uninstall_dropin  # noqa: F401

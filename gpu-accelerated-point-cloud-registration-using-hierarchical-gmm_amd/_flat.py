@@ -32,6 +32,12 @@ class DevicePoints:
     def __len__(self):
         return self.shape[0]
 
+    def get(self):
+        """The cloud back on the host, float32 [N,3] (``cupy.asnumpy``)."""
+        if self._h is None:
+            raise RuntimeError("this DevicePoints has been freed")
+        return self.ctx.points_download(self._h)
+
     def bind(self):
         if self._h is None:
             raise RuntimeError("this DevicePoints has been freed")
@@ -74,9 +80,10 @@ def _param(a):
 
 
 @contextlib.contextmanager
-def timer(message):
-    """gmm_impl.timer: synchronise, time, print (gmm_waymo/src/gmm_impl.py:43-50)."""
-    ctx = default_context()
+def timer(message, ctx=None):
+    """gmm_impl.timer: synchronise, time, print (gmm_waymo/src/gmm_impl.py:43-50).  ``ctx``: the context whose stream
+    is waited for (default: the process-wide one, like the reference's null stream)."""
+    ctx = ctx or default_context()
     ctx.synchronize()
     start = time.time()
     yield

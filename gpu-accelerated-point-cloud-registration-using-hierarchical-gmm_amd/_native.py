@@ -6,6 +6,7 @@ gfx950 device is visible, loading / context creation raises ``HgmmError`` loudly
 from __future__ import annotations
 
 import ctypes as C
+import contextlib
 import os
 import threading
 import weakref
@@ -77,6 +78,7 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_points_bind", [ctx, _vp])
         _sig(lib, "hgmm_points_destroy", [ctx, _vp])
         _sig(lib, "hgmm_points_count", [_vp], C.c_int64)
+        _sig(lib, "hgmm_points_download_f32", [ctx, _vp, _vp])
         _sig(lib, "hgmm_flat_estep", [ctx, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _f64p])
         _sig(lib, "hgmm_flat_estep_async", [ctx, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
         _sig(lib, "hgmm_flat_estep_dev", [ctx, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
@@ -676,6 +678,13 @@ class Context:
         self._points_handles.add(h.value)
         return h
 
+    def points_download(self, handle=None):
+        """The float32 rows [N,3] of a resident cloud (None: the bound one) as a NumPy array."""
+        n = int(self.lib.hgmm_points_count(handle)) if handle else self.num_points
+        out = np.empty((n, 3), dtype=np.float32)
+        self._check(self.lib.hgmm_points_download_f32(self.h, handle, _ptr(out)))
+        return out
+
     def points_bind(self, handle):
         """Every following call works on this cloud (None: the cloud of the last set_points)."""
         self._check(self.lib.hgmm_points_bind(self.h, handle))
@@ -1109,8 +1118,12 @@ _default_ctx = None
 
 
 def default_context() -> Context:
-    """Process-wide context on the rank's GPU (LOCAL_RANK, else device 0)."""
+    """The context the module-level API works on: the calling THREAD's (``use_context``, what a replica worker runs
+    under) or else the process-wide one on the rank's GPU (LOCAL_RANK, else device 0)."""
     global _default_ctx
+    tl = getattr(_thread_ctx, "ctx", None)
+    if tl is not None and getattr(tl, "h", None):
+        return tl
     if _default_ctx is None or not getattr(_default_ctx, "h", None):
         _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
     return _default_ctx
@@ -1119,3 +1132,19 @@ def default_context() -> Context:
 def set_default_context(ctx):
     global _default_ctx
     _default_ctx = ctx
+
+
+_thread_ctx = threading.local()
+
+
+@contextlib.contextmanager
+def use_context(ctx):
+    """Inside the block ``default_context()`` of THIS thread is ``ctx``: every module-level function of the mirrors
+    (``train_gmm``, ``buildGMMTree``, ``registration_gmmreg`` ...) that is not handed a context runs on it.  One thread
+    per context is how hgmm_amd.replicas fans independent pairs / frames out over the GPUs."""
+    prev = getattr(_thread_ctx, "ctx", None)
+    _thread_ctx.ctx = ctx
+    try:
+        yield ctx
+    finally:
+        _thread_ctx.ctx = prev

@@ -679,7 +679,14 @@ __global__ __launch_bounds__(BLOCK) void flat_logprob_rows_pk_kernel(
 // (The single-row kernel this replaces for predict ran 0.33 ms per 10^6 x 800 frame; its row maximum, index search
 //  and two 6-step wave reductions were one dependent chain per row.)
 // ------------------------------------------------------------------------------------------
-template <int NV4, int NV1>
+// MODE 0: every lane searches its own K values for the row maximum (compare + select per component on all 64 lanes)
+//         and a second 4-wide DPP reduction finds the smallest index -- although ONE lane holds the maximum.
+// MODE 1: the search leaves the per-lane VALU stream: `ballot(lane_max == m)` names the lanes that hold the maximum; when
+//         it is exactly one lane (every row of real data) its K values are read into SGPRs (K v_readlane) and compared as
+//         bit patterns on the scalar unit, which runs beside the other waves' vector work.  Ties across lanes, a +0 / -0
+//         pair or NaNs take the MODE 0 search for that row alone (wave-uniform branch), so the labels are those of MODE 0
+//         bit for bit.
+template <int NV4, int NV1, int MODE>
 __global__ __launch_bounds__(BLOCK) void flat_predict_rows_kernel(
     const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int J, int Jpad,
     int32_t* __restrict__ labels) {
@@ -709,9 +716,11 @@ __global__ __launch_bounds__(BLOCK) void flat_predict_rows_kernel(
         g0s = ld(PK_G + 0, j); g1s = ld(PK_G + 1, j); g2s = ld(PK_G + 2, j);
         cs = ld(PK_C, j);
     }
-    float njf[K];                                  // -(index): the smallest index is the largest of these
+    float njf[MODE == 0 ? K : 1];                  // -(index): the smallest index is the largest of these
+    if (MODE == 0) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) njf[k] = -(float)L::j_of(k, lane);
+        for (int k = 0; k < K; ++k) njf[k] = -(float)L::j_of(k, lane);
+    }
 
     const int64_t nw = (int64_t)gridDim.x * WAVES_PER_BLOCK;
     const int64_t gw = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
@@ -757,19 +766,52 @@ __global__ __launch_bounds__(BLOCK) void flat_predict_rows_kernel(
             }
             m[r] = mm;
         }
+        float lm[ROWS];
+        if (MODE == 1) {
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) lm[r] = m[r];
+        }
         wave_max4_dpp(m);
         float b[ROWS];
+        if (MODE == 1) {
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            float best = NEG_INF;                                  // descending k: the last hit is the lane's smallest index
+            for (int r = 0; r < ROWS; ++r) {
+                const unsigned long long holders = __builtin_amdgcn_ballot_w64(lm[r] == m[r]);
+                int kk = -1, hl = 0;
+                if (__builtin_popcountll(holders) == 1) {          // wave-uniform
+                    hl = (int)__builtin_ctzll(holders);
+                    const int mb = __float_as_int(m[r]);
 #pragma unroll
-            for (int k = K - 1; k >= 0; --k) {
-                const float val = (ODD && k == K - 1) ? wls[r] : ((k & 1) ? wl[r][k >> 1].y : wl[r][k >> 1].x);
-                best = (val == m[r]) ? njf[k] : best;
+                    for (int k = K - 1; k >= 0; --k) {
+                        const float val = (ODD && k == K - 1) ? wls[r] : ((k & 1) ? wl[r][k >> 1].y : wl[r][k >> 1].x);
+                        kk = (__builtin_amdgcn_readlane(__float_as_int(val), hl) == mb) ? k : kk;
+                    }
+                }
+                if (kk >= 0) {
+                    b[r] = -(float)L::j_of(kk, hl);
+                } else {                                            // several holders, or no bitwise match: the per-lane search
+                    int bk = -1;                                    // (slot numbers are inline constants: no index table in registers)
+#pragma unroll
+                    for (int k = K - 1; k >= 0; --k) {
+                        const float val = (ODD && k == K - 1) ? wls[r] : ((k & 1) ? wl[r][k >> 1].y : wl[r][k >> 1].x);
+                        bk = (val == m[r]) ? k : bk;
+                    }
+                    b[r] = wave_max_dpp(bk < 0 ? NEG_INF : -(float)L::j_of(bk, lane));
+                }
             }
-            b[r] = best;
+        } else {
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                float best = NEG_INF;                              // descending k: the last hit is the lane's smallest index
+#pragma unroll
+                for (int k = K - 1; k >= 0; --k) {
+                    const float val = (ODD && k == K - 1) ? wls[r] : ((k & 1) ? wl[r][k >> 1].y : wl[r][k >> 1].x);
+                    best = (val == m[r]) ? njf[MODE == 0 ? k : 0] : best;
+                }
+                b[r] = best;
+            }
+            wave_max4_dpp(b);
         }
-        wave_max4_dpp(b);
         if (lane < ROWS) {
             const int64_t row = g * ROWS + lane;
             const float mb = lane == 0 ? m[0] : lane == 1 ? m[1] : lane == 2 ? m[2] : m[3];
@@ -2056,7 +2098,16 @@ static bool launch_predict_rows(hgmm_ctx* c, int nv4, int nv1, int32_t* labels) 
     const int grid = grid_for(c, (c->n + 3) / 4, env_int("HGMM_PREDICT_BPC", c->n >= 400000 ? 8 : 4));
     const float* X = c->x_aos.as<float>();
     const float* pk = c->f_pack.as<float>();
-#define PRED_R(A, B) flat_predict_rows_kernel<A, B><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, labels)
+    // (MODE 1 -- ballot + 13 v_readlane + scalar compares, 157 VGPRs = 3 waves per SIMD instead of 174 = 2 -- measured on the
+    //  C3 frame: 0.251 ms against MODE 0's 0.246 at J = 800, 0.334 against 0.276 at J = 1024, equal within noise below;
+    //  labels identical.  profiles/r05/predict_modes.log.  The marginal cost per component is already the VALU floor of
+    //  4.5 packed + 2.5 plain instructions; what remains is ~0.06 ms that does not depend on J.)
+    const int mode = env_int("HGMM_PREDICT_MODE", 0);
+#define PRED_R(A, B)                                                                                                 \
+    do {                                                                                                             \
+        if (mode == 1) flat_predict_rows_kernel<A, B, 1><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, labels);  \
+        else flat_predict_rows_kernel<A, B, 0><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, labels);           \
+    } while (0)
     if (nv4 == 3 && nv1 == 1) PRED_R(3, 1);
     else if (nv4 == 3 && nv1 == 0) PRED_R(3, 0);
     else if (nv4 == 3 && nv1 == 2) PRED_R(3, 2);
@@ -2421,7 +2472,6 @@ extern "C" int hgmm_flat_estep(hgmm_ctx* c, int cov_type, int variant, int J, co
                                const float* inv_std, const float* w, float* dev_log_resp,
                                float* dev_lpn, int32_t* dev_argmax, double* mean_lpn_out) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     int grid = 0;
     HGMM_TRY(flat_estep_enqueue(c, cov_type, variant, J, mu, inv_std, w, dev_log_resp, dev_lpn, dev_argmax, &grid));
     if (mean_lpn_out) {
@@ -2440,7 +2490,6 @@ extern "C" int hgmm_flat_estep_async(hgmm_ctx* c, int cov_type, int variant, int
                                      const float* inv_std, const float* w, float* dev_log_resp,
                                      float* dev_lpn, int32_t* dev_argmax, double* dev_mean_lpn) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     int grid = 0;
     HGMM_TRY(flat_estep_enqueue(c, cov_type, variant, J, mu, inv_std, w, dev_log_resp, dev_lpn, dev_argmax, &grid));
     if (dev_mean_lpn) {
@@ -2454,7 +2503,6 @@ extern "C" int hgmm_flat_estep_dev(hgmm_ctx* c, int cov_type, int variant, int J
                                    const float* dev_inv_std, const float* dev_w, float* dev_log_resp,
                                    float* dev_lpn, int32_t* dev_argmax, double* dev_mean_lpn) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     int grid = 0;
     HGMM_TRY(flat_estep_enqueue(c, cov_type, variant, J, dev_mu, dev_inv_std, dev_w, dev_log_resp, dev_lpn, dev_argmax,
                                 &grid, /*params_on_device=*/true));
@@ -2467,7 +2515,6 @@ extern "C" int hgmm_flat_estep_dev(hgmm_ctx* c, int cov_type, int variant, int J
 
 extern "C" int hgmm_pace_info(hgmm_ctx* c, double* target_gbs_out, int* steps_down_out, int* steps_up_out) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     pace_poll(c);
     const int fixed = env_int("HGMM_ESTEP_TARGET_GBS", -1);
     if (target_gbs_out) *target_gbs_out = fixed >= 0 ? (double)fixed : (c->pace.target > 0.0 ? c->pace.target : (double)ESTEP_TARGET_GBS);
@@ -2671,7 +2718,6 @@ __global__ void flat_elementwise_kernel(int op, int64_t n, const float* __restri
 extern "C" int hgmm_elementwise_f32(hgmm_ctx* c, int op, int64_t n, const float* dev_a, const float* dev_b,
                                     float scalar, float* dev_out) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     if (op < 0 || op > HGMM_EW_MIN) return fail(c, HGMM_ERR_ARG, "elementwise op %d", op);
     if (n < 0 || (n > 0 && (!dev_a || !dev_out))) return fail(c, HGMM_ERR_ARG, "elementwise: NULL array");
     if (n == 0) return HGMM_OK;
@@ -2714,7 +2760,6 @@ extern "C" int hgmm_flat_train_begin(hgmm_ctx* c, int cov_type, int variant, int
                                      const float* mu, const float* cov, const float* w,
                                      int lls_capacity) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     HGMM_TRY(flat_check(c, cov_type, variant, J));
     HGMM_TRY(flat_setup(c, cov_type, variant, J));
     if (lls_capacity < 1) lls_capacity = 1;
@@ -2733,7 +2778,6 @@ extern "C" int hgmm_flat_train_begin(hgmm_ctx* c, int cov_type, int variant, int
 
 extern "C" int hgmm_flat_train_step(hgmm_ctx* c, int iters) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     if (!c->flat.active) return fail(c, HGMM_ERR_STATE, "hgmm_flat_train_step before hgmm_flat_train_begin");
     for (int i = 0; i < iters; ++i) HGMM_TRY(enqueue_em_iteration(c));
     return HGMM_OK;
@@ -2742,7 +2786,6 @@ extern "C" int hgmm_flat_train_step(hgmm_ctx* c, int iters) {
 extern "C" int hgmm_flat_train_end(hgmm_ctx* c, float* mu, float* cov, float* w, float* inv_std_out,
                                    float* lls_out, int* n_iter_out, int* converged_out) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     FlatState& f = c->flat;
     if (!f.active) return fail(c, HGMM_ERR_STATE, "hgmm_flat_train_end before hgmm_flat_train_begin");
     // The results come back through the pinned ring: the whole parameter block [cov | mu | w | inv], the control words
@@ -2802,7 +2845,6 @@ extern "C" int hgmm_flat_train(hgmm_ctx* c, int cov_type, int variant, int J, in
                                float* mu, float* cov, float* w, float* inv_std_out, float* lls_out,
                                int* n_iter_out, int* converged_out) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     if (max_iter < 0) return fail(c, HGMM_ERR_ARG, "max_iter < 0");
     HGMM_TRY(hgmm_flat_train_begin(c, cov_type, variant, J, tol, mu, cov, w, max_iter));
     HGMM_TRY(hgmm_flat_train_step(c, max_iter));
@@ -2813,7 +2855,6 @@ extern "C" int hgmm_flat_stats(hgmm_ctx* c, int cov_type, int variant, int J, co
                                const float* inv_std, const float* w, double* stats_out,
                                double* sum_lpn_out, double* n_points_out) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     HGMM_TRY(flat_check(c, cov_type, variant, J));
     HGMM_TRY(flat_setup(c, cov_type, variant, J));
     HGMM_TRY(flat_upload(c, mu, inv_std, false, w));

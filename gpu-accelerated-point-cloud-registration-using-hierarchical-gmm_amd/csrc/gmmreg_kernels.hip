@@ -63,7 +63,6 @@ using namespace hgmm;
 extern "C" int hgmm_gauss_transform(hgmm_ctx* c, const double* centres, int n_centres, const double* points,
                                     int n_points, const double* weights, int n_weights, double h, double* out) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     if (!centres || !points || !weights || !out) return fail(c, HGMM_ERR_ARG, "gauss transform: NULL argument");
     if (n_centres < 1 || n_points < 1) return fail(c, HGMM_ERR_ARG, "gauss transform: empty point set");
     if (n_weights < 1 || n_weights > GT_MAX_W)

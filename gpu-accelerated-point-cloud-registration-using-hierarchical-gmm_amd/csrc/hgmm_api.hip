@@ -632,7 +632,6 @@ extern "C" int hgmm_destroy(hgmm_ctx* c) {
 extern "C" int hgmm_device_info(hgmm_ctx* c, char* name, int name_len, int* compute_units,
                                 int64_t* hbm_bytes) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     hipDeviceProp_t prop;
     HGMM_HIP(c, hipGetDeviceProperties(&prop, c->device));
     if (name && name_len > 0) {
@@ -647,7 +646,6 @@ extern "C" int hgmm_device_info(hgmm_ctx* c, char* name, int name_len, int* comp
 
 extern "C" int hgmm_synchronize(hgmm_ctx* c) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     HGMM_HIP(c, ctx_stream_sync(c));
     return HGMM_OK;
 }
@@ -661,7 +659,6 @@ extern "C" int hgmm_alloc(hgmm_ctx* c, size_t bytes, void** dev_out) {
 }
 extern "C" int hgmm_free(hgmm_ctx* c, void* dev) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     if (!dev) return HGMM_OK;
     HGMM_HIP(c, ctx_stream_sync(c));
     HGMM_HIP(c, hipFree(dev));
@@ -689,7 +686,6 @@ extern "C" int hgmm_host_scalars(hgmm_ctx* c, int count, double** host_out, doub
 }
 extern "C" int hgmm_event_record(hgmm_ctx* c, int slot) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     if (slot < 0 || slot >= HGMM_EVENT_SLOTS) return fail(c, HGMM_ERR_ARG, "event slot %d", slot);
     HGMM_HIP(c, hipSetDevice(c->device));
     if (!c->ev_slots[slot]) HGMM_HIP(c, hipEventCreateWithFlags(&c->ev_slots[slot], hipEventDisableTiming));
@@ -698,7 +694,6 @@ extern "C" int hgmm_event_record(hgmm_ctx* c, int slot) {
 }
 extern "C" int hgmm_event_wait(hgmm_ctx* c, int slot) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     if (slot < 0 || slot >= HGMM_EVENT_SLOTS) return fail(c, HGMM_ERR_ARG, "event slot %d", slot);
     if (!c->ev_slots[slot]) return fail(c, HGMM_ERR_STATE, "event slot %d was never recorded", slot);
     HGMM_HIP(c, hipEventSynchronize(c->ev_slots[slot]));
@@ -706,14 +701,12 @@ extern "C" int hgmm_event_wait(hgmm_ctx* c, int slot) {
 }
 extern "C" int hgmm_h2d(hgmm_ctx* c, void* dev_dst, const void* host_src, size_t bytes) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     HGMM_HIP(c, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, c->stream));
     HGMM_HIP(c, ctx_stream_sync(c));
     return HGMM_OK;
 }
 extern "C" int hgmm_d2h(hgmm_ctx* c, void* host_dst, const void* dev_src, size_t bytes) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     HGMM_HIP(c, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, c->stream));
     HGMM_HIP(c, ctx_stream_sync(c));
     return HGMM_OK;
@@ -721,7 +714,6 @@ extern "C" int hgmm_d2h(hgmm_ctx* c, void* host_dst, const void* dev_src, size_t
 
 extern "C" int hgmm_d2d(hgmm_ctx* c, void* dev_dst, const void* dev_src, size_t bytes) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     if (bytes == 0) return HGMM_OK;
     if (!dev_dst || !dev_src) return fail(c, HGMM_ERR_ARG, "hgmm_d2d: NULL pointer");
     HGMM_HIP(c, hipMemcpyAsync(dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice, c->stream));
@@ -829,7 +821,6 @@ extern "C" int hgmm_points_create_f64(hgmm_ctx* c, const double* xyz, int64_t n,
 
 extern "C" int hgmm_points_bind(hgmm_ctx* c, hgmm_points* p) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     if (!p) p = c->own_points.n > 0 ? &c->own_points : nullptr;      // NULL: back to the cloud of hgmm_set_points_*
     if (p && p->ctx != c) return fail(c, HGMM_ERR_ARG, "hgmm_points_bind: the cloud belongs to another context");
     if (p == c->bound) return HGMM_OK;             // (kernels already enqueued keep the pointers they were launched with)
@@ -839,7 +830,6 @@ extern "C" int hgmm_points_bind(hgmm_ctx* c, hgmm_points* p) {
 
 extern "C" int hgmm_points_destroy(hgmm_ctx* c, hgmm_points* p) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     if (!p) return HGMM_OK;
     if (p->ctx != c || p == &c->own_points) return fail(c, HGMM_ERR_ARG, "hgmm_points_destroy: not a cloud created on this context");
     if (c->bound == p) bind_points(c, nullptr);
@@ -852,6 +842,16 @@ extern "C" int hgmm_points_destroy(hgmm_ctx* c, hgmm_points* p) {
 }
 
 extern "C" int64_t hgmm_points_count(const hgmm_points* p) { return p ? p->n : 0; }
+
+extern "C" int hgmm_points_download_f32(hgmm_ctx* c, const hgmm_points* p, float* xyz_out) {
+    HGMM_ENTER(c);
+    if (!p) p = c->bound;                          // NULL: the cloud the context works on
+    if (!p || !xyz_out) return fail(c, HGMM_ERR_ARG, "hgmm_points_download_f32: no cloud / NULL output");
+    if (p->ctx != c && p != &c->own_points) return fail(c, HGMM_ERR_ARG, "hgmm_points_download_f32: the cloud belongs to another context");
+    HGMM_HIP(c, hipMemcpyAsync(xyz_out, p->x_aos.p, sizeof(float) * 3 * (size_t)p->n, hipMemcpyDeviceToHost, c->stream));
+    HGMM_HIP(c, ctx_stream_sync(c));
+    return HGMM_OK;
+}
 
 // ---- RCCL -----------------------------------------------------------------------------------
 extern "C" int hgmm_comm_unique_id(void* id128_out) {
@@ -1049,7 +1049,6 @@ extern "C" int hgmm_comm_init_ipc(hgmm_ctx* c, int nranks, int rank, const char*
 
 extern "C" int hgmm_comm_destroy(hgmm_ctx* c) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     HGMM_HIP(c, hipSetDevice(c->device));                  // (the current device is per THREAD: a caller may tear down from another one)
     if (c->hcomm) {
         HGMM_HIP(c, ctx_stream_sync(c));
@@ -1096,14 +1095,12 @@ extern "C" int hgmm_comm_allreduce_f64(hgmm_ctx* c, double* host_inout, int n, i
 // ---- profiling --------------------------------------------------------------------------------
 extern "C" int hgmm_profile_enable(hgmm_ctx* c, int on) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     if (!on) HGMM_TRY(profile_collect(c));
     c->profiling = on != 0;
     return HGMM_OK;
 }
 extern "C" int hgmm_profile_reset(hgmm_ctx* c) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     HGMM_TRY(profile_collect(c));
     for (int i = 0; i < HGMM_K_COUNT; ++i) { c->prof_ms[i] = 0.0; c->prof_n[i] = 0; }
     return HGMM_OK;

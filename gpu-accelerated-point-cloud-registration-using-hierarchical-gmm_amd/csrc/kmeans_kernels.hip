@@ -1041,7 +1041,6 @@ extern "C" int hgmm_kmeans_center_f64(const double* x, int64_t n, double* mean3,
 extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const double* rand_vals,
                                     int n_trials, int64_t* ids_out, double* centers_out) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     HGMM_TRY(km_check(c, k));
     if (k > c->n) return fail(c, HGMM_ERR_ARG, "kmeans++: k = %d exceeds the %lld points", k, (long long)c->n);
     if (n_trials < 1 || n_trials > KM_MAX_TRIALS)
@@ -1238,7 +1237,6 @@ int km_enqueue(hgmm_ctx* c, int k, const KmLaunch& L, const int* done) {
 extern "C" int hgmm_kmeans_step(hgmm_ctx* c, int k, const double* centers, int reset_labels,
                                 double* sums_out, double* inertia_out, int64_t* n_changed_out) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     HGMM_TRY(km_check(c, k));
     if (!centers) return fail(c, HGMM_ERR_ARG, "kmeans: centers is NULL");
     KmLaunch L;
@@ -1261,7 +1259,6 @@ extern "C" int hgmm_kmeans_lloyd(hgmm_ctx* c, int k, double* centers_inout, int 
                                  int reset_labels, int* n_iter_out, int* strict_out, int* needs_host_out,
                                  double* sums_out, int64_t* n_changed_out) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     HGMM_TRY(km_check(c, k));
     if (!centers_inout) return fail(c, HGMM_ERR_ARG, "kmeans: centers is NULL");
     if (c->comm_on()) return fail(c, HGMM_ERR_STATE, "kmeans: the device-resident Lloyd loop is single-rank; "
@@ -1307,7 +1304,6 @@ extern "C" int hgmm_kmeans_lloyd(hgmm_ctx* c, int k, double* centers_inout, int 
 
 extern "C" int hgmm_kmeans_labels(hgmm_ctx* c, int32_t* labels_out, double* min_dist2_out) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     if (c->km_labels_n != c->n || c->n <= 0 || !c->km_labels.p)
         return fail(c, HGMM_ERR_STATE, "kmeans: no assignment on the device (call hgmm_kmeans_step first)");
     if (labels_out)

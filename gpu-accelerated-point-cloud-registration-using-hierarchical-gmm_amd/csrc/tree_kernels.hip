@@ -1733,7 +1733,6 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                                double* cov_out, int32_t* leaf_idx_out, int32_t* iters_per_level_out,
                                double* q_trace_out, int q_capacity, int* q_len_out) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     if (!c->have_f64 || c->n <= 0) return fail(c, HGMM_ERR_STATE, "tree build: set points first");
     if (L < 1 || L > 6) return fail(c, HGMM_ERR_ARG, "tree levels L = %d outside 1..6", L);
     if (!init_mu) return fail(c, HGMM_ERR_ARG, "init_mu is NULL");
@@ -2249,7 +2248,6 @@ static int reg_estep_fixed(hgmm_ctx* c, const double* rot, const double* t, doub
 extern "C" int hgmm_tree_reg_estep(hgmm_ctx* c, const double* rot, const double* t, double scale,
                                    double lambda_c, double* m0_out, double* m1_out, double* m2_out) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     double D = 1.0;
     int F = 0;
     HGMM_TRY(reg_estep_fixed<NMOM>(c, rot, t, scale, lambda_c, &D, &F));
@@ -3176,7 +3174,6 @@ extern "C" int hgmm_fullcov_fit(hgmm_ctx* c, int J, double ls, double ld, const 
                                 int max_iters, double* pi_out, double* mu_out, double* cov_out,
                                 int32_t* labels_out, double* q_trace_out, int q_capacity, int* q_len_out) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     if (!c->have_f64 || c->n <= 0) return fail(c, HGMM_ERR_STATE, "full-covariance fit: set points first");
     if (J < 1 || J > 4096) return fail(c, HGMM_ERR_ARG, "J = %d outside 1..4096", J);
     if (!init_mu) return fail(c, HGMM_ERR_ARG, "init_mu is NULL");
@@ -3613,7 +3610,6 @@ extern "C" int hgmm_tree_loglik(hgmm_ctx* c, int64_t T, const double* pi, const 
 
 extern "C" int hgmm_tree_stats(hgmm_ctx* c, unsigned long long* pairs_out, int* flags_out) {
     HGMM_ENTER(c);
-    if (!c) return HGMM_ERR_ARG;
     HGMM_HIP(c, hipSetDevice(c->device));
     HGMM_TRY(tree_flags(c, false));
     unsigned char h[64];

@@ -56,16 +56,15 @@ class GMM_GPU_Base:
         """``init`` = optional explicit ``(means, weights, covs)`` (the reference always draws
         them with the host RNG; tests and benchmarks pass them in)."""
         if isinstance(X, DevicePoints):                   # already resident (hgmm_amd.asarray): no upload
-            if init is None:
-                raise TypeError("fit(DevicePoints) needs init=(means, weights, covs): the reference's initialiser "
-                                "samples from the HOST array (gmm_impl.py:26-41)")
-            means, weights, covs = init
+            # the reference's initialiser samples from the HOST array (gmm_impl.py:26-41): one download of the
+            # float32 rows when the caller brings no initial parameters
+            means, weights, covs = init if init is not None else self._init_params(X.get())
             dev_X = X
         else:
             X = np.asarray(X)
             means, weights, covs = init if init is not None else self._init_params(X)
             dev_X = asarray(X.astype(np.float32))
-        with timer(self._label):
+        with timer(self._label, getattr(dev_X, "ctx", None)):
             inv, mu, w, cov, lls = train_gmm(dev_X, self.max_iter, self.tol,
                                              np.asarray(means, np.float32), np.asarray(covs, np.float32),
                                              np.asarray(weights, np.float32), cov_type=self.cov_type)

@@ -224,3 +224,121 @@ def attach_communicator(ctx, rank: int | None = None, world: int | None = None, 
     uid = broadcast_from_rank0(rank, world, uid, transport, exchange=exchange)
     ctx.comm_init(world, rank, uid)
     return ctx
+
+
+class TcpGroup:
+    """The ranks of one job joined by PERSISTENT plain-TCP connections to rank 0 (a star): ``allgather`` / ``barrier`` /
+    ``max`` for jobs whose ranks do not share a communicator -- the replica mode, where every GPU registers its own scan
+    pairs and the only thing the ranks ever exchange is "ready" and a wall-clock figure (bench.py --mode pairs).
+    One round trip is ~0.1 ms on a loopback; nothing here touches the GPU."""
+
+    def __init__(self, rank: int | None = None, world: int | None = None, port_offset: int = 237, timeout: float = 120.0):
+        r, _, w = env_rank_world()
+        self.rank = r if rank is None else rank
+        self.world = w if world is None else world
+        self.timeout = timeout
+        self.conns = {}                    # rank 0: peer rank -> socket
+        self.sock = None                   # other ranks: the socket to rank 0
+        if self.world == 1:
+            return
+        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(os.environ.get("MASTER_PORT", "29500")) + port_offset
+        offsets = tuple(o - PORT_OFFSETS[0] for o in PORT_OFFSETS)
+        if self.rank == 0:
+            srv = None
+            for off in offsets:
+                s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                try:
+                    s.bind((addr, port + off))
+                    srv = s
+                    break
+                except OSError:
+                    s.close()
+            if srv is None:
+                raise OSError("TcpGroup: no free port among %s" % [port + o for o in offsets])
+            srv.listen(self.world)
+            srv.settimeout(timeout)
+            try:
+                while len(self.conns) < self.world - 1:
+                    try:
+                        conn, _ = srv.accept()
+                    except socket.timeout:
+                        raise TimeoutError("TcpGroup: %d of %d ranks joined within %.0f s"
+                                           % (len(self.conns) + 1, self.world, timeout))
+                    conn.settimeout(10.0)
+                    try:
+                        if _recv_exact(conn, len(_MAGIC)) != _MAGIC:
+                            conn.close()
+                            continue
+                        peer = struct.unpack("<I", _recv_exact(conn, 4))[0]
+                        if not (0 < peer < self.world) or peer in self.conns:
+                            conn.close()
+                            continue
+                        conn.sendall(_ACK)
+                        conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        conn.settimeout(timeout)
+                        self.conns[peer] = conn
+                    except (ConnectionError, socket.timeout, OSError):
+                        conn.close()
+            finally:
+                srv.close()
+            return
+        deadline = time.time() + timeout
+        while self.sock is None:
+            for off in offsets:
+                try:
+                    s = socket.create_connection((addr, port + off), timeout=5.0)
+                    s.settimeout(10.0)
+                    s.sendall(_MAGIC + struct.pack("<I", self.rank))
+                    if _recv_exact(s, len(_ACK)) == _ACK:
+                        s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        s.settimeout(timeout)
+                        self.sock = s
+                        break
+                    s.close()
+                except (ConnectionError, socket.timeout, OSError):
+                    continue
+            if self.sock is None:
+                if time.time() > deadline:
+                    raise TimeoutError("TcpGroup: rank 0 not reachable on %s ports %s" % (addr, [port + o for o in offsets]))
+                time.sleep(0.05)
+
+    def allgather(self, payload: bytes):
+        """Every rank's payload on every rank, in rank order."""
+        if self.world == 1:
+            return [payload]
+        if self.rank == 0:
+            got = [payload] + [None] * (self.world - 1)
+            for peer, conn in self.conns.items():
+                n = struct.unpack("<I", _recv_exact(conn, 4))[0]
+                got[peer] = _recv_exact(conn, n)
+            blob = b"".join(struct.pack("<I", len(b)) + b for b in got)
+            for conn in self.conns.values():
+                conn.sendall(struct.pack("<I", len(blob)) + blob)
+            return got
+        self.sock.sendall(struct.pack("<I", len(payload)) + payload)
+        blob = _recv_exact(self.sock, struct.unpack("<I", _recv_exact(self.sock, 4))[0])
+        out, at = [], 0
+        while at < len(blob):
+            n = struct.unpack("<I", blob[at:at + 4])[0]
+            out.append(blob[at + 4:at + 4 + n])
+            at += 4 + n
+        return out
+
+    def barrier(self):
+        self.allgather(b"")
+
+    def allgather_f64(self, values):
+        """[world, len(values)] float64."""
+        import numpy as np
+        v = np.ascontiguousarray(values, dtype=np.float64).ravel()
+        return np.stack([np.frombuffer(b, dtype=np.float64) for b in self.allgather(v.tobytes())])
+
+    def close(self):
+        for conn in self.conns.values():
+            conn.close()
+        self.conns = {}
+        if self.sock is not None:
+            self.sock.close()
+            self.sock = None

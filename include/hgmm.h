@@ -122,6 +122,10 @@ int hgmm_points_create_f64(hgmm_ctx* ctx, const double* xyz, int64_t n, hgmm_poi
 int hgmm_points_bind(hgmm_ctx* ctx, hgmm_points* points);
 int hgmm_points_destroy(hgmm_ctx* ctx, hgmm_points* points);
 int64_t hgmm_points_count(const hgmm_points* points);
+/* The float32 rows [n,3] of a resident cloud back on the host (`cupy.asnumpy(dev_X)`): what a caller needs to draw the
+ * reference's initial parameters (init_gmm_params samples the HOST array, gmm_waymo/src/gmm_impl.py:26-41) for a cloud it
+ * only holds as a handle.  points = NULL: the cloud the context is working on.  Synchronises the context's stream. */
+int hgmm_points_download_f32(hgmm_ctx* ctx, const hgmm_points* points, float* xyz_out);
 
 /* ---- flat GMM EM (diag / spherical) ------------------------------------------------
  * hgmm_flat_estep   <- e_step()            gmm_waymo gmm_impl.py:105-116, gmmreg_gpu gmm_impl.py:55-61

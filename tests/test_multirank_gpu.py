@@ -20,6 +20,30 @@ pytestmark = pytest.mark.gpu
 N_ALL, SPLIT = 6000, 2300          # uneven shards
 
 
+def _bounds(world):
+    """Cut points of `world` uneven contiguous shards of the N_ALL points (world = 2: the historical 2300 / 3700)."""
+    if world == 2:
+        return [0, SPLIT, N_ALL]
+    return [0] + [int(N_ALL * ((r + 1) / world) ** 1.15) for r in range(world - 1)] + [N_ALL]
+
+
+def _gpu_count():
+    import ctypes
+    import hgmm_amd
+    cnt = ctypes.c_int(0)
+    hgmm_amd.load_library().hgmm_device_count(ctypes.byref(cnt))
+    return cnt.value
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 def _cloud():
     rs = np.random.RandomState(17)
     centres = rs.rand(9, 3)
@@ -61,30 +85,30 @@ def _run_all(ctx, lo, hi):
     return out
 
 
-def _worker(rank, name, q, rccl_port=None, backend="host"):
+def _worker(rank, name, q, rccl_port=None, backend="host", world=2):
     try:
-        _worker_body(rank, name, q, rccl_port, backend)
+        _worker_body(rank, name, q, rccl_port, backend, world)
     except BaseException as e:                              # the parent must not wait out its timeout for a dead rank
         import traceback
         q.put((rank, "rank %d failed: %r\n%s" % (rank, e, traceback.format_exc()), None))
         raise
 
 
-def _worker_body(rank, name, q, rccl_port, backend):
+def _worker_body(rank, name, q, rccl_port, backend, world):
     import hgmm_amd
     if rccl_port is None:
         ctx = hgmm_amd.Context(0)
         if backend == "ipc":
-            ctx.comm_init_ipc(2, rank, name)
+            ctx.comm_init_ipc(world, rank, name)
         else:
-            ctx.comm_init_host(2, rank, name)
+            ctx.comm_init_host(world, rank, name)
     else:
         from hgmm_amd import parallel
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(rccl_port), RANK=str(rank), LOCAL_RANK=str(rank),
-                          WORLD_SIZE="2")
+                          WORLD_SIZE=str(world))
         ctx = hgmm_amd.Context(rank)                       # one rank per GPU
-        parallel.attach_communicator(ctx, rank, 2, transport="tcp")
-    lo, hi = (0, SPLIT) if rank == 0 else (SPLIT, N_ALL)
+        parallel.attach_communicator(ctx, rank, world, transport="tcp")
+    lo, hi = _bounds(world)[rank], _bounds(world)[rank + 1]
     res = _run_all(ctx, lo, hi)
     total = ctx.allreduce([float(hi - lo)])[0]
     ctx.close()
@@ -100,6 +124,12 @@ def test_two_ranks_on_one_gpu_peer_exchange_backend():
     kernel per all-reduce) behind the same call sites: two processes that share the box's GPU map each other's
     exchange buffers through hipIpc handles.  Same fits, same iteration counts, bitwise equal models on both ranks."""
     _two_ranks_match_single_context(None, backend="ipc")
+
+
+def test_three_uneven_ranks_on_one_gpu_peer_exchange_backend():
+    """world = 3 (uneven shards 1697 / 2066 / 2237) through the same code the multi-GPU tests below use with
+    world = min(8, GPUs): a 1-GPU box thereby runs the world > 2 comparison logic too."""
+    _ranks_match_single_context(None, backend="ipc", world=3)
 
 
 def test_peer_exchange_collectives_two_ranks_one_gpu():
@@ -186,12 +216,13 @@ def test_two_full_frames_joint_fit_matches_oracle_fixture(backend):
 
 
 def _full_frames_joint_fit(backend, world):
+    port = _free_port() if backend == "rccl" else None
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flat_uniform%dx1M_J800_oracle.npz" % world))
     assert int(g["frames"]) == world
     name = "hgmm_%dx1m_%s_%d" % (world, backend, os.getpid())
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    procs = [mpc.Process(target=_joint_fit_worker, args=(r, name, q, backend, world)) for r in range(world)]
+    procs = [mpc.Process(target=_joint_fit_worker, args=(r, name, q, backend, world, port)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=300) for _ in procs)
@@ -209,12 +240,12 @@ def _full_frames_joint_fit(backend, world):
         np.testing.assert_allclose(w, g["w"], rtol=1e-5, atol=1e-10)
         np.testing.assert_allclose(cov, g["cov"], rtol=1e-4, atol=1e-9)
         np.testing.assert_allclose(inv, g["inv"], rtol=1e-4)
-    for rank in range(1, world):
+    for rank in range(1, world):                              # (RCCL's all-reduce also leaves every rank with the same sums)
         for a, b in zip(got[0], got[rank]):
             assert np.array_equal(a, b)
 
 
-def _joint_fit_worker(rank, name, q, backend, world=2):
+def _joint_fit_worker(rank, name, q, backend, world=2, rccl_port=None):
     try:
         import hgmm_amd
         N, J = 1_000_000, 800
@@ -224,8 +255,15 @@ def _joint_fit_worker(rank, name, q, backend, world=2):
         mu0 = frame0[idx].copy()
         w0 = (np.ones(J) / J).astype(np.float32)
         cov0 = (0.1 * np.ones((J, 3))).astype(np.float32)
-        ctx = hgmm_amd.Context(0)
-        (ctx.comm_init_ipc if backend == "ipc" else ctx.comm_init_host)(world, rank, name)
+        if backend == "rccl":                                 # one rank per GPU, RCCL over xGMI
+            from hgmm_amd import parallel
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(rccl_port), RANK=str(rank), LOCAL_RANK=str(rank),
+                              WORLD_SIZE=str(world))
+            ctx = hgmm_amd.Context(rank)
+            parallel.attach_communicator(ctx, rank, world, transport="tcp")
+        else:
+            ctx = hgmm_amd.Context(0)
+            (ctx.comm_init_ipc if backend == "ipc" else ctx.comm_init_host)(world, rank, name)
         ctx.set_points(frame)
         inv, mu, w, cov, lls, _ = ctx.flat_train(3, 0.0, mu0, cov0, w0, "diag", "W")
         ctx.comm_destroy()
@@ -241,21 +279,27 @@ def _ipc_payloads(rank):
     return [rs.randn(n) * 10.0 ** rs.randint(-3, 4) for n in (1, 7, 511, 512, 513, 7170, 65536, 65537, 150001)]
 
 
-def _ipc_collectives_expected():
-    a, b = _ipc_payloads(0), _ipc_payloads(1)
+def _ipc_collectives_expected(world=2):
+    """What the exchange must return: the slices added up in RANK ORDER (((r0 + r1) + r2) + ...), maxima likewise."""
+    per_rank = [_ipc_payloads(r) for r in range(world)]
     out = []
     for rep in range(3):
-        for x, y in zip(a, b):
-            out.append((x + rep) + (y + rep))
-            out.append(np.maximum(x + rep, y + rep))
+        for i in range(len(per_rank[0])):
+            tot = per_rank[0][i] + rep
+            mx = per_rank[0][i] + rep
+            for r in range(1, world):
+                tot = tot + (per_rank[r][i] + rep)
+                mx = np.maximum(mx, per_rank[r][i] + rep)
+            out.append(tot)
+            out.append(mx)
     return out
 
 
-def _ipc_collectives_worker(rank, name, q, device=0):
+def _ipc_collectives_worker(rank, name, q, device=0, world=2):
     try:
         import hgmm_amd
         ctx = hgmm_amd.Context(device)
-        ctx.comm_init_ipc(2, rank, name)
+        ctx.comm_init_ipc(world, rank, name)
         out = []
         for rep in range(3):
             for x in _ipc_payloads(rank):
@@ -269,39 +313,38 @@ def _ipc_collectives_worker(rank, name, q, device=0):
         raise
 
 
+def test_rccl_ranks_on_all_gpus():
+    """Same comparison over RCCL / xGMI, one rank per GPU on min(8, visible GPUs) of them (the driver's 8-GPU node runs
+    world = 8; a 1-GPU box skips): every family's sharded fit against the single-context fit on the whole cloud."""
+    n = _gpu_count()
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs (found %d)" % n)
+    _ranks_match_single_context(_free_port(), backend="rccl", world=min(8, n))
+
+
 def test_rccl_two_ranks_two_gpus():
-    """Same comparison over RCCL / xGMI when the box has two GPUs (the driver's 8-GPU node; a 1-GPU box skips)."""
-    import ctypes
-    import socket
-    import hgmm_amd
-    cnt = ctypes.c_int(0)
-    hgmm_amd.load_library().hgmm_device_count(ctypes.byref(cnt))
-    if cnt.value < 2:
-        pytest.skip("needs >= 2 GPUs (found %d)" % cnt.value)
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    _two_ranks_match_single_context(port)
+    """The two-rank case by itself (what a 2-GPU box can run; the test above covers it on larger nodes with world > 2)."""
+    n = _gpu_count()
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs (found %d)" % n)
+    _ranks_match_single_context(_free_port(), backend="rccl", world=2)
 
 
-def test_peer_exchange_two_ranks_two_gpus():
-    """The one-shot peer exchange ACROSS two GPUs (each rank maps the other's exchange buffer over xGMI / PCIe through
-    its hipIpc handle): the collectives by themselves, bitwise equal on both ranks and equal to the host's sums.  Needs
-    two GPUs (the driver's multi-GPU node; a 1-GPU box skips)."""
-    import ctypes
-    import hgmm_amd
-    cnt = ctypes.c_int(0)
-    hgmm_amd.load_library().hgmm_device_count(ctypes.byref(cnt))
-    if cnt.value < 2:
-        pytest.skip("needs >= 2 GPUs (found %d)" % cnt.value)
-    name = "hgmm_ipc2_%d" % os.getpid()
+def test_peer_exchange_ranks_on_all_gpus():
+    """The one-shot peer exchange ACROSS min(8, visible GPUs) GPUs (each rank maps every other rank's exchange buffer
+    over xGMI through its hipIpc handle): the collectives by themselves, bitwise equal on all ranks and equal to the
+    host's sums in rank order.  Needs two GPUs (the driver's multi-GPU node; a 1-GPU box skips)."""
+    n = _gpu_count()
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs (found %d)" % n)
+    world = min(8, n)
+    name = "hgmm_ipc%d_%d" % (world, os.getpid())
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    procs = [mpc.Process(target=_ipc_collectives_worker, args=(r, name, q, r)) for r in range(2)]
+    procs = [mpc.Process(target=_ipc_collectives_worker, args=(r, name, q, r, world)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=180) for _ in procs)
+    got = dict(q.get(timeout=240) for _ in procs)
     setup = [v for v in got.values() if isinstance(v, str) and "peer exchange:" in v and ("hipIpc" in v or "uncached" in v or "map" in v)]
     if setup:
         for p in procs:
@@ -313,17 +356,42 @@ def test_peer_exchange_two_ranks_two_gpus():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    exp = _ipc_collectives_expected()
-    for a, b, e in zip(got[0], got[1], exp):
-        assert np.array_equal(a, b) and np.array_equal(a, e)
+    exp = _ipc_collectives_expected(world)
+    for rank in range(world):
+        assert len(got[rank]) == len(exp)
+        for a, e in zip(got[rank], exp):
+            assert np.array_equal(a, e)
+
+
+def test_configs4_over_rccl_on_eight_gpus():
+    """BASELINE configs[4] AS WRITTEN: 8 frames x 1M points, J = 800, one frame per GPU on 8 x MI355X, the (7 J + 2)
+    float64 sufficient statistics all-reduced by RCCL over xGMI before every M-step -- against oracle.flat_em's float64
+    EM on the 8M points together (tests/golden/flat_uniform8x1M_J800_oracle.npz).  Skips below 8 GPUs (the 8-ranks-on-
+    one-GPU test above runs the same data path through the peer exchange there)."""
+    n = _gpu_count()
+    if n < 8:
+        pytest.skip("needs 8 GPUs (found %d)" % n)
+    _full_frames_joint_fit("rccl", 8)
+
+
+def test_two_full_frames_over_rccl_on_two_gpus():
+    """configs[4] in small over RCCL: two 1M-point frames on two GPUs against the 2M-point oracle fixture."""
+    n = _gpu_count()
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs (found %d)" % n)
+    _full_frames_joint_fit("rccl", 2)
 
 
 def _two_ranks_match_single_context(rccl_port, backend="host"):
+    _ranks_match_single_context(rccl_port, backend, 2)
+
+
+def _ranks_match_single_context(rccl_port, backend="host", world=2):
     import hgmm_amd
     name = "hgmm_test_%s_%d" % (backend, os.getpid())
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    procs = [mpc.Process(target=_worker, args=(r, name, q, rccl_port, backend)) for r in range(2)]
+    procs = [mpc.Process(target=_worker, args=(r, name, q, rccl_port, backend, world)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
@@ -338,8 +406,9 @@ def _two_ranks_match_single_context(rccl_port, backend="host"):
     ctx = hgmm_amd.Context(0)
     ref = _run_all(ctx, 0, N_ALL)
     ctx.close()
-    cut = {0: slice(0, SPLIT), 1: slice(SPLIT, N_ALL)}
-    for rank in (0, 1):
+    b = _bounds(world)
+    cut = {r: slice(b[r], b[r + 1]) for r in range(world)}
+    for rank in range(world):
         r = got[rank]
         for variant in ("W", "G"):
             mu, w, cov, lls = r["flat_" + variant]
@@ -355,8 +424,8 @@ def _two_ranks_match_single_context(rccl_port, backend="host"):
         np.testing.assert_allclose(pi, rpi, rtol=0, atol=1e-12)
         np.testing.assert_allclose(mu, rmu, rtol=0, atol=1e-11)
         np.testing.assert_allclose(cov, rcov, rtol=1e-8, atol=1e-14)
-        for a, b in zip(r["reg"], ref["reg"]):
-            np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-12)
+        for a, b_ in zip(r["reg"], ref["reg"]):
+            np.testing.assert_allclose(a, b_, rtol=1e-10, atol=1e-12)
         pi, mu, cov, labels, qt = r["full"]
         rpi, rmu, rcov, rlabels, rq = ref["full"]
         assert len(qt) == len(rq) and np.array_equal(labels, rlabels[cut[rank]])
@@ -367,7 +436,8 @@ def _two_ranks_match_single_context(rccl_port, backend="host"):
         assert n_iter == rn and np.array_equal(labels, rl[cut[rank]])
         np.testing.assert_allclose(centres, rc, rtol=0, atol=1e-12)
         np.testing.assert_allclose(inertia, ri, rtol=1e-10)
-    # both ranks hold identical models
+    # all ranks hold identical models
     for key in ("flat_W", "flat_G", "tree", "full") if backend == "ipc" else ("flat_W", "tree", "full"):
-        for a, b in zip(got[0][key][:3], got[1][key][:3]):
-            assert np.array_equal(a, b)
+        for rank in range(1, world):
+            for a, b_ in zip(got[0][key][:3], got[rank][key][:3]):
+                assert np.array_equal(a, b_)
