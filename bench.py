@@ -1036,6 +1036,193 @@ def rank_main(args):
         sys.exit(3)
 
 
+# ------------------------------------------------------------------------------------------------
+# --mode pairs: replica fan-out of INDEPENDENT scan pairs (north_star: "independent scan pairs ... fan out across the
+# GPUs"; SURVEY 8e: "Independent scan pairs: no communication ('replicas')")
+# ------------------------------------------------------------------------------------------------
+PAIR_TARGETS = 16            # distinct perturbed targets a rank cycles through
+PAIR_KW = dict(tree_level=3, lambda_c=0.01, ls=20, sig2=0.004)      # the reference GPU file's constants (hgmm_gpu.py:469-477, 687)
+PAIR_MAXITER, PAIR_TOL = 20, 1.0e-4                                 # registration_gmmtree's defaults (hgmm_gpu.py:802)
+
+
+def _quat_rot(q):
+    qx, qy, qz, qw = q
+    return np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                     [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                     [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+
+
+def scan_pairs(rank, count=PAIR_TARGETS):
+    """The rank's scan pairs: source = bun000.ply (40 256 points), target = bun045.ply (40 097 points, another scan of
+    the object, ~94 % overlap) placed by its ground-truth pose of the reference's data/bun.conf and then moved by a
+    known rigid motion that differs per pair (4-8 deg about a random axis, up to 6 mm; seed = 1000 rank + k).
+    -> (source [N,3] f64, [(target [M,3] f64, truth [N,3] f64 = where the source belongs), ...])."""
+    g = os.path.join(ROOT, "tests", "golden")
+    a = np.load(os.path.join(g, "bun000_xyz.npy")).astype(np.float64)
+    b = np.load(os.path.join(g, "bun045_xyz.npy")).astype(np.float64)
+    conf = np.load(os.path.join(g, "bun_conf.npz"))
+    pose = conf["poses"][list(conf["names"]).index("bun045.ply")]
+    world = b @ _quat_rot(pose[3:]) + pose[:3]             # bun.conf convention: p_world = R(q)^T p + t
+    out = []
+    for k in range(count):
+        rs = np.random.RandomState(1000 * rank + k)
+        axis = rs.randn(3)
+        axis /= np.linalg.norm(axis)
+        th = np.deg2rad(rs.uniform(4.0, 8.0))
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        Rd = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+        td = rs.uniform(-0.006, 0.006, 3)
+        out.append((world @ Rd.T + td, a @ Rd.T + td))
+    return a, out
+
+
+def register_pair(ctx, source, target):
+    """ONE unit of work, exactly the reference's call (src/python/hgmm/hgmm_gpu.py:802-807): build the GMM tree of the
+    source, register the target against it.  -> (MstepResult, registration iterations)."""
+    from hgmm_amd.hgmm.hgmm_gpu import GMMTree
+    gt = GMMTree(source, ctx=ctx, **PAIR_KW)
+    res = gt.registration(target, PAIR_MAXITER, PAIR_TOL)
+    return res, int(gt.n_iter_)
+
+
+def pairs_cpu_baseline():
+    """The oracle (oracle/hgmm_tree.py: the CPU twin's buildGMMTree + GMMTree.registration restated in NumPy) on a
+    BOUNDED sample of the same pair: every 8th point of both scans, same constants."""
+    from oracle import hgmm_tree
+    a, pairs = scan_pairs(0, 1)
+    S, Tg = a[::8], pairs[0][0][::8]
+    L = PAIR_KW["tree_level"]
+    T = hgmm_tree.n_total(L)
+    idx = np.random.RandomState(72).randint(T, size=T)
+    t0 = time.perf_counter()
+    pi, mu, cov, tr = hgmm_tree.build_tree(S, L, float(PAIR_KW["ls"]), 1e-4, idx, PAIR_KW["sig2"], 1000)
+    t1 = time.perf_counter()
+    _, _, _, trace = hgmm_tree.register(Tg, pi, mu, cov, L, PAIR_KW["lambda_c"], PAIR_MAXITER, PAIR_TOL)
+    t2 = time.perf_counter()
+    return {"value": 1.0 / (t2 - t0), "unit": "pairs/s on the sample", "cores": 1, "host_cpu_count": os.cpu_count(),
+            "kind": "port",
+            "sample": "oracle.hgmm_tree.build_tree + register on every 8th point of the pair (%d / %d points), L=3: "
+                      "build %.2f s (%s level iterations), registration %.2f s (%d iterations); the cost is linear in "
+                      "the points, so the full pair is ~8x this" % (len(S), len(Tg), t1 - t0, list(tr.iters_per_level),
+                                                                   t2 - t1, len(trace))}
+
+
+def pairs_main(args):
+    """One process per GPU, NO communicator: every rank registers its own scan pairs on its own context; the ranks only
+    meet over plain TCP for the timing barrier and the max-over-ranks block time.  `value` = pairs registered per second
+    by all ranks together."""
+    guard = _StdoutGuard()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import hgmm_amd
+    from hgmm_amd import parallel
+    rehearsal = "HGMM_BENCH_DEVICE" in os.environ and world > 1
+    device = int(os.environ["HGMM_BENCH_DEVICE"]) if rehearsal else local_rank
+    if not rehearsal:
+        for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            vis = [v for v in os.environ.get(var, "").split(",") if v.strip()]
+            if vis and len(vis) <= local_rank:
+                device = local_rank % len(vis)
+                break
+    ctx = hgmm_amd.Context(device)
+    info = ctx.device_info()
+    group = parallel.TcpGroup(rank, world)
+    source, pairs = scan_pairs(rank)
+    K, W = args.steps, args.warmup
+
+    def barrier():
+        ctx.synchronize()
+        group.barrier()
+
+    step = 0
+    for _ in range(max(W, 1)):
+        register_pair(ctx, source, pairs[step % len(pairs)][0])
+        step += 1
+    blocks, iters, errs, starts = [], [], [], []
+    while True:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            tgt, truth = pairs[step % len(pairs)]
+            res, n_it = register_pair(ctx, source, tgt)
+            iters.append(n_it)
+            errs.append(float(np.linalg.norm(res.transformation.transform(source) - truth, axis=1).mean()))
+            starts.append(float(np.linalg.norm(source - truth, axis=1).mean()))
+            step += 1
+        ctx.synchronize()
+        dt_local = time.perf_counter() - t0
+        barrier()
+        blocks.append(float(group.allgather_f64([dt_local]).max()))          # identical on every rank
+        if (sum(blocks) >= args.min_time and len(blocks) >= 3) or len(blocks) >= MAX_BLOCKS:
+            break
+    # accuracy of what was timed (the method has no outlier model: on these partially overlapping scans it settles a
+    # few millimetres off the ground truth, tests/test_tree_gpu.py::test_registration_real_scan_pair_against_bun_conf)
+    mine = np.array([np.max(errs), np.mean(errs), np.mean(starts), float(np.sum(iters)), float(len(iters))])
+    allr = group.allgather_f64(mine)
+    ok = bool(allr[:, 0].max() < 0.006)
+    # kernel time of one pair under the hipEvent profiler (not part of the timing)
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    register_pair(ctx, source, pairs[0][0])
+    ctx.synchronize()
+    ctx.profile_enable(False)
+    prof = {k: ctx.profile_get(k) for k in ("tree_estep", "tree_loglik", "tree_reg")}
+    out = None
+    if rank == 0:
+        med = float(np.median(blocks))
+        n_iter_total, n_pairs = float(allr[:, 3].sum()), float(allr[:, 4].sum())
+        out = {
+            "metric": "registered scan pairs/sec (registration_gmmtree: GMM-tree build of the source + registration of the target)",
+            "value": world * K / med, "unit": "pairs/s (all GPUs)", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * med / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "Stanford bunny scans bun000 / bun045 (tests/golden), poses from the reference's bun.conf",
+            "mode": "pairs",
+            "config": {"workload": "replicas: every GPU registers its own scan pairs, no communicator -- source bun000.ply "
+                                   "(40256 pts), target bun045.ply (40097 pts) placed by bun.conf and moved by a known rigid "
+                                   "motion per pair (4-8 deg, <= 6 mm); registration_gmmtree(source, target, maxiter=20, "
+                                   "tol=1e-4, tree_level=3, lambda_c=0.01, ls=20, sig2=0.004) = the reference's unit of work "
+                                   "(src/python/hgmm/hgmm_gpu.py:802-807); host arrays in, transformation out",
+                       "pairs_per_gpu_per_step": 1, "device": info["name"], "compute_units": info["compute_units"],
+                       "parallelism": "replicas x%d (no collective)" % world,
+                       **({"rehearsal": "all ranks on ONE device -- flow check, not a measurement"} if rehearsal else {})},
+            "timing": {"blocks": len(blocks), "steps_per_block": K, "timed_s": float(sum(blocks)),
+                       "median_block_ms": med * 1e3, "first_block_pairs_per_s": world * K / blocks[0],
+                       "rule": "value = world x K / median block; a block = K pairs per rank between TCP barrier + "
+                               "stream synchronisation on both sides, MAX over ranks"},
+            "pairs_per_s_per_gpu": K / med,
+            "registration_iterations_per_pair": n_iter_total / max(n_pairs, 1),
+            "registration_iterations_per_s_per_gpu": (n_iter_total / max(n_pairs, 1)) * K / med,
+            "accuracy": {"mean_misalignment_before_mm": 1e3 * float(allr[:, 2].mean()),
+                         "mean_misalignment_after_mm": 1e3 * float(allr[:, 1].mean()),
+                         "max_misalignment_after_mm": 1e3 * float(allr[:, 0].max()), "bound_mm": 6.0, "ok": ok},
+            "kernels_ms_per_pair": {k: {"ms": v[0], "launches": v[1]} for k, v in prof.items()},
+            "h2d_note": "each step uploads both clouds (2 x 0.97 MB) through the reference's host-array API: ~0.1 ms of the step",
+            "roofline": None,
+            "roofline_note": "latency-bound: ~100 level-iterations of three small kernels per pair on 40 k points "
+                             "(SURVEY 8d: 'report wall-time per build, not roofline'); the HBM roofline of the path is "
+                             "measured by the default mode's materialising E-step",
+        }
+        if not ok:
+            out["error"] = "a registered pair ended more than 6 mm from its ground truth"
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = pairs_cpu_baseline()
+            except Exception as e:
+                out["cpu_baseline"] = {"error": repr(e)}
+        else:
+            out["cpu_baseline"] = None
+        guard.restore()
+        print(json.dumps(out))
+        sys.stdout.flush()
+        guard = _StdoutGuard()
+    group.barrier()
+    group.close()
+    ctx.close()
+    if not ok:
+        sys.exit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1043,6 +1230,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--min-time", type=float, default=MIN_TIMED_S,
                     help="timed K-step blocks repeat until this many seconds of timed work (default 1.0)")
+    ap.add_argument("--mode", default="fit", choices=["fit", "pairs"],
+                    help="fit (default): the headline joint EM fit, frames sharded over the GPUs with an all-reduce of the "
+                         "sufficient statistics; pairs: independent scan pairs, one registration_gmmtree per GPU and step, "
+                         "no communicator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--estep-reps", type=int, default=30)
     ap.add_argument("--skip", default="", help="comma-separated side legs to skip (bunny,hgmm,tree_1M,fullcov,...)")
@@ -1055,7 +1246,10 @@ def main():
     args.skip = set(s for s in args.skip.split(",") if s)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args, sys.argv[1:]))
-    rank_main(args)
+    if args.mode == "pairs":
+        pairs_main(args)
+    else:
+        rank_main(args)
 
 
 if __name__ == "__main__":

@@ -37,4 +37,16 @@ if "FAIL_RANK_1" in sys.argv[-1] and os.environ.get("RANK") == "1":
 hgmm_amd.Context = Ctx
 bench.N_POINTS = 2000
 bench.synth_frame = lambda seed, n=None: np.random.RandomState(seed).rand(2000, 3).astype(np.float32)
+if "pairs" in sys.argv:                                        # --mode pairs: the registration itself needs the engine
+    class _Tf:
+        def transform(self, x):
+            return x
+
+    class _Res:
+        transformation = _Tf()
+
+    _cloud = np.random.RandomState(3).rand(50, 3)
+    bench.scan_pairs = lambda rank, count=16: (_cloud, [(_cloud + 0.01, _cloud + 1e-4)] * 2)
+    bench.register_pair = lambda ctx, source, target: (_Res(), 7)
+    bench.pairs_cpu_baseline = lambda: {"value": 0.1, "unit": "pairs/s on the sample", "cores": 1, "kind": "port", "sample": "fake"}
 bench.main()

@@ -261,6 +261,32 @@ def test_a_hanging_backend_setup_times_out_and_falls_back():
     assert "rccl" in d["config"]["fallback"] and "peer exchange" in d["config"]["collective"]
 
 
+def test_pairs_mode_two_ranks_without_a_communicator():
+    """--mode pairs: every rank registers its own scan pairs, the ranks only meet over the TCP star for the timing
+    barrier and the max-over-ranks block time; one line from rank 0, no collective in it."""
+    for mode in ("self", "plain"):
+        r = _run_launcher(2, mode, ["--mode", "pairs"])
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                  "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in d
+        assert d["mode"] == "pairs" and d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0
+        assert d["pairs_per_s_per_gpu"] * 2 == d["value"] and d["scaling"] == "weak"
+        assert d["registration_iterations_per_pair"] == 7.0 and d["accuracy"]["ok"] is True
+        assert "collective" not in d["config"] and "allreduce_us" not in d
+        assert d["timing"]["blocks"] >= 3
+
+
+def test_pairs_mode_single_rank_carries_a_cpu_baseline():
+    r = _run_launcher(1, "plain", ["--mode", "pairs"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["cpu_baseline"]["kind"] == "port" and d["mode"] == "pairs"
+
+
 def test_stdout_carries_the_json_line_only():
     """bench.py's stdout guard: whatever libraries print to file descriptor 1 while the bench runs (RCCL's version
     banner through C stdio, flushed at exit) lands on stderr; the restored stdout carries the one line."""

@@ -203,3 +203,71 @@ def test_contexts_on_all_gpus_from_threads():
         c.close()
     for i in range(n):
         _same(got[i], ref[i], "device %d" % i)
+
+
+# ---- the replica pool: independent scan pairs / frames fanned out over contexts (hgmm_amd.replicas) ----------------
+def _scan_pairs(bunny, count):
+    a = bunny.astype(np.float64)[::4]
+    out = []
+    for k in range(count):
+        rs = np.random.RandomState(50 + k)
+        axis = rs.randn(3)
+        axis /= np.linalg.norm(axis)
+        th = np.deg2rad(rs.uniform(3.0, 9.0))
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+        out.append((a, a[::-1] @ R.T + rs.uniform(-0.005, 0.005, 3)))
+    return out
+
+
+def test_register_pairs_over_a_replica_pool_matches_the_serial_calls(bunny):
+    """register_pairs = registration_gmmtree per pair (src/python/hgmm/hgmm_gpu.py:802-807), the pairs handed out to
+    several contexts (here: three on one GPU; on a multi-GPU node also one per device): same transformation per pair
+    as the serial calls, in the order of the input."""
+    import hgmm_amd
+    from hgmm_amd.hgmm.hgmm_gpu import registration_gmmtree
+    from hgmm_amd.replicas import register_pairs, device_count
+    pairs = _scan_pairs(bunny, 7)
+    kw = dict(tree_level=2, lambda_c=0.01, ls=20, sig2=0.004)
+    ctx = hgmm_amd.Context(0)
+    serial = [registration_gmmtree(s, t, maxiter=15, tol=1e-6, ctx=ctx, **kw) for s, t in pairs]
+    ctx.close()
+    for devices, per in (([0], 3), (None, 1)):
+        got = register_pairs(pairs, devices=devices, contexts_per_device=per, maxiter=15, tol=1e-6, **kw)
+        assert len(got) == len(pairs)
+        for g, r, (s, t) in zip(got, serial, pairs):
+            np.testing.assert_allclose(g.transformation.rot, r.transformation.rot, rtol=0, atol=1e-9)
+            np.testing.assert_allclose(g.transformation.t, r.transformation.t, rtol=0, atol=1e-10)
+            # and it is a registration: the source lands on the target (a permuted, moved copy of itself)
+            err = np.linalg.norm(g.transformation.transform(s) - t[::-1], axis=1).mean()
+            assert err < 2e-3, err
+    assert device_count() >= 1
+
+
+def test_fit_frames_over_a_replica_pool_and_module_level_api_in_threads(bunny):
+    """fit_frames = GMM_GPU_Base.fit per frame (gmm_waymo/src/gmm.py:65-84) on the worker's own context: the
+    module-level functions of the mirrors (train_gmm, init_gmm_params, asarray) pick the THREAD's context up through
+    use_context, so nothing runs on the process-wide default context."""
+    import hgmm_amd
+    from hgmm_amd.gmm_waymo import gmm_impl
+    from hgmm_amd.replicas import fit_frames, ReplicaPool
+    frames = [bunny[k::5].copy() for k in range(5)]
+    np.random.seed(4)
+    inits = [gmm_impl.init_gmm_params(f, 40, "diag") for f in frames]
+    ctx = hgmm_amd.Context(0)
+    ref = []
+    for f, (mu, w, cov) in zip(frames, inits):
+        ctx.set_points(f)
+        ref.append(ctx.flat_train(10, 0.0, mu, cov, w, "diag", "W"))
+    ctx.close()
+    with ReplicaPool(devices=[0], contexts_per_device=3) as pool:
+        def one(c, job):
+            f, (mu, w, cov) = job
+            assert hgmm_amd.default_context() is c
+            return gmm_impl.train_gmm(f, 10, 0.0, mu, cov, w, cov_type="diag")   # host array in: uploaded to THIS thread's context
+        got = pool.map(one, list(zip(frames, inits)))
+        for g, r in zip(got, ref):
+            np.testing.assert_allclose(g[1], r[1], rtol=0, atol=2e-6)           # means
+            np.testing.assert_allclose(np.asarray(g[4]), np.asarray(r[4]), rtol=0, atol=2e-6)
+        models = fit_frames(frames, n_components=40, max_iter=5, pool=pool)
+        assert len(models) == 5 and all(m.means_.shape == (40, 3) and np.isfinite(m.lls).all() for m in models)

@@ -892,12 +892,18 @@ def test_several_resident_clouds_per_context(ctx, bunny):
     with pytest.raises(RuntimeError):
         W.predict(devs[2], inv0, mu0, w0)
     assert (np.asarray(W.predict(devs[0], inv0, mu0, w0)) != want[0]).sum() <= 2
-    # the class API on resident clouds: fit needs an explicit init (the reference's samples from the host array)
+    # the class API on resident clouds: without an explicit init the reference's initialiser (which samples from the HOST
+    # array, gmm_impl.py:26-41) is fed one download of the resident rows -- the same draw as on the host array
     from hgmm_amd.gmm_waymo import gmm as Wg
     clf = Wg.GMM_GPU_Base(8, max_iter=3, tol=0.0)
     clf._verbose = False
-    with pytest.raises(TypeError):
-        clf.fit(devs[0])
+    assert np.array_equal(devs[0].get(), clouds[0].astype(np.float32))
+    np.random.seed(11)
+    clf.fit(devs[0])
+    drawn = clf.means_.copy()
+    np.random.seed(11)
+    clf.fit(clouds[0])
+    assert np.array_equal(clf.means_, drawn)
     clf.fit(devs[0], init=(mu0, w0, cov0))
     assert np.array_equal(clf.means_, fits[0][1])
     assert isinstance(clf.predict(devs[1]), hgmm_amd.DeviceArray) and clf.predict(clouds[1]).dtype == np.int64

@@ -189,3 +189,101 @@ def test_product_package_is_torch_free():
                         if t.startswith(("import torch", "from torch")):
                             hits.append("%s:%d" % (os.path.join(d, f), n))
     assert not hits, hits
+
+
+# ---- replica mode: TCP star between ranks that share no communicator, thread pool over contexts -------------------
+def _tcp_group_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from hgmm_amd import parallel
+    import time
+    g = parallel.TcpGroup(rank, world)
+    got = []
+    for rnd in range(50):                                   # many rounds over the SAME connections
+        got.append(g.allgather(("r%d-%d" % (rank, rnd)).encode() * (1 + rank)))
+    time.sleep(0.05 * rank)                                 # ranks arrive at the barrier at different times
+    g.barrier()
+    t_after = time.time()
+    mx = g.allgather_f64([float(rank), 10.0 - rank])
+    g.barrier()
+    g.close()
+    q.put((rank, got, t_after, mx))
+
+
+def test_tcp_group_allgather_barrier_world3():
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tcp_group_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in procs:
+        rank, got, t_after, mx = q.get(timeout=60)
+        out[rank] = (got, t_after, mx)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank in range(world):
+        got, _, mx = out[rank]
+        for rnd, row in enumerate(got):
+            assert row == [("r%d-%d" % (r, rnd)).encode() * (1 + r) for r in range(world)]
+        assert mx.shape == (world, 2) and list(mx[:, 0]) == [0.0, 1.0, 2.0] and mx[:, 1].max() == 10.0
+    # nobody left the barrier before the slowest rank (0.1 s late) entered it
+    ts = [out[r][1] for r in range(world)]
+    assert max(ts) - min(ts) < 0.05
+
+
+def test_replica_pool_fans_jobs_out_over_contexts_in_threads():
+    """hgmm_amd.replicas.ReplicaPool without a GPU: one stand-in context per 'device', one thread each; results in job
+    order, every job on exactly one context, module-level default_context() of a worker thread = its own context."""
+    import threading
+    import hgmm_amd
+    from hgmm_amd.replicas import ReplicaPool
+
+    class Fake:
+        def __init__(self, device):
+            self.device, self.h, self.jobs, self.busy = device, 1, [], threading.Lock()
+
+        def close(self):
+            self.h = None
+
+    made = []
+
+    def factory(device):
+        made.append(Fake(device))
+        return made[-1]
+
+    def fn(ctx, job):
+        assert hgmm_amd.default_context() is ctx            # use_context: the thread's default IS its replica's context
+        assert ctx.busy.acquire(blocking=False)             # a context is never driven by two threads at once
+        try:
+            ctx.jobs.append(job)
+            import time
+            time.sleep(0.002)
+            return job * job
+        finally:
+            ctx.busy.release()
+
+    with ReplicaPool(devices=[0, 1, 2], contexts_per_device=2, context_factory=factory) as pool:
+        assert pool.devices == [0, 0, 1, 1, 2, 2]
+        res = pool.map(fn, range(40))
+        assert res == [j * j for j in range(40)]
+        assert sorted(j for c in made for j in c.jobs) == list(range(40))
+        assert len(made) == 6 and sum(1 for c in made if c.jobs) >= 2
+        res2 = pool.map(fn, [5])                            # fewer jobs than contexts
+        assert res2 == [25]
+    assert all(c.h is None for c in made)
+    # a failing job stops the pool and surfaces
+    with ReplicaPool(devices=[0, 1], context_factory=factory) as pool:
+        def bad(ctx, job):
+            if job == 3:
+                raise ValueError("job 3")
+            return job
+        try:
+            pool.map(bad, range(8))
+            raise AssertionError("no error")
+        except RuntimeError as e:
+            assert "job 3" in repr(e.__cause__)
+    # outside a pool the thread-local override is gone
+    assert getattr(hgmm_amd._native._thread_ctx, "ctx", None) is None
