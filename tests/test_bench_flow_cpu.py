@@ -153,6 +153,8 @@ def test_bench_two_rank_flow():
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    # the compact per-leg summary closes the line (a reader that keeps only the line's tail still has it)
+    assert list(d)[-1] == "summary" and d["summary"]["it_per_s"] > 0 and "legs" in d
     # an N > 1 line must not read as "unmeasured": roofline (rank 0's E-step launch) and cpu_baseline are objects
     assert d["value"] > 0 and d["it_per_s_per_gpu"] * 2 == d["value"]
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0 and "cold_frac" in d["roofline"]

@@ -63,6 +63,8 @@ def main():
                       "MI355X_MICROARCH.md FETCH_SIZE under-reports wide (16 B/lane) coalesced streaming reads by 2x on "
                       "gfx950 -- applied to the M-step kernel's resp stream only (the E-step's reads are scalar loads "
                       "of X, uncorrected)",
+            "measured_on": __import__("datetime").date.today().isoformat(),
+            "commit": os.environ.get("HGMM_COMMIT", "unrecorded"),
             "flat_estep_bytes_per_launch": (e_f or 0) + (e_w or 0) if e_w else None,
             "flat_estep_fetch_bytes": e_f, "flat_estep_write_bytes": e_w,
             "flat_mstep_bytes_per_launch": 2 * (m_f or 0) + (m_w or 0) if m_f else None,
