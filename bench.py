@@ -350,6 +350,36 @@ def tree_1m_leg(ctx):
         ctx.tree_build(L, 80.0, 1e-4, P[idx], 0.01, 4)
         ts_leaf.append(time.perf_counter() - t0)
     dt, dt_leaf = float(np.median(ts)), float(np.median(ts_leaf))
+    # the same build with the stop rule's pdfs in float32 (hgmm_tree_set_precision: the reference GPU file's type)
+    f32 = None
+    if hasattr(ctx, "tree_set_precision"):
+        ctx.tree_set_precision(np.float32)
+        try:
+            ctx.tree_build(L, 80.0, 1e-4, P[idx], 0.01, 4, want_leaf=False)
+            t32 = []
+            for rep in range(5):
+                last = rep == 4
+                if last:
+                    ctx.profile_reset()
+                    ctx.profile_enable(True)
+                t0 = time.perf_counter()
+                r32 = ctx.tree_build(L, 80.0, 1e-4, P[idx], 0.01, 4, want_leaf=False)
+                t32.append(time.perf_counter() - t0)
+                if last:
+                    ctx.profile_enable(False)
+            ll32_ms, ll32_n = ctx.profile_get("tree_loglik")
+            ex32, _ = ctx.tree_stats()
+            f32 = {"build_ms": float(np.median(t32)) * 1e3, "loglik_kernel_ms_total": ll32_ms, "loglik_launches": ll32_n,
+                   "executed_pairs": ex32, "level_iterations": [int(v) for v in r32[4]],
+                   "node_tables_bitwise_equal_to_the_float64_build": bool(all(np.array_equal(a, b) for a, b in zip(r32[:3], (pi, mu, cov)))),
+                   "max_relative_dq_vs_float64": float(np.abs(np.asarray(r32[5]) / np.asarray(q) - 1.0).max()),
+                   # 20 packed + 6 plain + 4 transcendental VALU instructions per node for the thread's FOUR points
+                   "valu_instr_per_executed_pair": 7.5,
+                   "note": "level log-likelihood in packed float32 on workgroup-local coordinates, log() and the sum over "
+                           "the points in float64; E-step, moments and M-step float64 (tree identical while the levels "
+                           "stop after the same iterations)"}
+        finally:
+            ctx.tree_set_precision(np.float64)
     pairs = sum(int(it) * len(P) * 8 ** (l + 1) for l, it in enumerate(iters))
     # fp64 VALU instructions per EVALUATED pair (tree_loglik_kernel<4>, local-origin triangular form): 9 quadratic
     # form + compare 1 + exp 16 + accumulate 1 = 27 (all full-rate v_fma/v_mul/v_add_f64: one per 4 cycles per SIMD)
@@ -364,6 +394,7 @@ def tree_1m_leg(ctx):
             "level_iterations": [int(v) for v in iters],
             "ms_per_level_iteration": dt * 1e3 / max(int(iters.sum()), 1),
             "loglik_kernel_ms_total": ll_ms, "estep_kernel_ms_total": es_ms,
+            "float32_pdfs": f32,
             "dead_nodes_per_level_at_the_end": dead,
             "roofline": {"kernel": "tree_loglik_kernel<4>", "bound": "valu (fp64)",
                          "reference_pairs": pairs, "executed_pairs": executed,
@@ -931,7 +962,8 @@ def split_legs(out, args):
         "fused_frac_fp32_peak": _pick(out, "roofline_fused", "frac"),
         "cpu_it_per_s": _pick(out, "cpu_baseline", "value"),
         "bunny_J100_gpu_cpu_it_per_s": [_pick(legs, "bunny", "gpu_it_per_s"), _pick(legs, "bunny", "cpu_it_per_s")],
-        "c4_build_ms": _pick(legs, "hgmm", "build_ms"), "tree_1M_build_ms": _pick(legs, "tree_1M", "build_ms"),
+        "c4_build_ms": _pick(legs, "hgmm", "build_ms"),
+        "tree_1M_build_ms_f64_f32pdf": [_pick(legs, "tree_1M", "build_ms"), _pick(legs, "tree_1M", "float32_pdfs", "build_ms")],
         "fullcov_ms_per_it": _pick(legs, "fullcov", "ms_per_iteration"),
         "predict_ms": _pick(legs, "predict", "kernel_ms"), "mstep_frac": _pick(legs, "materialised_iteration", "roofline", "frac"),
         "kmeans_k800_1M_ms": [_pick(legs, "kmeans_init", "fit_ms_warm"), _pick(legs, "kmeans_init", "seeding_ms_warm")],

@@ -101,6 +101,7 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_tree_build", [ctx, C.c_int, C.c_double, C.c_double, _vp, C.c_double, C.c_int,
                                       _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.POINTER(C.c_int)])
         _sig(lib, "hgmm_tree_set_nodes", [ctx, C.c_int, _vp, _vp, _vp])
+        _sig(lib, "hgmm_tree_set_precision", [ctx, C.c_int])
         _sig(lib, "hgmm_tree_set_target", [ctx, _vp, C.c_int64])
         _sig(lib, "hgmm_tree_reg_estep", [ctx, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp])
         _sig(lib, "hgmm_tree_reg_normal", [ctx, _vp, _vp, C.c_double, C.c_double, _vp])
@@ -878,6 +879,16 @@ class Context:
                                              int(max_iters_per_level), _ptr(pi), _ptr(mu), _ptr(cov), _ptr(leaf),
                                              _ptr(iters), _ptr(q), qcap, C.byref(qlen)))
         return pi, mu, cov, leaf, iters, q[:qlen.value].copy()
+
+    def tree_set_precision(self, dtype):
+        """``np.float64`` (default, the reference CPU twin's type) or ``np.float32`` (its GPU file's, hgmm_gpu.py:472-484):
+        the level log-likelihood behind tree_build's stop rule evaluates its Gaussians in float32 on large clouds."""
+        dt = np.dtype(dtype)
+        if dt not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise ValueError("tree precision must be float64 or float32, not %s" % dt)
+        self._check(self.lib.hgmm_tree_set_precision(self.h, 1 if dt == np.dtype(np.float32) else 0))
+        self.tree_dtype = dt
+        return self
 
     def tree_set_nodes(self, L, pi, mu, cov):
         T = 8 * (8 ** L - 1) // 7

@@ -76,6 +76,7 @@ struct TreeState {
     int L = 0;
     int T = 0;
     bool nodes_ready = false;
+    bool pdf_f32 = false;             // hgmm_tree_set_precision: the level log-likelihood's pdfs in float32 (large clouds)
     double mu_rmax = -1.0;            // largest |mu_j| of the node table (< 0: not known on the host yet)
     bool momq_dirty = true;           // the fixed-point moment words hold sums nobody has cleared yet
     unsigned long long reg_seq = 0;   // sequence number of the last registration system handed over in pinned memory

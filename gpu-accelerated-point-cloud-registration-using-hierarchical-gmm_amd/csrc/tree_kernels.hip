@@ -1143,6 +1143,206 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
                                                  q_out, done, stop, flags, pair_count, exp2_tab}, smem);
 }
 
+// ------------------------------------------------------------------------------------------
+// The same level log-likelihood with the pdfs in FLOAT32 (hgmm_tree_set_precision(ctx, HGMM_PRECISION_F32_PDF): the type
+// of the reference's GPU file, hgmm_gpu.py:472-484 -- float32 points, float32 node and moment arrays), large clouds.
+//   * What stays float64: the points' coordinates relative to the workgroup's first point and every node's parameters in
+//     those coordinates (R, -R (mu - c), weight) are formed in float64 exactly as above and only THEN rounded -- the
+//     float32 numbers are of the size of the workgroup's extent over sigma, not of |x| over sigma; log(max(sum, eps))
+//     per point and the sum q over the points are float64.
+//   * What becomes float32: z = R d - b, y = -|z|^2 (R pre-scaled by sqrt(log2 e): 2^y is the pdf's exponential), 2^y by
+//     v_exp_f32, sum_j w_j 2^y_j per point: 20 packed instructions (two points per v_pk_fma_f32) + 4 v_exp_f32 per node
+//     for the thread's FOUR points, against 96 float64 instructions above.
+//   * Range: the reference clamps the sum at eps = 1e-15 before the logarithm (logLikelihoodValue, C:83), so a term
+//     below eps * 2^-30 / n_nodes cannot move a point's logarithm by 1e-9 -- nodes whose UPPER bound over the
+//     workgroup's box, log w - kappa dist(box, mu)^2, is below that never enter the tile, and a wave skips the
+//     exponentials of a node whose exponents are all below it: float32's exponent range (2^-126) is never approached.
+//   Accuracy of q against the float64 kernel: ~1e-7 relative per term, |dq| <~ 1e-7 N in the worst (fully correlated)
+//   case -- three orders of magnitude below the levels' stop thresholds (ls = 20 ... 80 for N = 40 k ... 1 M).  The
+//   E-step and the moments do NOT go through this kernel: as long as a level stops after the same number of iterations
+//   the tree is the float64 tree bit for bit.
+// ------------------------------------------------------------------------------------------
+typedef float f2t __attribute__((ext_vector_type(2)));
+typedef float f4t __attribute__((ext_vector_type(4)));
+constexpr double LLF_SQRT_LOG2E = 1.2011224087864498;    // sqrt(log2 e): |sqrt(log2 e) z|^2 = log2(e) |z|^2
+constexpr double LLF_LOG2E = 1.4426950408889634;
+constexpr double LLF_REL_BITS = 30.0;                    // a dropped term is below eps * 2^-30 / n_nodes
+__device__ __forceinline__ f2t llf_bc(float v) { return f2t{v, v}; }
+__device__ __forceinline__ f2t llf_fma(f2t a, f2t b, f2t c) { return __builtin_elementwise_fma(a, b, c); }
+
+__global__ __launch_bounds__(CH) void tree_loglik_f32_kernel(TreeLoglikArgs a) {
+    constexpr int PTS = 4;
+    __shared__ f4t tile[LL_TILE * 3];                      // per node: (r00 r01 r02 r11) (r12 r22 -b0 -b1) (-b2 w yskip 0)
+    __shared__ double shq[CH / 64];
+    __shared__ double shbox[CH / 64][6];
+    __shared__ int wcnt[CH / 64];
+    const int bx = (int)blockIdx.x, by = (int)blockIdx.y, gx = (int)gridDim.x, gy = (int)gridDim.y;
+    const double* __restrict__ xs = a.xs;
+    const int64_t n = a.n, n_pad = a.n_pad;
+    const double* __restrict__ prep = a.prep;
+    const int64_t lb = a.lb;
+    const int n_level_nodes = a.n_level_nodes, nodes_per_chunk = a.nodes_per_chunk;
+    const int stop_flag = a.done ? *a.done : 0;
+    const int fl = a.flags ? *a.flags : 0;
+    const int w = wave_in_block(), lane = lane_id();
+    const int64_t i_first = (int64_t)bx * PTS * CH;
+    const int64_t i_c = i_first < n ? i_first : n - 1;
+    const double c0 = xs[i_c], c1 = xs[n_pad + i_c], c2 = xs[2 * n_pad + i_c];
+    int64_t i[PTS];
+    bool active[PTS];
+    double r0[PTS], r1[PTS], r2[PTS];
+#pragma unroll
+    for (int p = 0; p < PTS; ++p) {
+        i[p] = i_first + (int64_t)p * CH + threadIdx.x;
+        active[p] = i[p] < n;
+        const int64_t il = active[p] ? i[p] : i_c;
+        r0[p] = xs[il]; r1[p] = xs[n_pad + il]; r2[p] = xs[2 * n_pad + il];
+    }
+    if (stop_flag) return;
+    const bool use_chol = !(fl & 1);                       // kernel-uniform
+    double lo0 = 0.0, lo1 = 0.0, lo2 = 0.0, hi0 = 0.0, hi1 = 0.0, hi2 = 0.0;
+    float xf0[PTS], xf1[PTS], xf2[PTS];
+#pragma unroll
+    for (int p = 0; p < PTS; ++p) {
+        double d0 = 0.0, d1 = 0.0, d2 = 0.0;               // inactive slots sit on the origin
+        if (active[p]) { d0 = r0[p] - c0; d1 = r1[p] - c1; d2 = r2[p] - c2; }
+        lo0 = fmin(lo0, d0); hi0 = fmax(hi0, d0);
+        lo1 = fmin(lo1, d1); hi1 = fmax(hi1, d1);
+        lo2 = fmin(lo2, d2); hi2 = fmax(hi2, d2);
+        xf0[p] = (float)d0; xf1[p] = (float)d1; xf2[p] = (float)d2;
+    }
+    {
+        const double b0 = -wave_max_f64(-lo0), b1 = -wave_max_f64(-lo1), b2 = -wave_max_f64(-lo2);
+        const double b3 = wave_max_f64(hi0), b4 = wave_max_f64(hi1), b5 = wave_max_f64(hi2);
+        if (lane == 0) {
+            shbox[w][0] = b0; shbox[w][1] = b1; shbox[w][2] = b2; shbox[w][3] = b3; shbox[w][4] = b4; shbox[w][5] = b5;
+        }
+    }
+    __syncthreads();
+    lo0 = fmin(fmin(shbox[0][0], shbox[1][0]), fmin(shbox[2][0], shbox[3][0]));
+    lo1 = fmin(fmin(shbox[0][1], shbox[1][1]), fmin(shbox[2][1], shbox[3][1]));
+    lo2 = fmin(fmin(shbox[0][2], shbox[1][2]), fmin(shbox[2][2], shbox[3][2]));
+    hi0 = fmax(fmax(shbox[0][3], shbox[1][3]), fmax(shbox[2][3], shbox[3][3]));
+    hi1 = fmax(fmax(shbox[0][4], shbox[1][4]), fmax(shbox[2][4], shbox[3][4]));
+    hi2 = fmax(fmax(shbox[0][5], shbox[1][5]), fmax(shbox[2][5], shbox[3][5]));
+    // a term below this (natural log) cannot move any point's log(max(sum, eps)) by 2^-30
+    const double abs_floor = log(TREE_EPS) - LLF_REL_BITS * 0.6931471805599453 - log((double)n_level_nodes);
+    const f2t X0[2] = {f2t{xf0[0], xf0[1]}, f2t{xf0[2], xf0[3]}};
+    const f2t X1[2] = {f2t{xf1[0], xf1[1]}, f2t{xf1[2], xf1[3]}};
+    const f2t X2[2] = {f2t{xf2[0], xf2[1]}, f2t{xf2[2], xf2[3]}};
+    f2t TOT[2] = {f2t{0.f, 0.f}, f2t{0.f, 0.f}};
+
+    const int node_begin = by * nodes_per_chunk;
+    const int node_end = (node_begin + nodes_per_chunk < n_level_nodes) ? node_begin + nodes_per_chunk : n_level_nodes;
+    int entered = 0;
+    for (int base = node_begin; base < node_end; base += LL_TILE) {
+        const int node = base + (int)threadIdx.x;
+        bool live = false;
+        f4t va = f4t{0.f, 0.f, 0.f, 0.f}, vb = va, vc = va;
+        if (node < node_end) {
+            const double* pr = prep + PREP_N * (lb + node);
+            const double wL = pr[10], kap = pr[PREP_KAPPA], u0 = pr[6], u1 = pr[7], u2 = pr[8];
+            const int fo = use_chol ? PREP_R : 0;
+            const double f0 = pr[fo], f1 = pr[fo + 1], f2 = pr[fo + 2], f3 = pr[fo + 3], f4 = pr[fo + 4], f5 = pr[fo + 5];
+            if (wL != 0.0) {
+                const double m0 = u0 - c0, m1 = u1 - c1, m2 = u2 - c2;
+                const double g0 = fmax(fmax(lo0 - m0, m0 - hi0), 0.0), g1 = fmax(fmax(lo1 - m1, m1 - hi1), 0.0),
+                             g2 = fmax(fmax(lo2 - m2, m2 - hi2), 0.0);
+                const double d2 = g0 * g0 + g1 * g1 + g2 * g2;
+                const double lw = log(wL);
+                live = !(lw - kap * d2 < abs_floor);
+                if (live) {
+                    const float ysk = (float)((abs_floor - lw) * LLF_LOG2E);            // skip threshold of 2^y, log2 units
+                    if (use_chol) {
+                        const double S = LLF_SQRT_LOG2E;
+                        va = f4t{(float)(S * f0), (float)(S * f1), (float)(S * f2), (float)(S * f3)};
+                        vb = f4t{(float)(S * f4), (float)(S * f5), (float)(-S * fma(f2, m2, fma(f1, m1, f0 * m0))),
+                                 (float)(-S * fma(f4, m2, f3 * m1))};
+                        vc = f4t{(float)(-S * (f5 * m2)), (float)wL, ysk, 0.f};
+                    } else {
+                        // symmetric form: (-log2(e) / 2) Sigma^-1 and the mean, one float32 quadratic form per point
+                        const double H = -0.5 * LLF_LOG2E;
+                        va = f4t{(float)(H * f0), (float)(H * f1), (float)(H * f2), (float)(H * f3)};
+                        vb = f4t{(float)(H * f4), (float)(H * f5), (float)m0, (float)m1};
+                        vc = f4t{(float)m2, (float)wL, ysk, 0.f};
+                    }
+                }
+            }
+        }
+        const unsigned long long mask = __ballot(live);
+        const int before = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[w] = __popcll(mask);
+        __syncthreads();                                   // also: every wave is done with the previous tile
+        int off = 0, cnt = 0;
+#pragma unroll
+        for (int ww = 0; ww < CH / 64; ++ww) {
+            const int t = wcnt[ww];
+            if (ww < w) off += t;
+            cnt += t;
+        }
+        if (live) {
+            f4t* dst = tile + 3 * (off + before);
+            dst[0] = va; dst[1] = vb; dst[2] = vc;
+        }
+        __syncthreads();
+        entered += cnt;
+        if (fl & 4) cnt = 0;                               // HGMM_TREE_LL_NOEVAL (measurement aid)
+        for (int k = 0; k < cnt; ++k) {
+            const f4t ta = tile[3 * k], tb = tile[3 * k + 1], tc = tile[3 * k + 2];
+            f2t y[2];
+            if (use_chol) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f2t z0 = llf_fma(llf_bc(ta.z), X2[h], llf_fma(llf_bc(ta.y), X1[h], llf_fma(llf_bc(ta.x), X0[h], llf_bc(tb.z))));
+                    const f2t z1 = llf_fma(llf_bc(tb.x), X2[h], llf_fma(llf_bc(ta.w), X1[h], llf_bc(tb.w)));
+                    const f2t z2 = llf_fma(llf_bc(tb.y), X2[h], llf_bc(tc.x));
+                    f2t t = -(z0 * z0);
+                    t = llf_fma(-z1, z1, t);
+                    y[h] = llf_fma(-z2, z2, t);
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f2t d0 = X0[h] - llf_bc(tb.z), d1 = X1[h] - llf_bc(tb.w), d2 = X2[h] - llf_bc(tc.x);
+                    const f2t t0 = llf_fma(llf_bc(2.f), llf_fma(llf_bc(ta.z), d2, llf_bc(ta.y) * d1), llf_bc(ta.x) * d0);
+                    const f2t t1 = llf_fma(llf_bc(2.f), llf_bc(tb.x) * d2, llf_bc(ta.w) * d1);
+                    y[h] = llf_fma(d2, llf_bc(tb.y) * d2, llf_fma(d1, t1, d0 * t0));
+                }
+            }
+            const float ymax = fmaxf(fmaxf(y[0].x, y[0].y), fmaxf(y[1].x, y[1].y));
+            if (__any(ymax > tc.z)) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f2t e = f2t{__builtin_amdgcn_exp2f(y[h].x), __builtin_amdgcn_exp2f(y[h].y)};
+                    TOT[h] = llf_fma(llf_bc(tc.y), e, TOT[h]);
+                }
+            }
+        }
+    }
+    if (a.pair_count && threadIdx.x == 0) {
+        const int64_t rest = n - i_first;
+        const int64_t pts = rest <= 0 ? 0 : (rest < (int64_t)PTS * CH ? rest : (int64_t)PTS * CH);
+        atomicAdd(a.pair_count, (unsigned long long)(pts * entered));
+    }
+    const float tot[PTS] = {TOT[0].x, TOT[0].y, TOT[1].x, TOT[1].y};
+    if (gy > 1) {
+#pragma unroll
+        for (int p = 0; p < PTS; ++p)
+            if (active[p]) a.partial[(size_t)by * n_pad + i[p]] = (double)tot[p];
+        return;
+    }
+    double lq = 0.0;
+#pragma unroll
+    for (int p = 0; p < PTS; ++p) lq += active[p] ? log(fmax((double)tot[p], TREE_EPS)) : 0.0;
+    lq = wave_sum_f64(lq);
+    __syncthreads();
+    if (lane_id() == 0) shq[wave_in_block()] = lq;
+    __syncthreads();
+    double t = 0.0;
+    for (int ww = 0; ww < CH / 64; ++ww) t += shq[ww];
+    store_block_q(t, a.block_q, bx, gx, a.ticket, a.q_out, a.stop);
+}
+
 // One launch for two independent pieces of work on the same parameters (small clouds, single GPU): the level
 // log-likelihood of iteration e and -- on workgroups of their own, behind them in the grid -- the E-step of iteration
 // e + 1.  Both read the node parameters iteration e's M-step left; neither reads what the other writes.  The E-step is
@@ -1958,6 +2158,10 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                         const unsigned g = (unsigned)(llblocks * chunks) + grid_chunks;
                         if (ll_pts == 2) tree_ll_estep_kernel<2><<<g, CH, 0, c->stream>>>(la, llblocks, chunks, ea);
                         else tree_ll_estep_kernel<1><<<g, CH, 0, c->stream>>>(la, llblocks, chunks, ea);
+                    } else if (ll_pts == 4 && c->tree.pdf_f32) {
+                        const TreeLoglikArgs la{xs_cur, n, n_pad, d_prep, lb, n_level, per_chunk, ll_partial, block_q, q_ticket,
+                                                q_dev, &ctl->done, chunks > 1 ? no_stop : stop, flags_ptr(c), pairs_ptr(c), nullptr};
+                        tree_loglik_f32_kernel<<<dim3(llblocks, chunks), CH, 0, c->stream>>>(la);
                     } else if (ll_pts == 4)
                         tree_loglik_kernel<4, true><<<dim3(llblocks, chunks), CH, 0, c->stream>>>(
                             xs_cur, n, n_pad, d_prep, lb, n_level, per_chunk, ll_partial, block_q, q_ticket, q_dev, &ctl->done,
@@ -2131,6 +2335,14 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     if (q_len_out) *q_len_out = q_len < q_capacity ? q_len : q_capacity;
     if (rc == HGMM_OK) { c->tree.nodes_ready = true; c->tree.mu_rmax = -1.0; }
     return rc;
+}
+
+extern "C" int hgmm_tree_set_precision(hgmm_ctx* c, int precision) {
+    HGMM_ENTER(c);
+    if (precision != HGMM_PRECISION_F64 && precision != HGMM_PRECISION_F32_PDF)
+        return fail(c, HGMM_ERR_ARG, "hgmm_tree_set_precision: unknown precision %d", precision);
+    c->tree.pdf_f32 = precision == HGMM_PRECISION_F32_PDF;
+    return HGMM_OK;
 }
 
 extern "C" int hgmm_tree_set_nodes(hgmm_ctx* c, int L, const double* pi, const double* mu, const double* cov) {

@@ -51,20 +51,35 @@ def _points(x):
 
 
 def buildGMMTree(points, maxTreeLevel, ls, ld, sig2=0.004, seed=72, init_idx=None,
-                 max_iters_per_level=1000, ctx: Context | None = None, return_trace=False):
+                 max_iters_per_level=1000, ctx: Context | None = None, return_trace=False, dtype=None):
     """-> (mixingCoeff[T], mean[T,3], covar[T,3,3])   (hgmm_gpu.py:466-548).
 
     ``init_idx`` (T indices into ``points``) overrides the reference's
-    ``np.random.seed(72); randint(nTotal, size=nTotal)`` draw."""
+    ``np.random.seed(72); randint(nTotal, size=nTotal)`` draw.
+
+    ``dtype``: the reference has this function twice -- float64 in the CPU twin (hgmm_cupy_cpu_working.py:122-160, the
+    canonical semantics) and float32 in the GPU file (``points.astype(np.float32)``, float32 node and moment arrays,
+    hgmm_gpu.py:472, 478-484).  Default: the points' own type -- float32 points give float32 tables and the float32-pdf
+    stop rule (``Context.tree_set_precision``), anything else the float64 path."""
     ctx = ctx or default_context()
-    P = np.ascontiguousarray(_points(points), dtype=np.float64)
+    raw = _points(points)
+    dt = np.dtype(dtype) if dtype is not None else (np.dtype(np.float32) if raw.dtype == np.float32 else np.dtype(np.float64))
+    if dt not in (np.dtype(np.float32), np.dtype(np.float64)):
+        raise ValueError("dtype must be float32 or float64")
+    P = np.ascontiguousarray(raw, dtype=np.float64)
     T = n_total_nodes(maxTreeLevel)
     if init_idx is None:
         rs = np.random.RandomState(seed)
         init_idx = rs.randint(T, size=T)
     ctx.set_points(P)
-    pi, mu, cov, leaf, iters, q = ctx.tree_build(maxTreeLevel, ls, ld, P[np.asarray(init_idx)], sig2,
-                                                 max_iters_per_level, want_leaf=bool(return_trace))
+    ctx.tree_set_precision(dt)
+    try:
+        pi, mu, cov, leaf, iters, q = ctx.tree_build(maxTreeLevel, ls, ld, P[np.asarray(init_idx)], sig2,
+                                                     max_iters_per_level, want_leaf=bool(return_trace))
+    finally:
+        ctx.tree_set_precision(np.float64)
+    if dt == np.dtype(np.float32):
+        pi, mu, cov = pi.astype(np.float32), mu.astype(np.float32), cov.astype(np.float32)
     if return_trace:
         return pi, mu, cov, {"leaf_idx": leaf, "iters_per_level": iters, "q_trace": q}
     return pi, mu, cov

@@ -220,6 +220,17 @@ int hgmm_tree_build(hgmm_ctx* ctx, int L, double ls, double ld, const double* in
                     int* q_len_out);
 int hgmm_tree_set_nodes(hgmm_ctx* ctx, int L, const double* pi, const double* mu,
                         const double* cov);
+/* Arithmetic type of the pdf evaluations behind hgmm_tree_build's STOP RULE.  The reference has both: its CPU twin is
+ * float64 throughout (hgmm_cupy_cpu_working.py; the default here and the parity reference), its GPU file float32
+ * throughout (`points.astype(np.float32)`, float32 node and moment arrays: hgmm/hgmm_gpu.py:472, 478-484).
+ * HGMM_PRECISION_F32_PDF: the level log-likelihood q = sum_i log max(sum_j pi_j N(x_i; j), eps) (logLikelihoodValue,
+ * hgmm_gpu.py:107-115) evaluates its N x 8^(l+1) Gaussians in packed float32 on coordinates relative to the workgroup's
+ * first point (formed in float64), with log() and the sum over the points in float64 -- on clouds of >= 400 000 points,
+ * where that kernel is most of a build; smaller clouds are bound by launch latencies and keep float64.  The E-step, the
+ * moments and the M-step stay float64: a level that stops after the same number of iterations yields the float64 tree bit
+ * for bit; q itself differs by ~1e-7 relative.  Stays in force for the context until set again. */
+enum { HGMM_PRECISION_F64 = 0, HGMM_PRECISION_F32_PDF = 1 };
+int hgmm_tree_set_precision(hgmm_ctx* ctx, int precision);
 /* Registration target cloud (host [n,3] float64), kept resident across iterations. */
 int hgmm_tree_set_target(hgmm_ctx* ctx, const double* xyz, int64_t n);
 /* E-step of the registration loop on the resident target transformed on the fly by

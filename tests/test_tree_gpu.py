@@ -615,3 +615,92 @@ def test_stop_rule_in_the_next_launch_equals_the_ticketed_tail(ctx, bunny, monke
             assert np.array_equal(x, y)
     if max_iters < 1000:
         assert list(a[4]) == [max_iters] * L
+
+
+# ---- float32 pdfs behind the stop rule (hgmm_tree_set_precision: the reference GPU file's type, hgmm_gpu.py:472-484) ----
+def _blobs(n, seed, k=40, spread=0.02):
+    rs = np.random.RandomState(seed)
+    centres = rs.rand(k, 3)
+    scale = spread * (0.5 + rs.rand(k, 1, 3))
+    which = rs.randint(k, size=n)
+    return centres[which] + scale[which, 0] * rs.randn(n, 3)
+
+
+def test_float32_pdf_mode_against_the_1M_oracle_fixture(ctx):
+    """HGMM_PRECISION_F32_PDF on the million-point build of the bench: q within float32's reach of the oracle's float64
+    trace, and -- the E-step and the moments stay float64 -- node tables and all 10^6 leaf assignments BITWISE those of
+    the float64 build (which test_tree_1M_matches_oracle_fixture pins to the oracle)."""
+    g = load_golden("hgmm_build_uniform1M_L4_oracle.npz")
+    N = int(g["n_points"])
+    P = np.random.RandomState(int(g["cloud_seed"])).rand(N, 3).astype(np.float32).astype(np.float64)
+    L = int(g["L"])
+    T = hgmm_tree.n_total(L)
+    idx = np.random.RandomState(int(g["init_seed"])).randint(N, size=T)
+    k = int(g["max_iters_per_level"])
+    args = (P, L, float(g["ls"]), float(g["ld"]), idx, float(g["sig2"]))
+    ref = build(ctx, *args, max_iters=k)
+    pairs64 = ctx.tree_stats()[0]
+    ctx.tree_set_precision(np.float32)
+    try:
+        got = build(ctx, *args, max_iters=k)
+        pairs32 = ctx.tree_stats()[0]
+        again = build(ctx, *args, max_iters=k)
+    finally:
+        ctx.tree_set_precision(np.float64)
+    assert list(got[4]) == list(g["iters_per_level"])
+    rel = np.abs(got[5] / g["q_trace"] - 1.0)
+    print("float32 pdfs: max relative dq vs the oracle %.3g (|dq| max %.3g); evaluated pairs %d (float64 kernel: %d)"
+          % (rel.max(), np.abs(got[5] - g["q_trace"]).max(), pairs32, pairs64))
+    assert rel.max() < 2e-6
+    for a, b in zip(got[:4], ref[:4]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(again[5], got[5])                     # deterministic
+    assert pairs32 <= pairs64                                   # the eps clamp lets go of nodes float64's exact-zero rule keeps
+
+
+@pytest.mark.parametrize("n", [430_000, 700_000])
+def test_float32_pdf_mode_builds_the_float64_tree_to_convergence(ctx, n, monkeypatch):
+    """Stop rule ON (no iteration budget in the way): a clustered cloud, L = 3, ls = 20.  Both precisions must stop every
+    level after the same number of iterations -- then the trees are identical bit for bit -- and q agrees to ~1e-7.
+    n = 430 000: the log-likelihood's node-chunked grid (partial sums + finish pass); 700 000: one chunk.  Then the same
+    with the symmetric-form fallback (HGMM_TREE_NO_CHOL=1)."""
+    P = _blobs(n, seed=n % 97)
+    L = 3
+    T = hgmm_tree.n_total(L)
+    idx = np.random.RandomState(3).randint(n, size=T)
+    args = (P, L, 20.0, 1e-4, idx, 0.004)
+    ref = build(ctx, *args, max_iters=300)
+    assert max(ref[4]) < 300 and min(ref[4]) >= 3               # converged by the rule, not by the budget
+    monkeypatch.setenv("HGMM_TREE_NO_CHOL", "1")              # (the fallback form changes the float64 E-step's last bits too)
+    ref_sym = build(ctx, *args, max_iters=300)
+    monkeypatch.delenv("HGMM_TREE_NO_CHOL")
+    ctx.tree_set_precision(np.float32)
+    try:
+        got = build(ctx, *args, max_iters=300)
+        monkeypatch.setenv("HGMM_TREE_NO_CHOL", "1")
+        sym = build(ctx, *args, max_iters=300)
+        monkeypatch.delenv("HGMM_TREE_NO_CHOL")
+    finally:
+        ctx.tree_set_precision(np.float64)
+    for name, res, want in (("triangular", got, ref), ("symmetric", sym, ref_sym)):
+        assert list(res[4]) == list(want[4]), (name, res[4], want[4])
+        rel = np.abs(res[5] / want[5] - 1.0).max()
+        print("n = %d, %s form: iterations %s, max relative dq %.3g" % (n, name, list(res[4]), rel))
+        assert rel < 2e-6
+        for a, b in zip(res[:4], want[:4]):
+            assert np.array_equal(a, b)
+
+
+def test_mirror_returns_the_type_it_is_handed(ctx, bunny):
+    """buildGMMTree exists twice in the reference: float64 in the CPU twin, float32 in the GPU file (hgmm_gpu.py:472-484).
+    The mirror follows the points' type (or ``dtype=``): float32 points -> float32 tables = the float64 tables rounded."""
+    from hgmm_amd.hgmm.hgmm_gpu import buildGMMTree
+    P32 = bunny[::5].copy()
+    assert P32.dtype == np.float32
+    ref = buildGMMTree(P32.astype(np.float64), 2, 20, 1e-4, ctx=ctx)
+    got = buildGMMTree(P32, 2, 20, 1e-4, ctx=ctx)
+    forced = buildGMMTree(P32, 2, 20, 1e-4, ctx=ctx, dtype=np.float64)
+    for g, r, f in zip(got, ref, forced):
+        assert g.dtype == np.float32 and r.dtype == np.float64 and f.dtype == np.float64
+        assert np.array_equal(g, r.astype(np.float32)) and np.array_equal(f, r)
+    assert ctx.tree_dtype == np.float64                          # the context's precision is put back
