@@ -790,7 +790,10 @@ COLLECTIVES = {
     "host": "host shared memory (device -> shm -> device)",
 }
 # what a rank moves on to when a backend cannot be set up on every rank (decided collectively, see choose_collective)
-FALLBACK_ORDER = {"auto": ["rccl", "ipc", "host"], "rccl": ["rccl", "ipc", "host"], "ipc": ["ipc", "host"], "host": ["host"]}
+# (the host backend comes BEFORE the peer exchange: the exchange has run with up to eight ranks on ONE GPU but never across
+#  two -- until a multi-GPU node has validated it, the headline must not depend on it; `--collective auto` still times it
+#  as the side leg `peer_exchange`, wrapped so that its failure cannot lose the line -- ADVICE r4)
+FALLBACK_ORDER = {"auto": ["rccl", "host", "ipc"], "rccl": ["rccl", "host", "ipc"], "ipc": ["ipc", "host"], "host": ["host"]}
 ATTACH_TIMEOUT_S = float(os.environ.get("HGMM_BENCH_ATTACH_TIMEOUT", "180"))
 
 
@@ -828,6 +831,7 @@ def choose_collective(ctx, rank, world, order, token, hosts, round0=1):
     flags over plain TCP, so a failure on some ranks only cannot leave the ranks on different backends.
     -> (kind or None, [(kind, error text), ...] of the attempts that failed somewhere)."""
     from hgmm_amd import parallel
+    import hgmm_amd
     failed = []
     for i, kind in enumerate(order):
         if kind != "rccl" and len(hosts) > 1:
@@ -836,14 +840,21 @@ def choose_collective(ctx, rank, world, order, token, hosts, round0=1):
         err = attach_collective(ctx, kind, rank, world, token)
         if err is not None:
             sys.stderr.write("rank %d: %s backend could not be set up: %r\n" % (rank, kind, err))
-        flags = parallel.allgather_bytes_tcp(rank, world, b"0" if err is not None else b"1", port_offset=137 + 10 * (round0 + i))
+        # (a rank that failed at once waits here for one that sits out its whole attach timeout: the agreement's own
+        #  deadline must outlast ATTACH_TIMEOUT_S, or the fast rank gives up before rank 0 even listens -- ADVICE r4)
+        flags = parallel.allgather_bytes_tcp(rank, world, b"0" if err is not None else b"1",
+                                             port_offset=137 + 10 * (round0 + i), timeout=ATTACH_TIMEOUT_S + 60.0)
         if all(f == b"1" for f in flags):
-            return kind, failed
+            return kind, failed, ctx
         failed.append((kind, repr(err) if err is not None else "failed on another rank"))
         if err is None:
             # this rank's communicator is useless without the others (the call may wait for peers that are gone)
             _run_with_timeout(ctx.comm_destroy, 30.0)
-    return None, failed
+        elif isinstance(err, TimeoutError):
+            # the abandoned attach thread may still be inside the library with this context: the next backend gets a
+            # context of its own (the old one is left to the daemon thread and never touched again)
+            ctx = hgmm_amd.Context(ctx.device_id)
+    return None, failed, ctx
 
 
 def timed_fit(ctx, args, world, init):
@@ -1049,11 +1060,12 @@ def rank_main(args):
         order = FALLBACK_ORDER[requested]
         if rehearsal:
             order = [k for k in order if k != "rccl"]
-        kind, failed_kinds = choose_collective(ctx, rank, world, order, token, hosts)
+        kind, failed_kinds, ctx = choose_collective(ctx, rank, world, order, token, hosts)
         if kind is None:
             sys.stderr.write("rank %d: no all-reduce backend could be set up on all ranks: %s\n" % (rank, failed_kinds))
             sys.exit(RCCL_INIT_FAILED)
     fallback = bool(failed_kinds) and not rehearsal
+    rehearsal_host_only = bool(hostcomm)                  # HGMM_BENCH_HOSTCOMM: the caller asked for the host backend alone
 
     frame = synth_frame(rank)
     mu0, w0, cov0 = init_params(synth_frame(0) if rank else frame)
@@ -1069,9 +1081,12 @@ def rank_main(args):
         sys.stderr.write("rank %d: model checksums differ across ranks: max %s min %s\n" % (rank, fit["checksum"], fit["checksum_lo"]))
     # --collective auto: the same joint fit once more over the one-shot peer exchange, reported beside the RCCL figure
     second = None
-    if world > 1 and requested == "auto" and kind == "rccl" and len(hosts) == 1:
+    if world > 1 and requested == "auto" and kind in ("rccl", "host") and len(hosts) == 1 and not rehearsal_host_only:
         _run_with_timeout(ctx.comm_destroy, 60.0)
-        k2, failed2 = choose_collective(ctx, rank, world, ["ipc"], token, hosts, round0=8)
+        k2, failed2, ctx2 = choose_collective(ctx, rank, world, ["ipc"], token, hosts, round0=8)
+        if ctx2 is not ctx:                             # (the peer-exchange attach hung: carry on with the fresh context)
+            ctx = ctx2
+            ctx.set_points(frame)
         f2 = None
         if k2 == "ipc":
             try:                                    # a side leg on hardware it has never seen must not lose the headline line
@@ -1085,8 +1100,8 @@ def rank_main(args):
             second = {"collective": COLLECTIVES["ipc"], "value": world * K / med2, "ms_per_step": 1e3 * med2 / K,
                       "allreduce_us": 1e3 * f2["ar_ms"] / max(f2["ar_n"], 1),
                       "identical_model_on_all_ranks": f2["consistent"],
-                      "model_bitwise_equal_to_the_rccl_fit": bool(same),
-                      "max_abs_dmu_vs_the_rccl_fit": float(np.abs(f2["model"][1] - fit["model"][1]).max()),
+                      "model_bitwise_equal_to_the_headline_fit": bool(same),
+                      "max_abs_dmu_vs_the_headline_fit": float(np.abs(f2["model"][1] - fit["model"][1]).max()),
                       "blocks": len(f2["blocks"]),
                       "note": "same frames, same initial parameters, same K-step blocks as `value`; only the all-reduce "
                               "behind the statistics differs (sums in rank order instead of RCCL's reduction order)"}
@@ -1428,7 +1443,7 @@ def main():
                     help="N > 1: the all-reduce behind the sufficient statistics.  auto (default): `value` over RCCL "
                          "and the same fit once more over the one-shot peer exchange (`peer_exchange`); rccl / ipc / "
                          "host: that backend only.  A backend that cannot be set up on every rank is replaced by the "
-                         "next of rccl -> ipc -> host, collectively, and the line says so (config.fallback)")
+                         "next of rccl -> host -> ipc, collectively, and the line says so (config.fallback)")
     args = ap.parse_args()
     args.skip = set(s for s in args.skip.split(",") if s)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

@@ -36,7 +36,8 @@ namespace hgmm {
 constexpr float NEG_INF = -__builtin_huge_valf();
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
-constexpr int PK_MU = 0, PK_G = 3, PK_C = 6;   // rows of the packed parameter table
+constexpr int PK_MU = 0, PK_G = 3, PK_C = 6, PK_W = 7;   // rows of the packed parameter table (PK_W: the raw weight, for the fused kernel's origin)
+constexpr int PK_ROWS = 8;
 typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int BLOCK = WAVES_PER_BLOCK * 64;
@@ -70,6 +71,9 @@ __device__ inline void pack_values(int j, bool valid, int Jpad, int variant, con
     pack[(PK_G + 1) * Jpad + j] = g1;
     pack[(PK_G + 2) * Jpad + j] = g2;
     pack[PK_C * Jpad + j] = c;
+    // (a component only counts towards the fused kernel's origin with a usable mean and a positive, finite weight)
+    const bool usable = valid && wj > 0.f && wj < 3.0e38f && fabsf(m0) < 3.0e38f && fabsf(m1) < 3.0e38f && fabsf(m2) < 3.0e38f;
+    pack[PK_W * Jpad + j] = usable ? wj : 0.f;
 }
 __device__ inline void pack_component(int j, int J, int Jpad, int cov_type, int variant,
                                       const float* mu, const float* inv, const float* w,
@@ -982,19 +986,35 @@ __global__ __launch_bounds__(BLOCK) void flat_fused_pk_kernel(
     // done:  sum r (x - mu) = sum r (x - o) - (mu - o) sum r.  The row's x - o is a wave-uniform operand, so the update
     // is one packed FMA per axis -- and the squares (x - mu)^2 the quadratic form needs anyway are what the second
     // moments need: the per-component differences themselves do not have to survive the row's reduction.  18 instead of
-    // 21 packed instructions per pair of components (round 4: 0.374 -> 0.33 ms at C3).  The origin is the mean of the
-    // component means (every wave derives the same one from the table; padding columns hold 0 and J divides) -- inside
-    // the model whatever the coordinates' offset and whatever outliers the cloud has.  The price: a first moment's
+    // 21 packed instructions per pair of components (round 4: 0.374 -> 0.33 ms at C3).  The origin is the weighted mean
+    // of the component means (every wave derives the same one from the table) -- inside the model whatever the
+    // coordinates' offset and whatever outliers the cloud has.  The price: a first moment's
     // rounding error is relative to the MODEL's extent instead of the component's, 2^-24 |x - o| per addition -- the
     // reference's own float32 resp.T @ X has it relative to |x| (tests: test_fit_far_from_the_origin,
     // test_train_far_points_and_mixed_scales).
-    float o0 = mu0s, o1 = mu1s, o2 = mu2s;
+    // ... WEIGHTED by the mixing weights (table row PK_W; 0 for padding, dead and non-finite components): a component
+    // that has lost its points sits wherever its last M-step left it -- at the coordinate origin, which for a cloud in
+    // map coordinates is kilometres outside the model -- and must not pull the common origin (and with it every
+    // component's rounding error) towards itself.
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f, ow = 0.f;
 #pragma unroll
-    for (int p = 0; p < KP; ++p) { o0 += mu0[p].x + mu0[p].y; o1 += mu1[p].x + mu1[p].y; o2 += mu2[p].x + mu2[p].y; }
+    for (int p = 0; p < KP; ++p) {
+        const float wa = pack[PK_W * Jpad + (2 * p) * 64 + lane], wb = pack[PK_W * Jpad + (2 * p + 1) * 64 + lane];
+        o0 = fmaf(wa, mu0[p].x, fmaf(wb, mu0[p].y, o0));
+        o1 = fmaf(wa, mu1[p].x, fmaf(wb, mu1[p].y, o1));
+        o2 = fmaf(wa, mu2[p].x, fmaf(wb, mu2[p].y, o2));
+        ow += wa + wb;
+    }
+    if (ODD) {
+        const float ws = pack[PK_W * Jpad + (K - 1) * 64 + lane];
+        o0 = fmaf(ws, mu0s, o0); o1 = fmaf(ws, mu1s, o1); o2 = fmaf(ws, mu2s, o2);
+        ow += ws;
+    }
     {
-        const float inv_j = 1.0f / (float)(J > 0 ? J : 1);
-        o0 = wave_sum_dpp(o0) * inv_j; o1 = wave_sum_dpp(o1) * inv_j; o2 = wave_sum_dpp(o2) * inv_j;
-        if (!(fabsf(o0) < 3.0e38f)) o0 = 0.f;            // (a NaN / inf mean in the table must not reach every component)
+        ow = wave_sum_dpp(ow);
+        const float inv_w = ow > 0.f ? 1.0f / ow : 0.f;      // (no usable component at all: the coordinate origin)
+        o0 = wave_sum_dpp(o0) * inv_w; o1 = wave_sum_dpp(o1) * inv_w; o2 = wave_sum_dpp(o2) * inv_w;
+        if (!(fabsf(o0) < 3.0e38f)) o0 = 0.f;
         if (!(fabsf(o1) < 3.0e38f)) o1 = 0.f;
         if (!(fabsf(o2) < 3.0e38f)) o2 = 0.f;
     }
@@ -1747,7 +1767,7 @@ static int flat_setup(hgmm_ctx* c, int cov_type, int variant, int J) {
         c->f_w.p = blk + 6 * (size_t)Jpad;  c->f_w.cap = sizeof(float) * Jpad;
         c->f_inv.p = blk + 7 * (size_t)Jpad; c->f_inv.cap = sizeof(float) * 3 * Jpad;
     }
-    HGMM_TRY(ensure(c, c->f_pack, sizeof(float) * FLAT_NSTAT * Jpad));
+    HGMM_TRY(ensure(c, c->f_pack, sizeof(float) * PK_ROWS * Jpad));
     HGMM_TRY(ensure(c, c->f_hint, sizeof(float) * 3 * Jpad));
     // grid_for() never launches more than min(FLAT_MAX_BLOCKS, 8 workgroups per CU)
     const size_t max_blocks = std::min<size_t>(FLAT_MAX_BLOCKS, (size_t)c->cus * 8);

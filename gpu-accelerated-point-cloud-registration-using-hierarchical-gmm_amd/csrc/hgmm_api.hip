@@ -4,12 +4,14 @@
 #include "wave_ops.h"
 
 #include <fcntl.h>
+#include <signal.h>
 #include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
 #include <atomic>
+#include <cerrno>
 #include <chrono>
 #include <algorithm>
 #include <cstdlib>
@@ -72,8 +74,10 @@ int profile_collect(hgmm_ctx* c) {
 // with ONE GPU (RCCL refuses two ranks on one device): the ranks are processes of one machine, every
 // all-reduce goes device -> POSIX shared memory -> summed in rank order -> device.  Deterministic,
 // slow, not a performance path.
+// Both shared-memory objects start with {ready, owner_pid}: see shm_attach.
 struct HostCommShm {
     std::atomic<int> ready;
+    std::atomic<int> owner_pid;
     std::atomic<int> count;
     std::atomic<int> generation;
     int nranks;
@@ -142,9 +146,53 @@ static int hostcomm_allreduce_dev(hgmm_ctx* c, double* dev, size_t n, int op) {
     return HGMM_OK;
 }
 
+// The ranks of a job meet in a POSIX shared-memory object that rank 0 creates (unlink + O_EXCL) and the others open by
+// name.  An object a CRASHED earlier run left under the same name must not be taken for this job's: its header says
+// ready = 1 already, and a rank that opened it before rank 0 replaced it would publish into an orphan and sit out the
+// barrier's timeout.  So the header carries the creator's pid: a joining rank accepts an object only once it is ready
+// AND its creator is alive, and otherwise lets go of it and opens the name again (rank 0's fresh object is zero-filled:
+// not ready until rank 0 has initialised it).  The owner clears `ready` before it unlinks.
+struct ShmHeader { std::atomic<int> ready; std::atomic<int> owner_pid; };
+static void* shm_attach(const std::string& name, size_t bytes, bool owner, int timeout_s) {
+    if (owner) {
+        shm_unlink(name.c_str());
+        const int fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) return nullptr;
+        if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); shm_unlink(name.c_str()); return nullptr; }
+        void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (p == MAP_FAILED) { shm_unlink(name.c_str()); return nullptr; }
+        static_cast<ShmHeader*>(p)->owner_pid.store((int)getpid(), std::memory_order_relaxed);
+        return p;                                           // (the caller fills its fields in, then stores ready = 1)
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const int fd = shm_open(name.c_str(), O_RDWR, 0600);
+        if (fd >= 0) {
+            struct stat st;
+            void* p = MAP_FAILED;
+            if (fstat(fd, &st) == 0 && (size_t)st.st_size >= bytes)
+                p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            close(fd);
+            if (p != MAP_FAILED) {
+                ShmHeader* h = static_cast<ShmHeader*>(p);
+                // a fresh object becomes ready within microseconds of its creation: give it a moment before re-opening
+                for (int spin = 0; spin < 200 && h->ready.load(std::memory_order_acquire) != 1; ++spin) usleep(100);
+                const int pid = h->owner_pid.load(std::memory_order_relaxed);
+                const bool alive = pid > 0 && (kill((pid_t)pid, 0) == 0 || errno == EPERM);
+                if (h->ready.load(std::memory_order_acquire) == 1 && alive) return p;
+                munmap(p, bytes);                           // an orphan, or not initialised yet: look at the name again
+            }
+        }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s)) return nullptr;
+        usleep(1000);
+    }
+}
+
 static void hostcomm_close(hgmm_ctx* c) {
     HostComm* h = c->hcomm;
     if (!h) return;
+    if (h->shm && h->owner) h->shm->ready.store(0, std::memory_order_release);
     if (h->shm) munmap(h->shm, h->bytes);
     if (h->owner) shm_unlink(h->name.c_str());
     delete h;
@@ -173,6 +221,7 @@ constexpr double IPC_TIMEOUT_S = 20.0;
 
 struct IpcShm {
     std::atomic<int> ready;
+    std::atomic<int> owner_pid;
     std::atomic<int> count;
     std::atomic<int> generation;
     std::atomic<int> failed;                     // some rank could not map a peer: nobody keeps the communicator
@@ -293,6 +342,7 @@ static void ipc_close(hgmm_ctx* c) {
     if (ic->shm) {
         // nobody frees its buffer while a peer still has it mapped
         if (ic->in_step) (void)ipc_barrier(c);
+        if (ic->owner) ic->shm->ready.store(0, std::memory_order_release);
         munmap(ic->shm, ic->shm_bytes);
     }
     if (ic->local) (void)hipFree(ic->local);
@@ -886,27 +936,8 @@ extern "C" int hgmm_comm_init_host(hgmm_ctx* c, int nranks, int rank, const char
     h->name = std::string("/") + name;
     h->bytes = sizeof(HostCommShm) + 64 + sizeof(double) * HOSTCOMM_SLOT * (size_t)nranks;
     h->owner = rank == 0;
-    int fd = -1;
-    if (rank == 0) {
-        shm_unlink(h->name.c_str());
-        fd = shm_open(h->name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
-        if (fd >= 0 && ftruncate(fd, (off_t)h->bytes) != 0) { close(fd); fd = -1; }
-    } else {
-        const auto t0 = std::chrono::steady_clock::now();
-        while (fd < 0) {
-            fd = shm_open(h->name.c_str(), O_RDWR, 0600);
-            struct stat st;
-            if (fd >= 0 && (fstat(fd, &st) != 0 || (size_t)st.st_size < h->bytes)) { close(fd); fd = -1; }
-            if (fd < 0) {
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(HOSTCOMM_TIMEOUT_S)) break;
-                usleep(1000);
-            }
-        }
-    }
-    if (fd < 0) { delete h; return fail(c, HGMM_ERR_STATE, "host communicator: cannot open shared memory %s", name); }
-    void* p = mmap(nullptr, h->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (p == MAP_FAILED) { delete h; return fail(c, HGMM_ERR_STATE, "host communicator: mmap failed"); }
+    void* p = shm_attach(h->name, h->bytes, h->owner, HOSTCOMM_TIMEOUT_S);
+    if (!p) { delete h; return fail(c, HGMM_ERR_STATE, "host communicator: cannot %s shared memory %s", rank == 0 ? "create" : "join", name); }
     h->shm = static_cast<HostCommShm*>(p);
     h->data = reinterpret_cast<double*>(static_cast<char*>(p) + ((sizeof(HostCommShm) + 63) / 64) * 64);
     if (rank == 0) {
@@ -915,21 +946,10 @@ extern "C" int hgmm_comm_init_host(hgmm_ctx* c, int nranks, int rank, const char
         h->shm->nranks = nranks;
         h->shm->slot_doubles = HOSTCOMM_SLOT;
         h->shm->ready.store(1, std::memory_order_release);
-    } else {
-        const auto t0 = std::chrono::steady_clock::now();
-        while (h->shm->ready.load(std::memory_order_acquire) != 1) {
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(HOSTCOMM_TIMEOUT_S)) {
-                munmap(p, h->bytes);
-                delete h;
-                return fail(c, HGMM_ERR_STATE, "host communicator: rank 0 never initialised %s", name);
-            }
-            usleep(1000);
-        }
-        if (h->shm->nranks != nranks) {
-            munmap(p, h->bytes);
-            delete h;
-            return fail(c, HGMM_ERR_ARG, "host communicator: world size mismatch");
-        }
+    } else if (h->shm->nranks != nranks) {
+        munmap(p, h->bytes);
+        delete h;
+        return fail(c, HGMM_ERR_ARG, "host communicator: world size mismatch");
     }
     c->hcomm = h;
     c->nranks = nranks;
@@ -980,27 +1000,8 @@ extern "C" int hgmm_comm_init_ipc(hgmm_ctx* c, int nranks, int rank, const char*
     ic->name = std::string("/") + name;
     ic->shm_bytes = sizeof(IpcShm);
     ic->owner = rank == 0;
-    int fd = -1;
-    if (rank == 0) {
-        shm_unlink(ic->name.c_str());
-        fd = shm_open(ic->name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
-        if (fd >= 0 && ftruncate(fd, (off_t)ic->shm_bytes) != 0) { close(fd); fd = -1; }
-    } else {
-        const auto t0 = std::chrono::steady_clock::now();
-        while (fd < 0) {
-            fd = shm_open(ic->name.c_str(), O_RDWR, 0600);
-            struct stat st;
-            if (fd >= 0 && (fstat(fd, &st) != 0 || (size_t)st.st_size < ic->shm_bytes)) { close(fd); fd = -1; }
-            if (fd < 0) {
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(HOSTCOMM_TIMEOUT_S)) break;
-                usleep(1000);
-            }
-        }
-    }
-    if (fd < 0) return bail(HGMM_ERR_STATE, "cannot open shared memory", name);
-    void* p = mmap(nullptr, ic->shm_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (p == MAP_FAILED) return bail(HGMM_ERR_STATE, "mmap failed", "");
+    void* p = shm_attach(ic->name, ic->shm_bytes, ic->owner, HOSTCOMM_TIMEOUT_S);
+    if (!p) return bail(HGMM_ERR_STATE, rank == 0 ? "cannot create shared memory" : "rank 0's shared memory never became ready", name);
     ic->shm = static_cast<IpcShm*>(p);
     if (rank == 0) {
         ic->shm->count.store(0);
@@ -1008,14 +1009,8 @@ extern "C" int hgmm_comm_init_ipc(hgmm_ctx* c, int nranks, int rank, const char*
         ic->shm->failed.store(0);
         ic->shm->nranks = nranks;
         ic->shm->ready.store(1, std::memory_order_release);
-    } else {
-        const auto t0 = std::chrono::steady_clock::now();
-        while (ic->shm->ready.load(std::memory_order_acquire) != 1) {
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(HOSTCOMM_TIMEOUT_S))
-                return bail(HGMM_ERR_STATE, "rank 0 never initialised", name);
-            usleep(1000);
-        }
-        if (ic->shm->nranks != nranks) return bail(HGMM_ERR_ARG, "world size mismatch", "");
+    } else if (ic->shm->nranks != nranks) {
+        return bail(HGMM_ERR_ARG, "world size mismatch", "");
     }
     ic->shm->handle[rank] = mine;
     ic->shm->device[rank] = c->device;

@@ -165,7 +165,7 @@ def test_bench_two_rank_flow():
     # --collective auto: the same joint fit once more over the one-shot peer exchange, beside the RCCL headline
     px = d["peer_exchange"]
     assert "peer exchange" in px["collective"] and px["value"] > 0 and px["identical_model_on_all_ranks"] is True
-    assert px["model_bitwise_equal_to_the_rccl_fit"] is True
+    assert px["model_bitwise_equal_to_the_headline_fit"] is True
     assert "torch" not in open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                             "bench.py")).read().split('"""', 2)[2].replace("torch.distributed.run", "")
 
@@ -208,27 +208,29 @@ def test_self_launch_reports_a_failing_rank():
 
 def test_ranks_of_an_external_launcher_fall_back_in_place_when_rccl_is_unavailable():
     """Started by something that is not bench.py's own launcher (torchrun in the driver's N > 1 runs): no restart is
-    possible, every rank moves on to the next backend -- the one-shot peer exchange -- and the line is still produced."""
+    possible, every rank moves on to the next backend -- host shared memory, the one that needs nothing from the GPUs'
+    interconnect -- and the line is still produced; the peer exchange is timed beside it as the side leg."""
     r = _run_launcher(2, "plain", ["--skip", "RCCL_BROKEN"])
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0
-    assert "rccl" in d["config"]["fallback"] and "peer exchange" in d["config"]["collective"]
-    assert "peer_exchange" not in d                           # the headline already ran on it
+    assert "rccl" in d["config"]["fallback"] and "host shared memory" in d["config"]["collective"]
+    assert "peer exchange" in d["peer_exchange"]["collective"] and d["peer_exchange"]["value"] > 0
 
 
-def test_fallback_chain_ends_on_the_host_backend():
-    """Neither RCCL nor the peer exchange: host shared memory, under bench.py's own launcher as under an external one."""
+def test_fallback_chain_keeps_the_line_when_the_peer_exchange_is_unavailable_too():
+    """Neither RCCL nor the peer exchange: the headline runs on host shared memory and the side leg reports that the
+    exchange could not be set up -- under bench.py's own launcher as under an external one."""
     for mode in ("self", "plain"):
         r = _run_launcher(2, mode, ["--skip", "RCCL_AND_IPC_BROKEN"])
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
         assert len(lines) == 1, r.stdout
         d = json.loads(lines[0])
-        assert "rccl" in d["config"]["fallback"] and "ipc" in d["config"]["fallback"]
-        assert "host shared memory" in d["config"]["collective"]
+        assert "rccl" in d["config"]["fallback"] and "host shared memory" in d["config"]["collective"]
+        assert "error" in d["peer_exchange"]
 
 
 def test_explicit_collective_is_used_alone():
@@ -246,7 +248,7 @@ def test_partial_rccl_failure_is_agreed_on_collectively():
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert "fallback" in d["config"] and "peer exchange" in d["config"]["collective"]
+    assert "fallback" in d["config"] and "host shared memory" in d["config"]["collective"]
     assert d["rank_consistency"]["identical_model_on_all_ranks"] is True
 
 
@@ -260,7 +262,7 @@ def test_a_hanging_backend_setup_times_out_and_falls_back():
         os.environ.pop("HGMM_BENCH_ATTACH_TIMEOUT", None)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][0])
-    assert "rccl" in d["config"]["fallback"] and "peer exchange" in d["config"]["collective"]
+    assert "rccl" in d["config"]["fallback"] and "host shared memory" in d["config"]["collective"]
 
 
 def test_pairs_mode_two_ranks_without_a_communicator():

@@ -165,8 +165,8 @@ def test_train_small(ctx, variant, cov_type):
 def test_fit_far_from_the_origin(ctx, cov_type):
     """A cloud in sensor coordinates: 60 m from the origin, 40 m across, clusters of a few decimetres (J = 100, which
     takes the packed fused kernel).  The fused kernel forms its quadratic forms from x - mu (nothing is lost to the
-    offset) and sums its first moments about the cloud's first point (their rounding error is relative to the cloud's
-    extent, 2^-24 x 40 m per addition).  The fitted means stay within 1e-4 m of the float64 oracle's -- 13 ulp of a
+    offset) and sums its first moments about the weighted mean of the component means (their rounding error is relative
+    to the model's extent, 2^-24 x 40 m per addition).  The fitted means stay within 1e-4 m of the float64 oracle's -- 13 ulp of a
     float32 coordinate at 100 m; the parameters travel between iterations as float32 like the reference's, and that, not
     the moment sums, sets the figure: the kernel that summed first moments about each component's own mean (round 3)
     differs from the oracle by the same 4.2e-5 m in the same elements -- and the log-likelihood trace within 5e-5."""
@@ -187,6 +187,31 @@ def test_fit_far_from_the_origin(ctx, cov_type):
           % (cov_type, np.abs(mu - o_mu).max(), np.abs(w - o_w).max(), np.abs(cov / o_cov - 1).max(), np.abs(lls - o_lls).max()))
     np.testing.assert_allclose(w, o_w, rtol=2e-5, atol=1e-7)
     np.testing.assert_allclose(cov, o_cov, rtol=1e-3, atol=1e-8)
+
+
+def test_fit_with_a_stray_component_far_outside_the_model(ctx):
+    """the fused kernel's common origin for the first moments is the WEIGHTED mean of the component means.
+    One component of the initial model sits 1e5 cloud extents away with a negligible weight (what a dead component at
+    the coordinate origin is to a cloud in map coordinates): an unweighted mean of the means would put the origin
+    40 km outside the cloud and cost every live component ~2^-24 x 40 km = 2.4 mm per addition; the fit must stay as
+    close to the float64 oracle as the same fit without the stray component does (1e-4 m)."""
+    rs = np.random.RandomState(12)
+    J, N = 100, 60000
+    centres = rs.rand(J - 1, 3) * np.array([40.0, 40.0, 4.0]) + np.array([60.0, -35.0, 1.0])
+    X = (centres[rs.randint(J - 1, size=N)] + rs.randn(N, 3) * np.array([0.3, 0.3, 0.1])).astype(np.float32)
+    mu0 = np.concatenate([X[rs.choice(N, J - 1, replace=False)], np.float32([[4.0e6, -4.0e6, 4.0e5]])]).astype(np.float32)
+    w0 = np.concatenate([np.ones(J - 1) / (J - 1) * (1 - 1e-12), [1e-12]]).astype(np.float32)
+    cov0 = np.full((J, 3), 1.0, np.float32)
+    ctx.set_points(X)
+    f64 = lambda a: np.asarray(a, dtype=np.float64)
+    inv, mu, w, cov, lls, conv = ctx.flat_train(6, 0.0, mu0, cov0, w0, "diag", "W")
+    o_inv, o_mu, o_w, o_cov, o_lls, _ = flat_em.train(f64(X), 6, 0.0, f64(mu0), f64(cov0), f64(w0), "diag", "W")
+    live = slice(0, J - 1)
+    print("stray component: max |mu - oracle| over the live components %.3g m, max |lls - oracle| %.3g"
+          % (np.abs(mu[live] - o_mu[live]).max(), np.abs(lls - o_lls).max()))
+    np.testing.assert_allclose(lls, o_lls, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(mu[live], o_mu[live], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(w[live], o_w[live], rtol=2e-5, atol=1e-7)
 
 
 def test_train_early_stop(ctx):
