@@ -91,6 +91,7 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_flat_predict", [ctx, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp])
         _sig(lib, "hgmm_flat_log_prob", [ctx, C.c_int, C.c_int, _vp, _vp, _vp])
         _sig(lib, "hgmm_pace_info", [ctx, _f64p, C.POINTER(C.c_int), C.POINTER(C.c_int)])
+        _sig(lib, "hgmm_pace_reset", [ctx])
         _sig(lib, "hgmm_flat_mstep", [ctx, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp])
         _sig(lib, "hgmm_flat_train", [ctx, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _vp, _vp, _vp,
                                       _vp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)])
@@ -772,6 +773,10 @@ class Context:
         t, n, u = C.c_double(), C.c_int(), C.c_int()
         self._check(self.lib.hgmm_pace_info(self.h, C.byref(t), C.byref(n), C.byref(u)))
         return t.value, n.value, u.value
+
+    def pace_reset(self):
+        """Forget the store pacer's learnt rate and ceiling (hgmm_pace_reset)."""
+        self._check(self.lib.hgmm_pace_reset(self.h))
 
     def flat_predict(self, inv_std, mu, w, cov_type="diag", variant="W"):
         if any(isinstance(a, DeviceArray) for a in (inv_std, mu, w)):

@@ -1901,6 +1901,10 @@ constexpr double PACE_MIN_BYTES = 256.0 * 1024 * 1024;
 // ... and upwards, carefully: the knee sat at 7.0 TB/s on one box and at 7.6 on another (profiles/r04/paced_fill_lease*.log).
 // After PACE_PROBE_AFTER clean launches in a row the rate is raised by 2 % on probation: three clean launches keep it, the
 // first long one takes it back, remembers the rate as a ceiling and doubles the wait before the next probe.
+// ... and a ceiling is a statement about the memory system's state WHEN it was learnt (another stream writing at the same
+// time, a hot chip), not for life: after PACE_FORGET_AFTER clean launches below it (HGMM_PACE_FORGET=<n>) it is forgotten and
+// the probes start over with their first waiting time.  hgmm_pace_reset() forgets everything at once.
+constexpr int PACE_FORGET_AFTER = 10000;
 constexpr int PACE_PROBE_AFTER = 24, PACE_PROBE_AFTER_MAX = 4096;
 constexpr double PACE_PROBE_STEP = 1.02;
 constexpr double PACE_CEILING_GBS = 7600.0;
@@ -1916,6 +1920,7 @@ static double pace_target(hgmm_ctx* c, int J) {
         p.probe_after = PACE_PROBE_AFTER;
         p.probe_base = 0.0;
         p.ceiling = 1e30;
+        p.since_ceiling = 0;
         p.J = J;
     }
     return p.target;
@@ -1948,6 +1953,7 @@ static void pace_poll(hgmm_ctx* c) {
                 // a probe is running: ONE long launch ends it (the memory system has said no), three clean ones accept it
                 if (slow) {
                     p.ceiling = p.target;
+                    p.since_ceiling = 0;
                     p.target = p.probe_base;
                     p.probe_base = 0.0;
                     p.probe_after = std::min(PACE_PROBE_AFTER_MAX, 2 * p.probe_after);
@@ -1962,12 +1968,19 @@ static void pace_poll(hgmm_ctx* c) {
                 p.clean = 0;
                 if (++p.strikes >= 3) {
                     p.ceiling = std::min(p.ceiling, p.target);
+                    p.since_ceiling = 0;
                     p.target = std::max(PACE_FLOOR_GBS, p.target * PACE_STEP);
                     p.strikes = 0;
                     p.steps_down++;
                 }
             } else {
                 p.strikes = 0;
+                if (p.ceiling < 1e29 && ++p.since_ceiling >= env_int("HGMM_PACE_FORGET", PACE_FORGET_AFTER)) {
+                    p.ceiling = 1e30;                       // what congested then need not congest now: probe afresh
+                    p.since_ceiling = 0;
+                    p.probe_after = PACE_PROBE_AFTER;
+                    p.ceilings_forgotten++;
+                }
                 const double up = p.target * PACE_PROBE_STEP;
                 if (probing_allowed && ++p.clean >= p.probe_after && up < p.ceiling * 0.995 && up <= PACE_CEILING_GBS) {
                     p.probe_base = p.target;
@@ -2530,6 +2543,15 @@ extern "C" int hgmm_flat_estep_dev(hgmm_ctx* c, int cov_type, int variant, int J
         flat_mean_lpn_kernel<<<1, 256, 0, c->stream>>>(c->f_lpn_partials.as<double>(), grid, (double)c->n, dev_mean_lpn);
         HGMM_HIP(c, hipGetLastError());
     }
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_pace_reset(hgmm_ctx* c) {
+    HGMM_ENTER(c);
+    PaceCtl& p = c->pace;
+    p.target = 0.0;                                        // the next paced launch starts over (pace_target)
+    p.steps_down = p.steps_up = p.ceilings_forgotten = 0;
+    p.tail = p.head;                                       // launches still in flight are not judged any more
     return HGMM_OK;
 }
 

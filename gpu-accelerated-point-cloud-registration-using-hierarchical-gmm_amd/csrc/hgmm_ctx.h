@@ -52,7 +52,9 @@ struct PaceCtl {
     int steps_up = 0;                  // probes upwards that held
     // probing upwards: after `probe_after` clean launches in a row the next ones are offered 2 % more; three clean ones
     // make that the new target, a single long one ends the probe, caps the rate below it and doubles `probe_after`
-    double ceiling = 1e30;             // a rate that was seen to congest: never probed again
+    double ceiling = 1e30;             // a rate that was seen to congest: not probed again until it is forgotten
+    int since_ceiling = 0;             // clean launches since the ceiling was learnt (forgotten after PACE_FORGET_AFTER)
+    int ceilings_forgotten = 0;
     double probe_base = 0.0;           // > 0: a probe is running, this is the rate to fall back to
     int clean = 0, probe_after = 0, probe_seen = 0;
     hipEvent_t ev[RING][2] = {};

@@ -169,6 +169,11 @@ int hgmm_flat_predict_dev(hgmm_ctx* ctx, int cov_type, int variant, int J,
  * after a run of clean launches it is raised by 2 % on probation (one long launch takes that back and caps the rate).
  * Measurement aid, no reference counterpart. */
 int hgmm_pace_info(hgmm_ctx* ctx, double* target_gbs_out, int* steps_down_out, int* steps_up_out);
+/* Forget what the controller has learnt (rate, ceiling, counters): the next paced launch starts at the initial rate again.
+ * A rate that congested once is remembered as a ceiling -- rightly while its cause lasts (another stream writing, a hot
+ * chip), wrongly for ever: the controller forgets a ceiling by itself after 10 000 clean launches below it
+ * (HGMM_PACE_FORGET=<n>); a caller that knows the cause is gone says so here.  Measurement aid, no reference counterpart. */
+int hgmm_pace_reset(hgmm_ctx* ctx);
 /* Un-normalised per-pair log-densities log N(x_i; mu_j, diag) -> dev_log_prob [N,J]
  * (estimate_log_prob / estimate_log_prob_spherical, gmm_waymo gmm_impl.py:53-78). */
 int hgmm_flat_log_prob(hgmm_ctx* ctx, int cov_type, int J, const float* mu, const float* inv_std,

@@ -554,6 +554,73 @@ def test_store_pacer_controller_backs_off(monkeypatch):
         c.close()
 
 
+def test_store_pacer_recovers_after_a_congested_phase(monkeypatch):
+    """What the controller learns under congestion must not bind it for life.  Phase 1: a second context on
+    the same GPU streams pure stores (util_fill) from its own thread while this one runs materialising E-steps -- their
+    launches run long, the rate steps down and the failed rate is remembered as a ceiling.  Phase 2: the other stream
+    stops; the ceiling is forgotten after HGMM_PACE_FORGET clean launches (40 here, 10 000 by default) and probes on
+    probation bring the rate back to where it started (within one 2 % step) or beyond.  Phase 3: the same congestion
+    again, then hgmm_pace_reset(): rate, ceiling and counters are back at their initial values at once.  The table is the
+    same whatever the rate."""
+    import threading
+    import hgmm_amd
+    N, J = 1_000_000, 800
+    X = np.random.RandomState(0).rand(N, 3).astype(np.float32)
+    idx = np.random.RandomState(100).choice(N, J, replace=False)
+    mu, w = X[idx].copy(), (np.ones(J) / J).astype(np.float32)
+    inv = (1 / np.sqrt(0.01 * np.ones((J, 3)))).astype(np.float32)
+    rows = np.arange(0, N, 20011)
+    monkeypatch.setenv("HGMM_PACE_FORGET", "40")
+    c, other = hgmm_amd.Context(0), hgmm_amd.Context(0)
+    try:
+        c.set_points(X)
+        lr = c.empty((N, J), np.float32)
+        hog_buf = other.empty((N, J), np.float32)
+        for _ in range(6):
+            c.flat_estep(inv, mu, w, out=lr)
+        ref = lr.get()[rows].copy()
+        start, down0, _ = c.pace_info()
+        assert down0 == 0
+
+        def congested(launches):
+            stop = threading.Event()
+
+            def hog():
+                while not stop.is_set():
+                    for _ in range(4):
+                        other.util_fill(hog_buf, 1.0, True, 0, 1)
+                    other.synchronize()
+            t = threading.Thread(target=hog)
+            t.start()
+            try:
+                for _ in range(launches):
+                    c.flat_estep(inv, mu, w, out=lr)
+            finally:
+                stop.set()
+                t.join(60)
+            return c.pace_info()
+
+        t1, d1, u1 = congested(60)
+        print("store pacer under a competing store stream: %.0f -> %.0f GB/s, %d steps down" % (start, t1, d1))
+        assert d1 >= 1 and t1 < start
+        for _ in range(400):
+            c.flat_estep(inv, mu, w, out=lr)
+        t2, d2, u2 = c.pace_info()
+        print("... and after 400 quiet launches: %.0f GB/s (%d probes held, %d steps down in all)" % (t2, u2, d2))
+        assert u2 >= 1 and t2 >= 0.979 * start
+        assert np.array_equal(lr.get()[rows], ref)
+        t3, d3, _ = congested(40)
+        assert t3 < t2
+        c.pace_reset()
+        assert c.pace_info() == (start, 0, 0)
+        c.flat_estep(inv, mu, w, out=lr)
+        assert c.pace_info()[0] == start and np.array_equal(lr.get()[rows], ref)
+        del lr, hog_buf
+    finally:
+        other.close()
+        c.close()
+
+
 def test_profiler_reports_kernel_time(ctx):
     X = np.random.RandomState(1).rand(20000, 3).astype(np.float32)
     ctx.set_points(X)
