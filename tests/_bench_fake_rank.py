@@ -39,6 +39,8 @@ bench.N_POINTS = 2000
 bench.synth_frame = lambda seed, n=None: np.random.RandomState(seed).rand(2000, 3).astype(np.float32)
 if "pairs" in sys.argv:                                        # --mode pairs: the registration itself needs the engine
     class _Tf:
+        rot, t = np.eye(3), np.zeros(3)
+
         def transform(self, x):
             return x
 
