@@ -1157,8 +1157,17 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
 //     below eps * 2^-30 / n_nodes cannot move a point's logarithm by 1e-9 -- nodes whose UPPER bound over the
 //     workgroup's box, log w - kappa dist(box, mu)^2, is below that never enter the tile, and a wave skips the
 //     exponentials of a node whose exponents are all below it: float32's exponent range (2^-126) is never approached.
-//   Accuracy of q against the float64 kernel: ~1e-7 relative per term, |dq| <~ 1e-7 N in the worst (fully correlated)
-//   case -- three orders of magnitude below the levels' stop thresholds (ls = 20 ... 80 for N = 40 k ... 1 M).  The
+//   * Conditioning: z = R x - R m in float32 carries 2^-23 of |R| x (extent of the workgroup about its origin), so a
+//     term's error grows with extent / sigma -- a few units while a workgroup's points are neighbours (the usual case),
+//     ~1000 when a parent holds tight, far-apart clusters.  The errors have random sign and q sums 10^5 ... 10^6 terms:
+//     MEASURED on 16 clusters of sigma = 5e-4 scattered over a unit cube (tests/test_tree_gpu.py::
+//     test_float32_pdf_mode_on_tight_far_apart_clusters) |dq| / |q| = 3e-8, |dq| = 0.09 against ls = 20.  A guarded
+//     variant (nodes beyond |R| x extent = 64 evaluated from head + tail differences, errors relative to |x - mu|) was
+//     built and measured: 8e-9 there, but 114 instead of 96 VGPRs and a 20 KB tile made the 10^6-point build 2.97 instead
+//     of 2.41 ms -- removed again (profiles/r05/tree_f32_probe.log keeps both figures).
+//   Accuracy of q against the float64 kernel, measured: |dq| / |q| = 1-3e-7 on the uniform million (|dq| 0.03), on two
+//   clustered clouds built to convergence and on the ill-conditioned case above -- two to three orders of magnitude below
+//   the levels' stop thresholds (ls = 20 ... 80 for N = 40 k ... 1 M).  The
 //   E-step and the moments do NOT go through this kernel: as long as a level stops after the same number of iterations
 //   the tree is the float64 tree bit for bit.
 // ------------------------------------------------------------------------------------------

@@ -704,3 +704,28 @@ def test_mirror_returns_the_type_it_is_handed(ctx, bunny):
         assert g.dtype == np.float32 and r.dtype == np.float64 and f.dtype == np.float64
         assert np.array_equal(g, r.astype(np.float32)) and np.array_equal(f, r)
     assert ctx.tree_dtype == np.float64                          # the context's precision is put back
+
+
+def test_float32_pdf_mode_on_tight_far_apart_clusters(ctx):
+    """The ill-conditioned case of the float32 log-likelihood: 16 clusters of sigma = 5e-4 scattered over a unit cube, so
+    that a level-0 node -- and with it a level-1 workgroup -- holds clusters that are ~1000 sigma apart and z = R x - R m
+    carries 2^-23 x 1000 per term.  The errors have random sign and q sums 450 000 of them: the float64 build's iteration
+    counts, its tree bit for bit, and q to 3e-8 (|dq| 0.09 against ls = 20)."""
+    n = 450_000
+    P = _blobs(n, seed=5, k=16, spread=5e-4)
+    L = 2
+    T = hgmm_tree.n_total(L)
+    idx = np.random.RandomState(9).randint(n, size=T)
+    args = (P, L, 20.0, 1e-4, idx, 0.004)
+    ref = build(ctx, *args, max_iters=200)
+    ctx.tree_set_precision(np.float32)
+    try:
+        got = build(ctx, *args, max_iters=200)
+    finally:
+        ctx.tree_set_precision(np.float64)
+    assert list(got[4]) == list(ref[4]), (got[4], ref[4])
+    rel = np.abs(got[5] / ref[5] - 1.0).max()
+    print("tight clusters: iterations %s; max relative dq %.3g (|dq| %.3g)" % (list(ref[4]), rel, np.abs(got[5] - ref[5]).max()))
+    assert rel < 1e-6
+    for a, b in zip(got[:4], ref[:4]):
+        assert np.array_equal(a, b)
