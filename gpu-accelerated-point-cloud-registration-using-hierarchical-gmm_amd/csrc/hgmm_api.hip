@@ -78,6 +78,7 @@ int profile_collect(hgmm_ctx* c) {
 struct HostCommShm {
     std::atomic<int> ready;
     std::atomic<int> owner_pid;
+    unsigned long long owner_pidns, created_s;      // (ShmHeader)
     std::atomic<int> count;
     std::atomic<int> generation;
     int nranks;
@@ -152,7 +153,19 @@ static int hostcomm_allreduce_dev(hgmm_ctx* c, double* dev, size_t n, int op) {
 // barrier's timeout.  So the header carries the creator's pid: a joining rank accepts an object only once it is ready
 // AND its creator is alive, and otherwise lets go of it and opens the name again (rank 0's fresh object is zero-filled:
 // not ready until rank 0 has initialised it).  The owner clears `ready` before it unlinks.
-struct ShmHeader { std::atomic<int> ready; std::atomic<int> owner_pid; };
+// (A pid only means something inside its PID namespace: ranks started in separate containers that share /dev/shm see each
+//  other's objects but not each other's pids.  The header therefore also carries the creator's namespace and the time of
+//  creation: a joiner from ANOTHER namespace cannot ask whether the creator lives and accepts an object younger than
+//  SHM_FOREIGN_MAX_AGE_S instead.)
+struct ShmHeader { std::atomic<int> ready; std::atomic<int> owner_pid; unsigned long long owner_pidns, created_s; };
+constexpr unsigned long long SHM_FOREIGN_MAX_AGE_S = 600;
+static unsigned long long my_pidns() {
+    struct stat st;
+    return stat("/proc/self/ns/pid", &st) == 0 ? (unsigned long long)st.st_ino : 0ull;
+}
+static unsigned long long now_s() {
+    return (unsigned long long)std::chrono::duration_cast<std::chrono::seconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+}
 static void* shm_attach(const std::string& name, size_t bytes, bool owner, int timeout_s) {
     if (owner) {
         shm_unlink(name.c_str());
@@ -162,7 +175,10 @@ static void* shm_attach(const std::string& name, size_t bytes, bool owner, int t
         void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
         close(fd);
         if (p == MAP_FAILED) { shm_unlink(name.c_str()); return nullptr; }
-        static_cast<ShmHeader*>(p)->owner_pid.store((int)getpid(), std::memory_order_relaxed);
+        ShmHeader* h = static_cast<ShmHeader*>(p);
+        h->owner_pid.store((int)getpid(), std::memory_order_relaxed);
+        h->owner_pidns = my_pidns();
+        h->created_s = now_s();
         return p;                                           // (the caller fills its fields in, then stores ready = 1)
     }
     const auto t0 = std::chrono::steady_clock::now();
@@ -179,7 +195,10 @@ static void* shm_attach(const std::string& name, size_t bytes, bool owner, int t
                 // a fresh object becomes ready within microseconds of its creation: give it a moment before re-opening
                 for (int spin = 0; spin < 200 && h->ready.load(std::memory_order_acquire) != 1; ++spin) usleep(100);
                 const int pid = h->owner_pid.load(std::memory_order_relaxed);
-                const bool alive = pid > 0 && (kill((pid_t)pid, 0) == 0 || errno == EPERM);
+                const unsigned long long ns = my_pidns();
+                const bool same_ns = ns != 0 && ns == h->owner_pidns;
+                const bool alive = same_ns ? (pid > 0 && (kill((pid_t)pid, 0) == 0 || errno == EPERM))
+                                           : (now_s() - h->created_s <= SHM_FOREIGN_MAX_AGE_S);
                 if (h->ready.load(std::memory_order_acquire) == 1 && alive) return p;
                 munmap(p, bytes);                           // an orphan, or not initialised yet: look at the name again
             }
@@ -222,6 +241,7 @@ constexpr double IPC_TIMEOUT_S = 20.0;
 struct IpcShm {
     std::atomic<int> ready;
     std::atomic<int> owner_pid;
+    unsigned long long owner_pidns, created_s;      // (ShmHeader)
     std::atomic<int> count;
     std::atomic<int> generation;
     std::atomic<int> failed;                     // some rank could not map a peer: nobody keeps the communicator

@@ -441,3 +441,56 @@ def _ranks_match_single_context(rccl_port, backend="host", world=2):
         for rank in range(1, world):
             for a, b_ in zip(got[0][key][:3], got[rank][key][:3]):
                 assert np.array_equal(a, b_)
+
+
+# ---- a stale shared-memory object of a crashed run must not be joined ---------------------------------------
+def _stale_name_worker(rank, name, q, backend, delay):
+    try:
+        import time
+        import hgmm_amd
+        time.sleep(delay)
+        ctx = hgmm_amd.Context(0)
+        (ctx.comm_init_ipc if backend == "ipc" else ctx.comm_init_host)(2, rank, name)
+        out = ctx.allreduce(np.arange(1000.0) * (rank + 1))
+        ctx.comm_destroy()
+        ctx.close()
+        q.put((rank, out))
+    except BaseException as e:
+        q.put((rank, "rank %d failed: %r" % (rank, e)))
+        raise
+
+
+@pytest.mark.parametrize("backend", ["host", "ipc"])
+def test_an_orphaned_shared_memory_object_is_not_joined(backend):
+    """A run that crashed left /dev/shm/<name> behind, marked ready.  Rank 1 of the next run with the same name arrives
+    BEFORE rank 0 has replaced the object: it must recognise the orphan (its creator's pid is dead), wait for rank 0's
+    fresh object and join that one -- not publish into the orphan and sit out the barrier's timeout."""
+    import struct
+    import subprocess
+    import sys
+    import time
+    name = "hgmm_stale_%s_%d" % (backend, os.getpid())
+    dead = subprocess.Popen([sys.executable, "-c", "pass"])
+    dead.wait()
+    pidns = os.stat("/proc/self/ns/pid").st_ino
+    path = "/dev/shm/" + name
+    with open(path, "wb") as f:                               # {ready = 1, owner_pid = a dead one, its namespace, created now}
+        f.write(struct.pack("<iiQQ", 1, dead.pid, pidns, int(time.time())))
+        f.truncate(64 << 20)
+    try:
+        mpc = mp.get_context("spawn")
+        q = mpc.Queue()
+        procs = [mpc.Process(target=_stale_name_worker, args=(r, name, q, backend, 1.5 if r == 0 else 0.0)) for r in range(2)]
+        t0 = time.time()
+        for p in procs:
+            p.start()
+        got = dict(q.get(timeout=120) for _ in procs)
+        for p in procs:
+            p.join(60)
+        assert not any(isinstance(v, str) for v in got.values()), got
+        assert time.time() - t0 < 40                          # (the barrier's timeout is 60 s: nobody waited it out)
+        for r in (0, 1):
+            assert np.array_equal(got[r], np.arange(1000.0) * 3)
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
