@@ -753,6 +753,26 @@ def published_charts_leg(ctx):
     return out
 
 
+def replica_pairs_leg(ctx):
+    """The replica mode (`bench.py --mode pairs`, hgmm_amd.replicas) as a side leg of the default line: independent scan
+    pairs, four contexts on this GPU, no communicator -- run as a process of its own (it creates its own contexts and
+    threads), one second of timed blocks."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "pairs", "--steps", "25", "--warmup", "3", "--min-time", "1.0",
+           "--no-cpu-baseline"]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    env["LOCAL_RANK"] = str(getattr(ctx, "device_id", 0))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "rc %d: %s" % (r.returncode, r.stderr[-400:])}
+    d = json.loads(lines[-1])
+    return {"workload": d["config"]["workload"], "pairs_per_s": d["value"], "contexts_per_gpu": d["config"]["contexts_per_gpu"],
+            "ms_per_step": d["ms_per_step"], "registration_iterations_per_pair": d["registration_iterations_per_pair"],
+            "accuracy": d["accuracy"], "kernels_ms_per_pair": d.get("kernels_ms_per_pair"), "blocks": d["timing"]["blocks"]}
+
+
 def fused_roofline(avg_launch_s, cus):
     """VALU accounting of flat_fused_pk_kernel<13> from the code object (tools/isa_count.py)."""
     out = {"kernel": "flat_fused_pk_kernel<13> (constant-shift loop)", "bound": "valu", "unit": "TFLOP/s",
@@ -939,7 +959,7 @@ def collective_world1_leg(ctx, args, init, base_it_per_s):
     return out
 
 
-LEG_KEYS = ("bunny", "hgmm", "tree_1M", "fullcov", "kmeans_init", "registration", "published_charts",
+LEG_KEYS = ("bunny", "hgmm", "tree_1M", "fullcov", "kmeans_init", "registration", "published_charts", "replica_pairs",
             "materialised_iteration", "predict", "estimate_log_prob", "collective_world1")
 
 
@@ -979,6 +999,7 @@ def split_legs(out, args):
         "predict_ms": _pick(legs, "predict", "kernel_ms"), "mstep_frac": _pick(legs, "materialised_iteration", "roofline", "frac"),
         "kmeans_k800_1M_ms": [_pick(legs, "kmeans_init", "fit_ms_warm"), _pick(legs, "kmeans_init", "seeding_ms_warm")],
         "registration_ms": _pick(legs, "registration", "total_ms"),
+        "replica_pairs_per_s_4ctx": _pick(legs, "replica_pairs", "pairs_per_s"),
         "allreduce_us_world1_rccl_ipc": [_pick(legs, "collective_world1", "rccl", "allreduce_us"),
                                          _pick(legs, "collective_world1", "ipc", "allreduce_us")],
         "chart_fit_100comp_s": {str(r["points"]): round(r["flat_100_components_30_iterations_s"], 4)
@@ -1208,7 +1229,7 @@ def rank_main(args):
         lr.free()
         for name, leg in (("bunny", bunny_leg), ("hgmm", hgmm_leg), ("tree_1M", tree_1m_leg), ("fullcov", fullcov_leg),
                           ("kmeans_init", kmeans_leg), ("registration", registration_leg),
-                          ("published_charts", published_charts_leg)):
+                          ("published_charts", published_charts_leg), ("replica_pairs", replica_pairs_leg)):
             if name in args.skip:
                 continue
             try:

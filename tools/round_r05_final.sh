@@ -17,9 +17,9 @@ for N in 2 8; do
   HGMM_BENCH_DEVICE=0 HGMM_BENCH_LEGS_FILE=$O/bench_legs_n${N}_rehearsal.json timeout 400 python bench.py --gpus $N --collective ipc --steps 20 --warmup 5 > $O/bench_n${N}_rehearsal_one_gpu_peer_exchange.json 2> $O/bench_n${N}_ipc.err; echo "rehearsal ipc N=$N rc $?"
 done
 HGMM_BENCH_DEVICE=0 HGMM_BENCH_LEGS_FILE=$O/bench_legs_n2_rehearsal_host.json timeout 400 python bench.py --gpus 2 --collective host --steps 20 --warmup 5 > $O/bench_n2_rehearsal_one_gpu_host.json 2> $O/bench_n2_host.err; echo "rehearsal host N=2 rc $?"
-timeout 700 rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python bench.py --skip published_charts > $O/bench_n1_under_rocprofv3.json 2> $O/bench_rocprof.err; echo "rocprof bench rc $?"
+timeout 700 rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python bench.py --skip published_charts,replica_pairs > $O/bench_n1_under_rocprofv3.json 2> $O/bench_rocprof.err; echo "rocprof bench rc $?"
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --pmc $C -d $O/pmc_$C -o pmc --output-format csv -- python bench.py --steps 4 --warmup 1 --estep-reps 3 --no-cpu-baseline --skip bunny,hgmm,tree_1M,fullcov,kmeans_init,registration,collective,published_charts > $O/pmc_$C.stdout 2> $O/pmc_$C.stderr; echo "pmc $C rc $?"
+  timeout 400 rocprofv3 --pmc $C -d $O/pmc_$C -o pmc --output-format csv -- python bench.py --steps 4 --warmup 1 --estep-reps 3 --no-cpu-baseline --skip bunny,hgmm,tree_1M,fullcov,kmeans_init,registration,collective,published_charts,replica_pairs > $O/pmc_$C.stdout 2> $O/pmc_$C.stderr; echo "pmc $C rc $?"
 done
 python tools/pmc_summary.py $O > /dev/null
 KT=$(find $O/kt -name "*kernel_trace.csv" | head -1); [ -n "$KT" ] && python tools/estep_patterns.py $KT > $O/rocprofv3_estep_by_grid.txt 2>&1
