@@ -271,3 +271,24 @@ def test_fit_frames_over_a_replica_pool_and_module_level_api_in_threads(bunny):
             np.testing.assert_allclose(np.asarray(g[4]), np.asarray(r[4]), rtol=0, atol=2e-6)
         models = fit_frames(frames, n_components=40, max_iter=5, pool=pool)
         assert len(models) == 5 and all(m.means_.shape == (40, 3) and np.isfinite(m.lls).all() for m in models)
+
+
+def test_register_pairs_gmmreg_over_a_replica_pool():
+    """method="gmmreg": registration_gmmreg (gmmreg_gpu/gmmreg.py:149-157) per pair -- the mixtures' KMeans initialiser
+    and EM fit, the Gauss transforms behind every BFGS cost evaluation: all of it on the WORKER's context (thread-local
+    default context), several pairs in flight; the same transformations as the serial calls."""
+    from conftest import load_golden
+    from hgmm_amd.gmmreg_gpu.gmmreg import registration_gmmreg
+    from hgmm_amd.replicas import register_pairs
+    g = load_golden("gmmreg_l2.npz")
+    src, tgt = g["reg_source"], g["reg_target"]
+    th = np.deg2rad(4.0)
+    rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    pairs = [(src, tgt), (src, tgt @ rz.T + 0.01), (src @ rz.T, tgt), (src, tgt)]
+    serial = [registration_gmmreg(s, t, n_gmm_components=30) for s, t in pairs]
+    got = register_pairs(pairs, devices=[0], contexts_per_device=2, method="gmmreg", n_gmm_components=30)
+    assert len(got) == len(pairs)
+    for a, b in zip(got, serial):
+        np.testing.assert_allclose(a.rot, b.rot, rtol=0, atol=1e-7)
+        np.testing.assert_allclose(a.t, b.t, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(got[0].rot, g["reg_rot"], atol=5e-3)
