@@ -1165,9 +1165,10 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
 //     variant (nodes beyond |R| x extent = 64 evaluated from head + tail differences, errors relative to |x - mu|) was
 //     built and measured: 8e-9 there, but 114 instead of 96 VGPRs and a 20 KB tile made the 10^6-point build 2.97 instead
 //     of 2.41 ms -- removed again (profiles/r05/tree_f32_probe.log keeps both figures).
-//   Accuracy of q against the float64 kernel, measured: |dq| / |q| = 1-3e-7 on the uniform million (|dq| 0.03), on two
-//   clustered clouds built to convergence and on the ill-conditioned case above -- two to three orders of magnitude below
-//   the levels' stop thresholds (ls = 20 ... 80 for N = 40 k ... 1 M).  The
+//   Accuracy of q against the float64 kernel, measured: |dq| = 0.02 ... 0.04 = 3-5e-8 per point on every cloud tried
+//   (the uniform million, clustered clouds of 0.4 - 0.9 M points built to convergence at L = 1 ... 3, seeded random
+//   shapes, the ill-conditioned case above; tests/test_tree_gpu.py) -- under 1 % of the smallest stop threshold in use
+//   (ls = 5) and 0.03 % of the bench's (ls = 80).  The
 //   E-step and the moments do NOT go through this kernel: as long as a level stops after the same number of iterations
 //   the tree is the float64 tree bit for bit.
 // ------------------------------------------------------------------------------------------

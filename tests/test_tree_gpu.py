@@ -729,3 +729,34 @@ def test_float32_pdf_mode_on_tight_far_apart_clusters(ctx):
     assert rel < 1e-6
     for a, b in zip(got[:4], ref[:4]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_float32_pdf_mode_random_large_clouds(ctx, seed):
+    """Seeded random shapes above the 400 000-point threshold: cloud size (ragged: not a multiple of the kernel's 1024
+    points per workgroup), number and tightness of the clusters, tree depth, stop threshold.  Float32 pdfs must stop every
+    level where float64 does and leave the float64 tree bit for bit."""
+    rs = np.random.RandomState(1000 + seed)
+    n = int(rs.randint(400_001, 900_000))
+    k = int(rs.choice([3, 9, 25, 80]))
+    spread = float(rs.choice([0.002, 0.01, 0.05]))
+    L = int(rs.choice([1, 2, 3]))
+    ls = float(rs.choice([5.0, 20.0, 80.0]))
+    P = _blobs(n, seed=seed, k=k, spread=spread)
+    T = hgmm_tree.n_total(L)
+    idx = rs.randint(n, size=T)
+    args = (P, L, ls, 1e-4, idx, float(rs.choice([0.0005, 0.004, 0.02])))
+    ref = build(ctx, *args, max_iters=150)
+    ctx.tree_set_precision(np.float32)
+    try:
+        got = build(ctx, *args, max_iters=150)
+    finally:
+        ctx.tree_set_precision(np.float64)
+    assert list(got[4]) == list(ref[4]), (got[4], ref[4])
+    # (q runs through zero while a tree forms: judged in absolute terms -- per point, and against the stop threshold)
+    dq = np.abs(got[5] - ref[5]).max()
+    print("seed %d: n = %d, %d clusters of spread %g, L = %d, ls = %g: iterations %s, max |dq| %.3g = %.2g per point = %.2g of ls"
+          % (seed, n, k, spread, L, ls, list(ref[4]), dq, dq / n, dq / ls))
+    assert dq < 2e-7 * n and dq < 0.02 * ls
+    for a, b in zip(got[:4], ref[:4]):
+        assert np.array_equal(a, b)
