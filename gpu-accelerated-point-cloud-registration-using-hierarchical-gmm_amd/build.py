@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhgmm_hip.so")
 SOURCES = ["hgmm_api.hip", "flat_kernels.hip", "tree_kernels.hip", "kmeans_kernels.hip", "gmmreg_kernels.hip"]
-HEADERS = ["hgmm_ctx.h", "wave_ops.h", os.path.join("..", "..", "include", "hgmm.h")]
+HEADERS = ["hgmm_ctx.h", "wave_ops.h", "tree_device.h", os.path.join("..", "..", "include", "hgmm.h")]
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

@@ -22,8 +22,7 @@
 //   tree_loglik_kernel    q = sum_i log max(sum_j pi_j N(x_i; j), eps) over ALL nodes of the
 //                         level, node table tiled through LDS, wave-uniform skip of far nodes.
 //   tree_reg_estep_kernel registration E-step: per target point descend the tree.
-#include "hgmm_ctx.h"
-#include "wave_ops.h"
+#include "tree_device.h"
 
 #include <algorithm>
 #include <type_traits>
@@ -34,333 +33,6 @@
 
 namespace hgmm {
 
-constexpr double TREE_EPS = 1.0e-15;                 // hgmm_cupy_cpu_working.py:29
-constexpr double TWO_PI_POW_1_5 = 15.749609945722419; // (2 pi)^(3/2)
-constexpr int PREP_N = 20;   // i00 i01 i02 i11 i12 i22 | mu0 mu1 mu2 | wE | wL | complexity | r00 r01 r02 r11 r12 r22 | kappa | kappa'
-// [12..17] R: upper-triangular factor of Sigma^-1 / 2 (R^T R = Sigma^-1 / 2), so that the exponent of the pdf is
-//          -(x-mu)^T Sigma^-1 (x-mu) / 2 = -|R (x - mu)|^2 : 9 fma/mul for a point given in coordinates where R mu is
-//          precomputed, against 14 for the symmetric form (tree_loglik_kernel, full_fused_kernel).
-// [18]     kappa = 1 / (2 lambda_max(Sigma)): the exponent is <= -kappa |x - mu|^2 for every x -- a whole node can be
-//          rejected for a whole box of points once kappa dist(box, mu)^2 passes the underflow threshold.
-// [19]     kappa' = lambda_max(Sigma^-1) / 2 (an upper bound of it): the exponent is >= -kappa' |x - mu|^2 for every x -- with
-//          the farthest corner of a box of points that is a LOWER bound of the node's pdf over the box (the relative
-//          reach test of tree_loglik_kernel); -1 where no bound is known.
-// A node whose Sigma^-1 is not numerically positive definite although det >= eps (cannot happen for a covariance
-// estimated from moments; a caller-supplied table may hold anything) raises bit 0 of the context's tree flags and the
-// consumers fall back to the symmetric form.
-constexpr int PREP_R = 12, PREP_KAPPA = 18, PREP_KAPPA2 = 19;
-constexpr int CH = 256;      // points per chunk = threads per workgroup
-constexpr int NMOM = 10;     // m0, m1[3], m2 unique[6] (xx xy xz yy yz zz)
-
-__host__ __device__ inline int64_t level_first(int l) {  // 8 (8^l - 1) / 7
-    int64_t p = 1;
-    for (int i = 0; i < l; ++i) p *= 8;
-    return 8 * (p - 1) / 7;
-}
-
-// d^T S d for a symmetric S given by its 6 unique entries, factored so that it costs 11 multiply /
-// fma instead of the 17 of the term-by-term form:
-//   d0 (s00 d0 + 2 (s01 d1 + s02 d2)) + d1 (s11 d1 + 2 s12 d2) + d2 (s22 d2)
-__device__ __forceinline__ double sym3_quad(double s00, double s01, double s02, double s11, double s12,
-                                            double s22, double d0, double d1, double d2) {
-    const double t0 = fma(2.0, fma(s02, d2, s01 * d1), s00 * d0);
-    const double t1 = fma(2.0, s12 * d2, s11 * d1);
-    return fma(d2, s22 * d2, fma(d1, t1, d0 * t0));
-}
-
-// exp(y) for y <= 0, branch-free, <= 1 ulp, four (or two) independent evaluations interleaved in one asm block so
-// that the dependent v_fma_f64 chain of one hides behind the others.
-//   n = round(y * 128 / ln 2)  (add / subtract 1.5 * 2^52: the integer sits in the low mantissa word),
-//   r = y - n ln2/128 in two pieces (|r| <= ln2/256 = 0.0027),   n = 128 m + j,
-//   exp(y) = 2^m * T[j] * e^r,  T[j] = 2^(j/128) from a 1 KB table in LDS (any 64 lanes hit distinct banks or the
-//   same word), e^r - 1 = r (1 + r (1/2 + r (1/6 + r (1/24 + r/120)))): degree 5 is enough at that range
-//   (r^6/720 < 6e-19), the result is formed as fma(T, e^r - 1, T) and 2^m goes into the exponent field.
-// 16 VALU instructions per value; the degree-13 polynomial on |r| <= ln2/2 that this replaces took 21.
-// Arguments below -708 are clamped (result < 3.3e-308, i.e. nothing).  A NaN argument is NOT propagated: fmin(NaN, 0)
-// is 0, the result is exp(0) = 1 -- a point with a NaN coordinate therefore contributes weight x 1 per node to the
-// sums it takes part in instead of poisoning them with NaN (the reference propagates NaN into every moment of the
-// nodes the point touches; neither result means anything -- callers must not pass non-finite points).
-__device__ const double EXP2_TAB[128] = {
-    0x1.0000000000000p+0, 0x1.0163da9fb3335p+0, 0x1.02c9a3e778061p+0, 0x1.04315e86e7f85p+0,
-    0x1.059b0d3158574p+0, 0x1.0706b29ddf6dep+0, 0x1.0874518759bc8p+0, 0x1.09e3ecac6f383p+0,
-    0x1.0b5586cf9890fp+0, 0x1.0cc922b7247f7p+0, 0x1.0e3ec32d3d1a2p+0, 0x1.0fb66affed31bp+0,
-    0x1.11301d0125b51p+0, 0x1.12abdc06c31ccp+0, 0x1.1429aaea92de0p+0, 0x1.15a98c8a58e51p+0,
-    0x1.172b83c7d517bp+0, 0x1.18af9388c8deap+0, 0x1.1a35beb6fcb75p+0, 0x1.1bbe084045cd4p+0,
-    0x1.1d4873168b9aap+0, 0x1.1ed5022fcd91dp+0, 0x1.2063b88628cd6p+0, 0x1.21f49917ddc96p+0,
-    0x1.2387a6e756238p+0, 0x1.251ce4fb2a63fp+0, 0x1.26b4565e27cddp+0, 0x1.284dfe1f56381p+0,
-    0x1.29e9df51fdee1p+0, 0x1.2b87fd0dad990p+0, 0x1.2d285a6e4030bp+0, 0x1.2ecafa93e2f56p+0,
-    0x1.306fe0a31b715p+0, 0x1.32170fc4cd831p+0, 0x1.33c08b26416ffp+0, 0x1.356c55f929ff1p+0,
-    0x1.371a7373aa9cbp+0, 0x1.38cae6d05d866p+0, 0x1.3a7db34e59ff7p+0, 0x1.3c32dc313a8e5p+0,
-    0x1.3dea64c123422p+0, 0x1.3fa4504ac801cp+0, 0x1.4160a21f72e2ap+0, 0x1.431f5d950a897p+0,
-    0x1.44e086061892dp+0, 0x1.46a41ed1d0057p+0, 0x1.486a2b5c13cd0p+0, 0x1.4a32af0d7d3dep+0,
-    0x1.4bfdad5362a27p+0, 0x1.4dcb299fddd0dp+0, 0x1.4f9b2769d2ca7p+0, 0x1.516daa2cf6642p+0,
-    0x1.5342b569d4f82p+0, 0x1.551a4ca5d920fp+0, 0x1.56f4736b527dap+0, 0x1.58d12d497c7fdp+0,
-    0x1.5ab07dd485429p+0, 0x1.5c9268a5946b7p+0, 0x1.5e76f15ad2148p+0, 0x1.605e1b976dc09p+0,
-    0x1.6247eb03a5585p+0, 0x1.6434634ccc320p+0, 0x1.6623882552225p+0, 0x1.68155d44ca973p+0,
-    0x1.6a09e667f3bcdp+0, 0x1.6c012750bdabfp+0, 0x1.6dfb23c651a2fp+0, 0x1.6ff7df9519484p+0,
-    0x1.71f75e8ec5f74p+0, 0x1.73f9a48a58174p+0, 0x1.75feb564267c9p+0, 0x1.780694fde5d3fp+0,
-    0x1.7a11473eb0187p+0, 0x1.7c1ed0130c132p+0, 0x1.7e2f336cf4e62p+0, 0x1.80427543e1a12p+0,
-    0x1.82589994cce13p+0, 0x1.8471a4623c7adp+0, 0x1.868d99b4492edp+0, 0x1.88ac7d98a6699p+0,
-    0x1.8ace5422aa0dbp+0, 0x1.8cf3216b5448cp+0, 0x1.8f1ae99157736p+0, 0x1.9145b0b91ffc6p+0,
-    0x1.93737b0cdc5e5p+0, 0x1.95a44cbc8520fp+0, 0x1.97d829fde4e50p+0, 0x1.9a0f170ca07bap+0,
-    0x1.9c49182a3f090p+0, 0x1.9e86319e32323p+0, 0x1.a0c667b5de565p+0, 0x1.a309bec4a2d33p+0,
-    0x1.a5503b23e255dp+0, 0x1.a799e1330b358p+0, 0x1.a9e6b5579fdbfp+0, 0x1.ac36bbfd3f37ap+0,
-    0x1.ae89f995ad3adp+0, 0x1.b0e07298db666p+0, 0x1.b33a2b84f15fbp+0, 0x1.b59728de5593ap+0,
-    0x1.b7f76f2fb5e47p+0, 0x1.ba5b030a1064ap+0, 0x1.bcc1e904bc1d2p+0, 0x1.bf2c25bd71e09p+0,
-    0x1.c199bdd85529cp+0, 0x1.c40ab5fffd07ap+0, 0x1.c67f12e57d14bp+0, 0x1.c8f6d9406e7b5p+0,
-    0x1.cb720dcef9069p+0, 0x1.cdf0b555dc3fap+0, 0x1.d072d4a07897cp+0, 0x1.d2f87080d89f2p+0,
-    0x1.d5818dcfba487p+0, 0x1.d80e316c98398p+0, 0x1.da9e603db3285p+0, 0x1.dd321f301b460p+0,
-    0x1.dfc97337b9b5fp+0, 0x1.e264614f5a129p+0, 0x1.e502ee78b3ff6p+0, 0x1.e7a51fbc74c83p+0,
-    0x1.ea4afa2a490dap+0, 0x1.ecf482d8e67f1p+0, 0x1.efa1bee615a27p+0, 0x1.f252b376bba97p+0,
-    0x1.f50765b6e4540p+0, 0x1.f7bfdad9cbe14p+0, 0x1.fa7c1819e90d8p+0, 0x1.fd3c22b8f71f1p+0,
-};
-constexpr int EXP_TAB_N = 128;
-// copy the table into LDS (first 128 threads of the workgroup; the caller synchronises)
-__device__ __forceinline__ void exp_tab_load(double* __restrict__ tab_lds) {
-    if (threadIdx.x < EXP_TAB_N) tab_lds[threadIdx.x] = EXP2_TAB[threadIdx.x];
-}
-
-#define HGMM_EXP_CONSTS                                                                                       \
-    constexpr double MAGIC = 6755399441055744.0;          /* 1.5 * 2^52 */                                      \
-    constexpr double INV = 184.6649652337873;             /* 128 / ln 2 */                                      \
-    constexpr double C_HI = 6.93147180369123816490e-01 / 128.0, C_LO = 1.90821492927058770002e-10 / 128.0
-
-__device__ __forceinline__ void exp_nonpos4(const double (&yin)[4], double (&out)[4], const double* __restrict__ tab) {
-    HGMM_EXP_CONSTS;
-    double r[4], T[4], q[4];
-    int m[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const double y = fmax(fmin(yin[k], 0.0), -708.0);
-        const double t = fma(y, INV, MAGIC);
-        const double nf = t - MAGIC;
-        r[k] = fma(nf, -C_LO, fma(nf, -C_HI, y));
-        const int n = __double2loint(t);                  // low mantissa word of t = n (two's complement)
-        T[k] = tab[n & (EXP_TAB_N - 1)];
-        m[k] = n >> 7;
-    }
-    // (one block of three-address v_fma_f64, consecutive instructions independent: hipcc would pick the two-address
-    //  v_fmac_f64 and pay a v_mov_b64 per step, and a block per value is a chain of dependent fp64 fmas)
-    asm("v_fma_f64 %0, %4, %12, %13\n\tv_fma_f64 %1, %5, %12, %13\n\tv_fma_f64 %2, %6, %12, %13\n\t"
-        "v_fma_f64 %3, %7, %12, %13\n\t"
-        "v_fma_f64 %0, %0, %4, %14\n\tv_fma_f64 %1, %1, %5, %14\n\tv_fma_f64 %2, %2, %6, %14\n\t"
-        "v_fma_f64 %3, %3, %7, %14\n\t"
-        "v_fma_f64 %0, %0, %4, 0.5\n\tv_fma_f64 %1, %1, %5, 0.5\n\tv_fma_f64 %2, %2, %6, 0.5\n\t"
-        "v_fma_f64 %3, %3, %7, 0.5\n\t"
-        "v_fma_f64 %0, %0, %4, 1.0\n\tv_fma_f64 %1, %1, %5, 1.0\n\tv_fma_f64 %2, %2, %6, 1.0\n\t"
-        "v_fma_f64 %3, %3, %7, 1.0\n\t"
-        "v_mul_f64 %0, %0, %4\n\tv_mul_f64 %1, %1, %5\n\tv_mul_f64 %2, %2, %6\n\tv_mul_f64 %3, %3, %7\n\t"
-        "v_fma_f64 %0, %8, %0, %8\n\tv_fma_f64 %1, %9, %1, %9\n\tv_fma_f64 %2, %10, %2, %10\n\t"
-        "v_fma_f64 %3, %11, %3, %11"
-        : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3])
-        : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]),
-          "v"(1.0 / 120.0), "v"(1.0 / 24.0), "v"(1.0 / 6.0));
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        out[k] = __hiloint2double(__double2hiint(q[k]) + (m[k] << 20), __double2loint(q[k]));
-}
-
-__device__ __forceinline__ void exp_nonpos2(const double (&yin)[2], double (&out)[2], const double* __restrict__ tab) {
-    HGMM_EXP_CONSTS;
-    double r[2], T[2], q[2];
-    int m[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const double y = fmax(fmin(yin[k], 0.0), -708.0);
-        const double t = fma(y, INV, MAGIC);
-        const double nf = t - MAGIC;
-        r[k] = fma(nf, -C_LO, fma(nf, -C_HI, y));
-        const int n = __double2loint(t);
-        T[k] = tab[n & (EXP_TAB_N - 1)];
-        m[k] = n >> 7;
-    }
-    asm("v_fma_f64 %0, %2, %6, %7\n\tv_fma_f64 %1, %3, %6, %7\n\t"
-        "v_fma_f64 %0, %0, %2, %8\n\tv_fma_f64 %1, %1, %3, %8\n\t"
-        "v_fma_f64 %0, %0, %2, 0.5\n\tv_fma_f64 %1, %1, %3, 0.5\n\t"
-        "v_fma_f64 %0, %0, %2, 1.0\n\tv_fma_f64 %1, %1, %3, 1.0\n\t"
-        "v_mul_f64 %0, %0, %2\n\tv_mul_f64 %1, %1, %3\n\t"
-        "v_fma_f64 %0, %4, %0, %4\n\tv_fma_f64 %1, %5, %1, %5"
-        : "=&v"(q[0]), "=&v"(q[1])
-        : "v"(r[0]), "v"(r[1]), "v"(T[0]), "v"(T[1]), "v"(1.0 / 120.0), "v"(1.0 / 24.0), "v"(1.0 / 6.0));
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-        out[k] = __hiloint2double(__double2hiint(q[k]) + (m[k] << 20), __double2loint(q[k]));
-}
-#undef HGMM_EXP_CONSTS
-
-// The same construction on a 2048-entry table (16 KB of LDS) for the throughput-bound kernels: n = round(y 2048 / ln 2),
-// |r| <= ln2 / 4096 = 1.7e-4, so e^r - 1 = r (1 + r (1/2 + r / 6)) is enough (r^4 / 24 < 3.5e-17): 4 instead of 6
-// instructions for the polynomial; and for exponents that are NON-POSITIVE BY CONSTRUCTION (-|R d|^2) the upper clamp
-// goes: 14 VALU instructions per value instead of 17.  The table (correctly rounded 2^(j/2048), formed in long double
-// on the host) lives in a context buffer and is copied to LDS by the kernel.
-constexpr int EXP_TAB2_BITS = 11;
-constexpr int EXP_TAB2_N = 1 << EXP_TAB2_BITS;
-template <bool NONPOS>
-__device__ __forceinline__ void exp_t11_4(const double (&yin)[4], double (&out)[4], const double* __restrict__ tab) {
-    constexpr double MAGIC = 6755399441055744.0;          /* 1.5 * 2^52 */
-    constexpr double INV = 2954.6394437405972;            /* 2048 / ln 2 */
-    constexpr double C_HI = 6.93147180369123816490e-01 / 2048.0, C_LO = 1.90821492927058770002e-10 / 2048.0;
-    double r[4], T[4], q[4];
-    int mh[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const double y = NONPOS ? fmax(yin[k], -708.0) : fmax(fmin(yin[k], 0.0), -708.0);
-        const double t = fma(y, INV, MAGIC);
-        const double nf = t - MAGIC;
-        r[k] = fma(nf, -C_LO, fma(nf, -C_HI, y));
-        const int n = __double2loint(t);                  // low mantissa word of t = n (two's complement)
-        T[k] = tab[n & (EXP_TAB2_N - 1)];
-        mh[k] = (int)((unsigned int)(n & ~(EXP_TAB2_N - 1)) << (20 - EXP_TAB2_BITS));   // (n >> 11) << 20: exponent-field increment
-    }
-    asm("v_fma_f64 %0, %4, %12, 0.5\n\tv_fma_f64 %1, %5, %12, 0.5\n\tv_fma_f64 %2, %6, %12, 0.5\n\t"
-        "v_fma_f64 %3, %7, %12, 0.5\n\t"
-        "v_fma_f64 %0, %0, %4, 1.0\n\tv_fma_f64 %1, %1, %5, 1.0\n\tv_fma_f64 %2, %2, %6, 1.0\n\t"
-        "v_fma_f64 %3, %3, %7, 1.0\n\t"
-        "v_mul_f64 %0, %0, %4\n\tv_mul_f64 %1, %1, %5\n\tv_mul_f64 %2, %2, %6\n\tv_mul_f64 %3, %3, %7\n\t"
-        "v_fma_f64 %0, %8, %0, %8\n\tv_fma_f64 %1, %9, %1, %9\n\tv_fma_f64 %2, %10, %2, %10\n\t"
-        "v_fma_f64 %3, %11, %3, %11"
-        : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3])
-        : "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(T[0]), "v"(T[1]), "v"(T[2]), "v"(T[3]), "v"(1.0 / 6.0));
-#pragma unroll
-    for (int k = 0; k < 4; ++k) out[k] = __hiloint2double(__double2hiint(q[k]) + mh[k], __double2loint(q[k]));
-}
-// The same exp in three stages, so that a caller can put the table look-ups of MANY values in flight before the first
-// one is needed (the one-block form above takes the table values as inputs of its asm block: the block cannot start
-// before every look-up has returned, and the polynomial does not overlap the LDS latency):
-//   exp_t11_head   clamp, n = round(y 2048 / ln 2), r = y - n ln2 / 2048, REQUEST T = 2^((n mod 2048) / 2048)
-//   exp_t11_poly4  p = e^r - 1 for four values (one asm block, inputs r only)
-//   exp_t11_tail   2^(n div 2048) * fma(T, p, T)
-struct ExpHead { double r, T; int mh; };
-template <bool NONPOS>
-__device__ __forceinline__ ExpHead exp_t11_head(double yin, const double* __restrict__ tab) {
-    constexpr double MAGIC = 6755399441055744.0, INV = 2954.6394437405972;
-    constexpr double C_HI = 6.93147180369123816490e-01 / 2048.0, C_LO = 1.90821492927058770002e-10 / 2048.0;
-    const double y = NONPOS ? fmax(yin, -708.0) : fmax(fmin(yin, 0.0), -708.0);
-    const double t = fma(y, INV, MAGIC);
-    const double nf = t - MAGIC;
-    ExpHead h;
-    h.r = fma(nf, -C_LO, fma(nf, -C_HI, y));
-    const int n = __double2loint(t);
-    h.T = tab[n & (EXP_TAB2_N - 1)];
-    h.mh = (int)((unsigned int)(n & ~(EXP_TAB2_N - 1)) << (20 - EXP_TAB2_BITS));
-    return h;
-}
-__device__ __forceinline__ void exp_t11_poly4(double r0, double r1, double r2, double r3, double (&p)[4]) {
-    asm("v_fma_f64 %0, %4, %8, 0.5\n\tv_fma_f64 %1, %5, %8, 0.5\n\tv_fma_f64 %2, %6, %8, 0.5\n\t"
-        "v_fma_f64 %3, %7, %8, 0.5\n\t"
-        "v_fma_f64 %0, %0, %4, 1.0\n\tv_fma_f64 %1, %1, %5, 1.0\n\tv_fma_f64 %2, %2, %6, 1.0\n\t"
-        "v_fma_f64 %3, %3, %7, 1.0\n\t"
-        "v_mul_f64 %0, %0, %4\n\tv_mul_f64 %1, %1, %5\n\tv_mul_f64 %2, %2, %6\n\tv_mul_f64 %3, %3, %7"
-        : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3])
-        : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(1.0 / 6.0));
-}
-__device__ __forceinline__ double exp_t11_tail(const ExpHead& h, double p) {
-    const double q = fma(h.T, p, h.T);
-    return __hiloint2double(__double2hiint(q) + h.mh, __double2loint(q));
-}
-__device__ __forceinline__ void exp_tab2_load(double* __restrict__ tab_lds, const double* __restrict__ tab_g) {
-    for (int e = threadIdx.x; e < EXP_TAB2_N; e += blockDim.x) tab_lds[e] = tab_g[e];
-}
-
-// ------------------------------------------------------------------------------------------
-// per-node preparation
-// ------------------------------------------------------------------------------------------
-__device__ inline double sym3_min_eig_over_trace(double a00, double a01, double a02, double a11,
-                                                 double a12, double a22) {
-    // closed-form eigenvalues of a symmetric 3x3 (trigonometric solution)
-    const double tr = a00 + a11 + a22;
-    const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
-    double e_min;
-    if (p1 == 0.0) {
-        e_min = fmin(a00, fmin(a11, a22));
-    } else {
-        const double q = tr / 3.0;
-        const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
-        const double p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * p1;
-        const double p = sqrt(p2 / 6.0);
-        const double ip = 1.0 / p;
-        const double c00 = b00 * ip, c01 = a01 * ip, c02 = a02 * ip, c11 = b11 * ip, c12 = a12 * ip,
-                     c22 = b22 * ip;
-        double r = 0.5 * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) +
-                          c02 * (c01 * c12 - c11 * c02));
-        r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
-        const double phi = acos(r) / 3.0;
-        e_min = q + 2.0 * p * cos(phi + 2.0943951023931953);   // + 2 pi / 3
-    }
-    return e_min / tr;
-}
-
-// An upper bound of the largest eigenvalue of a symmetric 3x3 that converges to it: Newton's iteration on the
-// characteristic polynomial started at the Frobenius norm (>= the spectral radius).  To the right of the largest
-// root the polynomial is increasing and convex, so the iterates decrease monotonically towards the root and EVERY
-// iterate is a valid bound -- which is all the reach test of the log-likelihood kernel needs.  ~60 flops; the
-// closed form (sqrt, acos, cos) this replaces cost more than the whole rest of a node's M-step.
-__device__ inline double sym3_max_eig_upper(double a00, double a01, double a02, double a11, double a12, double a22) {
-    const double c2 = a00 + a11 + a22;
-    const double c1 = (a00 * a11 - a01 * a01) + (a00 * a22 - a02 * a02) + (a11 * a22 - a12 * a12);
-    const double c0 = a00 * (a11 * a22 - a12 * a12) - a01 * (a01 * a22 - a12 * a02) + a02 * (a01 * a12 - a11 * a02);
-    double lam = sqrt(a00 * a00 + a11 * a11 + a22 * a22 + 2.0 * (a01 * a01 + a02 * a02 + a12 * a12));
-    if (!(lam > 0.0)) return lam;
-#pragma unroll
-    for (int it = 0; it < 6; ++it) {
-        const double pv = fma(fma(lam - c2, lam, c1), lam, -c0);                 // p(lam)
-        const double dv = fma(fma(3.0, lam, -2.0 * c2), lam, c1);                // p'(lam)
-        const double nxt = (dv > 0.0) ? lam - pv / dv : lam;
-        lam = (nxt < lam && nxt > 0.0) ? nxt : lam;                              // never move up, never leave the right branch
-    }
-    return lam * (1.0 + 1.0e-9);
-}
-
-__device__ __forceinline__ void prep_node(double p, double m0, double m1, double m2, double c00, double c01,
-                                          double c02, double c10, double c11, double c12, double c20,
-                                          double c21, double c22, double* __restrict__ o, int* __restrict__ flags,
-                                          bool with_complexity = true) {
-    const double det = c00 * (c11 * c22 - c12 * c21) - c01 * (c10 * c22 - c12 * c20) +
-                       c02 * (c10 * c21 - c11 * c20);
-#pragma unroll
-    for (int e = PREP_R; e < PREP_N; ++e) o[e] = 0.0;
-    o[PREP_KAPPA2] = -1.0;
-    if (det < TREE_EPS) {           // gaussianPdf returns 0 (hgmm_cupy_cpu_working.py:65-67)
-        o[0] = o[1] = o[2] = o[3] = o[4] = o[5] = 0.0;
-        o[9] = 0.0;
-        o[10] = 0.0;
-    } else {
-        const double id = 1.0 / det;
-        // symmetric part of the adjugate (covariances are symmetric by construction)
-        o[0] = (c11 * c22 - c12 * c21) * id;
-        o[1] = (c02 * c21 - c01 * c22) * id;
-        o[2] = (c01 * c12 - c02 * c11) * id;
-        o[3] = (c00 * c22 - c02 * c20) * id;
-        o[4] = (c02 * c10 - c00 * c12) * id;
-        o[5] = (c00 * c11 - c01 * c10) * id;
-        const double coef = 1.0 / (sqrt(det) * TWO_PI_POW_1_5);
-        o[9] = p * coef;
-        o[10] = (p < TREE_EPS) ? 0.0 : p * coef;   // logLikelihoodValue skips pi < eps (C:80)
-        // Cholesky factor of A = Sigma^-1 / 2:  A = R^T R, R upper triangular
-        const double a00 = 0.5 * o[0], a01 = 0.5 * o[1], a02 = 0.5 * o[2], a11 = 0.5 * o[3], a12 = 0.5 * o[4],
-                     a22 = 0.5 * o[5];
-        const double r00 = sqrt(a00);
-        const double r01 = a01 / r00, r02 = a02 / r00;
-        const double r11 = sqrt(a11 - r01 * r01);
-        const double r12 = (a12 - r01 * r02) / r11;
-        const double r22 = sqrt(a22 - r02 * r02 - r12 * r12);
-        const bool pd = (a00 > 0.0) && (r11 > 0.0) && (r22 > 0.0) && (r22 == r22) && (r11 == r11) &&
-                        (fabs(r12) < 1.0e300) && (fabs(r02) < 1.0e300);
-        if (pd) {
-            o[PREP_R + 0] = r00; o[PREP_R + 1] = r01; o[PREP_R + 2] = r02;
-            o[PREP_R + 3] = r11; o[PREP_R + 4] = r12; o[PREP_R + 5] = r22;
-            const double lmax = sym3_max_eig_upper(c00, c01, c02, c11, c12, c22);
-            o[PREP_KAPPA] = (lmax > 0.0 && lmax == lmax && lmax < 1.0e300) ? 0.5 / lmax : 0.0;
-            const double imax = sym3_max_eig_upper(o[0], o[1], o[2], o[3], o[4], o[5]);
-            o[PREP_KAPPA2] = (imax > 0.0 && imax == imax && imax < 1.0e300) ? 0.5 * imax : -1.0;
-        } else if (flags) {
-            atomicOr(flags, 1);
-        }
-    }
-    o[6] = m0; o[7] = m1; o[8] = m2;
-    // (the 'complexity' ratio feeds the registration E-step only: the build takes it once, when the tree is finished)
-    if (with_complexity) o[11] = sym3_min_eig_over_trace(c00, c01, c02, c11, c12, c22);
-}
 
 __global__ void tree_prep_kernel(const double* __restrict__ pi, const double* __restrict__ mu,
                                  const double* __restrict__ cov, int64_t j_begin, int64_t j_end,
@@ -445,228 +117,11 @@ __global__ void tree_chunks_kernel(const int* __restrict__ seg_start, int P, int
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// The level's stop rule WITHOUT a reduction tail: every workgroup of the NEXT launch in the stream (the next
-// iteration's E-step, or the one-workgroup tree_close_kernel behind a level's last budgeted iteration) adds up the
-// previous iteration's shares of q for itself -- same fixed order everywhere, so the same q and the same verdict -- and
-// workgroup 0 records it (trace, iteration count, stop flag, the host's progress word).  The log-likelihood kernels
-// just store their shares: no ticket, no atomic, no last-workgroup pass (store_block_q's chain of a drained store, two
-// arrival counters and a read-back was ~3 us at the end of every C4 iteration), and the build path is free of atomics.
-// State is double-buffered by launch parity (launch e reads slot (e - 1) & 1 and writes slot e & 1): a workgroup that
-// starts late must not read what workgroup 0 of its own launch has just written.
-// ------------------------------------------------------------------------------------------
-struct TreeLoopState { int it; int pad; double prev_q; };
-struct TreeFollow {                      // q_blocks == nullptr: nothing to follow (a level's first iteration)
-    const double* q_blocks; int nb;
-    const TreeLoopState* prev; TreeLoopState* next;
-    int* done; double ls; int max_iters; double* trace; int trace_cap; unsigned long long* host_word;
-};
-// true: the level has stopped -- this launch has nothing to do.  Called by all threads of a CH-thread workgroup.
-__device__ __forceinline__ bool tree_follow(const TreeFollow& f, int stop_flag, double* sh4) {
-    const double prev_q = f.prev->prev_q;                 // (requested together with the shares)
-    const int it = f.prev->it;
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < f.nb; i += CH) acc += f.q_blocks[i];
-    if (stop_flag) return true;                           // kernel-uniform
-    acc = wave_sum_f64(acc);                              // (the order of store_block_q's last workgroup / tree_sum_kernel)
-    if (lane_id() == 0) sh4[wave_in_block()] = acc;
-    __syncthreads();
-    const double q = sh4[0] + sh4[1] + sh4[2] + sh4[3];
-    const bool stop_now = fabs(q - prev_q) < f.ls || it + 1 >= f.max_iters;      // (hgmm_gpu.py:532; prev_q starts at 0)
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (it < f.trace_cap) f.trace[it] = q;
-        f.next->it = it + 1;
-        f.next->prev_q = q;
-        if (stop_now) *f.done = 1;
-        if (f.host_word)
-            __hip_atomic_store(f.host_word, ((unsigned long long)(stop_now ? 1 : 0) << 32) | (unsigned long long)(unsigned)(it + 1),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    return stop_now;
-}
-// The same for a workgroup of ONE wave (tree_moments_kernel): lane t adds up what threads t, t + 64, t + 128, t + 192 of a
-// CH-thread workgroup would have -- four separate sums, reduced and combined exactly as above, so the same q bit for bit.
-struct TreeFollowLoads { double acc[CH / 64]; double prev_q; int it; };
-// (the loads first -- the caller puts its own requests behind them and only then asks for the verdict, so that the two
-//  chains of trips to memory run side by side)
-__device__ __forceinline__ TreeFollowLoads tree_follow_wave_load(const TreeFollow& f) {
-    TreeFollowLoads r;
-    r.prev_q = f.prev->prev_q;
-    r.it = f.prev->it;
-#pragma unroll
-    for (int w = 0; w < CH / 64; ++w) r.acc[w] = 0.0;
-    for (int i0 = threadIdx.x; i0 < f.nb; i0 += CH) {
-#pragma unroll
-        for (int w = 0; w < CH / 64; ++w)
-            if (i0 + 64 * w < f.nb) r.acc[w] += f.q_blocks[i0 + 64 * w];
-    }
-    return r;
-}
-__device__ __forceinline__ bool tree_follow_wave_verdict(const TreeFollow& f, TreeFollowLoads r, int stop_flag) {
-    if (stop_flag) return true;
-#pragma unroll
-    for (int w = 0; w < CH / 64; ++w) r.acc[w] = wave_sum_f64(r.acc[w]);
-    double q = r.acc[0];
-#pragma unroll
-    for (int w = 1; w < CH / 64; ++w) q += r.acc[w];
-    const double prev_q = r.prev_q;
-    const int it = r.it;
-    const bool stop_now = fabs(q - prev_q) < f.ls || it + 1 >= f.max_iters;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (it < f.trace_cap) f.trace[it] = q;
-        f.next->it = it + 1;
-        f.next->prev_q = q;
-        if (stop_now) *f.done = 1;
-        if (f.host_word)
-            __hip_atomic_store(f.host_word, ((unsigned long long)(stop_now ? 1 : 0) << 32) | (unsigned long long)(unsigned)(it + 1),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    return stop_now;
-}
 __global__ __launch_bounds__(CH) void tree_close_kernel(TreeFollow f) {
     __shared__ double sh4[4];
     (void)tree_follow(f, *f.done, sh4);
 }
 
-// ------------------------------------------------------------------------------------------
-// E-step of one tree level
-// ------------------------------------------------------------------------------------------
-constexpr int ES_LD = 66;            // LDS row stride (doubles) of the moment contraction's operands: conflict-free fragment reads
-typedef double double4_es __attribute__((ext_vector_type(4)));
-// HALF: the wave's 64 points go through the LDS transpose 32 at a time (18 rows x 34 instead of x 66 doubles per wave:
-// 23 KB of LDS per workgroup instead of 42) -- same products, same order of accumulation, so the same sums bit for bit.
-// A million-point level is 3907 chunks = 15 workgroups per CU, of which the LDS admitted 3 at a time: the launch was
-// five rounds of one latency chain each.  Small clouds (less than one workgroup per CU) keep the one-pass form.
-struct TreeEstepArgs {
-    const double* xs; int64_t n_pad; const double* prep; const int* chunk_desc; const int* n_chunks;
-    int64_t parent_level_first; int level; double* partials; int* cur_sorted; const int* done;
-};
-// (c = the workgroup's chunk: blockIdx.x in tree_estep_kernel, an offset of it in tree_ll_estep_kernel)
-// LDS of one E-step workgroup, in doubles: exp table, tree_follow's four, the waves' [8][NMOM] sums, gamma rows, feature rows
-template <bool HALF>
-constexpr int tree_estep_lds() { return EXP_TAB_N + 4 + (CH / 64) * 8 * NMOM + (CH / 64) * (8 + NMOM) * (HALF ? ES_LD / 2 + 1 : ES_LD); }
-template <bool HALF>
-__device__ __forceinline__ void tree_estep_body(const int c, const TreeEstepArgs& a, const TreeFollow& follow,
-                                                double* __restrict__ smem) {
-    const double* __restrict__ xs = a.xs;
-    const int64_t n_pad = a.n_pad;
-    const double* __restrict__ prep = a.prep;
-    const int* __restrict__ chunk_desc = a.chunk_desc;
-    const int* __restrict__ n_chunks = a.n_chunks;
-    const int64_t parent_level_first = a.parent_level_first;
-    const int level = a.level;
-    double* __restrict__ partials = a.partials;
-    int* __restrict__ cur_sorted = a.cur_sorted;
-    const int* __restrict__ done = a.done;
-    // (the stop flag, the chunk count and this chunk's descriptor are requested together -- the descriptor table is
-    //  allocated for the whole grid, so the read is safe before the count is known: one trip to memory instead of three)
-    const int stop_flag = done ? *done : 0;        // the level converged in an earlier iteration of this batch
-    const int chunks_now = *n_chunks;
-    const int p = chunk_desc[3 * c + 0], begin = chunk_desc[3 * c + 1], end = chunk_desc[3 * c + 2];
-    double* exp_tab = smem;
-    double* sh_follow = smem + EXP_TAB_N;
-    exp_tab_load(exp_tab);                         // (synchronised below, once the points' loads are on their way)
-    if (c >= chunks_now) return;                   // (workgroup 0 always owns a chunk)
-    if (follow.q_blocks) {
-        if (tree_follow(follow, stop_flag, sh_follow)) return;       // the previous iteration's q stopped the level
-    } else if (stop_flag) {
-        return;
-    }
-    // node id of the parent: level 0 -> pseudo-parent -1; child(j) = 8 (j + 1)
-    const int64_t parent_node = (level == 0) ? -1 : parent_level_first + p;
-    const int64_t j0 = 8 * (parent_node + 1);
-    const int i = begin + (int)threadIdx.x;
-    const bool active = i < end;
-    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
-    if (active) { x0 = xs[i]; x1 = xs[n_pad + i]; x2 = xs[2 * n_pad + i]; }
-    __syncthreads();                               // exp_tab
-
-    double g[8];
-    double den = 0.0;
-    {
-        // the 8 children's exponents, then two interleaved branch-free exponentials of four (a child with
-        // wE = 0 -- pi = 0 or a singular covariance -- has an all-zero inverse: exponent 0, weight 0)
-        double yv[8], ev[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const double* pr = prep + PREP_N * (j0 + k);
-            const double d0 = x0 - pr[6], d1 = x1 - pr[7], d2 = x2 - pr[8];
-            yv[k] = -0.5 * sym3_quad(pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], d0, d1, d2);
-        }
-        const double ya[4] = {yv[0], yv[1], yv[2], yv[3]}, yb[4] = {yv[4], yv[5], yv[6], yv[7]};
-        double ea[4], eb[4];
-        exp_nonpos4(ya, ea, exp_tab);
-        exp_nonpos4(yb, eb, exp_tab);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { ev[k] = ea[k]; ev[4 + k] = eb[k]; }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const double wE = prep[PREP_N * (j0 + k) + 9];
-            // below the exponent range the library exp returns exactly 0; keep that (the clamp gives 3e-308)
-            g[k] = (wE == 0.0 || yv[k] < -745.0) ? 0.0 : wE * ev[k];
-            den += g[k];
-        }
-    }
-    // gamma = g / den if den > eps else 0; arg-max = first maximum  (C:174-187)
-    const bool good = den > TREE_EPS;
-    int am = 0;
-    double best = -1.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        g[k] = good ? g[k] / den : 0.0;
-        if (g[k] > best) { best = g[k]; am = k; }
-        if (g[k] < TREE_EPS || !active) g[k] = 0.0;      // accumulate() ignores gamma < eps (C:100)
-    }
-    if (active) cur_sorted[i] = (int)(j0 + am);
-
-    // The wave's 8 x 10 moment sums  M[k][m] = sum_lanes gamma[k] f[m]  as ONE dense contraction on the fp64 matrix
-    // cores: gamma and the features go through LDS (component- / feature-major, one row per child resp. feature),
-    // 16 v_mfma_f64_16x16x4_f64 walk the wave's 64 points four at a time.  (Round 2 took 80 DPP wave reductions here,
-    // ~1400 dependent fp64 instructions per wave -- a third of this latency-bound kernel's time at C4.)  Rows 8..15 of
-    // the A operand and columns 10..15 of B alias rows that exist: their products land in accumulator entries nobody reads.
-    constexpr int LD = HALF ? ES_LD / 2 + 1 : ES_LD;          // 34 / 66: the same bank pattern (stride = 4 mod 64 dwords)
-    constexpr int PASS_PTS = HALF ? 32 : 64;
-    double (*sh)[8 * NMOM] = reinterpret_cast<double (*)[8 * NMOM]>(smem + EXP_TAB_N + 4);
-    double (*GS)[8][LD] = reinterpret_cast<double (*)[8][LD]>(smem + EXP_TAB_N + 4 + (CH / 64) * 8 * NMOM);
-    double (*FS)[NMOM][LD] = reinterpret_cast<double (*)[NMOM][LD]>(smem + EXP_TAB_N + 4 + (CH / 64) * 8 * NMOM + (CH / 64) * 8 * LD);
-    const int w = wave_in_block();
-    const int lane = lane_id();
-    {
-        const double f[NMOM] = {1.0, x0, x1, x2, x0 * x0, x0 * x1, x0 * x2, x1 * x1, x1 * x2, x2 * x2};
-        const int a_idx = lane & 15, b_idx = lane >> 4;
-        const double* ga = &GS[w][a_idx & 7][b_idx];
-        const double* fb = &FS[w][a_idx < NMOM ? a_idx : NMOM - 1][b_idx];
-        double4_es acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int pass = 0; pass < 64 / PASS_PTS; ++pass) {
-            if (pass > 0) __builtin_amdgcn_wave_barrier();     // the previous pass's fragment reads are done (same wave, in order)
-            if (lane / PASS_PTS == pass) {
-                const int col = lane % PASS_PTS;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) GS[w][k][col] = g[k];
-#pragma unroll
-                for (int m = 0; m < NMOM; ++m) FS[w][m][col] = f[m];
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): this wave's LDS writes have landed
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int st = 0; st < PASS_PTS / 4; ++st)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[4 * st], fb[4 * st], acc, 0, 0, 0);
-        }
-        // D layout (f64 16x16x4): row (child) = (lane >> 4) + 4 r, column (feature) = lane & 15
-        if (a_idx < NMOM) {
-            sh[w][b_idx * NMOM + a_idx] = acc[0];
-            sh[w][(b_idx + 4) * NMOM + a_idx] = acc[1];
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 8 * NMOM) {
-        double t = 0.0;
-#pragma unroll
-        for (int ww = 0; ww < CH / 64; ++ww) t += sh[ww][threadIdx.x];
-        partials[(size_t)c * (8 * NMOM) + threadIdx.x] = t;
-    }
-}
 template <bool HALF>
 __global__ __launch_bounds__(CH) void tree_estep_kernel(
     const double* __restrict__ xs, int64_t n_pad, const double* __restrict__ prep,
@@ -679,33 +134,6 @@ __global__ __launch_bounds__(CH) void tree_estep_kernel(
                           follow, smem);
 }
 
-// one wave per child node of the level: fixed-order sum of its parent's chunk partials
-// ML estimate of one node from its moments (mlEstimator, hgmm_cupy_cpu_working.py:109-119) followed by
-// the node's E-step preparation, so that no separate prep launch is needed.
-__device__ __forceinline__ void mstep_node(const double* __restrict__ m, int64_t j, double n_points_total,
-                                           double ld, double* __restrict__ pi, double* __restrict__ mu,
-                                           double* __restrict__ cov, double* __restrict__ prep,
-                                           int* __restrict__ flags, bool with_complexity = true) {
-    const double m0 = m[0];
-    double* c = cov + 9 * j;
-    if (m0 < ld) {
-        pi[j] = 0.0;
-        mu[3 * j] = mu[3 * j + 1] = mu[3 * j + 2] = 0.0;
-        for (int e = 0; e < 9; ++e) c[e] = (e % 4 == 0) ? 1.0 : 0.0;
-        if (prep) prep_node(0.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0, prep + PREP_N * j, flags,
-                            with_complexity);
-        return;
-    }
-    const double p = m0 / n_points_total;
-    pi[j] = p;
-    const double u0 = m[1] / m0, u1 = m[2] / m0, u2 = m[3] / m0;
-    mu[3 * j] = u0; mu[3 * j + 1] = u1; mu[3 * j + 2] = u2;
-    const double s00 = m[4] / m0 - u0 * u0, s01 = m[5] / m0 - u0 * u1, s02 = m[6] / m0 - u0 * u2,
-                 s11 = m[7] / m0 - u1 * u1, s12 = m[8] / m0 - u1 * u2, s22 = m[9] / m0 - u2 * u2;
-    c[0] = s00; c[1] = s01; c[2] = s02; c[3] = s01; c[4] = s11; c[5] = s12; c[6] = s02; c[7] = s12; c[8] = s22;
-    if (prep) prep_node(p, u0, u1, u2, s00, s01, s02, s01, s11, s12, s02, s12, s22, prep + PREP_N * j, flags,
-                        with_complexity);
-}
 
 // fixed-order reduction of the chunk partials of one node (64 threads); with `fuse` the same
 // workgroup goes on to the node's M-step + preparation (single-GPU: no all-reduce in between)
@@ -754,377 +182,6 @@ __global__ void tree_mstep_kernel(const double* __restrict__ mom, int64_t lb, in
     mstep_node(mom + (size_t)cl * NMOM, lb + cl, n_points_total, ld, pi, mu, cov, prep, flags, with_complexity != 0);
 }
 
-// ------------------------------------------------------------------------------------------
-// level log-likelihood over ALL nodes of the level (logLikelihoodValue, C:72-85)
-// ------------------------------------------------------------------------------------------
-constexpr int LL_TILE = 256;
-// grid = (point blocks, node chunks).  With one chunk the per-point log is taken here; with several
-// (small clouds: not enough point blocks to fill 256 CUs) the per-chunk sums go to `partial`
-// [chunk][point] and tree_loglik_finish_kernel adds them in fixed order.
-// Stores a workgroup's share of q; with `ticket` the workgroup that finishes last also adds up all
-// shares -- in the same fixed order as tree_sum_kernel -- so that no separate reduction launch is
-// needed (the result does not depend on which workgroup happens to be last).
-struct TreeCtl { int done; int it; double prev_q; };
-// host_word (may be null): a word of pinned HOST memory that receives (done << 32 | iterations) after every update, so
-// that the host can follow the loop without a copy, an event or a synchronisation (hgmm_tree_build)
-struct TreeStop { TreeCtl* ctl; double ls; int max_iters; double* trace; int trace_cap; unsigned long long* host_word = nullptr; };   // ctl == nullptr: not here
-// the stop rule of one tree level (see tree_ctl_kernel); one thread
-__device__ __forceinline__ void tree_ctl_update(double q, const TreeStop& st) {
-    TreeCtl* ctl = st.ctl;
-    const int it = ctl->it;
-    if (it < st.trace_cap) st.trace[it] = q;
-    ctl->it = it + 1;
-    const int stop_now = (fabs(q - ctl->prev_q) < st.ls || it + 1 >= st.max_iters) ? 1 : 0;
-    if (stop_now) ctl->done = 1;
-    ctl->prev_q = q;
-    if (st.host_word)
-        __hip_atomic_store(st.host_word, ((unsigned long long)stop_now << 32) | (unsigned long long)(unsigned)(it + 1),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-// (With `stop.ctl` set the workgroup that finishes last also applies the level's stop rule -- every other workgroup
-//  of the launch has passed its own look at the flag by then -- which saves the one-thread launch per iteration.)
-// Hand-off between workgroups without fences (guide, inter-workgroup visibility: "8-byte agent-scope atomics on both
-// sides" is a complete protocol): a share is published with ONE relaxed agent-scope atomic store (write-through to
-// memory, not parked in this XCD's L2), the publishing lane drains its store, then takes a ticket; the workgroup
-// that draws the last ticket reads the shares back with relaxed agent-scope atomic loads (served below the L1 of its
-// CU).  Round 2 used __threadfence() on both sides -- L2 write-back + L1 invalidate, ~3.5 us each on this chip:
-// most of the duration of these microsecond kernels at C4.
-// Tickets are taken in TWO levels: workgroup b draws from counter 1 + (b mod NG), the workgroup that completes a
-// group draws from counter 0, the one that completes counter 0 is last.  Agent-scope atomics on ONE address are
-// served one after the other at ~20 ns each on this chip: with a single counter the 629 workgroups of the
-// small-cloud log-likelihood spent 12 us queueing for their tickets (measured: 15.5 us for an 8-node level).
-constexpr int TICKET_GROUPS = 64;                        // counter 0 = top level, counters 1 .. 64 = groups
-// ... and the counters sit 4 KB apart: device-scope atomics are executed at the memory side, one queue per channel --
-// 65 counters in three cache lines still queued behind each other (15.3 us for the 8-node level, unchanged).
-constexpr int TICKET_STRIDE = 1024;                      // unsigned ints between two counters
-__device__ __forceinline__ void store_block_q(double value, double* __restrict__ block_q, const int bx, int nb,
-                                              unsigned int* __restrict__ ticket, double* __restrict__ q_out,
-                                              const TreeStop& stop) {
-    __shared__ bool is_last;
-    __shared__ double sh_fin[4];
-    if (threadIdx.x == 0) {
-        is_last = false;
-        if (ticket) {
-            __hip_atomic_store(block_q + bx, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the share has left this CU before the ticket does
-            const int ng = nb < TICKET_GROUPS ? nb : TICKET_GROUPS;
-            const int g = (int)((unsigned)bx % (unsigned)ng);
-            const unsigned int members = (unsigned int)((nb - g + ng - 1) / ng);
-            unsigned int* mine = ticket + (size_t)(1 + g) * TICKET_STRIDE;
-            if (__hip_atomic_fetch_add(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
-                __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);             // ready for the next launch
-                is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)(ng - 1);
-            }
-        } else {
-            block_q[bx] = value;
-        }
-    }
-    __syncthreads();
-    if (!is_last) return;
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < nb; i += CH)
-        acc += __hip_atomic_load(block_q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    acc = wave_sum_f64(acc);
-    if (lane_id() == 0) sh_fin[wave_in_block()] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double q = sh_fin[0] + sh_fin[1] + sh_fin[2] + sh_fin[3];
-        *q_out = q;
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (stop.ctl) tree_ctl_update(q, stop);
-    }
-}
-
-// PTS points per thread: the node parameters come out of LDS as wave-wide broadcast reads (10 x 8 B x
-// 64 lanes per node and wave, ~40 LDS cycles for a CU whose four SIMDs need ~12 VALU cycles each for the
-// quadratic form), so the kernel is LDS-bound at one point per thread; every further point reuses the
-// same ten values.
-//
-// Round 3:
-//   * LOCAL ORIGIN + TRIANGULAR FORM.  A workgroup's points are neighbours (the cloud is regrouped per parent at every
-//     level), so they are expressed relative to the workgroup's first point c; the exponent is taken as
-//     -|R (x - c) - R (mu - c)|^2 with R^T R = Sigma^-1 / 2 (prep[12..17]) and b = R (mu - c) formed once per node and
-//     workgroup while the tile is loaded: 9 fma / mul per (point, node) pair instead of 14 (3 subtractions + the
-//     symmetric form).  Both terms are of the size of the workgroup's extent, so nothing is lost to cancellation
-//     (the global-coordinate version of the same form would lose |x| / sigma).
-//   * DEAD AND OUT-OF-REACH NODES NEVER ENTER THE TILE.  While a 256-node tile is loaded every thread looks at one
-//     node: pi < eps / singular nodes (weight 0) are dropped, and so is a node whose pdf underflows for EVERY point
-//     of the workgroup: exponent <= -kappa dist(box, mu)^2 with kappa = 1 / (2 lambda_max(Sigma)) and box = the
-//     bounding box of the workgroup's points.  Terms skipped this way are terms the wave-uniform test below would
-//     have skipped too (they are exactly 0 in float64), so q does not change by a bit.  The survivors are compacted
-//     in node order (ballot + popcount), the inner loop runs over them without a test per node.
-//   pair_count (optional): += (points of this workgroup) x (nodes that entered its tiles) -- the pairs actually evaluated.
-constexpr double LL_SKIP = -750.0;       // exp(y) == 0 in float64 below this exponent (denormals end at -745.13)
-constexpr double LL_CULL = 751.0;        // a node is out of reach when kappa dist^2 exceeds this (margin over LL_SKIP)
-constexpr double LL_REL_DROP = 46.1;     // ln(1e20) + margin: see the relative reach test in tree_loglik_kernel
-constexpr int LL_REL_MIN_NODES = 512;    // levels with fewer nodes skip the extra pass (measured: nothing to drop there)
-struct TreeLoglikArgs {
-    const double* xs; int64_t n; int64_t n_pad; const double* prep; int64_t lb; int n_level_nodes; int nodes_per_chunk;
-    double* partial; double* block_q; unsigned int* ticket; double* q_out; const int* done; TreeStop stop;
-    const int* flags; unsigned long long* pair_count; const double* exp2_tab;
-};
-// (bx, by) of a (gx, gy) grid: blockIdx / gridDim in tree_loglik_kernel, a slice of a 1-d grid in tree_ll_estep_kernel
-// LDS of one log-likelihood workgroup, in doubles: node tile, exp table, the waves' q / boxes / lref, the waves' counts (ints)
-template <bool BIGTAB>
-constexpr int tree_loglik_lds() { return LL_TILE * 10 + (BIGTAB ? EXP_TAB2_N : EXP_TAB_N) + (CH / 64) * (1 + 6 + 1) + (CH / 64) / 2; }
-template <int PTS, bool BIGTAB>
-__device__ __forceinline__ void tree_loglik_body(const int bx, const int by, const int gx, const int gy,
-                                                 const TreeLoglikArgs& a, double* __restrict__ smem) {
-    const double* __restrict__ xs = a.xs;
-    const int64_t n = a.n, n_pad = a.n_pad;
-    const double* __restrict__ prep = a.prep;
-    const int64_t lb = a.lb;
-    const int n_level_nodes = a.n_level_nodes, nodes_per_chunk = a.nodes_per_chunk;
-    double* __restrict__ partial = a.partial;
-    double* __restrict__ block_q = a.block_q;
-    unsigned int* __restrict__ ticket = a.ticket;
-    double* __restrict__ q_out = a.q_out;
-    const int* __restrict__ done = a.done;
-    const TreeStop& stop = a.stop;
-    const int* __restrict__ flags = a.flags;
-    unsigned long long* __restrict__ pair_count = a.pair_count;
-    const double* __restrict__ exp2_tab = a.exp2_tab;
-    const int stop_flag = done ? *done : 0;                // (looked at below, once the other requests are on their way)
-    constexpr int TAB_N = BIGTAB ? EXP_TAB2_N : EXP_TAB_N;
-    double (*tile)[10] = reinterpret_cast<double (*)[10]>(smem);
-    double* exp_tab = smem + LL_TILE * 10;
-    double* shq = exp_tab + TAB_N;
-    double (*shbox)[6] = reinterpret_cast<double (*)[6]>(shq + CH / 64);
-    double* shl = shq + (CH / 64) * 7;
-    int* wcnt = reinterpret_cast<int*>(shl + CH / 64);
-    if (BIGTAB) exp_tab2_load(exp_tab, exp2_tab); else exp_tab_load(exp_tab);   // (the tile loop's first barrier covers it)
-    const int fl = flags ? *flags : 0;
-    const int w = wave_in_block(), lane = lane_id();
-    // origin: the workgroup's first point
-    const int64_t i_first = (int64_t)bx * PTS * CH;
-    const int64_t i_c = i_first < n ? i_first : n - 1;
-    const double c0 = xs[i_c], c1 = xs[n_pad + i_c], c2 = xs[2 * n_pad + i_c];
-    int64_t i[PTS];
-    bool active[PTS];
-    double x0[PTS], x1[PTS], x2[PTS], tot[PTS];
-    double lo0 = 0.0, lo1 = 0.0, lo2 = 0.0, hi0 = 0.0, hi1 = 0.0, hi2 = 0.0;    // the origin itself is in the box
-    // (the stop flag, the form flag, the origin and the points are requested together: the launches of a small cloud are
-    //  chains of trips to memory, ~1.5 us each, and every trip taken side by side instead of in turn is that much less)
-    double r0[PTS], r1[PTS], r2[PTS];
-#pragma unroll
-    for (int p = 0; p < PTS; ++p) {
-        i[p] = i_first + (int64_t)p * CH + threadIdx.x;
-        active[p] = i[p] < n;
-        const int64_t il = active[p] ? i[p] : i_c;
-        r0[p] = xs[il]; r1[p] = xs[n_pad + il]; r2[p] = xs[2 * n_pad + il];
-    }
-    // Small clouds: the WEIGHTS of this thread's nodes in the first LL_WPRE tiles are requested with the points.  A level's
-    // dead nodes (pi < eps: 3370 of C4's 4096 level-3 slots) then cost 8 bytes each instead of the 17 parameters the tile
-    // loop asks for at once -- 70 KB per workgroup, 88 MB per launch of a kernel that lasts 15 us (C4: 2.32 -> 2.27 ms).
-    // (Also tried for these instantiations and dropped: two nodes per step of the evaluation loop, four exponentials
-    //  interleaved -- 2.29 ms: the loop is not what these launches wait for.)
-    constexpr int LL_WPRE = BIGTAB ? 0 : 2;
-    const int node_begin = by * nodes_per_chunk;
-    const int node_end = (node_begin + nodes_per_chunk < n_level_nodes) ? node_begin + nodes_per_chunk : n_level_nodes;
-    double wpre[LL_WPRE > 0 ? LL_WPRE : 1];
-#pragma unroll
-    for (int t = 0; t < LL_WPRE; ++t) {
-        const int nd = node_begin + t * LL_TILE + (int)threadIdx.x;
-        wpre[t] = nd < node_end ? prep[PREP_N * (lb + nd) + 10] : 0.0;
-    }
-    if (stop_flag) return;
-    const bool use_chol = !(fl & 1);                       // kernel-uniform
-#pragma unroll
-    for (int p = 0; p < PTS; ++p) {
-        x0[p] = x1[p] = x2[p] = tot[p] = 0.0;              // inactive slots sit on the origin
-        if (active[p]) {
-            x0[p] = r0[p] - c0; x1[p] = r1[p] - c1; x2[p] = r2[p] - c2;
-        }
-        lo0 = fmin(lo0, x0[p]); hi0 = fmax(hi0, x0[p]);
-        lo1 = fmin(lo1, x1[p]); hi1 = fmax(hi1, x1[p]);
-        lo2 = fmin(lo2, x2[p]); hi2 = fmax(hi2, x2[p]);
-    }
-    {
-        const double b0 = -wave_max_f64(-lo0), b1 = -wave_max_f64(-lo1), b2 = -wave_max_f64(-lo2);
-        const double b3 = wave_max_f64(hi0), b4 = wave_max_f64(hi1), b5 = wave_max_f64(hi2);
-        if (lane == 0) {
-            shbox[w][0] = b0; shbox[w][1] = b1; shbox[w][2] = b2; shbox[w][3] = b3; shbox[w][4] = b4; shbox[w][5] = b5;
-        }
-    }
-    __syncthreads();
-    lo0 = fmin(fmin(shbox[0][0], shbox[1][0]), fmin(shbox[2][0], shbox[3][0]));
-    lo1 = fmin(fmin(shbox[0][1], shbox[1][1]), fmin(shbox[2][1], shbox[3][1]));
-    lo2 = fmin(fmin(shbox[0][2], shbox[1][2]), fmin(shbox[2][2], shbox[3][2]));
-    hi0 = fmax(fmax(shbox[0][3], shbox[1][3]), fmax(shbox[2][3], shbox[3][3]));
-    hi1 = fmax(fmax(shbox[0][4], shbox[1][4]), fmax(shbox[2][4], shbox[3][4]));
-    hi2 = fmax(fmax(shbox[0][5], shbox[1][5]), fmax(shbox[2][5], shbox[3][5]));
-
-    // ---- relative reach: a lower bound of log(sum_j w_j pdf_j(x)) that holds for EVERY point of the workgroup ----
-    // For node j and any x in the box: log(w_j pdf_j(x)) >= log w_j - kappa'_j D_j^2 with D_j the distance from the mean
-    // to the farthest corner; the largest of these over the level's nodes, lref, bounds every point's sum from below.
-    // A node whose UPPER bound over the box, log w_j - kappa_j dist(box, mu_j)^2, is below lref - ln(1e20 n_nodes)
-    // cannot contribute more than 1e-20 of any point's sum even together with every other node dropped this way:
-    // four orders of magnitude below half an ulp of the sum, i.e. below what the ORDER of the additions already
-    // decides.  (The absolute test alone keeps a node until its pdf underflows, 38 sigma away; this one lets go of it
-    // ~10 sigma beyond the box.)  Every workgroup -- also the ones that take a chunk of the nodes -- looks at ALL of
-    // the level's nodes here, so that every chunk uses the same lref.
-    double lref = -INFINITY;
-    const double rel_margin = LL_REL_DROP + log((double)n_level_nodes);
-    // OPT-IN (HGMM_TREE_REL=1 -> bit 1 of the flags) and only in the large-cloud instantiation.  Measured: at 10^6
-    // points it takes the evaluated pairs from 22 % to 18 % of the reference's, 5.19 -> 5.04 ms per build -- 3 %, for
-    // which the default does not give up "q is bitwise the full sum's"; the 40 256-point build loses 0.2 ms to the
-    // extra pass (its launches are chains of latencies, and a converged bunny tree has 26 / 44 / 34 live nodes per level).
-    if (BIGTAB && n_level_nodes >= LL_REL_MIN_NODES && (fl & 2)) {
-        double best = -INFINITY;
-        for (int n0 = (int)threadIdx.x; n0 < n_level_nodes; n0 += 4 * CH) {
-            double wl[4], k2[4], u0[4], u1[4], u2[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {                  // (all twenty loads of the round in flight together)
-                const int nd = n0 + q * CH < n_level_nodes ? n0 + q * CH : n_level_nodes - 1;
-                const double* pr = prep + PREP_N * (lb + nd);
-                wl[q] = pr[10]; k2[q] = pr[PREP_KAPPA2]; u0[q] = pr[6]; u1[q] = pr[7]; u2[q] = pr[8];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (n0 + q * CH < n_level_nodes && wl[q] > 0.0 && k2[q] >= 0.0) {
-                    const double m0 = u0[q] - c0, m1 = u1[q] - c1, m2 = u2[q] - c2;
-                    const double f0 = fmax(m0 - lo0, hi0 - m0), f1 = fmax(m1 - lo1, hi1 - m1), f2 = fmax(m2 - lo2, hi2 - m2);
-                    best = fmax(best, log(wl[q]) - k2[q] * (f0 * f0 + f1 * f1 + f2 * f2));
-                }
-            }
-        }
-        best = wave_max_f64(best);
-        if (lane == 0) shl[w] = best;
-        __syncthreads();
-        lref = fmax(fmax(shl[0], shl[1]), fmax(shl[2], shl[3]));
-    }
-
-    int entered = 0;                                       // nodes that made it into this workgroup's tiles
-    for (int base = node_begin; base < node_end; base += LL_TILE) {
-        // ---- this thread's node of the tile: weight, reach test, parameters in workgroup coordinates ----
-        const int node = base + (int)threadIdx.x;
-        bool live = false;
-        double v[10];
-#pragma unroll
-        for (int e = 0; e < 10; ++e) v[e] = 0.0;
-        bool known_dead = false;                            // (weight already here and zero: nothing else is requested)
-        if constexpr (LL_WPRE > 0) {
-            const int ti = (base - node_begin) / LL_TILE;
-            if (ti < LL_WPRE) known_dead = (ti == 0 ? wpre[0] : wpre[LL_WPRE - 1]) == 0.0;
-        }
-        if (node < node_end && !known_dead) {
-            const double* pr = prep + PREP_N * (lb + node);
-            // (every field requested at once: two dependent rounds of loads are two trips to memory in a kernel
-            //  that lasts a handful of them)
-            const double wL = pr[10], kap = pr[PREP_KAPPA], u0 = pr[6], u1 = pr[7], u2 = pr[8];
-            const int fo = use_chol ? PREP_R : 0;
-            const double f0 = pr[fo], f1 = pr[fo + 1], f2 = pr[fo + 2], f3 = pr[fo + 3], f4 = pr[fo + 4], f5 = pr[fo + 5];
-            if (wL != 0.0) {
-                const double m0 = u0 - c0, m1 = u1 - c1, m2 = u2 - c2;              // mean relative to the origin
-                const double g0 = fmax(fmax(lo0 - m0, m0 - hi0), 0.0), g1 = fmax(fmax(lo1 - m1, m1 - hi1), 0.0),
-                             g2 = fmax(fmax(lo2 - m2, m2 - hi2), 0.0);
-                const double d2 = g0 * g0 + g1 * g1 + g2 * g2;                      // squared distance box <-> mean
-                live = !(kap * d2 > LL_CULL) && !(log(wL) - kap * d2 < lref - rel_margin);
-                if (live) {
-                    if (use_chol) {
-                        const double r00 = f0, r01 = f1, r02 = f2, r11 = f3, r12 = f4, r22 = f5;
-                        v[0] = r00; v[1] = r01; v[2] = r02; v[3] = r11; v[4] = r12; v[5] = r22;
-                        v[6] = -fma(r02, m2, fma(r01, m1, r00 * m0));               // -b = -R (mu - c)
-                        v[7] = -fma(r12, m2, r11 * m1);
-                        v[8] = -(r22 * m2);
-                    } else {
-                        // -1/2 Sigma^-1: the symmetric form is then the (non-positive) exponent itself
-                        v[0] = -0.5 * f0; v[1] = -0.5 * f1; v[2] = -0.5 * f2; v[3] = -0.5 * f3;
-                        v[4] = -0.5 * f4; v[5] = -0.5 * f5;
-                        v[6] = m0; v[7] = m1; v[8] = m2;
-                    }
-                    v[9] = wL;
-                }
-            }
-        }
-        const unsigned long long mask = __ballot(live);
-        const int before = __popcll(mask & ((1ull << lane) - 1ull));
-        // (wcnt of the previous tile was read before that tile's second barrier, which every wave has passed)
-        if (lane == 0) wcnt[w] = __popcll(mask);
-        __syncthreads();                                   // also: every wave is done with the previous tile
-        int off = 0, cnt = 0;
-#pragma unroll
-        for (int ww = 0; ww < CH / 64; ++ww) {
-            const int t = wcnt[ww];
-            if (ww < w) off += t;
-            cnt += t;
-        }
-        if (live) {
-            double* dst = tile[off + before];
-#pragma unroll
-            for (int e = 0; e < 10; ++e) dst[e] = v[e];
-        }
-        __syncthreads();
-        entered += cnt;
-        if (fl & 4) cnt = 0;                               // HGMM_TREE_LL_NOEVAL (measurement aid)
-        for (int k = 0; k < cnt; ++k) {
-            // (node parameters through the LDS tile: reading them with wave-uniform scalar loads
-            //  instead was measured 60 % slower for the C4 build, 8.6 vs 5.2 ms)
-            const double t0 = tile[k][0], t1 = tile[k][1], t2 = tile[k][2], t3 = tile[k][3], t4 = tile[k][4],
-                         t5 = tile[k][5], t6 = tile[k][6], t7 = tile[k][7], t8 = tile[k][8], wL = tile[k][9];
-            double yv[PTS];
-            bool need = false;
-#pragma unroll
-            for (int p = 0; p < PTS; ++p) {
-                if (use_chol) {
-                    const double z0 = fma(t2, x2[p], fma(t1, x1[p], fma(t0, x0[p], t6)));
-                    const double z1 = fma(t4, x2[p], fma(t3, x1[p], t7));
-                    const double z2 = fma(t5, x2[p], t8);
-                    yv[p] = -fma(z2, z2, fma(z1, z1, z0 * z0));                    // = -q / 2
-                } else {
-                    yv[p] = sym3_quad(t0, t1, t2, t3, t4, t5, x0[p] - t6, x1[p] - t7, x2[p] - t8);
-                }
-                need = need || (yv[p] > LL_SKIP);
-            }
-            // exp(-q / 2) underflows to exactly 0 in float64 beyond q ~ 1490: skip the exponentials when no lane
-            // of the wave needs one (points are sorted spatially); otherwise all PTS of them go through the
-            // branch-free interleaved exp (an argument below the range comes back as < 3.3e-308: nothing)
-            if (__any(need)) {
-                if constexpr (PTS == 4) {
-                    double e[4];
-                    if constexpr (BIGTAB) {
-                        if (use_chol) exp_t11_4<true>(yv, e, exp_tab); else exp_t11_4<false>(yv, e, exp_tab);
-                    } else {
-                        exp_nonpos4(yv, e, exp_tab);
-                    }
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) tot[p] = fma(wL, e[p], tot[p]);
-                } else if constexpr (PTS == 2) {
-                    double e[2];
-                    exp_nonpos2(yv, e, exp_tab);
-                    tot[0] = fma(wL, e[0], tot[0]);
-                    tot[1] = fma(wL, e[1], tot[1]);
-                } else {
-                    const double y2[2] = {yv[0], yv[0]};
-                    double e[2];
-                    exp_nonpos2(y2, e, exp_tab);
-                    tot[0] = fma(wL, e[0], tot[0]);
-                }
-            }
-        }
-    }
-    if (pair_count && threadIdx.x == 0) {
-        const int64_t rest = n - i_first;
-        const int64_t pts = rest <= 0 ? 0 : (rest < (int64_t)PTS * CH ? rest : (int64_t)PTS * CH);
-        atomicAdd(pair_count, (unsigned long long)(pts * entered));
-    }
-    if (gy > 1) {
-#pragma unroll
-        for (int p = 0; p < PTS; ++p)
-            if (active[p]) partial[(size_t)by * n_pad + i[p]] = tot[p];
-        return;
-    }
-    double lq = 0.0;
-#pragma unroll
-    for (int p = 0; p < PTS; ++p) lq += active[p] ? log(fmax(tot[p], TREE_EPS)) : 0.0;
-    lq = wave_sum_f64(lq);
-    __syncthreads();                                       // (shq is not aliased, but keep the tile loop's last readers behind)
-    if (lane_id() == 0) shq[wave_in_block()] = lq;
-    __syncthreads();
-    double t = 0.0;
-    for (int ww = 0; ww < CH / 64; ++ww) t += shq[ww];
-    store_block_q(t, block_q, bx, gx, ticket, q_out, stop);
-}
 template <int PTS, bool BIGTAB = false>
 __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restrict__ xs, int64_t n,
                                                          int64_t n_pad, const double* __restrict__ prep,
@@ -1458,21 +515,6 @@ __global__ __launch_bounds__(CH) void tree_hist_kernel(const int* __restrict__ c
     }
 }
 
-struct OpAddInt { __device__ __forceinline__ int operator()(int a, int b) const { return a + b; } };
-// inclusive prefix sum of one int per lane over the wave (DPP row_shr with zero fill + row broadcasts, no LDS)
-template <int CTRL, int ROW_MASK = 0xF>
-__device__ __forceinline__ int dpp_i32_zero(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, true);
-}
-__device__ __forceinline__ int wave_scan_i32(int v) {
-    v += dpp_i32_zero<0x111>(v);                  // row_shr:1
-    v += dpp_i32_zero<0x112>(v);                  // row_shr:2
-    v += dpp_i32_zero<0x114>(v);                  // row_shr:4
-    v += dpp_i32_zero<0x118>(v);                  // row_shr:8
-    v += dpp_i32_zero<DPP_ROW_BCAST15, 0xA>(v);
-    v += dpp_i32_zero<DPP_ROW_BCAST31, 0xC>(v);
-    return v;
-}
 
 // one WORKGROUP per parent: new segment sizes + per-chunk write offsets (relative to the parent's segment start,
 // children laid out k = 0..7 inside it).  Level 0 has ONE parent owning every chunk of the cloud (3907 at N = 1M):
@@ -1580,41 +622,6 @@ __global__ void tree_unsort_kernel(const int* __restrict__ perm, const int* __re
     if (i < n) out[perm[i]] = cur_sorted[i];
 }
 
-// ------------------------------------------------------------------------------------------
-// registration E-step (gmmTreeRegESTep, hgmm_cupy_cpu_working.py:202-228)
-// ------------------------------------------------------------------------------------------
-struct Rigid { double r[9]; double t[3]; double s; };
-
-
-// The moment accumulation of this E-step is the one place of the library where contributions from arbitrary
-// workgroups meet in the same memory words (a target point may land in any node; the points are not grouped by
-// node, and their tree paths change with every (R, t)).  Floating-point atomics would make the result depend on
-// arrival order, so the sums are taken in 64-bit FIXED POINT, where addition is associative: every run, every
-// grid shape and every sharding of the target gives bit-identical moments.
-//   * moments are taken about the node's own mean and scaled by the extent D (a power of two >= any |x - mu|):
-//     gamma (x - mu) / D and gamma (x - mu)(x - mu)^T / D^2 lie in [-1, 1], gamma in [0, 1];
-//   * scale 2^F, F = 62 - ceil(log2(n + 1)): n terms cannot overflow, resolution 2^-F (n = 40 k: 1.4e-14,
-//     n = 1 M: 2.3e-13, relative to D resp. D^2) -- below the 1e-12 the parity tests allow;
-//   * the registration M-step needs exactly these centred quantities (s - mu = c1 / m0), see tree_reg_normal_kernel.
-// NMQ = 10 (m0, c1[3], C2 unique[6]) for the API's full moment set, 4 (m0, c1) inside the registration loop.
-template <int CTRL, int MASK>
-__device__ __forceinline__ long long dpp_i64_or0(long long x) {           // lanes outside the row mask read 0
-    int lo = (int)(x & 0xffffffffLL), hi = (int)(x >> 32);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, MASK, 0xF, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, MASK, 0xF, true);
-    return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
-}
-__device__ __forceinline__ long long wave_sum_i64(long long v) {          // exact: integer adds, any order
-    v += dpp_i64_or0<DPP_QUAD_XOR1, 0xF>(v);
-    v += dpp_i64_or0<DPP_QUAD_XOR2, 0xF>(v);
-    v += dpp_i64_or0<DPP_ROW_HALF_MIRROR, 0xF>(v);
-    v += dpp_i64_or0<DPP_ROW_MIRROR, 0xF>(v);
-    v += dpp_i64_or0<DPP_ROW_BCAST15, 0xA>(v);
-    v += dpp_i64_or0<DPP_ROW_BCAST31, 0xC>(v);
-    const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffLL), 63);
-    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
-    return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
-}
 
 template <int NMQ>
 __global__ __launch_bounds__(CH) void tree_reg_estep_kernel(const double* __restrict__ tg, int64_t n,
