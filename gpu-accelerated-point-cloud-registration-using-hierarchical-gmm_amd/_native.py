@@ -134,6 +134,14 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_kmeans_center_f64", [_vp, C.c_int64, _vp, _vp, _vp])
         _sig(lib, "hgmm_tree_register", [ctx, _vp, _vp, C.c_double, C.c_double, C.c_int, C.c_double, _vp,
                                          C.POINTER(C.c_int), C.POINTER(C.c_int), _vp])
+        _i64p, _i32p = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+        _sig(lib, "hgmm_set_points_batch_f64", [ctx, C.c_int, C.POINTER(_vp), _i64p])
+        _sig(lib, "hgmm_tree_build_batch", [ctx, C.c_int, _i64p, C.c_int, C.c_double, C.c_double, _vp, C.c_double, C.c_int,
+                                            _vp, _vp, _vp, _vp, _vp, C.c_int, _vp])
+        _sig(lib, "hgmm_tree_get_nodes_batch", [ctx, C.c_int, _vp, _vp, _vp])
+        _sig(lib, "hgmm_tree_set_targets_batch", [ctx, C.c_int, C.POINTER(_vp), _i64p])
+        _sig(lib, "hgmm_tree_register_batch", [ctx, C.c_int, _vp, _vp, C.c_double, C.c_double, C.c_int, C.c_double, _vp,
+                                               _vp, _vp, _vp])
         _lib = lib
         return lib
 
@@ -944,6 +952,79 @@ class Context:
                                                 float(tol), _ptr(q), C.byref(done), C.byref(status), _ptr(trace)))
         q_out = None if np.isnan(q[0]) else float(q[0])
         return rot, t, done.value, q_out, status.value, (None if trace is None else trace[:done.value])
+
+    # -- batched HGMM: B independent clouds / scan pairs per launch set (hgmm_tree_*_batch) ------------------------------
+    @staticmethod
+    def _cloud_list(clouds, what):
+        arrs = [np.ascontiguousarray(getattr(a, "points", a), dtype=np.float64) for a in clouds]
+        if not arrs:
+            raise ValueError("%s: no clouds" % what)
+        for a in arrs:
+            if a.ndim != 2 or a.shape[1] != 3 or a.shape[0] < 1:
+                raise ValueError("%s: every cloud must be [N,3] with N >= 1, got %s" % (what, a.shape))
+        ptrs = (_vp * len(arrs))(*[a.ctypes.data for a in arrs])
+        counts = (C.c_int64 * len(arrs))(*[a.shape[0] for a in arrs])
+        return arrs, ptrs, counts
+
+    def set_points_batch(self, clouds):
+        """B clouds [N_b,3] become ONE resident cloud, cloud after cloud, each uploaded from its own array
+        (hgmm_set_points_batch_f64).  -> the float64 arrays that were uploaded (their lengths are the forest's counts)."""
+        arrs, ptrs, counts = self._cloud_list(clouds, "set_points_batch")
+        self._check(self.lib.hgmm_set_points_batch_f64(self.h, len(arrs), ptrs, counts))
+        self.n = int(sum(a.shape[0] for a in arrs))
+        self._batch_counts = [a.shape[0] for a in arrs]
+        return arrs
+
+    def tree_build_batch(self, counts, L, ls, ld, init_mu, sig2, max_iters_per_level=1000, want_tables=True,
+                         want_trace=False, q_capacity=None):
+        """``B = len(counts)`` trees on the resident cloud's consecutive pieces in the same launches (hgmm_tree_build_batch);
+        each bitwise what :meth:`tree_build` gives for that piece alone.  ``init_mu`` [B,T,3].
+        -> (pi [B,T], mu [B,T,3], cov [B,T,3,3]) or (None, None, None), iters [B,L], list of q traces or None."""
+        B = len(counts)
+        T = 8 * (8 ** L - 1) // 7
+        init_mu = np.ascontiguousarray(init_mu, dtype=np.float64)
+        if init_mu.shape != (B, T, 3):
+            raise ValueError("init_mu must be [%d,%d,3]" % (B, T))
+        cnt = (C.c_int64 * B)(*[int(v) for v in counts])
+        pi = np.empty((B, T)) if want_tables else None
+        mu = np.empty((B, T, 3)) if want_tables else None
+        cov = np.empty((B, T, 3, 3)) if want_tables else None
+        iters = np.zeros((B, L), np.int32)
+        qcap = int(q_capacity or L * min(max_iters_per_level, 4096)) if want_trace else 0
+        q = np.zeros((B, qcap)) if want_trace else None
+        qlen = np.zeros(B, np.int32) if want_trace else None
+        self._check(self.lib.hgmm_tree_build_batch(self.h, B, cnt, int(L), float(ls), float(ld), _ptr(init_mu), float(sig2),
+                                                   int(max_iters_per_level), _ptr(pi), _ptr(mu), _ptr(cov), _ptr(iters),
+                                                   _ptr(q), qcap, _ptr(qlen)))
+        traces = [q[b, :qlen[b]].copy() for b in range(B)] if want_trace else None
+        return (pi, mu, cov), iters, traces
+
+    def tree_get_nodes_batch(self, b, L):
+        T = 8 * (8 ** L - 1) // 7
+        pi, mu, cov = np.empty(T), np.empty((T, 3)), np.empty((T, 3, 3))
+        self._check(self.lib.hgmm_tree_get_nodes_batch(self.h, int(b), _ptr(pi), _ptr(mu), _ptr(cov)))
+        return pi, mu, cov
+
+    def tree_set_targets_batch(self, targets):
+        arrs, ptrs, counts = self._cloud_list(targets, "tree_set_targets_batch")
+        self._check(self.lib.hgmm_tree_set_targets_batch(self.h, len(arrs), ptrs, counts))
+        return arrs
+
+    def tree_register_batch(self, rot, t, scale=1.0, lambda_c=0.01, max_iter=20, tol=1.0e-4, q_prev=None, want_trace=False):
+        """Up to ``max_iter`` registration iterations of every (tree b, target b) pair of the resident forest in the same
+        launches (hgmm_tree_register_batch), each bitwise :meth:`tree_register` on that pair.
+        -> (rot [B,3,3], t [B,3], iterations [B], q [B] (NaN: none), status [B], traces or None)."""
+        rot = np.array(rot, dtype=np.float64).reshape(-1, 3, 3)
+        B = rot.shape[0]
+        t = np.array(t, dtype=np.float64).reshape(B, 3)
+        q = np.full(B, np.nan) if q_prev is None else np.array(q_prev, dtype=np.float64).reshape(B)
+        iters, status = np.zeros(B, np.int32), np.zeros(B, np.int32)
+        trace = np.zeros((B, max(int(max_iter), 1), 13)) if want_trace else None
+        self._check(self.lib.hgmm_tree_register_batch(self.h, B, _ptr(rot), _ptr(t), float(scale), float(lambda_c),
+                                                      int(max_iter), float(tol), _ptr(q), _ptr(iters), _ptr(status),
+                                                      _ptr(trace)))
+        traces = [trace[b, :iters[b]] for b in range(B)] if want_trace else None
+        return rot, t, iters, q, status, traces
 
     @staticmethod
     def _node_tables(pi, mu, cov):

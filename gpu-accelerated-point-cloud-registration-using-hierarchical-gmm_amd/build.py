@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhgmm_hip.so")
-SOURCES = ["hgmm_api.hip", "flat_kernels.hip", "tree_kernels.hip", "kmeans_kernels.hip", "gmmreg_kernels.hip"]
+SOURCES = ["hgmm_api.hip", "flat_kernels.hip", "tree_kernels.hip", "tree_batch.hip", "kmeans_kernels.hip", "gmmreg_kernels.hip"]
 HEADERS = ["hgmm_ctx.h", "wave_ops.h", "tree_device.h", os.path.join("..", "..", "include", "hgmm.h")]
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")

@@ -683,10 +683,13 @@ extern "C" int hgmm_destroy(hgmm_ctx* c) {
                       &c->t_parent, &c->t_current, &c->t_perm, &c->t_seg, &c->t_chunks, &c->t_partials,
                       &c->t_q, &c->tgt_soa64, &c->comm_buf, &c->t_xs3, &c->t_llp, &c->t_qtrace, &c->f_cm, &c->f_cs, &c->f_ca, &c->f_lpn2,
                       &c->km_closest, &c->km_block, &c->km_centres, &c->km_ids, &c->km_rand, &c->km_labels,
-                      &c->km_mind2, &c->km_partial, &c->km_out, &c->gt_buf, &c->t_momq, &c->t_flags, &c->exp_tab2, &c->t_tickets};
+                      &c->km_mind2, &c->km_partial, &c->km_out, &c->gt_buf, &c->t_momq, &c->t_flags, &c->exp_tab2, &c->t_tickets,
+                      &c->fr_pi, &c->fr_mu, &c->fr_cov, &c->fr_prep, &c->fr_mom, &c->fr_clouds, &c->fr_q, &c->fr_trace, &c->fr_tg,
+                      &c->fr_momq, &c->fr_reg};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->forest.host) (void)hipHostFree(c->forest.host);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
     for (hipEvent_t& e : c->ev_slots) if (e) (void)hipEventDestroy(e);
     if (c->pace.have_events)
@@ -854,6 +857,46 @@ extern "C" int hgmm_set_points_f64(hgmm_ctx* c, const double* xyz, int64_t n) {
     bind_points(c, nullptr);
     HGMM_TRY(points_upload_f64(c, &c->own_points, xyz, n));
     bind_points(c, &c->own_points);
+    return HGMM_OK;
+}
+
+// B clouds back to back as ONE resident cloud (the forest of hgmm_tree_build_batch): every cloud is uploaded from its own
+// host array -- no concatenated copy on the host -- into the context's own storage.  Only the float64 structure of arrays is
+// filled (the HGMM kernels' view); the flat EM's float32 rows are not, and the flat entry points say so.
+__global__ void aos_to_soa64_at(const double* __restrict__ in, int64_t n, int64_t first, int64_t n_pad,
+                                double* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int d = 0; d < 3; ++d) out[d * n_pad + first + i] = in[3 * i + d];
+}
+extern "C" int hgmm_set_points_batch_f64(hgmm_ctx* c, int B, const double* const* xyz, const int64_t* counts) {
+    HGMM_ENTER(c);
+    if (B < 1 || !xyz || !counts) return fail(c, HGMM_ERR_ARG, "set_points (batch): B = %d", B);
+    int64_t total = 0;
+    for (int b = 0; b < B; ++b) {
+        if (!xyz[b] || counts[b] < 1) return fail(c, HGMM_ERR_ARG, "set_points (batch): cloud %d is empty", b);
+        total += counts[b];
+    }
+    bind_points(c, nullptr);
+    hgmm_points* p = &c->own_points;
+    HGMM_TRY(points_alloc(c, p, total));
+    HGMM_TRY(ensure(c, c->scratch, sizeof(double) * 3 * (size_t)total));
+    double* stage = c->scratch.as<double>();
+    if (p->n_pad > total)                                    // the padding rows read as the origin, like hgmm_set_points_f64's
+        for (int d = 0; d < 3; ++d)
+            HGMM_HIP(c, hipMemsetAsync(p->x_soa64.as<double>() + (size_t)d * p->n_pad + total, 0,
+                                       sizeof(double) * (size_t)(p->n_pad - total), c->stream));
+    int64_t at = 0;
+    for (int b = 0; b < B; ++b) {
+        HGMM_HIP(c, hipMemcpyAsync(stage + 3 * at, xyz[b], sizeof(double) * 3 * (size_t)counts[b], hipMemcpyHostToDevice, c->stream));
+        aos_to_soa64_at<<<(unsigned)((counts[b] + 255) / 256), 256, 0, c->stream>>>(stage + 3 * at, counts[b], at, p->n_pad,
+                                                                                    p->x_soa64.as<double>());
+        at += counts[b];
+    }
+    HGMM_HIP(c, hipGetLastError());
+    HGMM_HIP(c, ctx_stream_sync(c));
+    bind_points(c, p);
+    c->have_f32 = false;
     return HGMM_OK;
 }
 

@@ -84,6 +84,23 @@ struct TreeState {
     unsigned long long reg_seq = 0;   // sequence number of the last registration system handed over in pinned memory
 };
 
+// A FOREST: B independent clouds whose trees are built / whose targets are registered by the same launches
+// (tree_batch.hip: hgmm_tree_build_batch, hgmm_tree_set_targets_batch, hgmm_tree_register_batch)
+struct ForestState {
+    int B = 0, L = 0, T = 0;
+    bool nodes_ready = false;
+    std::vector<int64_t> counts;          // points per cloud (they lie back to back in the context's resident cloud)
+    std::vector<double> mu_rmax;          // largest |mu_j| per tree (extent bound of the fixed-point moments)
+    int tg_B = 0;
+    std::vector<int64_t> tg_counts, tg_first;
+    std::vector<double> tg_rmax;          // largest |x| per target
+    int64_t tg_pad = 0;
+    bool momq_clean = false;              // every word of fr_momq is zero
+    unsigned long long seq = 0;           // sequence number of the last hand-over through pinned memory
+    void* host = nullptr;                 // pinned, coherent: progress words of the build, hand-over of the registration
+    size_t host_cap = 0;
+};
+
 }  // namespace hgmm
 
 // A point cloud resident in HBM that outlives the calls made on it (hgmm_points_create_*): the float32 row-major copy the
@@ -158,6 +175,16 @@ struct hgmm_ctx {
     hgmm::DevBuf tgt_soa64;                   // double [3][m_pad] registration target
     int64_t tgt_n = 0, tgt_pad = 0;
     double tgt_rmax = 0.0;                    // largest |x| of the target (extent bound of the fixed-point moments)
+
+    // ---- forest (batched trees: tree_batch.hip) ------------------------------------
+    hgmm::ForestState forest;
+    hgmm::DevBuf fr_pi, fr_mu, fr_cov, fr_prep, fr_mom;   // node tables [B T], as t_pi ... t_mom
+    hgmm::DevBuf fr_clouds;                   // ForestCloud [B] + int flags [B]
+    hgmm::DevBuf fr_q;                        // double: the clouds' shares of q
+    hgmm::DevBuf fr_trace;                    // double [B][L][trace_cap]
+    hgmm::DevBuf fr_tg;                       // double [3][tg_pad] the targets, back to back
+    hgmm::DevBuf fr_momq;                     // uint64 [B T][4] registration sums
+    hgmm::DevBuf fr_reg;                      // per-pair registration table + the 28 numbers per pair + per-pair r2max words
 
     // ---- KMeans initialiser (float64, on x_soa64) -----------------------------------
     hgmm::DevBuf km_closest;                  // double [n_pad] k-means++: min squared distance so far

@@ -357,9 +357,24 @@ struct TreeFollow {                      // q_blocks == nullptr: nothing to foll
     const double* q_blocks; int nb;
     const TreeLoopState* prev; TreeLoopState* next;
     int* done; double ls; int max_iters; double* trace; int trace_cap; unsigned long long* host_word;
+    int* final_it = nullptr;             // forest (tree_batch.hip): receives the level's iteration count together with *done
 };
+// what the workgroup that speaks for the loop leaves behind (one thread)
+__device__ __forceinline__ void tree_follow_record(const TreeFollow& f, int it, double q, bool stop_now) {
+    if (it < f.trace_cap) f.trace[it] = q;
+    f.next->it = it + 1;
+    f.next->prev_q = q;
+    if (stop_now) {
+        if (f.final_it) *f.final_it = it + 1;
+        *f.done = 1;
+    }
+    if (f.host_word)
+        __hip_atomic_store(f.host_word, ((unsigned long long)(stop_now ? 1 : 0) << 32) | (unsigned long long)(unsigned)(it + 1),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // true: the level has stopped -- this launch has nothing to do.  Called by all threads of a CH-thread workgroup.
-__device__ __forceinline__ bool tree_follow(const TreeFollow& f, int stop_flag, double* sh4) {
+// `speaker`: this workgroup records the verdict (serial build: workgroup 0 of the launch; forest: the cloud's first)
+__device__ __forceinline__ bool tree_follow(const TreeFollow& f, int stop_flag, double* sh4, bool speaker) {
     const double prev_q = f.prev->prev_q;                 // (requested together with the shares)
     const int it = f.prev->it;
     double acc = 0.0;
@@ -370,14 +385,8 @@ __device__ __forceinline__ bool tree_follow(const TreeFollow& f, int stop_flag, 
     __syncthreads();
     const double q = sh4[0] + sh4[1] + sh4[2] + sh4[3];
     const bool stop_now = fabs(q - prev_q) < f.ls || it + 1 >= f.max_iters;      // (hgmm_gpu.py:532; prev_q starts at 0)
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (it < f.trace_cap) f.trace[it] = q;
-        f.next->it = it + 1;
-        f.next->prev_q = q;
-        if (stop_now) *f.done = 1;
-        if (f.host_word)
-            __hip_atomic_store(f.host_word, ((unsigned long long)(stop_now ? 1 : 0) << 32) | (unsigned long long)(unsigned)(it + 1),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (speaker && threadIdx.x == 0) {
+        tree_follow_record(f, it, q, stop_now);
     }
     return stop_now;
 }
@@ -399,7 +408,7 @@ __device__ __forceinline__ TreeFollowLoads tree_follow_wave_load(const TreeFollo
     }
     return r;
 }
-__device__ __forceinline__ bool tree_follow_wave_verdict(const TreeFollow& f, TreeFollowLoads r, int stop_flag) {
+__device__ __forceinline__ bool tree_follow_wave_verdict(const TreeFollow& f, TreeFollowLoads r, int stop_flag, bool speaker) {
     if (stop_flag) return true;
 #pragma unroll
     for (int w = 0; w < CH / 64; ++w) r.acc[w] = wave_sum_f64(r.acc[w]);
@@ -409,14 +418,8 @@ __device__ __forceinline__ bool tree_follow_wave_verdict(const TreeFollow& f, Tr
     const double prev_q = r.prev_q;
     const int it = r.it;
     const bool stop_now = fabs(q - prev_q) < f.ls || it + 1 >= f.max_iters;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (it < f.trace_cap) f.trace[it] = q;
-        f.next->it = it + 1;
-        f.next->prev_q = q;
-        if (stop_now) *f.done = 1;
-        if (f.host_word)
-            __hip_atomic_store(f.host_word, ((unsigned long long)(stop_now ? 1 : 0) << 32) | (unsigned long long)(unsigned)(it + 1),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (speaker && threadIdx.x == 0) {
+        tree_follow_record(f, it, q, stop_now);
     }
     return stop_now;
 }
@@ -434,13 +437,41 @@ struct TreeEstepArgs {
     const double* xs; int64_t n_pad; const double* prep; const int* chunk_desc; const int* n_chunks;
     int64_t parent_level_first; int level; double* partials; int* cur_sorted; const int* done;
 };
+// A FOREST (tree_batch.hip): B independent clouds whose points lie back to back in one resident cloud and whose trees are
+// built by the same launches.  At level l the forest has B 8^l parent segments; segment p belongs to cloud p >> 3 l and is
+// the (p mod 8^l)-th parent of that cloud's level; cloud b's nodes are [b T, (b + 1) T) of the node tables.  Every
+// workgroup works for exactly one cloud and runs the arithmetic of the serial build of that cloud -- the same chunks, the
+// same orders of summation -- so a forest's trees are the serial trees bit for bit.
+struct alignas(128) ForestCloud {
+    int pt_first, pt_count;          // its points in the forest's order (every level's partition keeps a cloud contiguous)
+    int ll_gx, ll_gy, ll_per_chunk;  // the log-likelihood decomposition the SERIAL build uses for this cloud at this level: gx
+                                     //   blocks of PTS CH points x gy node chunks (reproduced for the order of its sums)
+    int q_first, q_count;            // its shares of q in block_q
+    int done;                        // device-written: the level has stopped ...
+    int final_it;                    //   ... after this many iterations
+    int pad;
+    double n_total;                  // pi = m0 / n_total
+    TreeLoopState st[2];             // tree_follow's state, double-buffered by launch parity
+};
+struct ForestArgs {
+    ForestCloud* clouds; int B; int T; int shift;       // shift = 3 l
+    double ls; int max_iters; double* trace_base; int trace_cap; int L; int level; unsigned long long* host_words;
+};
+// the follow of cloud b for the launch that follows iteration e - 1 (fc: the cloud's entry, already loaded)
+__device__ __forceinline__ TreeFollow forest_follow(const ForestArgs& fa, int b, int e, const double* block_q, int q_first,
+                                                    int q_count) {
+    ForestCloud* fc = fa.clouds + b;
+    return TreeFollow{block_q + q_first, q_count, fc->st + ((e - 1) & 1), fc->st + (e & 1), &fc->done, fa.ls, fa.max_iters,
+                      fa.trace_base + ((size_t)b * fa.L + fa.level) * fa.trace_cap, fa.trace_cap,
+                      fa.host_words ? fa.host_words + b : nullptr, &fc->final_it};
+}
 // (c = the workgroup's chunk: blockIdx.x in tree_estep_kernel, an offset of it in tree_ll_estep_kernel)
 // LDS of one E-step workgroup, in doubles: exp table, tree_follow's four, the waves' [8][NMOM] sums, gamma rows, feature rows
 template <bool HALF>
 constexpr int tree_estep_lds() { return EXP_TAB_N + 4 + (CH / 64) * 8 * NMOM + (CH / 64) * (8 + NMOM) * (HALF ? ES_LD / 2 + 1 : ES_LD); }
-template <bool HALF>
+template <bool HALF, bool FOREST = false>
 __device__ __forceinline__ void tree_estep_body(const int c, const TreeEstepArgs& a, const TreeFollow& follow,
-                                                double* __restrict__ smem) {
+                                                double* __restrict__ smem, const ForestArgs* fa = nullptr) {
     const double* __restrict__ xs = a.xs;
     const int64_t n_pad = a.n_pad;
     const double* __restrict__ prep = a.prep;
@@ -453,25 +484,39 @@ __device__ __forceinline__ void tree_estep_body(const int c, const TreeEstepArgs
     const int* __restrict__ done = a.done;
     // (the stop flag, the chunk count and this chunk's descriptor are requested together -- the descriptor table is
     //  allocated for the whole grid, so the read is safe before the count is known: one trip to memory instead of three)
-    const int stop_flag = done ? *done : 0;        // the level converged in an earlier iteration of this batch
+    int stop_flag = (!FOREST && done) ? *done : 0; // the level converged in an earlier iteration of this batch
     const int chunks_now = *n_chunks;
     const int p = chunk_desc[3 * c + 0], begin = chunk_desc[3 * c + 1], end = chunk_desc[3 * c + 2];
     double* exp_tab = smem;
     double* sh_follow = smem + EXP_TAB_N;
     exp_tab_load(exp_tab);                         // (synchronised below, once the points' loads are on their way)
     if (c >= chunks_now) return;                   // (workgroup 0 always owns a chunk)
-    if (follow.q_blocks) {
-        if (tree_follow(follow, stop_flag, sh_follow)) return;       // the previous iteration's q stopped the level
-    } else if (stop_flag) {
-        return;
-    }
-    // node id of the parent: level 0 -> pseudo-parent -1; child(j) = 8 (j + 1)
-    const int64_t parent_node = (level == 0) ? -1 : parent_level_first + p;
-    const int64_t j0 = 8 * (parent_node + 1);
     const int i = begin + (int)threadIdx.x;
     const bool active = i < end;
     double x0 = 0.0, x1 = 0.0, x2 = 0.0;
-    if (active) { x0 = xs[i]; x1 = xs[n_pad + i]; x2 = xs[2 * n_pad + i]; }
+    int pl = p;                                    // the parent's index within its cloud's level
+    int64_t node_off = 0;                          // first node of the cloud's tree
+    if constexpr (FOREST) {
+        // (the cloud's stop flag hangs on the descriptor: it is requested together with the points)
+        const int b = p >> fa->shift;
+        pl = p & ((1 << fa->shift) - 1);
+        node_off = (int64_t)b * fa->T;
+        stop_flag = fa->clouds[b].done;
+        if (active) { x0 = xs[i]; x1 = xs[n_pad + i]; x2 = xs[2 * n_pad + i]; }
+        if (stop_flag) return;                     // (a forest's E-steps never follow: launch e = 0 and the speculative ones)
+    } else {
+        if (follow.q_blocks) {
+            if (tree_follow(follow, stop_flag, sh_follow, blockIdx.x == 0)) return;   // the previous iteration's q stopped the level
+        } else if (stop_flag) {
+            return;
+        }
+    }
+    // node id of the parent: level 0 -> pseudo-parent -1; child(j) = 8 (j + 1)
+    const int64_t parent_node = (level == 0) ? -1 : parent_level_first + pl;
+    const int64_t j0 = node_off + 8 * (parent_node + 1);
+    if constexpr (!FOREST) {
+        if (active) { x0 = xs[i]; x1 = xs[n_pad + i]; x2 = xs[2 * n_pad + i]; }
+    }
     __syncthreads();                               // exp_tab
 
     double g[8];
@@ -697,12 +742,17 @@ struct TreeLoglikArgs {
     const double* xs; int64_t n; int64_t n_pad; const double* prep; int64_t lb; int n_level_nodes; int nodes_per_chunk;
     double* partial; double* block_q; unsigned int* ticket; double* q_out; const int* done; TreeStop stop;
     const int* flags; unsigned long long* pair_count; const double* exp2_tab;
+    int64_t i_base = 0; int q_count = 0;     // forest: the cloud's first point (n = one past its last), its number of q shares
 };
 // (bx, by) of a (gx, gy) grid: blockIdx / gridDim in tree_loglik_kernel, a slice of a 1-d grid in tree_ll_estep_kernel
 // LDS of one log-likelihood workgroup, in doubles: node tile, exp table, the waves' q / boxes / lref, the waves' counts (ints)
 template <bool BIGTAB>
 constexpr int tree_loglik_lds() { return LL_TILE * 10 + (BIGTAB ? EXP_TAB2_N : EXP_TAB_N) + (CH / 64) * (1 + 6 + 1) + (CH / 64) / 2; }
-template <int PTS, bool BIGTAB>
+// FOREST (tree_batch.hip): the workgroup takes ALL node chunks of its point block one after the other and adds the chunk
+// sums in chunk order, then forms the shares of q the serial build's finish kernel would (one per 256 points) -- the serial
+// sums in the serial order, without the serial form's [chunk][point] round trip (a forest fills the chip without
+// splitting the nodes); a node's parameters are requested only once its weight has turned out non-zero.
+template <int PTS, bool BIGTAB, bool FOREST = false>
 __device__ __forceinline__ void tree_loglik_body(const int bx, const int by, const int gx, const int gy,
                                                  const TreeLoglikArgs& a, double* __restrict__ smem) {
     const double* __restrict__ xs = a.xs;
@@ -731,7 +781,7 @@ __device__ __forceinline__ void tree_loglik_body(const int bx, const int by, con
     const int fl = flags ? *flags : 0;
     const int w = wave_in_block(), lane = lane_id();
     // origin: the workgroup's first point
-    const int64_t i_first = (int64_t)bx * PTS * CH;
+    const int64_t i_first = (FOREST ? a.i_base : (int64_t)0) + (int64_t)bx * PTS * CH;
     const int64_t i_c = i_first < n ? i_first : n - 1;
     const double c0 = xs[i_c], c1 = xs[n_pad + i_c], c2 = xs[2 * n_pad + i_c];
     int64_t i[PTS];
@@ -753,9 +803,9 @@ __device__ __forceinline__ void tree_loglik_body(const int bx, const int by, con
     // loop asks for at once -- 70 KB per workgroup, 88 MB per launch of a kernel that lasts 15 us (C4: 2.32 -> 2.27 ms).
     // (Also tried for these instantiations and dropped: two nodes per step of the evaluation loop, four exponentials
     //  interleaved -- 2.29 ms: the loop is not what these launches wait for.)
-    constexpr int LL_WPRE = BIGTAB ? 0 : 2;
-    const int node_begin = by * nodes_per_chunk;
-    const int node_end = (node_begin + nodes_per_chunk < n_level_nodes) ? node_begin + nodes_per_chunk : n_level_nodes;
+    constexpr int LL_WPRE = (BIGTAB || FOREST) ? 0 : 2;
+    int node_begin = by * nodes_per_chunk;
+    int node_end = (node_begin + nodes_per_chunk < n_level_nodes) ? node_begin + nodes_per_chunk : n_level_nodes;
     double wpre[LL_WPRE > 0 ? LL_WPRE : 1];
 #pragma unroll
     for (int t = 0; t < LL_WPRE; ++t) {
@@ -830,6 +880,15 @@ __device__ __forceinline__ void tree_loglik_body(const int bx, const int by, con
     }
 
     int entered = 0;                                       // nodes that made it into this workgroup's tiles
+    [[maybe_unused]] double totsum[PTS];                   // forest: the chunk sums added in chunk order (tree_loglik_finish_kernel)
+#pragma unroll
+    for (int p = 0; p < PTS; ++p) totsum[p] = 0.0;
+    const int cy_end = FOREST ? gy : 1;
+    for (int cy = 0; cy < cy_end; ++cy) {
+    if constexpr (FOREST) {
+        node_begin = cy * nodes_per_chunk;
+        node_end = (node_begin + nodes_per_chunk < n_level_nodes) ? node_begin + nodes_per_chunk : n_level_nodes;
+    }
     for (int base = node_begin; base < node_end; base += LL_TILE) {
         // ---- this thread's node of the tile: weight, reach test, parameters in workgroup coordinates ----
         const int node = base + (int)threadIdx.x;
@@ -841,6 +900,9 @@ __device__ __forceinline__ void tree_loglik_body(const int bx, const int by, con
         if constexpr (LL_WPRE > 0) {
             const int ti = (base - node_begin) / LL_TILE;
             if (ti < LL_WPRE) known_dead = (ti == 0 ? wpre[0] : wpre[LL_WPRE - 1]) == 0.0;
+        }
+        if constexpr (FOREST) {
+            if (node < node_end) known_dead = prep[PREP_N * (lb + node) + 10] == 0.0;
         }
         if (node < node_end && !known_dead) {
             const double* pr = prep + PREP_N * (lb + node);
@@ -938,6 +1000,32 @@ __device__ __forceinline__ void tree_loglik_body(const int bx, const int by, con
             }
         }
     }
+    if constexpr (FOREST) {
+        if (gy > 1) {
+#pragma unroll
+            for (int p = 0; p < PTS; ++p) { totsum[p] += tot[p]; tot[p] = 0.0; }
+        }
+    }
+    }
+    if constexpr (FOREST) {
+        if (gy > 1) {
+            // the serial build's tree_loglik_finish_kernel: one share per 256 points = per p of this workgroup
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < PTS; ++p) {
+                double lq = active[p] ? log(fmax(totsum[p], TREE_EPS)) : 0.0;
+                lq = wave_sum_f64(lq);
+                if (p > 0) __syncthreads();                // the previous share has been summed
+                if (lane_id() == 0) shq[wave_in_block()] = lq;
+                __syncthreads();
+                double t = 0.0;
+                for (int ww = 0; ww < CH / 64; ++ww) t += shq[ww];
+                const int share = bx * PTS + p;
+                if (threadIdx.x == 0 && share < a.q_count) block_q[share] = t;
+            }
+            return;
+        }
+    }
     if (pair_count && threadIdx.x == 0) {
         const int64_t rest = n - i_first;
         const int64_t pts = rest <= 0 ? 0 : (rest < (int64_t)PTS * CH ? rest : (int64_t)PTS * CH);
@@ -1012,5 +1100,367 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {          // exa
     const int hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
     return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
 }
+
+// (i: the thread's target point in `tg`, alive: it exists; prep / momq: the node table and the sums of THIS tree)
+constexpr int REG_LDS_NODES = 584;                       // levels 0..2 (8 + 64 + 512 nodes)
+template <int NMQ>
+__device__ __forceinline__ void tree_reg_estep_body(const int64_t i, bool alive, const double* __restrict__ tg,
+                                                    int64_t n_pad, const Rigid& tf, const double* __restrict__ prep, int L,
+                                                    double lambda_c, double inv_d, double fix_scale,
+                                                    unsigned long long* __restrict__ momq,
+                                                    unsigned long long* __restrict__ tab /* LDS [REG_LDS_NODES * NMQ] */) {
+    const int lds_nodes = (int)(level_first(L < 3 ? L : 3));
+    for (int e = threadIdx.x; e < lds_nodes * NMQ; e += CH) tab[e] = 0ull;
+    __syncthreads();
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+    if (alive) {
+        const double a = tg[i], b = tg[n_pad + i], c = tg[2 * n_pad + i];
+        // (explicit fused operations: the serial and the batched kernel must round alike whatever the compiler would pick)
+        x0 = fma(tf.s, fma(tf.r[2], c, fma(tf.r[1], b, tf.r[0] * a)), tf.t[0]);
+        x1 = fma(tf.s, fma(tf.r[5], c, fma(tf.r[4], b, tf.r[3] * a)), tf.t[1]);
+        x2 = fma(tf.s, fma(tf.r[8], c, fma(tf.r[7], b, tf.r[6] * a)), tf.t[2]);
+    }
+    int64_t search = -1;
+    for (int l = 0; l < L; ++l) {
+        if (!__any(alive)) break;
+        const int64_t j0 = 8 * (search + 1);
+        double g[8];
+        double den = 0.0;
+        if (alive) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const double* pr = prep + PREP_N * (j0 + k);
+                const double d0 = x0 - pr[6], d1 = x1 - pr[7], d2 = x2 - pr[8];
+                const double q = sym3_quad(pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], d0, d1, d2);
+                const double wE = pr[9];
+                g[k] = (wE == 0.0) ? 0.0 : wE * exp(-0.5 * q);
+                den += g[k];
+            }
+        }
+        double gs = 0.0;
+        int64_t s = 0;
+        bool contribute = false;
+        if (alive) {
+            const bool good = den > TREE_EPS;
+            int am = 0;
+            double best = -1.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const double gk = good ? g[k] / den : 0.0;
+                if (gk > best) { best = gk; am = k; }
+            }
+            s = j0 + am;
+            search = s;
+            if (prep[PREP_N * s + 11] <= lambda_c) {       // complexity(cov_s) <= lambda_c: stop
+                alive = false;
+            } else {
+                gs = best;
+                contribute = !(gs < TREE_EPS);
+            }
+        }
+        // this lane's contribution in fixed point, about the node's mean, in units of D
+        long long q[NMQ];
+#pragma unroll
+        for (int m = 0; m < NMQ; ++m) q[m] = 0;
+        if (contribute) {
+            const double* pr = prep + PREP_N * s;
+            const double u0 = (x0 - pr[6]) * inv_d, u1 = (x1 - pr[7]) * inv_d, u2 = (x2 - pr[8]) * inv_d;
+            const double gq = gs * fix_scale;
+            q[0] = __double2ll_rn(gq);
+            q[1] = __double2ll_rn(gq * u0); q[2] = __double2ll_rn(gq * u1); q[3] = __double2ll_rn(gq * u2);
+            if (NMQ == 10) {
+                q[4] = __double2ll_rn(gq * u0 * u0); q[5] = __double2ll_rn(gq * u0 * u1);
+                q[6] = __double2ll_rn(gq * u0 * u2); q[7] = __double2ll_rn(gq * u1 * u1);
+                q[8] = __double2ll_rn(gq * u1 * u2); q[9] = __double2ll_rn(gq * u2 * u2);
+            }
+        }
+        // The upper levels (few nodes, every workgroup hits all of them) are summed in LDS first and flushed once
+        // per workgroup; deeper nodes are spread thinly enough for direct atomics.  Integer adds commute, so
+        // neither the LDS order nor the arrival order of the global atomics can change the totals.
+        if (contribute) {
+            if (s < lds_nodes) {
+#pragma unroll
+                for (int m = 0; m < NMQ; ++m) atomicAdd(tab + NMQ * s + m, (unsigned long long)q[m]);
+            } else {
+#pragma unroll
+                for (int m = 0; m < NMQ; ++m) atomicAdd(momq + NMQ * s + m, (unsigned long long)q[m]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < lds_nodes * NMQ; e += CH) {
+        const unsigned long long v = tab[e];
+        if (v != 0ull) atomicAdd(momq + e, v);
+    }
+}
+
+
+// Normal equations of the registration M-step (GMMTree.maximization_step, hgmm_gpu.py:729-752).  The reference
+// stacks, for every node i with m0_i >= float32 eps, the three rows  [ s_i x n_c | n_c ] x = n_c . (mu_i - s_i),
+// n_c = the columns of V_i sqrt(m0_i / lambda_i)  (eigh of Sigma_i), s_i = m1_i / m0_i, and solves by lstsq.
+// Since sum_c n_c n_c^T = m0_i Sigma_i^-1 =: W_i (no eigen-decomposition needed) the normal equations are
+//   A^T A = sum_i P_i W_i P_i^T,  A^T b = sum_i P_i W_i d_i,  b^T b = sum_i d_i^T W_i d_i,   P_i = [ [s_i]_x ; I ],
+//   d_i = mu_i - s_i = -c1_i / m0_i.
+// out[28] = 21 upper-triangle entries of A^T A (row-major), 6 of A^T b, b^T b.  One workgroup, fixed order.
+// Input: the fixed-point sums (m0, c1) [T][4] themselves (already all-reduced over the ranks); they are set back
+// to zero here, so that the next iteration's E-step needs no separate clearing launch.
+__device__ __forceinline__ void tree_reg_normal_body(unsigned long long* __restrict__ momq /*[T][4]*/,
+                                                     double d_ext, double inv_scale,
+                                                     const double* __restrict__ prep, int64_t T,
+                                                     double* __restrict__ out, double* host_out,
+                                                     unsigned long long* host_seq, unsigned long long seq) {
+    double acc[28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+    for (int64_t j = threadIdx.x; j < T; j += 256) {
+        const double z = (double)(long long)momq[4 * j] * inv_scale;
+        const double c10 = (double)(long long)momq[4 * j + 1] * (d_ext * inv_scale);
+        const double c11 = (double)(long long)momq[4 * j + 2] * (d_ext * inv_scale);
+        const double c12 = (double)(long long)momq[4 * j + 3] * (d_ext * inv_scale);
+        momq[4 * j] = momq[4 * j + 1] = momq[4 * j + 2] = momq[4 * j + 3] = 0ull;
+        if (z < 1.1920928955078125e-07) continue;                  // np.finfo(np.float32).eps (hgmm_gpu.py:733)
+        const double* pr = prep + PREP_N * j;
+        const double w00 = z * pr[0], w01 = z * pr[1], w02 = z * pr[2], w11 = z * pr[3], w12 = z * pr[4], w22 = z * pr[5];
+        const double iz = 1.0 / z;
+        const double d0 = -c10 * iz, d1 = -c11 * iz, d2 = -c12 * iz;
+        const double s0 = pr[6] - d0, s1 = pr[7] - d1, s2 = pr[8] - d2;
+        const double W[3][3] = {{w00, w01, w02}, {w01, w11, w12}, {w02, w12, w22}};
+        // SW = [s]_x W : column c of SW = s x W[:,c]
+        double SW[3][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            SW[0][c] = s1 * W[2][c] - s2 * W[1][c];
+            SW[1][c] = s2 * W[0][c] - s0 * W[2][c];
+            SW[2][c] = s0 * W[1][c] - s1 * W[0][c];
+        }
+        // SWS^T = SW [s]_x^T : row r of it = -(SW[r,:] x s) ... (SW S^T)[r][c] = sum_k SW[r][k] S[c][k]
+        const double S[3][3] = {{0.0, -s2, s1}, {s2, 0.0, -s0}, {-s1, s0, 0.0}};
+        double TL[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) TL[r][c] = SW[r][0] * S[c][0] + SW[r][1] * S[c][1] + SW[r][2] * S[c][2];
+        const double Wd[3] = {W[0][0] * d0 + W[0][1] * d1 + W[0][2] * d2, W[1][0] * d0 + W[1][1] * d1 + W[1][2] * d2,
+                              W[2][0] * d0 + W[2][1] * d1 + W[2][2] * d2};
+        const double SWd[3] = {s1 * Wd[2] - s2 * Wd[1], s2 * Wd[0] - s0 * Wd[2], s0 * Wd[1] - s1 * Wd[0]};
+        // upper triangle of the 6x6, row-major: rows 0-2 = [TL | SW], rows 3-5 = [. | W]
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) {
+                double v;
+                if (r < 3 && c < 3) v = TL[r][c];
+                else if (r < 3) v = SW[r][c - 3];
+                else v = W[r - 3][c - 3];
+                acc[k++] += v;
+            }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { acc[21 + r] += SWd[r]; acc[24 + r] += Wd[r]; }
+        acc[27] += d0 * Wd[0] + d1 * Wd[1] + d2 * Wd[2];
+    }
+    __shared__ double sh[4][28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) {
+        const double v = wave_sum_f64(acc[k]);
+        if (lane_id() == 0) sh[wave_in_block()][k] = v;
+    }
+    __syncthreads();
+    // host_out / host_seq: coherent pinned HOST memory -- the 28 numbers, then (behind a system-scope release) the
+    // sequence number the host is polling for: the registration loop's one hand-over per iteration without a copy
+    // packet and a stream synchronisation
+    if (threadIdx.x < 64) {                                  // wave 0
+        if (threadIdx.x < 28) {
+            const double v = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+            out[threadIdx.x] = v;
+            if (host_out) host_out[threadIdx.x] = v;
+        }
+        if (host_out) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+
+// ---- the registration loop (hgmm_gpu.py:754-768) with its 6 x 6 M-step on the host side of this library ----------
+// eigenvalue range of a symmetric 6 x 6 matrix by cyclic Jacobi sweeps (for the conditioning test only)
+inline void sym6_eig_range(const double (&A)[6][6], double* lo, double* hi) {
+    double a[6][6];
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) a[i][j] = A[i][j];
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0;
+        for (int i = 0; i < 6; ++i) for (int j = i + 1; j < 6; ++j) off += a[i][j] * a[i][j];
+        if (off == 0.0) break;
+        for (int p = 0; p < 6; ++p)
+            for (int q = p + 1; q < 6; ++q) {
+                if (a[p][q] == 0.0) continue;
+                const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / std::sqrt(tt * tt + 1.0), sn = tt * cs;
+                for (int k = 0; k < 6; ++k) {
+                    const double akp = a[k][p], akq = a[k][q];
+                    a[k][p] = cs * akp - sn * akq;
+                    a[k][q] = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < 6; ++k) {
+                    const double apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = cs * apk - sn * aqk;
+                    a[q][k] = sn * apk + cs * aqk;
+                }
+            }
+    }
+    *lo = *hi = a[0][0];
+    for (int i = 1; i < 6; ++i) { *lo = std::min(*lo, a[i][i]); *hi = std::max(*hi, a[i][i]); }
+}
+// A x = b by Gaussian elimination with partial pivoting (what LAPACK's gesv does); false: singular
+inline bool solve6(const double (&A)[6][6], const double (&b)[6], double (&x)[6]) {
+    double m[6][7];
+    for (int i = 0; i < 6; ++i) { for (int j = 0; j < 6; ++j) m[i][j] = A[i][j]; m[i][6] = b[i]; }
+    for (int col = 0; col < 6; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 6; ++r) if (std::fabs(m[r][col]) > std::fabs(m[piv][col])) piv = r;
+        if (m[piv][col] == 0.0) return false;
+        if (piv != col) for (int j = 0; j < 7; ++j) std::swap(m[piv][j], m[col][j]);
+        for (int r = col + 1; r < 6; ++r) {
+            const double f = m[r][col] / m[col][col];
+            for (int j = col; j < 7; ++j) m[r][j] -= f * m[col][j];
+        }
+    }
+    for (int i = 5; i >= 0; --i) {
+        double s = m[i][6];
+        for (int j = i + 1; j < 6; ++j) s -= m[i][j] * x[j];
+        x[i] = s / m[i][i];
+    }
+    return true;
+}
+// (rot, t) <- (dR rot, dR t + v), dR = exp([omega]_x) by Rodrigues' formula   (twist_mul, hgmm_gpu.py:634-664)
+inline void twist_compose(const double (&x)[6], double* rot, double* t) {
+    const double w0 = x[0], w1 = x[1], w2 = x[2];
+    const double angle = std::sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+    double d[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    if (angle != 0.0) {
+        const double a = w0 / angle, b = w1 / angle, c = w2 / angle;
+        const double k[3][3] = {{0.0, -c, b}, {c, 0.0, -a}, {-b, a, 0.0}};
+        const double sn = std::sin(angle), oc = 1.0 - std::cos(angle);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double kk = 0.0;
+                for (int l = 0; l < 3; ++l) kk += k[i][l] * k[l][j];
+                d[i][j] += sn * k[i][j] + oc * kk;
+            }
+    }
+    double r2[9], t2[3];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) {
+            double v = 0.0;
+            for (int l = 0; l < 3; ++l) v += d[i][l] * rot[3 * l + j];
+            r2[3 * i + j] = v;
+        }
+        double v = 0.0;
+        for (int l = 0; l < 3; ++l) v += d[i][l] * t[l];
+        t2[i] = v + x[3 + i];
+    }
+    for (int i = 0; i < 9; ++i) rot[i] = r2[i];
+    for (int i = 0; i < 3; ++i) t[i] = t2[i];
+}
+
+// The host side of ONE registration iteration, shared by hgmm_tree_register and hgmm_tree_register_batch: o[28] = the
+// normal equations the device produced (tree_reg_normal_kernel).  -> 0: (rot, t) updated, go on; 1: updated and stopped by
+// |q - q_prev| < tol; 2: too ill-conditioned for normal equations (nothing updated): the caller takes the reference's
+// stacked least-squares M-step.  *q_out = this iteration's q (status 0 / 1).
+inline int reg_host_step(const double* o, double* rot, double* t, double* q_prev_inout, double tol, double* q_out) {
+    double A[6][6], b[6], x[6];
+    bool finite = true;
+    for (int i = 0, k = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j, ++k) { A[i][j] = A[j][i] = o[k]; finite = finite && std::isfinite(o[k]); }
+    for (int i = 0; i < 6; ++i) { b[i] = o[21 + i]; finite = finite && std::isfinite(b[i]); }
+    double lo = 0.0, hi = 0.0;
+    if (finite) sym6_eig_range(A, &lo, &hi);
+    if (!finite || !(hi > 0.0) || lo <= 1e-11 * hi || !solve6(A, b, x)) return 2;
+    double xb = 0.0;
+    for (int i = 0; i < 6; ++i) xb += x[i] * b[i];
+    const double q = std::max(o[27] - xb, 0.0);
+    twist_compose(x, rot, t);
+    *q_out = q;
+    const double qp = *q_prev_inout;
+    *q_prev_inout = q;
+    return (qp == qp && std::fabs(q - qp) < tol) ? 1 : 0;                                   // (NaN: no previous q)
+}
+
+// the lanes' shares of one node's moments: chunk partials of its parent, lane t takes chunks c0 + t, c0 + t + 64, ...
+// (tree_moments_kernel and its forest twin: the same order, then the same wave_sum_f64 per moment)
+__device__ __forceinline__ void tree_moments_gather(const double* __restrict__ partials, int c0, int c1, int k,
+                                                    double (&acc)[NMOM]) {
+#pragma unroll
+    for (int m = 0; m < NMOM; ++m) acc[m] = 0.0;
+    for (int c = c0 + (int)threadIdx.x; c < c1; c += 64) {
+        const double* src = partials + (size_t)c * (8 * NMOM) + k * NMOM;
+#pragma unroll
+        for (int m = 0; m < NMOM; ++m) acc[m] += src[m];
+    }
+}
+
+// How hgmm_tree_build splits a level's nodes over gridDim.y of the log-likelihood launch (small clouds: not enough point
+// blocks to fill the chip).  The split fixes the ORDER in which a point's node terms are added, so the forest build asks the
+// same function for every cloud.  llblocks = point blocks of the launch.
+inline void tree_ll_split(int llblocks, int n_level, int cus, int* chunks_out, int* per_chunk_out) {
+    int chunks = 1;
+    if (llblocks < 2 * cus && n_level > LL_TILE) {            // (N = 1e6: 977 workgroups are plenty -- no split, no finish pass)
+        chunks = (4 * cus + llblocks - 1) / llblocks;
+        const int max_chunks_l = (n_level + LL_TILE - 1) / LL_TILE;
+        if (chunks > max_chunks_l) chunks = max_chunks_l;
+    }
+    const int per_chunk = ((n_level + chunks - 1) / chunks + LL_TILE - 1) / LL_TILE * LL_TILE;
+    *per_chunk_out = per_chunk;
+    *chunks_out = (n_level + per_chunk - 1) / per_chunk;
+}
+
+// largest |mu_j| of a node table (host)
+inline double tree_mu_rmax(const double* mu, int64_t T) {
+    double m2 = 0.0;
+    for (int64_t j = 0; j < T; ++j) {
+        const double v = mu[3 * j] * mu[3 * j] + mu[3 * j + 1] * mu[3 * j + 1] + mu[3 * j + 2] * mu[3 * j + 2];
+        if (v > m2 && std::isfinite(v)) m2 = v;
+    }
+    return std::sqrt(m2);
+}
+// extent of the moved target about any node mean: |s R x + t - mu| <= |s| (Frobenius bound on R) max|x| + |t| + max|mu|
+inline double reg_extent(const Rigid& tf, double tgt_rmax, double mu_rmax) {
+    double rn = 0.0, tn = 0.0;
+    for (int i = 0; i < 9; ++i) rn += tf.r[i] * tf.r[i];
+    for (int i = 0; i < 3; ++i) tn += tf.t[i] * tf.t[i];
+    return std::fabs(tf.s) * std::sqrt(rn) * tgt_rmax + std::sqrt(tn) + mu_rmax;
+}
+// encoding of the registration E-step's fixed-point sums: D = the extent rounded up to a power of two, F fractional bits
+// such that n_all terms cannot overflow 62 bits
+inline void reg_encoding(double ext, double n_all, double* D_out, int* F_out) {
+    if (!(ext > 0.0) || !std::isfinite(ext)) ext = 1.0;
+    int e2 = 0;
+    (void)std::frexp(ext, &e2);                                   // ext < 2^e2
+    *D_out = std::ldexp(1.0, e2);
+    int nbits = 1;
+    while (std::ldexp(1.0, nbits) <= n_all) ++nbits;
+    *F_out = 62 - nbits;
+}
+
+// ---- kernels defined in tree_kernels.hip that the batched path (tree_batch.hip) launches as they are -----------------
+constexpr int OFF_BLOCK = 256;
+__global__ void tree_prep_kernel(const double* __restrict__ pi, const double* __restrict__ mu,
+                                 const double* __restrict__ cov, int64_t j_begin, int64_t j_end,
+                                 double* __restrict__ prep, int* __restrict__ flags);
+__global__ void tree_complexity_kernel(const double* __restrict__ cov, int64_t j_begin, int64_t j_end,
+                                       double* __restrict__ prep);
+__global__ void tree_init_nodes_kernel(const double* __restrict__ init_mu, double sig2, int64_t T,
+                                       double* pi, double* mu, double* cov);
+__global__ void tree_chunks_kernel(const int* __restrict__ seg_start, int P, int* __restrict__ chunk_first,
+                                   int* __restrict__ chunk_desc, int* __restrict__ n_chunks_out);
+__global__ __launch_bounds__(OFF_BLOCK) void tree_offsets_kernel(const int* __restrict__ hist,
+                                                                 const int* __restrict__ chunk_first,
+                                                                 const int* __restrict__ seg_start, int P,
+                                                                 int* __restrict__ chunk_off /*[chunks][8]*/,
+                                                                 int* __restrict__ new_seg_start /*[8P+1]*/);
+__global__ void tree_iota_kernel(int* perm, int64_t n);
+inline unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
 }  // namespace hgmm

@@ -119,7 +119,7 @@ __global__ void tree_chunks_kernel(const int* __restrict__ seg_start, int P, int
 
 __global__ __launch_bounds__(CH) void tree_close_kernel(TreeFollow f) {
     __shared__ double sh4[4];
-    (void)tree_follow(f, *f.done, sh4);
+    (void)tree_follow(f, *f.done, sh4, true);
 }
 
 template <bool HALF>
@@ -156,14 +156,8 @@ __global__ __launch_bounds__(64) void tree_moments_kernel(const double* __restri
     if (follow.q_blocks) fl = tree_follow_wave_load(follow);
     else if (stop_flag) return;
     double acc[NMOM];
-#pragma unroll
-    for (int m = 0; m < NMOM; ++m) acc[m] = 0.0;
-    for (int c = c0 + (int)threadIdx.x; c < c1; c += 64) {
-        const double* src = partials + (size_t)c * (8 * NMOM) + k * NMOM;
-#pragma unroll
-        for (int m = 0; m < NMOM; ++m) acc[m] += src[m];
-    }
-    if (follow.q_blocks && tree_follow_wave_verdict(follow, fl, stop_flag)) return;
+    tree_moments_gather(partials, c0, c1, k, acc);
+    if (follow.q_blocks && tree_follow_wave_verdict(follow, fl, stop_flag, blockIdx.x == 0)) return;
 #pragma unroll
     for (int m = 0; m < NMOM; ++m) acc[m] = wave_sum_f64(acc[m]);
     if (threadIdx.x == 0) {
@@ -520,7 +514,6 @@ __global__ __launch_bounds__(CH) void tree_hist_kernel(const int* __restrict__ c
 // children laid out k = 0..7 inside it).  Level 0 has ONE parent owning every chunk of the cloud (3907 at N = 1M):
 // a thread per parent walked them one by one, 0.3 ms of dependent loads per pass; here the chunks are spread over
 // the 256 threads, child totals by a reduction, offsets by a tiled scan.
-constexpr int OFF_BLOCK = 256;
 __global__ __launch_bounds__(OFF_BLOCK) void tree_offsets_kernel(const int* __restrict__ hist,
                                                                  const int* __restrict__ chunk_first,
                                                                  const int* __restrict__ seg_start, int P,
@@ -629,92 +622,9 @@ __global__ __launch_bounds__(CH) void tree_reg_estep_kernel(const double* __rest
                                                             const double* __restrict__ prep, int L,
                                                             double lambda_c, double inv_d, double fix_scale,
                                                             unsigned long long* __restrict__ momq) {
-    constexpr int LDS_NODES = 584;                       // levels 0..2 (8 + 64 + 512 nodes)
-    __shared__ unsigned long long tab[LDS_NODES * NMQ];
-    const int lds_nodes = (int)(level_first(L < 3 ? L : 3));
-    for (int e = threadIdx.x; e < lds_nodes * NMQ; e += CH) tab[e] = 0ull;
-    __syncthreads();
+    __shared__ unsigned long long tab[REG_LDS_NODES * NMQ];
     const int64_t i = (int64_t)blockIdx.x * CH + threadIdx.x;
-    bool alive = i < n;
-    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
-    if (alive) {
-        const double a = tg[i], b = tg[n_pad + i], c = tg[2 * n_pad + i];
-        x0 = tf.s * (tf.r[0] * a + tf.r[1] * b + tf.r[2] * c) + tf.t[0];
-        x1 = tf.s * (tf.r[3] * a + tf.r[4] * b + tf.r[5] * c) + tf.t[1];
-        x2 = tf.s * (tf.r[6] * a + tf.r[7] * b + tf.r[8] * c) + tf.t[2];
-    }
-    int64_t search = -1;
-    for (int l = 0; l < L; ++l) {
-        if (!__any(alive)) break;
-        const int64_t j0 = 8 * (search + 1);
-        double g[8];
-        double den = 0.0;
-        if (alive) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const double* pr = prep + PREP_N * (j0 + k);
-                const double d0 = x0 - pr[6], d1 = x1 - pr[7], d2 = x2 - pr[8];
-                const double q = sym3_quad(pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], d0, d1, d2);
-                const double wE = pr[9];
-                g[k] = (wE == 0.0) ? 0.0 : wE * exp(-0.5 * q);
-                den += g[k];
-            }
-        }
-        double gs = 0.0;
-        int64_t s = 0;
-        bool contribute = false;
-        if (alive) {
-            const bool good = den > TREE_EPS;
-            int am = 0;
-            double best = -1.0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const double gk = good ? g[k] / den : 0.0;
-                if (gk > best) { best = gk; am = k; }
-            }
-            s = j0 + am;
-            search = s;
-            if (prep[PREP_N * s + 11] <= lambda_c) {       // complexity(cov_s) <= lambda_c: stop
-                alive = false;
-            } else {
-                gs = best;
-                contribute = !(gs < TREE_EPS);
-            }
-        }
-        // this lane's contribution in fixed point, about the node's mean, in units of D
-        long long q[NMQ];
-#pragma unroll
-        for (int m = 0; m < NMQ; ++m) q[m] = 0;
-        if (contribute) {
-            const double* pr = prep + PREP_N * s;
-            const double u0 = (x0 - pr[6]) * inv_d, u1 = (x1 - pr[7]) * inv_d, u2 = (x2 - pr[8]) * inv_d;
-            const double gq = gs * fix_scale;
-            q[0] = __double2ll_rn(gq);
-            q[1] = __double2ll_rn(gq * u0); q[2] = __double2ll_rn(gq * u1); q[3] = __double2ll_rn(gq * u2);
-            if (NMQ == 10) {
-                q[4] = __double2ll_rn(gq * u0 * u0); q[5] = __double2ll_rn(gq * u0 * u1);
-                q[6] = __double2ll_rn(gq * u0 * u2); q[7] = __double2ll_rn(gq * u1 * u1);
-                q[8] = __double2ll_rn(gq * u1 * u2); q[9] = __double2ll_rn(gq * u2 * u2);
-            }
-        }
-        // The upper levels (few nodes, every workgroup hits all of them) are summed in LDS first and flushed once
-        // per workgroup; deeper nodes are spread thinly enough for direct atomics.  Integer adds commute, so
-        // neither the LDS order nor the arrival order of the global atomics can change the totals.
-        if (contribute) {
-            if (s < lds_nodes) {
-#pragma unroll
-                for (int m = 0; m < NMQ; ++m) atomicAdd(tab + NMQ * s + m, (unsigned long long)q[m]);
-            } else {
-#pragma unroll
-                for (int m = 0; m < NMQ; ++m) atomicAdd(momq + NMQ * s + m, (unsigned long long)q[m]);
-            }
-        }
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < lds_nodes * NMQ; e += CH) {
-        const unsigned long long v = tab[e];
-        if (v != 0ull) atomicAdd(momq + e, v);
-    }
+    tree_reg_estep_body<NMQ>(i, i < n, tg, n_pad, tf, prep, L, lambda_c, inv_d, fix_scale, momq, tab);
 }
 
 // fixed point -> float64, still centred: cm[T][NMQ] = (m0, c1 = sum gamma (x - mu), C2 = sum gamma (x - mu)(x - mu)^T)
@@ -749,15 +659,7 @@ __global__ void tree_reg_expand_kernel(const double* __restrict__ cm, const doub
             m2[9 * j + 3 * a + b] = c[idx[a][b]] + u[a] * c[1 + b] + c[1 + a] * u[b] + z * u[a] * u[b];
 }
 
-// Normal equations of the registration M-step (GMMTree.maximization_step, hgmm_gpu.py:729-752).  The reference
-// stacks, for every node i with m0_i >= float32 eps, the three rows  [ s_i x n_c | n_c ] x = n_c . (mu_i - s_i),
-// n_c = the columns of V_i sqrt(m0_i / lambda_i)  (eigh of Sigma_i), s_i = m1_i / m0_i, and solves by lstsq.
-// Since sum_c n_c n_c^T = m0_i Sigma_i^-1 =: W_i (no eigen-decomposition needed) the normal equations are
-//   A^T A = sum_i P_i W_i P_i^T,  A^T b = sum_i P_i W_i d_i,  b^T b = sum_i d_i^T W_i d_i,   P_i = [ [s_i]_x ; I ],
-//   d_i = mu_i - s_i = -c1_i / m0_i.
-// out[28] = 21 upper-triangle entries of A^T A (row-major), 6 of A^T b, b^T b.  One workgroup, fixed order.
-// Input: the fixed-point sums (m0, c1) [T][4] themselves (already all-reduced over the ranks); they are set back
-// to zero here, so that the next iteration's E-step needs no separate clearing launch.
+// (the body: csrc/tree_device.h, shared with the batched registration)
 __global__ __launch_bounds__(256) void tree_reg_normal_kernel(unsigned long long* __restrict__ momq /*[T][4]*/,
                                                               double d_ext, double inv_scale,
                                                               const double* __restrict__ prep, int64_t T,
@@ -765,77 +667,7 @@ __global__ __launch_bounds__(256) void tree_reg_normal_kernel(unsigned long long
                                                               double* host_out = nullptr,
                                                               unsigned long long* host_seq = nullptr,
                                                               unsigned long long seq = 0) {
-    double acc[28];
-#pragma unroll
-    for (int k = 0; k < 28; ++k) acc[k] = 0.0;
-    for (int64_t j = threadIdx.x; j < T; j += 256) {
-        const double z = (double)(long long)momq[4 * j] * inv_scale;
-        const double c10 = (double)(long long)momq[4 * j + 1] * (d_ext * inv_scale);
-        const double c11 = (double)(long long)momq[4 * j + 2] * (d_ext * inv_scale);
-        const double c12 = (double)(long long)momq[4 * j + 3] * (d_ext * inv_scale);
-        momq[4 * j] = momq[4 * j + 1] = momq[4 * j + 2] = momq[4 * j + 3] = 0ull;
-        if (z < 1.1920928955078125e-07) continue;                  // np.finfo(np.float32).eps (hgmm_gpu.py:733)
-        const double* pr = prep + PREP_N * j;
-        const double w00 = z * pr[0], w01 = z * pr[1], w02 = z * pr[2], w11 = z * pr[3], w12 = z * pr[4], w22 = z * pr[5];
-        const double iz = 1.0 / z;
-        const double d0 = -c10 * iz, d1 = -c11 * iz, d2 = -c12 * iz;
-        const double s0 = pr[6] - d0, s1 = pr[7] - d1, s2 = pr[8] - d2;
-        const double W[3][3] = {{w00, w01, w02}, {w01, w11, w12}, {w02, w12, w22}};
-        // SW = [s]_x W : column c of SW = s x W[:,c]
-        double SW[3][3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            SW[0][c] = s1 * W[2][c] - s2 * W[1][c];
-            SW[1][c] = s2 * W[0][c] - s0 * W[2][c];
-            SW[2][c] = s0 * W[1][c] - s1 * W[0][c];
-        }
-        // SWS^T = SW [s]_x^T : row r of it = -(SW[r,:] x s) ... (SW S^T)[r][c] = sum_k SW[r][k] S[c][k]
-        const double S[3][3] = {{0.0, -s2, s1}, {s2, 0.0, -s0}, {-s1, s0, 0.0}};
-        double TL[3][3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) TL[r][c] = SW[r][0] * S[c][0] + SW[r][1] * S[c][1] + SW[r][2] * S[c][2];
-        const double Wd[3] = {W[0][0] * d0 + W[0][1] * d1 + W[0][2] * d2, W[1][0] * d0 + W[1][1] * d1 + W[1][2] * d2,
-                              W[2][0] * d0 + W[2][1] * d1 + W[2][2] * d2};
-        const double SWd[3] = {s1 * Wd[2] - s2 * Wd[1], s2 * Wd[0] - s0 * Wd[2], s0 * Wd[1] - s1 * Wd[0]};
-        // upper triangle of the 6x6, row-major: rows 0-2 = [TL | SW], rows 3-5 = [. | W]
-        int k = 0;
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = r; c < 6; ++c) {
-                double v;
-                if (r < 3 && c < 3) v = TL[r][c];
-                else if (r < 3) v = SW[r][c - 3];
-                else v = W[r - 3][c - 3];
-                acc[k++] += v;
-            }
-#pragma unroll
-        for (int r = 0; r < 3; ++r) { acc[21 + r] += SWd[r]; acc[24 + r] += Wd[r]; }
-        acc[27] += d0 * Wd[0] + d1 * Wd[1] + d2 * Wd[2];
-    }
-    __shared__ double sh[4][28];
-#pragma unroll
-    for (int k = 0; k < 28; ++k) {
-        const double v = wave_sum_f64(acc[k]);
-        if (lane_id() == 0) sh[wave_in_block()][k] = v;
-    }
-    __syncthreads();
-    // host_out / host_seq: coherent pinned HOST memory -- the 28 numbers, then (behind a system-scope release) the
-    // sequence number the host is polling for: the registration loop's one hand-over per iteration without a copy
-    // packet and a stream synchronisation
-    if (threadIdx.x < 64) {                                  // wave 0
-        if (threadIdx.x < 28) {
-            const double v = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
-            out[threadIdx.x] = v;
-            if (host_out) host_out[threadIdx.x] = v;
-        }
-        if (host_out) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-            if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    tree_reg_normal_body(momq, d_ext, inv_scale, prep, T, out, host_out, host_seq, seq);
 }
 
 // expand the 10 unique moments into the reference layout m0[T], m1[T,3], m2[T,3,3]
@@ -858,7 +690,6 @@ __global__ void tree_copy_cplx_kernel(const double* __restrict__ prep, int64_t T
 // ------------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------------
-static unsigned nblk(int64_t n, int b) { return (unsigned)((n + b - 1) / b); }
 
 static int tree_flags(hgmm_ctx* c, bool reset);
 static int tree_alloc_nodes(hgmm_ctx* c, int L) {
@@ -1085,14 +916,8 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
         // over gridDim.y and add the per-chunk sums in a second (fixed-order) kernel
         const int pblocks = (int)nblk(n, CH);
         const int llblocks = (int)nblk(n, CH * ll_pts);        // log-likelihood grid: ll_pts points per thread
-        int chunks = 1;
-        if (llblocks < 2 * c->cus && n_level > LL_TILE) {     // (N = 1e6: 977 workgroups are plenty -- no split, no finish pass)
-            chunks = (4 * c->cus + llblocks - 1) / llblocks;
-            const int max_chunks_l = (n_level + LL_TILE - 1) / LL_TILE;
-            if (chunks > max_chunks_l) chunks = max_chunks_l;
-        }
-        const int per_chunk = ((n_level + chunks - 1) / chunks + LL_TILE - 1) / LL_TILE * LL_TILE;
-        chunks = (n_level + per_chunk - 1) / per_chunk;
+        int chunks = 1, per_chunk = n_level;
+        tree_ll_split(llblocks, n_level, c->cus, &chunks, &per_chunk);
         double* ll_partial = nullptr;
         if (chunks > 1) {
             rc = ensure(c, c->t_llp, sizeof(double) * (size_t)chunks * n_pad);
@@ -1424,31 +1249,19 @@ static int reg_estep_fixed(hgmm_ctx* c, const double* rot, const double* t, doub
         std::vector<double> mu((size_t)3 * T);
         HGMM_HIP(c, hipMemcpyAsync(mu.data(), c->t_mu.p, sizeof(double) * 3 * T, hipMemcpyDeviceToHost, c->stream));
         HGMM_HIP(c, ctx_stream_sync(c));
-        double m2 = 0.0;
-        for (int64_t j = 0; j < T; ++j) {
-            const double v = mu[3 * j] * mu[3 * j] + mu[3 * j + 1] * mu[3 * j + 1] + mu[3 * j + 2] * mu[3 * j + 2];
-            if (v > m2 && std::isfinite(v)) m2 = v;
-        }
-        c->tree.mu_rmax = std::sqrt(m2);
+        c->tree.mu_rmax = tree_mu_rmax(mu.data(), T);
     }
-    double rn = 0.0, tn = 0.0;
-    for (int i = 0; i < 9; ++i) rn += tf.r[i] * tf.r[i];
-    for (int i = 0; i < 3; ++i) tn += tf.t[i] * tf.t[i];
-    double ext = std::fabs(scale) * std::sqrt(rn) * c->tgt_rmax + std::sqrt(tn) + c->tree.mu_rmax;
+    double ext = reg_extent(tf, c->tgt_rmax, c->tree.mu_rmax);
     if (c->comm_on()) {                                           // every rank must use the same encoding
         double e = ext;
         HGMM_TRY(hgmm_comm_allreduce_f64(c, &e, 1, 1));
         ext = e;
     }
-    if (!(ext > 0.0) || !std::isfinite(ext)) ext = 1.0;
-    int e2 = 0;
-    (void)std::frexp(ext, &e2);                                   // ext < 2^e2
-    const double D = std::ldexp(1.0, e2);
     double n_all = (double)c->tgt_n;
     if (c->comm_on()) HGMM_TRY(hgmm_comm_allreduce_f64(c, &n_all, 1, 0));
-    int nbits = 1;
-    while (std::ldexp(1.0, nbits) <= n_all) ++nbits;
-    const int F = 62 - nbits;
+    double D = 1.0;
+    int F = 0;
+    reg_encoding(ext, n_all, &D, &F);
     // Invariant: momq_dirty == false  <=>  EVERY word of the buffer (its whole capacity, not just the words of the
     // current tree) is zero.  Earlier uses may have been larger (hgmm_tree_estep writes 2 NMOM T + 1 two-word sums,
     // hgmm_tree_reg_estep leaves [T][10] behind, a deeper tree has more nodes): clearing only this tree's words and
@@ -1539,90 +1352,6 @@ extern "C" int hgmm_tree_reg_normal(hgmm_ctx* c, const double* rot, const double
     return HGMM_OK;
 }
 
-// ---- the registration loop (hgmm_gpu.py:754-768) with its 6 x 6 M-step on the host side of this library ----------
-namespace {
-// eigenvalue range of a symmetric 6 x 6 matrix by cyclic Jacobi sweeps (for the conditioning test only)
-void sym6_eig_range(const double (&A)[6][6], double* lo, double* hi) {
-    double a[6][6];
-    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) a[i][j] = A[i][j];
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        double off = 0.0;
-        for (int i = 0; i < 6; ++i) for (int j = i + 1; j < 6; ++j) off += a[i][j] * a[i][j];
-        if (off == 0.0) break;
-        for (int p = 0; p < 6; ++p)
-            for (int q = p + 1; q < 6; ++q) {
-                if (a[p][q] == 0.0) continue;
-                const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
-                const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-                const double cs = 1.0 / std::sqrt(tt * tt + 1.0), sn = tt * cs;
-                for (int k = 0; k < 6; ++k) {
-                    const double akp = a[k][p], akq = a[k][q];
-                    a[k][p] = cs * akp - sn * akq;
-                    a[k][q] = sn * akp + cs * akq;
-                }
-                for (int k = 0; k < 6; ++k) {
-                    const double apk = a[p][k], aqk = a[q][k];
-                    a[p][k] = cs * apk - sn * aqk;
-                    a[q][k] = sn * apk + cs * aqk;
-                }
-            }
-    }
-    *lo = *hi = a[0][0];
-    for (int i = 1; i < 6; ++i) { *lo = std::min(*lo, a[i][i]); *hi = std::max(*hi, a[i][i]); }
-}
-// A x = b by Gaussian elimination with partial pivoting (what LAPACK's gesv does); false: singular
-bool solve6(const double (&A)[6][6], const double (&b)[6], double (&x)[6]) {
-    double m[6][7];
-    for (int i = 0; i < 6; ++i) { for (int j = 0; j < 6; ++j) m[i][j] = A[i][j]; m[i][6] = b[i]; }
-    for (int col = 0; col < 6; ++col) {
-        int piv = col;
-        for (int r = col + 1; r < 6; ++r) if (std::fabs(m[r][col]) > std::fabs(m[piv][col])) piv = r;
-        if (m[piv][col] == 0.0) return false;
-        if (piv != col) for (int j = 0; j < 7; ++j) std::swap(m[piv][j], m[col][j]);
-        for (int r = col + 1; r < 6; ++r) {
-            const double f = m[r][col] / m[col][col];
-            for (int j = col; j < 7; ++j) m[r][j] -= f * m[col][j];
-        }
-    }
-    for (int i = 5; i >= 0; --i) {
-        double s = m[i][6];
-        for (int j = i + 1; j < 6; ++j) s -= m[i][j] * x[j];
-        x[i] = s / m[i][i];
-    }
-    return true;
-}
-// (rot, t) <- (dR rot, dR t + v), dR = exp([omega]_x) by Rodrigues' formula   (twist_mul, hgmm_gpu.py:634-664)
-void twist_compose(const double (&x)[6], double* rot, double* t) {
-    const double w0 = x[0], w1 = x[1], w2 = x[2];
-    const double angle = std::sqrt(w0 * w0 + w1 * w1 + w2 * w2);
-    double d[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-    if (angle != 0.0) {
-        const double a = w0 / angle, b = w1 / angle, c = w2 / angle;
-        const double k[3][3] = {{0.0, -c, b}, {c, 0.0, -a}, {-b, a, 0.0}};
-        const double sn = std::sin(angle), oc = 1.0 - std::cos(angle);
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) {
-                double kk = 0.0;
-                for (int l = 0; l < 3; ++l) kk += k[i][l] * k[l][j];
-                d[i][j] += sn * k[i][j] + oc * kk;
-            }
-    }
-    double r2[9], t2[3];
-    for (int i = 0; i < 3; ++i) {
-        for (int j = 0; j < 3; ++j) {
-            double v = 0.0;
-            for (int l = 0; l < 3; ++l) v += d[i][l] * rot[3 * l + j];
-            r2[3 * i + j] = v;
-        }
-        double v = 0.0;
-        for (int l = 0; l < 3; ++l) v += d[i][l] * t[l];
-        t2[i] = v + x[3 + i];
-    }
-    for (int i = 0; i < 9; ++i) rot[i] = r2[i];
-    for (int i = 0; i < 3; ++i) t[i] = t2[i];
-}
-}  // namespace
-
 extern "C" int hgmm_tree_register(hgmm_ctx* c, double* rot, double* t, double scale, double lambda_c, int max_iter,
                                   double tol, double* q_prev_inout, int* iters_out, int* status_out,
                                   double* trace /*[max_iter][13] or NULL*/) {
@@ -1634,19 +1363,10 @@ extern "C" int hgmm_tree_register(hgmm_ctx* c, double* rot, double* t, double sc
     for (int it = 0; it < max_iter; ++it) {
         double o[28];
         HGMM_TRY(hgmm_tree_reg_normal(c, rot, t, scale, lambda_c, o));
-        double A[6][6], b[6], x[6];
-        bool finite = true;
-        for (int i = 0, k = 0; i < 6; ++i)
-            for (int j = i; j < 6; ++j, ++k) { A[i][j] = A[j][i] = o[k]; finite = finite && std::isfinite(o[k]); }
-        for (int i = 0; i < 6; ++i) { b[i] = o[21 + i]; finite = finite && std::isfinite(b[i]); }
-        double lo = 0.0, hi = 0.0;
-        if (finite) sym6_eig_range(A, &lo, &hi);
+        double q = 0.0;
         // too ill-conditioned for normal equations: the caller takes the reference's stacked least-squares M-step
-        if (!finite || !(hi > 0.0) || lo <= 1e-11 * hi || !solve6(A, b, x)) { *status_out = 2; return HGMM_OK; }
-        double xb = 0.0;
-        for (int i = 0; i < 6; ++i) xb += x[i] * b[i];
-        const double q = std::max(o[27] - xb, 0.0);
-        twist_compose(x, rot, t);
+        const int st = reg_host_step(o, rot, t, q_prev_inout, tol, &q);
+        if (st == 2) { *status_out = 2; return HGMM_OK; }
         if (trace) {
             double* tr = trace + (size_t)13 * it;
             for (int i = 0; i < 9; ++i) tr[i] = rot[i];
@@ -1654,9 +1374,7 @@ extern "C" int hgmm_tree_register(hgmm_ctx* c, double* rot, double* t, double sc
             tr[12] = q;
         }
         *iters_out = it + 1;
-        const double qp = *q_prev_inout;
-        *q_prev_inout = q;
-        if (qp == qp && std::fabs(q - qp) < tol) { *status_out = 1; return HGMM_OK; }      // (NaN: no previous q)
+        if (st == 1) { *status_out = 1; return HGMM_OK; }
     }
     return HGMM_OK;
 }

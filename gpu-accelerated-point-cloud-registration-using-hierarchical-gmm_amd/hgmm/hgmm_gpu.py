@@ -51,7 +51,7 @@ def _points(x):
 
 
 def buildGMMTree(points, maxTreeLevel, ls, ld, sig2=0.004, seed=72, init_idx=None,
-                 max_iters_per_level=1000, ctx: Context | None = None, return_trace=False, dtype=None):
+                 max_iters_per_level=1000, ctx: Context | None = None, return_trace=False, dtype=None, pdf_dtype=None):
     """-> (mixingCoeff[T], mean[T,3], covar[T,3,3])   (hgmm_gpu.py:466-548).
 
     ``init_idx`` (T indices into ``points``) overrides the reference's
@@ -60,11 +60,14 @@ def buildGMMTree(points, maxTreeLevel, ls, ld, sig2=0.004, seed=72, init_idx=Non
     ``dtype``: the reference has this function twice -- float64 in the CPU twin (hgmm_cupy_cpu_working.py:122-160, the
     canonical semantics) and float32 in the GPU file (``points.astype(np.float32)``, float32 node and moment arrays,
     hgmm_gpu.py:472, 478-484).  Default: the points' own type -- float32 points give float32 tables and the float32-pdf
-    stop rule (``Context.tree_set_precision``), anything else the float64 path."""
+    stop rule (``Context.tree_set_precision``), anything else the float64 path.  ``pdf_dtype`` (default: ``dtype``) sets the
+    stop rule's arithmetic alone: :class:`GMMTree` keeps float64 tables for its registration whatever the points' type
+    (``dtype=np.float64, pdf_dtype=<the points' type>``).  The context's own precision setting is restored afterwards."""
     ctx = ctx or default_context()
     raw = _points(points)
     dt = np.dtype(dtype) if dtype is not None else (np.dtype(np.float32) if raw.dtype == np.float32 else np.dtype(np.float64))
-    if dt not in (np.dtype(np.float32), np.dtype(np.float64)):
+    pdt = np.dtype(pdf_dtype) if pdf_dtype is not None else dt
+    if dt not in (np.dtype(np.float32), np.dtype(np.float64)) or pdt not in (np.dtype(np.float32), np.dtype(np.float64)):
         raise ValueError("dtype must be float32 or float64")
     P = np.ascontiguousarray(raw, dtype=np.float64)
     T = n_total_nodes(maxTreeLevel)
@@ -72,12 +75,13 @@ def buildGMMTree(points, maxTreeLevel, ls, ld, sig2=0.004, seed=72, init_idx=Non
         rs = np.random.RandomState(seed)
         init_idx = rs.randint(T, size=T)
     ctx.set_points(P)
-    ctx.tree_set_precision(dt)
+    prev = getattr(ctx, "tree_dtype", np.dtype(np.float64))     # (a precision the caller set on the context survives this call)
+    ctx.tree_set_precision(pdt)
     try:
         pi, mu, cov, leaf, iters, q = ctx.tree_build(maxTreeLevel, ls, ld, P[np.asarray(init_idx)], sig2,
                                                      max_iters_per_level, want_leaf=bool(return_trace))
     finally:
-        ctx.tree_set_precision(np.float64)
+        ctx.tree_set_precision(prev)
     if dt == np.dtype(np.float32):
         pi, mu, cov = pi.astype(np.float32), mu.astype(np.float32), cov.astype(np.float32)
     if return_trace:
@@ -224,9 +228,13 @@ class GMMTree():
         self._source = _points(source)
         self._eig_cache = None                       # node covariances are about to change
         t1 = time.time()
+        # float64 tables whatever the points' type: the registration re-uploads them, takes eigh of the covariances and
+        # 1 / sqrt of their eigenvalues -- a thin leaf covariance rounded to float32 can turn indefinite.  The
+        # stop rule's arithmetic still follows the points' type, as in buildGMMTree.
+        pdf = np.float32 if self._source.dtype == np.float32 else np.float64
         self._mixingCoeff, self._mean, self._covar = buildGMMTree(
             self._source, self._tree_level, self._ls, self._ld, sig2=self._sig2,
-            init_idx=self._init_idx, ctx=self._ctx)
+            init_idx=self._init_idx, ctx=self._ctx, dtype=np.float64, pdf_dtype=pdf)
         if self._verbose:
             print("Build tree Time: ", time.time() - t1)
 
@@ -323,7 +331,7 @@ class GMMTree():
         rot, t = twist_mul(x, tf.rot, tf.t)
         return MstepResult(RigidTransformation(rot, t), q)
 
-    def _registration_in_library(self, maxiter, tol):
+    def _registration_in_library(self, maxiter, tol, _resume=None):
         """The loop of :meth:`registration` without per-iteration Python: ``hgmm_tree_register`` iterates (E-step and
         normal equations on the device, 6 x 6 solve / twist / stop rule on the library's host side) until it stops or
         meets a system too ill-conditioned for normal equations; that one iteration is then done here with the
@@ -333,14 +341,19 @@ class GMMTree():
         rot, t = np.asarray(tf.rot, dtype=np.float64), np.asarray(tf.t, dtype=np.float64)
         q = None
         it = 0
+        host_step_due = False
+        if _resume is not None:                      # (a pair that left a batch at status 2: ``it`` iterations done, last q)
+            it, q, host_step_due = _resume
         while it < maxiter:
-            rot, t, done, q_new, status, _ = self._ctx.tree_register(rot, t, tf.scale, self._lambda_c, maxiter - it, tol, q)
-            it += done
-            if done:
-                q = q_new
-            self._tf_result = RigidTransformation(rot, t, tf.scale)
-            if status != 2:
-                break
+            if not host_step_due:
+                rot, t, done, q_new, status, _ = self._ctx.tree_register(rot, t, tf.scale, self._lambda_c, maxiter - it, tol, q)
+                it += done
+                if done:
+                    q = q_new
+                self._tf_result = RigidTransformation(rot, t, tf.scale)
+                if status != 2:
+                    break
+            host_step_due = False
             res = self.maximization_step(self.expectation_step(), self._tf_result)      # host M-step, one iteration
             self._tf_result = res.transformation
             rot, t = np.asarray(res.transformation.rot, dtype=np.float64), np.asarray(res.transformation.t, dtype=np.float64)
@@ -413,3 +426,50 @@ def registration_gmmtree(source, target, maxiter=20, tol=1.0e-4, callbacks=[], *
     gt = GMMTree(_points(source), **kargs)
     gt.set_callbacks(callbacks)
     return gt.registration(_points(target), maxiter, tol)
+
+
+def registration_gmmtree_batch(pairs, maxiter=20, tol=1.0e-4, ctx: Context | None = None, tree_level=5, lambda_c=0.01,
+                               ls=20, ld=1.0e-4, sig2=0.004, init_idx=None, return_info=False):
+    """``[registration_gmmtree(s, t, maxiter, tol, tree_level=..., ...) for s, t in pairs]`` (hgmm_gpu.py:802-807 per pair)
+    with ALL pairs in the same launches: the B source clouds are one resident forest (``hgmm_tree_build_batch``: levels in
+    lock-step, one stop rule per cloud), the B targets are registered against their trees together
+    (``hgmm_tree_register_batch``: one E-step + one normal-equations launch per iteration, the 6 x 6 solves on the host).
+    Every pair's tree, iteration counts and transformation are bitwise what the serial call returns for it.  A pair whose
+    normal equations turn ill-conditioned leaves the batch and is finished by the serial path (stacked least squares on
+    the host, like :meth:`GMMTree._registration_in_library`).  Clouds of 400 000 points or more go through the serial call.
+
+    -> list of ``MstepResult(transformation, q)`` in the order of ``pairs`` (+ a dict with the per-pair build / registration
+    iteration counts with ``return_info``)."""
+    ctx = ctx or default_context()
+    pairs = list(pairs)
+    if not pairs:
+        return ([], {}) if return_info else []
+    srcs = [np.ascontiguousarray(_points(s), dtype=np.float64) for s, _ in pairs]
+    tgts = [np.ascontiguousarray(_points(t), dtype=np.float64) for _, t in pairs]
+    B = len(pairs)
+    T = n_total_nodes(tree_level)
+    idx = np.asarray(init_idx) if init_idx is not None else np.random.RandomState(72).randint(T, size=T)
+    init_mu = np.stack([S[idx] for S in srcs])
+    ctx.set_points_batch(srcs)
+    _, build_iters, _ = ctx.tree_build_batch([len(S) for S in srcs], tree_level, ls, ld, init_mu, sig2, want_tables=False)
+    ctx.tree_set_targets_batch(tgts)
+    rot0 = np.tile(np.identity(3), (B, 1, 1))
+    rot, t, iters, q, status, _ = ctx.tree_register_batch(rot0, np.zeros((B, 3)), 1.0, lambda_c, maxiter, tol)
+    out = []
+    reg_iters = [int(v) for v in iters]
+    for b in range(B):
+        if status[b] == 2:                                        # finish this pair through the serial entries
+            gt = GMMTree(tree_level=tree_level, lambda_c=lambda_c, ls=ls, ld=ld, sig2=sig2, ctx=ctx)
+            gt.set_nodes(*ctx.tree_get_nodes_batch(b, tree_level))
+            gt._tf_result = RigidTransformation(rot[b], t[b])
+            ctx.tree_set_nodes(tree_level, gt._mixingCoeff, gt._mean, gt._covar)
+            ctx.tree_set_target(tgts[b])
+            res = gt._registration_in_library(maxiter, tol, _resume=(int(iters[b]), None if np.isnan(q[b]) else float(q[b]), True))
+            reg_iters[b] = int(gt.n_iter_)
+            out.append(res)
+            continue
+        tf = RigidTransformation(rot[b].copy(), t[b].copy())
+        out.append(MstepResult(tf.inverse(), np.array([q[b]]) if not np.isnan(q[b]) else np.array([])))
+    if return_info:
+        return out, {"build_iters": build_iters, "registration_iters": reg_iters, "status": [int(v) for v in status]}
+    return out

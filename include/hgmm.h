@@ -259,6 +259,35 @@ int hgmm_tree_reg_normal(hgmm_ctx* ctx, const double* rot, const double* t, doub
  * (eigh + QR on the host) and may call again.  trace (optional): per iteration rot, t, q.              */
 int hgmm_tree_register(hgmm_ctx* ctx, double* rot, double* t, double scale, double lambda_c, int max_iter, double tol,
                        double* q_prev_inout, int* iters_out, int* status_out, double* trace);
+/* ---- batched HGMM: B independent scan pairs per launch set ("forest") ------------------------------------------------
+ * The reference's unit of work is ONE pair -- registration_gmmtree(source, target) (hgmm/hgmm_gpu.py:802-807) =
+ * buildGMMTree(source) (hgmm_gpu.py:466-548) + GMMTree.registration(target) (hgmm_gpu.py:754-768, E-step 550-577) -- a
+ * chain of ~350 small launches for a 40 k-point scan.  These entries run B such pairs through the SAME launches; every
+ * pair's tree, iteration counts, q trace and (R, t) are bitwise those of hgmm_tree_build / hgmm_tree_register on that pair
+ * alone (same device functions, same chunks and orders of summation, same host steps).  No communicator.
+ *
+ * hgmm_set_points_batch_f64   B host arrays [counts[b],3] become ONE resident cloud, cloud after cloud (float64 view only:
+ *                             the flat EM entry points refuse it)
+ * hgmm_tree_build_batch       <- B x buildGMMTree on the resident cloud's B consecutive pieces (each < 400 000 points);
+ *                             init_mu [B][T][3]; outputs (each may be NULL) pi [B][T], mu [B][T][3], cov [B][T][3][3],
+ *                             iters [B][L], q_trace [B][q_capacity] + q_len [B] (levels back to back, as hgmm_tree_build).
+ *                             The levels run in lock-step: a level lasts as long as its slowest cloud.
+ * hgmm_tree_get_nodes_batch   tree b of the resident forest (host tables, as hgmm_tree_build returns them)
+ * hgmm_tree_set_targets_batch <- B x hgmm_tree_set_target
+ * hgmm_tree_register_batch    <- B x hgmm_tree_register on (tree b, target b): rot [B][9], t [B][3], q_prev [B] (NaN: none)
+ *                             updated in place; iters [B]; status [B] as hgmm_tree_register's (a pair that meets status 2
+ *                             leaves the batch at that iteration: the caller finishes it through the serial entries);
+ *                             trace (optional) [B][max_iter][13].  The 6 x 6 solves stay on the host.                       */
+int hgmm_set_points_batch_f64(hgmm_ctx* ctx, int B, const double* const* xyz, const int64_t* counts);
+int hgmm_tree_build_batch(hgmm_ctx* ctx, int B, const int64_t* counts, int L, double ls, double ld,
+                          const double* init_mu, double sig2, int max_iters_per_level,
+                          double* pi_out, double* mu_out, double* cov_out, int32_t* iters_out,
+                          double* q_trace_out, int q_capacity, int32_t* q_len_out);
+int hgmm_tree_get_nodes_batch(hgmm_ctx* ctx, int b, double* pi_out, double* mu_out, double* cov_out);
+int hgmm_tree_set_targets_batch(hgmm_ctx* ctx, int B, const double* const* xyz, const int64_t* counts);
+int hgmm_tree_register_batch(hgmm_ctx* ctx, int B, double* rot, double* t, double scale, double lambda_c,
+                             int max_iter, double tol, double* q_prev_inout, int32_t* iters_out,
+                             int32_t* status_out, double* trace);
 /* The steps buildGMMTree is made of, one at a time (reference function granularity).  Node tables
  * hold T nodes (any T >= 8, need not be a complete tree).
  * hgmm_tree_estep  <- gmmTreeEStep()       hgmm_cupy_cpu_working.py:162-191: parent_idx[N] arbitrary
