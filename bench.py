@@ -769,7 +769,7 @@ def replica_pairs_leg(ctx):
         return {"error": "rc %d: %s" % (r.returncode, r.stderr[-400:])}
     d = json.loads(lines[-1])
     return {"workload": d["config"]["workload"], "pairs_per_s": d["value"], "contexts_per_gpu": d["config"]["contexts_per_gpu"],
-            "ms_per_step": d["ms_per_step"], "registration_iterations_per_pair": d["registration_iterations_per_pair"],
+            "batch": d["config"].get("batch"), "ms_per_step": d["ms_per_step"], "registration_iterations_per_pair": d["registration_iterations_per_pair"],
             "accuracy": d["accuracy"], "kernels_ms_per_pair": d.get("kernels_ms_per_pair"), "blocks": d["timing"]["blocks"]}
 
 
@@ -999,7 +999,7 @@ def split_legs(out, args):
         "predict_ms": _pick(legs, "predict", "kernel_ms"), "mstep_frac": _pick(legs, "materialised_iteration", "roofline", "frac"),
         "kmeans_k800_1M_ms": [_pick(legs, "kmeans_init", "fit_ms_warm"), _pick(legs, "kmeans_init", "seeding_ms_warm")],
         "registration_ms": _pick(legs, "registration", "total_ms"),
-        "replica_pairs_per_s_4ctx": _pick(legs, "replica_pairs", "pairs_per_s"),
+        "replica_pairs_per_s": _pick(legs, "replica_pairs", "pairs_per_s"),
         "allreduce_us_world1_rccl_ipc": [_pick(legs, "collective_world1", "rccl", "allreduce_us"),
                                          _pick(legs, "collective_world1", "ipc", "allreduce_us")],
         "chart_fit_100comp_s": {str(r["points"]): round(r["flat_100_components_30_iterations_s"], 4)
@@ -1308,6 +1308,16 @@ def register_pair(ctx, source, target):
     return res, int(gt.n_iter_)
 
 
+def register_batch(ctx, source, targets):
+    """B units of work through the same launches (hgmm_amd.hgmm.hgmm_gpu.registration_gmmtree_batch): every pair's tree and
+    transformation are bitwise what register_pair returns for it (tests/test_tree_batch_gpu.py).
+    -> ([MstepResult ...], [registration iterations ...])."""
+    from hgmm_amd.hgmm.hgmm_gpu import registration_gmmtree_batch
+    res, info = registration_gmmtree_batch([(source, t) for t in targets], maxiter=PAIR_MAXITER, tol=PAIR_TOL, ctx=ctx,
+                                           return_info=True, **PAIR_KW)
+    return res, info["registration_iters"]
+
+
 def pairs_cpu_baseline():
     """The oracle (oracle/hgmm_tree.py: the CPU twin's buildGMMTree + GMMTree.registration restated in NumPy) on a
     BOUNDED sample of the same pair: every 8th point of both scans, same constants."""
@@ -1354,6 +1364,7 @@ def pairs_main(args):
     # latency chains that leave most of the chip idle -- so a second pair in flight on the same GPU nearly doubles the
     # rate (hgmm_amd.replicas.ReplicaPool(contexts_per_device=...) is the same thing as a product API)
     C = max(1, int(args.contexts_per_gpu))
+    Bt = max(1, int(args.batch))                      # pairs per context and step that share every launch (1: the serial call)
     ctxs = [hgmm_amd.Context(device) for _ in range(C)]
     ctx = ctxs[0]
     info = ctx.device_info()
@@ -1373,11 +1384,15 @@ def pairs_main(args):
                     if n_steps is None:
                         return
                     for _ in range(abs(n_steps)):
-                        tgt, truth = pairs[(wi + C * step) % len(pairs)]
-                        res, n_it = register_pair(c, source, tgt)
+                        ks = [(wi + C * (step * Bt + j)) % len(pairs) for j in range(Bt)]
+                        if Bt == 1:
+                            res, n_it = register_pair(c, source, pairs[ks[0]][0])
+                            results, n_its = [res], [n_it]
+                        else:
+                            results, n_its = register_batch(c, source, [pairs[k][0] for k in ks])
                         if n_steps > 0:                                         # (negative: warm-up, nothing recorded)
-                            iters.append(n_it)
-                            done.append((res.transformation, (wi + C * step) % len(pairs)))   # judged after the timing
+                            iters.extend(n_its)
+                            done.extend((r.transformation, k) for r, k in zip(results, ks))    # judged after the timing
                         step += 1
                     c.synchronize()
                     q_out.put(wi)
@@ -1447,7 +1462,7 @@ def pairs_main(args):
         n_iter_total, n_pairs = float(allr[:, 3].sum()), float(allr[:, 4].sum())
         out = {
             "metric": "registered scan pairs/sec (registration_gmmtree: GMM-tree build of the source + registration of the target)",
-            "value": world * C * K / med, "unit": "pairs/s (all GPUs)", "n_gpus": world, "steps": K, "warmup": W,
+            "value": world * C * K * Bt / med, "unit": "pairs/s (all GPUs)", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * med / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "Stanford bunny scans bun000 / bun045 (tests/golden), poses from the reference's bun.conf",
             "mode": "pairs",
@@ -1456,17 +1471,22 @@ def pairs_main(args):
                                    "motion per pair (4-8 deg, <= 6 mm); registration_gmmtree(source, target, maxiter=20, "
                                    "tol=1e-4, tree_level=3, lambda_c=0.01, ls=20, sig2=0.004) = the reference's unit of work "
                                    "(src/python/hgmm/hgmm_gpu.py:802-807); host arrays in, transformation out",
-                       "pairs_per_gpu_per_step": C, "contexts_per_gpu": C,
+                       "pairs_per_gpu_per_step": C * Bt, "contexts_per_gpu": C, "batch": Bt,
+                       "batching": ("registration_gmmtree_batch: %d pairs per context share every launch (forest build in "
+                                    "lock-step levels + batched registration, the 6 x 6 solves on the host); results bitwise "
+                                    "those of the serial call" % Bt) if Bt > 1 else "none: one registration_gmmtree call per pair",
                        "device": info["name"], "compute_units": info["compute_units"],
-                       "parallelism": "replicas x%d GPUs x %d contexts per GPU, one thread each (no collective)" % (world, C),
+                       "parallelism": "replicas x%d GPUs x %d contexts per GPU, one thread each, x %d pairs per launch set "
+                                      "(no collective)" % (world, C, Bt),
                        **({"rehearsal": "all ranks on ONE device -- flow check, not a measurement"} if rehearsal else {})},
             "timing": {"blocks": len(blocks), "steps_per_block": K, "timed_s": float(sum(blocks)),
-                       "median_block_ms": med * 1e3, "first_block_pairs_per_s": world * C * K / blocks[0],
-                       "rule": "value = world x C x K / median block; a block = K steps (one pair on each of the rank's C "
-                               "contexts, concurrently) between TCP barrier + stream synchronisation on both sides, MAX over ranks"},
-            "pairs_per_s_per_gpu": C * K / med,
+                       "median_block_ms": med * 1e3, "first_block_pairs_per_s": world * C * K * Bt / blocks[0],
+                       "rule": "value = world x C x K x batch / median block; a block = K steps (one batch of pairs on each of "
+                               "the rank's C contexts, concurrently) between TCP barrier + stream synchronisation on both "
+                               "sides, MAX over ranks"},
+            "pairs_per_s_per_gpu": C * K * Bt / med,
             "registration_iterations_per_pair": n_iter_total / max(n_pairs, 1),
-            "registration_iterations_per_s_per_gpu": (n_iter_total / max(n_pairs, 1)) * C * K / med,
+            "registration_iterations_per_s_per_gpu": (n_iter_total / max(n_pairs, 1)) * C * K * Bt / med,
             "accuracy": {"mean_misalignment_before_mm": 1e3 * float(allr[:, 2].mean()),
                          "mean_misalignment_after_mm": 1e3 * float(allr[:, 1].mean()),
                          "max_misalignment_after_mm": 1e3 * float(allr[:, 0].max()), "bound_mm": 6.0, "ok": ok},
@@ -1511,6 +1531,9 @@ def main():
                          "no communicator")
     ap.add_argument("--contexts-per-gpu", type=int, default=4,
                     help="--mode pairs: engine contexts (and threads) per GPU, each registering its own pairs (default 4)")
+    ap.add_argument("--batch", type=int, default=16,
+                    help="--mode pairs: pairs every context takes through the SAME launches per step "
+                         "(registration_gmmtree_batch; 1 = one registration_gmmtree call per pair, round 5's path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--estep-reps", type=int, default=30)
     ap.add_argument("--skip", default="", help="comma-separated side legs to skip (bunny,hgmm,tree_1M,fullcov,...)")

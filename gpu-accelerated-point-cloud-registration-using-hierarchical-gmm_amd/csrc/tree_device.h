@@ -1289,9 +1289,15 @@ inline void sym6_eig_range(const double (&A)[6][6], double* lo, double* hi) {
     double a[6][6];
     for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) a[i][j] = A[i][j];
     for (int sweep = 0; sweep < 30; ++sweep) {
-        double off = 0.0;
-        for (int i = 0; i < 6; ++i) for (int j = i + 1; j < 6; ++j) off += a[i][j] * a[i][j];
-        if (off == 0.0) break;
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < 6; ++i) {
+            diag += a[i][i] * a[i][i];
+            for (int j = i + 1; j < 6; ++j) off += a[i][j] * a[i][j];
+        }
+        // (the range feeds a test against 1e-11 of the largest eigenvalue: off-diagonal mass below 1e-32 of the diagonal's
+        //  moves no eigenvalue by 1e-16 of that scale.  Round 5 iterated to off == 0.0 -- a dozen more sweeps of nothing,
+        //  ~10 us of host time per pair and iteration, which is what bounds a BATCH of registrations)
+        if (off <= 1.0e-32 * diag) break;
         for (int p = 0; p < 6; ++p)
             for (int q = p + 1; q < 6; ++q) {
                 if (a[p][q] == 0.0) continue;

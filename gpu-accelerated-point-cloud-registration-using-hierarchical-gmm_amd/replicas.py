@@ -77,6 +77,13 @@ class ReplicaPool:
                         results[k] = fn(ctx, job)
             except BaseException as e:                       # noqa: BLE001 -- handed to the caller below
                 errors.append((i, e))
+                c = self._ctxs[i]                            # a context that failed mid-call is not handed out again
+                self._ctxs[i] = None
+                if c is not None:
+                    try:
+                        c.close()
+                    except Exception:                        # noqa: BLE001 -- the original error is the one to report
+                        pass
 
         threads = [threading.Thread(target=work, args=(i,), name="hgmm-replica-%d" % i, daemon=True)
                    for i in range(min(len(self.devices), max(len(jobs), 1)))]
@@ -98,18 +105,35 @@ class ReplicaPool:
 
 
 def register_pairs(pairs, devices=None, contexts_per_device: int = 1, maxiter: int = 20, tol: float = 1.0e-4,
-                   method: str = "gmmtree", pool: ReplicaPool | None = None, **kargs):
+                   method: str = "gmmtree", pool: ReplicaPool | None = None, batch: int = 1, **kargs):
     """Register every (source, target) pair of ``pairs`` -- arrays [N,3] or objects with ``.points`` -- with
     ``registration_gmmtree`` (``method='gmmtree'``, hgmm/hgmm_gpu.py:802-807; ``kargs`` = GMMTree's: tree_level,
-    lambda_c, ls, sig2, ...) or ``registration_gmmreg`` (``method='gmmreg'``, gmmreg_gpu/gmmreg.py:149-157), the pairs
-    fanned out over the pool's contexts.  -> the reference's per-pair results, in the order of ``pairs``."""
-    if method == "gmmtree":
-        from .hgmm.hgmm_gpu import registration_gmmtree
+    lambda_c, ls, sig2, ...) or ``registration_gmmreg`` (``method='gmmreg'``, gmmreg_gpu/gmmreg.py:149-157; it has no
+    iteration budget or tolerance of its own, so ``maxiter`` / ``tol`` other than the defaults are refused), the pairs
+    fanned out over the pool's contexts.  -> the reference's per-pair results, in the order of ``pairs``.
 
-        def one(ctx, pair):
-            return registration_gmmtree(pair[0], pair[1], maxiter=maxiter, tol=tol, ctx=ctx, **kargs)
+    ``batch`` > 1 (gmmtree only): every context takes ``batch`` pairs at a time through the SAME launches
+    (``registration_gmmtree_batch``: the trees built as one forest, the targets registered together) -- a 40 k-point pair
+    alone is a chain of ~350 small launches that leaves the chip idle; results are bitwise those of ``batch=1``.  Two
+    contexts per device let one batch's uploads and 6 x 6 solves overlap the other's kernels."""
+    pairs = list(pairs)
+    if method == "gmmtree":
+        from .hgmm.hgmm_gpu import registration_gmmtree, registration_gmmtree_batch
+
+        if int(batch) > 1:
+            def one(ctx, chunk):
+                return registration_gmmtree_batch(chunk, maxiter=maxiter, tol=tol, ctx=ctx, **kargs)
+        else:
+            def one(ctx, pair):
+                return registration_gmmtree(pair[0], pair[1], maxiter=maxiter, tol=tol, ctx=ctx, **kargs)
     elif method == "gmmreg":
         from .gmmreg_gpu.gmmreg import registration_gmmreg
+
+        if int(batch) > 1:
+            raise ValueError("batch > 1 is implemented for method='gmmtree' only")
+        if maxiter != 20 or tol != 1.0e-4:
+            raise ValueError("registration_gmmreg takes neither maxiter nor tol (its optimiser's settings live in "
+                             "L2DistRegistration); leave them at their defaults")
 
         def one(ctx, pair):
             return registration_gmmreg(pair[0], pair[1], ctx=ctx, **kargs)
@@ -118,6 +142,10 @@ def register_pairs(pairs, devices=None, contexts_per_device: int = 1, maxiter: i
     own = pool is None
     pool = pool or ReplicaPool(devices, contexts_per_device)
     try:
+        if method == "gmmtree" and int(batch) > 1:
+            B = int(batch)
+            chunks = [pairs[i:i + B] for i in range(0, len(pairs), B)]
+            return [r for rs in pool.map(one, chunks) for r in rs]
         return pool.map(one, pairs)
     finally:
         if own:

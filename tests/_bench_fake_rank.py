@@ -50,5 +50,6 @@ if "pairs" in sys.argv:                                        # --mode pairs: t
     _cloud = np.random.RandomState(3).rand(50, 3)
     bench.scan_pairs = lambda rank, count=16: (_cloud, [(_cloud + 0.01, _cloud + 1e-4)] * 2)
     bench.register_pair = lambda ctx, source, target: (_Res(), 7)
+    bench.register_batch = lambda ctx, source, targets: ([_Res() for _ in targets], [7] * len(targets))
     bench.pairs_cpu_baseline = lambda: {"value": 0.1, "unit": "pairs/s on the sample", "cores": 1, "kind": "port", "sample": "fake"}
 bench.main()

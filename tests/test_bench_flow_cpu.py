@@ -282,6 +282,14 @@ def test_pairs_mode_two_ranks_without_a_communicator():
         assert d["registration_iterations_per_pair"] == 7.0 and d["accuracy"]["ok"] is True
         assert "collective" not in d["config"] and "allreduce_us" not in d
         assert d["timing"]["blocks"] >= 3
+        # default: batches of pairs through the same launches; value counts pairs, not steps
+        B, C = d["config"]["batch"], d["config"]["contexts_per_gpu"]
+        assert B > 1 and d["config"]["pairs_per_gpu_per_step"] == B * C
+        assert abs(d["value"] * d["timing"]["median_block_ms"] * 1e-3 - 2 * C * d["steps"] * B) < 1e-6 * d["value"]
+    r = _run_launcher(1, "plain", ["--mode", "pairs", "--batch", "1", "--no-cpu-baseline"])         # round 5's path: one call per pair
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert d["config"]["batch"] == 1 and d["config"]["pairs_per_gpu_per_step"] == d["config"]["contexts_per_gpu"]
 
 
 def test_pairs_mode_single_rank_carries_a_cpu_baseline():
