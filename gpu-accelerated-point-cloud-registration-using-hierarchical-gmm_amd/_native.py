@@ -134,6 +134,10 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_kmeans_center_f64", [_vp, C.c_int64, _vp, _vp, _vp])
         _sig(lib, "hgmm_tree_register", [ctx, _vp, _vp, C.c_double, C.c_double, C.c_int, C.c_double, _vp,
                                          C.POINTER(C.c_int), C.POINTER(C.c_int), _vp])
+        _sig(lib, "hgmm_config_count", [])
+        _sig(lib, "hgmm_config_name", [C.c_int], C.c_char_p)
+        _sig(lib, "hgmm_config_set", [ctx, C.c_char_p, C.c_int])
+        _sig(lib, "hgmm_config_get", [ctx, C.c_char_p, C.POINTER(C.c_int)])
         _i64p, _i32p = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
         _sig(lib, "hgmm_set_points_batch_f64", [ctx, C.c_int, C.POINTER(_vp), _i64p])
         _sig(lib, "hgmm_tree_build_batch", [ctx, C.c_int, _i64p, C.c_int, C.c_double, C.c_double, _vp, C.c_double, C.c_int,
@@ -626,6 +630,35 @@ class Context:
 
     def _d2d(self, dst_ptr, src_ptr, nbytes):
         self._check(self.lib.hgmm_d2d(self.h, dst_ptr, src_ptr, int(nbytes)))
+
+    # -- per-context options (hgmm_config_*: each starts from HGMM_<NAME> in the environment at creation) -----------------
+    def config_names(self):
+        return [self.lib.hgmm_config_name(i).decode() for i in range(self.lib.hgmm_config_count())]
+
+    def config_get(self, name):
+        v = C.c_int()
+        self._check(self.lib.hgmm_config_get(self.h, name.encode(), C.byref(v)))
+        return v.value
+
+    def config_set(self, name, value):
+        self._check(self.lib.hgmm_config_set(self.h, name.encode(), int(value)))
+        return self
+
+    def config(self, **options):
+        """``with ctx.config(tree_overlap=0): ...`` -- options set for the block, restored afterwards."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            old = {k: self.config_get(k) for k in options}
+            try:
+                for k, v in options.items():
+                    self.config_set(k, v)
+                yield self
+            finally:
+                for k, v in old.items():
+                    self.config_set(k, v)
+        return scope()
 
     def synchronize(self):
         self._check(self.lib.hgmm_synchronize(self.h))

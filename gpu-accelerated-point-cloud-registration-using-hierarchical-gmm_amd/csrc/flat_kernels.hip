@@ -683,14 +683,12 @@ __global__ __launch_bounds__(BLOCK) void flat_logprob_rows_pk_kernel(
 // (The single-row kernel this replaces for predict ran 0.33 ms per 10^6 x 800 frame; its row maximum, index search
 //  and two 6-step wave reductions were one dependent chain per row.)
 // ------------------------------------------------------------------------------------------
-// MODE 0: every lane searches its own K values for the row maximum (compare + select per component on all 64 lanes)
-//         and a second 4-wide DPP reduction finds the smallest index -- although ONE lane holds the maximum.
-// MODE 1: the search leaves the per-lane VALU stream: `ballot(lane_max == m)` names the lanes that hold the maximum; when
-//         it is exactly one lane (every row of real data) its K values are read into SGPRs (K v_readlane) and compared as
-//         bit patterns on the scalar unit, which runs beside the other waves' vector work.  Ties across lanes, a +0 / -0
-//         pair or NaNs take the MODE 0 search for that row alone (wave-uniform branch), so the labels are those of MODE 0
-//         bit for bit.
-template <int NV4, int NV1, int MODE>
+// Every lane searches its own K values for the row maximum (compare + select per component on all 64 lanes) and a second
+// 4-wide DPP reduction finds the smallest index.  (Round 5 built the alternative -- ballot the lanes that hold the maximum,
+// read the single holder's K values into SGPRs, compare on the scalar unit: 157 instead of 174 registers, three waves per
+// SIMD -- and measured 0.251 against 0.246 ms at J = 800, 0.334 against 0.276 at J = 1024: removed in round 6,
+// profiles/r05/predict_modes.log keeps the figures.)
+template <int NV4, int NV1>
 __global__ __launch_bounds__(BLOCK) void flat_predict_rows_kernel(
     const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int J, int Jpad,
     int32_t* __restrict__ labels) {
@@ -720,11 +718,9 @@ __global__ __launch_bounds__(BLOCK) void flat_predict_rows_kernel(
         g0s = ld(PK_G + 0, j); g1s = ld(PK_G + 1, j); g2s = ld(PK_G + 2, j);
         cs = ld(PK_C, j);
     }
-    float njf[MODE == 0 ? K : 1];                  // -(index): the smallest index is the largest of these
-    if (MODE == 0) {
+    float njf[K];                                  // -(index): the smallest index is the largest of these
 #pragma unroll
-        for (int k = 0; k < K; ++k) njf[k] = -(float)L::j_of(k, lane);
-    }
+    for (int k = 0; k < K; ++k) njf[k] = -(float)L::j_of(k, lane);
 
     const int64_t nw = (int64_t)gridDim.x * WAVES_PER_BLOCK;
     const int64_t gw = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave_in_block();
@@ -770,52 +766,19 @@ __global__ __launch_bounds__(BLOCK) void flat_predict_rows_kernel(
             }
             m[r] = mm;
         }
-        float lm[ROWS];
-        if (MODE == 1) {
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) lm[r] = m[r];
-        }
         wave_max4_dpp(m);
         float b[ROWS];
-        if (MODE == 1) {
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                const unsigned long long holders = __builtin_amdgcn_ballot_w64(lm[r] == m[r]);
-                int kk = -1, hl = 0;
-                if (__builtin_popcountll(holders) == 1) {          // wave-uniform
-                    hl = (int)__builtin_ctzll(holders);
-                    const int mb = __float_as_int(m[r]);
+        for (int r = 0; r < ROWS; ++r) {
+            float best = NEG_INF;                                  // descending k: the last hit is the lane's smallest index
 #pragma unroll
-                    for (int k = K - 1; k >= 0; --k) {
-                        const float val = (ODD && k == K - 1) ? wls[r] : ((k & 1) ? wl[r][k >> 1].y : wl[r][k >> 1].x);
-                        kk = (__builtin_amdgcn_readlane(__float_as_int(val), hl) == mb) ? k : kk;
-                    }
-                }
-                if (kk >= 0) {
-                    b[r] = -(float)L::j_of(kk, hl);
-                } else {                                            // several holders, or no bitwise match: the per-lane search
-                    int bk = -1;                                    // (slot numbers are inline constants: no index table in registers)
-#pragma unroll
-                    for (int k = K - 1; k >= 0; --k) {
-                        const float val = (ODD && k == K - 1) ? wls[r] : ((k & 1) ? wl[r][k >> 1].y : wl[r][k >> 1].x);
-                        bk = (val == m[r]) ? k : bk;
-                    }
-                    b[r] = wave_max_dpp(bk < 0 ? NEG_INF : -(float)L::j_of(bk, lane));
-                }
+            for (int k = K - 1; k >= 0; --k) {
+                const float val = (ODD && k == K - 1) ? wls[r] : ((k & 1) ? wl[r][k >> 1].y : wl[r][k >> 1].x);
+                best = (val == m[r]) ? njf[k] : best;
             }
-        } else {
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                float best = NEG_INF;                              // descending k: the last hit is the lane's smallest index
-#pragma unroll
-                for (int k = K - 1; k >= 0; --k) {
-                    const float val = (ODD && k == K - 1) ? wls[r] : ((k & 1) ? wl[r][k >> 1].y : wl[r][k >> 1].x);
-                    best = (val == m[r]) ? njf[MODE == 0 ? k : 0] : best;
-                }
-                b[r] = best;
-            }
-            wave_max4_dpp(b);
+            b[r] = best;
         }
+        wave_max4_dpp(b);
         if (lane < ROWS) {
             const int64_t row = g * ROWS + lane;
             const float mb = lane == 0 ? m[0] : lane == 1 ? m[1] : lane == 2 ? m[2] : m[3];
@@ -833,100 +796,13 @@ __global__ __launch_bounds__(BLOCK) void flat_predict_rows_kernel(
 // ------------------------------------------------------------------------------------------
 // fused E+M: sufficient statistics without the N x J round trip
 //   s0_j = sum_i r_ij,  a_jd = sum_i r_ij (x_id - mu_jd),  b_jd = sum_i r_ij (x_id - mu_jd)^2
-// ------------------------------------------------------------------------------------------
-template <int NSLOT>
-__global__ __launch_bounds__(BLOCK) void flat_fused_kernel(
-    const float* __restrict__ X, const float* __restrict__ pack, int64_t n, int J, int Jpad,
-    float* __restrict__ partials, double* __restrict__ lpn_partials,
-    const int* __restrict__ done_flag) {
-    if (done_flag && *done_flag) return;
-    constexpr int K = NSLOT;
-    const int lane = lane_id();
-    LaneParams<0, NSLOT> P;
-    P.load(pack, Jpad, lane);
-    float a_s0[K], a_a0[K], a_a1[K], a_a2[K], a_b0[K], a_b1[K], a_b2[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) a_s0[k] = a_a0[k] = a_a1[k] = a_a2[k] = a_b0[k] = a_b1[k] = a_b2[k] = 0.f;
-
-    int64_t r0, r1;
-    wave_row_range(n, r0, r1);
-    double lsum = 0.0;
-    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
-    if (r0 < r1) { const float* xp = X + 3 * r0; x0 = xp[0]; x1 = xp[1]; x2 = xp[2]; }
-    for (int64_t row = r0; row < r1; ++row) {
-        // prefetch the next row's coordinates (wave-uniform scalar loads) behind this row's math
-        const int64_t nrow = (row + 1 < r1) ? row + 1 : row;
-        const float* xn = X + 3 * nrow;
-        const float nx0 = xn[0], nx1 = xn[1], nx2 = xn[2];
-
-        float wl[K];
-        float m = row_wl2<0, NSLOT>(P, x0, x1, x2, wl);
-        m = wave_max_dpp(m);
-        if (m == NEG_INF) m = 0.f;
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            wl[k] = __builtin_amdgcn_exp2f(wl[k] - m);
-            s += wl[k];
-        }
-        s = wave_sum_dpp(s);
-        float inv_den;
-        const float lpn2 = lpn2_from(m, s, inv_den);
-        lsum += (double)(lpn2 * LN2);
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float rr = wl[k] * inv_den;
-            const float d0 = x0 - P.mu0[k], d1 = x1 - P.mu1[k], d2 = x2 - P.mu2[k];
-            const float rd0 = rr * d0, rd1 = rr * d1, rd2 = rr * d2;
-            a_s0[k] += rr;
-            a_a0[k] += rd0; a_a1[k] += rd1; a_a2[k] += rd2;
-            a_b0[k] = fmaf(rd0, d0, a_b0[k]);
-            a_b1[k] = fmaf(rd1, d1, a_b1[k]);
-            a_b2[k] = fmaf(rd2, d2, a_b2[k]);
-        }
-        x0 = nx0; x1 = nx1; x2 = nx2;
-    }
-
-    // combine the workgroup's waves through LDS in a fixed order (deterministic), one HBM write
-    __shared__ float sh[FLAT_NSTAT * NSLOT * 64];
-    __shared__ double shl[WAVES_PER_BLOCK];
-    const int w = wave_in_block();
-    if (lane == 0) shl[w] = lsum;
-    for (int turn = 0; turn < WAVES_PER_BLOCK; ++turn) {
-        if (w == turn) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const int j = k * 64 + lane;
-                float* p = sh + j;
-                constexpr int ST = NSLOT * 64;
-                if (turn == 0) {
-                    p[0 * ST] = a_s0[k]; p[1 * ST] = a_a0[k]; p[2 * ST] = a_a1[k]; p[3 * ST] = a_a2[k];
-                    p[4 * ST] = a_b0[k]; p[5 * ST] = a_b1[k]; p[6 * ST] = a_b2[k];
-                } else {
-                    p[0 * ST] += a_s0[k]; p[1 * ST] += a_a0[k]; p[2 * ST] += a_a1[k]; p[3 * ST] += a_a2[k];
-                    p[4 * ST] += a_b0[k]; p[5 * ST] += a_b1[k]; p[6 * ST] += a_b2[k];
-                }
-            }
-        }
-        __syncthreads();
-    }
-    float* outp = partials + (size_t)blockIdx.x * FLAT_NSTAT * Jpad;
-    for (int idx = threadIdx.x; idx < FLAT_NSTAT * NSLOT * 64; idx += BLOCK) {
-        const int st = idx / (NSLOT * 64), j = idx % (NSLOT * 64);
-        outp[st * Jpad + j] = sh[idx];
-    }
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int i = 0; i < WAVES_PER_BLOCK; ++i) t += shl[i];
-        lpn_partials[blockIdx.x] = t;
-    }
-}
-
+// (the un-paired kernel of round 1 -- one component per VALU lane-instruction -- stayed behind HGMM_FUSED_PK=0 until
+//  round 6 and went with the switch: nothing else reached it)
 // ------------------------------------------------------------------------------------------
 // fused E+M with explicitly paired arithmetic: components (2p, 2p+1) of a lane travel together as
 // a float2, so that the centred quadratic form and the moment update issue as v_pk_add/mul/fma_f32
 // (two components per VALU instruction; the fp32 peak of gfx950 is only reachable with packed
-// ops).  Same mathematics, statistics layout and output as flat_fused_kernel.
+// ops).
 // ------------------------------------------------------------------------------------------
 //
 // CS = constant-shift log-sum-exp.  wl2_j <= c2_j for every point (the quadratic form is <= 0),
@@ -1855,16 +1731,6 @@ static void pick_layout(int J, int* nv4, int* nv1) {
     }
 }
 
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    if (!v || !*v) return dflt;
-    return atoi(v);
-}
-static bool env_flag(const char* name, bool dflt) {
-    const char* v = getenv(name);
-    if (!v || !*v) return dflt;
-    return v[0] != '0';
-}
 
 // LAYOUT_DISPATCH(nv4, nv1, M): expands M(NV4, NV1) for the supported (NV4, NV1) pairs
 #define LAYOUT_DISPATCH(nv4, nv1, M)                                                           \
@@ -1911,11 +1777,11 @@ constexpr double PACE_CEILING_GBS = 7600.0;
 
 // the rate the next paced launch of J-float rows offers
 static double pace_target(hgmm_ctx* c, int J) {
-    const int fixed = env_int("HGMM_ESTEP_TARGET_GBS", -1);
+    const int fixed = c->cfg[CFG_ESTEP_TARGET_GBS];
     if (fixed >= 0) return (double)fixed;
     PaceCtl& p = c->pace;
     if (p.target <= 0.0 || p.J != J) {
-        p.target = (double)env_int("HGMM_PACE_START", ESTEP_TARGET_GBS);
+        p.target = (double)c->cfg[CFG_PACE_START];
         p.strikes = p.clean = p.probe_seen = 0;
         p.probe_after = PACE_PROBE_AFTER;
         p.probe_base = 0.0;
@@ -1928,7 +1794,6 @@ static double pace_target(hgmm_ctx* c, int J) {
 // look at the launches that have finished since the last call (no waiting)
 static void pace_poll(hgmm_ctx* c) {
     PaceCtl& p = c->pace;
-    const bool probing_allowed = env_flag("HGMM_ESTEP_PROBE", true);
     while (p.tail != p.head) {
         const unsigned s = p.tail % PaceCtl::RING;
         if (hipEventQuery(p.ev[s][1]) != hipSuccess) { (void)hipGetLastError(); break; }
@@ -1975,14 +1840,14 @@ static void pace_poll(hgmm_ctx* c) {
                 }
             } else {
                 p.strikes = 0;
-                if (p.ceiling < 1e29 && ++p.since_ceiling >= env_int("HGMM_PACE_FORGET", PACE_FORGET_AFTER)) {
+                if (p.ceiling < 1e29 && ++p.since_ceiling >= c->cfg[CFG_PACE_FORGET]) {
                     p.ceiling = 1e30;                       // what congested then need not congest now: probe afresh
                     p.since_ceiling = 0;
                     p.probe_after = PACE_PROBE_AFTER;
                     p.ceilings_forgotten++;
                 }
                 const double up = p.target * PACE_PROBE_STEP;
-                if (probing_allowed && ++p.clean >= p.probe_after && up < p.ceiling * 0.995 && up <= PACE_CEILING_GBS) {
+                if (++p.clean >= p.probe_after && up < p.ceiling * 0.995 && up <= PACE_CEILING_GBS) {
                     p.probe_base = p.target;
                     p.target = up;
                     p.probe_seen = 0;
@@ -1997,13 +1862,13 @@ static void pace_poll(hgmm_ctx* c) {
 static bool pace_observe_begin(hgmm_ctx* c, double target, double bytes, int grid, unsigned long long** stamp_out) {
     PaceCtl& p = c->pace;
     *stamp_out = nullptr;
-    if (env_int("HGMM_ESTEP_TARGET_GBS", -1) >= 0 || !env_flag("HGMM_ESTEP_ADAPT", true)) return false;
+    if (c->cfg[CFG_ESTEP_TARGET_GBS] >= 0) return false;            // a fixed rate: nothing to control
     if (bytes < PACE_MIN_BYTES || target <= 0.0) return false;
     if (!p.have_events) {
         for (auto& pr : p.ev)
             if (hipEventCreate(&pr[0]) != hipSuccess || hipEventCreate(&pr[1]) != hipSuccess) return false;
         p.have_events = true;
-        if (env_flag("HGMM_PACE_STAMPS", true)) {
+        {
             void* h = nullptr;
             void* d = nullptr;
             const size_t bytes_st = sizeof(unsigned long long) * PaceCtl::RING * 2 * PaceCtl::STAMP_WG;
@@ -2079,28 +1944,20 @@ static bool launch_estep_rows(hgmm_ctx* c, int nv4, int nv1, int grid_r, bool cs
 // estimate_log_prob on the four-rows-in-flight kernel (the layouts the materialising E-step is instantiated for); false: not instantiated
 static bool launch_logprob_rows(hgmm_ctx* c, int nv4, int nv1, float* log_prob) {
     const FlatState& f = c->flat;
-    if (env_flag("HGMM_LOGPROB_SINGLE_ROW", false)) return false;
     const bool have = (nv4 >= 1 && nv4 <= 3 && nv1 <= 2) || (nv4 == 4 && nv1 == 0) || (nv4 == 0 && (nv1 == 1 || nv1 == 2));
     if (!have) return false;
     // Grid: with no reduction and no exponential left, the store stream is all this kernel waits for.  Un-paced it ran
     // 0.60 ms at every grid from 128 to 4096 workgroups on the box where the E-step took 0.54 (tools/logprob_sweep.py):
     // the write path was over-subscribed.  Paced like the E-step (StorePacer), two workgroups per CU: 0.506 ms.
     const int64_t groups = (c->n + 3) / 4;
-    int64_t g64 = (int64_t)c->cus * std::max(1, std::min(2, env_int("HGMM_LOGPROB_BPC", 2)));
-    if (env_int("HGMM_LOGPROB_GRID", 0) > 0) g64 = env_int("HGMM_LOGPROB_GRID", 0);
+    const int64_t g64 = (int64_t)c->cus * 2;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(g64, (groups + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
     const float* X = c->x_aos.as<float>();
     const float* pk = c->f_pack.as<float>();
     ProfScope prof(c, HGMM_K_FLAT_ESTEP);
-    const bool late = env_flag("HGMM_LOGPROB_LATE", true);
     // (the raw table follows the rate the E-step's controller has settled on for this row length)
-    const int lp_fixed = env_int("HGMM_LOGPROB_TARGET_GBS", -1);
-    const int pace = store_pace16(c, grid, f.J, lp_fixed >= 0 ? (double)lp_fixed : pace_target(c, f.J));
-#define LOGP_R(A, B)                                                                                                 \
-    do {                                                                                                             \
-        if (late) flat_logprob_rows_pk_kernel<A, B, true><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, log_prob, pace);  \
-        else flat_logprob_rows_pk_kernel<A, B, false><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, log_prob, pace);      \
-    } while (0)
+    const int pace = store_pace16(c, grid, f.J, pace_target(c, f.J));
+#define LOGP_R(A, B) flat_logprob_rows_pk_kernel<A, B, true><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, log_prob, pace)
     if (nv4 == 3 && nv1 == 1) LOGP_R(3, 1);
     else if (nv4 == 3 && nv1 == 0) LOGP_R(3, 0);
     else if (nv4 == 3 && nv1 == 2) LOGP_R(3, 2);
@@ -2119,8 +1976,8 @@ static bool launch_logprob_rows(hgmm_ctx* c, int nv4, int nv1, float* log_prob) 
 }
 
 // predict(): the four-rows-in-flight arg-max kernel for the layouts it is instantiated for (the others take the general kernel)
-static bool predict_rows_layout(int nv4, int nv1) {
-    if (env_flag("HGMM_PREDICT_SINGLE_ROW", false)) return false;
+static bool predict_rows_layout(const hgmm_ctx* c, int nv4, int nv1) {
+    if (c->cfg[CFG_PREDICT_SINGLE_ROW]) return false;
     return (nv4 == 3 && nv1 <= 2) || (nv4 == 4 && nv1 == 0) || (nv4 == 2 && nv1 <= 2) || (nv4 == 1 && nv1 <= 2) ||
            (nv4 == 0 && (nv1 == 1 || nv1 == 2));
 }
@@ -2128,19 +1985,12 @@ static bool launch_predict_rows(hgmm_ctx* c, int nv4, int nv1, int32_t* labels) 
     const FlatState& f = c->flat;
     // (one frame of 10^6 x 800: 0.38 / 0.26 / 0.26 / 0.24 ms with 1 / 2 / 3 / 4 workgroups per CU; the single-row kernel 0.36)
     // (N = 1e6: 8 workgroups per CU beat 4 at every J -- 0.258 -> 0.235 ms at J = 800, 0.080 -> 0.072 at J = 100; profiles/r04/small_j_grids.log)
-    const int grid = grid_for(c, (c->n + 3) / 4, env_int("HGMM_PREDICT_BPC", c->n >= 400000 ? 8 : 4));
+    const int grid = grid_for(c, (c->n + 3) / 4, c->n >= 400000 ? 8 : 4);
     const float* X = c->x_aos.as<float>();
     const float* pk = c->f_pack.as<float>();
-    // (MODE 1 -- ballot + 13 v_readlane + scalar compares, 157 VGPRs = 3 waves per SIMD instead of 174 = 2 -- measured on the
-    //  C3 frame: 0.251 ms against MODE 0's 0.246 at J = 800, 0.334 against 0.276 at J = 1024, equal within noise below;
-    //  labels identical.  profiles/r05/predict_modes.log.  The marginal cost per component is already the VALU floor of
-    //  4.5 packed + 2.5 plain instructions; what remains is ~0.06 ms that does not depend on J.)
-    const int mode = env_int("HGMM_PREDICT_MODE", 0);
-#define PRED_R(A, B)                                                                                                 \
-    do {                                                                                                             \
-        if (mode == 1) flat_predict_rows_kernel<A, B, 1><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, labels);  \
-        else flat_predict_rows_kernel<A, B, 0><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, labels);           \
-    } while (0)
+    // (the marginal cost per component is the VALU floor of 4.5 packed + 2.5 plain instructions; what remains is ~0.06 ms
+    //  that does not depend on J)
+#define PRED_R(A, B) flat_predict_rows_kernel<A, B><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, labels)
     if (nv4 == 3 && nv1 == 1) PRED_R(3, 1);
     else if (nv4 == 3 && nv1 == 0) PRED_R(3, 0);
     else if (nv4 == 3 && nv1 == 2) PRED_R(3, 2);
@@ -2181,8 +2031,7 @@ static bool launch_predict_rows(hgmm_ctx* c, int nv4, int nv1, int32_t* labels) 
 // waited for, two workgroups per CU; after an idle moment 3/4 of the CUs.
 static int estep_rows_grid(hgmm_ctx* c, bool cshift) {
     const bool after_mstep = c->flat.last_kernel == 2 || (c->flat.last_kernel == 1 && !c->flat.idle_since_launch);
-    const int full = grid_for(c, (c->n + 3) / 4, env_int("HGMM_ESTEP_BPC", after_mstep ? 2 : 1));
-    if (env_int("HGMM_ESTEP_GRID", 0) > 0) return std::min(full, env_int("HGMM_ESTEP_GRID", 0));
+    const int full = grid_for(c, (c->n + 3) / 4, after_mstep ? 2 : 1);
     if (after_mstep) return full;
     return cshift ? std::min(full, std::max(1, c->cus * 3 / 4)) : full;
 }
@@ -2190,7 +2039,7 @@ static int estep_rows_grid(hgmm_ctx* c, bool cshift) {
 template <bool NORMALISE>
 static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argmax, int* grid_out) {
     const FlatState& f = c->flat;
-    const int grid = grid_for(c, c->n, env_int("HGMM_ESTEP1_BPC", 2));
+    const int grid = grid_for(c, c->n, 2);
     *grid_out = grid;
     const float* X = c->x_aos.as<float>();
     const float* pk = c->f_pack.as<float>();
@@ -2200,9 +2049,9 @@ static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argma
     // (single-row kernel) non-temporal stores only for rows that are whole 16-byte pieces: J = 513 wrote its table in 0.364 ms
     // with them and in 0.251 ms without -- a line two rows share is written twice, each time in part
     // (profiles/r04/estep_nt_by_J.log)
-    const bool nt = NORMALISE && env_flag("HGMM_ESTEP_NT", true) && f.J % 4 == 0;
-    const int rr = env_int("HGMM_ESTEP_RR", 0);
-    if (!NORMALISE && !log_resp && !lpn && argmax && predict_rows_layout(nv4, nv1)) {      // predict(): labels only
+    const bool nt = NORMALISE && f.J % 4 == 0;
+    const int rr = 0;
+    if (!NORMALISE && !log_resp && !lpn && argmax && predict_rows_layout(c, nv4, nv1)) {      // predict(): labels only
         ProfScope prof(c, HGMM_K_FLAT_ESTEP);
         (void)launch_predict_rows(c, nv4, nv1, argmax);
         HGMM_HIP(c, hipGetLastError());
@@ -2217,9 +2066,9 @@ static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argma
         }
     }
     // Materialising path: 4 rows in flight per wave, at most ONE workgroup per CU (see the kernel's header)
-    const int rows = (NORMALISE && log_resp) ? env_int("HGMM_ESTEP_ROWS", 4) : 1;
+    const int rows = (NORMALISE && log_resp) ? 4 : 1;
     if (rows > 1) {
-        const bool cshift = env_flag("HGMM_ESTEP_CS", true) && !argmax;
+        const bool cshift = !argmax;
         // Paced stores (StorePacer): two workgroups per CU -- all resident at once, which the pacer's period assumes, and
         // enough waves for the arithmetic to keep up at any core clock -- offering the rows at the controlled target
         // rate (ESTEP_TARGET_GBS above).  The write path takes an evenly paced, phase-staggered 6.8 TB/s of these rows in
@@ -2230,7 +2079,7 @@ static int launch_estep(hgmm_ctx* c, float* log_resp, float* lpn, int32_t* argma
         //  resident, as the pacer's period assumes -- hide more of the rows' reduction chains: J = 64 0.110 -> 0.082 ms at
         //  N = 1e6; from J = 256 on two are as good or better, and more than fit at once break the pacing: profiles/r04/small_j_grids.log)
         const int bpc_rows = (c->n >= 400000 && f.J <= 128) ? 4 : 2;
-        const int grid_r = target > 0.0 ? grid_for(c, (c->n + 3) / 4, std::min(bpc_rows, env_int("HGMM_ESTEP_BPC", bpc_rows)))
+        const int grid_r = target > 0.0 ? grid_for(c, (c->n + 3) / 4, bpc_rows)
                                         : estep_rows_grid(c, cshift);
         const int pace = store_pace16(c, grid_r, f.J, target);
         c->flat.last_kernel = 1;
@@ -2275,17 +2124,14 @@ static int launch_fused(hgmm_ctx* c, const int* done_flag, int* grid_out, int* v
     // lanes hold few components and leave the register file empty, gain 10 - 28 % from 6 - 8 per CU: more resident waves
     // hide the row's reduction chain (N = 1e6: J = 64 0.105 -> 0.075 ms per iteration, J = 100 0.117 -> 0.098, J = 400
     // 0.227 -> 0.202; profiles/r04/fused_bpc_by_J.log).  More workgroups are more partials for the reduction to read:
-    // the iteration times above include it.  HGMM_FUSED_BPC=<n> fixes the number per CU.
+    // the iteration times above include it.  
     int grid;
-    if (env_int("HGMM_FUSED_BPC", 0) > 0) {
-        grid = grid_for(c, c->n, env_int("HGMM_FUSED_BPC", 2));
-    } else {
+    {
         const int bpc_max = ns <= 4 ? 8 : (ns <= 8 ? 6 : 4);
         const int64_t by_rows = c->n / (WAVES_PER_BLOCK * 100);
         const int64_t big = std::min<int64_t>(by_rows, std::min<int64_t>((int64_t)c->cus * bpc_max, FLAT_MAX_BLOCKS));
         grid = (int)std::max<int64_t>(grid_for(c, c->n, 2), big);
     }
-    if (env_int("HGMM_FUSED_GRID", 0) > 0) grid = std::min(grid, env_int("HGMM_FUSED_GRID", 0));
     *grid_out = grid;
     const float* X = c->x_aos.as<float>();
     const float* pk = c->f_pack.as<float>();
@@ -2298,24 +2144,16 @@ static int launch_fused(hgmm_ctx* c, const int* done_flag, int* grid_out, int* v
     //    which tips J = 800 over the 256-register line: 0.66 - 0.78 ms;
     //  * wave-uniform skipping of 64-component slots whose responsibilities are all < 1e-10
     //    never triggers while components are broad: 0 % gain.
-    const bool paired = env_flag("HGMM_FUSED_PK", true);
     //  * two rows in flight in the constant-shift kernel (differences recomputed instead of kept, so that
     //    only the exponentials of a row live between its phases): 216 instead of 221 instructions per row,
     //    but 256 VGPRs + 4 AGPRs = one wave per SIMD, 0.46 - 0.48 ms; forced to two waves per SIMD it
     //    spills 372 B per lane, 0.43 ms; one row (248 VGPRs, two waves per SIMD) stays the best, 0.405 ms;
-    //  * constant-shift log-sum-exp (HGMM_FUSED_CS, default on): see flat_fused_pk_kernel;
-    //    0.514 -> 0.440 ms.  (Round 1 saw no gain from the same change in the materialising E-step; with one
-    //    workgroup per CU that kernel turned out to be issue-bound, and the shorter loop pays once the grid is cut
-    //    to 3/4 of the CUs -- see estep_rows_grid.)
-    const bool cshift = env_flag("HGMM_FUSED_CS", true);
+    //  * constant-shift log-sum-exp: see flat_fused_pk_kernel; 0.514 -> 0.440 ms (a table whose largest constant
+    //    leaves the safe range takes the kernel's row-maximum loop by itself).
 #define FUSED_CASE(S)                                                                           \
     do {                                                                                        \
-        if (paired)                                                                             \
-            flat_fused_pk_kernel<S><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, part,  \
-                                                                  lp, done_flag, cshift ? 1 : 0); \
-        else                                                                                    \
-            flat_fused_kernel<S><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, part,   \
-                                                               lp, done_flag);                 \
+        flat_fused_pk_kernel<S><<<grid, BLOCK, 0, c->stream>>>(X, pk, c->n, f.J, f.Jpad, part,  \
+                                                              lp, done_flag, 1);              \
         *valid_j = S * 64;                                                                      \
     } while (0)
     ProfScope prof(c, HGMM_K_FLAT_FUSED);
@@ -2558,7 +2396,7 @@ extern "C" int hgmm_pace_reset(hgmm_ctx* c) {
 extern "C" int hgmm_pace_info(hgmm_ctx* c, double* target_gbs_out, int* steps_down_out, int* steps_up_out) {
     HGMM_ENTER(c);
     pace_poll(c);
-    const int fixed = env_int("HGMM_ESTEP_TARGET_GBS", -1);
+    const int fixed = c->cfg[CFG_ESTEP_TARGET_GBS];
     if (target_gbs_out) *target_gbs_out = fixed >= 0 ? (double)fixed : (c->pace.target > 0.0 ? c->pace.target : (double)ESTEP_TARGET_GBS);
     if (steps_down_out) *steps_down_out = c->pace.steps_down;
     if (steps_up_out) *steps_up_out = c->pace.steps_up;
@@ -2640,9 +2478,8 @@ static int flat_mstep_enqueue(hgmm_ctx* c, int cov_type, int variant, int J, con
     //  memory-level parallelism unused -- N = 1e6: J = 64 0.133 -> 0.061 ms with 8, J = 100 0.153 -> 0.082, J = 200 0.183 -> 0.131
     //  with 4, J = 400 0.271 -> 0.257; from J = 512 on two again: profiles/r04/small_j_grids.log)
     const int bpc_m = c->n >= 400000 ? (J <= 128 ? 8 : (J <= 448 ? 4 : 2)) : 2;
-    int grid = grid_for(c, c->n, env_int("HGMM_MSTEP_BPC", bpc_m));
-    if (env_int("HGMM_MSTEP_GRID", 0) > 0) grid = std::min(grid_for(c, c->n, 4), env_int("HGMM_MSTEP_GRID", 0));
-    const int rr = env_int("HGMM_MSTEP_RR", 1);     // rows dealt round-robin: 0.480 against 0.492 ms (profiles/r04/mstep_nt_rr_sweep.log)
+    const int grid = grid_for(c, c->n, bpc_m);
+    const int rr = 1;                               // rows dealt round-robin: 0.480 against 0.492 ms (profiles/r04/mstep_nt_rr_sweep.log)
     const float* X = c->x_aos.as<float>();
     float* part = c->f_partials.as<float>();
     const float* hint = c->f_hint.as<float>();
@@ -2650,7 +2487,7 @@ static int flat_mstep_enqueue(hgmm_ctx* c, int cov_type, int variant, int J, con
     // non-temporal loads: 6.1 -> 6.8 TB/s at J = 800, a gain or a tie for every row length that is a whole number of
     // 16-byte pieces -- and a loss when rows straddle them (J = 513: 0.380 vs 0.351 ms, J = 37: 0.176 vs 0.142: a line shared by
     // two rows is then fetched for each of them; profiles/r04/mstep_nt_by_J.log)
-    const bool ntload = env_flag("HGMM_MSTEP_NT", true) && J % 4 == 0;
+    const bool ntload = J % 4 == 0;
 #define MSTEP_LAUNCH(A, B, RESP, HINT, JV, PART)                                                               \
     do {                                                                                                       \
         if (is_log) {                                                                                          \

@@ -11,6 +11,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <cctype>
 #include <cerrno>
 #include <chrono>
 #include <algorithm>
@@ -236,7 +237,7 @@ constexpr size_t IPC_SLOT = (size_t)1 << 16;           // doubles per slot (512 
 constexpr int IPC_MAX_CHUNKS = (int)(IPC_SLOT / IPC_CHUNK);
 constexpr size_t IPC_FLAG_BYTES = sizeof(unsigned long long) * 2 * IPC_MAX_RANKS * IPC_MAX_CHUNKS;
 constexpr size_t IPC_BUF_BYTES = IPC_FLAG_BYTES + sizeof(double) * 2 * IPC_MAX_RANKS * IPC_SLOT;
-constexpr double IPC_TIMEOUT_S = 20.0;
+
 
 struct IpcShm {
     std::atomic<int> ready;
@@ -628,6 +629,53 @@ extern "C" const char* hgmm_last_error(const hgmm_ctx* c) {
     return g_create_error.c_str();
 }
 
+namespace hgmm {
+const ConfigSpec CONFIG_SPECS[CFG_COUNT] = {
+    {"estep_target_gbs", -1, -1, 20000}, {"pace_start", 6600, 1000, 20000}, {"pace_forget", 10000, 1, 1 << 30},
+    {"predict_single_row", 0, 0, 1},     {"tree_no_chol", 0, 0, 1},         {"tree_rel", 0, 0, 1},
+    {"tree_ahead", 2, 0, 64},            {"tree_tickets", 0, 0, 1},         {"tree_overlap", 1, 0, 1},
+    {"fullcov_two_pass", 0, 0, 1},       {"kmpp_two_launches", 0, 0, 1},    {"kmeans_acc_regs", 0, 0, 1},
+    {"ipc_timeout_s", 20, 1, 600},
+};
+static int config_find(const char* name) {
+    if (!name) return -1;
+    for (int k = 0; k < CFG_COUNT; ++k)
+        if (std::strcmp(name, CONFIG_SPECS[k].name) == 0) return k;
+    return -1;
+}
+// defaults, then HGMM_<NAME> from the environment (the library's one getenv)
+static void config_init(hgmm_ctx* c) {
+    for (int k = 0; k < CFG_COUNT; ++k) {
+        const ConfigSpec& sp = CONFIG_SPECS[k];
+        c->cfg[k] = sp.dflt;
+        std::string var = "HGMM_";
+        for (const char* p = sp.name; *p; ++p) var += (char)std::toupper((unsigned char)*p);
+        const char* v = std::getenv(var.c_str());
+        if (v && *v) c->cfg[k] = std::max(sp.lo, std::min(sp.hi, atoi(v)));
+    }
+}
+}  // namespace hgmm
+
+extern "C" int hgmm_config_count(void) { return CFG_COUNT; }
+extern "C" const char* hgmm_config_name(int index) { return (index >= 0 && index < CFG_COUNT) ? CONFIG_SPECS[index].name : nullptr; }
+extern "C" int hgmm_config_set(hgmm_ctx* c, const char* name, int value) {
+    if (!c) return HGMM_ERR_ARG;
+    const int k = config_find(name);
+    if (k < 0) return fail(c, HGMM_ERR_ARG, "hgmm_config_set: unknown option '%s'", name ? name : "(null)");
+    const ConfigSpec& sp = CONFIG_SPECS[k];
+    if (value < sp.lo || value > sp.hi)
+        return fail(c, HGMM_ERR_ARG, "hgmm_config_set: %s = %d outside [%d, %d]", sp.name, value, sp.lo, sp.hi);
+    c->cfg[k] = value;
+    return HGMM_OK;
+}
+extern "C" int hgmm_config_get(hgmm_ctx* c, const char* name, int* value_out) {
+    if (!c || !value_out) return HGMM_ERR_ARG;
+    const int k = config_find(name);
+    if (k < 0) return fail(c, HGMM_ERR_ARG, "hgmm_config_get: unknown option '%s'", name ? name : "(null)");
+    *value_out = c->cfg[k];
+    return HGMM_OK;
+}
+
 extern "C" int hgmm_create(int device_id, hgmm_ctx** out) {
     if (!out) return HGMM_ERR_ARG;
     *out = nullptr;
@@ -658,6 +706,7 @@ extern "C" int hgmm_create(int device_id, hgmm_ctx** out) {
     }
     hgmm_ctx* c = new hgmm_ctx();
     c->device = device_id;
+    config_init(c);
     c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -1053,8 +1102,7 @@ extern "C" int hgmm_comm_init_ipc(hgmm_ctx* c, int nranks, int rank, const char*
     ic->err_dev = static_cast<unsigned*>(ed);
     int khz = 0;
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0) khz = 100000;
-    double timeout_s = IPC_TIMEOUT_S;
-    if (const char* e = std::getenv("HGMM_IPC_TIMEOUT_S")) { const double v = atof(e); if (v > 0.0 && v < 600.0) timeout_s = v; }
+    const double timeout_s = (double)c->cfg[CFG_IPC_TIMEOUT_S];
     ic->timeout_ticks = (long long)(timeout_s * 1000.0 * (double)khz);
     hipIpcMemHandle_t mine;
     if ((e = hipIpcGetMemHandle(&mine, ic->local)) != hipSuccess)

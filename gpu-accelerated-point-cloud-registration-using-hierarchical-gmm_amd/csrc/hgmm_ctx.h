@@ -71,6 +71,31 @@ struct PaceCtl {
     int grid_at[RING] = {};
 };
 
+// Per-context options.  Each starts from the environment variable HGMM_<NAME IN CAPITALS>, read ONCE -- in hgmm_create, the
+// only getenv of the library -- and can be set per context afterwards (hgmm_config_set / Context.config_set).  Every option
+// selects a path that is also reached by data (another J, another cloud size, a failed factorisation) or is a documented
+// operating mode; each is listed in INTEGRATION.md and run against its golden by tests/test_config_gpu.py.  Round 5 had
+// 46 environment switches read at call time; the tuning knobs among them are fixed at their measured values now and
+// the rejected variants are gone with their code.
+enum ConfigKey {
+    CFG_ESTEP_TARGET_GBS,      // store pacing of the materialising E-step: -1 controlled (default), 0 un-paced, > 0 fixed rate in GB/s
+    CFG_PACE_START,            // rate the controller starts from, GB/s
+    CFG_PACE_FORGET,           // clean launches after which a ceiling learnt under congestion is forgotten
+    CFG_PREDICT_SINGLE_ROW,    // predict() on the general single-row kernel (the path of layouts the 4-row kernel is not built for)
+    CFG_TREE_NO_CHOL,          // symmetric instead of triangular form of the pdfs' exponent (the fallback of a failed factorisation)
+    CFG_TREE_REL,              // relative reach test of the level log-likelihood (large clouds; gives up the bitwise q for ~3 %)
+    CFG_TREE_AHEAD,            // iterations the host keeps enqueued ahead of the device in hgmm_tree_build (0: batches + control-word copy)
+    CFG_TREE_TICKETS,          // stop rule in the log-likelihood's last workgroup instead of the next launch
+    CFG_TREE_OVERLAP,          // small clouds: iteration e + 1's E-step rides in iteration e's log-likelihood launch
+    CFG_FULLCOV_TWO_PASS,      // two-kernel form of the full-covariance iteration (the path of J > 1024)
+    CFG_KMPP_TWO_LAUNCHES,     // k-means++ step and tail as two launches (the path of > 16.7 M points)
+    CFG_KMEANS_ACC_REGS,       // Lloyd sums in registers instead of LDS tables (the path of k > 1024)
+    CFG_IPC_TIMEOUT_S,         // seconds the peer exchange waits for a peer's flag before it reports the collective as failed
+    CFG_COUNT
+};
+struct ConfigSpec { const char* name; int dflt, lo, hi; };
+extern const ConfigSpec CONFIG_SPECS[CFG_COUNT];
+
 struct HostComm;                           // hgmm_api.hip
 struct IpcComm;                            // hgmm_api.hip: one-shot peer-to-peer exchange over mapped peer memory
 
@@ -112,6 +137,7 @@ struct hgmm_points {
 };
 
 struct hgmm_ctx {
+    int cfg[hgmm::CFG_COUNT] = {};    // hgmm::ConfigKey -> value (hgmm_create: defaults, then the environment)
     int device = 0;
     int cus = 256;
     int wall_khz = 0;                 // rate of wall_clock64() on this device (StorePacer, flat_kernels.hip)

@@ -104,161 +104,6 @@ __global__ __launch_bounds__(KM_BLOCK) void kmpp_first_kernel(const double* __re
     }
 }
 
-// One workgroup of 1024 threads.  Phase 1: inclusive scan of the block sums (-> bprefix, total
-// potential).  Phase 2: wave t locates random threshold t: binary search over the block prefix,
-// then a 256-element running sum inside that block (4 consecutive elements per lane).
-// = np.searchsorted(cumsum(closest), rand * pot) clipped to n - 1   (sklearn _kmeans_plusplus)
-__global__ __launch_bounds__(1024) void kmpp_pick_kernel(const double* __restrict__ closest, int64_t n,
-                                                         const double* __restrict__ bsum, int B,
-                                                         double* __restrict__ bprefix,
-                                                         const double* __restrict__ rand_c, int T,
-                                                         int64_t* __restrict__ cand,
-                                                         double* __restrict__ pot_out) {
-    __shared__ double wave_tot[16];
-    __shared__ double seg_end[1024];                     // inclusive prefix at the end of each thread's segment
-    __shared__ double total_sh;
-    const int tid = threadIdx.x, lane = lane_id(), wave = wave_in_block();
-    const int seg = (B + 1023) / 1024;
-    const int b0 = tid * seg, b1 = min(B, b0 + seg);
-    double loc = 0.0;
-    for (int b = b0; b < b1; ++b) loc += bsum[b];
-    const double incl = wave_scan_f64(loc);
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    double off = 0.0;
-    for (int w = 0; w < wave; ++w) off += wave_tot[w];
-    double run = off + (incl - loc);
-    for (int b = b0; b < b1; ++b) {
-        run += bsum[b];
-        bprefix[b] = run;
-    }
-    seg_end[tid] = off + incl;
-    if (tid == 1023) total_sh = off + incl;
-    __threadfence();
-    __syncthreads();
-    const double pot = total_sh;
-    if (tid == 0) pot_out[0] = pot;
-    if (wave >= T) return;
-    const double v = rand_c[wave] * pot;
-    const volatile double* bp = bprefix;                 // written by other waves of this workgroup
-    int lo = 0, hi = 1024;                               // first segment whose end >= v (LDS) ...
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (seg_end[mid] >= v) hi = mid; else lo = mid + 1;
-    }
-    hi = min(B, (lo + 1) * seg);                         // ... then the first block inside it
-    lo = min(B, lo * seg);
-    while (lo < hi && !(bp[lo] >= v)) ++lo;
-    if (lo == hi && hi < B) lo = hi;                     // rounding at the segment's end
-    int64_t found = n - 1;                               // np.clip(..., n - 1)
-    if (lo < B) {
-        const double base = lo > 0 ? bp[lo - 1] : 0.0;
-        const int64_t e0 = (int64_t)lo * KM_BLOCK + 4 * lane;
-        double c[4];
-        double s = 0.0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            s += (e0 + q < n) ? closest[e0 + q] : 0.0;
-            c[q] = s;
-        }
-        const double ex = base + (wave_scan_f64(s) - s);
-        int first_q = 4;
-#pragma unroll
-        for (int q = 3; q >= 0; --q)
-            if (e0 + q < n && ex + c[q] >= v) first_q = q;
-        const unsigned long long hit = __ballot(first_q < 4);
-        if (hit) {
-            const int l = __ffsll((long long)hit) - 1;
-            const int q = __builtin_amdgcn_readlane(first_q, l);
-            found = (int64_t)lo * KM_BLOCK + 4 * l + q;
-        } else {
-            // rounding at the block's end: the threshold falls on the first element after it
-            const int64_t nxt = (int64_t)(lo + 1) * KM_BLOCK;
-            found = nxt < n ? nxt : n - 1;
-        }
-    }
-    if (lane == 0) cand[wave] = found;
-}
-
-__global__ __launch_bounds__(KM_BLOCK) void kmpp_eval_kernel(const double* __restrict__ xs, int64_t n,
-                                                             int64_t n_pad,
-                                                             const double* __restrict__ closest,
-                                                             const int64_t* __restrict__ cand, int T,
-                                                             double* __restrict__ part) {
-    __shared__ double sh[KM_MAX_TRIALS][4];
-    const int64_t i = (int64_t)blockIdx.x * KM_BLOCK + threadIdx.x;
-    const bool live = i < n;
-    const double x = xs[i], y = xs[n_pad + i], z = xs[2 * n_pad + i];
-    const double cl = closest[i];
-    for (int t = 0; t < T; ++t) {
-        const int64_t ci = cand[t];
-        const double d = dist2(x, y, z, xs[ci], xs[n_pad + ci], xs[2 * n_pad + ci]);
-        const double w = wave_sum_f64(live ? fmin(cl, d) : 0.0);
-        if (lane_id() == 0) sh[t][wave_in_block()] = w;
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < T)
-        part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
-            (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
-}
-
-// One workgroup of 1024 threads: thread i adds blocks i, i + 1024, ... of every candidate (partials are
-// stored [t][B], so the reads are coalesced), waves and then the 16 wave totals are combined in
-// fixed order; thread 0 keeps the first minimum (np.argmin) and records the new centre.
-__global__ __launch_bounds__(1024) void kmpp_select_kernel(const double* __restrict__ xs, int64_t n_pad,
-                                                           const double* __restrict__ part, int B, int T,
-                                                           const int64_t* __restrict__ cand, int c,
-                                                           double* __restrict__ centres,
-                                                           int64_t* __restrict__ ids) {
-    __shared__ double wsum[KM_MAX_TRIALS][16];
-    const int lane = lane_id(), wave = wave_in_block();
-    double acc[KM_MAX_TRIALS];
-#pragma unroll
-    for (int t = 0; t < KM_MAX_TRIALS; ++t) acc[t] = 0.0;
-    for (int b = threadIdx.x; b < B; b += 1024) {
-#pragma unroll
-        for (int t = 0; t < KM_MAX_TRIALS; ++t)
-            if (t < T) acc[t] += part[(size_t)t * B + b];
-    }
-#pragma unroll
-    for (int t = 0; t < KM_MAX_TRIALS; ++t) {
-        if (t < T) {
-            const double w = wave_sum_f64(acc[t]);
-            if (lane == 0) wsum[t][wave] = w;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int best = 0;
-        double best_pot = 0.0;
-        for (int t = 0; t < T; ++t) {
-            double p = 0.0;
-            for (int w = 0; w < 16; ++w) p += wsum[t][w];
-            if (t == 0 || p < best_pot) { best = t; best_pot = p; }
-        }
-        const int64_t ci = cand[best];
-        ids[c] = ci;
-        centres[3 * c + 0] = xs[ci];
-        centres[3 * c + 1] = xs[n_pad + ci];
-        centres[3 * c + 2] = xs[2 * n_pad + ci];
-    }
-}
-
-__global__ __launch_bounds__(KM_BLOCK) void kmpp_update_kernel(const double* __restrict__ xs, int64_t n,
-                                                               int64_t n_pad,
-                                                               const double* __restrict__ centres, int c,
-                                                               double* __restrict__ closest,
-                                                               double* __restrict__ bsum) {
-    __shared__ double sh[4];
-    const int64_t i = (int64_t)blockIdx.x * KM_BLOCK + threadIdx.x;
-    const double cx = centres[3 * c], cy = centres[3 * c + 1], cz = centres[3 * c + 2];
-    double d = 0.0;
-    if (i < n) d = fmin(closest[i], dist2(xs[i], xs[n_pad + i], xs[2 * n_pad + i], cx, cy, cz));
-    closest[i] = d;
-    const double t = block_sum_256(d, sh);
-    if (threadIdx.x == 0) bsum[blockIdx.x] = t;
-}
-
 // ------------------------------------------------------------------------------------------
 // Fused seeding step: ONE pass over the points per centre instead of two (eval + update).
 //
@@ -283,8 +128,8 @@ __global__ __launch_bounds__(KM_BLOCK) void kmpp_update_kernel(const double* __r
 // group's 16 block sums 0.9, the block's points 0.9, hand-over 0.5 -- then the pass itself, whose operands are in
 // registers by then: 4.6 us of fp64 issue (1M points x 8 candidates x 8 instructions, 16 waves on each CU) and 2 us
 // until the last wave of the workgroup is through.  The two-launch form stays for clouds beyond 16.7 M points.
-// Fixed summation orders throughout, hence the same seeds run to run; the four-kernel form (kmpp_pick / eval /
-// select / update) is kept as the readable statement of the same algorithm and is used by nothing else.
+// Fixed summation orders throughout, hence the same seeds run to run.  (The four-kernel form of round 1 -- kmpp_pick /
+// eval / select / update behind HGMM_KMPP_UNFUSED -- left the library in round 6 with its switch.)
 // ------------------------------------------------------------------------------------------
 constexpr int KM_GROUP = 16;                             // 256-point blocks per step workgroup (one per wave)
 constexpr int KM_STEP_BLOCK = 64 * KM_GROUP;
@@ -1074,15 +919,7 @@ extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const 
         HGMM_HIP(c, hipMemcpyAsync(rand_dev, rand_vals, sizeof(double) * (size_t)(k - 1) * n_trials,
                                    hipMemcpyHostToDevice, c->stream));
     kmpp_first_kernel<<<B, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, first_id, closest, bsum, centres, ids);
-    if (std::getenv("HGMM_KMPP_UNFUSED")) {
-        for (int j = 1; j < k; ++j) {
-            kmpp_pick_kernel<<<1, 1024, 0, c->stream>>>(closest, n, bsum, B, bprefix,
-                                                        rand_dev + (size_t)(j - 1) * n_trials, n_trials, cand, pot);
-            kmpp_eval_kernel<<<B, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, closest, cand, n_trials, part);
-            kmpp_select_kernel<<<1, 1024, 0, c->stream>>>(xs, n_pad, part, B, n_trials, cand, j, centres, ids);
-            kmpp_update_kernel<<<B, KM_BLOCK, 0, c->stream>>>(xs, n, n_pad, centres, j, closest, bsum);
-        }
-    } else if (k > 1) {
+    if (k > 1) {
         // The candidates of centre j, their coordinates and their potentials live in buffer j & 1.
         double* cand_xyz = centres + 7 * (size_t)k;             // [2][T][3], behind the centre tables
         const bool t8 = n_trials <= 8;
@@ -1112,16 +949,11 @@ extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const 
         };
         kmpp_group_kernel<<<km_nblk(G, 256), 256, 0, c->stream>>>(bsum, B, G, g0);
         tail(0, 0, 1, rand_dev);
-        if (G <= KM_TAIL_LDS_GROUPS && !std::getenv("HGMM_KMPP_TWO_LAUNCHES")) {
+        if (G <= KM_TAIL_LDS_GROUPS && !c->cfg[CFG_KMPP_TWO_LAUNCHES]) {
             // one launch per centre (kmpp_fused_kernel): pass of centre 1, then for every further centre the tail of
             // the previous one inside the pass's own launch, and the last centre's tail on its own
             step(1, -1);
-            unsigned long long* dbg = nullptr;
-            if (std::getenv("HGMM_KMPP_DEBUG")) {
-                HGMM_TRY(ensure(c, c->scratch, 32 * sizeof(unsigned long long)));
-                dbg = c->scratch.as<unsigned long long>();
-                HGMM_HIP(c, hipMemsetAsync(dbg, 0, 32 * sizeof(unsigned long long), c->stream));
-            }
+            unsigned long long* dbg = nullptr;               // (phase clocks of thread 0: a debugging aid, off)
             for (int j = 2; j < k; ++j) {
                 const double* rnd = rand_dev + (size_t)(j - 1) * n_trials;
                 if (t8)
@@ -1132,16 +964,6 @@ extern "C" int hgmm_kmeans_plusplus(hgmm_ctx* c, int k, int64_t first_id, const 
                     kmpp_fused_kernel<KM_MAX_TRIALS><<<G, KM_STEP_BLOCK, 0, c->stream>>>(
                         xs, n, n_pad, closest, part_b(j - 1), part16_b(j - 1), part_b(j), part16_b(j), G, B, n_trials, j, rnd,
                         cand_b(j - 1), xyz_b(j - 1), cand_b(j), xyz_b(j), centres, ids, dbg);
-            }
-            if (dbg) {
-                unsigned long long h[32];
-                HGMM_HIP(c, hipMemcpyAsync(h, dbg, sizeof h, hipMemcpyDeviceToHost, c->stream));
-                HGMM_HIP(c, ctx_stream_sync(c));
-                for (int wg = 0; wg < 2; ++wg) {
-                    fprintf(stderr, "kmpp_fused_kernel workgroup %3d, us since kernel start (mean of %d launches):", wg ? 128 : 0, k - 2);
-                    for (int q : {1, 2, 3, 4, 5, 6, 7, 9, 8}) fprintf(stderr, " s%d %.2f", q, h[16 * wg + q] * 0.01 / std::max(1, k - 2));
-                    fprintf(stderr, "\n");
-                }
             }
             tail(k - 1, 1, 0, nullptr);
         } else {
@@ -1177,7 +999,7 @@ int km_prepare(hgmm_ctx* c, int k, int reset_labels, KmLaunch& L) {
     L.nslot = k <= 256 ? 4 : KM_ACC_SLOTS;
     L.k_alloc = (k + 64 * L.nslot - 1) / (64 * L.nslot) * (64 * L.nslot);
     L.nb_assign = (int)km_nblk(n, 2 * KM_BLOCK);
-    L.acc_lds = k <= 1024 && !std::getenv("HGMM_KMEANS_ACC_REGS");
+    L.acc_lds = k <= 1024 && !c->cfg[CFG_KMEANS_ACC_REGS];
     L.nb_acc = (int)std::min<int64_t>((L.acc_lds ? 1 : 2) * (int64_t)c->cus, km_nblk(n, KM_BLOCK));
     HGMM_TRY(ensure(c, c->km_labels, sizeof(int32_t) * n_pad));
     HGMM_TRY(ensure(c, c->km_mind2, sizeof(double) * n_pad));

@@ -84,8 +84,9 @@ __global__ __launch_bounds__(64) void forest_moments_kernel(const double* __rest
 // Iteration e's log-likelihood of every cloud + (with_estep) iteration e + 1's speculative E-step of every chunk, as in
 // tree_ll_estep_kernel.  Workgroups [0, B ll_stride): cloud w / ll_stride, point block w % ll_stride (clouds with fewer
 // blocks return); the rest: chunks.
-template <int WPE>
-__global__ __launch_bounds__(CH, WPE) void forest_ll_estep_kernel(const double* __restrict__ xs, int64_t n_pad,
+// (five waves per SIMD: 96 registers, no spills; 4 / 5 / 6 measured 14.2 / 13.9 / 14.4 ms per build of 32 bunny scans --
+//  the kernel keeps the fp64 pipe ~80 % busy at any of them, profiles/r06/pmc_sq_batch32.txt)
+__global__ __launch_bounds__(CH, 5) void forest_ll_estep_kernel(const double* __restrict__ xs, int64_t n_pad,
                                                              const double* __restrict__ prep, int64_t lb, int n_level,
                                                              double* __restrict__ block_q, const int* __restrict__ flags,
                                                              ForestArgs fa, int ll_stride, TreeEstepArgs ea, int with_estep) {
@@ -371,8 +372,6 @@ extern "C" int hgmm_tree_build_batch(hgmm_ctx* c, int B, const int64_t* counts, 
     std::vector<ForestCloud> table(B);
     int rc = HGMM_OK;
     const int ahead_iters = 2;                                  // iterations enqueued beyond the slowest running cloud (hgmm_tree_build)
-    int wpe = 4;
-    if (const char* e = std::getenv("HGMM_FOREST_WPE")) wpe = atoi(e);
     for (int l = 0; l < L && rc == HGMM_OK; ++l) {
         const int64_t lb = level_first(l), le = level_first(l + 1);
         const int n_level = (int)(le - lb);
@@ -425,10 +424,8 @@ extern "C" int hgmm_tree_build_batch(hgmm_ctx* c, int B, const int64_t* counts, 
                 const TreeEstepArgs ea_next{xs_cur, n_pad, d_prep, chunk_desc, n_chunks_dev, parent_first, l, partials,
                                             ((e + 1) & 1) ? cur1 : cur0, nullptr};
                 const unsigned g = (unsigned)(B * ll_stride) + (with_estep ? grid_chunks : 0u);
-#define FOREST_LL(W) forest_ll_estep_kernel<W><<<g, CH, 0, c->stream>>>(xs_cur, n_pad, d_prep, lb, n_level, block_q, d_flags, fa, \
-                                                                  ll_stride, ea_next, with_estep)
-                if (wpe == 6) FOREST_LL(6); else if (wpe == 5) FOREST_LL(5); else FOREST_LL(4);
-#undef FOREST_LL
+                forest_ll_estep_kernel<<<g, CH, 0, c->stream>>>(xs_cur, n_pad, d_prep, lb, n_level, block_q, d_flags, fa,
+                                                               ll_stride, ea_next, with_estep);
             }
             const hipError_t le = hipGetLastError();
             if (le != hipSuccess) return fail(c, HGMM_ERR_HIP, "tree build (batch): kernel launch failed: %s", hipGetErrorString(le));

@@ -717,17 +717,13 @@ static int tree_flags(hgmm_ctx* c, bool reset) {
     if (fresh_tickets || reset) HGMM_HIP(c, hipMemsetAsync(c->t_tickets.p, 0, TREE_TICKET_BYTES, c->stream));
     if (reset) {
         HGMM_HIP(c, hipMemsetAsync(c->t_flags.p, 0, TREE_FLAGS_BYTES, c->stream));
-        // HGMM_TREE_NO_CHOL=1: take the symmetric-form fallback everywhere (lets the tests hold both forms to the oracle)
-        // HGMM_TREE_REL=1: add the RELATIVE reach test of tree_loglik_kernel (bit 1).  Off by default: what the absolute
+        // tree_no_chol: take the symmetric-form fallback everywhere (lets the tests hold both forms to the oracle)
+        // tree_rel: add the RELATIVE reach test of tree_loglik_kernel (bit 1).  Off by default: what the absolute
         // test skips is exactly 0 in float64 (q and the stop rule are bitwise those of the full sum), what the relative
         // test drops is "only" below 1e-20 of every point's sum.
         int preset = 0;
-        if (const char* e = std::getenv("HGMM_TREE_NO_CHOL")) preset |= (e[0] == '1') ? 1 : 0;
-        if (const char* e = std::getenv("HGMM_TREE_REL")) preset |= (e[0] == '1') ? 2 : 0;
-        // HGMM_TREE_LL_NOEVAL=1 (measurement aid, WRONG q): the log-likelihood kernels build their node tiles -- loads,
-        // reach tests, compaction, barriers -- and skip the pdf evaluations: what is left of their time is everything a
-        // precomputed per-chunk node list could save at most (profiles/r04/tree_loglik_split.log)
-        if (const char* e = std::getenv("HGMM_TREE_LL_NOEVAL")) preset |= (e[0] == '1') ? 4 : 0;
+        if (c->cfg[CFG_TREE_NO_CHOL]) preset |= 1;
+        if (c->cfg[CFG_TREE_REL]) preset |= 2;
         if (preset) HGMM_HIP(c, hipMemsetAsync(c->t_flags.p, preset, 1, c->stream));
     }
     return HGMM_OK;
@@ -834,8 +830,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     // points per thread in the log-likelihood kernel (N = 1e6, L = 4 build: 10.2 / 8.4 / 8.0 ms with 1 / 2 / 4)
     // (one point per thread for small clouds was tried in round 3: C4 level 0 / 1 got slower, 11.5 / 16.0 vs 9.2 / 15.4 us --
     //  these launches are chains of memory round trips, not arithmetic)
-    int ll_pts = n >= 400000 ? 4 : 2;
-    if (const char* e = std::getenv("HGMM_TREE_LL_PTS")) ll_pts = atoi(e) >= 4 ? 4 : (atoi(e) >= 2 ? 2 : 1);
+    const int ll_pts = n >= 400000 ? 4 : 2;
     // (a 64-point / node-split form of the log-likelihood for small clouds -- four waves of a workgroup sharing 64 points and
     //  splitting the nodes, no finish pass -- was built and measured in round 3 and lost at every C4 level: 16.9 / 17.7 /
     //  20.2 / 49 us per iteration against 8.9 / 14.8 / 19.1 / 22.4 for this form: eight times as many workgroups each read
@@ -843,27 +838,23 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     if (ll_pts == 4) HGMM_TRY(ensure_exp_tab2(c));
     // the E-step's LDS transpose in two passes (half the LDS, twice the resident workgroups) once a level has more chunks
     // than the chip holds at a time
-    bool estep_half = n / CH > (int64_t)3 * c->cus;
-    if (const char* e = std::getenv("HGMM_TREE_ESTEP_HALF")) estep_half = e[0] == '1';
+    const bool estep_half = n / CH > (int64_t)3 * c->cus;
     // iterations enqueued per batch.  Round 2 (host waits at every batch boundary): 1/2/4/8/16 -> 6.8/6.3/5.6/5.1/5.3 ms @C4.
     // With the host one batch ahead (below) a level that stops at iteration k still has (ceil(k / B) + 1) B - k
     // iterations enqueued behind the stop (46 over C4's four levels at B = 8, 22 at B = 4) -- but each of those is three
     // launches that return at their first load, and a batch boundary (control-word copy + event) costs more than it
     // saves: 2/4/8 -> 3.67/3.60/3.46 ms @C4, 5.12/5.07/5.02 @1M on one box.
-    int batch_iters = 8;
-    if (const char* e = std::getenv("HGMM_TREE_BATCH")) batch_iters = std::max(1, std::min(64, atoi(e)));
+    const int batch_iters = 8;
     // single GPU: progress word in pinned host memory, polled (see the level loop); HGMM_TREE_AHEAD=0 -> the batch scheme
     // (C4, one box: batch scheme 3.16-3.6 ms; 1 / 2 / 3 / 4 / 6 iterations ahead: 3.39 / 2.88 / 3.0 / 2.94 / 2.97 ms -- with one
     //  the device waits for the host after every iteration; the host needs ~10 us to enqueue what the device runs in ~25)
-    int ahead_iters = 2;
-    if (const char* e = std::getenv("HGMM_TREE_AHEAD")) ahead_iters = std::max(0, std::min(64, atoi(e)));
+    const int ahead_iters = c->cfg[CFG_TREE_AHEAD];
     // the stop rule inside the next launch (tree_follow) instead of a ticketed tail of the log-likelihood: needs the
     // polled scheme with >= 2 iterations ahead (the verdict on iteration e is reached by launch e + 1)
-    const bool use_follow = !c->comm_on() && ahead_iters >= 2 && !std::getenv("HGMM_TREE_TICKETS");
+    const bool use_follow = !c->comm_on() && ahead_iters >= 2 && !c->cfg[CFG_TREE_TICKETS];
     // small clouds: iteration e + 1's (speculative) E-step rides in iteration e's log-likelihood launch and the moments
     // kernel takes over the stop rule (tree_ll_estep_kernel); HGMM_TREE_OVERLAP=0 -> one launch each, as for large clouds
-    bool overlap = use_follow && ahead_iters > 0 && !estep_half && ll_pts != 4;
-    if (const char* e = std::getenv("HGMM_TREE_OVERLAP")) overlap = overlap && e[0] != '0';
+    const bool overlap = use_follow && ahead_iters > 0 && !estep_half && ll_pts != 4 && c->cfg[CFG_TREE_OVERLAP];
     int* curbuf[2] = {cur, overlap ? cur + n_pad : cur};
     unsigned long long* host_word = nullptr;                   // host address / device address of the same pinned word
     unsigned long long* host_word_dev = nullptr;
@@ -2031,8 +2022,8 @@ static int fullcov_moments(hgmm_ctx* c, int J, int J16, int grid) {
 }
 
 // one-pass E-step (J16 <= FT_MAX_J16): denominators, arg-max, q and the statistics from ONE evaluation of the pdfs
-static bool fullcov_one_pass(int J16) {
-    if (const char* e = std::getenv("HGMM_FULLCOV_TWO_PASS")) if (e[0] == '1') return false;
+static bool fullcov_one_pass(const hgmm_ctx* c, int J16) {
+    if (c->cfg[CFG_FULLCOV_TWO_PASS]) return false;
     return J16 <= FT_MAX_J16;
 }
 // `ctl` (device): the launches look at ctl->done first and the sum of q applies the stop rule `stop` -- for a loop whose
@@ -2064,20 +2055,11 @@ static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_hos
         } else {
             HGMM_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&full_fused_kernel<2>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            long long* dbg = nullptr;
-            if (std::getenv("HGMM_FT_DEBUG")) { HGMM_HIP(c, hipMalloc(&dbg, 8 * 4 * 8)); }
+            // (last kernel argument: phase clocks per wave, a debugging aid that is off)
             full_fused_kernel<2><<<grid, FT_BLOCK, lds, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
                                                                    c->t_prep.as<double>(), J16, labels, block_q,
                                                                    c->t_partials.as<double>(), want_stats ? 1 : 0,
-                                                                   flags_ptr(c), c->exp_tab2.as<double>(), dbg, done);
-            if (dbg) {
-                long long h[32];
-                HGMM_HIP(c, ctx_stream_sync(c));
-                HGMM_HIP(c, hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost));
-                for (int w = 0; w < 8; ++w)
-                    fprintf(stderr, "wave %d: A %lld  B %lld  C %lld  wait %lld cycles\n", w, h[4 * w], h[4 * w + 1], h[4 * w + 2], h[4 * w + 3]);
-                (void)hipFree(dbg);
-            }
+                                                                   flags_ptr(c), c->exp_tab2.as<double>(), nullptr, done);
         }
     }
     HGMM_HIP(c, hipGetLastError());
@@ -2141,14 +2123,14 @@ extern "C" int hgmm_fullcov_fit(hgmm_ctx* c, int J, double ls, double ld, const 
     double n_total = (double)c->n;
     if (c->comm_on()) HGMM_TRY(hgmm_comm_allreduce_f64(c, &n_total, 1, 0));
     // E-step quantities of the initial parameters
-    const bool one_pass = fullcov_one_pass(J16);
+    const bool one_pass = fullcov_one_pass(c, J16);
     if (one_pass) HGMM_TRY(fullcov_fused(c, J, J16, lab_a, nullptr));
     else HGMM_TRY(fullcov_pass(c, J, lab_a, nullptr));
     int* lab_cur = lab_a;      // arg-max of the most recent E-step
     int* lab_nxt = lab_b;
     double prev_q = 0.0;
     int it = 0, q_len = 0;
-    if (one_pass && !c->comm_on() && !std::getenv("HGMM_FULLCOV_SYNC")) {
+    if (one_pass && !c->comm_on()) {
         // The stop rule on the device, the host one batch of iterations ahead (the scheme of hgmm_tree_build): the
         // launches of an iteration look at ctl->done first, the sum of q applies |q - prev_q| < ls / the budget, and the
         // host reads {done, iterations} through a pinned copy + an event while the next batch is already queued.
@@ -2249,7 +2231,7 @@ extern "C" int hgmm_fullcov_estep(hgmm_ctx* c, int J, const double* pi, const do
                                                            c->t_cov.as<double>(), 0, J16, c->t_prep.as<double>(), flags_ptr(c));
     int* lab = c->t_current.as<int>();
     double q = 0.0;
-    if (fullcov_one_pass(J16)) {
+    if (fullcov_one_pass(c, J16)) {
         HGMM_TRY(fullcov_fused(c, J, J16, lab, &q));
     } else {
         HGMM_TRY(fullcov_pass(c, J, lab, &q));

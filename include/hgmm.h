@@ -209,6 +209,26 @@ int hgmm_flat_stats(hgmm_ctx* ctx, int cov_type, int variant, int J,
                     const float* mu, const float* inv_std, const float* w,
                     double* stats_out, double* sum_lpn_out, double* n_points_out);
 
+/* ---- per-context options ---------------------------------------------------------------------------------------------
+ * The library reads the environment ONCE, in hgmm_create: every option below starts from HGMM_<NAME IN CAPITALS> when
+ * that variable is set, else from its default, and can be changed per context afterwards.  Each option selects a path
+ * that data also reaches (another J, another cloud size, a failed factorisation) or a documented operating mode; the table
+ * is in INTEGRATION.md and tests/test_config_gpu.py runs every option against its golden.  There is no reference
+ * counterpart: the reference has no configuration beyond its call arguments.
+ *   estep_target_gbs (-1)   store pacing of e_step()'s kernel: -1 controlled, 0 un-paced, > 0 fixed rate in GB/s
+ *   pace_start (6600), pace_forget (10000)   the pacing controller's start rate / clean launches until a learnt ceiling is forgotten
+ *   predict_single_row (0)  predict() on the general single-row kernel
+ *   tree_no_chol (0), tree_rel (0)   symmetric form of the tree pdfs' exponent / relative reach test of the level log-likelihood
+ *   tree_ahead (2), tree_tickets (0), tree_overlap (1)   hgmm_tree_build's host look-ahead, where its stop rule runs, E-step
+ *                           of iteration e + 1 inside iteration e's log-likelihood launch
+ *   fullcov_two_pass (0)    two-kernel form of hgmm_fullcov_fit's iteration (the path of J > 1024)
+ *   kmpp_two_launches (0), kmeans_acc_regs (0)   the KMeans initialiser's paths for > 16.7 M points / k > 1024
+ *   ipc_timeout_s (20)      seconds the peer exchange waits for a peer before the collective is reported as failed        */
+int hgmm_config_count(void);
+const char* hgmm_config_name(int index);                      /* NULL beyond hgmm_config_count() - 1 */
+int hgmm_config_set(hgmm_ctx* ctx, const char* name, int value);
+int hgmm_config_get(hgmm_ctx* ctx, const char* name, int* value_out);
+
 /* ---- hierarchical GMM (8-ary tree, full 3x3 covariance, float64) -------------------
  * hgmm_tree_build     <- buildGMMTree()     hgmm/hgmm_cupy_cpu_working.py:122-160 (CPU twin,
  *                        canonical) == hgmm/hgmm_gpu.py:466-548 (kernels 107-115, 387-426)

@@ -73,3 +73,24 @@ def test_api_surface_matches_reference_names():
     f = Wg.GMM_GPU(n_gmm_components=7, max_iter=3, tol=1e-3, cov_type='spherical')
     f.init()
     assert f._clf.num_components == 7 and f._clf.cov_type == 'spherical'
+
+
+def test_every_config_option_is_documented(lib):
+    """include/hgmm.h: hgmm_config_*.  The option table is read from the library itself (no GPU needed) and every name
+    must appear in INTEGRATION.md's table and in the header's comment; nothing in csrc/ reads the environment except
+    hgmm_create's one loop."""
+    names = [lib.hgmm_config_name(i).decode() for i in range(lib.hgmm_config_count())]
+    assert len(names) >= 10 and lib.hgmm_config_name(len(names)) is None
+    integration = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    header = open(os.path.join(ROOT, "include", "hgmm.h")).read()
+    for n in names:
+        assert "`%s`" % n in integration, n
+        assert n in header, n
+    csrc = os.path.join(ROOT, "gpu-accelerated-point-cloud-registration-using-hierarchical-gmm_amd", "csrc")
+    hits = []
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            for i, line in enumerate(open(os.path.join(csrc, f)), 1):
+                if re.search(r"\bgetenv\s*\(", line):
+                    hits.append("%s:%d" % (f, i))
+    assert len(hits) == 1 and hits[0].startswith("hgmm_api.hip"), hits

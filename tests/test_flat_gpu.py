@@ -514,9 +514,11 @@ def test_store_pacer_controller_backs_off(monkeypatch):
     mu, w = X[idx].copy(), (np.ones(J) / J).astype(np.float32)
     inv = (1 / np.sqrt(0.01 * np.ones((J, 3)))).astype(np.float32)
     rows = np.arange(0, N, 20011)
-    monkeypatch.setenv("HGMM_PACE_START", "7800")
+    monkeypatch.setenv("HGMM_PACE_START", "7800")        # (options start from the environment: read once, at creation)
     c = hgmm_amd.Context(0)
+    monkeypatch.delenv("HGMM_PACE_START")
     try:
+        assert c.config_get("pace_start") == 7800
         c.set_points(X)
         lr = c.empty((N, J), np.float32)
         mean0 = c.flat_estep(inv, mu, w, out=lr)[0]
@@ -540,10 +542,9 @@ def test_store_pacer_controller_backs_off(monkeypatch):
         del small, lr
     finally:
         c.close()
-    monkeypatch.delenv("HGMM_PACE_START")
-    monkeypatch.setenv("HGMM_ESTEP_TARGET_GBS", "6000")
-    c = hgmm_amd.Context(0)
+    c = hgmm_amd.Context(0).config_set("estep_target_gbs", 6000)
     try:
+        assert c.config_get("pace_start") == 6600
         c.set_points(X)
         lr = c.empty((N, J), np.float32)
         for _ in range(12):
@@ -570,8 +571,7 @@ def test_store_pacer_recovers_after_a_congested_phase(monkeypatch):
     mu, w = X[idx].copy(), (np.ones(J) / J).astype(np.float32)
     inv = (1 / np.sqrt(0.01 * np.ones((J, 3)))).astype(np.float32)
     rows = np.arange(0, N, 20011)
-    monkeypatch.setenv("HGMM_PACE_FORGET", "40")
-    c, other = hgmm_amd.Context(0), hgmm_amd.Context(0)
+    c, other = hgmm_amd.Context(0).config_set("pace_forget", 40), hgmm_amd.Context(0)
     try:
         c.set_points(X)
         lr = c.empty((N, J), np.float32)
@@ -1240,9 +1240,8 @@ def test_predict_four_row_kernel_and_array_reuse(ctx, monkeypatch):
         w = rs.rand(J).astype(np.float32)
         w /= w.sum()
         inv = (1.0 / (0.02 + 0.1 * rs.rand(*((J, 3) if ct == "diag" else (J,))))).astype(np.float32)
-        monkeypatch.setenv("HGMM_PREDICT_SINGLE_ROW", "1")
-        a = ctx.flat_predict(inv, mu, w, ct, var).get()
-        monkeypatch.delenv("HGMM_PREDICT_SINGLE_ROW")
+        with ctx.config(predict_single_row=1):
+            a = ctx.flat_predict(inv, mu, w, ct, var).get()
         b = ctx.flat_predict(inv, mu, w, ct, var).get()
         assert np.array_equal(a, b), (J, ct, var)
         o = flat_em.predict(Xs.astype(np.float64), inv.astype(np.float64), mu.astype(np.float64), w.astype(np.float64), ct, var)

@@ -154,23 +154,19 @@ def test_waymo_scale_properties(ctx):
 
 @pytest.mark.parametrize("n,k,trials", [(60000, 1200, None), (4000, 50, 16), (4000, 50, 1), (70000, 3, 3),
                                         (300, 2, 2), (1100000, 64, 5)])
-def test_seeding_forms_agree(ctx, monkeypatch, n, k, trials):
-    """The three statements of k-means++ seeding in the library pick the same points, bit for bit: one launch per
-    centre (kmpp_fused_kernel: every workgroup of the pass runs the previous centre's tail for itself; both the 8- and
-    the 16-candidate instantiation), two launches per centre (HGMM_KMPP_TWO_LAUNCHES=1: what clouds beyond 16.7 M
-    points take), and the four-kernel form kept as the readable statement (HGMM_KMPP_UNFUSED=1)."""
+def test_seeding_forms_agree(ctx, n, k, trials):
+    """The two forms of k-means++ seeding in the library pick the same points, bit for bit: one launch per centre
+    (kmpp_fused_kernel: every workgroup of the pass runs the previous centre's tail for itself; both the 8- and the
+    16-candidate instantiation) and two launches per centre (option kmpp_two_launches: what clouds beyond 16.7 M points
+    take).  (The four-kernel form of round 1 left the library in round 6; the seeds are held to scikit-learn's by
+    test_fit_matches_reference_init.)"""
     X = np.random.RandomState(n).rand(n, 3)
     ctx.set_points(X - X.mean(0))
     t = trials or (2 + int(np.log(k)))
     rand = np.random.RandomState(1).uniform(size=(k - 1, t))
     ids, centres = ctx.kmeans_plusplus(k, 7 % n, rand)
-    monkeypatch.setenv("HGMM_KMPP_TWO_LAUNCHES", "1")
-    ids2, centres2 = ctx.kmeans_plusplus(k, 7 % n, rand)
-    monkeypatch.delenv("HGMM_KMPP_TWO_LAUNCHES")
-    monkeypatch.setenv("HGMM_KMPP_UNFUSED", "1")
-    ids4, _ = ctx.kmeans_plusplus(k, 7 % n, rand)
-    monkeypatch.delenv("HGMM_KMPP_UNFUSED")
+    with ctx.config(kmpp_two_launches=1):
+        ids2, centres2 = ctx.kmeans_plusplus(k, 7 % n, rand)
     assert np.array_equal(ids, ids2) and np.array_equal(centres, centres2)
-    assert np.array_equal(ids, ids4)
     again = ctx.kmeans_plusplus(k, 7 % n, rand)
     assert np.array_equal(again[0], ids) and np.array_equal(again[1], centres)

@@ -530,10 +530,9 @@ def test_tree_1M_matches_oracle_fixture(ctx, monkeypatch):
     pairs_abs = ctx.tree_stats()[0]
     # test_tree_1M_relative_reach_opt_in: HGMM_TREE_REL=1 also drops nodes that together stay below 1e-20 of every
     # point's sum -- fewer pdf evaluations, the same tree, q within the bound (1e-20 per point is far below 1 ulp of q)
-    monkeypatch.setenv("HGMM_TREE_REL", "1")
-    rel = build(ctx, P, L, float(g["ls"]), float(g["ld"]), idx, float(g["sig2"]), max_iters=k)
-    pairs_rel, flags = ctx.tree_stats()
-    monkeypatch.delenv("HGMM_TREE_REL")
+    with ctx.config(tree_rel=1):
+        rel = build(ctx, P, L, float(g["ls"]), float(g["ld"]), idx, float(g["sig2"]), max_iters=k)
+        pairs_rel, flags = ctx.tree_stats()
     assert flags == 2 and pairs_rel < pairs_abs
     assert np.array_equal(rel[3], leaf) and np.array_equal(rel[2], cov)          # the E/M steps do not see the test
     np.testing.assert_allclose(rel[5], q, rtol=1e-14, atol=0)
@@ -556,8 +555,7 @@ def test_symmetric_form_fallback_and_pair_counter(ctx, bunny, monkeypatch):
     jdx = np.random.RandomState(3).choice(len(P), J, replace=False)
     o_full = hgmm_tree.build_flat_fullcov(P, J, 1.0, 1e-4, jdx, 0.0005, max_iters=8)
     for forced in (False, True):
-        if forced:
-            monkeypatch.setenv("HGMM_TREE_NO_CHOL", "1")
+        ctx.config_set("tree_no_chol", 1 if forced else 0)
         pi, mu, cov, leaf, iters, q = build(ctx, P, L, 80.0, 1e-4, idx, 0.00034)
         pairs, flags = ctx.tree_stats()
         assert flags == (1 if forced else 0)
@@ -574,7 +572,7 @@ def test_symmetric_form_fallback_and_pair_counter(ctx, bunny, monkeypatch):
         np.testing.assert_allclose(f_q, o_full[3], rtol=1e-9, atol=1e-6)
         assert np.array_equal(f_lab, o_full[4])
         np.testing.assert_allclose(f_cov, o_full[2], rtol=1e-6, atol=1e-14)
-    monkeypatch.delenv("HGMM_TREE_NO_CHOL")
+    ctx.config_set("tree_no_chol", 0)
     # a caller-supplied table with an indefinite "covariance" whose determinant is positive raises the flag
     pi8 = np.full(8, 1.0 / 8)
     mu8 = P[:8].copy()
@@ -597,18 +595,15 @@ def test_stop_rule_in_the_next_launch_equals_the_ticketed_tail(ctx, bunny, monke
     T = hgmm_tree.n_total(L)
     idx = np.random.RandomState(72).randint(T, size=T)
     a = build(ctx, P, L, 80.0, 1e-4, idx, 0.00034, max_iters)
-    monkeypatch.setenv("HGMM_TREE_TICKETS", "1")
-    b = build(ctx, P, L, 80.0, 1e-4, idx, 0.00034, max_iters)
-    monkeypatch.delenv("HGMM_TREE_TICKETS")
-    monkeypatch.setenv("HGMM_TREE_AHEAD", "0")
-    c = build(ctx, P, L, 80.0, 1e-4, idx, 0.00034, max_iters)
-    monkeypatch.delenv("HGMM_TREE_AHEAD")
+    with ctx.config(tree_tickets=1):
+        b = build(ctx, P, L, 80.0, 1e-4, idx, 0.00034, max_iters)
+    with ctx.config(tree_ahead=0):
+        c = build(ctx, P, L, 80.0, 1e-4, idx, 0.00034, max_iters)
     # round 4: for small clouds the default form also runs iteration e + 1's E-step (speculatively) inside iteration e's
     # log-likelihood launch, the moments kernel applies the stop rule and the assignment is double-buffered
     # (tree_ll_estep_kernel); HGMM_TREE_OVERLAP=0 is the one-launch-each form -- a fourth way to the same tree
-    monkeypatch.setenv("HGMM_TREE_OVERLAP", "0")
-    d = build(ctx, P, L, 80.0, 1e-4, idx, 0.00034, max_iters)
-    monkeypatch.delenv("HGMM_TREE_OVERLAP")
+    with ctx.config(tree_overlap=0):
+        d = build(ctx, P, L, 80.0, 1e-4, idx, 0.00034, max_iters)
     for other in (b, c, d):
         assert list(a[4]) == list(other[4])
         for x, y in zip((a[0], a[1], a[2], a[3], a[5]), (other[0], other[1], other[2], other[3], other[5])):
@@ -671,15 +666,13 @@ def test_float32_pdf_mode_builds_the_float64_tree_to_convergence(ctx, n, monkeyp
     args = (P, L, 20.0, 1e-4, idx, 0.004)
     ref = build(ctx, *args, max_iters=300)
     assert max(ref[4]) < 300 and min(ref[4]) >= 3               # converged by the rule, not by the budget
-    monkeypatch.setenv("HGMM_TREE_NO_CHOL", "1")              # (the fallback form changes the float64 E-step's last bits too)
-    ref_sym = build(ctx, *args, max_iters=300)
-    monkeypatch.delenv("HGMM_TREE_NO_CHOL")
+    with ctx.config(tree_no_chol=1):                          # (the fallback form changes the float64 E-step's last bits too)
+        ref_sym = build(ctx, *args, max_iters=300)
     ctx.tree_set_precision(np.float32)
     try:
         got = build(ctx, *args, max_iters=300)
-        monkeypatch.setenv("HGMM_TREE_NO_CHOL", "1")
-        sym = build(ctx, *args, max_iters=300)
-        monkeypatch.delenv("HGMM_TREE_NO_CHOL")
+        with ctx.config(tree_no_chol=1):
+            sym = build(ctx, *args, max_iters=300)
     finally:
         ctx.tree_set_precision(np.float64)
     for name, res, want in (("triangular", got, ref), ("symmetric", sym, ref_sym)):
