@@ -413,6 +413,34 @@ def tree_1m_leg(ctx):
                          "flags": flags}}
 
 
+def sharded_tree_leg(ctx, rank, world):
+    """N > 1, every rank takes part (the communicator of the joint fit is still attached): ONE HGMM over all ranks' frames
+    -- points stay on their GPU, the 10 8^(l+1) moments + q are all-reduced per level-iteration.  Reports what
+    keeping the host ahead of the device-side stop rule costs under a communicator: every rank tops its queue up to
+    min(iterations + 2, budget) per level, so the surplus is 2 level-iterations (4 all-reduces on unchanged operands) per
+    level; round 5 ran up to 15 blind iterations per level."""
+    P = synth_frame(rank).astype(np.float64)
+    L, T, budget = 4, 4680, 12
+    init = synth_frame(0).astype(np.float64)[np.random.RandomState(72).randint(N_POINTS, size=T)]
+    ctx.set_points(P)
+    ctx.tree_build(L, 80.0, 1e-4, init, 0.01, budget, want_leaf=False)               # warm-up
+    c0, s0 = ctx.comm_stats()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    pi, mu, cov, _, iters, q = ctx.tree_build(L, 80.0, 1e-4, init, 0.01, budget, want_leaf=False)
+    dt = time.perf_counter() - t0
+    c1, s1 = ctx.comm_stats()
+    digest = float(np.abs(mu).sum() + np.abs(cov).sum())
+    lo, hi = ctx.allreduce([-digest, digest], op="max")
+    return {"workload": "one HGMM (L = 4, ls = 80, <= %d iterations per level) over %d frames of 10^6 points, one per GPU"
+                        % (budget, world),
+            "ms": dt * 1e3, "level_iterations": [int(v) for v in iters], "collectives": int(c1 - c0),
+            "surplus_collectives": int(2 * (s1 - s0)), "surplus_level_iterations": int(s1 - s0),
+            "identical_tree_on_all_ranks": bool(-lo == hi),
+            "rule": "collectives = 1 (point count) + 2 per enqueued level-iteration (moments, q); enqueued = "
+                    "min(iterations + 2, budget) per level on every rank"}
+
+
 def info_cus(ctx):
     return int(ctx.device_info()["compute_units"])
 
@@ -1100,6 +1128,13 @@ def rank_main(args):
     fused_ms, fused_n, ar_ms, ar_n = fit["fused_ms"], fit["fused_n"], fit["ar_ms"], fit["ar_n"]
     if not consistent:
         sys.stderr.write("rank %d: model checksums differ across ranks: max %s min %s\n" % (rank, fit["checksum"], fit["checksum_lo"]))
+    sharded_tree = None
+    if world > 1 and "sharded_tree" not in args.skip:
+        try:                                        # every rank calls it or none does (args.skip is the same everywhere)
+            sharded_tree = sharded_tree_leg(ctx, rank, world)
+        except Exception as e:
+            sharded_tree = {"error": repr(e)}
+        ctx.set_points(frame)
     # --collective auto: the same joint fit once more over the one-shot peer exchange, reported beside the RCCL figure
     second = None
     if world > 1 and requested == "auto" and kind in ("rccl", "host") and len(hosts) == 1 and not rehearsal_host_only:
@@ -1174,6 +1209,9 @@ def rank_main(args):
             out["allreduce_launches"] = ar_n
             if second is not None:
                 out["peer_exchange"] = second
+            if sharded_tree is not None:
+                out["sharded_tree"] = sharded_tree
+                out["surplus_collectives"] = sharded_tree.get("surplus_collectives")
         if fused_avg_ms:
             out["roofline_fused"] = fused_roofline(fused_avg_ms * 1e-3, info["compute_units"])
         if not consistent:

@@ -134,6 +134,7 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_kmeans_center_f64", [_vp, C.c_int64, _vp, _vp, _vp])
         _sig(lib, "hgmm_tree_register", [ctx, _vp, _vp, C.c_double, C.c_double, C.c_int, C.c_double, _vp,
                                          C.POINTER(C.c_int), C.POINTER(C.c_int), _vp])
+        _sig(lib, "hgmm_comm_stats", [ctx, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)])
         _sig(lib, "hgmm_config_count", [])
         _sig(lib, "hgmm_config_name", [C.c_int], C.c_char_p)
         _sig(lib, "hgmm_config_set", [ctx, C.c_char_p, C.c_int])
@@ -1217,6 +1218,13 @@ class Context:
         include/hgmm.h): every all-reduce is one kernel per rank, all ranks end with bitwise the same sums."""
         self._check(self.lib.hgmm_comm_init_ipc(self.h, int(nranks), int(rank), name.encode()))
         self.nranks, self.rank = int(nranks), int(rank)
+
+    def comm_stats(self):
+        """-> (all-reduces this context has enqueued on its communicator, level-iterations of hgmm_tree_build enqueued
+        behind a level's stop): the cost of keeping the host ahead of a device-side stop rule under a communicator."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.hgmm_comm_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def comm_destroy(self):
         self._check(self.lib.hgmm_comm_destroy(self.h))

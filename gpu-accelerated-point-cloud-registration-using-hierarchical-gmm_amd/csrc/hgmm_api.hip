@@ -376,6 +376,7 @@ static void ipc_close(hgmm_ctx* c) {
 
 int allreduce_f64_dev(hgmm_ctx* c, double* dev, size_t n) {
     if (!c->comm_on()) return HGMM_OK;
+    c->collectives++;
     ProfScope prof(c, HGMM_K_ALLREDUCE);
     if (c->comm) {
         HGMM_NCCL(c, ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, c->comm, c->stream));
@@ -388,6 +389,7 @@ int allreduce_f64_dev(hgmm_ctx* c, double* dev, size_t n) {
 
 int allreduce_i64_dev(hgmm_ctx* c, long long* dev, size_t n) {
     if (!c->comm_on()) return HGMM_OK;
+    c->collectives++;
     ProfScope prof(c, HGMM_K_ALLREDUCE);
     if (c->comm) {
         HGMM_NCCL(c, ncclAllReduce(dev, dev, n, ncclInt64, ncclSum, c->comm, c->stream));
@@ -404,6 +406,7 @@ int allreduce_f64_oop(hgmm_ctx* c, const double* src, double* dst, size_t n) {
         if (src != dst) HGMM_HIP(c, hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
         return HGMM_OK;
     }
+    c->collectives++;
     ProfScope prof(c, HGMM_K_ALLREDUCE);
     if (c->comm) {
         HGMM_NCCL(c, ncclAllReduce(src, dst, n, ncclDouble, ncclSum, c->comm, c->stream));
@@ -1180,10 +1183,18 @@ extern "C" int hgmm_comm_destroy(hgmm_ctx* c) {
     return HGMM_OK;
 }
 
+extern "C" int hgmm_comm_stats(hgmm_ctx* c, unsigned long long* collectives_out, unsigned long long* surplus_tree_iterations_out) {
+    if (!c) return HGMM_ERR_ARG;
+    if (collectives_out) *collectives_out = c->collectives;
+    if (surplus_tree_iterations_out) *surplus_tree_iterations_out = c->tree.surplus_iterations;
+    return HGMM_OK;
+}
+
 extern "C" int hgmm_comm_allreduce_f64(hgmm_ctx* c, double* host_inout, int n, int op) {
     HGMM_ENTER(c);
     if (!c || !host_inout || n < 1) return HGMM_ERR_ARG;
     if (!c->comm_on()) return HGMM_OK;   // single rank: identity
+    c->collectives++;
     HGMM_TRY(ensure(c, c->comm_buf, sizeof(double) * (size_t)n));
     HGMM_HIP(c, hipMemcpyAsync(c->comm_buf.p, host_inout, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     if (c->icomm)

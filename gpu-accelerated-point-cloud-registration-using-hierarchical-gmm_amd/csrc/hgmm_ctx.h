@@ -107,6 +107,7 @@ struct TreeState {
     double mu_rmax = -1.0;            // largest |mu_j| of the node table (< 0: not known on the host yet)
     bool momq_dirty = true;           // the fixed-point moment words hold sums nobody has cleared yet
     unsigned long long reg_seq = 0;   // sequence number of the last registration system handed over in pinned memory
+    unsigned long long surplus_iterations = 0;   // (communicator) level-iterations enqueued behind a level's stop, all builds
 };
 
 // A FOREST: B independent clouds whose trees are built / whose targets are registered by the same launches
@@ -235,6 +236,7 @@ struct hgmm_ctx {
     int nranks = 1, rank = 0;
     hgmm::DevBuf comm_buf;
     bool comm_on() const { return comm != nullptr || hcomm != nullptr || icomm != nullptr; }
+    unsigned long long collectives = 0;       // all-reduces this context has enqueued on its communicator (hgmm_comm_stats)
 
     // ---- profiling --------------------------------------------------------------
     bool profiling = false;

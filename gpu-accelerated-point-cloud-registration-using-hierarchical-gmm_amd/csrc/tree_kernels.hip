@@ -858,7 +858,9 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     int* curbuf[2] = {cur, overlap ? cur + n_pad : cur};
     unsigned long long* host_word = nullptr;                   // host address / device address of the same pinned word
     unsigned long long* host_word_dev = nullptr;
-    if (!c->comm_on() && ahead_iters > 0) {
+    // (under a communicator too, round 6: every rank reads the same reduced q, so every rank's stop rule says the same and
+    //  every rank's host can follow its own device's progress word -- see the level loop)
+    if (ahead_iters > 0) {
         TreeCtl* hp0 = nullptr;
         HGMM_TRY(tree_host_ctl(c, &hp0));
         host_word = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(hp0) + 64);
@@ -1009,7 +1011,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                 if (c->comm_on()) {
                     rc = allreduce_f64_oop(c, q_dev, q_g, 1);
                     if (rc != HGMM_OK) return rc;
-                    tree_ctl_kernel<<<1, 1, 0, c->stream>>>(q_g, ctl, ls, max_iters_per_level, trace_dev, trace_cap);
+                    tree_ctl_kernel<<<1, 1, 0, c->stream>>>(q_g, ctl, ls, max_iters_per_level, trace_dev, trace_cap, host_word_dev);
                 }
             // a launch the runtime rejected (LDS / grid limits of another chip) would leave the progress word untouched
             // for ever: the loops below must hear about it here
@@ -1035,7 +1037,20 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
             while (rc == HGMM_OK) {
                 const unsigned long long w = __atomic_load_n(host_word, __ATOMIC_RELAXED);
                 it = (int)(w & 0xffffffffull);
-                if (w >> 32) break;                                           // the level has stopped after `it` iterations
+                if (w >> 32) {                                                // the level has stopped after `it` iterations
+                    // Under a communicator every rank must have enqueued the SAME collectives when it leaves the level.
+                    // How far a rank's host had got when it saw the stop is a matter of timing; min(it + ahead, budget)
+                    // is not: each rank tops its queue up to exactly that many iterations (the surplus ones return at
+                    // their first load, their all-reduces run out of place on unchanged operands).  Round 5 looked at
+                    // the stop word once per 8 iterations, one batch behind: up to 15 surplus iterations per level,
+                    // 46 over C4's four levels; now `ahead` (2) per level, whatever the backend.
+                    if (c->comm_on()) {
+                        const int must = std::min(it + ahead_iters, max_iters_per_level);
+                        while (rc == HGMM_OK && enq < must) rc = enqueue_iteration(enq++);
+                        c->tree.surplus_iterations += (unsigned long long)(enq - it);
+                    }
+                    break;
+                }
                 if (enq < max_iters_per_level && enq - it < ahead_iters) {
                     rc = enqueue_iteration(enq);
                     ++enq;

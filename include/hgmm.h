@@ -209,6 +209,12 @@ int hgmm_flat_stats(hgmm_ctx* ctx, int cov_type, int variant, int J,
                     const float* mu, const float* inv_std, const float* w,
                     double* stats_out, double* sum_lpn_out, double* n_points_out);
 
+/* All-reduces this context has enqueued on its communicator so far, and the level-iterations hgmm_tree_build has enqueued
+ * behind a level's stop (each costs two all-reduces on unchanged operands): under a communicator every rank must issue
+ * the same collectives, so each rank tops its queue up to min(iterations + tree_ahead, budget) per level -- 2 surplus
+ * iterations per level by default (round 5: up to 15).  Either pointer may be NULL.                                    */
+int hgmm_comm_stats(hgmm_ctx* ctx, unsigned long long* collectives_out, unsigned long long* surplus_tree_iterations_out);
+
 /* ---- per-context options ---------------------------------------------------------------------------------------------
  * The library reads the environment ONCE, in hgmm_create: every option below starts from HGMM_<NAME IN CAPITALS> when
  * that variable is set, else from its default, and can be changed per context afterwards.  Each option selects a path

@@ -97,6 +97,15 @@ class FakeContext:
     def flat_estep(self, inv, mu, w, cov_type="diag", variant="W", out=None, **kw):
         return 0.0, out, None, None
 
+    def tree_build(self, L, ls, ld, init_mu, sig2, max_iters_per_level=1000, q_capacity=None, want_leaf=True):
+        T = len(init_mu)
+        self._coll = getattr(self, "_coll", 0) + 1 + 2 * 4 * 5         # 3 iterations + 2 ahead on each of 4 levels
+        self._surplus = getattr(self, "_surplus", 0) + 2 * 4
+        return np.ones(T), np.ones((T, 3)), np.ones((T, 3, 3)), None, np.full(L, 3, np.int32), np.zeros(3 * L)
+
+    def comm_stats(self):
+        return getattr(self, "_coll", 0), getattr(self, "_surplus", 0)
+
     def profile_reset(self):
         pass
 
@@ -166,6 +175,10 @@ def test_bench_two_rank_flow():
     px = d["peer_exchange"]
     assert "peer exchange" in px["collective"] and px["value"] > 0 and px["identical_model_on_all_ranks"] is True
     assert px["model_bitwise_equal_to_the_headline_fit"] is True
+    # the sharded HGMM leg: what the look-ahead behind a device-side stop costs under a communicator
+    st = d["sharded_tree"]
+    assert st["level_iterations"] == [3, 3, 3, 3] and st["collectives"] == 41 and st["identical_tree_on_all_ranks"] is True
+    assert d["surplus_collectives"] == st["surplus_collectives"] == 16 and st["surplus_level_iterations"] == 8
     assert "torch" not in open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                             "bench.py")).read().split('"""', 2)[2].replace("torch.distributed.run", "")
 

@@ -74,8 +74,11 @@ def _run_all(ctx, lo, hi):
         inv, mu, w, cov, lls, _ = ctx.flat_train(6, 0.0, mu0, cov0, w0, "diag", variant)
         out["flat_" + variant] = (mu, w, cov, np.asarray(lls))
     ctx.set_points(X[lo:hi])
+    before = ctx.comm_stats()
     pi, mu, cov, leaf, iters, q = ctx.tree_build(2, 5.0, 1e-4, tree_init, 0.01, 60)
+    after = ctx.comm_stats()
     out["tree"] = (pi, mu, cov, leaf, np.asarray(iters), np.asarray(q))
+    out["tree_collectives"] = (after[0] - before[0], after[1] - before[1])
     ctx.tree_set_target(target[lo:hi])
     out["reg"] = ctx.tree_reg_estep(len(pi), lambda_c=0.01)
     pi, mu, cov, labels, q = ctx.fullcov_fit(8, 1.0, 1e-4, full_init, 0.01, 40)
@@ -424,6 +427,12 @@ def _ranks_match_single_context(rccl_port, backend="host", world=2):
         np.testing.assert_allclose(pi, rpi, rtol=0, atol=1e-12)
         np.testing.assert_allclose(mu, rmu, rtol=0, atol=1e-11)
         np.testing.assert_allclose(cov, rcov, rtol=1e-8, atol=1e-14)
+        # No blind batches behind a level's stop: every rank leaves a level with exactly min(it + 2, budget)
+        # iterations enqueued -- two all-reduces each (moments, q) -- plus the one all-reduce of the point count; the same
+        # number on every rank (a mismatch would hang RCCL), and the single context enqueues none.
+        enq = [min(int(it) + 2, 60) for it in iters]
+        assert r["tree_collectives"] == (1 + 2 * sum(enq), sum(enq) - int(sum(iters))), (r["tree_collectives"], list(iters))
+        assert ref["tree_collectives"] == (0, 0)
         for a, b_ in zip(r["reg"], ref["reg"]):
             np.testing.assert_allclose(a, b_, rtol=1e-10, atol=1e-12)
         pi, mu, cov, labels, qt = r["full"]
