@@ -420,20 +420,21 @@ def sharded_tree_leg(ctx, rank, world):
     min(iterations + 2, budget) per level, so the surplus is 2 level-iterations (4 all-reduces on unchanged operands) per
     level; round 5 ran up to 15 blind iterations per level."""
     P = synth_frame(rank).astype(np.float64)
-    L, T, budget = 4, 4680, 12
-    init = synth_frame(0).astype(np.float64)[np.random.RandomState(72).randint(N_POINTS, size=T)]
+    L, T, budget = 4, 4680, 40
+    ls = 1.0e-3 * N_POINTS * world                   # (a uniform cloud converges slowly: stop at 1e-3 per point, so that
+    init = synth_frame(0).astype(np.float64)[np.random.RandomState(72).randint(N_POINTS, size=T)]       # levels end by the rule)
     ctx.set_points(P)
-    ctx.tree_build(L, 80.0, 1e-4, init, 0.01, budget, want_leaf=False)               # warm-up
+    ctx.tree_build(L, ls, 1e-4, init, 0.01, budget, want_leaf=False)                 # warm-up
     c0, s0 = ctx.comm_stats()
     ctx.synchronize()
     t0 = time.perf_counter()
-    pi, mu, cov, _, iters, q = ctx.tree_build(L, 80.0, 1e-4, init, 0.01, budget, want_leaf=False)
+    pi, mu, cov, _, iters, q = ctx.tree_build(L, ls, 1e-4, init, 0.01, budget, want_leaf=False)
     dt = time.perf_counter() - t0
     c1, s1 = ctx.comm_stats()
     digest = float(np.abs(mu).sum() + np.abs(cov).sum())
     lo, hi = ctx.allreduce([-digest, digest], op="max")
-    return {"workload": "one HGMM (L = 4, ls = 80, <= %d iterations per level) over %d frames of 10^6 points, one per GPU"
-                        % (budget, world),
+    return {"workload": "one HGMM (L = 4, ls = %g, <= %d iterations per level) over %d frames of 10^6 points, one per GPU"
+                        % (ls, budget, world),
             "ms": dt * 1e3, "level_iterations": [int(v) for v in iters], "collectives": int(c1 - c0),
             "surplus_collectives": int(2 * (s1 - s0)), "surplus_level_iterations": int(s1 - s0),
             "identical_tree_on_all_ranks": bool(-lo == hi),
@@ -525,12 +526,13 @@ def estep_roofline_leg(ctx, lr, init, fitted, args):
     stream_s = s_ms / max(s_n, 1) * 1e-3
     alg_bytes = 12 * N_POINTS + 4 * N_POINTS * J_COMP + 4 * N_POINTS + 28 * J_COMP
     achieved = alg_bytes / avg_s / 1e9
-    traffic, traffic_source = None, None
+    traffic, traffic_source, rocprof_mean_us = None, None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
             traffic = rec.get("flat_estep_bytes_per_launch")
+            rocprof_mean_us = rec.get("flat_estep_rocprof_mean_us")
             traffic_source = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                               "kernel (separate runs of this bench command, measured %s on commit %s; counters cannot be "
                               "collected inside a timed run)" % (rec.get("measured_on", "in an earlier round"),
@@ -548,6 +550,10 @@ def estep_roofline_leg(ctx, lr, init, fitted, args):
     return {"kernel": "materialising E-step (flat_estep kernel, log_resp[N,J] written once)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+            "rocprof_mean_us": rocprof_mean_us,
+            "rocprof_mean_note": "mean launch duration of this kernel in the committed rocprofv3 --kernel-trace --stats of this "
+                                 "bench command (profiles/pmc_traffic.json, same lease as `traffic`); `avg_launch_ms` is this "
+                                 "run's own hipEvent figure",
             "rule": "achieved = algorithmic bytes / mean launch duration over the call patterns below (hipEvents), equal weights",
             "patterns_ms": {"blocking_calls": avg_s * 1e3, "unsynchronised_stream": stream_s * 1e3,
                             "right_behind_a_fit": cold_avg},

@@ -1263,7 +1263,9 @@ def default_context() -> Context:
     if tl is not None and getattr(tl, "h", None):
         return tl
     if _default_ctx is None or not getattr(_default_ctx, "h", None):
-        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+        with _default_ctx_lock:                       # two threads of a plain ThreadPoolExecutor must not both create one
+            if _default_ctx is None or not getattr(_default_ctx, "h", None):
+                _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
     return _default_ctx
 
 
@@ -1273,6 +1275,7 @@ def set_default_context(ctx):
 
 
 _thread_ctx = threading.local()
+_default_ctx_lock = threading.Lock()
 
 
 @contextlib.contextmanager

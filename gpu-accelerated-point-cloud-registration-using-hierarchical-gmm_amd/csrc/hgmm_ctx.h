@@ -161,7 +161,7 @@ struct hgmm_ctx {
     hgmm::PaceCtl pace;
     hgmm::DevBuf f_block;                     // float [10][Jpad]: the allocation behind the four arrays below
     hgmm::DevBuf f_mu, f_cov, f_w, f_inv;     // float model parameters (reference layout): NON-OWNING slices of f_block
-    hgmm::DevBuf f_pack;                      // float [7][Jpad] packed E-step params
+    hgmm::DevBuf f_pack;                      // float [PK_ROWS = 8][Jpad] packed E-step params (flat_kernels.hip: mu, g, c, w)
     hgmm::DevBuf f_partials;                  // float [blocks][7][Jpad]
     hgmm::DevBuf f_lpn_partials;              // double [blocks]
     hgmm::DevBuf f_stats;                     // double [7*Jpad + 2]  (+ sum lpn, + n)

@@ -953,7 +953,6 @@ __device__ __forceinline__ void tree_loglik_body(const int bx, const int by, con
         }
         __syncthreads();
         entered += cnt;
-        if (fl & 4) cnt = 0;                               // HGMM_TREE_LL_NOEVAL (measurement aid)
         for (int k = 0; k < cnt; ++k) {
             // (node parameters through the LDS tile: reading them with wave-uniform scalar loads
             //  instead was measured 60 % slower for the C4 build, 8.6 vs 5.2 ms)

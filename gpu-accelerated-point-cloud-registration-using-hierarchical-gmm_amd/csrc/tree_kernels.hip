@@ -230,9 +230,14 @@ constexpr double LLF_LOG2E = 1.4426950408889634;
 constexpr double LLF_REL_BITS = 30.0;                    // a dropped term is below eps * 2^-30 / n_nodes
 __device__ __forceinline__ f2t llf_bc(float v) { return f2t{v, v}; }
 __device__ __forceinline__ f2t llf_fma(f2t a, f2t b, f2t c) { return __builtin_elementwise_fma(a, b, c); }
+// float32 node parameters stay finite AND leave room for z = R x - b and |z|^2: a node tighter than sigma ~ 1e-15 would
+// overflow float32 (inf - inf = NaN in the z sums, and a NaN exponent silently drops the node from a point's sum); clamped,
+// its exponent is a huge negative number for every point float32 can tell from the mean, i.e. its pdf is 0 there
+__device__ __forceinline__ float llf_f32(double v) { return (float)fmax(fmin(v, 1.0e15), -1.0e15); }
 
 __global__ __launch_bounds__(CH) void tree_loglik_f32_kernel(TreeLoglikArgs a) {
     constexpr int PTS = 4;
+    static_assert(CH / 64 == 4 && LL_TILE == CH, "the box / count reductions below are written for four waves and one node per thread");
     __shared__ f4t tile[LL_TILE * 3];                      // per node: (r00 r01 r02 r11) (r12 r22 -b0 -b1) (-b2 w yskip 0)
     __shared__ double shq[CH / 64];
     __shared__ double shbox[CH / 64][6];
@@ -316,15 +321,15 @@ __global__ __launch_bounds__(CH) void tree_loglik_f32_kernel(TreeLoglikArgs a) {
                     const float ysk = (float)((abs_floor - lw) * LLF_LOG2E);            // skip threshold of 2^y, log2 units
                     if (use_chol) {
                         const double S = LLF_SQRT_LOG2E;
-                        va = f4t{(float)(S * f0), (float)(S * f1), (float)(S * f2), (float)(S * f3)};
-                        vb = f4t{(float)(S * f4), (float)(S * f5), (float)(-S * fma(f2, m2, fma(f1, m1, f0 * m0))),
-                                 (float)(-S * fma(f4, m2, f3 * m1))};
-                        vc = f4t{(float)(-S * (f5 * m2)), (float)wL, ysk, 0.f};
+                        va = f4t{llf_f32(S * f0), llf_f32(S * f1), llf_f32(S * f2), llf_f32(S * f3)};
+                        vb = f4t{llf_f32(S * f4), llf_f32(S * f5), llf_f32(-S * fma(f2, m2, fma(f1, m1, f0 * m0))),
+                                 llf_f32(-S * fma(f4, m2, f3 * m1))};
+                        vc = f4t{llf_f32(-S * (f5 * m2)), (float)wL, ysk, 0.f};
                     } else {
                         // symmetric form: (-log2(e) / 2) Sigma^-1 and the mean, one float32 quadratic form per point
                         const double H = -0.5 * LLF_LOG2E;
-                        va = f4t{(float)(H * f0), (float)(H * f1), (float)(H * f2), (float)(H * f3)};
-                        vb = f4t{(float)(H * f4), (float)(H * f5), (float)m0, (float)m1};
+                        va = f4t{llf_f32(H * f0), llf_f32(H * f1), llf_f32(H * f2), llf_f32(H * f3)};
+                        vb = f4t{llf_f32(H * f4), llf_f32(H * f5), (float)m0, (float)m1};
                         vc = f4t{(float)m2, (float)wL, ysk, 0.f};
                     }
                 }
@@ -347,7 +352,6 @@ __global__ __launch_bounds__(CH) void tree_loglik_f32_kernel(TreeLoglikArgs a) {
         }
         __syncthreads();
         entered += cnt;
-        if (fl & 4) cnt = 0;                               // HGMM_TREE_LL_NOEVAL (measurement aid)
         for (int k = 0; k < cnt; ++k) {
             const f4t ta = tile[3 * k], tb = tile[3 * k + 1], tc = tile[3 * k + 2];
             f2t y[2];

@@ -1,4 +1,4 @@
-"""Condenses the rocprofv3 outputs of tools/profile_round.sh:
+"""Condenses the rocprofv3 outputs of tools/round_r06.sh (earlier rounds: profile_round.sh):
   <dir>/kt/**/kt_kernel_stats.csv           -> <dir>/rocprofv3_kernel_stats.csv (copied)
   <dir>/pmc_<COUNTER>/**/pmc_counter_collection.csv -> <dir>/rocprofv3_pmc_<counter>.csv (mean per kernel)
   -> <dir>/pmc_traffic.json (bytes per launch of the three flat kernels; FETCH_SIZE / WRITE_SIZE are KB;
@@ -70,6 +70,43 @@ def main():
             "flat_mstep_bytes_per_launch": 2 * (m_f or 0) + (m_w or 0) if m_f else None,
             "flat_fused_bytes_per_launch": (f_f or 0) + (f_w or 0) if f_f is not None else None,
         }
+        # the SAME lease's kernel statistics and store-pacer state beside the counters (a 480 vs 500 us
+        # difference between leases must be attributable): mean launch durations from the --kernel-trace --stats pass,
+        # the pacer's rate / steps / probes from the JSON line each profiled bench run printed
+        stats_csv = os.path.join(out, "rocprofv3_kernel_stats.csv")
+        if os.path.exists(stats_csv):
+            means = {}
+            with open(stats_csv) as f:
+                for row in csv.DictReader(f):
+                    means[row["Name"]] = (float(row["AverageNs"]) / 1e3, int(row["Calls"]), float(row["MinNs"]) / 1e3, float(row["MaxNs"]) / 1e3)
+
+            def pick(needle):
+                for k, v in means.items():
+                    if needle in k:
+                        return {"mean_us": v[0], "calls": v[1], "min_us": v[2], "max_us": v[3]}
+                return None
+            summary["rocprof_kernel_stats"] = {"flat_estep_rows_pk_kernel": pick("flat_estep_rows_pk_kernel<3, 1, 4, true>"),
+                                               "flat_fused_pk_kernel<13>": pick("flat_fused_pk_kernel<13>"),
+                                               "flat_mstep_kernel": pick("flat_mstep_kernel"),
+                                               "full_fused_kernel<2>": pick("full_fused_kernel<2>"),
+                                               "source": "rocprofv3 --kernel-trace --stats of `python bench.py --skip published_charts,"
+                                                         "replica_pairs` on the same lease (rocprofv3_kernel_stats.csv)"}
+            e = summary["rocprof_kernel_stats"]["flat_estep_rows_pk_kernel"]
+            summary["flat_estep_rocprof_mean_us"] = e["mean_us"] if e else None
+        pacer = {}
+        for tag, name in (("kernel_trace_run", "bench_n1_under_rocprofv3.json"), ("pmc_FETCH_SIZE_run", "pmc_FETCH_SIZE.stdout"),
+                          ("pmc_WRITE_SIZE_run", "pmc_WRITE_SIZE.stdout"), ("unprofiled_run", "bench_n1.json")):
+            path = os.path.join(out, name)
+            try:
+                line = [l for l in open(path).read().splitlines() if l.strip().startswith("{")][-1]
+                r = json.loads(line)["roofline"]
+                pacer[tag] = {"store_pacer": r.get("store_pacer", {}), "patterns_ms": r.get("patterns_ms"),
+                              "avg_launch_ms": r.get("avg_launch_ms"), "frac": r.get("frac")}
+                for k in ("rule",):
+                    pacer[tag]["store_pacer"].pop(k, None)
+            except Exception:
+                continue
+        summary["estep_runs_of_this_lease"] = pacer
         with open(os.path.join(out, "pmc_traffic.json"), "w") as f:
             json.dump(summary, f, indent=1)
         print(json.dumps(summary, indent=1))
