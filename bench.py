@@ -1414,6 +1414,14 @@ def pairs_main(args):
     info = ctx.device_info()
     group = parallel.TcpGroup(rank, world)
     source, pairs = scan_pairs(rank)
+    # The scans ARE float32 (the .ply files; the reference's GPU file also casts, hgmm_gpu.py:472 points.astype(np.float32)):
+    # handed over as float32 the mirrors evaluate the build's stop rule in float32 (hgmm_tree_set_precision; tables, E-step,
+    # moments and registration stay float64, the trees are the float64 trees bit for bit whenever the iteration counts agree --
+    # tests/test_tree_batch_gpu.py); handed over as float64 everything is float64.  --scan-dtype picks what is timed as
+    # `value`; the other kind is timed behind it (`other_scan_dtype`).
+    kinds = {"float32": (source.astype(np.float32), [t.astype(np.float32) for t, _ in pairs]),
+             "float64": (source, [t for t, _ in pairs])}
+    active = {"kind": args.scan_dtype}
     K, W = args.steps, args.warmup
     iters, errs, starts, done = [], [], [], []
     failures = []
@@ -1429,12 +1437,13 @@ def pairs_main(args):
                         return
                     for _ in range(abs(n_steps)):
                         ks = [(wi + C * (step * Bt + j)) % len(pairs) for j in range(Bt)]
+                        src_k, tgt_k = kinds[active["kind"]]
                         if Bt == 1:
-                            res, n_it = register_pair(c, source, pairs[ks[0]][0])
+                            res, n_it = register_pair(c, src_k, tgt_k[ks[0]])
                             results, n_its = [res], [n_it]
                         else:
-                            results, n_its = register_batch(c, source, [pairs[k][0] for k in ks])
-                        if n_steps > 0:                                         # (negative: warm-up, nothing recorded)
+                            results, n_its = register_batch(c, src_k, [tgt_k[k] for k in ks])
+                        if n_steps > 0 and active["kind"] == args.scan_dtype:   # (negative: warm-up, nothing recorded)
                             iters.extend(n_its)
                             done.extend((r.transformation, k) for r, k in zip(results, ks))    # judged after the timing
                         step += 1
@@ -1474,6 +1483,22 @@ def pairs_main(args):
         blocks.append(float(group.allgather_f64([dt_local]).max()))          # identical on every rank
         if (sum(blocks) >= args.min_time and len(blocks) >= 3) or len(blocks) >= MAX_BLOCKS:
             break
+    # the other kind of scans, timed the same way (half the time)
+    other_kind = "float64" if args.scan_dtype == "float32" else "float32"
+    other_blocks = []
+    if not args.no_other_dtype:
+        active["kind"] = other_kind
+        run_steps(-max(W, 1))
+        while True:
+            barrier()
+            t0 = time.perf_counter()
+            run_steps(K)
+            dt_local = time.perf_counter() - t0
+            barrier()
+            other_blocks.append(float(group.allgather_f64([dt_local]).max()))
+            if (sum(other_blocks) >= 0.5 * args.min_time and len(other_blocks) >= 3) or len(other_blocks) >= MAX_BLOCKS:
+                break
+        active["kind"] = args.scan_dtype
     for q in q_ins:
         q.put(None)
     for t in threads:
@@ -1496,7 +1521,7 @@ def pairs_main(args):
     # kernel time of one pair under the hipEvent profiler (not part of the timing)
     ctx.profile_reset()
     ctx.profile_enable(True)
-    register_pair(ctx, source, pairs[0][0])
+    register_pair(ctx, kinds[args.scan_dtype][0], kinds[args.scan_dtype][1][0])
     ctx.synchronize()
     ctx.profile_enable(False)
     prof = {k: ctx.profile_get(k) for k in ("tree_estep", "tree_loglik", "tree_reg")}
@@ -1508,7 +1533,12 @@ def pairs_main(args):
             "metric": "registered scan pairs/sec (registration_gmmtree: GMM-tree build of the source + registration of the target)",
             "value": world * C * K * Bt / med, "unit": "pairs/s (all GPUs)", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * med / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "Stanford bunny scans bun000 / bun045 (tests/golden), poses from the reference's bun.conf",
+            "dtype": ("f64 (node tables, E-step, moments, registration); f32 pdfs in the build's stop rule (float32 scans: the "
+                      "reference GPU file's type, hgmm_gpu.py:472)" if args.scan_dtype == "float32" else "f64"),
+            "scan_dtype": args.scan_dtype,
+            "other_scan_dtype": ({"scan_dtype": other_kind, "pairs_per_s": world * C * K * Bt / float(np.median(other_blocks)),
+                                  "blocks": len(other_blocks)} if other_blocks else None),
+            "data": "Stanford bunny scans bun000 / bun045 (tests/golden), poses from the reference's bun.conf",
             "mode": "pairs",
             "config": {"workload": "replicas: every GPU registers its own scan pairs, no communicator -- source bun000.ply "
                                    "(40256 pts), target bun045.ply (40097 pts) placed by bun.conf and moved by a known rigid "
@@ -1578,6 +1608,10 @@ def main():
     ap.add_argument("--batch", type=int, default=16,
                     help="--mode pairs: pairs every context takes through the SAME launches per step "
                          "(registration_gmmtree_batch; 1 = one registration_gmmtree call per pair, round 5's path)")
+    ap.add_argument("--scan-dtype", default="float32", choices=["float32", "float64"],
+                    help="--mode pairs: the type the scans are handed over in (float32 = the files' and the reference GPU "
+                         "file's type: float32 pdfs in the build's stop rule; float64: float64 throughout)")
+    ap.add_argument("--no-other-dtype", action="store_true", help="--mode pairs: skip the timing of the other scan type")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--estep-reps", type=int, default=30)
     ap.add_argument("--skip", default="", help="comma-separated side legs to skip (bunny,hgmm,tree_1M,fullcov,...)")

@@ -86,12 +86,15 @@ __global__ __launch_bounds__(64) void forest_moments_kernel(const double* __rest
 // blocks return); the rest: chunks.
 // (five waves per SIMD: 96 registers, no spills; 4 / 5 / 6 measured 14.2 / 13.9 / 14.4 ms per build of 32 bunny scans --
 //  the kernel keeps the fp64 pipe ~80 % busy at any of them, profiles/r06/pmc_sq_batch32.txt)
+// F32: the log-likelihood workgroups evaluate their pdfs in float32 (hgmm_tree_set_precision; tree_loglik_f32_body)
+template <bool F32>
 __global__ __launch_bounds__(CH, 5) void forest_ll_estep_kernel(const double* __restrict__ xs, int64_t n_pad,
                                                              const double* __restrict__ prep, int64_t lb, int n_level,
                                                              double* __restrict__ block_q, const int* __restrict__ flags,
                                                              ForestArgs fa, int ll_stride, TreeEstepArgs ea, int with_estep) {
-    constexpr int LDS = tree_loglik_lds<false>() > tree_estep_lds<true>() ? tree_loglik_lds<false>() : tree_estep_lds<true>();
-    __shared__ double smem[LDS];
+    constexpr int LL_LDS = F32 ? tree_loglik_f32_lds() : tree_loglik_lds<false>();
+    constexpr int LDS = LL_LDS > tree_estep_lds<true>() ? LL_LDS : tree_estep_lds<true>();
+    __shared__ __attribute__((aligned(16))) double smem[LDS];
     const int w = (int)blockIdx.x;
     const int n_ll = fa.B * ll_stride;
     if (w < n_ll) {
@@ -103,7 +106,8 @@ __global__ __launch_bounds__(CH, 5) void forest_ll_estep_kernel(const double* __
         const TreeLoglikArgs la{xs, (int64_t)pt_first + pt_count, n_pad, prep, (int64_t)b * fa.T + lb, n_level, per_chunk,
                                 nullptr, block_q + q_first, nullptr, nullptr, nullptr, NO_STOP, flags + b, nullptr, nullptr,
                                 (int64_t)pt_first, q_count};
-        tree_loglik_body<2, false, true>(bx, 0, gx, gy, la, smem);
+        if constexpr (F32) tree_loglik_f32_body<2, true>(bx, 0, gx, gy, la, smem);
+        else tree_loglik_body<2, false, true>(bx, 0, gx, gy, la, smem);
     } else if (with_estep) {
         tree_estep_body<true, true>(w - n_ll, ea, NO_FOLLOW, smem, &fa);
     }
@@ -390,11 +394,13 @@ extern "C" int hgmm_tree_build_batch(hgmm_ctx* c, int B, const int64_t* counts, 
             fc.ll_gy = chunks;
             fc.ll_per_chunk = per_chunk;
             fc.q_first = q_at;
-            fc.q_count = chunks > 1 ? (int)nblk(counts[b], CH) : llblocks;
+            // (level 0: the E-step stores the shares, one per chunk -- a cloud's chunks are consecutive, TreeEstepArgs::q_shares)
+            fc.q_count = (l == 0 || chunks > 1) ? (int)nblk(counts[b], CH) : llblocks;
             q_at += fc.q_count;
             fc.n_total = (double)counts[b];
             ll_stride = std::max(ll_stride, llblocks);
         }
+        if (l == 0) ll_stride = 0;                              // no log-likelihood workgroups at level 0
         {
             void* st = nullptr;
             rc = stage_reserve(c, sizeof(ForestCloud) * B, &st);
@@ -420,12 +426,17 @@ extern "C" int hgmm_tree_build_batch(hgmm_ctx* c, int B, const int64_t* counts, 
                                                                                 d_pi, d_mu, d_cov, d_prep, d_flags, fa, block_q, e);
             {
                 ProfScope prof(c, HGMM_K_TREE_LOGLIK);
-                const int with_estep = e + 1 < max_iters_per_level ? 1 : 0;
+                // (level 0: behind the budget's last iteration the E-step runs for the shares of q alone)
+                const int with_estep = (e + 1 < max_iters_per_level || l == 0) ? 1 : 0;
                 const TreeEstepArgs ea_next{xs_cur, n_pad, d_prep, chunk_desc, n_chunks_dev, parent_first, l, partials,
-                                            ((e + 1) & 1) ? cur1 : cur0, nullptr};
+                                            ((e + 1) & 1) ? cur1 : cur0, nullptr, l == 0 ? block_q : nullptr};
                 const unsigned g = (unsigned)(B * ll_stride) + (with_estep ? grid_chunks : 0u);
-                forest_ll_estep_kernel<<<g, CH, 0, c->stream>>>(xs_cur, n_pad, d_prep, lb, n_level, block_q, d_flags, fa,
-                                                               ll_stride, ea_next, with_estep);
+                if (c->tree.pdf_f32)
+                    forest_ll_estep_kernel<true><<<g, CH, 0, c->stream>>>(xs_cur, n_pad, d_prep, lb, n_level, block_q, d_flags,
+                                                                         fa, ll_stride, ea_next, with_estep);
+                else
+                    forest_ll_estep_kernel<false><<<g, CH, 0, c->stream>>>(xs_cur, n_pad, d_prep, lb, n_level, block_q, d_flags,
+                                                                          fa, ll_stride, ea_next, with_estep);
             }
             const hipError_t le = hipGetLastError();
             if (le != hipSuccess) return fail(c, HGMM_ERR_HIP, "tree build (batch): kernel launch failed: %s", hipGetErrorString(le));

@@ -436,6 +436,11 @@ typedef double double4_es __attribute__((ext_vector_type(4)));
 struct TreeEstepArgs {
     const double* xs; int64_t n_pad; const double* prep; const int* chunk_desc; const int* n_chunks;
     int64_t parent_level_first; int level; double* partials; int* cur_sorted; const int* done;
+    // LEVEL 0 of the overlapped builds (small clouds, forests): the level's nodes ARE the root's eight children, so the
+    // log-likelihood of iteration e -- sum_i log max(sum_j [pi_j >= eps] pi_j N(x_i; j), eps), logLikelihoodValue C:72-85 --
+    // is a sum over the very eight terms iteration e + 1's E-step forms from the same parameters.  With q_shares set the
+    // E-step stores its chunk's share of it (chunk c -> q_shares[c]) and no log-likelihood workgroup runs for the level.
+    double* q_shares = nullptr;
 };
 // A FOREST (tree_batch.hip): B independent clouds whose points lie back to back in one resident cloud and whose trees are
 // built by the same launches.  At level l the forest has B 8^l parent segments; segment p belongs to cloud p >> 3 l and is
@@ -545,6 +550,14 @@ __device__ __forceinline__ void tree_estep_body(const int c, const TreeEstepArgs
             den += g[k];
         }
     }
+    if (a.q_shares) {                                  // (kernel-uniform)
+        // wL = wE, or 0 where pi < eps (prep_node): the log-likelihood leaves those nodes out, the E-step does not
+        double den_l = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) den_l += (prep[PREP_N * (j0 + k) + 10] == 0.0) ? 0.0 : g[k];
+        const double lq = wave_sum_f64(active ? log(fmax(den_l, TREE_EPS)) : 0.0);
+        if (lane_id() == 0) sh_follow[wave_in_block()] = lq;      // (read behind the barrier in front of the partials)
+    }
     // gamma = g / den if den > eps else 0; arg-max = first maximum  (C:174-187)
     const bool good = den > TREE_EPS;
     int am = 0;
@@ -603,6 +616,12 @@ __device__ __forceinline__ void tree_estep_body(const int c, const TreeEstepArgs
 #pragma unroll
         for (int ww = 0; ww < CH / 64; ++ww) t += sh[ww][threadIdx.x];
         partials[(size_t)c * (8 * NMOM) + threadIdx.x] = t;
+    }
+    if (a.q_shares && threadIdx.x == CH - 1) {
+        double t = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < CH / 64; ++ww) t += sh_follow[ww];
+        a.q_shares[c] = t;
     }
 }
 
@@ -1046,6 +1065,277 @@ __device__ __forceinline__ void tree_loglik_body(const int bx, const int by, con
     double t = 0.0;
     for (int ww = 0; ww < CH / 64; ++ww) t += shq[ww];
     store_block_q(t, block_q, bx, gx, ticket, q_out, stop);
+}
+
+// ------------------------------------------------------------------------------------------
+// The same level log-likelihood with the pdfs in FLOAT32 (hgmm_tree_set_precision(ctx, HGMM_PRECISION_F32_PDF): the type
+// of the reference's GPU file, hgmm_gpu.py:472-484 -- float32 points, float32 node and moment arrays), any cloud size (round 6: small clouds and forests too).
+//   * What stays float64: the points' coordinates relative to the workgroup's first point and every node's parameters in
+//     those coordinates (R, -R (mu - c), weight) are formed in float64 exactly as above and only THEN rounded -- the
+//     float32 numbers are of the size of the workgroup's extent over sigma, not of |x| over sigma; log(max(sum, eps))
+//     per point and the sum q over the points are float64.
+//   * What becomes float32: z = R d - b, y = -|z|^2 (R pre-scaled by sqrt(log2 e): 2^y is the pdf's exponential), 2^y by
+//     v_exp_f32, sum_j w_j 2^y_j per point: 20 packed instructions (two points per v_pk_fma_f32) + 4 v_exp_f32 per node
+//     for the thread's FOUR points, against 96 float64 instructions above.
+//   * Range: the reference clamps the sum at eps = 1e-15 before the logarithm (logLikelihoodValue, C:83), so a term
+//     below eps * 2^-30 / n_nodes cannot move a point's logarithm by 1e-9 -- nodes whose UPPER bound over the
+//     workgroup's box, log w - kappa dist(box, mu)^2, is below that never enter the tile, and a wave skips the
+//     exponentials of a node whose exponents are all below it: float32's exponent range (2^-126) is never approached.
+//   * Conditioning: z = R x - R m in float32 carries 2^-23 of |R| x (extent of the workgroup about its origin), so a
+//     term's error grows with extent / sigma -- a few units while a workgroup's points are neighbours (the usual case),
+//     ~1000 when a parent holds tight, far-apart clusters.  The errors have random sign and q sums 10^5 ... 10^6 terms:
+//     MEASURED on 16 clusters of sigma = 5e-4 scattered over a unit cube (tests/test_tree_gpu.py::
+//     test_float32_pdf_mode_on_tight_far_apart_clusters) |dq| / |q| = 3e-8, |dq| = 0.09 against ls = 20.  A guarded
+//     variant (nodes beyond |R| x extent = 64 evaluated from head + tail differences, errors relative to |x - mu|) was
+//     built and measured: 8e-9 there, but 114 instead of 96 VGPRs and a 20 KB tile made the 10^6-point build 2.97 instead
+//     of 2.41 ms -- removed again (profiles/r05/tree_f32_probe.log keeps both figures).
+//   Accuracy of q against the float64 kernel, measured: |dq| = 0.02 ... 0.04 = 3-5e-8 per point on every cloud tried
+//   (the uniform million, clustered clouds of 0.4 - 0.9 M points built to convergence at L = 1 ... 3, seeded random
+//   shapes, the ill-conditioned case above; tests/test_tree_gpu.py) -- under 1 % of the smallest stop threshold in use
+//   (ls = 5) and 0.03 % of the bench's (ls = 80).  The
+//   E-step and the moments do NOT go through this kernel: as long as a level stops after the same number of iterations
+//   the tree is the float64 tree bit for bit.
+// ------------------------------------------------------------------------------------------
+typedef float f2t __attribute__((ext_vector_type(2)));
+typedef float f4t __attribute__((ext_vector_type(4)));
+constexpr double LLF_SQRT_LOG2E = 1.2011224087864498;    // sqrt(log2 e): |sqrt(log2 e) z|^2 = log2(e) |z|^2
+constexpr double LLF_LOG2E = 1.4426950408889634;
+constexpr double LLF_REL_BITS = 30.0;                    // a dropped term is below eps * 2^-30 / n_nodes
+__device__ __forceinline__ f2t llf_bc(float v) { return f2t{v, v}; }
+__device__ __forceinline__ f2t llf_fma(f2t a, f2t b, f2t c) { return __builtin_elementwise_fma(a, b, c); }
+// float32 node parameters stay finite AND leave room for z = R x - b and |z|^2: a node tighter than sigma ~ 1e-15 would
+// overflow float32 (inf - inf = NaN in the z sums, and a NaN exponent silently drops the node from a point's sum); clamped,
+// its exponent is a huge negative number for every point float32 can tell from the mean, i.e. its pdf is 0 there
+__device__ __forceinline__ float llf_f32(double v) { return (float)fmax(fmin(v, 1.0e15), -1.0e15); }
+
+// LDS of one float32 log-likelihood workgroup, in doubles: node tile (three float4 per node), the waves' q, boxes, counts
+constexpr int tree_loglik_f32_lds() { return LL_TILE * 3 * 2 + (CH / 64) * (1 + 6) + (CH / 64) / 2; }
+// PTS = 4 (clouds of >= 400 000 points) or 2 (small clouds); FOREST as in tree_loglik_body: the workgroup takes ALL node
+// chunks of its point block one after the other and forms the serial build's shares of q (the chunk sums -- float32 sums
+// widened to float64, exactly what the serial form parks in `partial` -- added in chunk order).
+template <int PTS, bool FOREST>
+__device__ __forceinline__ void tree_loglik_f32_body(const int bx, const int by, const int gx, const int gy,
+                                                     const TreeLoglikArgs& a, double* __restrict__ smem) {
+    static_assert(PTS == 2 || PTS == 4, "points go through the packed instructions two at a time");
+    static_assert(CH / 64 == 4 && LL_TILE == CH, "the box / count reductions below are written for four waves and one node per thread");
+    constexpr int NH = PTS / 2;
+    f4t* tile = reinterpret_cast<f4t*>(smem);              // per node: (r00 r01 r02 r11) (r12 r22 -b0 -b1) (-b2 w yskip 0)
+    double* shq = smem + LL_TILE * 3 * 2;
+    double (*shbox)[6] = reinterpret_cast<double (*)[6]>(shq + CH / 64);
+    int* wcnt = reinterpret_cast<int*>(shq + (CH / 64) * 7);
+    const double* __restrict__ xs = a.xs;
+    const int64_t n = a.n, n_pad = a.n_pad;
+    const double* __restrict__ prep = a.prep;
+    const int64_t lb = a.lb;
+    const int n_level_nodes = a.n_level_nodes, nodes_per_chunk = a.nodes_per_chunk;
+    const int stop_flag = a.done ? *a.done : 0;
+    const int fl = a.flags ? *a.flags : 0;
+    const int w = wave_in_block(), lane = lane_id();
+    const int64_t i_first = (FOREST ? a.i_base : (int64_t)0) + (int64_t)bx * PTS * CH;
+    const int64_t i_c = i_first < n ? i_first : n - 1;
+    const double c0 = xs[i_c], c1 = xs[n_pad + i_c], c2 = xs[2 * n_pad + i_c];
+    int64_t i[PTS];
+    bool active[PTS];
+    double r0[PTS], r1[PTS], r2[PTS];
+#pragma unroll
+    for (int p = 0; p < PTS; ++p) {
+        i[p] = i_first + (int64_t)p * CH + threadIdx.x;
+        active[p] = i[p] < n;
+        const int64_t il = active[p] ? i[p] : i_c;
+        r0[p] = xs[il]; r1[p] = xs[n_pad + il]; r2[p] = xs[2 * n_pad + il];
+    }
+    if (stop_flag) return;
+    const bool use_chol = !(fl & 1);                       // kernel-uniform
+    double lo0 = 0.0, lo1 = 0.0, lo2 = 0.0, hi0 = 0.0, hi1 = 0.0, hi2 = 0.0;
+    float xf0[PTS], xf1[PTS], xf2[PTS];
+#pragma unroll
+    for (int p = 0; p < PTS; ++p) {
+        double d0 = 0.0, d1 = 0.0, d2 = 0.0;               // inactive slots sit on the origin
+        if (active[p]) { d0 = r0[p] - c0; d1 = r1[p] - c1; d2 = r2[p] - c2; }
+        lo0 = fmin(lo0, d0); hi0 = fmax(hi0, d0);
+        lo1 = fmin(lo1, d1); hi1 = fmax(hi1, d1);
+        lo2 = fmin(lo2, d2); hi2 = fmax(hi2, d2);
+        xf0[p] = (float)d0; xf1[p] = (float)d1; xf2[p] = (float)d2;
+    }
+    {
+        const double b0 = -wave_max_f64(-lo0), b1 = -wave_max_f64(-lo1), b2 = -wave_max_f64(-lo2);
+        const double b3 = wave_max_f64(hi0), b4 = wave_max_f64(hi1), b5 = wave_max_f64(hi2);
+        if (lane == 0) {
+            shbox[w][0] = b0; shbox[w][1] = b1; shbox[w][2] = b2; shbox[w][3] = b3; shbox[w][4] = b4; shbox[w][5] = b5;
+        }
+    }
+    __syncthreads();
+    lo0 = fmin(fmin(shbox[0][0], shbox[1][0]), fmin(shbox[2][0], shbox[3][0]));
+    lo1 = fmin(fmin(shbox[0][1], shbox[1][1]), fmin(shbox[2][1], shbox[3][1]));
+    lo2 = fmin(fmin(shbox[0][2], shbox[1][2]), fmin(shbox[2][2], shbox[3][2]));
+    hi0 = fmax(fmax(shbox[0][3], shbox[1][3]), fmax(shbox[2][3], shbox[3][3]));
+    hi1 = fmax(fmax(shbox[0][4], shbox[1][4]), fmax(shbox[2][4], shbox[3][4]));
+    hi2 = fmax(fmax(shbox[0][5], shbox[1][5]), fmax(shbox[2][5], shbox[3][5]));
+    // a term below this (natural log) cannot move any point's log(max(sum, eps)) by 2^-30
+    const double abs_floor = log(TREE_EPS) - LLF_REL_BITS * 0.6931471805599453 - log((double)n_level_nodes);
+    f2t X0[NH], X1[NH], X2[NH], TOT[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        X0[h] = f2t{xf0[2 * h], xf0[2 * h + 1]};
+        X1[h] = f2t{xf1[2 * h], xf1[2 * h + 1]};
+        X2[h] = f2t{xf2[2 * h], xf2[2 * h + 1]};
+        TOT[h] = f2t{0.f, 0.f};
+    }
+    [[maybe_unused]] double totsum[PTS];                   // forest: the chunk sums added in chunk order (tree_loglik_finish_kernel)
+#pragma unroll
+    for (int p = 0; p < PTS; ++p) totsum[p] = 0.0;
+
+    int node_begin = by * nodes_per_chunk;
+    int node_end = (node_begin + nodes_per_chunk < n_level_nodes) ? node_begin + nodes_per_chunk : n_level_nodes;
+    int entered = 0;
+    const int cy_end = FOREST ? gy : 1;
+    for (int cy = 0; cy < cy_end; ++cy) {
+    if constexpr (FOREST) {
+        node_begin = cy * nodes_per_chunk;
+        node_end = (node_begin + nodes_per_chunk < n_level_nodes) ? node_begin + nodes_per_chunk : n_level_nodes;
+    }
+    for (int base = node_begin; base < node_end; base += LL_TILE) {
+        const int node = base + (int)threadIdx.x;
+        bool live = false;
+        f4t va = f4t{0.f, 0.f, 0.f, 0.f}, vb = va, vc = va;
+        bool known_dead = false;                            // (forest: a node's parameters are requested once its weight is known)
+        if constexpr (FOREST) {
+            if (node < node_end) known_dead = prep[PREP_N * (lb + node) + 10] == 0.0;
+        }
+        if (node < node_end && !known_dead) {
+            const double* pr = prep + PREP_N * (lb + node);
+            const double wL = pr[10], kap = pr[PREP_KAPPA], u0 = pr[6], u1 = pr[7], u2 = pr[8];
+            const int fo = use_chol ? PREP_R : 0;
+            const double f0 = pr[fo], f1 = pr[fo + 1], f2 = pr[fo + 2], f3 = pr[fo + 3], f4 = pr[fo + 4], f5 = pr[fo + 5];
+            if (wL != 0.0) {
+                const double m0 = u0 - c0, m1 = u1 - c1, m2 = u2 - c2;
+                const double g0 = fmax(fmax(lo0 - m0, m0 - hi0), 0.0), g1 = fmax(fmax(lo1 - m1, m1 - hi1), 0.0),
+                             g2 = fmax(fmax(lo2 - m2, m2 - hi2), 0.0);
+                const double d2 = g0 * g0 + g1 * g1 + g2 * g2;
+                const double lw = log(wL);
+                live = !(lw - kap * d2 < abs_floor);
+                if (live) {
+                    const float ysk = (float)((abs_floor - lw) * LLF_LOG2E);            // skip threshold of 2^y, log2 units
+                    if (use_chol) {
+                        const double S = LLF_SQRT_LOG2E;
+                        va = f4t{llf_f32(S * f0), llf_f32(S * f1), llf_f32(S * f2), llf_f32(S * f3)};
+                        vb = f4t{llf_f32(S * f4), llf_f32(S * f5), llf_f32(-S * fma(f2, m2, fma(f1, m1, f0 * m0))),
+                                 llf_f32(-S * fma(f4, m2, f3 * m1))};
+                        vc = f4t{llf_f32(-S * (f5 * m2)), (float)wL, ysk, 0.f};
+                    } else {
+                        // symmetric form: (-log2(e) / 2) Sigma^-1 and the mean, one float32 quadratic form per point
+                        const double H = -0.5 * LLF_LOG2E;
+                        va = f4t{llf_f32(H * f0), llf_f32(H * f1), llf_f32(H * f2), llf_f32(H * f3)};
+                        vb = f4t{llf_f32(H * f4), llf_f32(H * f5), (float)m0, (float)m1};
+                        vc = f4t{(float)m2, (float)wL, ysk, 0.f};
+                    }
+                }
+            }
+        }
+        const unsigned long long mask = __ballot(live);
+        const int before = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[w] = __popcll(mask);
+        __syncthreads();                                   // also: every wave is done with the previous tile
+        int off = 0, cnt = 0;
+#pragma unroll
+        for (int ww = 0; ww < CH / 64; ++ww) {
+            const int t = wcnt[ww];
+            if (ww < w) off += t;
+            cnt += t;
+        }
+        if (live) {
+            f4t* dst = tile + 3 * (off + before);
+            dst[0] = va; dst[1] = vb; dst[2] = vc;
+        }
+        __syncthreads();
+        entered += cnt;
+        for (int k = 0; k < cnt; ++k) {
+            const f4t ta = tile[3 * k], tb = tile[3 * k + 1], tc = tile[3 * k + 2];
+            f2t y[NH];
+            if (use_chol) {
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const f2t z0 = llf_fma(llf_bc(ta.z), X2[h], llf_fma(llf_bc(ta.y), X1[h], llf_fma(llf_bc(ta.x), X0[h], llf_bc(tb.z))));
+                    const f2t z1 = llf_fma(llf_bc(tb.x), X2[h], llf_fma(llf_bc(ta.w), X1[h], llf_bc(tb.w)));
+                    const f2t z2 = llf_fma(llf_bc(tb.y), X2[h], llf_bc(tc.x));
+                    f2t t = -(z0 * z0);
+                    t = llf_fma(-z1, z1, t);
+                    y[h] = llf_fma(-z2, z2, t);
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const f2t d0 = X0[h] - llf_bc(tb.z), d1 = X1[h] - llf_bc(tb.w), d2 = X2[h] - llf_bc(tc.x);
+                    const f2t t0 = llf_fma(llf_bc(2.f), llf_fma(llf_bc(ta.z), d2, llf_bc(ta.y) * d1), llf_bc(ta.x) * d0);
+                    const f2t t1 = llf_fma(llf_bc(2.f), llf_bc(tb.x) * d2, llf_bc(ta.w) * d1);
+                    y[h] = llf_fma(d2, llf_bc(tb.y) * d2, llf_fma(d1, t1, d0 * t0));
+                }
+            }
+            float ymax = fmaxf(y[0].x, y[0].y);
+            if constexpr (NH == 2) ymax = fmaxf(ymax, fmaxf(y[1].x, y[1].y));
+            if (__any(ymax > tc.z)) {
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const f2t e = f2t{__builtin_amdgcn_exp2f(y[h].x), __builtin_amdgcn_exp2f(y[h].y)};
+                    TOT[h] = llf_fma(llf_bc(tc.y), e, TOT[h]);
+                }
+            }
+        }
+    }
+    if constexpr (FOREST) {
+        if (gy > 1) {
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                totsum[2 * h] += (double)TOT[h].x;
+                totsum[2 * h + 1] += (double)TOT[h].y;
+                TOT[h] = f2t{0.f, 0.f};
+            }
+        }
+    }
+    }
+    if constexpr (FOREST) {
+        if (gy > 1) {
+            // the serial build's tree_loglik_finish_kernel: one share per 256 points = per p of this workgroup
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < PTS; ++p) {
+                double lq = active[p] ? log(fmax(totsum[p], TREE_EPS)) : 0.0;
+                lq = wave_sum_f64(lq);
+                if (p > 0) __syncthreads();                // the previous share has been summed
+                if (lane_id() == 0) shq[wave_in_block()] = lq;
+                __syncthreads();
+                double t = 0.0;
+                for (int ww = 0; ww < CH / 64; ++ww) t += shq[ww];
+                const int share = bx * PTS + p;
+                if (threadIdx.x == 0 && share < a.q_count) a.block_q[share] = t;
+            }
+            return;
+        }
+    }
+    if (a.pair_count && threadIdx.x == 0) {
+        const int64_t rest = n - i_first;
+        const int64_t pts = rest <= 0 ? 0 : (rest < (int64_t)PTS * CH ? rest : (int64_t)PTS * CH);
+        atomicAdd(a.pair_count, (unsigned long long)(pts * entered));
+    }
+    float tot[PTS];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) { tot[2 * h] = TOT[h].x; tot[2 * h + 1] = TOT[h].y; }
+    if (gy > 1) {
+#pragma unroll
+        for (int p = 0; p < PTS; ++p)
+            if (active[p]) a.partial[(size_t)by * n_pad + i[p]] = (double)tot[p];
+        return;
+    }
+    double lq = 0.0;
+#pragma unroll
+    for (int p = 0; p < PTS; ++p) lq += active[p] ? log(fmax((double)tot[p], TREE_EPS)) : 0.0;
+    lq = wave_sum_f64(lq);
+    __syncthreads();
+    if (lane_id() == 0) shq[wave_in_block()] = lq;
+    __syncthreads();
+    double t = 0.0;
+    for (int ww = 0; ww < CH / 64; ++ww) t += shq[ww];
+    store_block_q(t, a.block_q, bx, gx, a.ticket, a.q_out, a.stop);
 }
 
 struct OpAddInt { __device__ __forceinline__ int operator()(int a, int b) const { return a + b; } };

@@ -194,218 +194,11 @@ __global__ __launch_bounds__(CH) void tree_loglik_kernel(const double* __restric
                                                  q_out, done, stop, flags, pair_count, exp2_tab}, smem);
 }
 
-// ------------------------------------------------------------------------------------------
-// The same level log-likelihood with the pdfs in FLOAT32 (hgmm_tree_set_precision(ctx, HGMM_PRECISION_F32_PDF): the type
-// of the reference's GPU file, hgmm_gpu.py:472-484 -- float32 points, float32 node and moment arrays), large clouds.
-//   * What stays float64: the points' coordinates relative to the workgroup's first point and every node's parameters in
-//     those coordinates (R, -R (mu - c), weight) are formed in float64 exactly as above and only THEN rounded -- the
-//     float32 numbers are of the size of the workgroup's extent over sigma, not of |x| over sigma; log(max(sum, eps))
-//     per point and the sum q over the points are float64.
-//   * What becomes float32: z = R d - b, y = -|z|^2 (R pre-scaled by sqrt(log2 e): 2^y is the pdf's exponential), 2^y by
-//     v_exp_f32, sum_j w_j 2^y_j per point: 20 packed instructions (two points per v_pk_fma_f32) + 4 v_exp_f32 per node
-//     for the thread's FOUR points, against 96 float64 instructions above.
-//   * Range: the reference clamps the sum at eps = 1e-15 before the logarithm (logLikelihoodValue, C:83), so a term
-//     below eps * 2^-30 / n_nodes cannot move a point's logarithm by 1e-9 -- nodes whose UPPER bound over the
-//     workgroup's box, log w - kappa dist(box, mu)^2, is below that never enter the tile, and a wave skips the
-//     exponentials of a node whose exponents are all below it: float32's exponent range (2^-126) is never approached.
-//   * Conditioning: z = R x - R m in float32 carries 2^-23 of |R| x (extent of the workgroup about its origin), so a
-//     term's error grows with extent / sigma -- a few units while a workgroup's points are neighbours (the usual case),
-//     ~1000 when a parent holds tight, far-apart clusters.  The errors have random sign and q sums 10^5 ... 10^6 terms:
-//     MEASURED on 16 clusters of sigma = 5e-4 scattered over a unit cube (tests/test_tree_gpu.py::
-//     test_float32_pdf_mode_on_tight_far_apart_clusters) |dq| / |q| = 3e-8, |dq| = 0.09 against ls = 20.  A guarded
-//     variant (nodes beyond |R| x extent = 64 evaluated from head + tail differences, errors relative to |x - mu|) was
-//     built and measured: 8e-9 there, but 114 instead of 96 VGPRs and a 20 KB tile made the 10^6-point build 2.97 instead
-//     of 2.41 ms -- removed again (profiles/r05/tree_f32_probe.log keeps both figures).
-//   Accuracy of q against the float64 kernel, measured: |dq| = 0.02 ... 0.04 = 3-5e-8 per point on every cloud tried
-//   (the uniform million, clustered clouds of 0.4 - 0.9 M points built to convergence at L = 1 ... 3, seeded random
-//   shapes, the ill-conditioned case above; tests/test_tree_gpu.py) -- under 1 % of the smallest stop threshold in use
-//   (ls = 5) and 0.03 % of the bench's (ls = 80).  The
-//   E-step and the moments do NOT go through this kernel: as long as a level stops after the same number of iterations
-//   the tree is the float64 tree bit for bit.
-// ------------------------------------------------------------------------------------------
-typedef float f2t __attribute__((ext_vector_type(2)));
-typedef float f4t __attribute__((ext_vector_type(4)));
-constexpr double LLF_SQRT_LOG2E = 1.2011224087864498;    // sqrt(log2 e): |sqrt(log2 e) z|^2 = log2(e) |z|^2
-constexpr double LLF_LOG2E = 1.4426950408889634;
-constexpr double LLF_REL_BITS = 30.0;                    // a dropped term is below eps * 2^-30 / n_nodes
-__device__ __forceinline__ f2t llf_bc(float v) { return f2t{v, v}; }
-__device__ __forceinline__ f2t llf_fma(f2t a, f2t b, f2t c) { return __builtin_elementwise_fma(a, b, c); }
-// float32 node parameters stay finite AND leave room for z = R x - b and |z|^2: a node tighter than sigma ~ 1e-15 would
-// overflow float32 (inf - inf = NaN in the z sums, and a NaN exponent silently drops the node from a point's sum); clamped,
-// its exponent is a huge negative number for every point float32 can tell from the mean, i.e. its pdf is 0 there
-__device__ __forceinline__ float llf_f32(double v) { return (float)fmax(fmin(v, 1.0e15), -1.0e15); }
-
+// (tree_loglik_f32_body, csrc/tree_device.h: the level log-likelihood with the pdfs in FLOAT32)
+template <int PTS>
 __global__ __launch_bounds__(CH) void tree_loglik_f32_kernel(TreeLoglikArgs a) {
-    constexpr int PTS = 4;
-    static_assert(CH / 64 == 4 && LL_TILE == CH, "the box / count reductions below are written for four waves and one node per thread");
-    __shared__ f4t tile[LL_TILE * 3];                      // per node: (r00 r01 r02 r11) (r12 r22 -b0 -b1) (-b2 w yskip 0)
-    __shared__ double shq[CH / 64];
-    __shared__ double shbox[CH / 64][6];
-    __shared__ int wcnt[CH / 64];
-    const int bx = (int)blockIdx.x, by = (int)blockIdx.y, gx = (int)gridDim.x, gy = (int)gridDim.y;
-    const double* __restrict__ xs = a.xs;
-    const int64_t n = a.n, n_pad = a.n_pad;
-    const double* __restrict__ prep = a.prep;
-    const int64_t lb = a.lb;
-    const int n_level_nodes = a.n_level_nodes, nodes_per_chunk = a.nodes_per_chunk;
-    const int stop_flag = a.done ? *a.done : 0;
-    const int fl = a.flags ? *a.flags : 0;
-    const int w = wave_in_block(), lane = lane_id();
-    const int64_t i_first = (int64_t)bx * PTS * CH;
-    const int64_t i_c = i_first < n ? i_first : n - 1;
-    const double c0 = xs[i_c], c1 = xs[n_pad + i_c], c2 = xs[2 * n_pad + i_c];
-    int64_t i[PTS];
-    bool active[PTS];
-    double r0[PTS], r1[PTS], r2[PTS];
-#pragma unroll
-    for (int p = 0; p < PTS; ++p) {
-        i[p] = i_first + (int64_t)p * CH + threadIdx.x;
-        active[p] = i[p] < n;
-        const int64_t il = active[p] ? i[p] : i_c;
-        r0[p] = xs[il]; r1[p] = xs[n_pad + il]; r2[p] = xs[2 * n_pad + il];
-    }
-    if (stop_flag) return;
-    const bool use_chol = !(fl & 1);                       // kernel-uniform
-    double lo0 = 0.0, lo1 = 0.0, lo2 = 0.0, hi0 = 0.0, hi1 = 0.0, hi2 = 0.0;
-    float xf0[PTS], xf1[PTS], xf2[PTS];
-#pragma unroll
-    for (int p = 0; p < PTS; ++p) {
-        double d0 = 0.0, d1 = 0.0, d2 = 0.0;               // inactive slots sit on the origin
-        if (active[p]) { d0 = r0[p] - c0; d1 = r1[p] - c1; d2 = r2[p] - c2; }
-        lo0 = fmin(lo0, d0); hi0 = fmax(hi0, d0);
-        lo1 = fmin(lo1, d1); hi1 = fmax(hi1, d1);
-        lo2 = fmin(lo2, d2); hi2 = fmax(hi2, d2);
-        xf0[p] = (float)d0; xf1[p] = (float)d1; xf2[p] = (float)d2;
-    }
-    {
-        const double b0 = -wave_max_f64(-lo0), b1 = -wave_max_f64(-lo1), b2 = -wave_max_f64(-lo2);
-        const double b3 = wave_max_f64(hi0), b4 = wave_max_f64(hi1), b5 = wave_max_f64(hi2);
-        if (lane == 0) {
-            shbox[w][0] = b0; shbox[w][1] = b1; shbox[w][2] = b2; shbox[w][3] = b3; shbox[w][4] = b4; shbox[w][5] = b5;
-        }
-    }
-    __syncthreads();
-    lo0 = fmin(fmin(shbox[0][0], shbox[1][0]), fmin(shbox[2][0], shbox[3][0]));
-    lo1 = fmin(fmin(shbox[0][1], shbox[1][1]), fmin(shbox[2][1], shbox[3][1]));
-    lo2 = fmin(fmin(shbox[0][2], shbox[1][2]), fmin(shbox[2][2], shbox[3][2]));
-    hi0 = fmax(fmax(shbox[0][3], shbox[1][3]), fmax(shbox[2][3], shbox[3][3]));
-    hi1 = fmax(fmax(shbox[0][4], shbox[1][4]), fmax(shbox[2][4], shbox[3][4]));
-    hi2 = fmax(fmax(shbox[0][5], shbox[1][5]), fmax(shbox[2][5], shbox[3][5]));
-    // a term below this (natural log) cannot move any point's log(max(sum, eps)) by 2^-30
-    const double abs_floor = log(TREE_EPS) - LLF_REL_BITS * 0.6931471805599453 - log((double)n_level_nodes);
-    const f2t X0[2] = {f2t{xf0[0], xf0[1]}, f2t{xf0[2], xf0[3]}};
-    const f2t X1[2] = {f2t{xf1[0], xf1[1]}, f2t{xf1[2], xf1[3]}};
-    const f2t X2[2] = {f2t{xf2[0], xf2[1]}, f2t{xf2[2], xf2[3]}};
-    f2t TOT[2] = {f2t{0.f, 0.f}, f2t{0.f, 0.f}};
-
-    const int node_begin = by * nodes_per_chunk;
-    const int node_end = (node_begin + nodes_per_chunk < n_level_nodes) ? node_begin + nodes_per_chunk : n_level_nodes;
-    int entered = 0;
-    for (int base = node_begin; base < node_end; base += LL_TILE) {
-        const int node = base + (int)threadIdx.x;
-        bool live = false;
-        f4t va = f4t{0.f, 0.f, 0.f, 0.f}, vb = va, vc = va;
-        if (node < node_end) {
-            const double* pr = prep + PREP_N * (lb + node);
-            const double wL = pr[10], kap = pr[PREP_KAPPA], u0 = pr[6], u1 = pr[7], u2 = pr[8];
-            const int fo = use_chol ? PREP_R : 0;
-            const double f0 = pr[fo], f1 = pr[fo + 1], f2 = pr[fo + 2], f3 = pr[fo + 3], f4 = pr[fo + 4], f5 = pr[fo + 5];
-            if (wL != 0.0) {
-                const double m0 = u0 - c0, m1 = u1 - c1, m2 = u2 - c2;
-                const double g0 = fmax(fmax(lo0 - m0, m0 - hi0), 0.0), g1 = fmax(fmax(lo1 - m1, m1 - hi1), 0.0),
-                             g2 = fmax(fmax(lo2 - m2, m2 - hi2), 0.0);
-                const double d2 = g0 * g0 + g1 * g1 + g2 * g2;
-                const double lw = log(wL);
-                live = !(lw - kap * d2 < abs_floor);
-                if (live) {
-                    const float ysk = (float)((abs_floor - lw) * LLF_LOG2E);            // skip threshold of 2^y, log2 units
-                    if (use_chol) {
-                        const double S = LLF_SQRT_LOG2E;
-                        va = f4t{llf_f32(S * f0), llf_f32(S * f1), llf_f32(S * f2), llf_f32(S * f3)};
-                        vb = f4t{llf_f32(S * f4), llf_f32(S * f5), llf_f32(-S * fma(f2, m2, fma(f1, m1, f0 * m0))),
-                                 llf_f32(-S * fma(f4, m2, f3 * m1))};
-                        vc = f4t{llf_f32(-S * (f5 * m2)), (float)wL, ysk, 0.f};
-                    } else {
-                        // symmetric form: (-log2(e) / 2) Sigma^-1 and the mean, one float32 quadratic form per point
-                        const double H = -0.5 * LLF_LOG2E;
-                        va = f4t{llf_f32(H * f0), llf_f32(H * f1), llf_f32(H * f2), llf_f32(H * f3)};
-                        vb = f4t{llf_f32(H * f4), llf_f32(H * f5), (float)m0, (float)m1};
-                        vc = f4t{(float)m2, (float)wL, ysk, 0.f};
-                    }
-                }
-            }
-        }
-        const unsigned long long mask = __ballot(live);
-        const int before = __popcll(mask & ((1ull << lane) - 1ull));
-        if (lane == 0) wcnt[w] = __popcll(mask);
-        __syncthreads();                                   // also: every wave is done with the previous tile
-        int off = 0, cnt = 0;
-#pragma unroll
-        for (int ww = 0; ww < CH / 64; ++ww) {
-            const int t = wcnt[ww];
-            if (ww < w) off += t;
-            cnt += t;
-        }
-        if (live) {
-            f4t* dst = tile + 3 * (off + before);
-            dst[0] = va; dst[1] = vb; dst[2] = vc;
-        }
-        __syncthreads();
-        entered += cnt;
-        for (int k = 0; k < cnt; ++k) {
-            const f4t ta = tile[3 * k], tb = tile[3 * k + 1], tc = tile[3 * k + 2];
-            f2t y[2];
-            if (use_chol) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f2t z0 = llf_fma(llf_bc(ta.z), X2[h], llf_fma(llf_bc(ta.y), X1[h], llf_fma(llf_bc(ta.x), X0[h], llf_bc(tb.z))));
-                    const f2t z1 = llf_fma(llf_bc(tb.x), X2[h], llf_fma(llf_bc(ta.w), X1[h], llf_bc(tb.w)));
-                    const f2t z2 = llf_fma(llf_bc(tb.y), X2[h], llf_bc(tc.x));
-                    f2t t = -(z0 * z0);
-                    t = llf_fma(-z1, z1, t);
-                    y[h] = llf_fma(-z2, z2, t);
-                }
-            } else {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f2t d0 = X0[h] - llf_bc(tb.z), d1 = X1[h] - llf_bc(tb.w), d2 = X2[h] - llf_bc(tc.x);
-                    const f2t t0 = llf_fma(llf_bc(2.f), llf_fma(llf_bc(ta.z), d2, llf_bc(ta.y) * d1), llf_bc(ta.x) * d0);
-                    const f2t t1 = llf_fma(llf_bc(2.f), llf_bc(tb.x) * d2, llf_bc(ta.w) * d1);
-                    y[h] = llf_fma(d2, llf_bc(tb.y) * d2, llf_fma(d1, t1, d0 * t0));
-                }
-            }
-            const float ymax = fmaxf(fmaxf(y[0].x, y[0].y), fmaxf(y[1].x, y[1].y));
-            if (__any(ymax > tc.z)) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f2t e = f2t{__builtin_amdgcn_exp2f(y[h].x), __builtin_amdgcn_exp2f(y[h].y)};
-                    TOT[h] = llf_fma(llf_bc(tc.y), e, TOT[h]);
-                }
-            }
-        }
-    }
-    if (a.pair_count && threadIdx.x == 0) {
-        const int64_t rest = n - i_first;
-        const int64_t pts = rest <= 0 ? 0 : (rest < (int64_t)PTS * CH ? rest : (int64_t)PTS * CH);
-        atomicAdd(a.pair_count, (unsigned long long)(pts * entered));
-    }
-    const float tot[PTS] = {TOT[0].x, TOT[0].y, TOT[1].x, TOT[1].y};
-    if (gy > 1) {
-#pragma unroll
-        for (int p = 0; p < PTS; ++p)
-            if (active[p]) a.partial[(size_t)by * n_pad + i[p]] = (double)tot[p];
-        return;
-    }
-    double lq = 0.0;
-#pragma unroll
-    for (int p = 0; p < PTS; ++p) lq += active[p] ? log(fmax((double)tot[p], TREE_EPS)) : 0.0;
-    lq = wave_sum_f64(lq);
-    __syncthreads();
-    if (lane_id() == 0) shq[wave_in_block()] = lq;
-    __syncthreads();
-    double t = 0.0;
-    for (int ww = 0; ww < CH / 64; ++ww) t += shq[ww];
-    store_block_q(t, a.block_q, bx, gx, a.ticket, a.q_out, a.stop);
+    __shared__ __attribute__((aligned(16))) double smem[tree_loglik_f32_lds()];
+    tree_loglik_f32_body<PTS, false>((int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y, a, smem);
 }
 
 // One launch for two independent pieces of work on the same parameters (small clouds, single GPU): the level
@@ -416,17 +209,20 @@ __global__ __launch_bounds__(CH) void tree_loglik_f32_kernel(TreeLoglikArgs a) {
 // moments are never read and its assignment sits in the OTHER of two buffers (iteration e's E-step wrote buffer e & 1).
 // What it buys: the E-step's chain of trips to memory (5 - 6 us at C4) runs beside the log-likelihood's instead of
 // behind it, and a level-iteration is two or three launches instead of three or four.
-template <int PTS>
+// F32: the log-likelihood workgroups evaluate their pdfs in float32 (hgmm_tree_set_precision; tree_loglik_f32_body)
+template <int PTS, bool F32 = false>
 __global__ __launch_bounds__(CH) void tree_ll_estep_kernel(TreeLoglikArgs la, int gx, int gy, TreeEstepArgs ea) {
     // (one LDS block for whichever of the two a workgroup turns out to be; the E-step in its two-pass form -- the same
     //  sums bit for bit -- so that both need ~23 KB and the launch's workgroups are all resident at once)
-    constexpr int LDS = tree_loglik_lds<false>() > tree_estep_lds<true>() ? tree_loglik_lds<false>() : tree_estep_lds<true>();
-    __shared__ double smem[LDS];
+    constexpr int LL_LDS = F32 ? tree_loglik_f32_lds() : tree_loglik_lds<false>();
+    constexpr int LDS = LL_LDS > tree_estep_lds<true>() ? LL_LDS : tree_estep_lds<true>();
+    __shared__ __attribute__((aligned(16))) double smem[LDS];
     const int nll = gx * gy;
     const int b = (int)blockIdx.x;
-    if (b < nll)
-        tree_loglik_body<PTS, false>(b % gx, b / gx, gx, gy, la, smem);
-    else
+    if (b < nll) {
+        if constexpr (F32) tree_loglik_f32_body<PTS, false>(b % gx, b / gx, gx, gy, la, smem);
+        else tree_loglik_body<PTS, false>(b % gx, b / gx, gx, gy, la, smem);
+    } else
         tree_estep_body<true>(b - nll, ea, TreeFollow{nullptr, 0, nullptr, nullptr, nullptr, 0.0, 0, nullptr, 0, nullptr}, smem);
 }
 
@@ -942,7 +738,9 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
         // has stopped).
         // follow mode (single GPU, polled look-ahead): launch e of the E-step adds up the shares of q that iteration e - 1
         // left behind and applies the stop rule itself (tree_follow); the log-likelihood kernels only store their shares
-        const int q_shares = chunks > 1 ? pblocks : llblocks;
+        // level 0 of an overlapped build: q comes out of the (next iteration's) E-step, one share per chunk (TreeEstepArgs)
+        const bool fused0 = overlap && l == 0;
+        const int q_shares = (fused0 || chunks > 1) ? pblocks : llblocks;
         auto follow_of = [&](int e) {
             return TreeFollow{block_q, q_shares, loop_state + ((e - 1) & 1), loop_state + (e & 1), &ctl->done, ls,
                               max_iters_per_level, trace_dev, trace_cap, host_word_dev};
@@ -989,18 +787,23 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
     tree_loglik_kernel<PTS><<<dim3(llblocks, chunks), CH, 0, c->stream>>>(                                 \
         xs_cur, n, n_pad, d_prep, lb, n_level, per_chunk, ll_partial, block_q, q_ticket, q_dev, &ctl->done, \
         chunks > 1 ? no_stop : stop, flags_ptr(c), pairs_ptr(c))
-                    if (overlap && e + 1 < max_iters_per_level) {
+                    if (overlap && (e + 1 < max_iters_per_level || fused0)) {
+                        // (level 0: no log-likelihood workgroups at all -- the E-step stores the shares of q; behind the
+                        //  budget's last iteration it runs for those alone, its moments and assignment are never read)
                         const TreeLoglikArgs la{xs_cur, n, n_pad, d_prep, lb, n_level, per_chunk, ll_partial, block_q, q_ticket,
                                                 q_dev, &ctl->done, no_stop, flags_ptr(c), pairs_ptr(c), nullptr};
                         const TreeEstepArgs ea{xs_cur, n_pad, d_prep, chunk_desc, n_chunks_dev, parent_first, l, partials,
-                                               curbuf[(e + 1) & 1], &ctl->done};
-                        const unsigned g = (unsigned)(llblocks * chunks) + grid_chunks;
-                        if (ll_pts == 2) tree_ll_estep_kernel<2><<<g, CH, 0, c->stream>>>(la, llblocks, chunks, ea);
-                        else tree_ll_estep_kernel<1><<<g, CH, 0, c->stream>>>(la, llblocks, chunks, ea);
-                    } else if (ll_pts == 4 && c->tree.pdf_f32) {
+                                               curbuf[(e + 1) & 1], &ctl->done, fused0 ? block_q : nullptr};
+                        const int gx = fused0 ? 0 : llblocks, gy = fused0 ? 0 : chunks;
+                        const unsigned g = (unsigned)(gx * gy) + grid_chunks;
+                        if (ll_pts == 2 && c->tree.pdf_f32) tree_ll_estep_kernel<2, true><<<g, CH, 0, c->stream>>>(la, gx, gy, ea);
+                        else if (ll_pts == 2) tree_ll_estep_kernel<2><<<g, CH, 0, c->stream>>>(la, gx, gy, ea);
+                        else tree_ll_estep_kernel<1><<<g, CH, 0, c->stream>>>(la, gx, gy, ea);
+                    } else if (c->tree.pdf_f32 && ll_pts >= 2) {
                         const TreeLoglikArgs la{xs_cur, n, n_pad, d_prep, lb, n_level, per_chunk, ll_partial, block_q, q_ticket,
                                                 q_dev, &ctl->done, chunks > 1 ? no_stop : stop, flags_ptr(c), pairs_ptr(c), nullptr};
-                        tree_loglik_f32_kernel<<<dim3(llblocks, chunks), CH, 0, c->stream>>>(la);
+                        if (ll_pts == 4) tree_loglik_f32_kernel<4><<<dim3(llblocks, chunks), CH, 0, c->stream>>>(la);
+                        else tree_loglik_f32_kernel<2><<<dim3(llblocks, chunks), CH, 0, c->stream>>>(la);
                     } else if (ll_pts == 4)
                         tree_loglik_kernel<4, true><<<dim3(llblocks, chunks), CH, 0, c->stream>>>(
                             xs_cur, n, n_pad, d_prep, lb, n_level, per_chunk, ll_partial, block_q, q_ticket, q_dev, &ctl->done,
@@ -1008,7 +811,7 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                     else if (ll_pts == 2) LL_LAUNCH(2);
                     else LL_LAUNCH(1);
 #undef LL_LAUNCH
-                    if (chunks > 1)
+                    if (chunks > 1 && !fused0)
                         tree_loglik_finish_kernel<<<pblocks, CH, 0, c->stream>>>(ll_partial, n, n_pad, chunks, block_q,
                                                                                 q_ticket, q_dev, &ctl->done, stop);
                 }

@@ -429,7 +429,7 @@ def registration_gmmtree(source, target, maxiter=20, tol=1.0e-4, callbacks=[], *
 
 
 def registration_gmmtree_batch(pairs, maxiter=20, tol=1.0e-4, ctx: Context | None = None, tree_level=5, lambda_c=0.01,
-                               ls=20, ld=1.0e-4, sig2=0.004, init_idx=None, return_info=False):
+                               ls=20, ld=1.0e-4, sig2=0.004, init_idx=None, return_info=False, pdf_dtype=None):
     """``[registration_gmmtree(s, t, maxiter, tol, tree_level=..., ...) for s, t in pairs]`` (hgmm_gpu.py:802-807 per pair)
     with ALL pairs in the same launches: the B source clouds are one resident forest (``hgmm_tree_build_batch``: levels in
     lock-step, one stop rule per cloud), the B targets are registered against their trees together
@@ -438,12 +438,32 @@ def registration_gmmtree_batch(pairs, maxiter=20, tol=1.0e-4, ctx: Context | Non
     normal equations turn ill-conditioned leaves the batch and is finished by the serial path (stacked least squares on
     the host, like :meth:`GMMTree._registration_in_library`).  Clouds of 400 000 points or more go through the serial call.
 
+    ``pdf_dtype``: the arithmetic of the build's stop rule, as in :class:`GMMTree` -- default: each SOURCE's own type
+    (float32 scans, the type of the reference's GPU file, hgmm_gpu.py:472: float32 pdfs; anything else float64); pairs
+    of either kind in one call run as two batches.  Tables, E-step, moments and the registration are float64 either way.
+
     -> list of ``MstepResult(transformation, q)`` in the order of ``pairs`` (+ a dict with the per-pair build / registration
     iteration counts with ``return_info``)."""
     ctx = ctx or default_context()
     pairs = list(pairs)
     if not pairs:
         return ([], {}) if return_info else []
+    if pdf_dtype is None:
+        kinds = [np.dtype(np.float32) if _points(s).dtype == np.float32 else np.dtype(np.float64) for s, _ in pairs]
+        if len(set(kinds)) > 1:                                   # one batch per kind, results back in the caller's order
+            out, info = [None] * len(pairs), {"build_iters": [None] * len(pairs), "registration_iters": [None] * len(pairs),
+                                              "status": [None] * len(pairs)}
+            for kind in sorted(set(kinds), key=str):
+                sel = [k for k, v in enumerate(kinds) if v == kind]
+                r, inf = registration_gmmtree_batch([pairs[k] for k in sel], maxiter, tol, ctx, tree_level, lambda_c, ls, ld,
+                                                    sig2, init_idx, True, kind)
+                for j, k in enumerate(sel):
+                    out[k] = r[j]
+                    for key in info:
+                        info[key][k] = inf[key][j]
+            info["build_iters"] = np.asarray(info["build_iters"])
+            return (out, info) if return_info else out
+        pdf_dtype = kinds[0]
     srcs = [np.ascontiguousarray(_points(s), dtype=np.float64) for s, _ in pairs]
     tgts = [np.ascontiguousarray(_points(t), dtype=np.float64) for _, t in pairs]
     B = len(pairs)
@@ -451,7 +471,12 @@ def registration_gmmtree_batch(pairs, maxiter=20, tol=1.0e-4, ctx: Context | Non
     idx = np.asarray(init_idx) if init_idx is not None else np.random.RandomState(72).randint(T, size=T)
     init_mu = np.stack([S[idx] for S in srcs])
     ctx.set_points_batch(srcs)
-    _, build_iters, _ = ctx.tree_build_batch([len(S) for S in srcs], tree_level, ls, ld, init_mu, sig2, want_tables=False)
+    prev = getattr(ctx, "tree_dtype", np.dtype(np.float64))     # (a precision the caller set on the context survives this call)
+    ctx.tree_set_precision(pdf_dtype)
+    try:
+        _, build_iters, _ = ctx.tree_build_batch([len(S) for S in srcs], tree_level, ls, ld, init_mu, sig2, want_tables=False)
+    finally:
+        ctx.tree_set_precision(prev)
     ctx.tree_set_targets_batch(tgts)
     rot0 = np.tile(np.identity(3), (B, 1, 1))
     rot, t, iters, q, status, _ = ctx.tree_register_batch(rot0, np.zeros((B, 3)), 1.0, lambda_c, maxiter, tol)

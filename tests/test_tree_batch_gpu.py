@@ -62,6 +62,35 @@ def test_build_batch_is_bitwise_the_serial_build(ctx, bunny, L, ls, sig2):
     assert len({tuple(r) for r in iters.tolist()}) > 1                 # the clouds do stop at different iterations
 
 
+@pytest.mark.parametrize("L,ls,sig2", [(2, 20.0, 0.004), (3, 20.0, 0.004), (3, 80.0, 0.00034)])
+def test_build_batch_float32_pdfs_is_bitwise_the_serial_build_and_keeps_the_float64_trees(ctx, bunny, L, ls, sig2):
+    """hgmm_tree_set_precision(F32_PDF) on small clouds and forests (round 6): the stop rule's log-likelihood in float32.
+    (i) batch == serial bit for bit in that mode too (trees, iteration counts, q traces); (ii) against the float64 mode:
+    |dq| stays far below the stop threshold, and where a level stops after the same number of iterations the tree is
+    the float64 tree bit for bit (E-step and moments are float64 in both) -- here: on every cloud."""
+    clouds = ragged_clouds(bunny)
+    T = hgmm_tree.n_total(L)
+    idx = np.random.RandomState(72).randint(T, size=T)
+    idx = np.minimum(idx, min(len(c) for c in clouds) - 1)
+    (pi64, mu64, cov64), iters64, traces64 = batch_build(ctx, clouds, L, ls, 1e-4, idx, sig2)
+    ctx.tree_set_precision(np.float32)
+    try:
+        (pi, mu, cov), iters, traces = batch_build(ctx, clouds, L, ls, 1e-4, idx, sig2)
+        worst = 0.0
+        for b, P in enumerate(clouds):
+            s_pi, s_mu, s_cov, _, s_iters, s_q = serial_build(ctx, P, L, ls, 1e-4, idx, sig2)
+            assert list(iters[b]) == list(s_iters), (b, iters[b], s_iters)
+            assert np.array_equal(traces[b], s_q), (b, np.abs(traces[b] - s_q).max())
+            assert np.array_equal(pi[b], s_pi) and np.array_equal(mu[b], s_mu) and np.array_equal(cov[b], s_cov), b
+            assert list(iters[b]) == list(iters64[b]), (b, iters[b], iters64[b])
+            assert np.array_equal(pi[b], pi64[b]) and np.array_equal(mu[b], mu64[b]) and np.array_equal(cov[b], cov64[b]), b
+            worst = max(worst, np.abs(traces[b] - traces64[b]).max())
+    finally:
+        ctx.tree_set_precision(np.float64)
+    print("L=%d: largest |q_f32 - q_f64| over %d clouds' traces: %.3g (stop threshold %g)" % (L, len(clouds), worst, ls))
+    assert 0.0 < worst < 0.01 * ls                                     # (> 0: the float32 kernel did run)
+
+
 @pytest.mark.parametrize("name", ["hgmm_build_L2.npz", "hgmm_build_L3.npz"])
 def test_build_batch_matches_reference_golden(ctx, bunny, name):
     """The reference's own build goldens as members of a batch (beside other clouds)."""
@@ -129,6 +158,31 @@ def test_registration_batch_is_bitwise_the_serial_registration(ctx, bunny):
         assert np.array_equal(np.ravel(ref.q), np.ravel(res[k].q)), k
     print("registration iterations per pair:", info["registration_iters"], "build:", info["build_iters"].tolist())
     assert len(set(info["registration_iters"])) > 1
+
+
+def test_registration_batch_of_float32_scans_is_bitwise_the_serial_registration(ctx, bunny):
+    """float32 scans (the reference's GPU file casts to float32, hgmm_gpu.py:472): both mirrors take the stop rule's pdfs
+    in float32 for them -- the serial GMMTree and the batch still agree bit for bit; a batch that mixes float32 and
+    float64 sources runs as two batches and returns the pairs in the caller's order."""
+    from hgmm_amd.hgmm.hgmm_gpu import GMMTree, registration_gmmtree_batch
+    b32 = bunny.astype(np.float32)
+    b45 = np.load(os.path.join(GOLDEN, "bun045_xyz.npy")).astype(np.float32)
+    srcs = [b32[::4], b32[::9].astype(np.float64), b45[::5], b32[1::6]]
+    pairs = [(srcs[0], _moved(srcs[0][::2].astype(np.float64), 7.0, [0.2, 1, 0.1], [0.004, -0.002, 0.003])),
+             (srcs[1], _moved(srcs[1], 3.0, [1, 0.3, 0.0], [0.001, 0.0, -0.002])),
+             (srcs[2], _moved(b45[2::7].astype(np.float64), 10.0, [0, 0.2, 1], [-0.003, 0.004, 0.0]).astype(np.float32)),
+             (srcs[3], _moved(srcs[3].astype(np.float64), 5.0, [1, 1, 1], [0.002, 0.002, 0.002]))]
+    kw = dict(tree_level=3, lambda_c=0.01, ls=20, sig2=0.004)
+    res, info = registration_gmmtree_batch(pairs, maxiter=20, tol=1e-4, ctx=ctx, return_info=True, **kw)
+    assert ctx.tree_dtype == np.dtype(np.float64)                      # the context's own setting came back
+    for k, (s, t) in enumerate(pairs):
+        gt = GMMTree(s, ctx=ctx, **kw)
+        ref = gt.registration(t, 20, 1e-4)
+        assert int(gt.n_iter_) == info["registration_iters"][k], (k, gt.n_iter_, info["registration_iters"])
+        assert np.array_equal(ref.transformation.rot, res[k].transformation.rot), k
+        assert np.array_equal(ref.transformation.t, res[k].transformation.t), k
+        assert np.array_equal(np.ravel(ref.q), np.ravel(res[k].q)), k
+    assert info["build_iters"].shape == (4, 3)
 
 
 def test_registration_batch_matches_reference_trace(ctx):

@@ -604,10 +604,20 @@ def test_stop_rule_in_the_next_launch_equals_the_ticketed_tail(ctx, bunny, monke
     # (tree_ll_estep_kernel); HGMM_TREE_OVERLAP=0 is the one-launch-each form -- a fourth way to the same tree
     with ctx.config(tree_overlap=0):
         d = build(ctx, P, L, 80.0, 1e-4, idx, 0.00034, max_iters)
+    # round 6: in the overlapped form LEVEL 0's q comes out of the E-step workgroups (the level's nodes are the root's eight
+    # children: the E-step's own eight terms, symmetric quadratic form, one share per 256-point chunk) instead of separate
+    # log-likelihood workgroups (triangular form about a local origin, one share per 512 points) -- the same sum to the
+    # last few bits, not the same bits; the trees, assignments and iteration counts stay bitwise, and b, c, d (none of
+    # them overlapped) keep bitwise q among themselves.
     for other in (b, c, d):
         assert list(a[4]) == list(other[4])
-        for x, y in zip((a[0], a[1], a[2], a[3], a[5]), (other[0], other[1], other[2], other[3], other[5])):
+        for x, y in zip((a[0], a[1], a[2], a[3]), (other[0], other[1], other[2], other[3])):
             assert np.array_equal(x, y)
+        np.testing.assert_allclose(a[5], other[5], rtol=1e-13, atol=0)
+        n0 = int(a[4][0])
+        assert np.array_equal(a[5][n0:], other[5][n0:])                # (the levels below are the same arithmetic)
+    for other in (c, d):
+        assert np.array_equal(b[5], other[5])
     if max_iters < 1000:
         assert list(a[4]) == [max_iters] * L
 

@@ -3,7 +3,7 @@
 per batch size B the wall time of the four C calls -- upload of the sources, forest build, upload of the targets,
 batched registration -- and the pairs/s they add up to, next to the serial call on one pair.
 
-    python tools/pair_batch_probe.py [B ...]
+    python tools/pair_batch_probe.py [--f32] [B ...]      (--f32: float32 scans -> the stop rule's pdfs in float32)
 """
 import os
 import sys
@@ -19,9 +19,13 @@ from hgmm_amd.hgmm.hgmm_gpu import n_total_nodes  # noqa: E402
 
 
 def main():
-    sizes = [int(v) for v in sys.argv[1:]] or [1, 2, 4, 8, 16, 32, 64]
+    f32 = "--f32" in sys.argv
+    sizes = [int(v) for v in sys.argv[1:] if v != "--f32"] or [1, 2, 4, 8, 16, 32, 64]
     ctx = hgmm_amd.Context(0)
     source, pairs = bench.scan_pairs(0)
+    if f32:
+        source = source.astype(np.float32)
+        ctx.tree_set_precision(np.float32)                 # (the batched calls below; the serial mirror follows the source's type)
     kw = bench.PAIR_KW
     L = kw["tree_level"]
     T = n_total_nodes(L)
