@@ -64,6 +64,7 @@ __global__ __launch_bounds__(64) void forest_moments_kernel(const double* __rest
     const int q_first = fc->q_first, q_count = fc->q_count;
     const double n_total = fc->n_total;
     const int c0 = chunk_first[seg], c1 = chunk_first[seg + 1];
+    if (e >= 1 && c0 == c1 && cl != 0) return;      // (children of a parent without points: tree_moments_kernel)
     const TreeFollow follow = forest_follow(fa, b, e, block_q, q_first, q_count);
     TreeFollowLoads fl;
     if (e >= 1) fl = tree_follow_wave_load(follow);
@@ -75,6 +76,35 @@ __global__ __launch_bounds__(64) void forest_moments_kernel(const double* __rest
     for (int m = 0; m < NMOM; ++m) acc[m] = wave_sum_f64(acc[m]);
     if (threadIdx.x == 0) {
         const int64_t node = (int64_t)b * fa.T + lb + cl;
+#pragma unroll
+        for (int m = 0; m < NMOM; ++m) mom[(size_t)node * NMOM + m] = acc[m];
+        mstep_node(acc, node, n_total, ld, pi, mu, cov, prep, flags + b, /*with_complexity=*/false);
+    }
+}
+
+// The same for the eight children of one parent per wave (tree_moments_gather8: the same sums bit for bit)
+__global__ __launch_bounds__(64) void forest_moments8_kernel(const double* __restrict__ partials,
+                                                             const int* __restrict__ chunk_first, int n_level,
+                                                             double* __restrict__ mom, int64_t lb, double ld, double* pi,
+                                                             double* mu, double* cov, double* prep, int* __restrict__ flags,
+                                                             ForestArgs fa, const double* __restrict__ block_q, int e) {
+    const int seg = blockIdx.x;                      // forest-wide parent segment; its children are cg = 8 seg + k
+    const int b = (8 * seg) / n_level, cl0 = 8 * seg - b * n_level;
+    ForestCloud* fc = fa.clouds + b;
+    const int stop_flag = fc->done;
+    const int q_first = fc->q_first, q_count = fc->q_count;
+    const double n_total = fc->n_total;
+    const int c0 = chunk_first[seg], c1 = chunk_first[seg + 1];
+    if (e >= 1 && c0 == c1 && cl0 != 0) return;      // (children of a parent without points: tree_moments_kernel)
+    const TreeFollow follow = forest_follow(fa, b, e, block_q, q_first, q_count);
+    TreeFollowLoads fl;
+    if (e >= 1) fl = tree_follow_wave_load(follow);
+    else if (stop_flag) return;
+    double acc[NMOM];
+    tree_moments_gather8(partials, c0, c1, acc);
+    if (e >= 1 && tree_follow_wave_verdict(follow, fl, stop_flag, cl0 == 0)) return;
+    if ((threadIdx.x & 7) == 0) {
+        const int64_t node = (int64_t)b * fa.T + lb + cl0 + ((int)threadIdx.x >> 3);
 #pragma unroll
         for (int m = 0; m < NMOM; ++m) mom[(size_t)node * NMOM + m] = acc[m];
         mstep_node(acc, node, n_total, ld, pi, mu, cov, prep, flags + b, /*with_complexity=*/false);
@@ -422,8 +452,8 @@ extern "C" int hgmm_tree_build_batch(hgmm_ctx* c, int B, const int64_t* counts, 
                 ProfScope prof(c, HGMM_K_TREE_ESTEP);
                 forest_estep_kernel<true><<<grid_chunks, CH, 0, c->stream>>>(ea_now, fa);
             }
-            forest_moments_kernel<<<(unsigned)(B * n_level), 64, 0, c->stream>>>(partials, chunk_first, n_level, d_mom, lb, ld,
-                                                                                d_pi, d_mu, d_cov, d_prep, d_flags, fa, block_q, e);
+            forest_moments8_kernel<<<(unsigned)(B * n_level / 8), 64, 0, c->stream>>>(partials, chunk_first, n_level, d_mom, lb, ld,
+                                                                                     d_pi, d_mu, d_cov, d_prep, d_flags, fa, block_q, e);
             {
                 ProfScope prof(c, HGMM_K_TREE_LOGLIK);
                 // (level 0: behind the budget's last iteration the E-step runs for the shares of q alone)

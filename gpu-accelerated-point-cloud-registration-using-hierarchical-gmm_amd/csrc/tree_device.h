@@ -242,6 +242,35 @@ __device__ __forceinline__ void exp_tab2_load(double* __restrict__ tab_lds, cons
     for (int e = threadIdx.x; e < EXP_TAB2_N; e += blockDim.x) tab_lds[e] = tab_g[e];
 }
 
+// log(x) for a positive, finite, NORMAL x (the callers clamp at eps = 1e-15 or test for 0 first): the classic reduction
+// x = 2^k (1 + f), sqrt(1/2) < 1 + f < sqrt(2), s = f / (2 + f), log(1 + f) = f - f^2/2 + s (f^2/2 + R(s^2)) with the
+// degree-7 minimax R of fdlibm's e_log.c (error < 1 ulp) -- ~40 VALU instructions against the library call's ~95 with its
+// special cases.  Used where a logarithm is taken per point and launch (the float32-pdf log-likelihood, the level-0 q of
+// the E-step); the float64 log-likelihood kernels keep the library call and with it round 5's bits.
+constexpr double LN_TREE_EPS = -34.538776394910684;  // log(1e-15)
+__device__ __forceinline__ double log_pos_f64(double x) {
+    constexpr double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    constexpr double LG1 = 6.666666666666735130e-01, LG2 = 3.999999999940941908e-01, LG3 = 2.857142874366239149e-01,
+                     LG4 = 2.222219843214978396e-01, LG5 = 1.818357216161805012e-01, LG6 = 1.531383769920937332e-01,
+                     LG7 = 1.479819860511658591e-01;
+    int hx = __double2hiint(x);
+    const int lx = __double2loint(x);
+    int k = (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    const int i = (hx + 0x95f64) & 0x100000;
+    const double m = __hiloint2double(hx | (i ^ 0x3ff00000), lx);      // x / 2^k normalised into [sqrt(1/2), sqrt(2))
+    k += i >> 20;
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double dk = (double)k;
+    const double z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, LG6, LG4), LG2);
+    const double t2 = z * fma(w, fma(w, fma(w, LG7, LG5), LG3), LG1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+}
+
 // ------------------------------------------------------------------------------------------
 // per-node preparation
 // ------------------------------------------------------------------------------------------
@@ -555,16 +584,19 @@ __device__ __forceinline__ void tree_estep_body(const int c, const TreeEstepArgs
         double den_l = 0.0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) den_l += (prep[PREP_N * (j0 + k) + 10] == 0.0) ? 0.0 : g[k];
-        const double lq = wave_sum_f64(active ? log(fmax(den_l, TREE_EPS)) : 0.0);
+        const double lq = wave_sum_f64(active ? log_pos_f64(fmax(den_l, TREE_EPS)) : 0.0);
         if (lane_id() == 0) sh_follow[wave_in_block()] = lq;      // (read behind the barrier in front of the partials)
     }
     // gamma = g / den if den > eps else 0; arg-max = first maximum  (C:174-187)
+    // (round 6: ONE division per point -- gamma_k = g_k (1 / den), within an ulp of g_k / den; eight fp64 divisions were
+    //  ~90 of the E-step's ~550 instructions per point)
     const bool good = den > TREE_EPS;
+    const double inv_den = good ? 1.0 / den : 0.0;
     int am = 0;
     double best = -1.0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        g[k] = good ? g[k] / den : 0.0;
+        g[k] = g[k] * inv_den;
         if (g[k] > best) { best = g[k]; am = k; }
         if (g[k] < TREE_EPS || !active) g[k] = 0.0;      // accumulate() ignores gamma < eps (C:100)
     }
@@ -1172,7 +1204,14 @@ __device__ __forceinline__ void tree_loglik_f32_body(const int bx, const int by,
     hi1 = fmax(fmax(shbox[0][4], shbox[1][4]), fmax(shbox[2][4], shbox[3][4]));
     hi2 = fmax(fmax(shbox[0][5], shbox[1][5]), fmax(shbox[2][5], shbox[3][5]));
     // a term below this (natural log) cannot move any point's log(max(sum, eps)) by 2^-30
-    const double abs_floor = log(TREE_EPS) - LLF_REL_BITS * 0.6931471805599453 - log((double)n_level_nodes);
+    // (a tree level has 8^(l+1) nodes: the logarithm of a power of two needs no log)
+    const double ln_nodes = (n_level_nodes & (n_level_nodes - 1)) == 0 ? 0.6931471805599453 * (double)(31 - __clz(n_level_nodes))
+                                                                       : log((double)n_level_nodes);
+    const double abs_floor = LN_TREE_EPS - LLF_REL_BITS * 0.6931471805599453 - ln_nodes;
+    // (A RELATIVE floor -- lref - 30 ln 2 - ln n with lref = max_j [log w_j - kappa'_j D_j^2], a lower bound of every point's
+    //  sum over the workgroup's box -- was built and measured in round 6: on the scans' thin, surface-like Gaussians
+    //  kappa' D^2 over a 512-point box runs into the hundreds, lref never rises above the absolute floor, and the extra pass
+    //  over the level's nodes only cost: 8.41e7 -> 8.43e7 VALU instructions per level-2 launch of 32 bunny scans.)
     f2t X0[NH], X1[NH], X2[NH], TOT[NH];
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
@@ -1212,7 +1251,7 @@ __device__ __forceinline__ void tree_loglik_f32_body(const int bx, const int by,
                 const double g0 = fmax(fmax(lo0 - m0, m0 - hi0), 0.0), g1 = fmax(fmax(lo1 - m1, m1 - hi1), 0.0),
                              g2 = fmax(fmax(lo2 - m2, m2 - hi2), 0.0);
                 const double d2 = g0 * g0 + g1 * g1 + g2 * g2;
-                const double lw = log(wL);
+                const double lw = log_pos_f64(wL);
                 live = !(lw - kap * d2 < abs_floor);
                 if (live) {
                     const float ysk = (float)((abs_floor - lw) * LLF_LOG2E);            // skip threshold of 2^y, log2 units
@@ -1299,7 +1338,7 @@ __device__ __forceinline__ void tree_loglik_f32_body(const int bx, const int by,
             __syncthreads();
 #pragma unroll
             for (int p = 0; p < PTS; ++p) {
-                double lq = active[p] ? log(fmax(totsum[p], TREE_EPS)) : 0.0;
+                double lq = active[p] ? log_pos_f64(fmax(totsum[p], TREE_EPS)) : 0.0;
                 lq = wave_sum_f64(lq);
                 if (p > 0) __syncthreads();                // the previous share has been summed
                 if (lane_id() == 0) shq[wave_in_block()] = lq;
@@ -1328,7 +1367,7 @@ __device__ __forceinline__ void tree_loglik_f32_body(const int bx, const int by,
     }
     double lq = 0.0;
 #pragma unroll
-    for (int p = 0; p < PTS; ++p) lq += active[p] ? log(fmax((double)tot[p], TREE_EPS)) : 0.0;
+    for (int p = 0; p < PTS; ++p) lq += active[p] ? log_pos_f64(fmax((double)tot[p], TREE_EPS)) : 0.0;
     lq = wave_sum_f64(lq);
     __syncthreads();
     if (lane_id() == 0) shq[wave_in_block()] = lq;
@@ -1399,6 +1438,8 @@ __device__ __forceinline__ void tree_reg_estep_body(const int64_t i, bool alive,
                                                     unsigned long long* __restrict__ momq,
                                                     unsigned long long* __restrict__ tab /* LDS [REG_LDS_NODES * NMQ] */) {
     const int lds_nodes = (int)(level_first(L < 3 ? L : 3));
+    __shared__ double exp_tab[EXP_TAB_N];                  // the build's exponential (exp_nonpos4): 17 instructions per value
+    exp_tab_load(exp_tab);
     for (int e = threadIdx.x; e < lds_nodes * NMQ; e += CH) tab[e] = 0ull;
     __syncthreads();
     double x0 = 0.0, x1 = 0.0, x2 = 0.0;
@@ -1416,13 +1457,24 @@ __device__ __forceinline__ void tree_reg_estep_body(const int64_t i, bool alive,
         double g[8];
         double den = 0.0;
         if (alive) {
+            // (round 6: the build E-step's arithmetic -- two interleaved table exponentials of four instead of eight
+            //  library calls -- and ONE division: only the largest responsibility is used, and g_k / den is monotone in g_k)
+            double yv[8], wE[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const double* pr = prep + PREP_N * (j0 + k);
                 const double d0 = x0 - pr[6], d1 = x1 - pr[7], d2 = x2 - pr[8];
-                const double q = sym3_quad(pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], d0, d1, d2);
-                const double wE = pr[9];
-                g[k] = (wE == 0.0) ? 0.0 : wE * exp(-0.5 * q);
+                yv[k] = -0.5 * sym3_quad(pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], d0, d1, d2);
+                wE[k] = pr[9];
+            }
+            const double ya[4] = {yv[0], yv[1], yv[2], yv[3]}, yb[4] = {yv[4], yv[5], yv[6], yv[7]};
+            double ea[4], eb[4];
+            exp_nonpos4(ya, ea, exp_tab);
+            exp_nonpos4(yb, eb, exp_tab);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const double ev = k < 4 ? ea[k & 3] : eb[k & 3];
+                g[k] = (wE[k] == 0.0 || yv[k] < -745.0) ? 0.0 : wE[k] * ev;     // (below the range the library exp is exactly 0)
                 den += g[k];
             }
         }
@@ -1432,12 +1484,12 @@ __device__ __forceinline__ void tree_reg_estep_body(const int64_t i, bool alive,
         if (alive) {
             const bool good = den > TREE_EPS;
             int am = 0;
-            double best = -1.0;
+            double gbest = -1.0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const double gk = good ? g[k] / den : 0.0;
-                if (gk > best) { best = gk; am = k; }
-            }
+            for (int k = 0; k < 8; ++k)
+                if (g[k] > gbest) { gbest = g[k]; am = k; }                     // first maximum (C:187 argmax)
+            if (!good) am = 0;                                                  // all responsibilities are 0: the first child
+            const double best = good ? gbest / den : 0.0;
             s = j0 + am;
             search = s;
             if (prep[PREP_N * s + 11] <= lambda_c) {       // complexity(cov_s) <= lambda_c: stop
@@ -1694,6 +1746,49 @@ __device__ __forceinline__ void tree_moments_gather(const double* __restrict__ p
 #pragma unroll
         for (int m = 0; m < NMOM; ++m) acc[m] += src[m];
     }
+}
+
+// The same sums, bit for bit, for the EIGHT children of one parent in one wave (round 6: small clouds and forests, where
+// a parent has a handful of chunks and a wave per child spent ~700 instructions -- ten 64-lane reductions, the stop rule,
+// the M-step in one lane -- on sixteen numbers): lane 8 k + j works for child k.  tree_moments_kernel's wave adds, per
+// moment, a_t = sum_i partial[c0 + t + 64 i] in lane t and then reduces the 64 lanes by the butterfly of wave_sum_f64:
+// rows of eight lanes first (R_m, m = t / 8: quad xor 1, quad xor 2, half-row mirror), then
+// ((R_7 + R_6) + (R_5 + R_4)) + ((R_3 + R_2) + (R_1 + R_0)).  Here the eight lanes of a child take the eight rows one
+// after the other -- the same three steps inside the row, the same tree above it -- and a row no chunk falls into is the
+// +0.0 it would have been.  Every lane of the child's group ends up with the child's ten totals.
+__device__ __forceinline__ void tree_moments_gather8(const double* __restrict__ partials, int c0, int c1,
+                                                     double (&tot)[NMOM]) {
+    const int k = (int)threadIdx.x >> 3, j = (int)threadIdx.x & 7;
+    auto row = [&](int m, double (&r)[NMOM]) {
+#pragma unroll
+        for (int q = 0; q < NMOM; ++q) r[q] = 0.0;
+        if (c0 + 8 * m >= c1) return;                     // (wave-uniform: all of a wave's lanes work for the same parent)
+        for (int c = c0 + 8 * m + j; c < c1; c += 64) {
+            const double* src = partials + (size_t)c * (8 * NMOM) + k * NMOM;
+#pragma unroll
+            for (int q = 0; q < NMOM; ++q) r[q] += src[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NMOM; ++q) {
+            r[q] += dpp_f64<DPP_QUAD_XOR1>(r[q]);
+            r[q] += dpp_f64<DPP_QUAD_XOR2>(r[q]);
+            r[q] += dpp_f64<DPP_ROW_HALF_MIRROR>(r[q]);
+        }
+    };
+    double a[NMOM], b[NMOM], c[NMOM];
+    row(0, a); row(1, b);
+#pragma unroll
+    for (int q = 0; q < NMOM; ++q) a[q] += b[q];          // S0 = R0 + R1
+    row(2, b); row(3, c);
+#pragma unroll
+    for (int q = 0; q < NMOM; ++q) a[q] = (b[q] + c[q]) + a[q];   // S1 + S0
+    row(4, b); row(5, c);
+#pragma unroll
+    for (int q = 0; q < NMOM; ++q) b[q] += c[q];          // S2
+    double d[NMOM];
+    row(6, c); row(7, d);
+#pragma unroll
+    for (int q = 0; q < NMOM; ++q) tot[q] = ((c[q] + d[q]) + b[q]) + a[q];   // (S3 + S2) + (S1 + S0)
 }
 
 // How hgmm_tree_build splits a level's nodes over gridDim.y of the log-likelihood launch (small clouds: not enough point

@@ -152,6 +152,9 @@ __global__ __launch_bounds__(64) void tree_moments_kernel(const double* __restri
     const int c0 = chunk_first[p], c1 = chunk_first[p + 1];
     // (tree_ll_estep_kernel's launch order: this launch is the one that follows iteration e - 1's log-likelihood; if the
     //  level turns out to have stopped, the partial moments read here are the speculative E-step's and go nowhere)
+    // (a parent without points has no chunks, at any iteration of the level: its children's tables were written by the
+    //  level's first iteration -- pi = 0, mu = 0, cov = I -- and would be rewritten unchanged; wave 0 speaks for the loop)
+    if (follow.q_blocks && c0 == c1 && blockIdx.x != 0) return;
     TreeFollowLoads fl;
     if (follow.q_blocks) fl = tree_follow_wave_load(follow);
     else if (stop_flag) return;
@@ -164,6 +167,29 @@ __global__ __launch_bounds__(64) void tree_moments_kernel(const double* __restri
 #pragma unroll
         for (int m = 0; m < NMOM; ++m) mom[(size_t)cl * NMOM + m] = acc[m];
         if (fuse) mstep_node(acc, lb + cl, n_points_total, ld, pi, mu, cov, prep, flags, /*with_complexity=*/false);
+    }
+}
+// the eight children of one parent per wave (tree_moments_gather8: the same sums bit for bit); overlapped builds
+__global__ __launch_bounds__(64) void tree_moments8_kernel(const double* __restrict__ partials,
+                                                           const int* __restrict__ chunk_first, double* __restrict__ mom,
+                                                           int64_t lb, double n_points_total, double ld, double* pi, double* mu,
+                                                           double* cov, double* prep, int* __restrict__ flags,
+                                                           const int* __restrict__ done, TreeFollow follow) {
+    const int p = blockIdx.x;             // level-local parent; its children are cl = 8 p + k
+    const int stop_flag = done ? *done : 0;
+    const int c0 = chunk_first[p], c1 = chunk_first[p + 1];
+    if (follow.q_blocks && c0 == c1 && p != 0) return;
+    TreeFollowLoads fl;
+    if (follow.q_blocks) fl = tree_follow_wave_load(follow);
+    else if (stop_flag) return;
+    double acc[NMOM];
+    tree_moments_gather8(partials, c0, c1, acc);
+    if (follow.q_blocks && tree_follow_wave_verdict(follow, fl, stop_flag, p == 0)) return;
+    if ((threadIdx.x & 7) == 0) {
+        const int cl = 8 * p + ((int)threadIdx.x >> 3);
+#pragma unroll
+        for (int m = 0; m < NMOM; ++m) mom[(size_t)cl * NMOM + m] = acc[m];
+        mstep_node(acc, lb + cl, n_points_total, ld, pi, mu, cov, prep, flags, /*with_complexity=*/false);
     }
 }
 __global__ void tree_mstep_kernel(const double* __restrict__ mom, int64_t lb, int n_level_nodes,
@@ -227,6 +253,8 @@ __global__ __launch_bounds__(CH) void tree_ll_estep_kernel(TreeLoglikArgs la, in
 }
 
 
+// FASTLOG: the float32-pdf mode's logarithm (log_pos_f64, as in tree_loglik_f32_body's own finish for forests)
+template <bool FASTLOG = false>
 __global__ __launch_bounds__(CH) void tree_loglik_finish_kernel(const double* __restrict__ partial, int64_t n,
                                                                 int64_t n_pad, int n_chunks,
                                                                 double* __restrict__ block_q,
@@ -240,7 +268,7 @@ __global__ __launch_bounds__(CH) void tree_loglik_finish_kernel(const double* __
     if (i < n) {
         double tot = 0.0;
         for (int c = 0; c < n_chunks; ++c) tot += partial[(size_t)c * n_pad + i];
-        lq = log(fmax(tot, TREE_EPS));
+        lq = FASTLOG ? log_pos_f64(fmax(tot, TREE_EPS)) : log(fmax(tot, TREE_EPS));
     }
     lq = wave_sum_f64(lq);
     if (lane_id() == 0) shq[wave_in_block()] = lq;
@@ -763,10 +791,14 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                 }
                 // single GPU: reduction, M-step and preparation of a node in one launch; with a
                 // communicator the all-reduce of the moments sits between reduction and M-step
-                tree_moments_kernel<<<n_level, 64, 0, c->stream>>>(partials, chunk_first, n_level, d_mom + NMOM * lb,
-                                                                   c->comm_on() ? 0 : 1, lb, n_total, ld, d_pi, d_mu, d_cov,
-                                                                   d_prep, flags_ptr(c), &ctl->done,
-                                                                   (overlap && e >= 1) ? follow_of(e) : no_follow);
+                if (overlap)                                                   // (small clouds: a wave per parent, same bits)
+                    tree_moments8_kernel<<<n_level / 8, 64, 0, c->stream>>>(partials, chunk_first, d_mom + NMOM * lb, lb, n_total,
+                                                                            ld, d_pi, d_mu, d_cov, d_prep, flags_ptr(c), &ctl->done,
+                                                                            e >= 1 ? follow_of(e) : no_follow);
+                else
+                    tree_moments_kernel<<<n_level, 64, 0, c->stream>>>(partials, chunk_first, n_level, d_mom + NMOM * lb,
+                                                                       c->comm_on() ? 0 : 1, lb, n_total, ld, d_pi, d_mu, d_cov,
+                                                                       d_prep, flags_ptr(c), &ctl->done, no_follow);
                 if (c->comm_on()) {
                     rc = allreduce_f64_oop(c, d_mom + NMOM * lb, mom_g, (size_t)NMOM * n_level);
                     if (rc != HGMM_OK) return rc;
@@ -811,9 +843,14 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                     else if (ll_pts == 2) LL_LAUNCH(2);
                     else LL_LAUNCH(1);
 #undef LL_LAUNCH
-                    if (chunks > 1 && !fused0)
-                        tree_loglik_finish_kernel<<<pblocks, CH, 0, c->stream>>>(ll_partial, n, n_pad, chunks, block_q,
-                                                                                q_ticket, q_dev, &ctl->done, stop);
+                    if (chunks > 1 && !fused0) {
+                        if (c->tree.pdf_f32 && ll_pts >= 2)
+                            tree_loglik_finish_kernel<true><<<pblocks, CH, 0, c->stream>>>(ll_partial, n, n_pad, chunks, block_q,
+                                                                                          q_ticket, q_dev, &ctl->done, stop);
+                        else
+                            tree_loglik_finish_kernel<false><<<pblocks, CH, 0, c->stream>>>(ll_partial, n, n_pad, chunks, block_q,
+                                                                                           q_ticket, q_dev, &ctl->done, stop);
+                    }
                 }
                 if (c->comm_on()) {
                     rc = allreduce_f64_oop(c, q_dev, q_g, 1);
