@@ -789,9 +789,9 @@ def published_charts_leg(ctx):
 
 def replica_pairs_leg(ctx):
     """The replica mode (`bench.py --mode pairs`, hgmm_amd.replicas) as a side leg of the default line: independent scan
-    pairs, four contexts on this GPU, no communicator -- run as a process of its own (it creates its own contexts and
-    threads), one second of timed blocks."""
-    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "pairs", "--steps", "25", "--warmup", "3", "--min-time", "1.0",
+    pairs, eight contexts x 32 pairs per launch set on this GPU (the mode's defaults), no communicator -- run as a process
+    of its own (it creates its own contexts and threads)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "pairs", "--steps", "6", "--warmup", "2", "--min-time", "1.5",
            "--no-cpu-baseline"]
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
@@ -803,7 +803,8 @@ def replica_pairs_leg(ctx):
         return {"error": "rc %d: %s" % (r.returncode, r.stderr[-400:])}
     d = json.loads(lines[-1])
     return {"workload": d["config"]["workload"], "pairs_per_s": d["value"], "contexts_per_gpu": d["config"]["contexts_per_gpu"],
-            "batch": d["config"].get("batch"), "ms_per_step": d["ms_per_step"], "registration_iterations_per_pair": d["registration_iterations_per_pair"],
+            "batch": d["config"].get("batch"), "scan_dtype": d.get("scan_dtype"), "other_scan_dtype": d.get("other_scan_dtype"),
+            "ms_per_step": d["ms_per_step"], "registration_iterations_per_pair": d["registration_iterations_per_pair"],
             "accuracy": d["accuracy"], "kernels_ms_per_pair": d.get("kernels_ms_per_pair"), "blocks": d["timing"]["blocks"]}
 
 
@@ -1603,9 +1604,9 @@ def main():
                     help="fit (default): the headline joint EM fit, frames sharded over the GPUs with an all-reduce of the "
                          "sufficient statistics; pairs: independent scan pairs, one registration_gmmtree per GPU and step, "
                          "no communicator")
-    ap.add_argument("--contexts-per-gpu", type=int, default=4,
-                    help="--mode pairs: engine contexts (and threads) per GPU, each registering its own pairs (default 4)")
-    ap.add_argument("--batch", type=int, default=16,
+    ap.add_argument("--contexts-per-gpu", type=int, default=8,
+                    help="--mode pairs: engine contexts (and threads) per GPU, each registering its own pairs (default 8)")
+    ap.add_argument("--batch", type=int, default=32,
                     help="--mode pairs: pairs every context takes through the SAME launches per step "
                          "(registration_gmmtree_batch; 1 = one registration_gmmtree call per pair, round 5's path)")
     ap.add_argument("--scan-dtype", default="float32", choices=["float32", "float64"],

@@ -638,7 +638,7 @@ const ConfigSpec CONFIG_SPECS[CFG_COUNT] = {
     {"predict_single_row", 0, 0, 1},     {"tree_no_chol", 0, 0, 1},         {"tree_rel", 0, 0, 1},
     {"tree_ahead", 2, 0, 64},            {"tree_tickets", 0, 0, 1},         {"tree_overlap", 1, 0, 1},
     {"fullcov_two_pass", 0, 0, 1},       {"kmpp_two_launches", 0, 0, 1},    {"kmeans_acc_regs", 0, 0, 1},
-    {"ipc_timeout_s", 20, 1, 600},
+    {"ipc_timeout_s", 20, 1, 600},       {"reg_device_solve", 0, 0, 1},
 };
 static int config_find(const char* name) {
     if (!name) return -1;

@@ -91,6 +91,7 @@ enum ConfigKey {
     CFG_KMPP_TWO_LAUNCHES,     // k-means++ step and tail as two launches (the path of > 16.7 M points)
     CFG_KMEANS_ACC_REGS,       // Lloyd sums in registers instead of LDS tables (the path of k > 1024)
     CFG_IPC_TIMEOUT_S,         // seconds the peer exchange waits for a peer's flag before it reports the collective as failed
+    CFG_REG_DEVICE_SOLVE,      // registration loop without the host: 6 x 6 solve, twist, stop rule and the next encoding on the device
     CFG_COUNT
 };
 struct ConfigSpec { const char* name; int dflt, lo, hi; };

@@ -237,13 +237,6 @@ __global__ void forest_target_kernel(const double* __restrict__ aos, int64_t n, 
     if (lane_id() == 0 && bits != 0ull) atomicMax(r2max_bits, bits);
 }
 
-struct ForestRegPair {
-    Rigid tf;
-    double inv_d, fix_scale, d_ext, inv_scale;
-    int tg_first, tg_count;
-    int active, pad;
-};
-
 template <int NMQ>
 __global__ __launch_bounds__(CH) void forest_reg_estep_kernel(const double* __restrict__ tg, int64_t tg_pad,
                                                               const ForestRegPair* __restrict__ tab,
@@ -273,6 +266,26 @@ __global__ __launch_bounds__(256) void forest_reg_normal_kernel(unsigned long lo
                          host_out + 28 * b, host_seq + b, seq);
 }
 
+// reg_device_solve: the normal equations of pair b, then -- one thread -- the host's part of the iteration (reg_device_step)
+// and the pair's progress word for the host: (left the loop << 32) | iterations done
+__global__ __launch_bounds__(256) void forest_reg_solve_kernel(unsigned long long* __restrict__ momq, ForestRegPair* tab,
+                                                               const double* __restrict__ prep, int T,
+                                                               double* __restrict__ out, double tol, int max_iter,
+                                                               double* __restrict__ trace, unsigned long long* host_words) {
+    const int b = blockIdx.x;
+    ForestRegPair* pr = tab + b;
+    if (!pr->active) return;
+    tree_reg_normal_body(momq + (size_t)4 * T * b, pr->d_ext, pr->inv_scale, prep + (size_t)PREP_N * T * b, T, out + 28 * b,
+                         nullptr, nullptr, 0ull);
+    __syncthreads();                                         // (the 28 sums are in `out`, written by this workgroup)
+    if (threadIdx.x == 0) {
+        const int it = pr->it;
+        reg_device_step(out + 28 * b, pr, tol, max_iter, trace ? trace + ((size_t)b * max_iter + it) * 13 : nullptr);
+        __hip_atomic_store(host_words + b, ((unsigned long long)(pr->active ? 0 : 1) << 32) | (unsigned long long)(unsigned)pr->it,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -294,6 +307,117 @@ static int forest_host(hgmm_ctx* c, int B, unsigned long long** words, double** 
 }
 
 static int64_t forest_T(int L) { return level_first(L); }
+
+// The registration loop of B pairs with the device on its own (reg_device_solve): every iteration is two launches -- the
+// E-step of all pairs, then per pair the normal equations + reg_device_step -- enqueued by a host that only follows the
+// pairs' progress words and keeps a few iterations ahead of the slowest running pair; launches behind a pair's stop
+// return at their first load.  tab_dev: B entries; out_dev: 28 B doubles.  The caller's arrays are filled at the end.
+int forest_register_on_device(::hgmm_ctx* c, int B, const double* tg, int64_t tg_pad, const int64_t* tg_first,
+                              const int64_t* tg_counts, const double* tg_rmax, const double* mu_rmax, const double* prep, int T,
+                              int L, unsigned long long* momq, double* rot, double* t, double scale, double lambda_c,
+                              int max_iter, double tol, double* q_prev_inout, int32_t* iters_out, int32_t* status_out,
+                              double* trace) {
+    for (int b = 0; b < B; ++b) { iters_out[b] = 0; status_out[b] = 0; }
+    if (max_iter < 1) return HGMM_OK;
+    HGMM_TRY(ensure(c, c->fr_reg, (sizeof(ForestRegPair) + 28 * sizeof(double) + sizeof(unsigned long long)) * (size_t)B + 512));
+    const size_t trace_bytes = trace ? sizeof(double) * 13 * (size_t)max_iter * B : 0;
+    if (trace) HGMM_TRY(ensure(c, c->fr_trace, trace_bytes));
+    ForestRegPair* d_tab = c->fr_reg.as<ForestRegPair>();
+    double* d_out = reinterpret_cast<double*>(d_tab + B);
+    double* d_trace = trace ? c->fr_trace.as<double>() : nullptr;
+    unsigned long long* words = nullptr;
+    double* unused28 = nullptr;
+    HGMM_TRY(forest_host(c, B, &words, &unused28));
+    void* d_words = nullptr;
+    HGMM_HIP(c, hipHostGetDevicePointer(&d_words, words, 0));
+    std::vector<ForestRegPair> tab(B);
+    int64_t longest = 0;
+    for (int b = 0; b < B; ++b) {
+        ForestRegPair& pr = tab[b];
+        std::memset(&pr, 0, sizeof pr);
+        pr.active = 1;
+        pr.tg_first = (int)tg_first[b];
+        pr.tg_count = (int)tg_counts[b];
+        for (int i = 0; i < 9; ++i) pr.tf.r[i] = rot[9 * b + i];
+        for (int i = 0; i < 3; ++i) pr.tf.t[i] = t[3 * b + i];
+        pr.tf.s = scale;
+        double D = 1.0;
+        int Fb = 0;
+        reg_encoding(reg_extent(pr.tf, tg_rmax[b], mu_rmax[b]), (double)tg_counts[b], &D, &Fb);
+        pr.inv_d = 1.0 / D;
+        pr.fix_scale = std::ldexp(1.0, Fb);
+        pr.d_ext = D;
+        pr.inv_scale = std::ldexp(1.0, -Fb);
+        pr.tg_rmax = tg_rmax[b];
+        pr.mu_rmax = mu_rmax[b];
+        pr.has_q = (q_prev_inout[b] == q_prev_inout[b]) ? 1 : 0;              // (NaN: no previous q)
+        pr.q_prev = pr.has_q ? q_prev_inout[b] : 0.0;
+        longest = std::max(longest, tg_counts[b]);
+        __atomic_store_n(words + b, 0ull, __ATOMIC_RELAXED);
+    }
+    {
+        void* st = nullptr;
+        HGMM_TRY(stage_reserve(c, sizeof(ForestRegPair) * B, &st));
+        std::memcpy(st, tab.data(), sizeof(ForestRegPair) * B);
+        HGMM_HIP(c, hipMemcpyAsync(d_tab, st, sizeof(ForestRegPair) * B, hipMemcpyHostToDevice, c->stream));
+    }
+    const int ahead = 3;
+    int enq = 0;
+    unsigned spins = 0;
+    while (true) {
+        bool all_done = true;
+        int it_min = 0x7fffffff;
+        unsigned long long sig = 0;
+        for (int b = 0; b < B; ++b) {
+            const unsigned long long w = __atomic_load_n(words + b, __ATOMIC_RELAXED);
+            sig += w;
+            if (w >> 32) continue;
+            all_done = false;
+            it_min = std::min(it_min, (int)(w & 0xffffffffull));
+        }
+        if (all_done) break;
+        if (enq < max_iter && enq - it_min < ahead) {
+            {
+                ProfScope prof(c, HGMM_K_TREE_REG);
+                forest_reg_estep_kernel<4><<<dim3(nblk(longest, CH), B), CH, 0, c->stream>>>(tg, tg_pad, d_tab, prep, T, L, lambda_c, momq);
+            }
+            forest_reg_solve_kernel<<<B, 256, 0, c->stream>>>(momq, d_tab, prep, T, d_out, tol, max_iter, d_trace,
+                                                             static_cast<unsigned long long*>(d_words));
+            HGMM_HIP(c, hipGetLastError());
+            ++enq;
+            spins = 0;
+            continue;
+        }
+        __builtin_ia32_pause();
+        if ((++spins & 0x3fff) == 0) {
+            const hipError_t qe = hipStreamQuery(c->stream);
+            if (qe != hipSuccess && qe != hipErrorNotReady)
+                return fail(c, HGMM_ERR_HIP, "registration (device loop): device error: %s", hipGetErrorString(qe));
+            if (qe == hipSuccess) {
+                unsigned long long sig2 = 0;
+                for (int b = 0; b < B; ++b) sig2 += __atomic_load_n(words + b, __ATOMIC_ACQUIRE);
+                if (sig2 == sig) return fail(c, HGMM_ERR_STATE, "registration (device loop): no progress (%d iterations enqueued)", enq);
+            }
+        }
+    }
+    std::vector<double> trace_host(trace ? (size_t)13 * max_iter * B : 0);
+    {
+        StagedDownloads dl(c);
+        dl.add(tab.data(), d_tab, sizeof(ForestRegPair) * B);
+        if (trace) dl.add(trace_host.data(), d_trace, trace_bytes);
+        HGMM_HIP(c, dl.finish());
+    }
+    for (int b = 0; b < B; ++b) {
+        const ForestRegPair& pr = tab[b];
+        for (int i = 0; i < 9; ++i) rot[9 * b + i] = pr.tf.r[i];
+        for (int i = 0; i < 3; ++i) t[3 * b + i] = pr.tf.t[i];
+        iters_out[b] = pr.it;
+        status_out[b] = pr.status;
+        if (pr.has_q) q_prev_inout[b] = pr.q_prev;
+        if (trace) std::memcpy(trace + (size_t)13 * max_iter * b, trace_host.data() + (size_t)13 * max_iter * b, sizeof(double) * 13 * (size_t)pr.it);
+    }
+    return HGMM_OK;
+}
 
 }  // namespace hgmm
 
@@ -461,7 +585,11 @@ extern "C" int hgmm_tree_build_batch(hgmm_ctx* c, int B, const int64_t* counts, 
                 const TreeEstepArgs ea_next{xs_cur, n_pad, d_prep, chunk_desc, n_chunks_dev, parent_first, l, partials,
                                             ((e + 1) & 1) ? cur1 : cur0, nullptr, l == 0 ? block_q : nullptr};
                 const unsigned g = (unsigned)(B * ll_stride) + (with_estep ? grid_chunks : 0u);
-                if (c->tree.pdf_f32)
+                if (l == 0)
+                    // (level 0 is E-step workgroups only: the plain E-step kernel -- 72 registers instead of the fused kernel's
+                    //  92-96, one more wave per SIMD for a launch that is a chain of trips to memory)
+                    forest_estep_kernel<true><<<grid_chunks, CH, 0, c->stream>>>(ea_next, fa);
+                else if (c->tree.pdf_f32)
                     forest_ll_estep_kernel<true><<<g, CH, 0, c->stream>>>(xs_cur, n_pad, d_prep, lb, n_level, block_q, d_flags,
                                                                          fa, ll_stride, ea_next, with_estep);
                 else
@@ -656,6 +784,11 @@ extern "C" int hgmm_tree_register_batch(hgmm_ctx* c, int B, double* rot, double*
         HGMM_HIP(c, hipMemsetAsync(c->fr_momq.p, 0, c->fr_momq.cap, c->stream));
         F.momq_clean = true;
     }
+    if (c->cfg[CFG_REG_DEVICE_SOLVE])
+        return forest_register_on_device(c, B, c->fr_tg.as<double>(), F.tg_pad, F.tg_first.data(), F.tg_counts.data(),
+                                         F.tg_rmax.data(), F.mu_rmax.data(), c->fr_prep.as<double>(), T, L,
+                                         c->fr_momq.as<unsigned long long>(), rot, t, scale, lambda_c, max_iter, tol,
+                                         q_prev_inout, iters_out, status_out, trace);
     unsigned long long* words = nullptr;
     double* h_out = nullptr;
     HGMM_TRY(forest_host(c, B, &words, &h_out));

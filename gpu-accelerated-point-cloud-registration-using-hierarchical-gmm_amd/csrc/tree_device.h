@@ -1816,23 +1816,143 @@ inline double tree_mu_rmax(const double* mu, int64_t T) {
     return std::sqrt(m2);
 }
 // extent of the moved target about any node mean: |s R x + t - mu| <= |s| (Frobenius bound on R) max|x| + |t| + max|mu|
-inline double reg_extent(const Rigid& tf, double tgt_rmax, double mu_rmax) {
+__host__ __device__ inline double reg_extent(const Rigid& tf, double tgt_rmax, double mu_rmax) {
     double rn = 0.0, tn = 0.0;
     for (int i = 0; i < 9; ++i) rn += tf.r[i] * tf.r[i];
     for (int i = 0; i < 3; ++i) tn += tf.t[i] * tf.t[i];
-    return std::fabs(tf.s) * std::sqrt(rn) * tgt_rmax + std::sqrt(tn) + mu_rmax;
+    return fabs(tf.s) * sqrt(rn) * tgt_rmax + sqrt(tn) + mu_rmax;
 }
 // encoding of the registration E-step's fixed-point sums: D = the extent rounded up to a power of two, F fractional bits
 // such that n_all terms cannot overflow 62 bits
-inline void reg_encoding(double ext, double n_all, double* D_out, int* F_out) {
-    if (!(ext > 0.0) || !std::isfinite(ext)) ext = 1.0;
+__host__ __device__ inline void reg_encoding(double ext, double n_all, double* D_out, int* F_out) {
+    if (!(ext > 0.0) || !(ext < 1.0e300)) ext = 1.0;              // (not positive, NaN or infinite)
     int e2 = 0;
-    (void)std::frexp(ext, &e2);                                   // ext < 2^e2
-    *D_out = std::ldexp(1.0, e2);
+    (void)frexp(ext, &e2);                                        // ext < 2^e2
+    *D_out = ldexp(1.0, e2);
     int nbits = 1;
-    while (std::ldexp(1.0, nbits) <= n_all) ++nbits;
+    while (ldexp(1.0, nbits) <= n_all) ++nbits;
     *F_out = 62 - nbits;
 }
+
+// One pair of a batched registration (tree_batch.hip).  The first block is what the E-step and the normal-equation kernels
+// read; the second is the loop's state when the device runs it alone (reg_device_solve, reg_device_step below).
+struct ForestRegPair {
+    Rigid tf;
+    double inv_d, fix_scale, d_ext, inv_scale;
+    int tg_first, tg_count;
+    int active, pad;
+    double q_prev, tg_rmax, mu_rmax;     // q of the previous iteration (valid with has_q), extent bounds of the encoding
+    int has_q, it, status, pad2;         // iterations done; 0: running / budget used up, 1: |dq| < tol, 2: ill-conditioned
+};
+
+// The host side of a registration iteration (reg_host_step) done by ONE device thread (per-context option
+// reg_device_solve, off by default: north_star keeps the rigid solve on the host, and the host path is the parity
+// reference): o[28] = the normal equations; solves the 6 x 6 system, composes the twist, applies the stop rule and
+// prepares the fixed-point encoding of the next E-step, all in the pair's table entry -- the next launch reads (R, t)
+// from device memory and the host only follows a progress word.  Differences to the host path, both inside the 1e-8 the
+// per-iteration trace is held to: Cholesky instead of elimination with pivoting, the device's sin / cos, fused
+// multiply-adds; the conditioning test is on the Cholesky pivots (smallest pivot <= 1e-11 largest diagonal entry --
+// implied by the host's eigenvalue test failing, not equivalent to it): such a pair stops with status 2 and the caller
+// finishes it on the host path, as in the host loop.
+__device__ inline void reg_device_step(const double* __restrict__ o, ForestRegPair* pr, double tol, int max_iter,
+                                       double* __restrict__ trace_row) {
+    double A[6][6], b[6], x[6], y[6];
+    bool ok = true;
+    double dmax = 0.0;
+    for (int i = 0, k = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j, ++k) { A[i][j] = A[j][i] = o[k]; ok = ok && (fabs(o[k]) < 1.0e300); }
+    for (int i = 0; i < 6; ++i) { b[i] = o[21 + i]; ok = ok && (fabs(b[i]) < 1.0e300); dmax = fmax(dmax, A[i][i]); }
+    double pmin = 1.0e300;
+    for (int j = 0; j < 6 && ok; ++j) {                       // A = L L^T, L in the lower triangle of A
+        double s = A[j][j];
+        for (int k = 0; k < j; ++k) s -= A[j][k] * A[j][k];
+        pmin = fmin(pmin, s);
+        if (!(s > 0.0)) { ok = false; break; }
+        const double d = sqrt(s);
+        A[j][j] = d;
+        for (int i = j + 1; i < 6; ++i) {
+            double v = A[i][j];
+            for (int k = 0; k < j; ++k) v -= A[i][k] * A[j][k];
+            A[i][j] = v / d;
+        }
+    }
+    if (!ok || !(dmax > 0.0) || pmin <= 1.0e-11 * dmax) {
+        pr->status = 2;
+        pr->active = 0;
+        return;
+    }
+    for (int i = 0; i < 6; ++i) {
+        double v = b[i];
+        for (int k = 0; k < i; ++k) v -= A[i][k] * y[k];
+        y[i] = v / A[i][i];
+    }
+    for (int i = 5; i >= 0; --i) {
+        double v = y[i];
+        for (int k = i + 1; k < 6; ++k) v -= A[k][i] * x[k];
+        x[i] = v / A[i][i];
+    }
+    double xb = 0.0;
+    for (int i = 0; i < 6; ++i) xb += x[i] * b[i];
+    const double q = fmax(o[27] - xb, 0.0);
+    // (rot, t) <- (dR rot, dR t + v), dR = exp([omega]_x)   (twist_compose)
+    Rigid tf = pr->tf;
+    {
+        const double w0 = x[0], w1 = x[1], w2 = x[2];
+        const double angle = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+        double d[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        if (angle != 0.0) {
+            const double a = w0 / angle, bb = w1 / angle, c = w2 / angle;
+            const double k[3][3] = {{0.0, -c, bb}, {c, 0.0, -a}, {-bb, a, 0.0}};
+            const double sn = sin(angle), oc = 1.0 - cos(angle);
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    double kk = 0.0;
+                    for (int l = 0; l < 3; ++l) kk += k[i][l] * k[l][j];
+                    d[i][j] += sn * k[i][j] + oc * kk;
+                }
+        }
+        double r2[9], t2[3];
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) {
+                double v = 0.0;
+                for (int l = 0; l < 3; ++l) v += d[i][l] * tf.r[3 * l + j];
+                r2[3 * i + j] = v;
+            }
+            double v = 0.0;
+            for (int l = 0; l < 3; ++l) v += d[i][l] * tf.t[l];
+            t2[i] = v + x[3 + i];
+        }
+        for (int i = 0; i < 9; ++i) tf.r[i] = r2[i];
+        for (int i = 0; i < 3; ++i) tf.t[i] = t2[i];
+    }
+    pr->tf = tf;
+    const int it = pr->it;
+    if (trace_row) {
+        for (int i = 0; i < 9; ++i) trace_row[i] = tf.r[i];
+        for (int i = 0; i < 3; ++i) trace_row[9 + i] = tf.t[i];
+        trace_row[12] = q;
+    }
+    const bool stop = pr->has_q && fabs(q - pr->q_prev) < tol;
+    pr->q_prev = q;
+    pr->has_q = 1;
+    pr->it = it + 1;
+    if (stop) pr->status = 1;
+    if (stop || it + 1 >= max_iter) { pr->active = 0; return; }
+    double D = 1.0;
+    int F = 0;
+    reg_encoding(reg_extent(tf, pr->tg_rmax, pr->mu_rmax), (double)pr->tg_count, &D, &F);
+    pr->inv_d = 1.0 / D;
+    pr->fix_scale = ldexp(1.0, F);
+    pr->d_ext = D;
+    pr->inv_scale = ldexp(1.0, -F);
+}
+
+// the registration loop on the device alone (tree_batch.hip; hgmm_tree_register uses it with B = 1 on the serial buffers)
+int forest_register_on_device(::hgmm_ctx* c, int B, const double* tg, int64_t tg_pad, const int64_t* tg_first,
+                              const int64_t* tg_counts, const double* tg_rmax, const double* mu_rmax, const double* prep, int T,
+                              int L, unsigned long long* momq, double* rot, double* t, double scale, double lambda_c,
+                              int max_iter, double tol, double* q_prev_inout, int32_t* iters_out, int32_t* status_out,
+                              double* trace);
 
 // ---- kernels defined in tree_kernels.hip that the batched path (tree_batch.hip) launches as they are -----------------
 constexpr int OFF_BLOCK = 256;

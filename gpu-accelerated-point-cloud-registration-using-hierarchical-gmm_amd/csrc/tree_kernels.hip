@@ -1210,6 +1210,33 @@ extern "C" int hgmm_tree_register(hgmm_ctx* c, double* rot, double* t, double sc
         return c ? fail(c, HGMM_ERR_ARG, "tree_register: NULL argument") : HGMM_ERR_ARG;
     *iters_out = 0;
     *status_out = 0;                                  // 0: iteration budget used up, 1: |dq| < tol, 2: host M-step needed
+    if (c->cfg[CFG_REG_DEVICE_SOLVE] && !c->comm_on()) {
+        // the loop on the device alone (forest_register_on_device: one pair on this context's tree and target)
+        if (!c->tree.nodes_ready) return fail(c, HGMM_ERR_STATE, "registration: no tree (build or set_nodes first)");
+        if (c->tgt_n <= 0) return fail(c, HGMM_ERR_STATE, "registration: call hgmm_tree_set_target first");
+        const int64_t T = c->tree.T;
+        if (c->tree.mu_rmax < 0.0) {
+            std::vector<double> mu((size_t)3 * T);
+            HGMM_HIP(c, hipMemcpyAsync(mu.data(), c->t_mu.p, sizeof(double) * 3 * T, hipMemcpyDeviceToHost, c->stream));
+            HGMM_HIP(c, ctx_stream_sync(c));
+            c->tree.mu_rmax = tree_mu_rmax(mu.data(), T);
+        }
+        const size_t want = sizeof(unsigned long long) * NMOM * T;
+        if (c->t_momq.cap < want || !c->t_momq.p || c->tree.momq_dirty) {      // (reg_estep_fixed's invariant)
+            HGMM_TRY(ensure(c, c->t_momq, want));
+            HGMM_HIP(c, hipMemsetAsync(c->t_momq.p, 0, c->t_momq.cap, c->stream));
+            c->tree.momq_dirty = false;
+        }
+        const int64_t first = 0, count = c->tgt_n;
+        int32_t it32 = 0, st32 = 0;
+        HGMM_TRY(forest_register_on_device(c, 1, c->tgt_soa64.as<double>(), c->tgt_pad, &first, &count, &c->tgt_rmax,
+                                           &c->tree.mu_rmax, c->t_prep.as<double>(), (int)T, c->tree.L,
+                                           c->t_momq.as<unsigned long long>(), rot, t, scale, lambda_c, max_iter, tol,
+                                           q_prev_inout, &it32, &st32, trace));
+        *iters_out = it32;
+        *status_out = st32;
+        return HGMM_OK;
+    }
     for (int it = 0; it < max_iter; ++it) {
         double o[28];
         HGMM_TRY(hgmm_tree_reg_normal(c, rot, t, scale, lambda_c, o));

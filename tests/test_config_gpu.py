@@ -12,6 +12,7 @@ import pytest
 import test_flat_gpu
 import test_fullcov_gpu
 import test_kmeans_gpu
+import test_tree_batch_gpu
 import test_tree_gpu
 
 pytestmark = pytest.mark.gpu
@@ -48,6 +49,17 @@ def _kmeans(ctx, bunny):
         test_kmeans_gpu.test_fit_matches_reference_init(ctx, bunny, name)
 
 
+def _reg(ctx, bunny):
+    # the registration loop with the 6 x 6 solve, the twist and the stop rule on the device: the reference's recorded
+    # per-iteration transforms (1e-8), the Python path's trajectory and stopping iteration, budget split == one call;
+    # batches of pairs bit for bit the serial call under the same option, an ill-conditioned pair leaving its batch
+    test_tree_gpu.test_registration_loop_inside_the_library(ctx, bunny)
+    test_tree_gpu.test_registration_real_scan_pair_against_bun_conf(ctx, bunny)
+    test_tree_batch_gpu.test_registration_batch_is_bitwise_the_serial_registration(ctx, bunny)
+    test_tree_batch_gpu.test_registration_batch_matches_reference_trace(ctx)
+    test_tree_batch_gpu.test_registration_batch_ill_conditioned_pair_falls_back_like_the_serial_path(ctx, bunny)
+
+
 CASES = {
     "estep_target_gbs": [(0, _flat), (6000, _flat)],
     "pace_start": [(5800, _flat)],
@@ -62,6 +74,7 @@ CASES = {
     "kmpp_two_launches": [(1, _kmeans)],
     "kmeans_acc_regs": [(1, _kmeans)],
     "ipc_timeout_s": [(5, None)],            # behaviour: tests/test_multirank_gpu.py (a peer that never arrives)
+    "reg_device_solve": [(1, _reg)],
 }
 
 

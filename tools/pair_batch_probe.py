@@ -3,7 +3,8 @@
 per batch size B the wall time of the four C calls -- upload of the sources, forest build, upload of the targets,
 batched registration -- and the pairs/s they add up to, next to the serial call on one pair.
 
-    python tools/pair_batch_probe.py [--f32] [B ...]      (--f32: float32 scans -> the stop rule's pdfs in float32)
+    python tools/pair_batch_probe.py [--f32] [--device-solve] [B ...]
+        --f32: float32 scans -> the stop rule's pdfs in float32;  --device-solve: the registration loop on the device alone
 """
 import os
 import sys
@@ -20,8 +21,10 @@ from hgmm_amd.hgmm.hgmm_gpu import n_total_nodes  # noqa: E402
 
 def main():
     f32 = "--f32" in sys.argv
-    sizes = [int(v) for v in sys.argv[1:] if v != "--f32"] or [1, 2, 4, 8, 16, 32, 64]
+    sizes = [int(v) for v in sys.argv[1:] if not v.startswith("--")] or [1, 2, 4, 8, 16, 32, 64]
     ctx = hgmm_amd.Context(0)
+    if "--device-solve" in sys.argv:
+        ctx.config_set("reg_device_solve", 1)
     source, pairs = bench.scan_pairs(0)
     if f32:
         source = source.astype(np.float32)
