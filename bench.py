@@ -1353,6 +1353,9 @@ def register_pair(ctx, source, target):
     return res, int(gt.n_iter_)
 
 
+PHASES = []           # phases_ms of every batched call (list.append is atomic): where a step's wall time went, per thread
+
+
 def register_batch(ctx, source, targets):
     """B units of work through the same launches (hgmm_amd.hgmm.hgmm_gpu.registration_gmmtree_batch): every pair's tree and
     transformation are bitwise what register_pair returns for it (tests/test_tree_batch_gpu.py).
@@ -1360,6 +1363,7 @@ def register_batch(ctx, source, targets):
     from hgmm_amd.hgmm.hgmm_gpu import registration_gmmtree_batch
     res, info = registration_gmmtree_batch([(source, t) for t in targets], maxiter=PAIR_MAXITER, tol=PAIR_TOL, ctx=ctx,
                                            return_info=True, **PAIR_KW)
+    PHASES.append(info.get("phases_ms"))
     return res, info["registration_iters"]
 
 
@@ -1566,6 +1570,8 @@ def pairs_main(args):
                          "mean_misalignment_after_mm": 1e3 * float(allr[:, 1].mean()),
                          "max_misalignment_after_mm": 1e3 * float(allr[:, 0].max()), "bound_mm": 6.0, "ok": ok},
             "kernels_ms_per_pair": {k: {"ms": v[0], "launches": v[1]} for k, v in prof.items()},
+            "host_phases_ms_per_batch": ({k: float(np.mean([p[k] for p in PHASES if p])) for k in PHASES[-1]}
+                                         if PHASES and PHASES[-1] else None),
             "h2d_note": "each step uploads both clouds (2 x 0.97 MB) through the reference's host-array API: ~0.1 ms of the step",
             "roofline": None,
             "roofline_note": "latency-bound: ~100 level-iterations of three small kernels per pair on 40 k points "

@@ -41,9 +41,13 @@ __global__ void forest_prep_kernel(const double* __restrict__ pi, const double* 
               prep + PREP_N * j, flags + j / T);
 }
 
+// (An XCD-aware work order -- XCD x taking the x-th contiguous eighth of the chunks instead of every eighth chunk, so that a
+//  few clouds' node parameters stay in one XCD's scalar caches and L2 -- was built and measured in round 6: the build of 32
+//  bunny scans went from 8.9 to 13.9 ms, 3650 -> 2740 pairs/s.  Eight widely spaced streams through the point arrays cost
+//  more than the scalar loads' ~800-cycle misses; the grid order stays.)
 // launch 0 of a level: the E-step of every chunk of every cloud
 template <bool HALF>
-__global__ __launch_bounds__(CH) void forest_estep_kernel(TreeEstepArgs ea, ForestArgs fa) {
+__global__ __launch_bounds__(CH, 7) void forest_estep_kernel(TreeEstepArgs ea, ForestArgs fa) {
     __shared__ double smem[tree_estep_lds<HALF>()];
     tree_estep_body<HALF, true>((int)blockIdx.x, ea, NO_FOLLOW, smem, &fa);
 }
@@ -114,11 +118,12 @@ __global__ __launch_bounds__(64) void forest_moments8_kernel(const double* __res
 // Iteration e's log-likelihood of every cloud + (with_estep) iteration e + 1's speculative E-step of every chunk, as in
 // tree_ll_estep_kernel.  Workgroups [0, B ll_stride): cloud w / ll_stride, point block w % ll_stride (clouds with fewer
 // blocks return); the rest: chunks.
-// (five waves per SIMD: 96 registers, no spills; 4 / 5 / 6 measured 14.2 / 13.9 / 14.4 ms per build of 32 bunny scans --
-//  the kernel keeps the fp64 pipe ~80 % busy at any of them, profiles/r06/pmc_sq_batch32.txt)
+// (float64 pdfs: five waves per SIMD, 96 registers, no spills; 4 / 5 / 6 measured 14.2 / 13.9 / 14.4 ms per build of 32 bunny
+//  scans -- the kernel keeps the fp64 pipe ~80 % busy at any of them, profiles/r06/pmc_sq_batch32.txt.  float32 pdfs: the
+//  launch is latency chains of E-step workgroups for the larger part -- six waves at 80 registers, still without spills)
 // F32: the log-likelihood workgroups evaluate their pdfs in float32 (hgmm_tree_set_precision; tree_loglik_f32_body)
 template <bool F32>
-__global__ __launch_bounds__(CH, 5) void forest_ll_estep_kernel(const double* __restrict__ xs, int64_t n_pad,
+__global__ __launch_bounds__(CH, F32 ? 6 : 5) void forest_ll_estep_kernel(const double* __restrict__ xs, int64_t n_pad,
                                                              const double* __restrict__ prep, int64_t lb, int n_level,
                                                              double* __restrict__ block_q, const int* __restrict__ flags,
                                                              ForestArgs fa, int ll_stride, TreeEstepArgs ea, int with_estep) {
@@ -241,15 +246,16 @@ template <int NMQ>
 __global__ __launch_bounds__(CH) void forest_reg_estep_kernel(const double* __restrict__ tg, int64_t tg_pad,
                                                               const ForestRegPair* __restrict__ tab,
                                                               const double* __restrict__ prep, int T, int L,
-                                                              double lambda_c, unsigned long long* __restrict__ momq) {
+                                                              double lambda_c, unsigned long long* __restrict__ momq, int gx) {
     __shared__ unsigned long long lds[REG_LDS_NODES * NMQ];
-    const int b = blockIdx.y;
+    const int item = (int)blockIdx.x;                  // (a one-dimensional grid of gx x B items)
+    const int b = item / gx, bx = item - b * gx;
     const ForestRegPair* pr = tab + b;
     const int active = pr->active, first = pr->tg_first, count = pr->tg_count;
-    if (!active || (int64_t)blockIdx.x * CH >= count) return;
+    if (!active || (int64_t)bx * CH >= count) return;
     const Rigid tf = pr->tf;
     const double inv_d = pr->inv_d, fix_scale = pr->fix_scale;
-    const int64_t li = (int64_t)blockIdx.x * CH + threadIdx.x;
+    const int64_t li = (int64_t)bx * CH + threadIdx.x;
     tree_reg_estep_body<NMQ>(first + li, li < count, tg, tg_pad, tf, prep + (size_t)PREP_N * T * b, L, lambda_c, inv_d,
                              fix_scale, momq + (size_t)NMQ * T * b, lds);
 }
@@ -379,7 +385,8 @@ int forest_register_on_device(::hgmm_ctx* c, int B, const double* tg, int64_t tg
         if (enq < max_iter && enq - it_min < ahead) {
             {
                 ProfScope prof(c, HGMM_K_TREE_REG);
-                forest_reg_estep_kernel<4><<<dim3(nblk(longest, CH), B), CH, 0, c->stream>>>(tg, tg_pad, d_tab, prep, T, L, lambda_c, momq);
+                forest_reg_estep_kernel<4><<<nblk(longest, CH) * (unsigned)B, CH, 0, c->stream>>>(tg, tg_pad, d_tab, prep, T, L, lambda_c, momq,
+                                                                                                  (int)nblk(longest, CH));
             }
             forest_reg_solve_kernel<<<B, 256, 0, c->stream>>>(momq, d_tab, prep, T, d_out, tol, max_iter, d_trace,
                                                              static_cast<unsigned long long*>(d_words));
@@ -832,8 +839,9 @@ extern "C" int hgmm_tree_register_batch(hgmm_ctx* c, int B, double* rot, double*
         const unsigned long long seq = ++F.seq;
         {
             ProfScope prof(c, HGMM_K_TREE_REG);
-            forest_reg_estep_kernel<4><<<dim3(nblk(longest, CH), B), CH, 0, c->stream>>>(
-                c->fr_tg.as<double>(), F.tg_pad, d_tab, c->fr_prep.as<double>(), T, L, lambda_c, c->fr_momq.as<unsigned long long>());
+            forest_reg_estep_kernel<4><<<nblk(longest, CH) * (unsigned)B, CH, 0, c->stream>>>(
+                c->fr_tg.as<double>(), F.tg_pad, d_tab, c->fr_prep.as<double>(), T, L, lambda_c, c->fr_momq.as<unsigned long long>(),
+                (int)nblk(longest, CH));
         }
         forest_reg_normal_kernel<<<B, 256, 0, c->stream>>>(c->fr_momq.as<unsigned long long>(), d_tab, c->fr_prep.as<double>(), T,
                                                           d_out, static_cast<double*>(d_hout),

@@ -501,8 +501,10 @@ __device__ __forceinline__ TreeFollow forest_follow(const ForestArgs& fa, int b,
 }
 // (c = the workgroup's chunk: blockIdx.x in tree_estep_kernel, an offset of it in tree_ll_estep_kernel)
 // LDS of one E-step workgroup, in doubles: exp table, tree_follow's four, the waves' [8][NMOM] sums, gamma rows, feature rows
+// (the waves' [8][NMOM] sums live in the first rows of the wave's own gamma block: a wave writes them once its last
+//  fragment reads have landed in registers -- 20.6 KB per workgroup in the two-pass form, seven workgroups per CU)
 template <bool HALF>
-constexpr int tree_estep_lds() { return EXP_TAB_N + 4 + (CH / 64) * 8 * NMOM + (CH / 64) * (8 + NMOM) * (HALF ? ES_LD / 2 + 1 : ES_LD); }
+constexpr int tree_estep_lds() { return EXP_TAB_N + 4 + (CH / 64) * (8 + NMOM) * (HALF ? ES_LD / 2 + 1 : ES_LD); }
 template <bool HALF, bool FOREST = false>
 __device__ __forceinline__ void tree_estep_body(const int c, const TreeEstepArgs& a, const TreeFollow& follow,
                                                 double* __restrict__ smem, const ForestArgs* fa = nullptr) {
@@ -609,9 +611,10 @@ __device__ __forceinline__ void tree_estep_body(const int c, const TreeEstepArgs
     // the A operand and columns 10..15 of B alias rows that exist: their products land in accumulator entries nobody reads.
     constexpr int LD = HALF ? ES_LD / 2 + 1 : ES_LD;          // 34 / 66: the same bank pattern (stride = 4 mod 64 dwords)
     constexpr int PASS_PTS = HALF ? 32 : 64;
-    double (*sh)[8 * NMOM] = reinterpret_cast<double (*)[8 * NMOM]>(smem + EXP_TAB_N + 4);
-    double (*GS)[8][LD] = reinterpret_cast<double (*)[8][LD]>(smem + EXP_TAB_N + 4 + (CH / 64) * 8 * NMOM);
-    double (*FS)[NMOM][LD] = reinterpret_cast<double (*)[NMOM][LD]>(smem + EXP_TAB_N + 4 + (CH / 64) * 8 * NMOM + (CH / 64) * 8 * LD);
+    double (*GS)[8][LD] = reinterpret_cast<double (*)[8][LD]>(smem + EXP_TAB_N + 4);
+    double (*FS)[NMOM][LD] = reinterpret_cast<double (*)[NMOM][LD]>(smem + EXP_TAB_N + 4 + (CH / 64) * 8 * LD);
+    static_assert(8 * LD >= 8 * NMOM, "the wave's sums fit into its gamma block");
+    auto sh = [&](int ww) -> double* { return &GS[ww][0][0]; };      // wave ww's [8][NMOM] sums (aliases its gamma rows)
     const int w = wave_in_block();
     const int lane = lane_id();
     {
@@ -637,16 +640,18 @@ __device__ __forceinline__ void tree_estep_body(const int c, const TreeEstepArgs
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ga[4 * st], fb[4 * st], acc, 0, 0, 0);
         }
         // D layout (f64 16x16x4): row (child) = (lane >> 4) + 4 r, column (feature) = lane & 15
+        __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the last fragments are in registers
+        __builtin_amdgcn_wave_barrier();
         if (a_idx < NMOM) {
-            sh[w][b_idx * NMOM + a_idx] = acc[0];
-            sh[w][(b_idx + 4) * NMOM + a_idx] = acc[1];
+            sh(w)[b_idx * NMOM + a_idx] = acc[0];
+            sh(w)[(b_idx + 4) * NMOM + a_idx] = acc[1];
         }
     }
     __syncthreads();
     if (threadIdx.x < 8 * NMOM) {
         double t = 0.0;
 #pragma unroll
-        for (int ww = 0; ww < CH / 64; ++ww) t += sh[ww][threadIdx.x];
+        for (int ww = 0; ww < CH / 64; ++ww) t += sh(ww)[threadIdx.x];
         partials[(size_t)c * (8 * NMOM) + threadIdx.x] = t;
     }
     if (a.q_shares && threadIdx.x == CH - 1) {

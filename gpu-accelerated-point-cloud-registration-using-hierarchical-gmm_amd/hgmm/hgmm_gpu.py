@@ -464,22 +464,28 @@ def registration_gmmtree_batch(pairs, maxiter=20, tol=1.0e-4, ctx: Context | Non
             info["build_iters"] = np.asarray(info["build_iters"])
             return (out, info) if return_info else out
         pdf_dtype = kinds[0]
+    clock = [time.perf_counter()]
     srcs = [np.ascontiguousarray(_points(s), dtype=np.float64) for s, _ in pairs]
     tgts = [np.ascontiguousarray(_points(t), dtype=np.float64) for _, t in pairs]
     B = len(pairs)
     T = n_total_nodes(tree_level)
     idx = np.asarray(init_idx) if init_idx is not None else np.random.RandomState(72).randint(T, size=T)
     init_mu = np.stack([S[idx] for S in srcs])
+    clock.append(time.perf_counter())
     ctx.set_points_batch(srcs)
+    clock.append(time.perf_counter())
     prev = getattr(ctx, "tree_dtype", np.dtype(np.float64))     # (a precision the caller set on the context survives this call)
     ctx.tree_set_precision(pdf_dtype)
     try:
         _, build_iters, _ = ctx.tree_build_batch([len(S) for S in srcs], tree_level, ls, ld, init_mu, sig2, want_tables=False)
     finally:
         ctx.tree_set_precision(prev)
+    clock.append(time.perf_counter())
     ctx.tree_set_targets_batch(tgts)
+    clock.append(time.perf_counter())
     rot0 = np.tile(np.identity(3), (B, 1, 1))
     rot, t, iters, q, status, _ = ctx.tree_register_batch(rot0, np.zeros((B, 3)), 1.0, lambda_c, maxiter, tol)
+    clock.append(time.perf_counter())
     out = []
     reg_iters = [int(v) for v in iters]
     for b in range(B):
@@ -496,5 +502,11 @@ def registration_gmmtree_batch(pairs, maxiter=20, tol=1.0e-4, ctx: Context | Non
         tf = RigidTransformation(rot[b].copy(), t[b].copy())
         out.append(MstepResult(tf.inverse(), np.array([q[b]]) if not np.isnan(q[b]) else np.array([])))
     if return_info:
-        return out, {"build_iters": build_iters, "registration_iters": reg_iters, "status": [int(v) for v in status]}
+        clock.append(time.perf_counter())
+        # wall time of the call's phases, ms: host preparation (type conversion, initial means), upload of the sources, forest
+        # build, upload of the targets, batched registration, result objects
+        phases = dict(zip(("prepare", "sources_up", "build", "targets_up", "register", "results"),
+                          (1e3 * np.diff(clock)).tolist()))
+        return out, {"build_iters": build_iters, "registration_iters": reg_iters, "status": [int(v) for v in status],
+                     "phases_ms": phases}
     return out
