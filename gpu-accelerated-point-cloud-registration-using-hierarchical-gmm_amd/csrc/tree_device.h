@@ -547,6 +547,10 @@ __device__ __forceinline__ void tree_estep_body(const int c, const TreeEstepArgs
             return;
         }
     }
+    // (The children's parameters are read by scalar loads, ~25 per wave.  Round 6 suspected them -- in a forest every CU sees
+    //  the nodes of every cloud in turn and the 16 KB scalar cache misses, SQ_INST_LEVEL_SMEM / SQ_INSTS_SMEM -- and
+    //  staged the 8 x 11 values through LDS with ONE vector load per workgroup, requested with the points: 24 more
+    //  registers, and the build of 32 bunny scans went from 9.04 to 9.52 ms.  The scalar loads stay.)
     // node id of the parent: level 0 -> pseudo-parent -1; child(j) = 8 (j + 1)
     const int64_t parent_node = (level == 0) ? -1 : parent_level_first + pl;
     const int64_t j0 = node_off + 8 * (parent_node + 1);

@@ -256,10 +256,12 @@ int hgmm_tree_set_nodes(hgmm_ctx* ctx, int L, const double* pi, const double* mu
  * throughout (`points.astype(np.float32)`, float32 node and moment arrays: hgmm/hgmm_gpu.py:472, 478-484).
  * HGMM_PRECISION_F32_PDF: the level log-likelihood q = sum_i log max(sum_j pi_j N(x_i; j), eps) (logLikelihoodValue,
  * hgmm_gpu.py:107-115) evaluates its N x 8^(l+1) Gaussians in packed float32 on coordinates relative to the workgroup's
- * first point (formed in float64), with log() and the sum over the points in float64 -- on clouds of >= 400 000 points,
- * where that kernel is most of a build; smaller clouds are bound by launch latencies and keep float64.  The E-step, the
- * moments and the M-step stay float64: a level that stops after the same number of iterations yields the float64 tree bit
- * for bit; q itself differs by ~1e-7 relative.  Stays in force for the context until set again. */
+ * first point (formed in float64), with log() and the sum over the points in float64 -- on clouds of any size and in
+ * hgmm_tree_build_batch (round 6; round 5: clouds of >= 400 000 points only).  Level 0 of a small cloud or a forest needs
+ * no such kernel in either mode: its q comes out of the float64 E-step's own eight terms.  The E-step, the moments and
+ * the M-step stay float64: a level that stops after the same number of iterations yields the float64 tree bit for bit; q
+ * itself differs by ~1e-7 relative (|dq| < 1 % of the smallest stop threshold in use on every cloud tried,
+ * tests/test_tree_gpu.py, tests/test_tree_batch_gpu.py).  Stays in force for the context until set again. */
 enum { HGMM_PRECISION_F64 = 0, HGMM_PRECISION_F32_PDF = 1 };
 int hgmm_tree_set_precision(hgmm_ctx* ctx, int precision);
 /* Registration target cloud (host [n,3] float64), kept resident across iterations. */
@@ -282,7 +284,12 @@ int hgmm_tree_reg_normal(hgmm_ctx* ctx, const double* rot, const double* t, doub
  * |q - q_prev| < tol.  rot [9] row-major and t [3] are updated in place; *q_prev_inout: NaN = no previous q.
  * status: 0 = max_iter iterations done, 1 = stopped by tol, 2 = the normal equations of the NEXT iteration are too
  * ill-conditioned (or not finite): the caller runs that iteration with the reference's stacked least squares
- * (eigh + QR on the host) and may call again.  trace (optional): per iteration rot, t, q.              */
+ * (eigh + QR on the host) and may call again.  trace (optional): per iteration rot, t, q.
+ * Per-context option reg_device_solve = 1 (hgmm_config_set; off by default -- the host solve is the parity reference):
+ * the whole loop runs on the device -- Cholesky solve of the 6 x 6 system, twist, stop rule and the fixed-point encoding
+ * of the next E-step in one device thread behind the normal equations, the host only follows a progress word.  Same
+ * trajectory to ~1e-12 (device sin / cos, fused multiply-adds, Cholesky instead of pivoted elimination); status 2 is
+ * decided on the Cholesky pivots (smallest pivot <= 1e-11 largest diagonal entry).  Not under a communicator.      */
 int hgmm_tree_register(hgmm_ctx* ctx, double* rot, double* t, double scale, double lambda_c, int max_iter, double tol,
                        double* q_prev_inout, int* iters_out, int* status_out, double* trace);
 /* ---- batched HGMM: B independent scan pairs per launch set ("forest") ------------------------------------------------
@@ -303,7 +310,8 @@ int hgmm_tree_register(hgmm_ctx* ctx, double* rot, double* t, double scale, doub
  * hgmm_tree_register_batch    <- B x hgmm_tree_register on (tree b, target b): rot [B][9], t [B][3], q_prev [B] (NaN: none)
  *                             updated in place; iters [B]; status [B] as hgmm_tree_register's (a pair that meets status 2
  *                             leaves the batch at that iteration: the caller finishes it through the serial entries);
- *                             trace (optional) [B][max_iter][13].  The 6 x 6 solves stay on the host.                       */
+ *                             trace (optional) [B][max_iter][13].  The 6 x 6 solves stay on the host unless the context's
+ *                             reg_device_solve option is set (see hgmm_tree_register): then one device thread per pair.    */
 int hgmm_set_points_batch_f64(hgmm_ctx* ctx, int B, const double* const* xyz, const int64_t* counts);
 int hgmm_tree_build_batch(hgmm_ctx* ctx, int B, const int64_t* counts, int L, double ls, double ld,
                           const double* init_mu, double sig2, int max_iters_per_level,
