@@ -84,29 +84,55 @@ def main():
         p("## Independent scan pairs: contexts per GPU x pairs per launch set (`bench_pairs_n1_c<C>_b<B>.json`; default line: "
           "`bench_pairs_n1.json`)")
         p("")
-        p("| contexts | batch | pairs/s | ms per step | max misalignment mm |")
-        p("|---|---|---|---|---|")
+        p("| contexts | batch | pairs/s, float32 scans (float32 pdfs in the stop rule) | pairs/s, float64 scans | ms per step | "
+          "max misalignment mm |")
+        p("|---|---|---|---|---|---|")
         rows = []
         for f in files:
             r = load_line(f)
             if r:
-                rows.append((r["config"]["contexts_per_gpu"], r["config"]["batch"], r["value"], r["ms_per_step"],
-                             r["accuracy"]["max_misalignment_after_mm"]))
-        for c, bt, v, ms, acc in sorted(rows):
-            p("| %d | %d | %.0f | %.2f | %.2f |" % (c, bt, v, ms, acc))
+                both = {r.get("scan_dtype", "float64"): r["value"]}
+                o = r.get("other_scan_dtype")
+                if o:
+                    both[o["scan_dtype"]] = o["pairs_per_s"]
+                rows.append((r["config"]["contexts_per_gpu"], r["config"]["batch"], both.get("float32"), both.get("float64"),
+                             r["ms_per_step"], r["accuracy"]["max_misalignment_after_mm"]))
+        for c, bt, v32, v64, ms, acc in sorted(rows):
+            p("| %d | %d | %s | %s | %.2f | %.2f |" % (c, bt, fmt(v32, "%.0f"), fmt(v64, "%.0f"), ms, acc))
         dflt = load_line(os.path.join(d, "bench_pairs_n1.json"))
         if dflt:
+            o = dflt.get("other_scan_dtype") or {}
             p("")
-            p("default (`--contexts-per-gpu %d --batch %d`): **%.0f pairs/s**" % (dflt["config"]["contexts_per_gpu"],
-                                                                                   dflt["config"]["batch"], dflt["value"]))
-    probe = os.path.join(d, "pair_batch_probe.log")
-    if os.path.exists(probe):
-        p("")
-        p("## Where a batch's time goes (`pair_batch_probe.log`, one context)")
-        p("")
-        p("```")
-        out.extend(open(probe).read().strip().splitlines())
-        p("```")
+            p("default (`--contexts-per-gpu %d --batch %d --scan-dtype %s`): **%.0f pairs/s**; %s scans: %s pairs/s; host phases "
+              "per batch, ms: %s" % (dflt["config"]["contexts_per_gpu"], dflt["config"]["batch"], dflt.get("scan_dtype"),
+                                     dflt["value"], o.get("scan_dtype"), fmt(o.get("pairs_per_s"), "%.0f"),
+                                     json.dumps({k: round(v, 2) for k, v in (dflt.get("host_phases_ms_per_batch") or {}).items()})))
+        busy = os.path.join(d, "gpu_busy_pairs_default.txt")
+        if os.path.exists(busy):
+            p("")
+            p("GPU under the default line (`gpu_busy_pairs_default.txt`, rocprofv3 kernel trace of the same command):")
+            p("")
+            p("```")
+            out.extend(open(busy).read().strip().splitlines()[:6])
+            p("```")
+    for name, title in (("pair_batch_probe.log", "float64 scans"), ("pair_batch_probe_f32.log", "float32 scans"),
+                        ("pair_batch_probe_f32_device_solve.log", "float32 scans, reg_device_solve = 1")):
+        probe = os.path.join(d, name)
+        if os.path.exists(probe):
+            p("")
+            p("## Where a batch's time goes, one context, %s (`%s`)" % (title, name))
+            p("")
+            p("```")
+            out.extend(open(probe).read().strip().splitlines())
+            p("```")
+    for name in ("forest_levels_batch32_f32.txt", "forest_levels_batch32_f64.txt"):
+        fl = os.path.join(d, name)
+        if os.path.exists(fl):
+            durs = [float(l.split()[6]) for l in open(fl) if "forest_ll_estep" in l or ("forest_estep_kernel" in l)]
+            span = [l for l in open(fl) if l.startswith("build span")]
+            p("")
+            p("* `%s`: the E-step / log-likelihood launches of the last build of 32 pairs, us, in launch order: first 3 %s ... "
+              "last 3 %s; %s" % (name, durs[:3], durs[-3:], span[0].strip() if span else ""))
     kt = os.path.join(d, "kernel_trace_batch32.txt")
     if os.path.exists(kt):
         p("")
