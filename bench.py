@@ -487,6 +487,34 @@ def fullcov_leg(ctx):
     out["roofline"] = {"bound": "valu+mfma (fp64)", "unit": "TFLOP/s", "achieved": flop / (dt / iters) / 1e12,
                        "peak": FP64_VECTOR_PEAK_TF, "frac": flop / (dt / iters) / 1e12 / FP64_VECTOR_PEAK_TF,
                        "flop_per_pair": 36}
+    # the same fit with the FLOAT32 TILE (Context.tree_set_precision(np.float32): the reference GPU file's type; opt-in):
+    # time, and how far its result is from the float64 fit's after the same 20 iterations
+    try:
+        ref = ctx.fullcov_fit(J, 1e-30, 1e-4, P[idx], 0.01, iters)
+        ctx.tree_set_precision(np.float32)
+        ctx.fullcov_fit(J, 1e-30, 1e-4, P[idx], 0.01, 2)
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        t0 = time.perf_counter()
+        got = ctx.fullcov_fit(J, 1e-30, 1e-4, P[idx], 0.01, iters)
+        dt32 = time.perf_counter() - t0
+        ctx.profile_enable(False)
+        ms, nl = ctx.profile_get("full_fused")
+        var = np.abs(np.einsum("jii->j", ref[2])) / 3.0
+        out["float32_tile"] = {
+            "ms_per_iteration": dt32 * 1e3 / iters, "kernel_avg_ms": ms / nl if nl else None, "launches": nl,
+            "vs_float64_after_%d_iterations" % iters: {
+                "labels_differing": int((ref[3] != got[3]).sum()), "points": int(len(ref[3])),
+                "max_abs_dq": float(np.abs(ref[4] - got[4]).max()),
+                "max_rel_dpi": float(np.max(np.abs(ref[0] - got[0]) / np.maximum(ref[0], 1e-300))),
+                "max_abs_dmu": float(np.abs(ref[1] - got[1]).max()),
+                "max_dcov_over_variance": float(np.max(np.abs(ref[2] - got[2]).reshape(J, -1).max(1) / var))},
+            "note": "pdfs, tile, gamma and the statistics' products in float32 (v_mfma_f32_16x16x4_f32 about the cloud's "
+                    "centroid, float partials per 256 points added in float64); row sums, 1 / den, log and the M-step float64"}
+    except Exception as e:                                            # noqa: BLE001 -- a side figure must not take the leg down
+        out["float32_tile"] = {"error": repr(e)}
+    finally:
+        ctx.tree_set_precision(np.float64)
     return out
 
 
@@ -791,7 +819,7 @@ def replica_pairs_leg(ctx):
     """The replica mode (`bench.py --mode pairs`, hgmm_amd.replicas) as a side leg of the default line: independent scan
     pairs, eight contexts x 32 pairs per launch set on this GPU (the mode's defaults), no communicator -- run as a process
     of its own (it creates its own contexts and threads)."""
-    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "pairs", "--steps", "6", "--warmup", "2", "--min-time", "1.5",
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "pairs", "--steps", "20", "--warmup", "2", "--min-time", "3.0",
            "--no-cpu-baseline"]
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
@@ -1031,6 +1059,7 @@ def split_legs(out, args):
         "c4_build_ms": _pick(legs, "hgmm", "build_ms"),
         "tree_1M_build_ms_f64_f32pdf": [_pick(legs, "tree_1M", "build_ms"), _pick(legs, "tree_1M", "float32_pdfs", "build_ms")],
         "fullcov_ms_per_it": _pick(legs, "fullcov", "ms_per_iteration"),
+        "fullcov_f32_tile_ms_per_it": _pick(legs, "fullcov", "float32_tile", "ms_per_iteration"),
         "predict_ms": _pick(legs, "predict", "kernel_ms"), "mstep_frac": _pick(legs, "materialised_iteration", "roofline", "frac"),
         "kmeans_k800_1M_ms": [_pick(legs, "kmeans_init", "fit_ms_warm"), _pick(legs, "kmeans_init", "seeding_ms_warm")],
         "registration_ms": _pick(legs, "registration", "total_ms"),

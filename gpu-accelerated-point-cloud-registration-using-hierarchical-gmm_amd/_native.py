@@ -130,6 +130,7 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_profile_enable", [ctx, C.c_int])
         _sig(lib, "hgmm_profile_reset", [ctx])
         _sig(lib, "hgmm_profile_get", [ctx, C.c_int, _f64p, C.POINTER(C.c_int64)])
+        _sig(lib, "hgmm_fullcov_phase_clocks", [ctx, C.c_int, C.POINTER(C.c_int64)])
         _sig(lib, "hgmm_util_fill_f32", [ctx, _vp, C.c_int64, C.c_float, C.c_int])
         _sig(lib, "hgmm_kmeans_center_f64", [_vp, C.c_int64, _vp, _vp, _vp])
         _sig(lib, "hgmm_tree_register", [ctx, _vp, _vp, C.c_double, C.c_double, C.c_int, C.c_double, _vp,
@@ -1245,6 +1246,16 @@ class Context:
     def util_fill(self, arr, value=0.0, nontemporal=True, mode=0, grid_mult=0):
         flags = (1 if nontemporal else 0) | (int(mode) << 8) | (int(grid_mult) << 16)
         self._check(self.lib.hgmm_util_fill_f32(self.h, arr.ptr, arr.size, float(value), flags))
+
+    def fullcov_phase_clocks(self, enable):
+        """Arm (True) the phase clocks of the one-pass full-covariance kernels, or disarm them (False) and return the last
+        launch's cycles [8 waves][4: phase A, phase B, phase C, barrier wait] (hgmm_fullcov_phase_clocks)."""
+        if enable:
+            self._check(self.lib.hgmm_fullcov_phase_clocks(self.h, 1, None))
+            return None
+        out = np.zeros((8, 4), np.int64)
+        self._check(self.lib.hgmm_fullcov_phase_clocks(self.h, 0, out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
 
     def profile_get(self, kernel):
         ms, n = C.c_double(), C.c_int64()

@@ -737,7 +737,7 @@ extern "C" int hgmm_destroy(hgmm_ctx* c) {
                       &c->km_closest, &c->km_block, &c->km_centres, &c->km_ids, &c->km_rand, &c->km_labels,
                       &c->km_mind2, &c->km_partial, &c->km_out, &c->gt_buf, &c->t_momq, &c->t_flags, &c->exp_tab2, &c->t_tickets,
                       &c->fr_pi, &c->fr_mu, &c->fr_cov, &c->fr_prep, &c->fr_mom, &c->fr_clouds, &c->fr_q, &c->fr_trace, &c->fr_tg,
-                      &c->fr_momq, &c->fr_reg};
+                      &c->fr_momq, &c->fr_reg, &c->ff_origin, &c->ff_clocks};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);

@@ -212,6 +212,9 @@ struct hgmm_ctx {
     hgmm::DevBuf fr_trace;                    // double [B][L][trace_cap]
     hgmm::DevBuf fr_tg;                       // double [3][tg_pad] the targets, back to back
     hgmm::DevBuf fr_momq;                     // uint64 [B T][4] registration sums
+    hgmm::DevBuf ff_clocks;                   // int64 [8][4] phase clocks of the one-pass full-covariance kernels (armed: ff_clocks_on)
+    bool ff_clocks_on = false;
+    hgmm::DevBuf ff_origin;                   // double [256][3] partial coordinate sums: origin of the float32 full-covariance statistics
     hgmm::DevBuf fr_reg;                      // per-pair registration table + the 28 numbers per pair + per-pair r2max words
 
     // ---- KMeans initialiser (float64, on x_soa64) -----------------------------------

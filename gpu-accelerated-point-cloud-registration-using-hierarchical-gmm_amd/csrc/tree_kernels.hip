@@ -1838,6 +1838,394 @@ __global__ __launch_bounds__(FT_BLOCK) void full_fused_kernel(
         full_fused_body<CPL, true>(xs, n, n_pad, prep, J16, label_out, block_q, partials, want_stats, dbg, lds, exp2_tab);
 }
 
+// ------------------------------------------------------------------------------------------
+// The one-pass E-step with a FLOAT32 TILE (hgmm_tree_set_precision(ctx, HGMM_PRECISION_F32_PDF): the type of the
+// reference's GPU file, hgmm/hgmm_gpu.py:472, 478-484 -- float32 points, float32 node and moment arrays; round 6).
+// Same three phases on a tile of 16 points, g[p][j] kept in LDS as float (52 KB at J = 800 instead of 117: TWO
+// workgroups per CU at <= 128 registers, whose phases run out of step):
+//   phase A  a lane's TWO ADJACENT components as one float2: the exponent from head + tail DIFFERENCES
+//            d = (x_head - m_head) + (x_tail - m_tail) of coordinates and means relative to the cloud's first point (the
+//            cloud is not spatially sorted: the plain float32 difference would carry 6e-8 of the cloud's extent, this
+//            carries 6e-8 of |x - mu|), z = R d with R pre-scaled by sqrt(log2 e), 2^(-|z|^2) by v_exp_f32: 21 packed
+//            instructions + 2 transcendental per point for two components (float64: 48 + two table exponentials)
+//   phase B  row sums, first arg-max, the log-likelihood's row sum: float32 reads, four values per lane and step added in
+//            float32, the steps and the lanes in float64; 1 / den and log() in float64
+//   phase C  statistics on v_mfma_f32_16x16x4_f32 about the cloud's first point o (features 1, d, d d^T of d = x - o in
+//            float32), gamma = g (1 / den) thresholded at eps as in float64.  The accumulators are float32: a workgroup
+//            hands them over every FF_SEG tiles (1024 points) as one float partial per segment, and
+//            full_reduce_f32_kernel adds the segments in float64 and moves the moments from o to the cloud's own origin.
+//            Measured on the reference's kind of data (tools/fullcov_f32_stats_error.py: uniform cube, sigma = 0.03):
+//            covariances to 3e-6 of sigma^2 -- the float32 REFERENCE accumulates all N points in float32.
+// Triangular form only (a table with a failed factorisation takes the float64 kernel), J16 <= 1024.
+// ------------------------------------------------------------------------------------------
+constexpr int FF_P = 16, FF_WAVES = 8, FF_BLOCK = FF_WAVES * 64, FF_SEG = 16;
+// The origin of the float32 statistics: the cloud's CENTROID (the float32 second moments are accumulated about it and
+// moved to the cloud's own frame in float64: their rounding is relative to |x - o|^2, and no point is closer to all
+// others).  FF_OPARTS workgroups leave partial coordinate sums; the consumers add them in one fixed order (ff_origin,
+// one wave), so the fused kernel and the reduction use the same o bit for bit.
+constexpr int FF_OPARTS = 256;
+__global__ __launch_bounds__(256) void full_origin_parts_kernel(const double* __restrict__ xs, int64_t n, int64_t n_pad,
+                                                                double* __restrict__ parts /*[FF_OPARTS][3]*/) {
+    __shared__ double sh[4][3];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)FF_OPARTS * 256) {
+        a0 += xs[i]; a1 += xs[n_pad + i]; a2 += xs[2 * n_pad + i];
+    }
+    a0 = wave_sum_f64(a0); a1 = wave_sum_f64(a1); a2 = wave_sum_f64(a2);
+    if (lane_id() == 0) { sh[wave_in_block()][0] = a0; sh[wave_in_block()][1] = a1; sh[wave_in_block()][2] = a2; }
+    __syncthreads();
+    if (threadIdx.x < 3) parts[blockIdx.x * 3 + threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+// all 64 lanes of ONE wave: the centroid's coordinate d (every lane returns it)
+__device__ __forceinline__ double ff_origin(const double* __restrict__ parts, int d, double inv_n) {
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < FF_OPARTS / 64; ++k) a += parts[(lane_id() + 64 * k) * 3 + d];
+    return wave_sum_f64(a) * inv_n;
+}
+__host__ __device__ inline int ff_ld(int J16) {            // floats per point row: == 16 or 48 (mod 64) -> the four rows of an
+    int ld = J16 + 16;                                      // A fragment fall into four different 16-bank groups
+    while ((ld & 63) != 16 && (ld & 63) != 48) ld += 16;
+    return ld;
+}
+inline size_t ff_lds_bytes(int J16) {
+    return sizeof(float) * ((size_t)FF_P * ff_ld(J16) + 16 * FF_P + FF_P + J16 + 2 * 2 * 3 * FF_P * 2) + sizeof(double) * (2 * FF_P + 2);
+}
+
+__global__ __launch_bounds__(FF_BLOCK, 4) void full_fused_f32_kernel(
+    const double* __restrict__ xs, int64_t n, int64_t n_pad, const double* __restrict__ prep, int J16,
+    int* __restrict__ label_out, double* __restrict__ block_q, float* __restrict__ partials /*[segments][J16][NMOM]*/,
+    int segs_per_wg, int want_stats, const int* __restrict__ flags, const int* __restrict__ done,
+    const double* __restrict__ origin_parts, long long* __restrict__ dbg) {
+    extern __shared__ double lds_raw[];
+    if (done && *done) return;
+    const bool use_chol = !(flags && (*flags & 1));        // kernel-uniform: some Sigma^-1 failed its factorisation -> symmetric form
+    long long tA = 0, tB = 0, tC = 0, tW = 0, tm = 0;
+#define FF_TICK(acc) do { if (dbg) { const long long now_ = clock64(); acc += now_ - tm; tm = now_; } } while (0)
+    const int LD = ff_ld(J16);
+    double* TOT = lds_raw;                                  // [2][FF_P] row sums over the components with pi >= eps (-1: dead point)
+    float* G = reinterpret_cast<float*>(TOT + 2 * FF_P + 2);      // [FF_P][LD]
+    float* F = G + (size_t)FF_P * LD;                       // [FF_P points][16 features]
+    float* INV = F + 16 * FF_P;                             // [FF_P] 1 / denominator (0: dead point)
+    float* WL = INV + FF_P;                                 // [J16] 1 where pi_j >= eps
+    f2t* XH = reinterpret_cast<f2t*>(WL + J16);             // [2][3][FF_P] {v, v}: head of x - o, double-buffered
+    f2t* XT = XH + 2 * 3 * FF_P;                            // ... and its tail
+    const int w = wave_in_block(), lane = lane_id();
+    const int tid = (int)threadIdx.x;
+    const int npair = J16 / 2;
+    const bool mine = tid < npair;
+    // the origin: wave 0 adds the partial sums up, everybody reads the three numbers from LDS (TOT's row 0 is not used
+    // before the first tile's phase B, two barriers from here)
+    if (tid < 64) {
+        const double inv_n = 1.0 / (double)n;
+        const double c0 = ff_origin(origin_parts, 0, inv_n), c1 = ff_origin(origin_parts, 1, inv_n), c2 = ff_origin(origin_parts, 2, inv_n);
+        if (tid == 0) { TOT[0] = c0; TOT[1] = c1; TOT[2] = c2; }
+    }
+    __syncthreads();
+    const double o0 = TOT[0], o1 = TOT[1], o2 = TOT[2];
+    __syncthreads();
+    // this lane's two components 2 tid, 2 tid + 1
+    f2t r00 = {0.f, 0.f}, r01 = r00, r02 = r00, r11 = r00, r12 = r00, r22 = r00, nh0 = r00, nh1 = r00, nh2 = r00, nt0 = r00,
+        nt1 = r00, nt2 = r00, we = r00;
+    if (mine) {
+        float v[2][13];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const double* pr = prep + PREP_N * (2 * tid + c);
+            // triangular form: sqrt(log2 e) R;  symmetric form: (log2 e / 2) Sigma^-1
+            const double S = use_chol ? LLF_SQRT_LOG2E : 0.5 * LLF_LOG2E;
+            const int fo = use_chol ? PREP_R : 0;
+            const double u0 = pr[6] - o0, u1 = pr[7] - o1, u2 = pr[8] - o2;
+            v[c][0] = llf_f32(S * pr[fo]); v[c][1] = llf_f32(S * pr[fo + 1]); v[c][2] = llf_f32(S * pr[fo + 2]);
+            v[c][3] = llf_f32(S * pr[fo + 3]); v[c][4] = llf_f32(S * pr[fo + 4]); v[c][5] = llf_f32(S * pr[fo + 5]);
+            const float h0 = (float)u0, h1 = (float)u1, h2 = (float)u2;
+            v[c][6] = -h0; v[c][7] = -h1; v[c][8] = -h2;
+            v[c][9] = -(float)(u0 - (double)h0); v[c][10] = -(float)(u1 - (double)h1); v[c][11] = -(float)(u2 - (double)h2);
+            v[c][12] = (float)pr[9];
+        }
+        r00 = f2t{v[0][0], v[1][0]}; r01 = f2t{v[0][1], v[1][1]}; r02 = f2t{v[0][2], v[1][2]};
+        r11 = f2t{v[0][3], v[1][3]}; r12 = f2t{v[0][4], v[1][4]}; r22 = f2t{v[0][5], v[1][5]};
+        nh0 = f2t{v[0][6], v[1][6]}; nh1 = f2t{v[0][7], v[1][7]}; nh2 = f2t{v[0][8], v[1][8]};
+        nt0 = f2t{v[0][9], v[1][9]}; nt1 = f2t{v[0][10], v[1][10]}; nt2 = f2t{v[0][11], v[1][11]};
+        we = f2t{v[0][12], v[1][12]};
+    }
+    int my_small = 0;
+    for (int j = tid; j < J16; j += FF_BLOCK) {
+        const double wl = prep[PREP_N * j + 10], wev = prep[PREP_N * j + 9];
+        WL[j] = (wl != 0.0) ? 1.f : 0.f;
+        if (wl == 0.0 && wev != 0.0) my_small = 1;
+    }
+    for (int e = tid; e < FF_P * LD; e += FF_BLOCK) G[e] = 0.f;
+    const bool any_small = __syncthreads_or(my_small) != 0;
+    const int ntiles = J16 / 16;
+    constexpr int MAXT = (FT_MAX_J16 / 16 + FF_WAVES - 1) / FF_WAVES;      // 8
+    f4t acc[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) acc[t] = f4t{0.f, 0.f, 0.f, 0.f};
+    const int a_idx = lane & 15, b_idx = lane >> 4;
+
+    const int64_t tiles = (n + FF_P - 1) / FF_P;
+    const int64_t per = (int64_t)segs_per_wg * FF_SEG;
+    const int64_t t0 = (int64_t)blockIdx.x * per;
+    const int64_t t1 = (t0 + per < tiles) ? t0 + per : tiles;
+    constexpr int LQ_WAVE = 7;                             // (the wave with the fewest components at J = 800)
+    double lq = 0.0;
+    const int st_d = tid / FF_P, st_p = tid % FF_P;
+    const double st_o = st_d == 0 ? o0 : (st_d == 1 ? o1 : o2);
+    auto stage = [&](int64_t tile, int buf) {
+        if (tid < 3 * FF_P) {
+            int64_t i = tile * FF_P + st_p;
+            i = i < n ? i : n - 1;
+            const double dv = xs[(size_t)st_d * n_pad + i] - st_o;
+            const float h = (float)dv, tl = (float)(dv - (double)h);
+            XH[(buf * 3 + st_d) * FF_P + st_p] = f2t{h, h};
+            XT[(buf * 3 + st_d) * FF_P + st_p] = f2t{tl, tl};
+        }
+    };
+    auto tile_loglik = [&](int par) {
+        const double tv = (lane < FF_P) ? TOT[par * FF_P + lane] : -1.0;
+        double term = (tv >= 0.0) ? log_pos_f64(fmax(tv, TREE_EPS)) : 0.0;
+        term = wave_sum_f64(term);
+        lq += term;
+    };
+    auto flush = [&](int64_t seg) {                        // the wave's accumulator tiles -> the segment's float partial
+        // (the segment index is made opaque: otherwise the eight tiles' addresses are formed ahead of the tile loop and kept
+        //  in registers through it -- 199 registers instead of 86)
+        int seg_lo = (int)seg;
+        asm volatile("" : "+s"(seg_lo));
+        seg = seg_lo;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            const int ct = w + t * FF_WAVES;
+            if (ct < ntiles) {
+                if (a_idx < NMOM) {
+                    // D layout (f32 16x16x4): row (component) = 4 (lane >> 4) + r, column (feature) = lane & 15
+                    float* dst = partials + ((size_t)seg * J16 + 16 * ct + 4 * b_idx) * NMOM + a_idx;
+                    dst[0] = acc[t].x; dst[NMOM] = acc[t].y; dst[2 * NMOM] = acc[t].z; dst[3 * NMOM] = acc[t].w;
+                }
+                acc[t] = f4t{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    if (t0 < t1) stage(t0, 0);
+    __syncthreads();
+    for (int64_t seg0 = t0; seg0 < t1; seg0 += FF_SEG) {
+    const int64_t seg1 = (seg0 + FF_SEG < t1) ? seg0 + FF_SEG : t1;
+    for (int64_t tile = seg0; tile < seg1; ++tile) {
+        const int64_t base = tile * FF_P;
+        const int buf = (int)((tile - t0) & 1);
+        if (dbg) tm = clock64();
+        if (w == LQ_WAVE && tile > t0) tile_loglik(buf ^ 1);
+        // ---- phase A ----------------------------------------------------------------------------------------------
+        if (mine) {
+            const f2t* xh = XH + buf * 3 * FF_P;
+            const f2t* xt = XT + buf * 3 * FF_P;
+#pragma unroll 4
+            for (int p = 0; p < FF_P; ++p) {
+                const f2t d0 = (xh[p] + nh0) + (xt[p] + nt0);
+                const f2t d1 = (xh[FF_P + p] + nh1) + (xt[FF_P + p] + nt1);
+                const f2t d2 = (xh[2 * FF_P + p] + nh2) + (xt[2 * FF_P + p] + nt2);
+                f2t q;
+                if (use_chol) {
+                    const f2t z0 = llf_fma(r02, d2, llf_fma(r01, d1, r00 * d0));
+                    const f2t z1 = llf_fma(r12, d2, r11 * d1);
+                    const f2t z2 = r22 * d2;
+                    q = llf_fma(z2, z2, llf_fma(z1, z1, z0 * z0));
+                } else {
+                    const f2t t0 = llf_fma(llf_bc(2.f), llf_fma(r02, d2, r01 * d1), r00 * d0);
+                    const f2t t1 = llf_fma(llf_bc(2.f), r12 * d2, r11 * d1);
+                    q = llf_fma(d2, r22 * d2, llf_fma(d1, t1, d0 * t0));
+                }
+                const f2t e = f2t{__builtin_amdgcn_exp2f(-q.x), __builtin_amdgcn_exp2f(-q.y)};
+                *reinterpret_cast<f2t*>(G + (size_t)p * LD + 2 * tid) = we * e;
+            }
+        }
+        if (tile + 1 < t1) stage(tile + 1, buf ^ 1);
+        FF_TICK(tA);
+        __syncthreads();
+        FF_TICK(tW);
+        // ---- phase B: wave w owns points 2 w, 2 w + 1 (one per half-wave) ---------------------------------------------
+        {
+            const int h = lane >> 5, sub = lane & 31;
+            const int p = w * 2 + h;
+            const float* Gp = G + (size_t)p * LD;
+            const int J128 = (J16 + 127) & ~127;                       // (the row is zero beyond J16: LD >= J16 + 16 ... see below)
+            double den = 0.0, tot = 0.0;
+            float best = -1.f;
+            int jbest = 0;
+            for (int jb = 0; jb < J128; jb += 128) {
+                const int j = jb + 4 * sub;
+                f4t gv = f4t{0.f, 0.f, 0.f, 0.f};
+                if (j < J16) gv = *reinterpret_cast<const f4t*>(Gp + j);
+                const float m4 = fmaxf(fmaxf(gv.x, gv.y), fmaxf(gv.z, gv.w));
+                den += (double)((gv.x + gv.y) + (gv.z + gv.w));
+                jbest = (m4 > best) ? j : jbest;
+                best = fmaxf(best, m4);
+                if (any_small && j < J16) {
+                    const f4t wl = *reinterpret_cast<const f4t*>(WL + j);
+                    tot += (double)((gv.x * wl.x + gv.y * wl.y) + (gv.z * wl.z + gv.w * wl.w));
+                }
+            }
+            int am;
+            {
+                const f4t gv = *reinterpret_cast<const f4t*>(Gp + jbest);
+                am = jbest + ((gv.x == best) ? 0 : ((gv.y == best) ? 1 : ((gv.z == best) ? 2 : 3)));
+            }
+            double den0, den1, bm0, bm1;
+            halfwave_sum_f64(den, den0, den1);
+            halfwave_max_f64((double)best, bm0, bm1);
+            const double den_h = h ? den1 : den0;
+            const float bm_h = (float)(h ? bm1 : bm0);
+            int c0, c1;
+            halfwave_min_i32((best == bm_h) ? am : 0x7fffffff, c0, c1);
+            double tot_h = den_h;
+            if (any_small) {
+                double t0s, t1s;
+                halfwave_sum_f64(tot, t0s, t1s);
+                tot_h = h ? t1s : t0s;
+            }
+            const double inv = 1.0 / den_h;
+            if (sub == 0) {
+                const bool live = base + p < n;
+                const bool good = den_h > TREE_EPS;
+                INV[p] = (live && good) ? (float)inv : 0.f;
+                TOT[buf * FF_P + p] = live ? tot_h : -1.0;
+                if (live) label_out[base + p] = good ? (h ? c1 : c0) : 0;
+            }
+            if (sub < 16) {
+                const f2t* xh = XH + buf * 3 * FF_P;
+                const float x0 = xh[p].x, x1 = xh[FF_P + p].x, x2 = xh[2 * FF_P + p].x;
+                float f = 0.f;
+                switch (sub) {
+                    case 0: f = 1.f; break;
+                    case 1: f = x0; break;
+                    case 2: f = x1; break;
+                    case 3: f = x2; break;
+                    case 4: f = x0 * x0; break;
+                    case 5: f = x0 * x1; break;
+                    case 6: f = x0 * x2; break;
+                    case 7: f = x1 * x1; break;
+                    case 8: f = x1 * x2; break;
+                    case 9: f = x2 * x2; break;
+                    default: f = 0.f;
+                }
+                F[p * 16 + sub] = f;
+            }
+        }
+        FF_TICK(tB);
+        __syncthreads();
+        FF_TICK(tW);
+        // ---- phase C: v_mfma_f32_16x16x4_f32, A[i][k] in lane i + 16 k, B[k][j] in lane j + 16 k ----------------------
+        if (want_stats) {
+            float bfrag[4], ifrag[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                ifrag[s] = INV[4 * s + b_idx];
+                bfrag[s] = F[(4 * s + b_idx) * 16 + a_idx];
+            }
+            // (the next tile's four A values are requested before the current tile's are consumed; the fences keep the
+            //  compiler from requesting ALL tiles' values at once -- 168 registers instead of 84 for the rest of the kernel)
+            float araw[2][4];
+            const int row_off = b_idx * LD + a_idx, srow = 4 * LD;
+            auto load_a = [&](int ct, float (&dst)[4]) {
+                // (the tile's offset is made opaque: left alone the compiler forms all 28 addresses ahead of the loop, spills
+                //  them and reloads four per tile from scratch)
+                int off = row_off + 16 * ct;
+                asm volatile("" : "+v"(off));
+#pragma unroll
+                for (int s = 0; s < 4; ++s) dst[s] = G[off + s * srow];
+            };
+            if (w < ntiles) load_a(w, araw[0]);
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                const int ct = w + t * FF_WAVES;                       // wave-uniform
+                if (ct < ntiles) {
+                    if (t + 1 < MAXT && ct + FF_WAVES < ntiles) load_a(ct + FF_WAVES, araw[(t + 1) & 1]);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        float a = araw[t & 1][s] * ifrag[s];
+                        if (a < 1.0e-15f) a = 0.f;                     // accumulate() drops gamma < eps (C:100)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfrag[s], acc[t], 0, 0, 0);
+                    }
+                    asm volatile("" ::: "memory");
+                }
+            }
+        }
+        FF_TICK(tC);
+        __syncthreads();                                               // G is overwritten by the next tile
+        FF_TICK(tW);
+    }
+    if (want_stats) flush((int64_t)blockIdx.x * segs_per_wg + (seg0 - t0) / FF_SEG);
+    }
+    if (w == LQ_WAVE && t0 < t1) tile_loglik((int)((t1 - 1 - t0) & 1));
+    if (dbg && lane == 0 && blockIdx.x == 7) {
+        dbg[w * 4 + 0] = tA; dbg[w * 4 + 1] = tB; dbg[w * 4 + 2] = tC; dbg[w * 4 + 3] = tW;
+    }
+    if (w == LQ_WAVE && lane == 0) block_q[blockIdx.x] = lq;
+#undef FF_TICK
+}
+
+// The segments' float partials -> float64 moments, in two fixed-order stages (one wave per component walking all ~4000
+// segments was 350 us -- strided 40-byte reads; this is ~35):
+//   stage 1  FF_RB workgroups; workgroup b adds segments b, b + FF_RB, ... element by element in float64 (coalesced reads
+//            of whole [J16][NMOM] rows) -> part64 [FF_RB][J16 NMOM]
+//   stage 2  one wave per component: lane = 16 slice + feature, slice s adds blocks s, s + 4, ...; then the moments are
+//            moved from the centroid o to the cloud's own origin: M1 = M1' + o M0, M2 = M2' + o M1'^T + M1' o^T + o o^T M0
+constexpr int FF_RB = 128;
+__global__ __launch_bounds__(256) void full_reduce_f32_stage1_kernel(const float* __restrict__ partials, int nseg,
+                                                                     int segs_per_wg, int64_t tiles, int J16,
+                                                                     double* __restrict__ part64,
+                                                                     const int* __restrict__ done = nullptr) {
+    // grid = (element chunks of 1024, FF_RB): a thread owns four consecutive elements (one 16-byte load per segment)
+    if (done && *done) return;
+    const int E = J16 * NMOM;                                          // a multiple of 4 (J16 is one of 16)
+    const int e = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 4;
+    if (e >= E) return;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int sgm = blockIdx.y; sgm < nseg; sgm += FF_RB) {
+        // (segment s = the (s mod segs_per_wg)-th of workgroup s / segs_per_wg; a workgroup's segments beyond the cloud's
+        //  last tile were never written)
+        const int64_t first_tile = ((int64_t)(sgm / segs_per_wg) * segs_per_wg + sgm % segs_per_wg) * FF_SEG;
+        if (first_tile >= tiles) continue;
+        const f4t v = *reinterpret_cast<const f4t*>(partials + (size_t)sgm * E + e);
+        a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+    }
+    double* dst = part64 + (size_t)blockIdx.y * E + e;
+    dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3;
+}
+__global__ __launch_bounds__(64) void full_reduce_f32_kernel(const double* __restrict__ part64, int J, int J16,
+                                                             const double* __restrict__ origin_parts, int64_t n,
+                                                             double* __restrict__ mom,
+                                                             const int* __restrict__ done = nullptr) {
+    const int j = blockIdx.x;
+    if (j >= J) return;
+    if (done && *done) return;
+    __shared__ double sh[4][16];
+    const double inv_n = 1.0 / (double)n;
+    const double oc0 = ff_origin(origin_parts, 0, inv_n), oc1 = ff_origin(origin_parts, 1, inv_n), oc2 = ff_origin(origin_parts, 2, inv_n);
+    const int feat = (int)threadIdx.x & 15, slice = (int)threadIdx.x >> 4;
+    double a = 0.0;
+    if (feat < NMOM)
+        for (int b = slice; b < FF_RB; b += 4) a += part64[((size_t)b * J16 + j) * NMOM + feat];
+    sh[slice][feat] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m[NMOM];
+#pragma unroll
+        for (int f = 0; f < NMOM; ++f) m[f] = (sh[0][f] + sh[1][f]) + (sh[2][f] + sh[3][f]);
+        const double o[3] = {oc0, oc1, oc2};
+        const double m0 = m[0], d[3] = {m[1], m[2], m[3]};
+        double* dst = mom + (size_t)j * NMOM;
+        dst[0] = m0;
+        for (int k = 0; k < 3; ++k) dst[1 + k] = d[k] + o[k] * m0;
+        const int ia[6] = {0, 0, 0, 1, 1, 2}, ib[6] = {0, 1, 2, 1, 2, 2};
+        for (int k = 0; k < 6; ++k) {
+            const int r = ia[k], c2 = ib[k];
+            dst[4 + k] = m[4 + k] + o[r] * d[c2] + d[r] * o[c2] + o[r] * o[c2] * m0;
+        }
+    }
+}
+
 // one wave per component: fixed-order sum over the workgroups' partials
 __global__ __launch_bounds__(64) void full_reduce_kernel(const double* __restrict__ partials, int nblocks,
                                                          int J, int J16, double* __restrict__ mom,
@@ -1919,7 +2307,50 @@ static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_hos
     const int64_t tiles = (c->n + FT_P - 1) / FT_P;
     const int grid = (int)std::min<int64_t>(tiles, c->cus);             // 100+ KB of LDS: one workgroup per CU
     double* block_q = c->t_q.as<double>();
-    double* q_dev = block_q + nblk(c->n, CH) + 2 * c->cus;
+    double* q_dev = block_q + nblk(c->n, CH) + 2 * c->cus;                // (the loop's q lives here whichever kernel runs)
+    if (c->tree.pdf_f32) {
+        // float32 tile (hgmm_tree_set_precision): two workgroups per CU, float partials per segment of FF_SEG tiles
+        const int64_t tiles16 = (c->n + FF_P - 1) / FF_P;
+        const int want_wgs = 2 * c->cus;
+        const int segs_per_wg = (int)std::max<int64_t>(1, ((tiles16 + want_wgs - 1) / want_wgs + FF_SEG - 1) / FF_SEG);
+        const int grid32 = (int)((tiles16 + (int64_t)segs_per_wg * FF_SEG - 1) / ((int64_t)segs_per_wg * FF_SEG));
+        const int nseg = grid32 * segs_per_wg;
+        // [segments][J16][NMOM] floats, then stage 1's [FF_RB][J16][NMOM] doubles (8-byte aligned: an even number of floats)
+        HGMM_TRY(ensure(c, c->t_partials, sizeof(float) * (size_t)nseg * J16 * NMOM + sizeof(double) * (size_t)FF_RB * J16 * NMOM + 8));
+        // (grid32 <= 2 CUs: the workgroups' shares of q fit in front of q_dev, where hgmm_fullcov_fit's loop expects it)
+        const size_t lds32 = ff_lds_bytes(J16);
+        HGMM_TRY(ensure(c, c->ff_origin, sizeof(double) * 3 * FF_OPARTS));
+        double* oparts = c->ff_origin.as<double>();
+        full_origin_parts_kernel<<<FF_OPARTS, 256, 0, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad, oparts);
+        {
+            ProfScope prof(c, HGMM_K_FULL_FUSED);
+            HGMM_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&full_fused_f32_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
+            full_fused_f32_kernel<<<grid32, FF_BLOCK, lds32, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
+                                                                         c->t_prep.as<double>(), J16, labels, block_q,
+                                                                         c->t_partials.as<float>(), segs_per_wg,
+                                                                         want_stats ? 1 : 0, flags_ptr(c), done, oparts,
+                                                                         c->ff_clocks_on ? c->ff_clocks.as<long long>() : nullptr);
+        }
+        HGMM_HIP(c, hipGetLastError());
+        if (want_stats) {
+            double* part64 = reinterpret_cast<double*>(c->t_partials.as<float>() + (size_t)nseg * J16 * NMOM);
+            full_reduce_f32_stage1_kernel<<<dim3(nblk((int64_t)J16 * NMOM, 1024), FF_RB), 256, 0, c->stream>>>(
+                c->t_partials.as<float>(), nseg, segs_per_wg, tiles16, J16, part64, done);
+            full_reduce_f32_kernel<<<J, 64, 0, c->stream>>>(part64, J, J16, oparts, c->n, c->t_mom.as<double>(), done);
+        }
+        tree_sum_kernel<<<1, 256, 0, c->stream>>>(block_q, grid32, q_dev, done, stop);
+        HGMM_HIP(c, hipGetLastError());
+        if (c->comm_on()) {
+            HGMM_TRY(allreduce_f64_dev(c, c->t_mom.as<double>(), (size_t)NMOM * J));
+            HGMM_TRY(allreduce_f64_dev(c, q_dev, 1));
+        }
+        if (q_host) {
+            HGMM_HIP(c, hipMemcpyAsync(q_host, q_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HGMM_HIP(c, ctx_stream_sync(c));
+        }
+        return HGMM_OK;
+    }
     const size_t lds = ft_lds_bytes(J16);
     HGMM_TRY(ensure_exp_tab2(c));
     // (a 16-wave form of this kernel -- 1024 threads, one component per lane, 128 registers -- was built and measured in
@@ -1945,7 +2376,8 @@ static int fullcov_fused(hgmm_ctx* c, int J, int J16, int* labels, double* q_hos
             full_fused_kernel<2><<<grid, FT_BLOCK, lds, c->stream>>>(c->x_soa64.as<double>(), c->n, c->n_pad,
                                                                    c->t_prep.as<double>(), J16, labels, block_q,
                                                                    c->t_partials.as<double>(), want_stats ? 1 : 0,
-                                                                   flags_ptr(c), c->exp_tab2.as<double>(), nullptr, done);
+                                                                   flags_ptr(c), c->exp_tab2.as<double>(),
+                                                                   c->ff_clocks_on ? c->ff_clocks.as<long long>() : nullptr, done);
         }
     }
     HGMM_HIP(c, hipGetLastError());
@@ -2094,6 +2526,24 @@ extern "C" int hgmm_fullcov_fit(hgmm_ctx* c, int J, double ls, double ld, const 
         HGMM_HIP(c, dl.finish());
     }
     if (q_len_out) *q_len_out = q_len < q_capacity ? q_len : q_capacity;
+    return HGMM_OK;
+}
+
+extern "C" int hgmm_fullcov_phase_clocks(hgmm_ctx* c, int enable, int64_t* clocks_out) {
+    HGMM_ENTER(c);
+    if (enable) {
+        HGMM_TRY(ensure(c, c->ff_clocks, sizeof(long long) * 32));
+        HGMM_HIP(c, hipMemsetAsync(c->ff_clocks.p, 0, sizeof(long long) * 32, c->stream));
+        c->ff_clocks_on = true;
+        return HGMM_OK;
+    }
+    c->ff_clocks_on = false;
+    if (clocks_out) {
+        if (!c->ff_clocks.p) return fail(c, HGMM_ERR_STATE, "phase clocks were never armed");
+        static_assert(sizeof(long long) == sizeof(int64_t), "clock words");
+        HGMM_HIP(c, hipMemcpyAsync(clocks_out, c->ff_clocks.p, sizeof(long long) * 32, hipMemcpyDeviceToHost, c->stream));
+        HGMM_HIP(c, ctx_stream_sync(c));
+    }
     return HGMM_OK;
 }
 

@@ -437,6 +437,12 @@ int hgmm_comm_allreduce_f64(hgmm_ctx* ctx, double* host_inout, int n, int op /*0
 int hgmm_profile_enable(hgmm_ctx* ctx, int on);
 int hgmm_profile_reset(hgmm_ctx* ctx);
 int hgmm_profile_get(hgmm_ctx* ctx, int kernel_id, double* total_ms_out, int64_t* launches_out);
+/* Phase clocks of the one-pass full-covariance kernels (a profiling aid like the event profiler above; no reference
+ * counterpart): enable = 1 arms them -- the following hgmm_fullcov_estep / hgmm_fullcov_fit launches record, per wave of
+ * workgroup 7, the clock64() cycles spent in phase A (pdfs -> tile), phase B (row sums, arg-max), phase C (statistics on
+ * the matrix cores) and waiting at the phases' barriers; enable = 0 disarms them and copies the last launch's
+ * clocks_out[8 waves][4] (A, B, C, wait).  profiles/r06/fullcov_phase_clocks.log is made with it.                      */
+int hgmm_fullcov_phase_clocks(hgmm_ctx* ctx, int enable, int64_t* clocks_out);
 /* Streams `value` into n float32 of a device buffer with 16-byte (optionally non-temporal)
  * stores: the pure-write HBM ceiling the E-step's log_resp stream is compared with. */
 int hgmm_util_fill_f32(hgmm_ctx* ctx, float* dev, int64_t n, float value, int nontemporal);

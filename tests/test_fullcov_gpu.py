@@ -156,3 +156,96 @@ def test_fullcov_1M_matches_oracle_fixture(ctx):
     assert np.array_equal(lab_s, np.argmax(gam, axis=1))
     assert np.array_equal(lab_s, lab_e[:20000])
     np.testing.assert_allclose(q_s, np.log(np.maximum(gm.sum(1), 1e-15)).sum(), rtol=1e-11)
+
+
+# ---- float32 tile (Context.tree_set_precision(np.float32): the reference GPU file's type, hgmm/hgmm_gpu.py:472-484) --------
+# full_fused_f32_kernel: pdfs, the 16-point tile, gamma and the statistics' products in float32 (matrix cores,
+# v_mfma_f32_16x16x4_f32, about the cloud's centroid); row sums, 1 / den, log(), the segments' sums and the M-step in
+# float64.  Opt-in; float64 stays the default and the parity reference.  Held to: the reference's goldens (labels and
+# iteration counts equal, parameters to 1e-5 of their scale), the 10^6-point oracle fixture, every component layout,
+# a cloud far from the origin, the symmetric-form fallback.
+
+def _f32(ctx):
+    class _Mode:
+        def __enter__(self):
+            ctx.tree_set_precision(np.float32)
+        def __exit__(self, *a):
+            ctx.tree_set_precision(np.float64)
+    return _Mode()
+
+
+def _cov_err(cov, ref):
+    """largest |d Sigma_ab| over a component's mean variance (the scale a covariance entry is meaningful on)"""
+    scale = np.abs(np.einsum("jii->j", ref)) / 3.0
+    return float(np.max(np.abs(cov - ref).reshape(len(ref), -1).max(1) / np.maximum(scale, 1e-300)))
+
+
+@pytest.mark.parametrize("J", [8, 32])
+def test_fullcov_float32_tile_matches_reference_golden(ctx, J):
+    g = load_golden("fullcov_flat.npz")
+    P = g["points"]
+    tag = "J%d_" % J
+    ctx.set_points(P)
+    with _f32(ctx):
+        pi, mu, cov, labels, q = ctx.fullcov_fit(J, 80.0, 1e-4, P[g[tag + "init_idx"]], 0.00034)
+    assert len(q) == len(g[tag + "q_trace"])                            # the same number of iterations
+    assert np.array_equal(labels, g[tag + "current_idx"])               # every label
+    # (fits run to convergence, 60-70 iterations: the per-iteration float32 differences -- ~1e-6 -- have that long to grow)
+    np.testing.assert_allclose(q, g[tag + "q_trace"], rtol=1e-6, atol=1e-2)
+    np.testing.assert_allclose(pi, g[tag + "pi"], rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(mu, g[tag + "mu"], rtol=0, atol=1e-5)
+    assert _cov_err(cov, g[tag + "cov"]) < 1e-3
+    print("J = %d: %d iterations, |dq| max %.3g, |d pi| / pi %.2g, |d mu| %.2g, |d cov| / variance %.2g"
+          % (J, len(q), np.abs(q - g[tag + "q_trace"]).max(), np.max(np.abs(pi - g[tag + "pi"]) / g[tag + "pi"]),
+             np.abs(mu - g[tag + "mu"]).max(), _cov_err(cov, g[tag + "cov"])))
+
+
+def test_fullcov_float32_tile_1M_against_oracle_fixture(ctx):
+    """The 10^6-point, J = 800, 3-iteration oracle fixture: pi and mu within 1e-5, Sigma within 3e-5 of a component's
+    variance (float32 second moments about the centroid: |x - o|^2 / sigma^2 ~ 300 here), at most 10 of 10^6 labels
+    off (top-two responsibilities within float32 rounding of each other), bitwise rerun; the statistics' sum over
+    ragged shards equals the whole cloud's to float32-accumulation accuracy."""
+    g = load_golden("fullcov_uniform1M_J800_oracle.npz")
+    N, J, iters = int(g["n_points"]), int(g["J"]), int(g["max_iters"])
+    P = np.random.RandomState(int(g["cloud_seed"])).rand(N, 3).astype(np.float32).astype(np.float64)
+    idx = np.random.RandomState(int(g["init_seed"])).choice(N, J, replace=False)
+    ctx.set_points(P)
+    with _f32(ctx):
+        pi, mu, cov, labels, q = ctx.fullcov_fit(J, float(g["ls"]), float(g["ld"]), P[idx], float(g["sig2"]), iters)
+        again = ctx.fullcov_fit(J, float(g["ls"]), float(g["ld"]), P[idx], float(g["sig2"]), iters)
+        m0, m1, m2, lab_e, q_e = ctx.fullcov_estep(pi, mu, cov)
+    assert np.array_equal(again[4], q) and np.array_equal(again[3], labels) and np.array_equal(again[2], cov)
+    assert len(q) == iters
+    assert np.abs(q - g["q_trace"]).max() < 0.5                          # (|q| ~ 1e4 here: densities near 1)
+    np.testing.assert_allclose(pi, g["pi"], rtol=1e-5)
+    np.testing.assert_allclose(mu, g["mu"], rtol=0, atol=1e-5)
+    assert _cov_err(cov, g["cov"]) < 3e-5
+    off = int((labels[g["sample"]] != g["labels_sample"]).sum())
+    assert off <= 2 and np.abs(np.bincount(labels, minlength=J) - g["population"]).sum() <= 20
+    assert abs(m0.sum() - N) <= 1e-6 * N
+    print("1M fixture, float32 tile: |dq| %.3g, |d pi| / pi %.2g, |d mu| %.2g, |d cov| / variance %.2g, sampled labels off %d / %d"
+          % (np.abs(q - g["q_trace"]).max(), np.max(np.abs(pi - g["pi"]) / g["pi"]), np.abs(mu - g["mu"]).max(),
+             _cov_err(cov, g["cov"]), off, len(g["sample"])))
+
+
+@pytest.mark.parametrize("J", [17, 100, 513, 540, 800, 1024])
+def test_fullcov_float32_tile_layouts_far_origin_and_fallback(ctx, bunny, J):
+    """Component counts that fill the lanes' pairs differently (an odd number of 16-blocks, more than 896, 1024), the cloud
+    moved 50 units from the origin (the float32 features are taken about the centroid), and the symmetric-form fallback
+    (tree_no_chol = 1): against the oracle at float32 accuracy."""
+    P0 = bunny[::30][:1300].astype(np.float64)
+    idx = np.random.RandomState(J).choice(len(P0), J, replace=False)
+    for shift, no_chol in ((0.0, 0), (50.0, 0), (0.0, 1)):
+        P = P0 + shift
+        ctx.set_points(P)
+        with _f32(ctx), ctx.config(tree_no_chol=no_chol):
+            pi, mu, cov, labels, q = ctx.fullcov_fit(J, 1e-30, 1e-4, P[idx], 0.0005, 3)
+        o_pi, o_mu, o_cov, o_q, o_cur = hgmm_tree.build_flat_fullcov(P, J, 1e-30, 1e-4, idx, 0.0005, max_iters=3)
+        assert (labels != o_cur).sum() <= 2
+        np.testing.assert_allclose(q, o_q, rtol=1e-6, atol=1e-2)
+        # (1300 points over up to 1024 components: two or three points per component -- a layout test, the accuracy tests
+        #  are the two above)
+        np.testing.assert_allclose(pi, o_pi, rtol=1e-3, atol=1e-7)
+        np.testing.assert_allclose(mu, o_mu, rtol=0, atol=1e-5)
+        live = o_pi > 1e-6
+        assert _cov_err(cov[live], o_cov[live]) < 1e-3, (shift, no_chol, _cov_err(cov[live], o_cov[live]))

@@ -17,7 +17,7 @@ HGMM_BENCH_LEGS_FILE=$O/bench_legs_n1.json timeout 900 python bench.py > $O/benc
 timeout 300 python bench.py --mode pairs > $O/bench_pairs_n1.json 2> $O/bench_pairs_n1.err; echo "pairs n1 rc $?"
 for cfg in "1 1" "4 1" "8 1" "1 32" "2 32" "4 16" "4 32" "8 16" "8 32" "12 16"; do
   set -- $cfg
-  timeout 200 python bench.py --mode pairs --contexts-per-gpu $1 --batch $2 --steps 6 --warmup 2 --min-time 1.5 --no-cpu-baseline \
+  timeout 200 python bench.py --mode pairs --contexts-per-gpu $1 --batch $2 --steps 20 --warmup 2 --min-time 3 --no-cpu-baseline \
     > $O/bench_pairs_n1_c$1_b$2.json 2> /dev/null; echo "pairs C=$1 B=$2 rc $?"
 done
 python tools/pair_batch_probe.py 1 4 16 32 64 > $O/pair_batch_probe.log 2>&1; echo "pair probe rc $?"
