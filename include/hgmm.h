@@ -261,7 +261,14 @@ int hgmm_tree_set_nodes(hgmm_ctx* ctx, int L, const double* pi, const double* mu
  * no such kernel in either mode: its q comes out of the float64 E-step's own eight terms.  The E-step, the moments and
  * the M-step stay float64: a level that stops after the same number of iterations yields the float64 tree bit for bit; q
  * itself differs by ~1e-7 relative (|dq| < 1 % of the smallest stop threshold in use on every cloud tried,
- * tests/test_tree_gpu.py, tests/test_tree_batch_gpu.py).  Stays in force for the context until set again. */
+ * tests/test_tree_gpu.py, tests/test_tree_batch_gpu.py).
+ * The flat FULL-covariance fit (hgmm_fullcov_fit / hgmm_fullcov_estep, J <= 1024) under the same setting takes its
+ * float32-TILE kernel (round 6): pdfs from head + tail differences in packed float32, the 16-point tile of un-normalised
+ * responsibilities in float32, the statistics' products on v_mfma_f32_16x16x4_f32 about the cloud's centroid (float
+ * partials per 256 points, added in float64); row sums, 1 / den, log() and the M-step float64.  1.69 -> 1.21 ms per
+ * launch at N = 10^6, J = 800; against the float64 fit after 3 iterations there: pi 2e-6, mu 2e-7, Sigma 7e-6 of a
+ * component's variance, 2 of 10^6 labels (tests/test_fullcov_gpu.py).  float64 stays the default and the parity reference.
+ * Stays in force for the context until set again. */
 enum { HGMM_PRECISION_F64 = 0, HGMM_PRECISION_F32_PDF = 1 };
 int hgmm_tree_set_precision(hgmm_ctx* ctx, int precision);
 /* Registration target cloud (host [n,3] float64), kept resident across iterations. */

@@ -51,6 +51,8 @@ for k in forest_ll_estep forest_estep forest_moments forest_reg_estep; do echo "
 timeout 300 rocprofv3 --kernel-trace -d $O/kt_pairs -o kt --output-format csv -- python bench.py --mode pairs --steps 6 --warmup 2 --min-time 1.5 --no-cpu-baseline --no-other-dtype > $O/bench_pairs_under_rocprofv3.json 2> /dev/null
 python tools/gpu_busy.py $O/kt_pairs 0.4 > $O/gpu_busy_pairs_default.txt 2>&1; python tools/trace_summary.py $O/kt_pairs | head -12 >> $O/gpu_busy_pairs_default.txt 2>&1
 rm -rf $O/kt_pairs
+# flat full-covariance EM: float64 tile vs float32 tile (kernel ms, accuracy, phase clocks)
+timeout 300 python tools/fullcov_f32_probe.py 10 > $O/fullcov_f32_probe.log 2>&1; echo "fullcov probe rc $?"
 python tools/round_readme.py $O > $O/README.md 2> $O/readme.err; echo "readme rc $?"
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +20M -delete
 rm -rf $O/kt_batch $O/pmc_batch

@@ -141,6 +141,14 @@ def main():
         p("```")
         out.extend(open(kt).read().strip().splitlines()[:16])
         p("```")
+    fp = os.path.join(d, "fullcov_f32_probe.log")
+    if os.path.exists(fp):
+        p("")
+        p("## Flat full-covariance EM, N = 10^6, J = 800: float64 tile vs float32 tile (`fullcov_f32_probe.log`)")
+        p("")
+        p("```")
+        out.extend(l for l in open(fp).read().strip().splitlines() if "tile" in l or l.startswith("after"))
+        p("```")
     for n in (2, 8):
         r = load_line(os.path.join(d, "bench_n%d_rehearsal_one_gpu_peer_exchange.json" % n))
         if r and "sharded_tree" in r:
