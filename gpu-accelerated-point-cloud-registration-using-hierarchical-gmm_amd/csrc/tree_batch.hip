@@ -583,8 +583,12 @@ extern "C" int hgmm_tree_build_batch(hgmm_ctx* c, int B, const int64_t* counts, 
                 ProfScope prof(c, HGMM_K_TREE_ESTEP);
                 forest_estep_kernel<true><<<grid_chunks, CH, 0, c->stream>>>(ea_now, fa);
             }
-            forest_moments8_kernel<<<(unsigned)(B * n_level / 8), 64, 0, c->stream>>>(partials, chunk_first, n_level, d_mom, lb, ld,
-                                                                                     d_pi, d_mu, d_cov, d_prep, d_flags, fa, block_q, e);
+            if (l > 0)
+                forest_moments8_kernel<<<(unsigned)(B * n_level / 8), 64, 0, c->stream>>>(partials, chunk_first, n_level, d_mom, lb, ld,
+                                                                                         d_pi, d_mu, d_cov, d_prep, d_flags, fa, block_q, e);
+            else                                                    // (level 0: a wave per child, tree_moments8_kernel's note)
+                forest_moments_kernel<<<(unsigned)(B * n_level), 64, 0, c->stream>>>(partials, chunk_first, n_level, d_mom, lb, ld,
+                                                                                    d_pi, d_mu, d_cov, d_prep, d_flags, fa, block_q, e);
             {
                 ProfScope prof(c, HGMM_K_TREE_LOGLIK);
                 // (level 0: behind the budget's last iteration the E-step runs for the shares of q alone)

@@ -791,14 +791,17 @@ extern "C" int hgmm_tree_build(hgmm_ctx* c, int L, double ls, double ld, const d
                 }
                 // single GPU: reduction, M-step and preparation of a node in one launch; with a
                 // communicator the all-reduce of the moments sits between reduction and M-step
-                if (overlap)                                                   // (small clouds: a wave per parent, same bits)
+                // (small clouds below level 0: a wave per parent, same bits.  Level 0 is ONE parent with all of the cloud's chunks:
+                //  eight waves gathering side by side are 3 us quicker than one wave taking the eight rows in turn)
+                if (overlap && l > 0)
                     tree_moments8_kernel<<<n_level / 8, 64, 0, c->stream>>>(partials, chunk_first, d_mom + NMOM * lb, lb, n_total,
                                                                             ld, d_pi, d_mu, d_cov, d_prep, flags_ptr(c), &ctl->done,
                                                                             e >= 1 ? follow_of(e) : no_follow);
                 else
                     tree_moments_kernel<<<n_level, 64, 0, c->stream>>>(partials, chunk_first, n_level, d_mom + NMOM * lb,
                                                                        c->comm_on() ? 0 : 1, lb, n_total, ld, d_pi, d_mu, d_cov,
-                                                                       d_prep, flags_ptr(c), &ctl->done, no_follow);
+                                                                       d_prep, flags_ptr(c), &ctl->done,
+                                                                       (overlap && e >= 1) ? follow_of(e) : no_follow);
                 if (c->comm_on()) {
                     rc = allreduce_f64_oop(c, d_mom + NMOM * lb, mom_g, (size_t)NMOM * n_level);
                     if (rc != HGMM_OK) return rc;
