@@ -58,3 +58,55 @@ def test_noisy_target_generator(bunny):
     back = tgt[:len(src)] @ Rz                      # undo the rotation: inliers sit on the source
     d = np.abs(back[:, None, :] - src[None, :500, :]).sum(2).min(0)
     assert np.median(d) < 0.01
+
+
+def test_batch_mirror_groups_pairs_by_the_sources_type_and_keeps_the_callers_order():
+    """registration_gmmtree_batch (host logic only, a recording stand-in for the context): pairs whose SOURCE is float32 run
+    as one batch with the float32-pdf stop rule, the others as another with float64; results and per-pair information
+    come back in the caller's order; the context's own precision setting is restored."""
+    from hgmm_amd.hgmm import hgmm_gpu as H
+
+    class Recorder:
+        def __init__(self):
+            self.tree_dtype = np.dtype(np.float64)
+            self.calls = []
+            self._n = 0
+
+        def tree_set_precision(self, dt):
+            self.tree_dtype = np.dtype(dt)
+            self.calls.append(("precision", str(np.dtype(dt))))
+
+        def set_points_batch(self, clouds):
+            self._n = len(clouds)
+            self.calls.append(("sources", [len(c) for c in clouds]))
+            return clouds
+
+        def tree_build_batch(self, counts, L, ls, ld, init_mu, sig2, want_tables=False):
+            self.calls.append(("build", str(self.tree_dtype), list(counts)))
+            return (None, None, None), np.tile(np.arange(1, L + 1), (len(counts), 1)), None
+
+        def tree_set_targets_batch(self, targets):
+            self.calls.append(("targets", [len(t) for t in targets]))
+
+        def tree_register_batch(self, rot, t, scale, lambda_c, maxiter, tol):
+            B = len(rot)
+            # the "registration" marks every pair with the length of ... nothing: identity, q = pair count so far
+            return rot, t, np.full(B, 3, np.int32), np.arange(B, dtype=float), np.zeros(B, np.int32), None
+
+    rs = np.random.RandomState(0)
+    sizes = [700, 710, 720, 730, 740]
+    kinds = [np.float32, np.float64, np.float32, np.float64, np.float32]
+    pairs = [(rs.rand(n, 3).astype(k), rs.rand(n + 5, 3)) for n, k in zip(sizes, kinds)]
+    ctx = Recorder()
+    res, info = H.registration_gmmtree_batch(pairs, maxiter=3, tol=1e-4, ctx=ctx, tree_level=2, return_info=True)
+    assert len(res) == 5 and all(r is not None for r in res)
+    builds = [c for c in ctx.calls if c[0] == "build"]
+    assert sorted((b[1], tuple(b[2])) for b in builds) == [("float32", (700, 720, 740)), ("float64", (710, 730))]
+    assert ctx.tree_dtype == np.dtype(np.float64)                         # restored
+    assert info["build_iters"].shape == (5, 2) and info["registration_iters"] == [3] * 5 and info["status"] == [0] * 5
+    # the q values number the pairs inside their own batch: float32 batch -> pairs 0, 2, 4 get 0, 1, 2
+    assert [float(np.ravel(r.q)[0]) for r in res] == [0.0, 0.0, 1.0, 1.0, 2.0]
+    # one kind only: one batch, no regrouping; an explicit pdf_dtype overrides the sources' types
+    ctx2 = Recorder()
+    H.registration_gmmtree_batch(pairs, maxiter=3, ctx=ctx2, tree_level=2, pdf_dtype=np.float64)
+    assert [c for c in ctx2.calls if c[0] == "build"] == [("build", "float64", sizes)]
