@@ -16,6 +16,7 @@ to the Numba file's (seed 72, sig2 = 0.004, hgmm_gpu.py:469-477) and can be over
 """
 from __future__ import annotations
 
+import contextlib
 import time
 from collections import namedtuple
 
@@ -115,20 +116,32 @@ def logLikelihoodValue(mixingCoeff, mean, covar, data, j0, j1, ctx: Context | No
 
 
 def fitFullCovGMM(points, n_components, ls=80.0, ld=1.0e-4, sig2=0.00034, init_idx=None, seed=None,
-                  max_iters=1000, ctx: Context | None = None, return_trace=False):
+                  max_iters=1000, ctx: Context | None = None, return_trace=False, dtype=None):
     """Flat full-covariance GMM = ONE tree level with branching ``n_components`` (the reference's
     CPU twin run with its module global ``n_node = J`` and ``buildGMMTree(P, 1, ls, ld)``,
     hgmm_cupy_cpu_working.py:30,122-160).  -> (mixingCoeff[J], mean[J,3], covar[J,3,3]).
 
     ``init_idx``: J indices of the initial means (default: the twin's draw
-    ``RandomState(J).randint(J, size=J)`` -- note it only ever picks among the first J points)."""
+    ``RandomState(J).randint(J, size=J)`` -- note it only ever picks among the first J points).
+
+    ``dtype=np.float32`` (explicit only; the points' own type does NOT switch it): the float32-tile kernel for this fit
+    (``Context.tree_set_precision``; J <= 1024) -- float32 pdfs, tile and matrix-core statistics about the centroid, float64
+    row sums / log / M-step; ~25 % faster per iteration at 10^6 x 800, Sigma to ~1e-5 of a variance.  The context's own
+    setting is restored afterwards."""
     ctx = ctx or default_context()
     P = np.ascontiguousarray(_points(points), dtype=np.float64)
     J = int(n_components)
     if init_idx is None:
         init_idx = np.random.RandomState(J if seed is None else seed).randint(J, size=J)
     ctx.set_points(P)
-    pi, mu, cov, labels, q = ctx.fullcov_fit(J, ls, ld, P[np.asarray(init_idx)], sig2, max_iters)
+    prev = getattr(ctx, "tree_dtype", np.dtype(np.float64))
+    if dtype is not None:
+        ctx.tree_set_precision(dtype)
+    try:
+        pi, mu, cov, labels, q = ctx.fullcov_fit(J, ls, ld, P[np.asarray(init_idx)], sig2, max_iters)
+    finally:
+        if dtype is not None:
+            ctx.tree_set_precision(prev)
     if return_trace:
         return pi, mu, cov, {"labels": labels, "q_trace": q}
     return pi, mu, cov
@@ -203,7 +216,7 @@ class GMMTree():
     hard-codes (20, 1e-4, 0.004, seed 72)."""
 
     def __init__(self, source=None, tree_level=5, lambda_c=0.01, ls=20, ld=1.0e-4, sig2=0.004,
-                 init_idx=None, ctx: Context | None = None, verbose=False):
+                 init_idx=None, ctx: Context | None = None, verbose=False, solve_on_device=False):
         self._source = None
         self._tree_level = tree_level
         self._lambda_c = lambda_c
@@ -214,6 +227,9 @@ class GMMTree():
         self._ctx_arg = ctx
         self._verbose = verbose
         self._device_mstep = True            # False: every iteration through expectation_step + maximization_step
+        # True: the library's loop also solves the 6 x 6 system, composes the twist and applies the stop rule on the device
+        # (per-context option reg_device_solve; the host solve is the default and the parity reference)
+        self._solve_on_device = bool(solve_on_device)
         self._target_id = None
         if source is not None:
             self.set_source(source)
@@ -346,7 +362,8 @@ class GMMTree():
             it, q, host_step_due = _resume
         while it < maxiter:
             if not host_step_due:
-                rot, t, done, q_new, status, _ = self._ctx.tree_register(rot, t, tf.scale, self._lambda_c, maxiter - it, tol, q)
+                with (self._ctx.config(reg_device_solve=1) if self._solve_on_device else contextlib.nullcontext()):
+                    rot, t, done, q_new, status, _ = self._ctx.tree_register(rot, t, tf.scale, self._lambda_c, maxiter - it, tol, q)
                 it += done
                 if done:
                     q = q_new
@@ -429,7 +446,8 @@ def registration_gmmtree(source, target, maxiter=20, tol=1.0e-4, callbacks=[], *
 
 
 def registration_gmmtree_batch(pairs, maxiter=20, tol=1.0e-4, ctx: Context | None = None, tree_level=5, lambda_c=0.01,
-                               ls=20, ld=1.0e-4, sig2=0.004, init_idx=None, return_info=False, pdf_dtype=None):
+                               ls=20, ld=1.0e-4, sig2=0.004, init_idx=None, return_info=False, pdf_dtype=None,
+                               solve_on_device=False):
     """``[registration_gmmtree(s, t, maxiter, tol, tree_level=..., ...) for s, t in pairs]`` (hgmm_gpu.py:802-807 per pair)
     with ALL pairs in the same launches: the B source clouds are one resident forest (``hgmm_tree_build_batch``: levels in
     lock-step, one stop rule per cloud), the B targets are registered against their trees together
@@ -456,7 +474,7 @@ def registration_gmmtree_batch(pairs, maxiter=20, tol=1.0e-4, ctx: Context | Non
             for kind in sorted(set(kinds), key=str):
                 sel = [k for k, v in enumerate(kinds) if v == kind]
                 r, inf = registration_gmmtree_batch([pairs[k] for k in sel], maxiter, tol, ctx, tree_level, lambda_c, ls, ld,
-                                                    sig2, init_idx, True, kind)
+                                                    sig2, init_idx, True, kind, solve_on_device)
                 for j, k in enumerate(sel):
                     out[k] = r[j]
                     for key in info:
@@ -484,13 +502,17 @@ def registration_gmmtree_batch(pairs, maxiter=20, tol=1.0e-4, ctx: Context | Non
     ctx.tree_set_targets_batch(tgts)
     clock.append(time.perf_counter())
     rot0 = np.tile(np.identity(3), (B, 1, 1))
-    rot, t, iters, q, status, _ = ctx.tree_register_batch(rot0, np.zeros((B, 3)), 1.0, lambda_c, maxiter, tol)
+    if solve_on_device:                                          # (per-context option reg_device_solve for this call)
+        with ctx.config(reg_device_solve=1):
+            rot, t, iters, q, status, _ = ctx.tree_register_batch(rot0, np.zeros((B, 3)), 1.0, lambda_c, maxiter, tol)
+    else:
+        rot, t, iters, q, status, _ = ctx.tree_register_batch(rot0, np.zeros((B, 3)), 1.0, lambda_c, maxiter, tol)
     clock.append(time.perf_counter())
     out = []
     reg_iters = [int(v) for v in iters]
     for b in range(B):
         if status[b] == 2:                                        # finish this pair through the serial entries
-            gt = GMMTree(tree_level=tree_level, lambda_c=lambda_c, ls=ls, ld=ld, sig2=sig2, ctx=ctx)
+            gt = GMMTree(tree_level=tree_level, lambda_c=lambda_c, ls=ls, ld=ld, sig2=sig2, ctx=ctx, solve_on_device=solve_on_device)
             gt.set_nodes(*ctx.tree_get_nodes_batch(b, tree_level))
             gt._tf_result = RigidTransformation(rot[b], t[b])
             ctx.tree_set_nodes(tree_level, gt._mixingCoeff, gt._mean, gt._covar)

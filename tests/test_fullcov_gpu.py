@@ -249,3 +249,18 @@ def test_fullcov_float32_tile_layouts_far_origin_and_fallback(ctx, bunny, J):
         np.testing.assert_allclose(mu, o_mu, rtol=0, atol=1e-5)
         live = o_pi > 1e-6
         assert _cov_err(cov[live], o_cov[live]) < 1e-3, (shift, no_chol, _cov_err(cov[live], o_cov[live]))
+
+
+def test_fitFullCovGMM_dtype_argument_selects_the_float32_tile_for_the_call(ctx, bunny):
+    from hgmm_amd.hgmm.hgmm_gpu import fitFullCovGMM
+    P = bunny[::10].astype(np.float64)
+    idx = np.random.RandomState(3).choice(len(P), 48, replace=False)
+    a = fitFullCovGMM(P, 48, ls=1e-30, init_idx=idx, max_iters=4, ctx=ctx)
+    b = fitFullCovGMM(P, 48, ls=1e-30, init_idx=idx, max_iters=4, ctx=ctx, dtype=np.float32)
+    c = fitFullCovGMM(P.astype(np.float32), 48, ls=1e-30, init_idx=idx, max_iters=4, ctx=ctx)     # float32 POINTS do not switch it
+    assert ctx.tree_dtype == np.dtype(np.float64)
+    assert not np.array_equal(a[1], b[1])                                    # another kernel ran ...
+    np.testing.assert_allclose(b[1], a[1], rtol=0, atol=1e-6)                # ... to float32 accuracy
+    np.testing.assert_allclose(b[0], a[0], rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(c[1], fitFullCovGMM(P.astype(np.float32).astype(np.float64), 48, ls=1e-30, init_idx=idx,
+                                                   max_iters=4, ctx=ctx)[1], rtol=0, atol=0)

@@ -241,3 +241,25 @@ def test_batch_rejects_what_it_cannot_reproduce(ctx, bunny):
         ctx.tree_build_batch([100, 200], 2, 20.0, 1e-4, np.zeros((2, T, 3)), 0.004)
     with pytest.raises(hgmm_amd.HgmmError):                            # no forest of that size resident
         ctx.tree_register_batch(np.tile(np.eye(3), (7, 1, 1)), np.zeros((7, 3)))
+
+
+def test_solve_on_device_through_the_mirrors(ctx, bunny):
+    """``GMMTree(..., solve_on_device=True)`` / ``registration_gmmtree_batch(..., solve_on_device=True)``: the per-context
+    option reg_device_solve for the duration of the call -- serial and batched still bit for bit each other, within 1e-9
+    of the host-solve path, the option back to what it was."""
+    from hgmm_amd.hgmm.hgmm_gpu import GMMTree, registration_gmmtree_batch
+    b = bunny.astype(np.float64)
+    srcs = [b[::5], b[::8], b[2::9]]
+    pairs = [(s, _moved(s, 4.0 + k, [0.3, 1, 0.2 * k], [0.002, -0.001 * k, 0.001])) for k, s in enumerate(srcs)]
+    kw = dict(tree_level=3, lambda_c=0.01, ls=20, sig2=0.004)
+    res, info = registration_gmmtree_batch(pairs, maxiter=20, tol=1e-4, ctx=ctx, return_info=True, solve_on_device=True, **kw)
+    assert ctx.config_get("reg_device_solve") == 0
+    for k, (s, t) in enumerate(pairs):
+        gt = GMMTree(s, ctx=ctx, solve_on_device=True, **kw)
+        dev = gt.registration(t, 20, 1e-4)
+        assert int(gt.n_iter_) == info["registration_iters"][k]
+        assert np.array_equal(dev.transformation.rot, res[k].transformation.rot) and np.array_equal(dev.transformation.t, res[k].transformation.t)
+        host = GMMTree(s, ctx=ctx, **kw).registration(t, 20, 1e-4)
+        np.testing.assert_allclose(dev.transformation.rot, host.transformation.rot, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(dev.transformation.t, host.transformation.t, rtol=0, atol=1e-9)
+    assert ctx.config_get("reg_device_solve") == 0
