@@ -427,6 +427,11 @@ int hgmm_comm_destroy(hgmm_ctx* ctx);
  * meet in the POSIX shared-memory object `name` (they may share a GPU, which RCCL does not allow), every
  * all-reduce goes device -> host -> summed in rank order -> device.  For exercising the N > 1 path on a
  * single-GPU box; not a performance path.                                                          */
+/* `name` (here and in hgmm_comm_init_ipc) must be unique to the JOB -- rank 0 creates the object, the others join the
+ * object of that name: give it a token the ranks agreed on beforehand (bench.py: a random token of rank 0, handed out
+ * over the TCP star; tests: the pid of the launching process).  Joiners refuse an object whose creator is gone (pid
+ * in the same pid namespace) or that is older than 10 minutes in a foreign one, but a crashed earlier job's object
+ * under the SAME name whose creator's pid has been recycled cannot be told apart from the live one.                  */
 int hgmm_comm_init_host(hgmm_ctx* ctx, int nranks, int rank, const char* name);
 /* One-shot exchange backend behind the same all-reduce call sites (the message is 57 KB, latency is
  * everything): the ranks are processes of ONE node, one GPU each.  Every rank owns an exchange buffer in uncached
