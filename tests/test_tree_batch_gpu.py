@@ -46,7 +46,7 @@ def ragged_clouds(bunny):
     return [b[::20], b45[::3], blobs, b[::7], b[5:205] * 1.0, b[::2], load_golden("hgmm_build_L3.npz")["points"]]
 
 
-@pytest.mark.parametrize("L,ls,sig2", [(2, 20.0, 0.004), (3, 20.0, 0.004), (3, 80.0, 0.00034)])
+@pytest.mark.parametrize("L,ls,sig2", [(1, 20.0, 0.004), (2, 20.0, 0.004), (3, 20.0, 0.004), (3, 80.0, 0.00034), (4, 20.0, 0.004)])
 def test_build_batch_is_bitwise_the_serial_build(ctx, bunny, L, ls, sig2):
     clouds = ragged_clouds(bunny)
     T = hgmm_tree.n_total(L)
@@ -62,7 +62,7 @@ def test_build_batch_is_bitwise_the_serial_build(ctx, bunny, L, ls, sig2):
     assert len({tuple(r) for r in iters.tolist()}) > 1                 # the clouds do stop at different iterations
 
 
-@pytest.mark.parametrize("L,ls,sig2", [(2, 20.0, 0.004), (3, 20.0, 0.004), (3, 80.0, 0.00034)])
+@pytest.mark.parametrize("L,ls,sig2", [(1, 20.0, 0.004), (2, 20.0, 0.004), (3, 20.0, 0.004), (3, 80.0, 0.00034), (4, 20.0, 0.004)])
 def test_build_batch_float32_pdfs_is_bitwise_the_serial_build_and_keeps_the_float64_trees(ctx, bunny, L, ls, sig2):
     """hgmm_tree_set_precision(F32_PDF) on small clouds and forests (round 6): the stop rule's log-likelihood in float32.
     (i) batch == serial bit for bit in that mode too (trees, iteration counts, q traces); (ii) against the float64 mode:
@@ -88,7 +88,8 @@ def test_build_batch_float32_pdfs_is_bitwise_the_serial_build_and_keeps_the_floa
     finally:
         ctx.tree_set_precision(np.float64)
     print("L=%d: largest |q_f32 - q_f64| over %d clouds' traces: %.3g (stop threshold %g)" % (L, len(clouds), worst, ls))
-    assert 0.0 < worst < 0.01 * ls                                     # (> 0: the float32 kernel did run)
+    assert worst < 0.01 * ls
+    assert (worst > 0.0) == (L > 1)                # (level 0 has no log-likelihood kernel in either mode; below it the float32 one ran)
 
 
 @pytest.mark.parametrize("name", ["hgmm_build_L2.npz", "hgmm_build_L3.npz"])
