@@ -142,10 +142,12 @@ def load_library(path: str = LIB_PATH):
         _sig(lib, "hgmm_config_get", [ctx, C.c_char_p, C.POINTER(C.c_int)])
         _i64p, _i32p = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
         _sig(lib, "hgmm_set_points_batch_f64", [ctx, C.c_int, C.POINTER(_vp), _i64p])
+        _sig(lib, "hgmm_set_points_batch_f32", [ctx, C.c_int, C.POINTER(_vp), _i64p])
         _sig(lib, "hgmm_tree_build_batch", [ctx, C.c_int, _i64p, C.c_int, C.c_double, C.c_double, _vp, C.c_double, C.c_int,
                                             _vp, _vp, _vp, _vp, _vp, C.c_int, _vp])
         _sig(lib, "hgmm_tree_get_nodes_batch", [ctx, C.c_int, _vp, _vp, _vp])
         _sig(lib, "hgmm_tree_set_targets_batch", [ctx, C.c_int, C.POINTER(_vp), _i64p])
+        _sig(lib, "hgmm_tree_set_targets_batch_f32", [ctx, C.c_int, C.POINTER(_vp), _i64p])
         _sig(lib, "hgmm_tree_register_batch", [ctx, C.c_int, _vp, _vp, C.c_double, C.c_double, C.c_int, C.c_double, _vp,
                                                _vp, _vp, _vp])
         _lib = lib
@@ -991,21 +993,26 @@ class Context:
     # -- batched HGMM: B independent clouds / scan pairs per launch set (hgmm_tree_*_batch) ------------------------------
     @staticmethod
     def _cloud_list(clouds, what):
-        arrs = [np.ascontiguousarray(getattr(a, "points", a), dtype=np.float64) for a in clouds]
-        if not arrs:
+        """-> (arrays kept alive, pointer table, counts, all_float32).  A list of float32 clouds stays float32 (the library
+        widens on the device: exactly the float64 values, half the bytes, no host pass); anything else becomes float64."""
+        raw = [np.asarray(getattr(a, "points", a)) for a in clouds]
+        if not raw:
             raise ValueError("%s: no clouds" % what)
+        all32 = all(a.dtype == np.float32 for a in raw)
+        arrs = [np.ascontiguousarray(a, dtype=np.float32 if all32 else np.float64) for a in raw]
         for a in arrs:
             if a.ndim != 2 or a.shape[1] != 3 or a.shape[0] < 1:
                 raise ValueError("%s: every cloud must be [N,3] with N >= 1, got %s" % (what, a.shape))
         ptrs = (_vp * len(arrs))(*[a.ctypes.data for a in arrs])
         counts = (C.c_int64 * len(arrs))(*[a.shape[0] for a in arrs])
-        return arrs, ptrs, counts
+        return arrs, ptrs, counts, all32
 
     def set_points_batch(self, clouds):
         """B clouds [N_b,3] become ONE resident cloud, cloud after cloud, each uploaded from its own array
-        (hgmm_set_points_batch_f64).  -> the float64 arrays that were uploaded (their lengths are the forest's counts)."""
-        arrs, ptrs, counts = self._cloud_list(clouds, "set_points_batch")
-        self._check(self.lib.hgmm_set_points_batch_f64(self.h, len(arrs), ptrs, counts))
+        (hgmm_set_points_batch_f64 / _f32).  -> the arrays that were uploaded (their lengths are the forest's counts)."""
+        arrs, ptrs, counts, all32 = self._cloud_list(clouds, "set_points_batch")
+        entry = self.lib.hgmm_set_points_batch_f32 if all32 else self.lib.hgmm_set_points_batch_f64
+        self._check(entry(self.h, len(arrs), ptrs, counts))
         self.n = int(sum(a.shape[0] for a in arrs))
         self._batch_counts = [a.shape[0] for a in arrs]
         return arrs
@@ -1041,8 +1048,9 @@ class Context:
         return pi, mu, cov
 
     def tree_set_targets_batch(self, targets):
-        arrs, ptrs, counts = self._cloud_list(targets, "tree_set_targets_batch")
-        self._check(self.lib.hgmm_tree_set_targets_batch(self.h, len(arrs), ptrs, counts))
+        arrs, ptrs, counts, all32 = self._cloud_list(targets, "tree_set_targets_batch")
+        entry = self.lib.hgmm_tree_set_targets_batch_f32 if all32 else self.lib.hgmm_tree_set_targets_batch
+        self._check(entry(self.h, len(arrs), ptrs, counts))
         return arrs
 
     def tree_register_batch(self, rot, t, scale=1.0, lambda_c=0.01, max_iter=20, tol=1.0e-4, q_prev=None, want_trace=False):

@@ -915,13 +915,16 @@ extern "C" int hgmm_set_points_f64(hgmm_ctx* c, const double* xyz, int64_t n) {
 // B clouds back to back as ONE resident cloud (the forest of hgmm_tree_build_batch): every cloud is uploaded from its own
 // host array -- no concatenated copy on the host -- into the context's own storage.  Only the float64 structure of arrays is
 // filled (the HGMM kernels' view); the flat EM's float32 rows are not, and the flat entry points say so.
-__global__ void aos_to_soa64_at(const double* __restrict__ in, int64_t n, int64_t first, int64_t n_pad,
+// (IN = double or float: float32 rows are widened on the device -- exact --, half the bytes over PCIe and no host pass)
+template <class IN>
+__global__ void aos_to_soa64_at(const IN* __restrict__ in, int64_t n, int64_t first, int64_t n_pad,
                                 double* __restrict__ out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    for (int d = 0; d < 3; ++d) out[d * n_pad + first + i] = in[3 * i + d];
+    for (int d = 0; d < 3; ++d) out[d * n_pad + first + i] = (double)in[3 * i + d];
 }
-extern "C" int hgmm_set_points_batch_f64(hgmm_ctx* c, int B, const double* const* xyz, const int64_t* counts) {
+template <class IN>
+static int set_points_batch(hgmm_ctx* c, int B, const IN* const* xyz, const int64_t* counts) {
     HGMM_ENTER(c);
     if (B < 1 || !xyz || !counts) return fail(c, HGMM_ERR_ARG, "set_points (batch): B = %d", B);
     int64_t total = 0;
@@ -932,17 +935,17 @@ extern "C" int hgmm_set_points_batch_f64(hgmm_ctx* c, int B, const double* const
     bind_points(c, nullptr);
     hgmm_points* p = &c->own_points;
     HGMM_TRY(points_alloc(c, p, total));
-    HGMM_TRY(ensure(c, c->scratch, sizeof(double) * 3 * (size_t)total));
-    double* stage = c->scratch.as<double>();
+    HGMM_TRY(ensure(c, c->scratch, sizeof(IN) * 3 * (size_t)total));
+    IN* stage = c->scratch.as<IN>();
     if (p->n_pad > total)                                    // the padding rows read as the origin, like hgmm_set_points_f64's
         for (int d = 0; d < 3; ++d)
             HGMM_HIP(c, hipMemsetAsync(p->x_soa64.as<double>() + (size_t)d * p->n_pad + total, 0,
                                        sizeof(double) * (size_t)(p->n_pad - total), c->stream));
     int64_t at = 0;
     for (int b = 0; b < B; ++b) {
-        HGMM_HIP(c, hipMemcpyAsync(stage + 3 * at, xyz[b], sizeof(double) * 3 * (size_t)counts[b], hipMemcpyHostToDevice, c->stream));
-        aos_to_soa64_at<<<(unsigned)((counts[b] + 255) / 256), 256, 0, c->stream>>>(stage + 3 * at, counts[b], at, p->n_pad,
-                                                                                    p->x_soa64.as<double>());
+        HGMM_HIP(c, hipMemcpyAsync(stage + 3 * at, xyz[b], sizeof(IN) * 3 * (size_t)counts[b], hipMemcpyHostToDevice, c->stream));
+        aos_to_soa64_at<IN><<<(unsigned)((counts[b] + 255) / 256), 256, 0, c->stream>>>(stage + 3 * at, counts[b], at, p->n_pad,
+                                                                                        p->x_soa64.as<double>());
         at += counts[b];
     }
     HGMM_HIP(c, hipGetLastError());
@@ -950,6 +953,12 @@ extern "C" int hgmm_set_points_batch_f64(hgmm_ctx* c, int B, const double* const
     bind_points(c, p);
     c->have_f32 = false;
     return HGMM_OK;
+}
+extern "C" int hgmm_set_points_batch_f64(hgmm_ctx* c, int B, const double* const* xyz, const int64_t* counts) {
+    return set_points_batch<double>(c, B, xyz, counts);
+}
+extern "C" int hgmm_set_points_batch_f32(hgmm_ctx* c, int B, const float* const* xyz, const int64_t* counts) {
+    return set_points_batch<float>(c, B, xyz, counts);
 }
 
 extern "C" int hgmm_points_create_f32(hgmm_ctx* c, const float* xyz, int64_t n, hgmm_points** out) {

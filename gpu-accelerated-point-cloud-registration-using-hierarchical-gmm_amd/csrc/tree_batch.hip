@@ -220,12 +220,13 @@ __global__ __launch_bounds__(CH) void forest_scatter_kernel(const double* __rest
 
 // targets: [n,3] rows -> the forest's structure of arrays at `first`, and the largest |x|^2 of the cloud (the same
 // products and sums, in the same order, as hgmm_tree_set_target's host loop: no fused operations)
-__global__ void forest_target_kernel(const double* __restrict__ aos, int64_t n, int64_t first, int64_t pad,
+template <class IN>                                        // (double, or float widened here: the same float64 values either way)
+__global__ void forest_target_kernel(const IN* __restrict__ aos, int64_t n, int64_t first, int64_t pad,
                                      double* __restrict__ soa, unsigned long long* __restrict__ r2max_bits) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double r2 = 0.0;
     if (i < n) {
-        const double x = aos[3 * i], y = aos[3 * i + 1], z = aos[3 * i + 2];
+        const double x = (double)aos[3 * i], y = (double)aos[3 * i + 1], z = (double)aos[3 * i + 2];
         soa[first + i] = x;
         soa[pad + first + i] = y;
         soa[2 * pad + first + i] = z;
@@ -729,7 +730,8 @@ extern "C" int hgmm_tree_get_nodes_batch(hgmm_ctx* c, int b, double* pi_out, dou
     return HGMM_OK;
 }
 
-extern "C" int hgmm_tree_set_targets_batch(hgmm_ctx* c, int B, const double* const* xyz, const int64_t* counts) {
+template <class IN>
+static int set_targets_batch(hgmm_ctx* c, int B, const IN* const* xyz, const int64_t* counts) {
     HGMM_ENTER(c);
     if (B < 1 || B > 4096 || !xyz || !counts) return fail(c, HGMM_ERR_ARG, "targets (batch): B = %d", B);
     ForestState& F = c->forest;
@@ -743,7 +745,7 @@ extern "C" int hgmm_tree_set_targets_batch(hgmm_ctx* c, int B, const double* con
     if (total > 0x7fffffff - 1024) return fail(c, HGMM_ERR_ARG, "too many target points for 32-bit indices");
     const int64_t pad = (total + 255) / 256 * 256;
     HGMM_TRY(ensure(c, c->fr_tg, sizeof(double) * 3 * pad));
-    HGMM_TRY(ensure(c, c->scratch, sizeof(double) * 3 * (size_t)total));
+    HGMM_TRY(ensure(c, c->scratch, sizeof(IN) * 3 * (size_t)total));
     HGMM_TRY(ensure(c, c->fr_reg, (sizeof(ForestRegPair) + 28 * sizeof(double) + sizeof(unsigned long long)) * (size_t)B + 512));
     // layout of fr_reg: [pairs table][28 B doubles][B r2max words]
     unsigned long long* r2bits = reinterpret_cast<unsigned long long*>(c->fr_reg.as<char>() +
@@ -752,12 +754,12 @@ extern "C" int hgmm_tree_set_targets_batch(hgmm_ctx* c, int B, const double* con
     F.tg_counts.assign(counts, counts + B);
     F.tg_first.assign(B, 0);
     int64_t at = 0;
-    double* stage = c->scratch.as<double>();
+    IN* stage = c->scratch.as<IN>();
     for (int b = 0; b < B; ++b) {
         F.tg_first[b] = at;
-        HGMM_HIP(c, hipMemcpyAsync(stage + 3 * at, xyz[b], sizeof(double) * 3 * (size_t)counts[b], hipMemcpyHostToDevice, c->stream));
-        forest_target_kernel<<<nblk(counts[b], 256), 256, 0, c->stream>>>(stage + 3 * at, counts[b], at, pad, c->fr_tg.as<double>(),
-                                                                         r2bits + b);
+        HGMM_HIP(c, hipMemcpyAsync(stage + 3 * at, xyz[b], sizeof(IN) * 3 * (size_t)counts[b], hipMemcpyHostToDevice, c->stream));
+        forest_target_kernel<IN><<<nblk(counts[b], 256), 256, 0, c->stream>>>(stage + 3 * at, counts[b], at, pad, c->fr_tg.as<double>(),
+                                                                             r2bits + b);
         at += counts[b];
     }
     HGMM_HIP(c, hipGetLastError());
@@ -776,6 +778,13 @@ extern "C" int hgmm_tree_set_targets_batch(hgmm_ctx* c, int B, const double* con
     F.tg_pad = pad;
     F.tg_B = B;
     return HGMM_OK;
+}
+
+extern "C" int hgmm_tree_set_targets_batch(hgmm_ctx* c, int B, const double* const* xyz, const int64_t* counts) {
+    return set_targets_batch<double>(c, B, xyz, counts);
+}
+extern "C" int hgmm_tree_set_targets_batch_f32(hgmm_ctx* c, int B, const float* const* xyz, const int64_t* counts) {
+    return set_targets_batch<float>(c, B, xyz, counts);
 }
 
 extern "C" int hgmm_tree_register_batch(hgmm_ctx* c, int B, double* rot, double* t, double scale, double lambda_c,

@@ -483,12 +483,14 @@ def registration_gmmtree_batch(pairs, maxiter=20, tol=1.0e-4, ctx: Context | Non
             return (out, info) if return_info else out
         pdf_dtype = kinds[0]
     clock = [time.perf_counter()]
-    srcs = [np.ascontiguousarray(_points(s), dtype=np.float64) for s, _ in pairs]
-    tgts = [np.ascontiguousarray(_points(t), dtype=np.float64) for _, t in pairs]
+    # (float32 clouds are handed over as they are -- the library widens them on the device, exactly -- and only the T rows of
+    #  the initial means are widened here)
+    srcs = [_points(s) for s, _ in pairs]
+    tgts = [_points(t) for _, t in pairs]
     B = len(pairs)
     T = n_total_nodes(tree_level)
     idx = np.asarray(init_idx) if init_idx is not None else np.random.RandomState(72).randint(T, size=T)
-    init_mu = np.stack([S[idx] for S in srcs])
+    init_mu = np.stack([np.asarray(S[idx], dtype=np.float64) for S in srcs])
     clock.append(time.perf_counter())
     ctx.set_points_batch(srcs)
     clock.append(time.perf_counter())

@@ -320,12 +320,17 @@ int hgmm_tree_register(hgmm_ctx* ctx, double* rot, double* t, double scale, doub
  *                             trace (optional) [B][max_iter][13].  The 6 x 6 solves stay on the host unless the context's
  *                             reg_device_solve option is set (see hgmm_tree_register): then one device thread per pair.    */
 int hgmm_set_points_batch_f64(hgmm_ctx* ctx, int B, const double* const* xyz, const int64_t* counts);
+/* ... and from float32 rows (the scans' files, `points.astype(np.float32)` of hgmm/hgmm_gpu.py:472): widened to float64 on
+ * the device -- exactly, so every result equals the float64 entry's on the widened arrays -- half the bytes per upload and
+ * no conversion pass on the host.  hgmm_tree_set_targets_batch_f32 likewise.                                           */
+int hgmm_set_points_batch_f32(hgmm_ctx* ctx, int B, const float* const* xyz, const int64_t* counts);
 int hgmm_tree_build_batch(hgmm_ctx* ctx, int B, const int64_t* counts, int L, double ls, double ld,
                           const double* init_mu, double sig2, int max_iters_per_level,
                           double* pi_out, double* mu_out, double* cov_out, int32_t* iters_out,
                           double* q_trace_out, int q_capacity, int32_t* q_len_out);
 int hgmm_tree_get_nodes_batch(hgmm_ctx* ctx, int b, double* pi_out, double* mu_out, double* cov_out);
 int hgmm_tree_set_targets_batch(hgmm_ctx* ctx, int B, const double* const* xyz, const int64_t* counts);
+int hgmm_tree_set_targets_batch_f32(hgmm_ctx* ctx, int B, const float* const* xyz, const int64_t* counts);
 int hgmm_tree_register_batch(hgmm_ctx* ctx, int B, double* rot, double* t, double scale, double lambda_c,
                              int max_iter, double tol, double* q_prev_inout, int32_t* iters_out,
                              int32_t* status_out, double* trace);

@@ -264,3 +264,34 @@ def test_solve_on_device_through_the_mirrors(ctx, bunny):
         np.testing.assert_allclose(dev.transformation.rot, host.transformation.rot, rtol=0, atol=1e-9)
         np.testing.assert_allclose(dev.transformation.t, host.transformation.t, rtol=0, atol=1e-9)
     assert ctx.config_get("reg_device_solve") == 0
+
+
+def test_float32_clouds_are_widened_on_the_device_exactly(ctx, bunny):
+    """hgmm_set_points_batch_f32 / hgmm_tree_set_targets_batch_f32: float32 rows in, widened to float64 on the device --
+    trees and transformations bit for bit those of the float64 entries on the host-widened arrays."""
+    b32 = bunny.astype(np.float32)
+    clouds32 = [b32[::6], b32[1::9], b32[::14]]
+    clouds64 = [c.astype(np.float64) for c in clouds32]
+    T = hgmm_tree.n_total(3)
+    idx = np.random.RandomState(72).randint(T, size=T)
+    idx = np.minimum(idx, min(len(c) for c in clouds32) - 1)
+    out = {}
+    for name, clouds in (("f32", clouds32), ("f64", clouds64)):
+        arrs = ctx.set_points_batch(clouds)
+        assert arrs[0].dtype == (np.float32 if name == "f32" else np.float64)
+        tabs, iters, _ = ctx.tree_build_batch([len(a) for a in arrs], 3, 20.0, 1e-4, np.stack([a[idx] for a in arrs]), 0.004)
+        tg = [_moved(c.astype(np.float64), 5.0, [0.1, 1, 0.3], [0.003, 0.0, -0.002]).astype(c.dtype) for c in clouds]
+        ctx.tree_set_targets_batch(tg)
+        reg = ctx.tree_register_batch(np.tile(np.eye(3), (3, 1, 1)), np.zeros((3, 3)), 1.0, 0.01, 12, 1e-6)
+        out[name] = (tabs, iters, reg)
+    (ta, ia, ra), (tb, ib, rb) = out["f32"], out["f64"]
+    assert np.array_equal(ia, ib)
+    for x, y in zip(ta, tb):
+        assert np.array_equal(x, y)
+    # (the float64 targets were made from the float32 ones' values: _moved(...).astype(float32) widened again)
+    tg64 = [_moved(c.astype(np.float64), 5.0, [0.1, 1, 0.3], [0.003, 0.0, -0.002]).astype(np.float32).astype(np.float64) for c in clouds32]
+    ctx.set_points_batch(clouds64)
+    ctx.tree_build_batch([len(a) for a in clouds64], 3, 20.0, 1e-4, np.stack([a[idx] for a in clouds64]), 0.004, want_tables=False)
+    ctx.tree_set_targets_batch(tg64)
+    rc = ctx.tree_register_batch(np.tile(np.eye(3), (3, 1, 1)), np.zeros((3, 3)), 1.0, 0.01, 12, 1e-6)
+    assert np.array_equal(ra[0], rc[0]) and np.array_equal(ra[1], rc[1]) and np.array_equal(ra[2], rc[2])
