@@ -1601,7 +1601,9 @@ def pairs_main(args):
             "kernels_ms_per_pair": {k: {"ms": v[0], "launches": v[1]} for k, v in prof.items()},
             "host_phases_ms_per_batch": ({k: float(np.mean([p[k] for p in PHASES if p])) for k in PHASES[-1]}
                                          if PHASES and PHASES[-1] else None),
-            "h2d_note": "each step uploads both clouds (2 x 0.97 MB) through the reference's host-array API: ~0.1 ms of the step",
+            "h2d_note": "every pair's two clouds are uploaded from host arrays through the reference's host-array API (float32 "
+                        "scans: 2 x 0.48 MB per pair, widened on the device; float64: 2 x 0.97 MB): `sources_up` + `targets_up` of "
+                        "host_phases_ms_per_batch",
             "roofline": None,
             "roofline_note": "latency-bound: ~100 level-iterations of three small kernels per pair on 40 k points "
                              "(SURVEY 8d: 'report wall-time per build, not roofline'); the HBM roofline of the path is "

@@ -43,7 +43,7 @@ def main():
     print("serial registration_gmmtree: %.3f ms per pair = %.0f pairs/s" % (serial * 1e3, 1 / serial))
     for B in sizes:
         srcs = [source] * B
-        tgts = [pairs[k % len(pairs)][0] for k in range(B)]
+        tgts = [pairs[k % len(pairs)][0].astype(np.float32) if f32 else pairs[k % len(pairs)][0] for k in range(B)]
         rows = []
         for rep in range(6):
             t = [time.perf_counter()]
