@@ -1731,9 +1731,51 @@ inline int reg_host_step(const double* o, double* rot, double* t, double* q_prev
     for (int i = 0, k = 0; i < 6; ++i)
         for (int j = i; j < 6; ++j, ++k) { A[i][j] = A[j][i] = o[k]; finite = finite && std::isfinite(o[k]); }
     for (int i = 0; i < 6; ++i) { b[i] = o[21 + i]; finite = finite && std::isfinite(b[i]); }
+    // The conditioning rule is lambda_min <= 1e-11 lambda_max.  A cheap certificate of the opposite first: with A = L L^T,
+    // lambda_min >= 1 / ||A^-1||_inf and lambda_max <= ||A||_inf, so 1 / ||A^-1||_inf > 1e-11 ||A||_inf settles it without
+    // the eigenvalues (~0.2 us instead of the Jacobi sweeps' ~2 us per pair and iteration -- the host's share of a batched
+    // registration); only a system that fails the certificate gets the exact test.  Same verdicts, same solve.
+    bool well = false;
+    if (finite) {
+        double Lm[6][6], Li[6][6];
+        bool spd = true;
+        for (int j = 0; j < 6 && spd; ++j) {
+            double sdiag = A[j][j];
+            for (int k = 0; k < j; ++k) sdiag -= Lm[j][k] * Lm[j][k];
+            if (!(sdiag > 0.0)) { spd = false; break; }
+            Lm[j][j] = std::sqrt(sdiag);
+            for (int i = j + 1; i < 6; ++i) {
+                double v = A[i][j];
+                for (int k = 0; k < j; ++k) v -= Lm[i][k] * Lm[j][k];
+                Lm[i][j] = v / Lm[j][j];
+            }
+        }
+        if (spd) {
+            for (int c2 = 0; c2 < 6; ++c2)                         // Li = L^-1 (lower triangular), column by column
+                for (int i = 0; i < 6; ++i) {
+                    if (i < c2) { Li[i][c2] = 0.0; continue; }
+                    double v = (i == c2) ? 1.0 : 0.0;
+                    for (int k = c2; k < i; ++k) v -= Lm[i][k] * Li[k][c2];
+                    Li[i][c2] = v / Lm[i][i];
+                }
+            double ninv = 0.0, na = 0.0;
+            for (int i = 0; i < 6; ++i) {
+                double ri = 0.0, ra = 0.0;
+                for (int j = 0; j < 6; ++j) {
+                    double aij = 0.0;                              // (A^-1)_ij = sum_k Li[k][i] Li[k][j]
+                    for (int k = (i > j ? i : j); k < 6; ++k) aij += Li[k][i] * Li[k][j];
+                    ri += std::fabs(aij);
+                    ra += std::fabs(A[i][j]);
+                }
+                ninv = std::max(ninv, ri);
+                na = std::max(na, ra);
+            }
+            well = std::isfinite(ninv) && ninv > 0.0 && 1.0 / ninv > 1.0e-10 * na;      // (a decade of margin for its own rounding)
+        }
+    }
     double lo = 0.0, hi = 0.0;
-    if (finite) sym6_eig_range(A, &lo, &hi);
-    if (!finite || !(hi > 0.0) || lo <= 1e-11 * hi || !solve6(A, b, x)) return 2;
+    if (finite && !well) sym6_eig_range(A, &lo, &hi);
+    if (!finite || (!well && (!(hi > 0.0) || lo <= 1e-11 * hi)) || !solve6(A, b, x)) return 2;
     double xb = 0.0;
     for (int i = 0; i < 6; ++i) xb += x[i] * b[i];
     const double q = std::max(o[27] - xb, 0.0);
