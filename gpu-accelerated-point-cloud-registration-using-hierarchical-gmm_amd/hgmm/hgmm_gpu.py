@@ -445,6 +445,9 @@ def registration_gmmtree(source, target, maxiter=20, tol=1.0e-4, callbacks=[], *
     return gt.registration(_points(target), maxiter, tol)
 
 
+BATCH_MAX_POINTS = 400000       # hgmm_tree_build_batch takes clouds below this size (csrc/tree_batch.hip)
+
+
 def registration_gmmtree_batch(pairs, maxiter=20, tol=1.0e-4, ctx: Context | None = None, tree_level=5, lambda_c=0.01,
                                ls=20, ld=1.0e-4, sig2=0.004, init_idx=None, return_info=False, pdf_dtype=None,
                                solve_on_device=False):
@@ -466,6 +469,27 @@ def registration_gmmtree_batch(pairs, maxiter=20, tol=1.0e-4, ctx: Context | Non
     pairs = list(pairs)
     if not pairs:
         return ([], {}) if return_info else []
+    big = [k for k, (s, _) in enumerate(pairs) if len(_points(s)) >= BATCH_MAX_POINTS]
+    if big:
+        # a cloud of >= 400 000 points fills the chip by itself and takes the serial build's four-points-per-thread
+        # log-likelihood, which the batched path does not reproduce: those pairs run one by one, the rest as a batch
+        out = [None] * len(pairs)
+        info = {"build_iters": np.full((len(pairs), tree_level), -1, np.int32), "registration_iters": [None] * len(pairs),
+                "status": [None] * len(pairs)}
+        for k in big:
+            gt = GMMTree(pairs[k][0], tree_level=tree_level, lambda_c=lambda_c, ls=ls, ld=ld, sig2=sig2, init_idx=init_idx, ctx=ctx,
+                         solve_on_device=solve_on_device)
+            out[k] = gt.registration(_points(pairs[k][1]), maxiter, tol)
+            info["registration_iters"][k], info["status"][k] = int(gt.n_iter_), 0
+        rest = [k for k in range(len(pairs)) if k not in set(big)]
+        if rest:
+            r, inf = registration_gmmtree_batch([pairs[k] for k in rest], maxiter, tol, ctx, tree_level, lambda_c, ls, ld, sig2,
+                                                init_idx, True, pdf_dtype, solve_on_device)
+            for j, k in enumerate(rest):
+                out[k] = r[j]
+                info["build_iters"][k] = inf["build_iters"][j]
+                info["registration_iters"][k], info["status"][k] = inf["registration_iters"][j], inf["status"][j]
+        return (out, info) if return_info else out
     if pdf_dtype is None:
         kinds = [np.dtype(np.float32) if _points(s).dtype == np.float32 else np.dtype(np.float64) for s, _ in pairs]
         if len(set(kinds)) > 1:                                   # one batch per kind, results back in the caller's order

@@ -295,3 +295,27 @@ def test_float32_clouds_are_widened_on_the_device_exactly(ctx, bunny):
     ctx.tree_set_targets_batch(tg64)
     rc = ctx.tree_register_batch(np.tile(np.eye(3), (3, 1, 1)), np.zeros((3, 3)), 1.0, 0.01, 12, 1e-6)
     assert np.array_equal(ra[0], rc[0]) and np.array_equal(ra[1], rc[1]) and np.array_equal(ra[2], rc[2])
+
+
+def test_a_pair_too_large_for_the_batch_runs_serially_inside_the_batched_call(ctx, bunny):
+    """Sources of >= 400 000 points are refused by hgmm_tree_build_batch (they fill the chip alone and take another
+    log-likelihood kernel); registration_gmmtree_batch runs those pairs through the serial call and batches the rest."""
+    import hgmm_amd
+    from hgmm_amd.hgmm.hgmm_gpu import GMMTree, registration_gmmtree_batch
+    rs = np.random.RandomState(2)
+    cen = rs.rand(40, 3) * 0.2
+    big = cen[rs.randint(40, size=410000)] + 0.004 * rs.randn(410000, 3)
+    small = bunny[::10].astype(np.float64)
+    pairs = [(small, _moved(small, 5.0, [0, 1, 0], [0.002, 0.0, 0.001])), (big, _moved(big[::50], 2.0, [1, 0, 0], [0.001, 0.001, 0.0])),
+             (small[::2], _moved(small[::2], 3.0, [0, 0, 1], [0.0, 0.001, 0.0]))]
+    kw = dict(tree_level=2, lambda_c=0.01, ls=80, sig2=0.004)
+    with pytest.raises(hgmm_amd.HgmmError):
+        ctx.set_points_batch([p[0] for p in pairs])
+        ctx.tree_build_batch([len(p[0]) for p in pairs], 2, 80.0, 1e-4, np.zeros((3, hgmm_tree.n_total(2), 3)), 0.004)
+    res, info = registration_gmmtree_batch(pairs, maxiter=10, tol=1e-4, ctx=ctx, return_info=True, **kw)
+    assert list(info["build_iters"][1]) == [-1, -1] and (info["build_iters"][[0, 2]] > 0).all()
+    for k, (s, t) in enumerate(pairs):
+        gt = GMMTree(s, ctx=ctx, **kw)
+        ref = gt.registration(t, 10, 1e-4)
+        assert np.array_equal(ref.transformation.rot, res[k].transformation.rot) and np.array_equal(ref.transformation.t, res[k].transformation.t), k
+        assert int(gt.n_iter_) == info["registration_iters"][k]
