@@ -264,3 +264,20 @@ def test_fitFullCovGMM_dtype_argument_selects_the_float32_tile_for_the_call(ctx,
     np.testing.assert_allclose(b[0], a[0], rtol=1e-4, atol=1e-9)
     np.testing.assert_allclose(c[1], fitFullCovGMM(P.astype(np.float32).astype(np.float64), 48, ls=1e-30, init_idx=idx,
                                                    max_iters=4, ctx=ctx)[1], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("N,J", [(1, 3), (15, 4), (64, 16), (777, 17), (5032, 100)])
+def test_fullcov_float32_tile_small_clouds_vs_oracle(ctx, bunny, N, J):
+    """Clouds smaller than a tile / a segment / a workgroup's share (one point, 15, 64, ...) through the float32-tile kernel."""
+    P = bunny[:: max(1, len(bunny) // N)][:N].astype(np.float64)
+    rs = np.random.RandomState(J)
+    idx = rs.choice(len(P), J, replace=len(P) < J)
+    ctx.set_points(P)
+    with _f32(ctx):
+        pi, mu, cov, labels, q = ctx.fullcov_fit(J, 1.0, 1e-4, P[idx], 0.0005, 8)
+    o_pi, o_mu, o_cov, o_q, o_cur = hgmm_tree.build_flat_fullcov(P, J, 1.0, 1e-4, idx, 0.0005, max_iters=8)
+    assert len(q) == len(o_q)
+    assert (labels != o_cur).sum() <= max(1, N // 2000)
+    np.testing.assert_allclose(q, o_q, rtol=1e-5, atol=1e-2)
+    np.testing.assert_allclose(pi, o_pi, rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(mu, o_mu, rtol=0, atol=1e-5)
