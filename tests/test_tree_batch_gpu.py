@@ -319,3 +319,32 @@ def test_a_pair_too_large_for_the_batch_runs_serially_inside_the_batched_call(ct
         ref = gt.registration(t, 10, 1e-4)
         assert np.array_equal(ref.transformation.rot, res[k].transformation.rot) and np.array_equal(ref.transformation.t, res[k].transformation.t), k
         assert int(gt.n_iter_) == info["registration_iters"][k]
+
+
+def test_the_bun_conf_scan_pair_in_a_batch_is_bitwise_the_serial_call():
+    """The pair bench.py --mode pairs times -- bun000.ply against bun045.ply placed by the reference's bun.conf and moved by
+    a known rigid motion -- as members of a batch (float32 and float64 scans): transformation, q and iteration counts bit
+    for bit the serial registration_gmmtree's, and within the bench's 6 mm of the ground truth."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import hgmm_amd
+    from hgmm_amd.hgmm.hgmm_gpu import GMMTree, registration_gmmtree_batch
+    c = hgmm_amd.Context(0)
+    try:
+        source, pairs = bench.scan_pairs(0, 3)
+        for dt in (np.float32, np.float64):
+            src = source.astype(dt)
+            batch = [(src, t.astype(dt)) for t, _ in pairs]
+            res, info = registration_gmmtree_batch(batch, maxiter=bench.PAIR_MAXITER, tol=bench.PAIR_TOL, ctx=c, return_info=True,
+                                                   **bench.PAIR_KW)
+            for k, (s, t) in enumerate(batch):
+                gt = GMMTree(s, ctx=c, **bench.PAIR_KW)
+                ref = gt.registration(t, bench.PAIR_MAXITER, bench.PAIR_TOL)
+                assert np.array_equal(ref.transformation.rot, res[k].transformation.rot), (dt, k)
+                assert np.array_equal(ref.transformation.t, res[k].transformation.t), (dt, k)
+                assert int(gt.n_iter_) == info["registration_iters"][k]
+                err = np.linalg.norm(res[k].transformation.transform(source) - pairs[k][1], axis=1).mean()
+                assert err < 0.006, (dt, k, err)
+    finally:
+        c.close()
