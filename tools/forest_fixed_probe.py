@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A forest build of B bunny scans with a FIXED number of iterations per level (ls = 0: the stop rule never fires), for
 timing experiments in which the arithmetic is deliberately altered: wall time of hgmm_tree_build_batch.
-    python tools/forest_fixed_probe.py [B] [iterations per level] [--f32]"""
+    python tools/forest_fixed_probe.py [B] [iterations per level] [levels] [--f32]"""
 import os
 import sys
 import time
@@ -21,7 +21,7 @@ ctx = hgmm_amd.Context(0)
 if "--f32" in sys.argv:
     ctx.tree_set_precision(np.float32)
 source, _ = bench.scan_pairs(0, 1)
-L = 3
+L = int(args[2]) if len(args) > 2 else 3
 T = n_total_nodes(L)
 idx = np.random.RandomState(72).randint(T, size=T)
 arrs = ctx.set_points_batch([source] * B)
